@@ -1,0 +1,193 @@
+/*
+ * flexenv.h — C ABI of the MI355X-native flexibility-provision hot path.
+ *
+ * The reference (kosmylo/Safe-MARL) is pure Python and has no FFI layer: its
+ * boundary is the duck-typed object protocol of SURVEY.md §8(b).  This header
+ * is the boundary a binding would use instead; each entry point names the
+ * reference interface it replaces (paths under /root/reference).  The Python
+ * host side (safe-marl_amd/flex_env.py) binds it with ctypes and presents the
+ * reference's FlexibilityProvisionEnv / TransReplayBuffer surface on top.
+ *
+ * Conventions
+ *  - plain C types only; `stream` is a hipStream_t passed as void*.
+ *  - every `dev` pointer is device memory owned by the caller; the library owns
+ *    only the FlexEnv handle and its internal per-env state.
+ *  - all calls are asynchronous on `stream`; one FlexEnv per device; a handle is
+ *    not thread-safe.
+ *  - return 0 on success, negative FLEX_E* for API errors (bad argument, HIP
+ *    error).  Per-env numerical failure is DATA (`failed[i]`), never an error
+ *    code — mirroring env:314-337, where a failed solve is caught, penalised
+ *    and reported in info["solver_failed"].
+ */
+#ifndef FLEXENV_H
+#define FLEXENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLEX_MAX_BUS 64      /* one lane per bus in a 64-wide wavefront */
+#define FLEX_MAX_AGENTS 8
+#define FLEX_MAX_CHILDREN 8
+#define FLEX_INFO_W 7        /* reward, revenue, der_cost, ess_cost, discomfort, voltage_penalty, cumulative_reward (env:696-704) */
+
+#define FLEX_OK 0
+#define FLEX_EINVAL (-22)
+#define FLEX_ENOMEM (-12)
+#define FLEX_EHIP (-5)
+
+/* dtype tags for action input / observation output */
+#define FLEX_F64 0
+#define FLEX_F32 1
+
+/* linear solver used for the Newton step */
+#define FLEX_SOLVER_TREE 0   /* leaf->root 2x2 block elimination on the radial Jacobian (no fill-in) */
+#define FLEX_SOLVER_DENSE 1  /* dense LU of the 2(n-1) x 2(n-1) Jacobian, kept as the reference variant */
+
+/* Scalars of madrl/args/env_args/flex_provision.yaml:3-33 plus solver controls. */
+typedef struct FlexCfg {
+    int32_t n_agents;          /* len(buildings), env:66 */
+    int32_t history;           /* env:65 */
+    int32_t episode_limit;     /* env:61 */
+    int32_t per_hour;          /* 60 // time_delta, env:416,477 */
+    int32_t n_start_days;      /* pv_days - episode_days, env:421-424 */
+    int32_t raw_actions;       /* 1 = the safemaddpg branch env:268-274 (no scaling) */
+    int32_t pf_max_iter;       /* Newton cap; beyond it the env reports solver_failed */
+    int32_t solver;            /* FLEX_SOLVER_* */
+    int32_t warm_start;        /* 1 = start Newton from the previous solution instead of 1∠0 */
+    int32_t reserved0;
+    double v_min, v_max;       /* env:685 */
+    double e_min, e_max;       /* env:637,647 */
+    double p_ch_max, p_dis_max;/* env:630-631 */
+    double eta_ch, eta_dis;    /* env:634; pf.py:37-38 */
+    double tan_phi;            /* tan(acos(cos_phi_max)), env:623 */
+    double max_power_reduction;/* env:278,677 */
+    double pv_cost, ess_cost, discomfort_coeff, voltage_coeff; /* env:682-685 */
+    double dt;                 /* 24 / episode_limit, pf.py:23-24 */
+    double fail_penalty;       /* 200, env:336 */
+    double pf_tol;             /* inf-norm power mismatch, pu */
+    double action_low, action_high; /* env:716-719 */
+    uint64_t seed;             /* key of the Philox reset stream */
+} FlexCfg;
+
+/* Rooted radial feeder, HOST arrays in bus-index order (utils/create_net.py:8-39 flattened). */
+typedef struct NetFix {
+    int32_t n_bus;
+    int32_t slack;               /* bus index with bus_types == 1 (pf.py:51-53) */
+    int32_t n_levels;            /* 1 + max distance from the slack */
+    int32_t max_children;
+    const int32_t* parent;       /* [n_bus], -1 at the slack */
+    const int32_t* level;        /* [n_bus] */
+    const int32_t* child;        /* [n_bus * max_children], -1 padded */
+    const double* r;             /* [n_bus] pu resistance of the line to parent (0 at slack) */
+    const double* x;             /* [n_bus] */
+    const int32_t* agent_bus;    /* [n_agents] bus index of each building */
+} NetFix;
+
+/* Device-resident series table: rows x cols fp64 row-major,
+ * cols = [Pd(n_bus) | Qd(n_bus) | Ppv(n_agents) | price]  (env:473-547 slices of it). */
+typedef struct SeriesTab {
+    const double* table;         /* dev */
+    int64_t rows;
+    int32_t cols;
+} SeriesTab;
+
+/* Injected episode draws (parity mode).  All device arrays; any may be NULL to fall back to the
+ * Philox stream for that item. */
+typedef struct ResetSpec {
+    const int32_t* day;          /* dev [N]  env:86  */
+    const int32_t* hour;         /* dev [N]  env:85  */
+    const int32_t* interval;     /* dev [N]  env:87  */
+    const double* e0;            /* dev [N, n_agents]    env:100 */
+    const double* a0;            /* dev [N, 4*n_agents]  env:103 */
+} ResetSpec;
+
+typedef struct FlexEnv FlexEnv;
+
+/* fields of flexenv_peek — the reference's _get_* accessors (env:740-778) and attributes */
+enum FlexField {
+    FLEX_PEEK_V = 0,            /* f64 [N, n_bus]   current_voltage           env:740 */
+    FLEX_PEEK_E = 1,            /* f64 [N, n_agents] current_ess_energy       env:760 */
+    FLEX_PEEK_E_INIT = 2,       /* f64 [N, n_agents] initial_ess_energy       env:100,354 */
+    FLEX_PEEK_PRED = 3,         /* f64 [N, n_agents] power_reduction          env:764 */
+    FLEX_PEEK_CH = 4,           /* f64 [N, n_agents] ess_charging             env:768 */
+    FLEX_PEEK_DIS = 5,          /* f64 [N, n_agents] ess_discharging          env:772 */
+    FLEX_PEEK_QPV = 6,          /* f64 [N, n_agents] q_pv                     env:756 */
+    FLEX_PEEK_PCT = 7,          /* f64 [N, n_agents] percentage_reduction     env:284 */
+    FLEX_PEEK_CUMREW = 8,       /* f64 [N]          cumulative_reward         env:343 */
+    FLEX_PEEK_STEPS = 9,        /* i32 [N]          steps                     env:342 */
+    FLEX_PEEK_ROW = 10,         /* i32 [N]          absolute series row of the current data, env:609-619 */
+    FLEX_PEEK_START = 11,       /* i32 [N]          episode start row         env:477 */
+    FLEX_PEEK_PF_ITERS = 12,    /* i32 [N]          Newton iterations of the last solve */
+    FLEX_PEEK_EPISODE = 13      /* i32 [N]          reset-attempt counter of the Philox stream */
+};
+
+/* Replaces FlexibilityProvisionEnv.__init__ (env:34-72) minus its reset; `series.table` must stay
+ * valid for the life of the handle. */
+int flexenv_create(const FlexCfg* cfg, const NetFix* net, const SeriesTab* series,
+                   int32_t n_envs, int32_t device, FlexEnv** out);
+void flexenv_destroy(FlexEnv* env);
+
+/* Replaces reset()/manual_reset() (env:74-155, 157-239) for every env whose mask byte is non-zero
+ * (mask == NULL: all).  Draws come from `inj` where given, else from the Philox reset stream; a
+ * failed initial solve re-draws (env:83,150-153) up to 8 times, then sets failed[i].  If `obs` is
+ * non-NULL the first observation of each reset env is pushed and written (rows of other envs are
+ * left untouched) — the get_obs() of env:155. */
+int flexenv_reset(FlexEnv* env, const uint8_t* mask /*dev [N] or NULL*/, const ResetSpec* inj /*or NULL*/,
+                  void* obs /*dev [N, n_agents, 6*history] or NULL*/, int32_t obs_dtype,
+                  uint8_t* failed /*dev [N] or NULL*/, void* stream);
+
+/* Replaces step() (env:241-356).  `actions` is [N, n_agents, 4] in the dtype given (the reference
+ * hands float32 values that NumPy 1.26 promotes to float64 before any arithmetic, util.py:184 +
+ * env:278).  If `obs` is non-NULL the get_obs() that model.py:223 issues right after step() is fused
+ * into the same launch. */
+int flexenv_step(FlexEnv* env, const void* actions, int32_t act_dtype,
+                 double* reward /*dev [N]*/, uint8_t* done /*dev [N]*/,
+                 double* info /*dev [N, FLEX_INFO_W] or NULL*/, uint8_t* failed /*dev [N] or NULL*/,
+                 void* obs /*dev [N, n_agents, 6*history] or NULL*/, int32_t obs_dtype, void* stream);
+
+/* Replaces get_obs() (env:370-403): stateful, appends to the history on every call. */
+int flexenv_obs(FlexEnv* env, void* obs /*dev [N, n_agents, 6*history]*/, int32_t obs_dtype, void* stream);
+
+/* Replaces get_state() (env:358-368): [Pd | Qd | Ppv | V | price | E]. */
+int flexenv_state(FlexEnv* env, double* state /*dev [N, 3*n_bus + 2*n_agents + 1]*/, void* stream);
+
+/* The reference's attribute reads and _get_* accessors (env:740-778). */
+int flexenv_peek(FlexEnv* env, int32_t field, void* dev_out, void* stream);
+
+/* Overwrite a peekable f64 field (tests and checkpoint restore): same shapes as flexenv_peek. */
+int flexenv_poke(FlexEnv* env, int32_t field, const void* dev_in, void* stream);
+
+int32_t flexenv_num_envs(const FlexEnv* env);
+int32_t flexenv_obs_size(const FlexEnv* env);    /* 6*history, env:71 */
+int32_t flexenv_state_size(const FlexEnv* env);  /* env:72 */
+
+/* Replaces power_flow_solver_simplified (utils/pf.py:115-192) on a batch: net loads per bus in,
+ * |V| per bus out.  Optional outputs (NULL to skip) are indexed by the bus at the far end of each
+ * line from the slack: isqr = |I|^2, pl/ql = power received at that bus (pf.py:85-88 convention). */
+int pf_solve_batch(const NetFix* net, int32_t n, const double* pnet /*dev [n, n_bus]*/,
+                   const double* qnet /*dev [n, n_bus]*/, double* v /*dev [n, n_bus]*/,
+                   double* isqr, double* pl, double* ql /*dev [n, n_bus] or NULL*/,
+                   int32_t* iters /*dev [n] or NULL*/, uint8_t* failed /*dev [n] or NULL*/,
+                   double tol, int32_t max_iter, int32_t solver, void* stream);
+
+/* Safety layer of SAFEMADDPG.safety_layer_optimization (madrl/models/safemaddpg.py:176-299) as the
+ * separable closed-form projection of SURVEY.md App. D, one lane per (env, building).
+ * proposed: policy output [N, n_agents, 4] (f32/f64) -> parse_actions (safemaddpg.py:142-174) against
+ * the env's current data -> per-building QP -> `adjusted` [N, 4*n_agents] f64 in the reference's
+ * type-major order [pr x n | ch x n | dis x n | q x n] (safemaddpg.py:297). */
+int flexenv_safety_project(FlexEnv* env, const void* proposed, int32_t dtype,
+                           const double* s_p /*dev [n_agents] row sums of W_P*/,
+                           const double* s_q /*dev [n_agents]*/, const double* beta /*dev [n_agents]*/,
+                           double v_min, double v_max, double penalty,
+                           double* adjusted /*dev [N, 4*n_agents]*/,
+                           uint8_t* intervened /*dev [N] or NULL*/, void* stream);
+
+const char* flexenv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLEXENV_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of include/flexenv.h.  The HIP library is the product path: if it is
+missing or fails to load this module raises — there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libflexenv_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+FLEX_MAX_BUS = 64
+FLEX_MAX_AGENTS = 8
+FLEX_MAX_CHILDREN = 8
+FLEX_INFO_W = 7
+FLEX_F64, FLEX_F32 = 0, 1
+FLEX_SOLVER_TREE, FLEX_SOLVER_DENSE = 0, 1
+
+PEEK = dict(V=0, E=1, E_INIT=2, PRED=3, CH=4, DIS=5, QPV=6, PCT=7, CUMREW=8, STEPS=9, ROW=10, START=11,
+            PF_ITERS=12, EPISODE=13)
+INFO_KEYS = ("reward", "revenue", "der_cost", "ess_cost", "discomfort_penalty", "voltage_penalty",
+             "cumulative_reward")  # env:696-704
+
+
+class FlexCfg(C.Structure):
+    _fields_ = [
+        ("n_agents", C.c_int32), ("history", C.c_int32), ("episode_limit", C.c_int32), ("per_hour", C.c_int32),
+        ("n_start_days", C.c_int32), ("raw_actions", C.c_int32), ("pf_max_iter", C.c_int32), ("solver", C.c_int32),
+        ("warm_start", C.c_int32), ("reserved0", C.c_int32),
+        ("v_min", C.c_double), ("v_max", C.c_double), ("e_min", C.c_double), ("e_max", C.c_double),
+        ("p_ch_max", C.c_double), ("p_dis_max", C.c_double), ("eta_ch", C.c_double), ("eta_dis", C.c_double),
+        ("tan_phi", C.c_double), ("max_power_reduction", C.c_double), ("pv_cost", C.c_double),
+        ("ess_cost", C.c_double), ("discomfort_coeff", C.c_double), ("voltage_coeff", C.c_double),
+        ("dt", C.c_double), ("fail_penalty", C.c_double), ("pf_tol", C.c_double), ("action_low", C.c_double),
+        ("action_high", C.c_double), ("seed", C.c_uint64),
+    ]
+
+
+class NetFix(C.Structure):
+    _fields_ = [
+        ("n_bus", C.c_int32), ("slack", C.c_int32), ("n_levels", C.c_int32), ("max_children", C.c_int32),
+        ("parent", C.POINTER(C.c_int32)), ("level", C.POINTER(C.c_int32)), ("child", C.POINTER(C.c_int32)),
+        ("r", C.POINTER(C.c_double)), ("x", C.POINTER(C.c_double)), ("agent_bus", C.POINTER(C.c_int32)),
+    ]
+
+
+class SeriesTab(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int32)]
+
+
+class ResetSpec(C.Structure):
+    _fields_ = [("day", C.c_void_p), ("hour", C.c_void_p), ("interval", C.c_void_p), ("e0", C.c_void_p),
+                ("a0", C.c_void_p)]
+
+
+# every symbol include/flexenv.h declares
+SYMBOLS = (
+    "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
+    "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_obs_size", "flexenv_state_size",
+    "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
+)
+
+_lib = None
+
+
+class FlexLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libflexenv_hip.so (built in-tree by safe_marl_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FlexLibraryError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the box
+        raise FlexLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise FlexLibraryError(f"{LIB_PATH} lacks symbols {missing}")
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.flexenv_create.argtypes = [C.POINTER(FlexCfg), C.POINTER(NetFix), C.POINTER(SeriesTab), i32, i32,
+                                   C.POINTER(vp)]
+    lib.flexenv_create.restype = C.c_int
+    lib.flexenv_destroy.argtypes = [vp]
+    lib.flexenv_destroy.restype = None
+    lib.flexenv_reset.argtypes = [vp, vp, C.POINTER(ResetSpec), vp, i32, vp, vp]
+    lib.flexenv_reset.restype = C.c_int
+    lib.flexenv_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp]
+    lib.flexenv_step.restype = C.c_int
+    lib.flexenv_obs.argtypes = [vp, vp, i32, vp]
+    lib.flexenv_obs.restype = C.c_int
+    lib.flexenv_state.argtypes = [vp, vp, vp]
+    lib.flexenv_state.restype = C.c_int
+    lib.flexenv_peek.argtypes = [vp, i32, vp, vp]
+    lib.flexenv_peek.restype = C.c_int
+    lib.flexenv_poke.argtypes = [vp, i32, vp, vp]
+    lib.flexenv_poke.restype = C.c_int
+    for name in ("flexenv_num_envs", "flexenv_obs_size", "flexenv_state_size"):
+        getattr(lib, name).argtypes = [vp]
+        getattr(lib, name).restype = i32
+    lib.pf_solve_batch.argtypes = [C.POINTER(NetFix), i32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, i32, i32, vp]
+    lib.pf_solve_batch.restype = C.c_int
+    lib.flexenv_safety_project.argtypes = [vp, vp, i32, vp, vp, vp, C.c_double, C.c_double, C.c_double, vp, vp, vp]
+    lib.flexenv_safety_project.restype = C.c_int
+    lib.flexenv_version.argtypes = []
+    lib.flexenv_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise FlexLibraryError(f"{what} failed with code {rc}")

@@ -1,0 +1,243 @@
+// Device-side building blocks of the flexibility-provision hot path (gfx950 only).
+//
+// Execution model: ONE 64-lane wavefront per environment, ONE lane per bus.  Lanes are numbered
+// in a depth-first preorder of the radial feeder rooted at the slack bus (host: build_devnet),
+// so for the common "chain" bus its only child sits in lane+1.  Everything an environment needs
+// per step — its series row, its 20 actions, its voltage vector — is read with coalesced
+// one-double-per-lane loads straight into registers; there is no cross-environment reuse, so
+// nothing is staged through LDS (the network tables are 64-entry arrays shared by every wave and
+// live in L2/L1).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "flexenv.h"
+
+#define FLEX_WAVE 64
+#define FLEX_WAVES_PER_BLOCK 4
+
+// Network tables in LANE order (device memory, one copy per handle).
+struct DevNet {
+    int32_t n_bus, slack_lane, n_levels, max_children, n_agents, pad0, pad1, pad2;
+    int32_t bus_of_lane[FLEX_MAX_BUS];      // -1 for lanes >= n_bus
+    int32_t lane_of_bus[FLEX_MAX_BUS];
+    int32_t par_lane[FLEX_MAX_BUS];         // own lane for the slack and for idle lanes
+    int32_t level[FLEX_MAX_BUS];            // -1 for idle lanes
+    int32_t agent_of_lane[FLEX_MAX_BUS];    // -1 if the bus has no building
+    int32_t lane_of_agent[FLEX_MAX_AGENTS];
+    int32_t slots_at_level[FLEX_MAX_BUS];   // child slots in use by receivers at level L-1
+    int32_t child_lane[FLEX_MAX_CHILDREN][FLEX_MAX_BUS];  // -1 padded
+    double g[FLEX_MAX_BUS], b[FLEX_MAX_BUS];   // series admittance of the line to the parent: 1/(r+jx)
+    double gd[FLEX_MAX_BUS], bd[FLEX_MAX_BUS]; // Ybus diagonal: own line + children's lines
+    double r[FLEX_MAX_BUS], x[FLEX_MAX_BUS];
+};
+
+// Per-lane registers holding this bus's row of the Ybus and its place in the tree.
+struct LaneNet {
+    int lane, bus, par, lev, agent;
+    bool pq;                 // a PQ bus (not slack, not idle)
+    double g, b, gd, bd;
+    int ch[FLEX_MAX_CHILDREN];
+};
+
+__device__ __forceinline__ void load_lane_net(const DevNet* __restrict__ net, int lane, LaneNet& ln) {
+    ln.lane = lane;
+    ln.bus = net->bus_of_lane[lane];
+    ln.par = net->par_lane[lane];
+    ln.lev = net->level[lane];
+    ln.agent = net->agent_of_lane[lane];
+    ln.pq = (ln.bus >= 0) && (lane != net->slack_lane);
+    ln.g = net->g[lane];
+    ln.b = net->b[lane];
+    ln.gd = net->gd[lane];
+    ln.bd = net->bd[lane];
+#pragma unroll
+    for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) ln.ch[k] = net->child_lane[k][lane];
+}
+
+// ---- wavefront reductions (shuffle butterflies; every lane ends with the result) -------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, FLEX_WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, FLEX_WAVE));
+    return v;
+}
+
+__device__ __forceinline__ double clipd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+// ---- Newton-Raphson on the Ybus, current-mismatch form, rectangular coordinates ---------------
+// Unknowns per PQ bus: V = e + jf.  Residual per bus (utils/pf.py:65-94 restated on the Ybus,
+// SURVEY.md App. B):   R_i = sum_k Y_ik V_k - conj(S_i / V_i),   S_i = -(Pnet_i + j Qnet_i).
+// On a radial feeder row i of the Ybus couples bus i to its parent and its children only, so the
+// injected current is formed from branch currents J_i = y_i (V_parent - V_i): one pull from the
+// parent lane, one per child slot.  The Jacobian's off-diagonal 2x2 blocks are the constant
+// [[g,-b],[b,g]] of each line; only the diagonal block depends on V.  The Newton step solves
+// J dV = -R exactly by leaf->root block elimination (no fill-in on a tree) and root->leaf
+// back-substitution.  Convergence is tested on the POWER mismatch inf-norm (wavefront max).
+//
+// Returns true when converged; `iters` = Newton steps taken.
+__device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, const LaneNet& ln,
+                                               double pnet, double qnet, double& e, double& f,
+                                               double tol, int max_iter, int& iters) {
+    const int n_levels = net->n_levels, maxc = net->max_children;
+    const double ps = -pnet, qs = -qnet;
+    const int lane = ln.lane;
+    bool ok = false;
+    int it = 0;
+    for (;; ++it) {
+        // branch current from the parent into this bus (zero for slack/idle: g = b = 0)
+        const double ep = __shfl(e, ln.par, FLEX_WAVE), fp = __shfl(f, ln.par, FLEX_WAVE);
+        const double de = ep - e, df = fp - f;
+        const double jr = ln.g * de - ln.b * df, ji = ln.b * de + ln.g * df;
+        double ir = -jr, ii = -ji;   // current injected at this bus = children's inflow - own inflow
+#pragma unroll
+        for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) {
+            if (k < maxc) {
+                const bool has = ln.ch[k] >= 0;
+                const int src = has ? ln.ch[k] : lane;
+                const double tr = __shfl(jr, src, FLEX_WAVE), ti = __shfl(ji, src, FLEX_WAVE);
+                ir += has ? tr : 0.0;
+                ii += has ? ti : 0.0;
+            }
+        }
+        // power mismatch  S_calc - S_spec,  S_calc = V conj(I)
+        const double dP = e * ir + f * ii - ps;
+        const double dQ = f * ir - e * ii - qs;
+        double err = fmax(fabs(dP), fabs(dQ));
+        if (!(err == err)) err = __builtin_inf();   // NaN must not hide behind fmax
+        err = wave_max(ln.pq ? err : 0.0);
+        if (err < tol) { ok = true; break; }
+        if (it >= max_iter) break;
+
+        // specified current conj(S/V) and its derivative wrt (e, f)
+        const double inv_d = 1.0 / (e * e + f * f);
+        const double isr = (ps * e + qs * f) * inv_d, isi = (ps * f - qs * e) * inv_d;
+        double rhs0 = isr - ir, rhs1 = isi - ii;
+        double d11 = ln.gd - (ps - 2.0 * e * isr) * inv_d;
+        double d12 = -ln.bd - (qs - 2.0 * f * isr) * inv_d;
+        double d21 = ln.bd - (-qs - 2.0 * e * isi) * inv_d;
+        double d22 = ln.gd - (ps - 2.0 * f * isi) * inv_d;
+
+        // leaf -> root: D_p -= Yb D_c^-1 Yb ; rhs_p += Yb D_c^-1 rhs_c   (Yb = [[g,-b],[b,g]])
+        for (int L = n_levels - 1; L >= 1; --L) {
+            const double idet = 1.0 / (d11 * d22 - d12 * d21);
+            const double i11 = d22 * idet, i12 = -d12 * idet, i21 = -d21 * idet, i22 = d11 * idet;
+            const double t11 = ln.g * i11 - ln.b * i21, t12 = ln.g * i12 - ln.b * i22;
+            const double t21 = ln.b * i11 + ln.g * i21, t22 = ln.b * i12 + ln.g * i22;
+            const double s11 = t11 * ln.g + t12 * ln.b, s12 = t12 * ln.g - t11 * ln.b;
+            const double s21 = t21 * ln.g + t22 * ln.b, s22 = t22 * ln.g - t21 * ln.b;
+            const double u0 = t11 * rhs0 + t12 * rhs1, u1 = t21 * rhs0 + t22 * rhs1;
+            const int nslots = net->slots_at_level[L];
+#pragma unroll
+            for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) {
+                if (k < nslots) {
+                    const bool has = (ln.ch[k] >= 0) && (ln.lev == L - 1) && ln.pq;
+                    const int src = (ln.ch[k] >= 0) ? ln.ch[k] : lane;
+                    const double a11 = __shfl(s11, src, FLEX_WAVE), a12 = __shfl(s12, src, FLEX_WAVE);
+                    const double a21 = __shfl(s21, src, FLEX_WAVE), a22 = __shfl(s22, src, FLEX_WAVE);
+                    const double b0 = __shfl(u0, src, FLEX_WAVE), b1 = __shfl(u1, src, FLEX_WAVE);
+                    if (has) {
+                        d11 -= a11; d12 -= a12; d21 -= a21; d22 -= a22;
+                        rhs0 += b0; rhs1 += b1;
+                    }
+                }
+            }
+        }
+        // root -> leaf: dV_i = D_i^-1 (rhs_i + Yb dV_parent), dV_slack = 0
+        const double idet = 1.0 / (d11 * d22 - d12 * d21);
+        const double i11 = d22 * idet, i12 = -d12 * idet, i21 = -d21 * idet, i22 = d11 * idet;
+        double dx0 = 0.0, dx1 = 0.0;
+        for (int L = 1; L < n_levels; ++L) {
+            const double p0 = __shfl(dx0, ln.par, FLEX_WAVE), p1 = __shfl(dx1, ln.par, FLEX_WAVE);
+            const double w0 = rhs0 + ln.g * p0 - ln.b * p1, w1 = rhs1 + ln.b * p0 + ln.g * p1;
+            if (ln.lev == L && ln.pq) {
+                dx0 = i11 * w0 + i12 * w1;
+                dx1 = i21 * w0 + i22 * w1;
+            }
+        }
+        e += dx0;
+        f += dx1;
+    }
+    iters = it;
+    return ok;
+}
+
+// ---- per-building action handling (env:262-293, 621-677) -----------------------------------------
+struct FlexAct { double pct, pred, ch, dis, q; };
+
+// _clip_power_charging_discharging, env:628-661 (note env:634 has no dt: SURVEY A4)
+__device__ __forceinline__ void clip_charge(const FlexCfg& c, double& ch, double& dis, double e_now) {
+    ch = clipd(ch, 0.0, c.p_ch_max);
+    dis = clipd(dis, 0.0, c.p_dis_max);
+    const double e_next = e_now + c.eta_ch * ch - (1.0 / c.eta_dis) * dis;
+    if (e_next > c.e_max) {
+        const double excess = e_next - c.e_max;
+        if (ch > excess / c.eta_ch) {
+            ch -= excess / c.eta_ch;
+        } else {
+            dis += (excess - ch * c.eta_ch) * c.eta_dis;
+            ch = 0.0;
+        }
+    } else if (e_next < c.e_min) {
+        const double lack = c.e_min - e_next;
+        if (dis > lack * c.eta_dis) {
+            dis -= lack * c.eta_dis;
+        } else {
+            ch += (lack - dis / c.eta_dis) / c.eta_ch;
+            dis = 0.0;
+        }
+    }
+    ch = clipd(ch, 0.0, c.p_ch_max);
+    dis = clipd(dis, 0.0, c.p_dis_max);
+}
+
+__device__ __forceinline__ FlexAct parse_actions(const FlexCfg& c, bool raw, double a0, double a1, double a2,
+                                                 double a3, double pd, double ppv, double e_clip) {
+    FlexAct o;
+    double pr, ch, dis, q;
+    if (raw) {                                   // env:268-274
+        pr = a0; ch = a1; dis = a2; q = a3;
+    } else {                                     // env:276-281
+        pr = c.max_power_reduction * a0;
+        ch = c.p_ch_max * a1;
+        dis = c.p_dis_max * a2;
+        const double lim = c.tan_phi * ppv;      // env:621-626
+        q = clipd(-lim + a3 * (lim - (-lim)), -lim, lim);
+    }
+    pr = clipd(pr, 0.0, c.max_power_reduction);  // env:284, 677
+    if (ch > 0.0 && dis > 0.0) {                 // env:663-674
+        if (ch > dis) { ch -= dis; dis = 0.0; }
+        else { dis -= ch; ch = 0.0; }
+    }
+    clip_charge(c, ch, dis, e_clip);             // env:289-290
+    o.pct = pr; o.ch = ch; o.dis = dis; o.q = q;
+    o.pred = pd * pr;                            // env:293
+    return o;
+}
+
+// ---- Philox4x32-10 reset stream (DESIGN.md "reset stream"; restated in oracle/env_oracle.py) ----
+#define FLEX_PHILOX_M0 0xD2511F53u
+#define FLEX_PHILOX_M1 0xCD9E8D57u
+#define FLEX_PHILOX_W0 0x9E3779B9u
+#define FLEX_PHILOX_W1 0xBB67AE85u
+#define FLEX_RESET_TAG 0x5AFE0001u
+
+__device__ __forceinline__ void philox_pair(uint32_t block, uint32_t episode, uint32_t env, uint64_t seed,
+                                            double& u0, double& u1) {
+    uint32_t c0 = block, c1 = episode, c2 = env, c3 = FLEX_RESET_TAG;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(FLEX_PHILOX_M0, c0), lo0 = FLEX_PHILOX_M0 * c0;
+        const uint32_t hi1 = __umulhi(FLEX_PHILOX_M1, c2), lo1 = FLEX_PHILOX_M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += FLEX_PHILOX_W0; k1 += FLEX_PHILOX_W1;
+    }
+    const uint64_t a = ((uint64_t)c0 << 32) | c1, b = ((uint64_t)c2 << 32) | c3;
+    u0 = (double)(a >> 11) * (1.0 / 9007199254740992.0);
+    u1 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+}

@@ -1,0 +1,777 @@
+// flexenv.hip — kernels and C-ABI host side of the flexibility-provision hot path (gfx950).
+// Boundary: include/flexenv.h.  Reference semantics: SURVEY.md §8(a) a1-a12; every kernel cites
+// the reference lines (under /root/reference) whose behaviour it reproduces.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "flex_device.h"
+
+#define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { \
+    fprintf(stderr, "[flexenv] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+    return FLEX_EHIP; } } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Per-environment state (device, owned by the handle).  Layout is array-of-records per FIELD with
+// the environment as the slow index, so each wavefront touches a few short contiguous runs.
+// ------------------------------------------------------------------------------------------------
+enum { AF_E = 0, AF_EINIT, AF_PRED, AF_CH, AF_DIS, AF_Q, AF_PCT, AF_COUNT };          // agent fields
+enum { IF_STEPS = 0, IF_START, IF_ROW, IF_OBSCNT, IF_EPISODE, IF_ITERS, IF_COUNT = 8 }; // int fields
+
+struct DevState {
+    double* vm;        // [N, n_bus]   |V| in BUS order           (current_voltage, env:146,310)
+    double* ve;        // [N, 64]      Re V in LANE order          (warm start)
+    double* vf;        // [N, 64]      Im V in LANE order
+    double* agent;     // [N, AF_COUNT, FLEX_MAX_AGENTS]
+    double* cumrew;    // [N]
+    int32_t* ienv;     // [N, IF_COUNT]
+    float* ring;       // [N, n_agents, history, 6]  observation history ring (env:387-401)
+};
+
+struct FlexEnv {
+    FlexCfg cfg;
+    int32_t n_envs, n_bus, device;
+    SeriesTab series;
+    DevNet* net;       // device
+    DevNet hnet;       // host copy
+    DevState st;
+};
+
+struct KArgs {
+    FlexCfg cfg;
+    const DevNet* net;
+    DevState st;
+    const double* series;
+    int64_t rows;
+    int32_t cols, n_envs, n_bus;
+};
+
+__device__ __forceinline__ double load_action(const void* p, int dtype, int64_t i) {
+    return dtype == FLEX_F32 ? (double)((const float*)p)[i] : ((const double*)p)[i];
+}
+
+__device__ __forceinline__ int64_t clamp_row(int64_t r, int64_t rows) { return r < 0 ? 0 : (r >= rows ? rows - 1 : r); }
+
+// Reward terms, env:679-706.  Building terms live in building lanes, voltages in all bus lanes.
+struct RewardOut { double reward, revenue, der, ess, disc, vpen; };
+__device__ __forceinline__ RewardOut reward_terms(const FlexCfg& c, bool is_bld, bool is_bus, double price,
+                                                  double pred, double ch, double dis, double q, double v) {
+    RewardOut r;
+    r.revenue = wave_sum(is_bld ? price * pred : 0.0);
+    r.der = wave_sum(is_bld ? c.pv_cost * q : 0.0);                       // signed: SURVEY A6
+    r.ess = wave_sum(is_bld ? c.ess_cost * (ch + dis) : 0.0);
+    r.disc = wave_sum(is_bld ? c.discomfort_coeff * pred * pred : 0.0);
+    r.vpen = wave_sum(is_bus ? c.voltage_coeff * fmax(0.0, fmax(v - c.v_max, c.v_min - v)) : 0.0);  // all buses: A7
+    r.reward = r.revenue - r.der - r.ess - r.disc - r.vpen;
+    return r;
+}
+
+// get_obs (env:370-403): push this step's 6 features per agent into the ring and emit the
+// stacked [n_agents, history*6] observation with zero left-padding (A16).  Called by one wavefront.
+template <typename OutT>
+__device__ __forceinline__ void push_and_emit_obs(const KArgs& a, int env, int lane, const LaneNet& ln, int k,
+                                                  double pd, double qd, double ppv, double v, double price,
+                                                  double e, OutT* __restrict__ out) {
+    // k = observations already pushed this episode (read by the caller before it wrote any state)
+    const int H = a.cfg.history, na = a.cfg.n_agents;
+    int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
+    const int slot = k % H;
+    float* ring = a.st.ring + (int64_t)env * na * H * 6;
+    OutT* o = out ? out + (int64_t)env * na * H * 6 : nullptr;
+    // history part: entries k-(H-1) .. k-1 come from the ring, older ones are zeros
+    const int total = na * H * 6;
+    for (int idx = lane; idx < total; idx += FLEX_WAVE) {
+        const int ag = idx / (H * 6), rem = idx - ag * (H * 6), h = rem / 6, ft = rem - h * 6;
+        if (h == H - 1 || !o) continue;
+        const int src = k - (H - 1) + h;
+        float val = 0.0f;
+        if (src >= 0) val = ring[(ag * H + (src % H)) * 6 + ft];
+        o[idx] = (OutT)val;
+    }
+    if (ln.agent >= 0) {
+        const double feat[6] = {pd, qd, ppv, v, price, e};   // env:377-382
+        float* r = ring + (ln.agent * H + slot) * 6;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            r[t] = (float)feat[t];
+            if (o) o[(ln.agent * H + (H - 1)) * 6 + t] = (OutT)feat[t];
+        }
+    }
+    if (lane == 0) ie[IF_OBSCNT] = k + 1;
+}
+
+// -------------------------------------------------------------------------------------------------
+// step(): env:241-356 for one environment per wavefront, get_obs() optionally fused (model.py:220-223)
+// -------------------------------------------------------------------------------------------------
+template <typename ObsT>
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
+void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, double* __restrict__ reward,
+                      uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
+                      ObsT* __restrict__ obs, int want_obs) {
+    const int lane = threadIdx.x & 63;
+    const int env = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (env >= a.n_envs) return;
+    const FlexCfg& c = a.cfg;
+    LaneNet ln;
+    load_lane_net(a.net, lane, ln);
+    const int nb = a.n_bus, na = c.n_agents;
+    int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
+    const int steps = ie[IF_STEPS], start = ie[IF_START], obs_cnt = ie[IF_OBSCNT];
+    const int64_t row = clamp_row(ie[IF_ROW], a.rows);
+    const bool is_bus = ln.bus >= 0, is_bld = ln.agent >= 0;
+    const int ag = is_bld ? ln.agent : 0;
+
+    // current data row (loaded by the previous step / reset: env:340, A2)
+    const double* sr = a.series + row * a.cols;
+    const double pd = is_bus ? sr[ln.bus] : 0.0;
+    const double qd = is_bus ? sr[nb + ln.bus] : 0.0;
+    const double ppv = is_bld ? sr[2 * nb + ag] : 0.0;
+    const double price = sr[2 * nb + na];
+
+    double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
+    const double e_cur = is_bld ? agst[AF_E * FLEX_MAX_AGENTS + ag] : 0.0;
+    const double e_init = is_bld ? agst[AF_EINIT * FLEX_MAX_AGENTS + ag] : 0.0;
+
+    // actions -> physical set-points (env:260-293)
+    FlexAct act = {0, 0, 0, 0, 0};
+    if (is_bld) {
+        const int64_t base = ((int64_t)env * na + ag) * 4;
+        act = parse_actions(c, c.raw_actions != 0, load_action(actions, act_dtype, base),
+                            load_action(actions, act_dtype, base + 1), load_action(actions, act_dtype, base + 2),
+                            load_action(actions, act_dtype, base + 3), pd, ppv, e_cur);
+    }
+    // net load per bus (pf.py:69-73, 81-82)
+    const double pnet = pd - act.pred - ppv + act.ch - act.dis;
+    const double qnet = qd - act.q;
+
+    // power flow (pf.py:10-113)
+    double e = 1.0, f = 0.0;
+    if (c.warm_start) { e = a.st.ve[(int64_t)env * 64 + lane]; f = a.st.vf[(int64_t)env * 64 + lane]; }
+    int iters = 0;
+    const bool ok = pf_newton_tree(a.net, ln, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters);
+
+    double v, pred, ch, dis, q, e_new;
+    if (ok) {
+        v = sqrt(e * e + f * f);                                                       // pf.py:108
+        pred = act.pred; ch = act.ch; dis = act.dis; q = act.q;
+        e_new = e_init + c.dt * (c.eta_ch * ch - (1.0 / c.eta_dis) * dis);             // pf.py:96-98
+        if (is_bus) a.st.vm[(int64_t)env * nb + ln.bus] = v;
+        a.st.ve[(int64_t)env * 64 + lane] = e;
+        a.st.vf[(int64_t)env * 64 + lane] = f;
+        if (is_bld) {
+            agst[AF_PRED * FLEX_MAX_AGENTS + ag] = pred;
+            agst[AF_CH * FLEX_MAX_AGENTS + ag] = ch;
+            agst[AF_DIS * FLEX_MAX_AGENTS + ag] = dis;
+            agst[AF_Q * FLEX_MAX_AGENTS + ag] = q;
+        }
+    } else {                                                                           // env:314-328
+        v = is_bus ? a.st.vm[(int64_t)env * nb + ln.bus] : 1.0;
+        pred = is_bld ? agst[AF_PRED * FLEX_MAX_AGENTS + ag] : 0.0;
+        ch = is_bld ? agst[AF_CH * FLEX_MAX_AGENTS + ag] : 0.0;
+        dis = is_bld ? agst[AF_DIS * FLEX_MAX_AGENTS + ag] : 0.0;
+        q = is_bld ? agst[AF_Q * FLEX_MAX_AGENTS + ag] : 0.0;
+        e_new = e_cur;
+    }
+    if (is_bld) {
+        agst[AF_PCT * FLEX_MAX_AGENTS + ag] = act.pct;
+        agst[AF_E * FLEX_MAX_AGENTS + ag] = e_new;
+        agst[AF_EINIT * FLEX_MAX_AGENTS + ag] = e_new;                                 // env:354
+    }
+
+    RewardOut rw = reward_terms(c, is_bld, is_bus, price, pred, ch, dis, q, v);         // env:330-335
+    const double cum_before = a.st.cumrew[env];
+    double rwd = rw.reward;
+    if (!ok) rwd -= c.fail_penalty;                                                    // env:336
+    const int new_steps = steps + 1;                                                   // env:342
+    const bool term = (new_steps >= c.episode_limit) || !ok;                           // env:345
+    const int64_t new_row = clamp_row((int64_t)start + steps, a.rows);                  // env:340 reads row `steps` (A2)
+    if (lane == 0) {
+        reward[env] = rwd;
+        done[env] = term ? 1 : 0;
+        if (failed) failed[env] = ok ? 0 : 1;
+        if (info) {
+            double* io = info + (int64_t)env * FLEX_INFO_W;
+            io[0] = rw.reward; io[1] = rw.revenue; io[2] = rw.der; io[3] = rw.ess;
+            io[4] = rw.disc; io[5] = rw.vpen; io[6] = cum_before;                      // A9
+        }
+        a.st.cumrew[env] = cum_before + rwd;                                           // env:343
+        ie[IF_STEPS] = new_steps;
+        ie[IF_ROW] = (int32_t)new_row;
+        ie[IF_ITERS] = iters;
+    }
+    if (want_obs) {
+        const double* nr = a.series + new_row * a.cols;
+        push_and_emit_obs<ObsT>(a, env, lane, ln, obs_cnt, is_bus ? nr[ln.bus] : 0.0, is_bus ? nr[nb + ln.bus] : 0.0,
+                                is_bld ? nr[2 * nb + ag] : 0.0, v, nr[2 * nb + na], e_new, obs);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// get_obs(): env:370-403 standalone
+// -------------------------------------------------------------------------------------------------
+template <typename ObsT>
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
+void flex_obs_kernel(KArgs a, ObsT* __restrict__ obs) {
+    const int lane = threadIdx.x & 63;
+    const int env = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (env >= a.n_envs) return;
+    LaneNet ln;
+    load_lane_net(a.net, lane, ln);
+    const int nb = a.n_bus, na = a.cfg.n_agents;
+    const int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
+    const double* sr = a.series + clamp_row(ie[IF_ROW], a.rows) * a.cols;
+    const bool is_bus = ln.bus >= 0, is_bld = ln.agent >= 0;
+    const int ag = is_bld ? ln.agent : 0;
+    const double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
+    push_and_emit_obs<ObsT>(a, env, lane, ln, ie[IF_OBSCNT], is_bus ? sr[ln.bus] : 0.0, is_bus ? sr[nb + ln.bus] : 0.0,
+                            is_bld ? sr[2 * nb + ag] : 0.0, is_bus ? a.st.vm[(int64_t)env * nb + ln.bus] : 0.0,
+                            sr[2 * nb + na], is_bld ? agst[AF_E * FLEX_MAX_AGENTS + ag] : 0.0, obs);
+}
+
+// get_state(): env:358-368  [Pd | Qd | Ppv | V | price | E]
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
+void flex_state_kernel(KArgs a, double* __restrict__ state) {
+    const int lane = threadIdx.x & 63;
+    const int env = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (env >= a.n_envs) return;
+    const int nb = a.n_bus, na = a.cfg.n_agents;
+    const int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
+    const double* sr = a.series + clamp_row(ie[IF_ROW], a.rows) * a.cols;
+    const int width = 3 * nb + 2 * na + 1;
+    double* o = state + (int64_t)env * width;
+    const double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
+    for (int i = lane; i < width; i += FLEX_WAVE) {
+        double v;
+        if (i < 2 * nb + na) v = sr[i];
+        else if (i < 3 * nb + na) v = a.st.vm[(int64_t)env * nb + (i - 2 * nb - na)];
+        else if (i == 3 * nb + na) v = sr[2 * nb + na];
+        else v = agst[AF_E * FLEX_MAX_AGENTS + (i - 3 * nb - na - 1)];
+        o[i] = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// reset()/manual_reset(): env:74-155, 157-239
+// -------------------------------------------------------------------------------------------------
+// draw d of the reset stream lives in lane d/2 (u0 for even d, u1 for odd d)
+__device__ __forceinline__ double flex_draw(double u0, double u1, int d) {
+    const double a = __shfl(u0, d >> 1, FLEX_WAVE), b = __shfl(u1, d >> 1, FLEX_WAVE);
+    return (d & 1) ? b : a;
+}
+
+struct DevResetSpec { const int32_t *day, *hour, *interval; const double *e0, *a0; };
+
+template <typename ObsT>
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
+void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec inj, ObsT* __restrict__ obs,
+                       int want_obs, uint8_t* __restrict__ failed) {
+    const int lane = threadIdx.x & 63;
+    const int env = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (env >= a.n_envs) return;
+    if (mask && !mask[env]) return;
+    const FlexCfg& c = a.cfg;
+    LaneNet ln;
+    load_lane_net(a.net, lane, ln);
+    const int nb = a.n_bus, na = c.n_agents;
+    int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
+    const bool is_bus = ln.bus >= 0, is_bld = ln.agent >= 0;
+    const int ag = is_bld ? ln.agent : 0;
+    double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
+    const bool all_injected = inj.day && inj.hour && inj.interval && inj.e0 && inj.a0;
+    const int max_attempts = all_injected ? 1 : 8;
+    uint32_t episode = (uint32_t)ie[IF_EPISODE];
+
+    bool ok = false;
+    int start = 0, iters = 0;
+    int64_t row = 0;
+    double e = 1.0, f = 0.0, e0 = 0.0, pd = 0.0, qd = 0.0, ppv = 0.0, price = 0.0, e_new = 0.0;
+    FlexAct act = {0, 0, 0, 0, 0};
+    for (int attempt = 0; attempt < max_attempts && !ok; ++attempt, ++episode) {
+        // lane j holds Philox block j of this attempt: draws 2j and 2j+1
+        double u0, u1;
+        philox_pair((uint32_t)lane, episode, (uint32_t)env, c.seed, u0, u1);
+        // draw d lives in lane d/2, component d%2
+        // NOTE: both halves are pulled unconditionally and selected afterwards — a shuffle inside a
+        // lane-divergent branch would read lanes that are masked off there.
+        #define FLEX_DRAW(d) flex_draw(u0, u1, (d))
+        int hour = inj.hour ? inj.hour[env] : (int)(FLEX_DRAW(0) * 24.0);                      // env:85,412
+        int day = inj.day ? inj.day[env] : (int)(FLEX_DRAW(1) * (double)c.n_start_days);       // env:86,424
+        int interval = inj.interval ? inj.interval[env] : (int)(FLEX_DRAW(2) * (double)c.per_hour);  // env:87,416
+        start = interval + hour * c.per_hour + day * 24 * c.per_hour;                          // env:477
+        row = clamp_row((int64_t)start + 1, a.rows);                                           // steps = 1: env:76,98
+        const double* sr = a.series + row * a.cols;
+        pd = is_bus ? sr[ln.bus] : 0.0;
+        qd = is_bus ? sr[nb + ln.bus] : 0.0;
+        ppv = is_bld ? sr[2 * nb + ag] : 0.0;
+        price = sr[2 * nb + na];
+        const double lo = 0.9 * (c.e_max / 2), hi = 1.1 * (c.e_max / 2);                        // env:100
+        const int de = 3 + ag, da = 3 + na + 4 * ag;
+        const double ue = flex_draw(u0, u1, de);
+        const double ua0 = flex_draw(u0, u1, da), ua1 = flex_draw(u0, u1, da + 1);
+        const double ua2 = flex_draw(u0, u1, da + 2), ua3 = flex_draw(u0, u1, da + 3);
+        if (is_bld) {
+            e0 = inj.e0 ? inj.e0[(int64_t)env * na + ag] : lo + (hi - lo) * ue;
+            const double* ia = inj.a0 ? inj.a0 + ((int64_t)env * na + ag) * 4 : nullptr;
+            const double span = c.action_high - c.action_low;                                   // env:716-719
+            const double av0 = ia ? ia[0] : c.action_low + span * ua0, av1 = ia ? ia[1] : c.action_low + span * ua1;
+            const double av2 = ia ? ia[2] : c.action_low + span * ua2, av3 = ia ? ia[3] : c.action_low + span * ua3;
+            act = parse_actions(c, false, av0, av1, av2, av3, pd, ppv, e0);                     // env:113-130
+        }
+        const double pnet = pd - act.pred - ppv + act.ch - act.dis;
+        const double qnet = qd - act.q;
+        e = 1.0; f = 0.0;
+        ok = pf_newton_tree(a.net, ln, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters);       // env:134-144
+        e_new = e0 + c.dt * (c.eta_ch * act.ch - (1.0 / c.eta_dis) * act.dis);                  // pf.py:96-98
+        #undef FLEX_DRAW
+    }
+    const double v = sqrt(e * e + f * f);
+    if (is_bus) a.st.vm[(int64_t)env * nb + ln.bus] = v;
+    a.st.ve[(int64_t)env * 64 + lane] = ok ? e : 1.0;
+    a.st.vf[(int64_t)env * 64 + lane] = ok ? f : 0.0;
+    if (is_bld) {
+        agst[AF_E * FLEX_MAX_AGENTS + ag] = e_new;          // env:147
+        agst[AF_EINIT * FLEX_MAX_AGENTS + ag] = e0;         // A5: stays the pre-solve draw
+        agst[AF_PRED * FLEX_MAX_AGENTS + ag] = act.pred;
+        agst[AF_CH * FLEX_MAX_AGENTS + ag] = act.ch;
+        agst[AF_DIS * FLEX_MAX_AGENTS + ag] = act.dis;
+        agst[AF_Q * FLEX_MAX_AGENTS + ag] = act.q;
+        agst[AF_PCT * FLEX_MAX_AGENTS + ag] = act.pct;
+    }
+    if (lane == 0) {
+        a.st.cumrew[env] = 0.0;                             // env:77
+        ie[IF_STEPS] = 1;                                   // env:76
+        ie[IF_START] = start;
+        ie[IF_ROW] = (int32_t)row;
+        ie[IF_OBSCNT] = 0;                                  // env:79-80
+        ie[IF_EPISODE] = (int32_t)episode;
+        ie[IF_ITERS] = iters;
+        if (failed) failed[env] = ok ? 0 : 1;
+    }
+    if (want_obs) push_and_emit_obs<ObsT>(a, env, lane, ln, 0, pd, qd, ppv, v, price, e_new, obs);
+}
+
+// -------------------------------------------------------------------------------------------------
+// power_flow_solver_simplified on a batch: utils/pf.py:115-192
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
+void pf_batch_kernel(const DevNet* __restrict__ net, int n, int nb, const double* __restrict__ pnet,
+                     const double* __restrict__ qnet, double* __restrict__ v, double* __restrict__ isqr,
+                     double* __restrict__ pl, double* __restrict__ ql, int32_t* __restrict__ iters_out,
+                     uint8_t* __restrict__ failed, double tol, int max_iter) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (i >= n) return;
+    LaneNet ln;
+    load_lane_net(net, lane, ln);
+    const bool is_bus = ln.bus >= 0;
+    const double p = is_bus ? pnet[(int64_t)i * nb + ln.bus] : 0.0;
+    const double q = is_bus ? qnet[(int64_t)i * nb + ln.bus] : 0.0;
+    double e = 1.0, f = 0.0;
+    int iters = 0;
+    const bool ok = pf_newton_tree(net, ln, p, q, e, f, tol, max_iter, iters);
+    // line quantities in the receiving-end convention of pf.py:85-88
+    const double ep = __shfl(e, ln.par, FLEX_WAVE), fp = __shfl(f, ln.par, FLEX_WAVE);
+    if (is_bus) {
+        v[(int64_t)i * nb + ln.bus] = sqrt(e * e + f * f);
+        const double de = ep - e, df = fp - f;
+        const double jr = ln.g * de - ln.b * df, ji = ln.b * de + ln.g * df;
+        if (isqr) isqr[(int64_t)i * nb + ln.bus] = jr * jr + ji * ji;
+        if (pl) pl[(int64_t)i * nb + ln.bus] = e * jr + f * ji;
+        if (ql) ql[(int64_t)i * nb + ln.bus] = f * jr - e * ji;
+    }
+    if (lane == 0) {
+        if (iters_out) iters_out[i] = iters;
+        if (failed) failed[i] = ok ? 0 : 1;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Safety layer, madrl/models/safemaddpg.py:142-299, one lane per (env, building).
+// with V_pred(bus) = sP*P_net[bus] + sQ*Q_net[bus] + beta (own-bus only,
+// safemaddpg.py:266,272) the QP separates per building into
+//     min |x - x0|^2 + rho*(s_lo + s_up)   s.t.  v_min - s_lo <= c.x + d <= v_max + s_up,
+//     x = (pr, ch, dis, q), pr,ch,dis >= 0, q free, s >= 0,
+//     c = (-sP*Pd, sP, -sP, sQ),  d = sP*Pd + sQ*Qd + beta.
+// For each side of the slab the minimiser is found by active-set enumeration over the three
+// sign constraints (8 subsets), each subset solved in closed form; the exact L1 penalty caps the
+// multiplier at rho (beyond it the slack absorbs the rest).
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void qp_side(const double x0[4], const double cvec[4], double d, double bound,
+                                        double sign /* +1: c.x+d <= bound ; -1: c.x+d >= bound */,
+                                        double rho, double xout[4], bool& changed) {
+    // constraint h(x) = sign*(c.x + d - bound) <= slack, slack >= 0 with cost rho*slack.
+    // Start from the projection of x0 on the sign constraints alone.
+    double best[4], bestobj = 1e300;
+    bool found = false;
+    double xfree[4] = {fmax(x0[0], 0.0), fmax(x0[1], 0.0), fmax(x0[2], 0.0), x0[3]};
+    double h0 = sign * (cvec[0] * xfree[0] + cvec[1] * xfree[1] + cvec[2] * xfree[2] + cvec[3] * xfree[3] + d - bound);
+    if (h0 <= 0.0) {
+        for (int t = 0; t < 4; ++t) xout[t] = xfree[t];
+        changed = false;
+        return;
+    }
+    changed = true;
+    // enumerate active sets A (bits over x0..x2 fixed at 0)
+    for (int A = 0; A < 8; ++A) {
+        double cc = 0.0, cx = 0.0;
+        for (int t = 0; t < 4; ++t) {
+            const bool fixed = (t < 3) && ((A >> t) & 1);
+            if (!fixed) { cc += cvec[t] * cvec[t]; cx += cvec[t] * x0[t]; }
+        }
+        // x = x0 - lam*sign*c/2 on free coords; h(x) = sign*(cx + d - bound) - lam*cc/2 = slack
+        const double hfree = sign * (cx + d - bound);
+        double lam;               // multiplier of the slab constraint, 0 <= lam <= rho
+        if (cc > 0.0) lam = fmin(fmax(2.0 * hfree / cc, 0.0), rho);
+        else lam = (hfree > 0.0) ? rho : 0.0;
+        double x[4];
+        bool feas = true;
+        for (int t = 0; t < 4; ++t) {
+            const bool fixed = (t < 3) && ((A >> t) & 1);
+            x[t] = fixed ? 0.0 : x0[t] - 0.5 * lam * sign * cvec[t];
+            if (t < 3 && x[t] < -1e-15) feas = false;
+        }
+        if (!feas) continue;
+        double h = sign * (cvec[0] * x[0] + cvec[1] * x[1] + cvec[2] * x[2] + cvec[3] * x[3] + d - bound);
+        const double slack = fmax(h, 0.0);
+        double obj = rho * slack;
+        for (int t = 0; t < 4; ++t) obj += (x[t] - x0[t]) * (x[t] - x0[t]);
+        if (obj < bestobj) { bestobj = obj; found = true; for (int t = 0; t < 4; ++t) best[t] = x[t]; }
+    }
+    for (int t = 0; t < 4; ++t) xout[t] = found ? fmax(best[t], t < 3 ? 0.0 : -1e300) : xfree[t];
+}
+
+__global__ void flex_safety_kernel(KArgs a, const void* __restrict__ proposed, int dtype,
+                                   const double* __restrict__ s_p, const double* __restrict__ s_q,
+                                   const double* __restrict__ beta, double v_min, double v_max, double rho,
+                                   double* __restrict__ adjusted, uint8_t* __restrict__ intervened) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int na = a.cfg.n_agents;
+    if (tid >= a.n_envs * na) return;
+    const int env = tid / na, ag = tid - env * na;
+    const FlexCfg& c = a.cfg;
+    const int nb = a.n_bus;
+    const int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
+    const double* sr = a.series + clamp_row(ie[IF_ROW], a.rows) * a.cols;
+    const int bus = a.net->bus_of_lane[a.net->lane_of_agent[ag]];
+    const double pd = sr[bus], qd = sr[nb + bus], ppv = sr[2 * nb + ag];
+    const double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
+    const double e_cur = agst[AF_E * FLEX_MAX_AGENTS + ag];
+    const int64_t base = ((int64_t)env * na + ag) * 4;
+    // parse_actions, safemaddpg.py:142-174: always the scaled branch, clip vs current_ess_energy
+    FlexAct p = parse_actions(c, false, load_action(proposed, dtype, base), load_action(proposed, dtype, base + 1),
+                              load_action(proposed, dtype, base + 2), load_action(proposed, dtype, base + 3),
+                              pd, ppv, e_cur);
+    const double x0[4] = {p.pct, p.ch, p.dis, p.q};
+    const double sp = s_p[ag], sq = s_q[ag];
+    const double cvec[4] = {-sp * pd, sp, -sp, sq};
+    const double d = sp * pd + sq * qd + beta[ag];
+    double x[4];
+    bool ch_up = false, ch_lo = false;
+    qp_side(x0, cvec, d, v_max, +1.0, rho, x, ch_up);
+    if (!ch_up) qp_side(x0, cvec, d, v_min, -1.0, rho, x, ch_lo);
+    double* o = adjusted + (int64_t)env * 4 * na;          // type-major, safemaddpg.py:297 (A13)
+    o[0 * na + ag] = x[0]; o[1 * na + ag] = x[1]; o[2 * na + ag] = x[2]; o[3 * na + ag] = x[3];
+    if (intervened && (ch_up || ch_lo)) intervened[env] = 1;
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+static int build_devnet(const NetFix* nf, int n_agents, DevNet* dn) {
+    const int n = nf->n_bus;
+    if (n < 2 || n > FLEX_MAX_BUS || n_agents < 1 || n_agents > FLEX_MAX_AGENTS) return FLEX_EINVAL;
+    if (nf->max_children < 1 || nf->max_children > FLEX_MAX_CHILDREN) return FLEX_EINVAL;
+    if (nf->slack < 0 || nf->slack >= n) return FLEX_EINVAL;
+    memset(dn, 0, sizeof(*dn));
+    dn->n_bus = n; dn->n_levels = nf->n_levels; dn->max_children = nf->max_children; dn->n_agents = n_agents;
+    // depth-first preorder from the slack: the first child of a bus lands in the next lane
+    std::vector<int> order, stack;
+    stack.push_back(nf->slack);
+    while (!stack.empty()) {
+        int u = stack.back(); stack.pop_back();
+        order.push_back(u);
+        for (int k = nf->max_children - 1; k >= 0; --k) {
+            int cidx = nf->child[u * nf->max_children + k];
+            if (cidx >= 0) { if (cidx >= n) return FLEX_EINVAL; stack.push_back(cidx); }
+        }
+        if ((int)order.size() > n) return FLEX_EINVAL;
+    }
+    if ((int)order.size() != n) return FLEX_EINVAL;
+    for (int l = 0; l < FLEX_MAX_BUS; ++l) {
+        dn->bus_of_lane[l] = -1; dn->lane_of_bus[l] = -1; dn->par_lane[l] = l; dn->level[l] = -1;
+        dn->agent_of_lane[l] = -1; dn->gd[l] = 1.0;
+        for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) dn->child_lane[k][l] = -1;
+    }
+    for (int l = 0; l < n; ++l) { dn->bus_of_lane[l] = order[l]; dn->lane_of_bus[order[l]] = l; }
+    dn->slack_lane = dn->lane_of_bus[nf->slack];
+    int maxlev = 0;
+    for (int l = 0; l < n; ++l) {
+        const int b = order[l];
+        const int p = nf->parent[b];
+        dn->level[l] = nf->level[b];
+        if (nf->level[b] < 0 || nf->level[b] >= FLEX_MAX_BUS) return FLEX_EINVAL;
+        if (nf->level[b] > maxlev) maxlev = nf->level[b];
+        if (b == nf->slack) {
+            if (p != -1 || nf->level[b] != 0) return FLEX_EINVAL;
+            continue;
+        }
+        if (p < 0 || p >= n || nf->level[p] != nf->level[b] - 1) return FLEX_EINVAL;
+        dn->par_lane[l] = dn->lane_of_bus[p];
+        const double r = nf->r[b], x = nf->x[b], z2 = r * r + x * x;
+        if (!(z2 > 0.0)) return FLEX_EINVAL;
+        dn->r[l] = r; dn->x[l] = x;
+        dn->g[l] = r / z2; dn->b[l] = -x / z2;
+    }
+    if (maxlev + 1 != nf->n_levels) return FLEX_EINVAL;
+    for (int l = 0; l < n; ++l) { dn->gd[l] = dn->g[l]; dn->bd[l] = dn->b[l]; }
+    for (int l = 0; l < n; ++l) {
+        const int b = order[l];
+        int used = 0;
+        for (int k = 0; k < nf->max_children; ++k) {
+            const int cidx = nf->child[b * nf->max_children + k];
+            if (cidx < 0) continue;
+            if (nf->parent[cidx] != b) return FLEX_EINVAL;
+            const int cl = dn->lane_of_bus[cidx];
+            dn->child_lane[used++][l] = cl;
+            dn->gd[l] += dn->g[cl]; dn->bd[l] += dn->b[cl];
+        }
+        const int lev = dn->level[l];
+        if (lev + 1 < FLEX_MAX_BUS && used > dn->slots_at_level[lev + 1] && l != dn->slack_lane)
+            dn->slots_at_level[lev + 1] = used;
+    }
+    for (int a = 0; a < n_agents; ++a) {
+        const int b = nf->agent_bus[a];
+        if (b < 0 || b >= n || b == nf->slack) return FLEX_EINVAL;
+        const int l = dn->lane_of_bus[b];
+        if (dn->agent_of_lane[l] >= 0) return FLEX_EINVAL;   // one building per bus
+        dn->agent_of_lane[l] = a; dn->lane_of_agent[a] = l;
+    }
+    return FLEX_OK;
+}
+
+static KArgs make_args(const FlexEnv* e) {
+    KArgs k;
+    k.cfg = e->cfg; k.net = e->net; k.st = e->st; k.series = e->series.table;
+    k.rows = e->series.rows; k.cols = e->series.cols; k.n_envs = e->n_envs; k.n_bus = e->n_bus;
+    return k;
+}
+
+static inline dim3 env_grid(int n) { return dim3((n + FLEX_WAVES_PER_BLOCK - 1) / FLEX_WAVES_PER_BLOCK); }
+static inline dim3 env_block() { return dim3(FLEX_WAVE * FLEX_WAVES_PER_BLOCK); }
+
+extern "C" {
+
+const char* flexenv_version(void) { return "flexenv-hip 0.1 (gfx950)"; }
+
+int flexenv_create(const FlexCfg* cfg, const NetFix* net, const SeriesTab* series, int32_t n_envs,
+                   int32_t device, FlexEnv** out) {
+    if (!cfg || !net || !series || !out || n_envs < 1) return FLEX_EINVAL;
+    if (cfg->n_agents < 1 || cfg->n_agents > FLEX_MAX_AGENTS || cfg->history < 1 || cfg->episode_limit < 1)
+        return FLEX_EINVAL;
+    if (cfg->solver != FLEX_SOLVER_TREE) return FLEX_EINVAL;
+    if (series->cols != 2 * net->n_bus + cfg->n_agents + 1 || series->rows < 2 || !series->table) return FLEX_EINVAL;
+    if (cfg->per_hour < 1 || cfg->n_start_days < 1) return FLEX_EINVAL;
+    // every reachable row must exist: start + 1 + (episode_limit + history)
+    const int64_t max_start = (int64_t)(cfg->per_hour - 1) + 23LL * cfg->per_hour +
+                              (int64_t)(cfg->n_start_days - 1) * 24 * cfg->per_hour;
+    if (max_start + cfg->episode_limit + 1 >= series->rows) return FLEX_EINVAL;
+    FlexEnv* e = new (std::nothrow) FlexEnv();
+    if (!e) return FLEX_ENOMEM;
+    memset(e, 0, sizeof(*e));
+    e->cfg = *cfg; e->n_envs = n_envs; e->n_bus = net->n_bus; e->device = device; e->series = *series;
+    int rc = build_devnet(net, cfg->n_agents, &e->hnet);
+    if (rc != FLEX_OK) { delete e; return rc; }
+    HIP_TRY(hipSetDevice(device));
+    const int64_t N = n_envs;
+    HIP_TRY(hipMalloc(&e->net, sizeof(DevNet)));
+    HIP_TRY(hipMemcpy(e->net, &e->hnet, sizeof(DevNet), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&e->st.vm, N * net->n_bus * sizeof(double)));
+    HIP_TRY(hipMalloc(&e->st.ve, N * 64 * sizeof(double)));
+    HIP_TRY(hipMalloc(&e->st.vf, N * 64 * sizeof(double)));
+    HIP_TRY(hipMalloc(&e->st.agent, N * AF_COUNT * FLEX_MAX_AGENTS * sizeof(double)));
+    HIP_TRY(hipMalloc(&e->st.cumrew, N * sizeof(double)));
+    HIP_TRY(hipMalloc(&e->st.ienv, N * IF_COUNT * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&e->st.ring, N * cfg->n_agents * cfg->history * 6 * sizeof(float)));
+    HIP_TRY(hipMemset(e->st.vm, 0, N * net->n_bus * sizeof(double)));
+    HIP_TRY(hipMemset(e->st.ve, 0, N * 64 * sizeof(double)));
+    HIP_TRY(hipMemset(e->st.vf, 0, N * 64 * sizeof(double)));
+    HIP_TRY(hipMemset(e->st.agent, 0, N * AF_COUNT * FLEX_MAX_AGENTS * sizeof(double)));
+    HIP_TRY(hipMemset(e->st.cumrew, 0, N * sizeof(double)));
+    HIP_TRY(hipMemset(e->st.ienv, 0, N * IF_COUNT * sizeof(int32_t)));
+    HIP_TRY(hipMemset(e->st.ring, 0, N * cfg->n_agents * cfg->history * 6 * sizeof(float)));
+    *out = e;
+    return FLEX_OK;
+}
+
+void flexenv_destroy(FlexEnv* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipFree(e->net); (void)hipFree(e->st.vm); (void)hipFree(e->st.ve); (void)hipFree(e->st.vf);
+    (void)hipFree(e->st.agent); (void)hipFree(e->st.cumrew); (void)hipFree(e->st.ienv); (void)hipFree(e->st.ring);
+    delete e;
+}
+
+int32_t flexenv_num_envs(const FlexEnv* e) { return e ? e->n_envs : 0; }
+int32_t flexenv_obs_size(const FlexEnv* e) { return e ? 6 * e->cfg.history : 0; }
+int32_t flexenv_state_size(const FlexEnv* e) { return e ? 3 * e->n_bus + 2 * e->cfg.n_agents + 1 : 0; }
+
+int flexenv_reset(FlexEnv* e, const uint8_t* mask, const ResetSpec* inj, void* obs, int32_t obs_dtype,
+                  uint8_t* failed, void* stream) {
+    if (!e) return FLEX_EINVAL;
+    if (obs && obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64) return FLEX_EINVAL;
+    DevResetSpec d = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (inj) { d.day = inj->day; d.hour = inj->hour; d.interval = inj->interval; d.e0 = inj->e0; d.a0 = inj->a0; }
+    KArgs k = make_args(e);
+    hipStream_t s = (hipStream_t)stream;
+    if (obs && obs_dtype == FLEX_F64)
+        hipLaunchKernelGGL(flex_reset_kernel<double>, env_grid(e->n_envs), env_block(), 0, s, k, mask, d, (double*)obs, 1, failed);
+    else
+        hipLaunchKernelGGL(flex_reset_kernel<float>, env_grid(e->n_envs), env_block(), 0, s, k, mask, d, (float*)obs, obs ? 1 : 0, failed);
+    HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* reward, uint8_t* done, double* info,
+                 uint8_t* failed, void* obs, int32_t obs_dtype, void* stream) {
+    if (!e || !actions || !reward || !done) return FLEX_EINVAL;
+    if (act_dtype != FLEX_F32 && act_dtype != FLEX_F64) return FLEX_EINVAL;
+    if (obs && obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64) return FLEX_EINVAL;
+    KArgs k = make_args(e);
+    hipStream_t s = (hipStream_t)stream;
+    if (obs && obs_dtype == FLEX_F64)
+        hipLaunchKernelGGL(flex_step_kernel<double>, env_grid(e->n_envs), env_block(), 0, s, k, actions, act_dtype,
+                           reward, done, info, failed, (double*)obs, 1);
+    else
+        hipLaunchKernelGGL(flex_step_kernel<float>, env_grid(e->n_envs), env_block(), 0, s, k, actions, act_dtype,
+                           reward, done, info, failed, (float*)obs, obs ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+int flexenv_obs(FlexEnv* e, void* obs, int32_t obs_dtype, void* stream) {
+    if (!e || !obs || (obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64)) return FLEX_EINVAL;
+    KArgs k = make_args(e);
+    hipStream_t s = (hipStream_t)stream;
+    if (obs_dtype == FLEX_F64)
+        hipLaunchKernelGGL(flex_obs_kernel<double>, env_grid(e->n_envs), env_block(), 0, s, k, (double*)obs);
+    else
+        hipLaunchKernelGGL(flex_obs_kernel<float>, env_grid(e->n_envs), env_block(), 0, s, k, (float*)obs);
+    HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+int flexenv_state(FlexEnv* e, double* state, void* stream) {
+    if (!e || !state) return FLEX_EINVAL;
+    KArgs k = make_args(e);
+    hipLaunchKernelGGL(flex_state_kernel, env_grid(e->n_envs), env_block(), 0, (hipStream_t)stream, k, state);
+    HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+// strided field <-> dense [N, width] copies for peek/poke
+__global__ void flex_gather_f64(const double* __restrict__ src, int64_t stride, int width, int n, double* __restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * width) return;
+    dst[t] = src[(t / width) * stride + (t % width)];
+}
+__global__ void flex_scatter_f64(double* __restrict__ dst, int64_t stride, int width, int n, const double* __restrict__ src) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * width) return;
+    dst[(t / width) * stride + (t % width)] = src[t];
+}
+__global__ void flex_gather_i32(const int32_t* __restrict__ src, int64_t stride, int n, int32_t* __restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    dst[t] = src[t * stride];
+}
+
+static int field_f64(FlexEnv* e, int field, double** base, int64_t* stride, int* width) {
+    const int na = e->cfg.n_agents;
+    switch (field) {
+        case FLEX_PEEK_V: *base = e->st.vm; *stride = e->n_bus; *width = e->n_bus; return 1;
+        case FLEX_PEEK_CUMREW: *base = e->st.cumrew; *stride = 1; *width = 1; return 1;
+        case FLEX_PEEK_E: case FLEX_PEEK_E_INIT: case FLEX_PEEK_PRED: case FLEX_PEEK_CH: case FLEX_PEEK_DIS:
+        case FLEX_PEEK_QPV: case FLEX_PEEK_PCT: {
+            static const int map[8] = {-1, AF_E, AF_EINIT, AF_PRED, AF_CH, AF_DIS, AF_Q, AF_PCT};
+            *base = e->st.agent + map[field] * FLEX_MAX_AGENTS;
+            *stride = AF_COUNT * FLEX_MAX_AGENTS; *width = na; return 1;
+        }
+        default: return 0;
+    }
+}
+
+int flexenv_peek(FlexEnv* e, int32_t field, void* dev_out, void* stream) {
+    if (!e || !dev_out) return FLEX_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    double* base; int64_t stride; int width;
+    if (field_f64(e, field, &base, &stride, &width)) {
+        const int64_t tot = (int64_t)e->n_envs * width;
+        hipLaunchKernelGGL(flex_gather_f64, dim3((tot + 255) / 256), dim3(256), 0, s, base, stride, width, e->n_envs, (double*)dev_out);
+        HIP_TRY(hipGetLastError());
+        return FLEX_OK;
+    }
+    int col;
+    switch (field) {
+        case FLEX_PEEK_STEPS: col = IF_STEPS; break;
+        case FLEX_PEEK_ROW: col = IF_ROW; break;
+        case FLEX_PEEK_START: col = IF_START; break;
+        case FLEX_PEEK_PF_ITERS: col = IF_ITERS; break;
+        case FLEX_PEEK_EPISODE: col = IF_EPISODE; break;
+        default: return FLEX_EINVAL;
+    }
+    hipLaunchKernelGGL(flex_gather_i32, dim3((e->n_envs + 255) / 256), dim3(256), 0, s, e->st.ienv + col, (int64_t)IF_COUNT, e->n_envs, (int32_t*)dev_out);
+    HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+int flexenv_poke(FlexEnv* e, int32_t field, const void* dev_in, void* stream) {
+    if (!e || !dev_in) return FLEX_EINVAL;
+    double* base; int64_t stride; int width;
+    if (!field_f64(e, field, &base, &stride, &width)) return FLEX_EINVAL;
+    const int64_t tot = (int64_t)e->n_envs * width;
+    hipLaunchKernelGGL(flex_scatter_f64, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, base, stride, width, e->n_envs, (const double*)dev_in);
+    HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+int pf_solve_batch(const NetFix* net, int32_t n, const double* pnet, const double* qnet, double* v, double* isqr,
+                   double* pl, double* ql, int32_t* iters, uint8_t* failed, double tol, int32_t max_iter,
+                   int32_t solver, void* stream) {
+    if (!net || n < 1 || !pnet || !qnet || !v || solver != FLEX_SOLVER_TREE) return FLEX_EINVAL;
+    DevNet h;
+    int32_t dummy_agent = -1;
+    // agents are irrelevant for a bare solve: give build_devnet one placeholder building off the slack
+    NetFix nf = *net;
+    for (int b = 0; b < net->n_bus; ++b) if (b != net->slack) { dummy_agent = b; break; }
+    nf.agent_bus = &dummy_agent;
+    int rc = build_devnet(&nf, 1, &h);
+    if (rc != FLEX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    DevNet* d = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&d, sizeof(DevNet), s));
+    HIP_TRY(hipMemcpyAsync(d, &h, sizeof(DevNet), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // h is a stack object
+    hipLaunchKernelGGL(pf_batch_kernel, env_grid(n), env_block(), 0, s, d, n, net->n_bus, pnet, qnet, v, isqr, pl, ql,
+                       iters, failed, tol, max_iter);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipFreeAsync(d, s));
+    return FLEX_OK;
+}
+
+int flexenv_safety_project(FlexEnv* e, const void* proposed, int32_t dtype, const double* s_p, const double* s_q,
+                           const double* beta, double v_min, double v_max, double penalty, double* adjusted,
+                           uint8_t* intervened, void* stream) {
+    if (!e || !proposed || !s_p || !s_q || !beta || !adjusted) return FLEX_EINVAL;
+    if (dtype != FLEX_F32 && dtype != FLEX_F64) return FLEX_EINVAL;
+    KArgs k = make_args(e);
+    hipStream_t s = (hipStream_t)stream;
+    if (intervened) HIP_TRY(hipMemsetAsync(intervened, 0, e->n_envs, s));
+    const int tot = e->n_envs * e->cfg.n_agents;
+    hipLaunchKernelGGL(flex_safety_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, k, proposed, dtype, s_p, s_q, beta,
+                       v_min, v_max, penalty, adjusted, intervened);
+    HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+}  // extern "C"

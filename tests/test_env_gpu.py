@@ -1,0 +1,213 @@
+"""GPU parity: the HIP environment (through the C ABI) vs the scalar CPU oracle on identical
+injected episodes.  Tolerances: V, E, reward terms <= 1e-10 absolute (north_star: 1e-6);
+done/steps/failed exact; observations equal after the float32 cast their consumer applies
+(util.py:145)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _oracle_envs(net, series, n, cfg=None, alg=None):
+    from oracle.env_oracle import FlexEnvOracle
+    return [FlexEnvOracle(net, cfg or {}, series.active, series.reactive, series.pv, series.price,
+                          time_delta=series.time_delta, alg=alg) for _ in range(n)]
+
+
+def _spec(rng, n, series, na, e_max=0.025):
+    day = rng.integers(0, series.n_start_days(96), n).astype(np.int32)
+    hour = rng.integers(0, 24, n).astype(np.int32)
+    interval = rng.integers(0, series.per_hour, n).astype(np.int32)
+    e0 = rng.uniform(0.9 * e_max / 2, 1.1 * e_max / 2, (n, na))
+    a0 = rng.uniform(0, 1, (n, 4 * na))
+    return dict(day=day, hour=hour, interval=interval, e0=e0, a0=a0)
+
+
+def _compare_state(vec, oracles, tag):
+    v = vec.peek("V").cpu().numpy()
+    e = vec.peek("E").cpu().numpy()
+    ei = vec.peek("E_INIT").cpu().numpy()
+    for i, o in enumerate(oracles):
+        assert np.abs(v[i] - o.current_voltage).max() < TOL, tag
+        assert np.abs(e[i] - np.array(o.current_ess_energy)).max() < TOL, tag
+        assert np.abs(ei[i] - np.array(o.initial_ess_energy)).max() < TOL, tag
+
+
+@pytest.mark.parametrize("action_range", [(0.5, 1.0), (0.0, 1.0)])
+def test_full_episode_matches_oracle(net, series_small, action_range):
+    """95 steps x 48 envs: reward, info, done, V, E, obs, state at every step.  (0.5,1.0) is the range the
+    reference actually delivers; (0,1) exercises the ESS clipping branches."""
+    import torch
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    n, na = 48, 5
+    rng = np.random.default_rng(3)
+    vec = VecFlexProvisionEnv({}, n, series=series_small, net=net)
+    oracles = _oracle_envs(net, series_small, n)
+    spec = _spec(rng, n, series_small, na)
+    obs = vec.reset(spec=spec).cpu().numpy()
+    assert vec.failed.sum().item() == 0
+    for i, o in enumerate(oracles):
+        oo, _ = o.reset(spec=(spec["day"][i], spec["hour"][i], spec["interval"][i], spec["e0"][i], spec["a0"][i]))
+        assert np.array_equal(np.stack(oo).astype(np.float32), obs[i])
+    _compare_state(vec, oracles, "reset")
+    state = vec.get_state().cpu().numpy()
+    for i, o in enumerate(oracles):
+        assert np.abs(state[i] - o.get_state()).max() < TOL
+    for t in range(95):
+        acts = rng.uniform(*action_range, (n, na, 4)).astype(np.float32)   # float32 like util.py:184
+        reward, done, info = vec.step(torch.from_numpy(acts).cuda())
+        obs = vec.get_obs().cpu().numpy()
+        reward, done, info = reward.cpu().numpy(), done.cpu().numpy(), info.cpu().numpy()
+        for i, o in enumerate(oracles):
+            r, d, inf = o.step(acts[i].astype(np.float64))
+            assert abs(r - reward[i]) < TOL, (t, i)
+            assert d == bool(done[i])
+            ref = [inf[k] for k in ("reward", "revenue", "der_cost", "ess_cost", "discomfort_penalty",
+                                    "voltage_penalty", "cumulative_reward")]
+            assert np.abs(np.array(ref) - info[i]).max() < TOL
+            oo = np.stack(o.get_obs()).astype(np.float32)
+            assert np.allclose(oo, obs[i], rtol=2e-7, atol=0)
+        if t % 10 == 0 or t == 94:
+            _compare_state(vec, oracles, f"step {t}")
+    assert done.all() and (vec.peek("STEPS").cpu().numpy() == 96).all()
+    state = vec.get_state().cpu().numpy()
+    for i, o in enumerate(oracles):
+        assert np.abs(state[i] - o.get_state()).max() < TOL
+
+
+def test_fused_obs_equals_separate(net, series_small):
+    import torch
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    n = 32
+    rng = np.random.default_rng(5)
+    a = VecFlexProvisionEnv({}, n, series=series_small, net=net, seed=11)
+    b = VecFlexProvisionEnv({}, n, series=series_small, net=net, seed=11)
+    oa = a.reset().clone()
+    ob = b.reset().clone()
+    assert torch.equal(oa, ob)
+    for t in range(30):
+        acts = torch.from_numpy(rng.uniform(0.5, 1, (n, 5, 4))).cuda()
+        a.step(acts, fuse_obs=True)
+        b.step(acts)
+        b.get_obs()
+        assert torch.equal(a.obs, b.obs)
+        assert torch.equal(a.reward, b.reward)
+
+
+def test_solver_failure_semantics(net, series_small):
+    """A8/env:314-337: on a failed solve the reward is computed from the restored previous
+    actions/voltages, minus 200; the episode terminates; the data row still advances."""
+    import torch
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.series import SeriesTable
+    from oracle.env_oracle import FlexEnvOracle
+    sc = SeriesTable(series_small.table.copy(), series_small.n_bus, series_small.n_agents)
+    rng = np.random.default_rng(9)
+    spec = _spec(rng, 2, sc, 5)
+    spec["day"][:] = 3; spec["hour"][:] = 2
+    spec["interval"][:] = [1, 2]
+    s1 = 2 + 2 * 4 + 3 * 96
+    # step k >= 2 solves with row start+k-1 (A2): env 1 meets the poisoned row at step 3, env 0 at step 4
+    sc.table[s1 + 2, 1:33] *= 40.0
+    vec = VecFlexProvisionEnv({}, 2, series=sc, net=net)
+    vec.reset(spec=spec)
+    oracles = [FlexEnvOracle(net, {}, sc.active, sc.reactive, sc.pv, sc.price) for _ in range(2)]
+    for i, o in enumerate(oracles):
+        o.reset(spec=(spec["day"][i], spec["hour"][i], spec["interval"][i], spec["e0"][i], spec["a0"][i]))
+    fails = []
+    for t in range(3):
+        acts = rng.uniform(0.5, 1, (2, 5, 4))
+        reward, done, info = vec.step(torch.from_numpy(acts).cuda())
+        failed = vec.failed.cpu().numpy()
+        obs = vec.get_obs().cpu().numpy()
+        for i, o in enumerate(oracles):
+            r, d, inf = o.step(acts[i])
+            assert abs(r - reward[i].item()) < TOL
+            assert d == bool(done[i].item())
+            assert bool(failed[i]) == bool(inf.get("solver_failed", False))
+            assert np.allclose(np.stack(o.get_obs()).astype(np.float32), obs[i], rtol=2e-7, atol=0)
+        fails.append(failed.copy())
+        _compare_state(vec, oracles, f"fail step {t}")
+    assert [list(f) for f in fails] == [[0, 0], [0, 0], [0, 1]]
+    assert reward[1].item() < -190 and done[1].item() == 1 and done[0].item() == 0
+
+
+def test_safemaddpg_raw_action_branch(net, series_small):
+    """env:268-274: with alg == 'safemaddpg' the actions are physical set-points, not scaled."""
+    import torch
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    n = 8
+    rng = np.random.default_rng(13)
+    vec = VecFlexProvisionEnv({"alg": "safemaddpg"}, n, series=series_small, net=net)
+    oracles = _oracle_envs(net, series_small, n, alg="safemaddpg")
+    spec = _spec(rng, n, series_small, 5)
+    vec.reset(spec=spec)
+    for i, o in enumerate(oracles):
+        o.reset(spec=(spec["day"][i], spec["hour"][i], spec["interval"][i], spec["e0"][i], spec["a0"][i]))
+    for t in range(10):
+        acts = rng.uniform(0.5, 1.0, (n, 5, 4))
+        reward, done, _ = vec.step(torch.from_numpy(acts).cuda())
+        for i, o in enumerate(oracles):
+            r, d, _ = o.step(acts[i])
+            assert abs(r - reward[i].item()) < TOL
+    _compare_state(vec, oracles, "raw")
+
+
+def test_philox_reset_stream_matches_restatement(net, series_small):
+    """Device-drawn episodes (no injection) equal the oracle's restatement of the Philox stream."""
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from oracle.env_oracle import reset_draws, DEFAULT_CFG
+    n = 40
+    vec = VecFlexProvisionEnv({}, n, series=series_small, net=net, seed=1234)
+    obs = vec.reset().cpu().numpy()
+    oracles = _oracle_envs(net, series_small, n)
+    start = vec.peek("START").cpu().numpy()
+    for i, o in enumerate(oracles):
+        spec = reset_draws(i, 0, 1234, 5, series_small.n_start_days(96), series_small.per_hour, DEFAULT_CFG)
+        oo, _ = o.reset(spec=spec)
+        assert o.start == start[i]
+        assert np.allclose(np.stack(oo).astype(np.float32), obs[i], rtol=2e-7, atol=0)
+    _compare_state(vec, oracles, "philox reset")
+    # masked second reset: only masked envs move on to episode counter 1
+    mask = np.zeros(n, np.uint8)
+    mask[::3] = 1
+    vec.reset(mask=mask)
+    ep = vec.peek("EPISODE").cpu().numpy()
+    assert (ep == 1 + mask).all()
+    start2 = vec.peek("START").cpu().numpy()
+    for i in range(n):
+        if mask[i]:
+            spec = reset_draws(i, 1, 1234, 5, series_small.n_start_days(96), series_small.per_hour, DEFAULT_CFG)
+            assert start2[i] == spec[2] + spec[1] * 4 + spec[0] * 96
+        else:
+            assert start2[i] == start[i]
+
+
+def test_three_agent_variant(net, series_small):
+    """BASELINE.json's '3-agent' config: buildings [5,15,25]."""
+    import torch
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from oracle.env_oracle import FlexEnvOracle
+    args = {"buildings": [5, 15, 25], "pv_nodes": [5, 15, 25], "ess_nodes": [5, 15, 25]}
+    net3 = create_network(args)
+    s3 = make_synthetic_series(net3, n_days=10)
+    n = 8
+    rng = np.random.default_rng(17)
+    vec = VecFlexProvisionEnv(args, n, series=s3, net=net3)
+    spec = _spec(rng, n, s3, 3)
+    vec.reset(spec=spec)
+    oracles = [FlexEnvOracle(net3, {}, s3.active, s3.reactive, s3.pv, s3.price) for _ in range(n)]
+    for i, o in enumerate(oracles):
+        o.reset(spec=(spec["day"][i], spec["hour"][i], spec["interval"][i], spec["e0"][i], spec["a0"][i]))
+    for t in range(12):
+        acts = rng.uniform(0, 1, (n, 3, 4))
+        reward, _, _ = vec.step(torch.from_numpy(acts).cuda())
+        obs = vec.get_obs().cpu().numpy()
+        for i, o in enumerate(oracles):
+            r, _, _ = o.step(acts[i])
+            assert abs(r - reward[i].item()) < TOL
+            assert np.allclose(np.stack(o.get_obs()).astype(np.float32), obs[i], rtol=2e-7, atol=0)
+    assert obs.shape == (n, 3, 144)
