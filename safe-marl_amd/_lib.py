@@ -72,6 +72,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  It must be mapped FIRST so that
+    # this library resolves to the same HIP runtime instance torch allocates device memory with;
+    # loading in the other order leaves two runtimes in the process and every pointer foreign.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise FlexLibraryError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
