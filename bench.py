@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--warm-start", type=int, default=1)
+    ap.add_argument("--solver", choices=["sweep", "newton"], default="sweep",
+                    help="sweep: backward/forward sweeps + Newton verification; newton: NR with tree elimination")
     return ap.parse_args()
 
 
@@ -101,7 +103,8 @@ def main():
     net = create_network()
     series = make_synthetic_series(net)                      # 1096 days x 96 rows x 72 cols fp64 (60.6 MB)
     env = VecFlexProvisionEnv({}, a.envs, device=f"cuda:{local_rank}", net=net, series=series,
-                              seed=1234 + 1000 * rank, warm_start=bool(a.warm_start))
+                              seed=1234 + 1000 * rank, warm_start=bool(a.warm_start),
+                              solver={"sweep": 2, "newton": 0}[a.solver])
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)
     # the range the reference's translate_action actually delivers (util.py:125-128), float32 like util.py:184
@@ -150,6 +153,7 @@ def main():
     kern_ms = sum(durs) / len(durs)
     failed_frac = float(env.failed.float().mean().item())
     iters_mean = float(env.peek("PF_ITERS").float().mean().item())
+    sweeps_mean = float(env.peek("PF_SWEEPS").float().mean().item())
 
     if rank == 0:
         total_env_steps = a.envs * world * a.steps
@@ -179,7 +183,7 @@ def main():
                             "5 agents, masked auto-reset each step",
                 "envs_per_gpu": a.envs, "n_agents": env.n_agents, "n_bus": env.n_bus,
                 "warm_start": bool(a.warm_start), "launches_per_step": 2,
-                "device_ms_per_step": dev_ms / a.steps, "pf_newton_iters_mean": iters_mean,
+                "device_ms_per_step": dev_ms / a.steps, "solver": a.solver, "pf_newton_iters_mean": iters_mean, "pf_sweeps_mean": sweeps_mean,
                 "solver_failed_frac": failed_frac,
             },
             "roofline": {

@@ -45,6 +45,8 @@ extern "C" {
 /* linear solver used for the Newton step */
 #define FLEX_SOLVER_TREE 0   /* leaf->root 2x2 block elimination on the radial Jacobian (no fill-in) */
 #define FLEX_SOLVER_DENSE 1  /* dense LU of the 2(n-1) x 2(n-1) Jacobian, kept as the reference variant */
+#define FLEX_SOLVER_SWEEP 2  /* backward/forward sweeps (Z-bus Gauss via wavefront scans), then the TREE Newton
+                                solver verifies the Ybus mismatch and finishes/falls back if needed */
 
 /* Scalars of madrl/args/env_args/flex_provision.yaml:3-33 plus solver controls. */
 typedef struct FlexCfg {
@@ -121,7 +123,8 @@ enum FlexField {
     FLEX_PEEK_ROW = 10,         /* i32 [N]          absolute series row of the current data, env:609-619 */
     FLEX_PEEK_START = 11,       /* i32 [N]          episode start row         env:477 */
     FLEX_PEEK_PF_ITERS = 12,    /* i32 [N]          Newton iterations of the last solve */
-    FLEX_PEEK_EPISODE = 13      /* i32 [N]          reset-attempt counter of the Philox stream */
+    FLEX_PEEK_EPISODE = 13,     /* i32 [N]          reset-attempt counter of the Philox stream */
+    FLEX_PEEK_PF_SWEEPS = 14    /* i32 [N]          sweeps of the last solve (FLEX_SOLVER_SWEEP) */
 };
 
 /* Replaces FlexibilityProvisionEnv.__init__ (env:34-72) minus its reset; `series.table` must stay

@@ -14,10 +14,10 @@ FLEX_MAX_AGENTS = 8
 FLEX_MAX_CHILDREN = 8
 FLEX_INFO_W = 7
 FLEX_F64, FLEX_F32 = 0, 1
-FLEX_SOLVER_TREE, FLEX_SOLVER_DENSE = 0, 1
+FLEX_SOLVER_TREE, FLEX_SOLVER_DENSE, FLEX_SOLVER_SWEEP = 0, 1, 2
 
 PEEK = dict(V=0, E=1, E_INIT=2, PRED=3, CH=4, DIS=5, QPV=6, PCT=7, CUMREW=8, STEPS=9, ROW=10, START=11,
-            PF_ITERS=12, EPISODE=13)
+            PF_ITERS=12, EPISODE=13, PF_SWEEPS=14)
 INFO_KEYS = ("reward", "revenue", "der_cost", "ess_cost", "discomfort_penalty", "voltage_penalty",
              "cumulative_reward")  # env:696-704
 

@@ -17,7 +17,7 @@
 // the environment as the slow index, so each wavefront touches a few short contiguous runs.
 // ------------------------------------------------------------------------------------------------
 enum { AF_E = 0, AF_EINIT, AF_PRED, AF_CH, AF_DIS, AF_Q, AF_PCT, AF_COUNT };          // agent fields
-enum { IF_STEPS = 0, IF_START, IF_ROW, IF_OBSCNT, IF_EPISODE, IF_ITERS, IF_COUNT = 8 }; // int fields
+enum { IF_STEPS = 0, IF_START, IF_ROW, IF_OBSCNT, IF_EPISODE, IF_ITERS, IF_SWEEPS, IF_COUNT = 8 }; // int fields
 
 struct DevState {
     double* vm;        // [N, n_bus]   |V| in BUS order           (current_voltage, env:146,310)
@@ -148,8 +148,8 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
     // power flow (pf.py:10-113)
     double e = 1.0, f = 0.0;
     if (c.warm_start) { e = a.st.ve[(int64_t)env * 64 + lane]; f = a.st.vf[(int64_t)env * 64 + lane]; }
-    int iters = 0;
-    const bool ok = pf_newton_tree(a.net, ln, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters);
+    int iters = 0, sweeps = 0;
+    const bool ok = pf_solve(a.net, ln, c.solver, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters, sweeps);
 
     double v, pred, ch, dis, q, e_new;
     if (ok) {
@@ -199,6 +199,7 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
         ie[IF_STEPS] = new_steps;
         ie[IF_ROW] = (int32_t)new_row;
         ie[IF_ITERS] = iters;
+        ie[IF_SWEEPS] = sweeps;
     }
     if (want_obs) {
         const double* nr = a.series + new_row * a.cols;
@@ -283,7 +284,7 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
     uint32_t episode = (uint32_t)ie[IF_EPISODE];
 
     bool ok = false;
-    int start = 0, iters = 0;
+    int start = 0, iters = 0, sweeps = 0;
     int64_t row = 0;
     double e = 1.0, f = 0.0, e0 = 0.0, pd = 0.0, qd = 0.0, ppv = 0.0, price = 0.0, e_new = 0.0;
     FlexAct act = {0, 0, 0, 0, 0};
@@ -321,7 +322,7 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
         const double pnet = pd - act.pred - ppv + act.ch - act.dis;
         const double qnet = qd - act.q;
         e = 1.0; f = 0.0;
-        ok = pf_newton_tree(a.net, ln, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters);       // env:134-144
+        ok = pf_solve(a.net, ln, c.solver, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters, sweeps);  // env:134-144
         e_new = e0 + c.dt * (c.eta_ch * act.ch - (1.0 / c.eta_dis) * act.dis);                  // pf.py:96-98
         #undef FLEX_DRAW
     }
@@ -346,6 +347,7 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
         ie[IF_OBSCNT] = 0;                                  // env:79-80
         ie[IF_EPISODE] = (int32_t)episode;
         ie[IF_ITERS] = iters;
+        ie[IF_SWEEPS] = sweeps;
         if (failed) failed[env] = ok ? 0 : 1;
     }
     if (want_obs) push_and_emit_obs<ObsT>(a, env, lane, ln, 0, pd, qd, ppv, v, price, e_new, obs);
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
 void pf_batch_kernel(const DevNet* __restrict__ net, int n, int nb, const double* __restrict__ pnet,
                      const double* __restrict__ qnet, double* __restrict__ v, double* __restrict__ isqr,
                      double* __restrict__ pl, double* __restrict__ ql, int32_t* __restrict__ iters_out,
-                     uint8_t* __restrict__ failed, double tol, int max_iter) {
+                     uint8_t* __restrict__ failed, double tol, int max_iter, int solver) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -368,8 +370,8 @@ void pf_batch_kernel(const DevNet* __restrict__ net, int n, int nb, const double
     const double p = is_bus ? pnet[(int64_t)i * nb + ln.bus] : 0.0;
     const double q = is_bus ? qnet[(int64_t)i * nb + ln.bus] : 0.0;
     double e = 1.0, f = 0.0;
-    int iters = 0;
-    const bool ok = pf_newton_tree(net, ln, p, q, e, f, tol, max_iter, iters);
+    int iters = 0, sweeps = 0;
+    const bool ok = pf_solve(net, ln, solver, p, q, e, f, tol, max_iter, iters, sweeps);
     // line quantities in the receiving-end convention of pf.py:85-88
     const double ep = __shfl(e, ln.par, FLEX_WAVE), fp = __shfl(f, ln.par, FLEX_WAVE);
     if (is_bus) {
@@ -381,7 +383,7 @@ void pf_batch_kernel(const DevNet* __restrict__ net, int n, int nb, const double
         if (ql) ql[(int64_t)i * nb + ln.bus] = f * jr - e * ji;
     }
     if (lane == 0) {
-        if (iters_out) iters_out[i] = iters;
+        if (iters_out) iters_out[i] = iters + 1000 * sweeps;   // Newton steps + 1000 * sweeps
         if (failed) failed[i] = ok ? 0 : 1;
     }
 }
@@ -540,6 +542,22 @@ static int build_devnet(const NetFix* nf, int n_agents, DevNet* dn) {
         if (lev + 1 < FLEX_MAX_BUS && used > dn->slots_at_level[lev + 1] && l != dn->slack_lane)
             dn->slots_at_level[lev + 1] = used;
     }
+    // sweep-solver tables: subtree ranges (preorder => contiguous) and 2^k-th ancestors
+    {
+        std::vector<int> size(FLEX_MAX_BUS, 1);
+        for (int l = n - 1; l >= 1; --l) size[dn->par_lane[l]] += (dn->par_lane[l] != l) ? size[l] : 0;
+        for (int l = 0; l < FLEX_MAX_BUS; ++l) {
+            dn->sub_end[l] = (l < n) ? l + size[l] - 1 : l;
+            dn->anc[0][l] = (l < n) ? dn->par_lane[l] : l;   // slack: itself
+        }
+        for (int k = 1; k < FLEX_JUMP_ROUNDS; ++k)
+            for (int l = 0; l < FLEX_MAX_BUS; ++l) dn->anc[k][l] = dn->anc[k - 1][dn->anc[k - 1][l]];
+        int rounds = 0;
+        while ((1 << rounds) < nf->n_levels - 1) ++rounds;
+        dn->n_jump_rounds = rounds;
+        if (rounds > FLEX_JUMP_ROUNDS) return FLEX_EINVAL;
+        if (dn->slack_lane != 0) return FLEX_EINVAL;   // preorder from the slack puts it in lane 0
+    }
     for (int a = 0; a < n_agents; ++a) {
         const int b = nf->agent_bus[a];
         if (b < 0 || b >= n || b == nf->slack) return FLEX_EINVAL;
@@ -569,7 +587,7 @@ int flexenv_create(const FlexCfg* cfg, const NetFix* net, const SeriesTab* serie
     if (!cfg || !net || !series || !out || n_envs < 1) return FLEX_EINVAL;
     if (cfg->n_agents < 1 || cfg->n_agents > FLEX_MAX_AGENTS || cfg->history < 1 || cfg->episode_limit < 1)
         return FLEX_EINVAL;
-    if (cfg->solver != FLEX_SOLVER_TREE) return FLEX_EINVAL;
+    if (cfg->solver != FLEX_SOLVER_TREE && cfg->solver != FLEX_SOLVER_SWEEP) return FLEX_EINVAL;
     if (series->cols != 2 * net->n_bus + cfg->n_agents + 1 || series->rows < 2 || !series->table) return FLEX_EINVAL;
     if (cfg->per_hour < 1 || cfg->n_start_days < 1) return FLEX_EINVAL;
     // every reachable row must exist: start + 1 + (episode_limit + history)
@@ -718,6 +736,7 @@ int flexenv_peek(FlexEnv* e, int32_t field, void* dev_out, void* stream) {
         case FLEX_PEEK_START: col = IF_START; break;
         case FLEX_PEEK_PF_ITERS: col = IF_ITERS; break;
         case FLEX_PEEK_EPISODE: col = IF_EPISODE; break;
+        case FLEX_PEEK_PF_SWEEPS: col = IF_SWEEPS; break;
         default: return FLEX_EINVAL;
     }
     hipLaunchKernelGGL(flex_gather_i32, dim3((e->n_envs + 255) / 256), dim3(256), 0, s, e->st.ienv + col, (int64_t)IF_COUNT, e->n_envs, (int32_t*)dev_out);
@@ -738,7 +757,7 @@ int flexenv_poke(FlexEnv* e, int32_t field, const void* dev_in, void* stream) {
 int pf_solve_batch(const NetFix* net, int32_t n, const double* pnet, const double* qnet, double* v, double* isqr,
                    double* pl, double* ql, int32_t* iters, uint8_t* failed, double tol, int32_t max_iter,
                    int32_t solver, void* stream) {
-    if (!net || n < 1 || !pnet || !qnet || !v || solver != FLEX_SOLVER_TREE) return FLEX_EINVAL;
+    if (!net || n < 1 || !pnet || !qnet || !v || (solver != FLEX_SOLVER_TREE && solver != FLEX_SOLVER_SWEEP)) return FLEX_EINVAL;
     DevNet h;
     int32_t dummy_agent = -1;
     // agents are irrelevant for a bare solve: give build_devnet one placeholder building off the slack
@@ -753,7 +772,7 @@ int pf_solve_batch(const NetFix* net, int32_t n, const double* pnet, const doubl
     HIP_TRY(hipMemcpyAsync(d, &h, sizeof(DevNet), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));   // h is a stack object
     hipLaunchKernelGGL(pf_batch_kernel, env_grid(n), env_block(), 0, s, d, n, net->n_bus, pnet, qnet, v, isqr, pl, ql,
-                       iters, failed, tol, max_iter);
+                       iters, failed, tol, max_iter, solver);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipFreeAsync(d, s));
     return FLEX_OK;

@@ -59,7 +59,7 @@ class VecFlexProvisionEnv:
     """
 
     def __init__(self, env_args=None, n_envs=1, device="cuda:0", net=None, series=None, pf_tol=1e-12,
-                 pf_max_iter=20, warm_start=False, solver=_lib.FLEX_SOLVER_TREE, seed=None):
+                 pf_max_iter=20, warm_start=False, solver=_lib.FLEX_SOLVER_SWEEP, seed=None):
         args = dict(DEFAULT_ENV_ARGS)
         args.update(env_args or {})
         self.args_dict = args
@@ -244,7 +244,7 @@ class VecFlexProvisionEnv:
         return self.n_agents
 
 
-def pf_solve_batch(net, pnet, qnet, tol=1e-12, max_iter=20, want_branch=False):
+def pf_solve_batch(net, pnet, qnet, tol=1e-12, max_iter=20, want_branch=False, solver=_lib.FLEX_SOLVER_SWEEP):
     """power_flow_solver_simplified (pf.py:115-192) on a batch of net loads [n, n_bus] (device f64)."""
     lib = _lib.load()
     t = build_tables(net)
@@ -268,7 +268,7 @@ def pf_solve_batch(net, pnet, qnet, tol=1e-12, max_iter=20, want_branch=False):
     if want_branch:
         isqr, pl, ql = (torch.zeros_like(pnet) for _ in range(3))
     _lib.check(lib.pf_solve_batch(C.byref(nf), n, _ptr(pnet), _ptr(qnet), _ptr(v), _ptr(isqr), _ptr(pl), _ptr(ql),
-                                  _ptr(iters), _ptr(failed), tol, max_iter, _lib.FLEX_SOLVER_TREE, _stream()),
+                                  _ptr(iters), _ptr(failed), tol, max_iter, solver, _stream()),
                "pf_solve_batch")
     out = dict(v=v, iters=iters, failed=failed)
     if want_branch:

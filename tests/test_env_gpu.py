@@ -34,15 +34,16 @@ def _compare_state(vec, oracles, tag):
         assert np.abs(ei[i] - np.array(o.initial_ess_energy)).max() < TOL, tag
 
 
+@pytest.mark.parametrize("solver,warm", [(0, False), (2, False), (2, True)])
 @pytest.mark.parametrize("action_range", [(0.5, 1.0), (0.0, 1.0)])
-def test_full_episode_matches_oracle(net, series_small, action_range):
+def test_full_episode_matches_oracle(net, series_small, action_range, solver, warm):
     """95 steps x 48 envs: reward, info, done, V, E, obs, state at every step.  (0.5,1.0) is the range the
     reference actually delivers; (0,1) exercises the ESS clipping branches."""
     import torch
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
     n, na = 48, 5
     rng = np.random.default_rng(3)
-    vec = VecFlexProvisionEnv({}, n, series=series_small, net=net)
+    vec = VecFlexProvisionEnv({}, n, series=series_small, net=net, solver=solver, warm_start=warm)
     oracles = _oracle_envs(net, series_small, n)
     spec = _spec(rng, n, series_small, na)
     obs = vec.reset(spec=spec).cpu().numpy()

@@ -7,6 +7,9 @@ pytestmark = pytest.mark.gpu
 TOL_V = 1e-10
 
 
+SOLVERS = [0, 2]   # FLEX_SOLVER_TREE (Newton + tree elimination), FLEX_SOLVER_SWEEP (sweeps, Newton-verified)
+
+
 def _solve(net, p, q, **kw):
     import torch
     from safe_marl_amd.flex_env import pf_solve_batch
@@ -28,7 +31,8 @@ def test_base_case_literature_band(net, base_loads):
     assert abs(loss_kw - 202.677) < 0.05
 
 
-def test_random_injections_match_oracle(net, base_loads):
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_random_injections_match_oracle(net, base_loads, solver):
     from oracle import pf_oracle
     p, q = base_loads
     rng = np.random.default_rng(7)
@@ -37,8 +41,10 @@ def test_random_injections_match_oracle(net, base_loads):
     Q = q[None] * rng.uniform(-0.5, 1.6, (n, len(p)))
     # reverse flows: PV-heavy cases
     P[::5] -= rng.uniform(0, 0.3, (len(P[::5]), len(p))) * (np.arange(len(p)) > 0)
-    out = _solve(net, P, Q, want_branch=True)
+    out = _solve(net, P, Q, want_branch=True, solver=solver)
     assert out["failed"].sum() == 0
+    if solver == 2:   # sweeps did the work; Newton only verified (iters = newton + 1000*sweeps)
+        assert (out["iters"] % 1000 <= 1).all() and (out["iters"] // 1000 >= 3).all()
     worst = 0.0
     for i in range(0, n, 4):
         sol = pf_oracle.solve_pf(net, P[i], Q[i])
@@ -76,11 +82,23 @@ def test_distflow_residuals_of_gpu_solution(net, base_loads):
         assert res < 1e-11
 
 
-def test_voltage_collapse_reports_failed(net, base_loads):
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_voltage_collapse_reports_failed(net, base_loads, solver):
     """No power-flow solution exists at 20x load: failure is data, not an exception (env:314-337)."""
     p, q = base_loads
-    out = _solve(net, np.stack([p, 20 * p]), np.stack([q, 20 * q]))
+    out = _solve(net, np.stack([p, 20 * p]), np.stack([q, 20 * q]), solver=solver)
     assert list(out["failed"]) == [0, 1]
+
+
+def test_heavy_load_near_collapse_both_solvers_agree(net, base_loads):
+    """3.2x load (min |V| ~ 0.6 pu): sweeps converge slowly or stall, the Newton fallback must finish."""
+    from oracle import pf_oracle
+    p, q = base_loads
+    ref = pf_oracle.nr_polar(net, 3.2 * p, 3.2 * q, max_iter=30)[0]
+    for solver in SOLVERS:
+        out = _solve(net, 3.2 * p[None], 3.2 * q[None], solver=solver)
+        assert not out["failed"][0]
+        assert np.abs(out["v"][0] - ref).max() < 1e-9
 
 
 def test_other_topology_star_and_chain():
@@ -95,6 +113,7 @@ def test_other_topology_star_and_chain():
     buses = net9["bus_numbers"]
     p = np.array([net9["active_power_demand"][b] for b in buses])
     q = np.array([net9["reactive_power_demand"][b] for b in buses])
-    out = _solve(net9, p[None], q[None])
     sol = pf_oracle.solve_pf(net9, p, q)
-    assert np.abs(out["v"][0] - sol["vm"]).max() < TOL_V
+    for solver in SOLVERS:
+        out = _solve(net9, p[None], q[None], solver=solver)
+        assert np.abs(out["v"][0] - sol["vm"]).max() < TOL_V
