@@ -38,7 +38,22 @@ struct FlexEnv {
     DevState st;
 };
 
+// Diagnostic build only (-DFLEX_STAMPS): per-phase s_memtime stamps, lane 0 of each wave, written to a
+// buffer nothing else reads (cdna_hip_programming.md §7 "In-kernel stamps").  Never timed, never shipped.
+#ifdef FLEX_STAMPS
+#define FLEX_STAMP(slot) do { unsigned long long _t; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    if (a.stamps && lane == 0) a.stamps[(int64_t)env * 8 + (slot)] = _t; } while (0)
+#define FLEX_STAMP_RT(slot) do { unsigned long long _t; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    if (a.stamps && lane == 0) a.stamps[(int64_t)env * 8 + (slot)] = _t; } while (0)
+#else
+#define FLEX_STAMP(slot) do { } while (0)
+#define FLEX_STAMP_RT(slot) do { } while (0)
+#endif
+
 struct KArgs {
+    unsigned long long* stamps;
     FlexCfg cfg;
     const DevNet* net;
     DevState st;
@@ -101,17 +116,84 @@ __device__ __forceinline__ void push_and_emit_obs(const KArgs& a, int env, int l
     if (lane == 0) ie[IF_OBSCNT] = k + 1;
 }
 
+// Fast path of the same get_obs(): the history part of the stacked observation does not depend on
+// this step's solve, so its ring reads are issued BEFORE the solve (as float2 units held in
+// registers) and only the stores remain on the wave's critical path afterwards.
+#define FLEX_OBS_UNITS 9     // float2 units per lane: 64*9 = 576 >= 8 agents * 24 history * 3
+struct ObsIter {             // walks units u = lane + 64*j without a division per unit
+    int ag, rem, q64, r64, H3;
+    __device__ __forceinline__ ObsIter(int lane, int H) {
+        H3 = H * 3; ag = lane / H3; rem = lane - ag * H3; q64 = 64 / H3; r64 = 64 - q64 * H3;
+    }
+    __device__ __forceinline__ void next() { ag += q64; rem += r64; if (rem >= H3) { rem -= H3; ++ag; } }
+};
+
+__device__ __forceinline__ void obs_prefetch(const KArgs& a, int env, int lane, int k, float2 (&buf)[FLEX_OBS_UNITS]) {
+    const int H = a.cfg.history, na = a.cfg.n_agents, total = na * H * 3;
+    const int s1 = (k % H) + 1;                       // slot of history entry h is (s1 + h) mod H
+    const float* ring = a.st.ring + (int64_t)env * na * H * 6;
+    ObsIter it(lane, H);
+#pragma unroll
+    for (int j = 0; j < FLEX_OBS_UNITS; ++j) {
+        const int u = lane + 64 * j, h = it.rem / 3, c = it.rem - 3 * h;
+        float2 v = make_float2(0.0f, 0.0f);
+        if (u < total && h < H - 1 && k - (H - 1) + h >= 0) {
+            int slot = s1 + h; if (slot >= H) slot -= H;
+            v = *reinterpret_cast<const float2*>(ring + (it.ag * H + slot) * 6 + 2 * c);
+        }
+        buf[j] = v;
+        it.next();
+    }
+}
+
+template <typename OutT>
+__device__ __forceinline__ void obs_store(const KArgs& a, int env, int lane, const LaneNet& ln, int k,
+                                          const float2 (&buf)[FLEX_OBS_UNITS], double pd, double qd, double ppv,
+                                          double v, double price, double e, OutT* __restrict__ out) {
+    const int H = a.cfg.history, na = a.cfg.n_agents, total = na * H * 3;
+    int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
+    float* ring = a.st.ring + (int64_t)env * na * H * 6;
+    OutT* o = out + (int64_t)env * na * H * 6;
+    ObsIter it(lane, H);
+#pragma unroll
+    for (int j = 0; j < FLEX_OBS_UNITS; ++j) {
+        const int u = lane + 64 * j, h = it.rem / 3;
+        if (u < total && h < H - 1) {
+            if constexpr (sizeof(OutT) == 4) {
+                *reinterpret_cast<float2*>(o + 2 * u) = buf[j];
+            } else {
+                *reinterpret_cast<double2*>(o + 2 * u) = make_double2((double)buf[j].x, (double)buf[j].y);
+            }
+        }
+        it.next();
+    }
+    if (ln.agent >= 0) {
+        const double feat[6] = {pd, qd, ppv, v, price, e};   // env:377-382
+        float* r = ring + (ln.agent * H + (k % H)) * 6;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            r[t] = (float)feat[t];
+            o[(ln.agent * H + (H - 1)) * 6 + t] = (OutT)feat[t];
+        }
+    }
+    if (lane == 0) ie[IF_OBSCNT] = k + 1;
+}
+
 // -------------------------------------------------------------------------------------------------
 // step(): env:241-356 for one environment per wavefront, get_obs() optionally fused (model.py:220-223)
 // -------------------------------------------------------------------------------------------------
+// 4096 envs = 16 wavefronts per CU = 4 per SIMD: the whole batch must be co-resident (<= 128 VGPRs),
+// otherwise the last blocks start only when the first ones retire and the launch takes twice as long.
 template <typename ObsT>
-__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, 4)
 void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, double* __restrict__ reward,
                       uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
                       ObsT* __restrict__ obs, int want_obs) {
     const int lane = threadIdx.x & 63;
     const int env = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (env >= a.n_envs) return;
+    FLEX_STAMP_RT(5);
+    FLEX_STAMP(0);
     const FlexCfg& c = a.cfg;
     LaneNet ln;
     load_lane_net(a.net, lane, ln);
@@ -133,6 +215,19 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
     const double e_cur = is_bld ? agst[AF_E * FLEX_MAX_AGENTS + ag] : 0.0;
     const double e_init = is_bld ? agst[AF_EINIT * FLEX_MAX_AGENTS + ag] : 0.0;
 
+    // everything the get_obs() epilogue needs that does not depend on the solve is requested now:
+    // the row env:340 will load (start + steps, A2) and the history part of the stacked observation
+    const int64_t new_row = clamp_row((int64_t)start + steps, a.rows);
+    const double* nr = a.series + new_row * a.cols;
+    double n_pd = 0.0, n_qd = 0.0, n_ppv = 0.0, n_price = 0.0;
+    float2 hist[FLEX_OBS_UNITS];
+    const bool obs_fast = want_obs && (na * c.history * 3 <= 64 * FLEX_OBS_UNITS);
+    if (want_obs) {
+        n_pd = is_bus ? nr[ln.bus] : 0.0; n_qd = is_bus ? nr[nb + ln.bus] : 0.0;
+        n_ppv = is_bld ? nr[2 * nb + ag] : 0.0; n_price = nr[2 * nb + na];
+    }
+    if (obs_fast) obs_prefetch(a, env, lane, obs_cnt, hist);
+
     // actions -> physical set-points (env:260-293)
     FlexAct act = {0, 0, 0, 0, 0};
     if (is_bld) {
@@ -149,7 +244,16 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
     double e = 1.0, f = 0.0;
     if (c.warm_start) { e = a.st.ve[(int64_t)env * 64 + lane]; f = a.st.vf[(int64_t)env * 64 + lane]; }
     int iters = 0, sweeps = 0;
+#ifdef FLEX_STAMPS
+    asm volatile("" :: "v"(pnet), "v"(qnet), "v"(e), "v"(f));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    FLEX_STAMP(1);
     const bool ok = pf_solve(a.net, ln, c.solver, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters, sweeps);
+#ifdef FLEX_STAMPS
+    asm volatile("" :: "v"(e), "v"(f));
+#endif
+    FLEX_STAMP(2);
 
     double v, pred, ch, dis, q, e_new;
     if (ok) {
@@ -185,7 +289,6 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
     if (!ok) rwd -= c.fail_penalty;                                                    // env:336
     const int new_steps = steps + 1;                                                   // env:342
     const bool term = (new_steps >= c.episode_limit) || !ok;                           // env:345
-    const int64_t new_row = clamp_row((int64_t)start + steps, a.rows);                  // env:340 reads row `steps` (A2)
     if (lane == 0) {
         reward[env] = rwd;
         done[env] = term ? 1 : 0;
@@ -201,11 +304,19 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
         ie[IF_ITERS] = iters;
         ie[IF_SWEEPS] = sweeps;
     }
+#ifdef FLEX_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    FLEX_STAMP(3);
     if (want_obs) {
-        const double* nr = a.series + new_row * a.cols;
-        push_and_emit_obs<ObsT>(a, env, lane, ln, obs_cnt, is_bus ? nr[ln.bus] : 0.0, is_bus ? nr[nb + ln.bus] : 0.0,
-                                is_bld ? nr[2 * nb + ag] : 0.0, v, nr[2 * nb + na], e_new, obs);
+        if (obs_fast) obs_store<ObsT>(a, env, lane, ln, obs_cnt, hist, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
+        else push_and_emit_obs<ObsT>(a, env, lane, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
     }
+#ifdef FLEX_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    FLEX_STAMP(4);
+    FLEX_STAMP_RT(6);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -552,6 +663,17 @@ static int build_devnet(const NetFix* nf, int n_agents, DevNet* dn) {
         }
         for (int k = 1; k < FLEX_JUMP_ROUNDS; ++k)
             for (int l = 0; l < FLEX_MAX_BUS; ++l) dn->anc[k][l] = dn->anc[k - 1][dn->anc[k - 1][l]];
+        // chain segments
+        int max_depth = 0;
+        for (int l = 0; l < FLEX_MAX_BUS; ++l) {
+            const bool cont = (l > 0) && (l < n) && (dn->par_lane[l] == l - 1);
+            dn->seg_start[l] = cont ? dn->seg_start[l - 1] : l;
+            if (cont) { dn->seg_par[l] = dn->seg_par[l - 1]; dn->seg_depth[l] = dn->seg_depth[l - 1]; }
+            else if (l == 0 || l >= n) { dn->seg_par[l] = l; dn->seg_depth[l] = 0; }
+            else { dn->seg_par[l] = dn->par_lane[l]; dn->seg_depth[l] = dn->seg_depth[dn->par_lane[l]] + 1; }
+            if (dn->seg_depth[l] > max_depth) max_depth = dn->seg_depth[l];
+        }
+        dn->n_seg_rounds = max_depth;
         int rounds = 0;
         while ((1 << rounds) < nf->n_levels - 1) ++rounds;
         dn->n_jump_rounds = rounds;
@@ -568,8 +690,12 @@ static int build_devnet(const NetFix* nf, int n_agents, DevNet* dn) {
     return FLEX_OK;
 }
 
+static unsigned long long* g_stamps = nullptr;
+extern "C" void flexenv_debug_set_stamps(unsigned long long* dev) { g_stamps = dev; }
+
 static KArgs make_args(const FlexEnv* e) {
     KArgs k;
+    k.stamps = g_stamps;
     k.cfg = e->cfg; k.net = e->net; k.st = e->st; k.series = e->series.table;
     k.rows = e->series.rows; k.cols = e->series.cols; k.n_envs = e->n_envs; k.n_bus = e->n_bus;
     return k;
