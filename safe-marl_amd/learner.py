@@ -1,0 +1,421 @@
+"""MADDPG / SAFEMADDPG on device-resident batches, with the reference's class and method names
+(madrl/models/model.py, maddpg.py, safemaddpg.py) so that ``PGTrainer(args, MADDPG, env, logger)``
+and reference state_dicts keep working.
+
+What is different from the reference, by design:
+  * every method takes batches of any size (thousands of envs), never assumes batch 1;
+  * a replay batch is already a tuple of device tensors (replay_buffer.DeviceReplayBuffer): there is no
+    numpy -> tensor -> device ``unpack_data`` round trip per sub-update (model.py:308-323);
+  * the centralised critic does not materialise its [B*n, n*(o+a)+n] input (maddpg.py:33-76); it forms
+    fc1's output from the column blocks of fc1.weight — the observation block once per sample instead
+    of n times — which is the same affine map up to fp32 summation order;
+  * the rollout steps N environments per iteration without a host sync (``train_process`` on a
+    VecFlexProvisionEnv) and the soft target update is one fused ``torch._foreach`` call.
+The N=1 path through ``FlexibilityProvisionEnv`` reproduces the reference's cadence exactly.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch as th
+import torch.nn as nn
+
+from .nets import MLPAgent, MLPCritic, RNNAgent
+from .replay_buffer import Transition
+from .util import prep_obs, scale_action, select_action, translate_action
+
+
+class Model(nn.Module):
+    """model.py:10-323, the parts the MADDPG path uses."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.device = th.device("cuda" if th.cuda.is_available() and self.args.cuda else "cpu")
+        self.n_ = self.args.agent_num
+        self.hid_dim = self.args.hid_size
+        self.obs_dim = self.args.obs_size
+        self.act_dim = self.args.action_dim
+        self.Transition = Transition
+        self.batchnorm = nn.BatchNorm1d(self.n_)
+
+    # -- construction ------------------------------------------------------------------------------
+    def construct_policy_net(self):
+        """model.py:145-169"""
+        input_shape = self.obs_dim + self.n_ if self.args.agent_id else self.obs_dim
+        if self.args.gaussian_policy:
+            raise NotImplementedError("gaussian policies are outside the MADDPG hot path")
+        Agent = {"mlp": MLPAgent, "rnn": RNNAgent}[self.args.agent_type]
+        count = 1 if self.args.shared_params else self.n_
+        self.policy_dicts = nn.ModuleList([Agent(input_shape, self.args) for _ in range(count)])
+
+    def init_weights(self, m):
+        """model.py:174-182"""
+        if type(m) == nn.Linear:
+            if self.args.init_type == "normal":
+                nn.init.normal_(m.weight, 0.0, self.args.init_std)
+            elif self.args.init_type == "orthogonal":
+                nn.init.orthogonal_(m.weight, gain=nn.init.calculate_gain(self.args.hid_activation))
+
+    def reload_params_to_target(self):
+        """model.py:22-26"""
+        self.target_net.policy_dicts.load_state_dict(self.policy_dicts.state_dict())
+        self.target_net.value_dicts.load_state_dict(self.value_dicts.state_dict())
+
+    def update_target(self):
+        """model.py:28-38: theta' <- (1 - target_lr) theta' + target_lr theta over every state_dict entry
+        of the policy and value nets (floating entries; the nets hold no buffers)."""
+        with th.no_grad():
+            tgt = list(self.target_net.policy_dicts.state_dict().values()) + \
+                list(self.target_net.value_dicts.state_dict().values())
+            src = list(self.policy_dicts.state_dict().values()) + list(self.value_dicts.state_dict().values())
+            th._foreach_mul_(tgt, 1 - self.args.target_lr)
+            th._foreach_add_(tgt, src, alpha=self.args.target_lr)
+
+    # -- policy ----------------------------------------------------------------------------------------
+    def policy(self, obs, schedule=None, last_act=None, last_hid=None, info={}, stat={}):
+        """model.py:102-140. obs [b, n, o] -> means [b, n, a], log_stds, hiddens [b, n, hid]."""
+        b = obs.size(0)
+        if self.args.agent_id:
+            ids = th.eye(self.n_, device=obs.device, dtype=obs.dtype).expand(b, -1, -1)
+            obs = th.cat((obs, ids), dim=-1)
+        if self.args.shared_params:
+            means, _, hiddens = self.policy_dicts[0](obs.reshape(b * self.n_, -1), last_hid)
+            means = means.view(b, self.n_, -1)
+            hiddens = hiddens.view(b, self.n_, -1)
+        else:
+            outs = [pol(obs[:, i, :], last_hid[:, i, :]) for i, pol in enumerate(self.policy_dicts)]
+            means = th.stack([o[0] for o in outs], dim=1)
+            hiddens = th.stack([o[2] for o in outs], dim=1)
+        # fixed_policy_std (model.py:121-123): log(1.0) = 0 at the default config
+        log_stds = th.full_like(means, float(np.log(self.args.fixed_policy_std)))
+        return means, log_stds, hiddens
+
+    # -- update cadence (model.py:40-71) -----------------------------------------------------------
+    def transition_update(self, trainer, trans, stat):
+        if self.args.replay:
+            if trans is not None:
+                trainer.replay_buffer.add_experience(trans)
+            replay_cond = trainer.steps > self.args.replay_warmup \
+                and len(trainer.replay_buffer.buffer) >= trainer.effective_batch_size() \
+                and trainer.steps % self.args.behaviour_update_freq == 0
+            if replay_cond:
+                for _ in range(self.args.value_update_epochs):
+                    trainer.value_replay_process(stat)
+                for _ in range(self.args.policy_update_epochs):
+                    trainer.policy_replay_process(stat)
+        else:
+            raise NotImplementedError("the MADDPG path always replays (default.yaml:22)")
+        if self.args.target and trainer.steps % self.args.target_update_freq == 0:
+            self.update_target()
+
+    # -- batches -----------------------------------------------------------------------------------------
+    def unpack_data(self, batch):
+        """model.py:308-323.  ``batch`` is a Transition of device tensors (replay_buffer.window) or, for
+        callers written against the reference, a Transition of per-sample tuples (trainer.py:68)."""
+        if not isinstance(batch.reward, th.Tensor):
+            batch = Transition(*[th.stack([th.as_tensor(np.asarray(x), dtype=th.float32) for x in f]).to(self.device)
+                                 for f in batch])
+            # model.py:312-320 concatenates the [1, n, x] per-step arrays along axis 0
+            batch = Transition(*[f.squeeze(1) if f.dim() == 4 else f for f in batch])
+        reward = batch.reward.float()
+        if self.args.reward_normalisation:
+            reward = self.batchnorm(reward)                               # train-mode batch statistics
+        done = batch.done.float().view(-1, 1)
+        last_step = batch.last_step.float().view(-1, 1)
+        # model.py:313 fills log_prob_a from batch.action; nothing downstream reads it
+        return (batch.state, batch.action, batch.action, batch.value, batch.next_value, reward, batch.next_state,
+                done, last_step, batch.action_avail, batch.last_hid, batch.hid)
+
+    # -- rollouts ------------------------------------------------------------------------------------------
+    def train_process(self, stat, trainer):
+        if hasattr(trainer.env, "handle"):          # VecFlexProvisionEnv: batched, sync-free rollout
+            return self._train_process_vec(stat, trainer)
+        return self._train_process_single(stat, trainer)
+
+    def _train_process_single(self, stat, trainer):
+        """model.py:198-267 on a reference-style env (lists of numpy observations, one env)."""
+        env = trainer.env
+        stat_train = {"mean_train_reward": 0}
+        state, _ = env.reset()
+        last_hid = self.policy_dicts[0].init_hidden()
+        avail = th.tensor(env.get_avail_actions())
+        t = 0
+        for t in range(self.args.max_steps):
+            state_ = prep_obs(state).to(self.device).contiguous().view(1, self.n_, self.obs_dim)
+            action, action_pol, log_prob_a, _, hid = self.get_actions(state_, status="train", exploration=True,
+                                                                      actions_avail=avail, target=False, last_hid=last_hid)
+            value = self.value(state_, action_pol)
+            _, actual = translate_action(self.args, action, env)
+            reward, done, info = env.step(actual)
+            next_state = env.get_obs()
+            next_state_ = prep_obs(next_state).to(self.device).contiguous().view(1, self.n_, self.obs_dim)
+            _, next_action_pol, _, _, _ = self.get_actions(next_state_, status="train", exploration=True,
+                                                           actions_avail=avail, target=False, last_hid=hid)
+            next_value = self.value(next_state_, next_action_pol)
+            done_ = done or t == self.args.max_steps - 1
+            trans = Transition(state, action_pol.detach().cpu().numpy(), log_prob_a.detach().cpu().numpy(),
+                               value.detach().cpu().numpy(), next_value.detach().cpu().numpy(),
+                               np.array([reward] * env.get_num_of_agents()), next_state, done, done_,
+                               env.get_avail_actions(), last_hid.detach().cpu().numpy(), hid.detach().cpu().numpy())
+            self.transition_update(trainer, trans, stat)
+            for k, v in info.items():
+                stat_train["mean_train_" + k] = stat_train.get("mean_train_" + k, 0) + v
+            stat_train["mean_train_reward"] += reward
+            trainer.steps += 1
+            if done_:
+                break
+            state, last_hid = next_state, hid
+        trainer.episodes += 1
+        for k, v in stat_train.items():
+            if k.split("_")[0] == "mean":
+                stat_train[k] = v / float(t + 1)
+        stat.update(stat_train)
+
+    def _train_process_vec(self, stat, trainer):
+        """The same rollout over N environments at once.  One "episode" is ``episode_limit - 1`` vector
+        steps (what one reference episode executes); environments that terminate early
+        (solver failure) are auto-reset by mask.  Nothing in the loop reads a device value on the host;
+        statistics are accumulated on the device and fetched once at the end."""
+        env = trainer.env
+        args = self.args
+        N = env.n_envs
+        horizon = min(args.max_steps, env.episode_limit - 1)
+        obs = env.reset().clone()
+        last_hid = th.zeros(N, self.n_, self.hid_dim, device=self.device)
+        avail = th.ones(N, self.n_, self.act_dim, device=self.device)
+        zeros_v = th.zeros(N, self.n_, 1, device=self.device)
+        info_sum = th.zeros(env.info.shape[1], dtype=th.float64, device=self.device)
+        rew_sum = th.zeros((), dtype=th.float64, device=self.device)
+        fail_sum = th.zeros((), dtype=th.float64, device=self.device)
+        for t in range(horizon):
+            with th.no_grad():
+                action, action_pol, log_prob_a, _, hid = self.get_actions(obs, status="train", exploration=True,
+                                                                          actions_avail=avail, target=False,
+                                                                          last_hid=last_hid)
+                actual = self.env_action(action)
+            reward, done, info = env.step(actual, fuse_obs=True)
+            next_obs = env.obs
+            donef = done.float()
+            last_step = donef if t < horizon - 1 else th.ones_like(donef)       # model.py:229
+            trainer.replay_buffer.add_batch(
+                state=obs, action=action_pol, log_prob_a=log_prob_a, value=zeros_v, next_value=zeros_v,
+                reward=reward.float().unsqueeze(1).expand(N, self.n_), next_state=next_obs, done=donef,
+                last_step=last_step, action_avail=avail, last_hid=last_hid, hid=hid)
+            self.transition_update(trainer, None, stat)
+            info_sum += info.sum(0)
+            rew_sum += reward.sum()
+            fail_sum += env.failed.sum()
+            trainer.steps += 1
+            # next iteration: terminated envs restart from a fresh episode with a zero hidden state
+            obs = next_obs.clone()
+            env.reset(mask=done, obs_out=obs)
+            last_hid = hid * (1.0 - donef).view(N, 1, 1)
+        trainer.episodes += 1
+        denom = float(N * horizon)
+        vals = th.cat([info_sum, rew_sum.view(1), fail_sum.view(1)]).cpu().numpy() / denom
+        from ._lib import INFO_KEYS
+        for i, k in enumerate(INFO_KEYS):
+            stat["mean_train_" + k] = float(vals[i])
+        stat["mean_train_reward"] = float(vals[-2])
+        stat["mean_train_solver_failed"] = float(vals[-1])
+
+    def env_action(self, action):
+        """translate_action (util.py:121-130) kept on the device: [N, n, a] in the env's range."""
+        return scale_action(self.args, action.detach()).view(-1, self.n_, self.act_dim)
+
+    def evaluation(self, stat, trainer):
+        """model.py:269-306 (test-mode rollouts; next-row f1 of SURVEY §8f)."""
+        env = trainer.env
+        if hasattr(env, "handle"):
+            return self._evaluation_vec(stat, trainer)
+        stat_test = {}
+        for _ in range(self.args.num_eval_episodes):
+            epi = {"mean_test_reward": 0}
+            state, _ = env.reset()
+            last_hid = self.policy_dicts[0].init_hidden()
+            avail = th.tensor(env.get_avail_actions())
+            t = 0
+            for t in range(self.args.max_steps):
+                state_ = prep_obs(state).to(self.device).contiguous().view(1, self.n_, self.obs_dim)
+                with th.no_grad():
+                    action, _, _, _, hid = self.get_actions(state_, status="test", exploration=False,
+                                                            actions_avail=avail, target=False, last_hid=last_hid)
+                _, actual = translate_action(self.args, action, env)
+                reward, done, info = env.step(actual)
+                done_ = done or t == self.args.max_steps - 1
+                next_state = env.get_obs()
+                for k, v in info.items():
+                    epi["mean_test_" + k] = epi.get("mean_test_" + k, 0) + v
+                epi["mean_test_reward"] += reward
+                if done_:
+                    break
+                state, last_hid = next_state, hid
+            for k, v in epi.items():
+                stat_test[k] = stat_test.get(k, 0) + v / float(t + 1)
+        for k, v in stat_test.items():
+            stat[k] = v / float(self.args.num_eval_episodes)
+
+    def _evaluation_vec(self, stat, trainer):
+        env = trainer.env
+        N = env.n_envs
+        horizon = min(self.args.max_steps, env.episode_limit - 1)
+        obs = env.reset().clone()
+        last_hid = th.zeros(N, self.n_, self.hid_dim, device=self.device)
+        avail = th.ones(N, self.n_, self.act_dim, device=self.device)
+        info_sum = th.zeros(env.info.shape[1], dtype=th.float64, device=self.device)
+        rew_sum = th.zeros((), dtype=th.float64, device=self.device)
+        for t in range(horizon):
+            with th.no_grad():
+                action, _, _, _, hid = self.get_actions(obs, status="test", exploration=False, actions_avail=avail,
+                                                        target=False, last_hid=last_hid)
+                actual = self.env_action(action)
+            reward, done, info = env.step(actual, fuse_obs=True)
+            info_sum += info.sum(0)
+            rew_sum += reward.sum()
+            donef = done.float()
+            obs = env.obs.clone()
+            env.reset(mask=done, obs_out=obs)
+            last_hid = hid * (1.0 - donef).view(N, 1, 1)
+        vals = th.cat([info_sum, rew_sum.view(1)]).cpu().numpy() / float(N * horizon)
+        from ._lib import INFO_KEYS
+        for i, k in enumerate(INFO_KEYS):
+            stat["mean_test_" + k] = float(vals[i])
+        stat["mean_test_reward"] = float(vals[-1])
+
+
+class MADDPG(Model):
+    """maddpg.py:7-123."""
+
+    def __init__(self, args, target_net=None):
+        super().__init__(args)
+        self.construct_model()
+        self.apply(self.init_weights)
+        if target_net is not None:
+            self.target_net = target_net
+            self.reload_params_to_target()
+        self.batchnorm = nn.BatchNorm1d(self.args.agent_num).to(self.device)      # maddpg.py:16
+
+    def construct_value_net(self):
+        """maddpg.py:18-27: input (obs+act)*n + n."""
+        input_shape = (self.obs_dim + self.act_dim) * self.n_ + (self.n_ if self.args.agent_id else 0)
+        count = 1 if self.args.shared_params else self.n_
+        self.value_dicts = nn.ModuleList([MLPCritic(input_shape, 1, self.args) for _ in range(count)])
+
+    def construct_model(self):
+        self.construct_value_net()
+        self.construct_policy_net()
+
+    def value(self, obs, act):
+        """maddpg.py:33-76.  Row i of the reference's critic input is
+        [obs_0..obs_{n-1} | onehot(i) | act_0..act_{n-1}] with act_j detached for j != i.  fc1 of that row is
+        W_obs @ obs_all + W_id[:, i] + W_act @ act_all(detached) + W_act[:, block i] @ (act_i - act_i.detach()) + b:
+        the first and third terms are shared by the n rows of a sample, the last one is zero-valued and only
+        carries agent i's own-action gradient.  Returns [b, n, 1]."""
+        b, n, o, a = obs.size(0), self.n_, self.obs_dim, self.act_dim
+        act_det = act.detach()
+        own = act - act_det                                               # zeros that carry d/d act_i
+        values = []
+        nets = self.value_dicts if not self.args.shared_params else [self.value_dicts[0]] * 1
+        if self.args.shared_params:
+            net = self.value_dicts[0]
+            W, bias = net.fc1.weight, net.fc1.bias
+            W_obs = W[:, :n * o]
+            off = n * o
+            if self.args.agent_id:
+                W_id = W[:, off:off + n]                                  # [hid, n]
+                off += n
+            W_act = W[:, off:off + n * a]
+            shared = obs.reshape(b, n * o) @ W_obs.t() + act_det.reshape(b, n * a) @ W_act.t() + bias   # [b, hid]
+            h = shared.unsqueeze(1).expand(b, n, -1)
+            if self.args.agent_id:
+                h = h + W_id.t().unsqueeze(0)                             # [1, n, hid]
+            h = h + th.einsum("bia,hia->bih", own, W_act.view(-1, n, a))
+            v, _ = net.forward_from_hidden(h.reshape(b * n, -1))
+            return v.view(b, n, 1)
+        for i, net in enumerate(nets):                                    # non-shared critics: plain input rows
+            acts_i = act_det.clone()
+            acts_i[:, i] = act[:, i]
+            ids = th.eye(n, device=obs.device, dtype=obs.dtype)[i].expand(b, -1)
+            parts = [obs.reshape(b, n * o)] + ([ids] if self.args.agent_id else []) + [acts_i.reshape(b, n * a)]
+            v, _ = net(th.cat(parts, dim=-1), None)
+            values.append(v)
+        return th.stack(values, dim=1)
+
+    def get_actions(self, state, status, exploration, actions_avail, target=False, last_hid=None):
+        """maddpg.py:78-98 (continuous branch)."""
+        pol = self.target_net.policy if (target and self.args.target) else self.policy
+        means, log_stds, hiddens = pol(state, last_hid=last_hid)
+        actions, log_prob_a = select_action(self.args, means, status=status, exploration=exploration,
+                                            info={"log_std": log_stds})
+        restore_mask = 1.0 - (actions_avail.to(means.device) == 0).float()
+        restore_actions = restore_mask * actions
+        return actions, restore_actions, log_prob_a, (means, log_stds), hiddens
+
+    def get_loss(self, batch):
+        """maddpg.py:100-123: policy_loss = -Q(s, pi(s)).mean(); value_loss = (r + gamma (1-done) Q'(s', pi(s')) - Q(s,a))^2.mean()."""
+        state, actions, _, _, _, rewards, next_state, done, _, actions_avail, last_hids, hids = self.unpack_data(batch)
+        _, actions_pol, _, action_out, _ = self.get_actions(state, status="train", exploration=False,
+                                                            actions_avail=actions_avail, target=False, last_hid=last_hids)
+        _, next_actions, _, _, _ = self.get_actions(next_state, status="train", exploration=False,
+                                                    actions_avail=actions_avail, target=not self.args.double_q,
+                                                    last_hid=hids)
+        values_pol = self.value(state, actions_pol).view(-1, self.n_)
+        values = self.value(state, actions).view(-1, self.n_)
+        next_values = self.target_net.value(next_state, next_actions.detach()).view(-1, self.n_)
+        assert values_pol.size() == next_values.size()
+        returns = rewards + self.args.gamma * (1 - done) * next_values.detach()
+        assert returns.size() == values.size()
+        deltas = returns - values
+        advantages = values_pol
+        if self.args.normalize_advantages:
+            advantages = self.batchnorm(advantages)
+        policy_loss = (-advantages).mean()
+        value_loss = deltas.pow(2).mean()
+        return policy_loss, value_loss, action_out
+
+
+class SAFEMADDPG(MADDPG):
+    """safemaddpg.py:14-299: MADDPG whose get_actions passes the proposed action through the safety layer.
+
+    The reference solves a Pyomo QP with Gurobi per call (safemaddpg.py:176-299) using a pickled sklearn
+    regressor (safemaddpg.py:27); here the layer is the HIP closed-form projection
+    (``flexenv_safety_project``) and the regressor's row sums come from ``safety_signal.fit_voltage_predictor``
+    (or any (s_p, s_q, beta) triple the caller passes as ``predictor``)."""
+
+    def __init__(self, args, env, target_net=None, predictor=None):
+        super().__init__(args, target_net)
+        self.env = env
+        self.V_min = args.v_min
+        self.V_max = args.v_max
+        self.solver_interventions = 0
+        self.solver_infeasible = 0
+        if predictor is None:
+            from .safety_signal import fit_voltage_predictor
+            vec = env.vec if hasattr(env, "vec") else env
+            predictor = fit_voltage_predictor(vec.net, device=vec.device).building_terms(vec.net)
+        self.predictor = predictor          # (s_p [n], s_q [n], beta [n]) per building
+
+    def safety_layer_optimization(self, proposed_actions):
+        """safemaddpg.py:176-299 on every env of the batch: returns [B, 4n] type-major adjusted actions."""
+        vec = self.env.vec if hasattr(self.env, "vec") else self.env
+        s_p, s_q, beta = self.predictor
+        adjusted, hit = vec.safety_project(proposed_actions.detach().reshape(-1, self.n_, self.act_dim),
+                                           s_p, s_q, beta, self.V_min, self.V_max)
+        self._last_intervened = hit
+        return adjusted
+
+    def get_actions(self, state, status, exploration, actions_avail, target=False, last_hid=None):
+        """safemaddpg.py:90-111.  During a loss evaluation (batch != env batch) the reference solves the QP on
+        batch element 0 against the live env and discards the result (safemaddpg.py:118-121);
+        that call is skipped here — it has no observable effect."""
+        actions, restore_actions, log_prob_a, action_out, hiddens = super().get_actions(
+            state, status, exploration, actions_avail, target, last_hid)
+        vec = self.env.vec if hasattr(self.env, "vec") else self.env
+        if state.size(0) != vec.n_envs:
+            return actions, restore_actions, log_prob_a, action_out, hiddens
+        adjusted = self.safety_layer_optimization(restore_actions).to(th.float32)   # safemaddpg.py:106-109
+        return adjusted, restore_actions, log_prob_a, action_out, hiddens
+
+    def env_action(self, action):
+        # the type-major flat vector is re-read agent-major by env.step (safemaddpg.py:297 vs env:268-274, A13)
+        return scale_action(self.args, action.detach()).reshape(-1, self.n_, self.act_dim)
