@@ -1,0 +1,128 @@
+"""GPU: the reference-shaped surface on top of the HIP path — FlexibilityProvisionEnv as a
+drop-in for train_agent.py's env, PGTrainer/MADDPG on it (N=1, reference cadence) and on the vectorised env."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _args(**over):
+    from safe_marl_amd.util import convert
+    d = json.load(open(os.path.join(G, "learner_args.json")))
+    d.update(cuda=True)
+    d.update(over)
+    return convert(d)
+
+
+def test_flexibility_provision_env_is_a_drop_in(net, series_small):
+    """Same constructor argument, RNG draw order, return types and attribute surface as the reference env; values
+    equal the scalar oracle driven by the same global NumPy seed."""
+    from safe_marl_amd.flex_env import FlexibilityProvisionEnv
+    from oracle.env_oracle import FlexEnvOracle
+    s = series_small
+    # both sides consume the GLOBAL NumPy stream (env:49,85-87,100,103), so run them one after the other
+    env = FlexibilityProvisionEnv({"seed": 7}, net=net, series=s)           # seeds np.random (env:49) and resets (env:69)
+    assert env.get_num_of_agents() == 5 and env.get_obs_size() == 144 and env.get_state_size() == 110
+    assert env.get_total_actions() == 4 and env.get_avail_actions().shape == (1, 5, 4)
+    obs, state = env.reset()                                                 # second reset
+    np.random.seed(7)
+    ora = FlexEnvOracle(net, {}, s.active, s.reactive, s.pv, s.price)
+    ora.reset()
+    o_obs, o_state = ora.reset()
+    assert isinstance(obs, list) and len(obs) == 5 and obs[0].shape == (144,) and state.shape == (110,)
+    assert np.abs(state - o_state).max() < 1e-10
+    assert np.allclose(np.stack(obs).astype(np.float32), np.stack(o_obs).astype(np.float32), rtol=2e-7, atol=0)
+    rng = np.random.default_rng(0)
+    for t in range(95):
+        a = rng.uniform(0.5, 1.0, (5, 4)).astype(np.float32)
+        r, d, info = env.step(a)
+        r2, d2, info2 = ora.step(a.astype(np.float64))
+        assert isinstance(r, float) and isinstance(d, bool) and set(info2) <= set(info)
+        assert abs(r - r2) < 1e-10 and d == d2
+        assert abs(info["cumulative_reward"] - info2["cumulative_reward"]) < 1e-9
+        nxt = env.get_obs()
+        assert np.allclose(np.stack(nxt).astype(np.float32), np.stack(ora.get_obs()).astype(np.float32), rtol=2e-7, atol=0)
+    assert d is True and env.steps == 96
+    # attribute surface safemaddpg.py and tester.py read (env:740-778)
+    assert set(env.current_active_demand) == set(net["bus_numbers"])
+    assert np.abs(env._get_bus_v() - ora.current_voltage).max() < 1e-10
+    assert np.abs(env._get_ess_energy() - np.array(ora.current_ess_energy)).max() < 1e-10
+    assert np.abs(env._get_power_reduction() - np.array(ora.power_reduction)).max() < 1e-10
+    assert env._get_price().shape == (1, 1)
+    obs2, _ = env.manual_reset(3, 5, 2)
+    assert env.vec.peek("START").item() == 2 + 5 * 4 + 3 * 96
+    env.close()
+
+
+def test_maddpg_trains_on_the_drop_in_env(net, series_small):
+    """train_agent.py:107,125-128 flow: PGTrainer(args, MADDPG, env, logger).run(stat, i) with the N=1 view."""
+    import torch as th
+    from safe_marl_amd.flex_env import FlexibilityProvisionEnv
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.trainer import PGTrainer
+    th.manual_seed(0)
+    env = FlexibilityProvisionEnv({"seed": 1}, net=net, series=series_small)
+    args = _args(behaviour_update_freq=30, target_update_freq=60, eval_freq=100, num_eval_episodes=1)
+    trainer = PGTrainer(args, MADDPG, env, None)
+    before = {k: v.clone() for k, v in trainer.behaviour_net.state_dict().items()}
+    stat = {}
+    trainer.run(stat, 1)          # one 95-step episode -> updates at steps 30, 60, 90
+    assert trainer.steps == 95 and trainer.episodes == 1 and len(trainer.replay_buffer.buffer) == 95
+    for k in ("mean_train_reward", "mean_train_revenue", "mean_train_value_loss", "mean_train_policy_loss",
+              "mean_train_policy_grad_norm", "mean_train_value_grad_norm", "mean_train_entropy"):
+        assert np.isfinite(stat[k]), k
+    after = trainer.behaviour_net.state_dict()
+    assert any(not th.equal(before[k], after[k]) for k in before if "policy_dicts" in k)
+    assert any(not th.equal(before[k], after[k]) for k in before if "value_dicts" in k)
+    sd = trainer.behaviour_net.state_dict()
+    assert any(k.startswith("target_net.") for k in sd)      # checkpoint format of train_agent.py:144-147
+
+
+def test_maddpg_trains_on_the_vectorised_env(net, series_small):
+    import torch as th
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.trainer import PGTrainer
+    th.manual_seed(0)
+    n = 256
+    env = VecFlexProvisionEnv({}, n, net=net, series=series_small, seed=3)
+    args = _args(behaviour_update_freq=30, target_update_freq=60)
+    trainer = PGTrainer(args, MADDPG, env, None, batch_scale=8, replay_capacity=n * 128)
+    stat = {}
+    trainer.behaviour_net.train_process(stat, trainer)
+    assert trainer.steps == 95 and len(trainer.replay_buffer.buffer) == 95 * n
+    assert np.isfinite(stat["mean_train_reward"]) and stat["mean_train_solver_failed"] == 0.0
+    assert np.isfinite(float(stat["mean_train_value_loss"])) and np.isfinite(float(stat["mean_train_policy_loss"]))
+    w = trainer.replay_buffer.window(0, n)
+    assert w.state.shape == (n, 5, 144) and w.state.is_cuda
+    # terminal transitions are flagged on the last vector step only (no failures here)
+    last = trainer.replay_buffer.window(94 * n, n)
+    assert last.done.sum().item() == n and trainer.replay_buffer.window(93 * n, n).done.sum().item() == 0
+    trainer.behaviour_net.evaluation(stat, trainer)
+    assert np.isfinite(stat["mean_test_reward"])
+
+
+def test_safemaddpg_actions_pass_through_the_hip_safety_layer(net, series_small):
+    import torch as th
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.learner import SAFEMADDPG
+    from safe_marl_amd.trainer import PGTrainer
+    th.manual_seed(0)
+    n = 64
+    env = VecFlexProvisionEnv({"alg": "safemaddpg"}, n, net=net, series=series_small, seed=9)
+    args = _args(alg="safemaddpg", v_min=0.9, v_max=1.1, behaviour_update_freq=30, target_update_freq=60)
+    trainer = PGTrainer(args, SAFEMADDPG, env, None, batch_scale=4, replay_capacity=n * 128)
+    model = trainer.behaviour_net
+    obs = env.reset().clone()
+    hid = th.zeros(n, 5, 64, device="cuda")
+    avail = th.ones(n, 5, 4, device="cuda")
+    adjusted, proposed, logp, _, _ = model.get_actions(obs, "train", True, avail, last_hid=hid)
+    assert adjusted.shape == (n, 20) and proposed.shape == (n, 5, 4) and adjusted.dtype == th.float32
+    assert (adjusted[:, :15] >= 0).all()                      # pr, ch, dis >= 0 (safemaddpg.py:196-198)
+    stat = {}
+    model.train_process(stat, trainer)
+    assert trainer.steps == 95 and np.isfinite(stat["mean_train_reward"])
