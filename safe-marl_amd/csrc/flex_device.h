@@ -1,12 +1,18 @@
 // Device-side building blocks of the flexibility-provision hot path (gfx950 only).
 //
-// Execution model: ONE 64-lane wavefront per environment, ONE lane per bus.  Lanes are numbered
-// in a depth-first preorder of the radial feeder rooted at the slack bus (host: build_devnet),
-// so for the common "chain" bus its only child sits in lane+1.  Everything an environment needs
-// per step — its series row, its 20 actions, its voltage vector — is read with coalesced
-// one-double-per-lane loads straight into registers; there is no cross-environment reuse, so
-// nothing is staged through LDS (the network tables are 64-entry arrays shared by every wave and
-// live in L2/L1).
+// Execution model: one LANE per PQ bus, one lane GROUP per environment.  The slack bus carries no
+// unknown (V = 1∠0, pf.py:51-53) and gets no lane, so the 33-bus feeder needs 32 lanes and a 64-wide
+// wavefront serves TWO environments (EPW = 2, group width LW = 32); feeders with more than 32 PQ buses
+// run one environment per wavefront (EPW = 1, LW = 64).  Every cross-lane operation stays inside a
+// group: DPP row operations never leave a 16-lane row, the row_bcast:15 step joins the two rows of a
+// 32-lane group (row_bcast:31 is added only for LW = 64), and ds_bpermute sources are group-relative.
+//
+// Lanes are numbered in a depth-first preorder of the radial feeder (children of the slack first), so
+// a subtree is a contiguous lane range and a chain bus has its only child in lane+1.  Everything an
+// environment needs per step — its series row, its 20 actions, its voltage vector — is read with
+// coalesced one-double-per-lane loads straight into registers; there is no cross-environment reuse,
+// so nothing is staged through LDS (the network tables are <=64-entry arrays shared by every
+// wavefront and live in L2/L1).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,13 +22,14 @@
 #define FLEX_WAVES_PER_BLOCK 4
 #define FLEX_JUMP_ROUNDS 6           // 2^6 >= FLEX_MAX_BUS
 
-// Network tables in LANE order (device memory, one copy per handle).
+// Network tables in group-local LANE order (device memory, one copy per handle).
 struct DevNet {
-    int32_t n_bus, slack_lane, n_levels, max_children, n_agents, pad0, pad1, pad2;
-    int32_t bus_of_lane[FLEX_MAX_BUS];      // -1 for lanes >= n_bus
-    int32_t lane_of_bus[FLEX_MAX_BUS];
-    int32_t par_lane[FLEX_MAX_BUS];         // own lane for the slack and for idle lanes
-    int32_t level[FLEX_MAX_BUS];            // -1 for idle lanes
+    int32_t n_bus, n_pq, n_levels, max_children, n_agents, slack_bus, epw, pad0;
+    int32_t bus_of_lane[FLEX_MAX_BUS];      // bus index of the PQ bus in this lane, -1 for idle lanes
+    int32_t lane_of_bus[FLEX_MAX_BUS];      // -1 for the slack
+    int32_t par_lane[FLEX_MAX_BUS];         // parent lane; own lane when the parent is the slack (or idle)
+    int32_t par_slack[FLEX_MAX_BUS];        // 1 when the parent is the slack bus
+    int32_t level[FLEX_MAX_BUS];            // distance from the slack (>= 1); -1 for idle lanes
     int32_t agent_of_lane[FLEX_MAX_BUS];    // -1 if the bus has no building
     int32_t lane_of_agent[FLEX_MAX_AGENTS];
     int32_t slots_at_level[FLEX_MAX_BUS];   // child slots in use by receivers at level L-1
@@ -30,57 +37,58 @@ struct DevNet {
     double g[FLEX_MAX_BUS], b[FLEX_MAX_BUS];   // series admittance of the line to the parent: 1/(r+jx)
     double gd[FLEX_MAX_BUS], bd[FLEX_MAX_BUS]; // Ybus diagonal: own line + children's lines
     double r[FLEX_MAX_BUS], x[FLEX_MAX_BUS];
-    // sweep solver: lanes are a DFS preorder, so subtree(l) = lanes [l, sub_end[l]]; anc[k][l] is the
-    // 2^k-th ancestor of l (the slack lane once the path runs out; own lane for idle lanes)
+    // sweep solver: subtree(l) = lanes [l, sub_end[l]]; chain segments of the preorder (lane l continues the
+    // segment of l-1 iff its parent is l-1): seg_start = first lane, seg_par = lane of the parent of the segment
+    // head, seg_depth = segment hops to a segment hanging off the slack; anc[k][l] = 2^k-th ancestor or -1.
     int32_t sub_end[FLEX_MAX_BUS];
+    int32_t seg_start[FLEX_MAX_BUS], seg_par[FLEX_MAX_BUS], seg_depth[FLEX_MAX_BUS];
     int32_t anc[FLEX_JUMP_ROUNDS][FLEX_MAX_BUS];
     int32_t n_jump_rounds, n_seg_rounds;
-    // chain segments of the preorder: lane l continues the segment of l-1 iff its parent is l-1.
-    // seg_start = first lane of the segment; seg_par = lane of the parent of the segment head;
-    // seg_depth = number of segment hops between this segment and the one holding the slack.
-    int32_t seg_start[FLEX_MAX_BUS], seg_par[FLEX_MAX_BUS], seg_depth[FLEX_MAX_BUS];
 };
 
-// Per-lane registers holding this bus's row of the Ybus and its place in the tree.
+// Per-lane registers: this bus's row of the Ybus and its place in the tree.
 struct LaneNet {
-    int lane, bus, par, lev, agent;
-    bool pq;                 // a PQ bus (not slack, not idle)
+    int lane, l, base, grp;      // wavefront lane, group-local lane, first lane of the group, group index
+    int bus, par, lev, agent;
+    bool pq, par_slack;
     double g, b, gd, bd, r, x;
-    int ch[FLEX_MAX_CHILDREN];
-    int sub_end;
-    int seg_par, seg_depth;
-    int mk[6];               // high words (1.0 or 0.0) of the segmented-scan step masks
+    int ch[FLEX_MAX_CHILDREN];   // wavefront lanes of the children (-1: none)
+    int sub_end, seg_par, seg_depth;
+    int mk[6];                   // high words (1.0 or 0.0) of the segmented-scan step masks
 };
 
+template <int EPW>
 __device__ __forceinline__ void load_lane_net(const DevNet* __restrict__ net, int lane, LaneNet& ln) {
-    ln.lane = lane;
-    ln.bus = net->bus_of_lane[lane];
-    ln.par = net->par_lane[lane];
-    ln.lev = net->level[lane];
-    ln.agent = net->agent_of_lane[lane];
-    ln.pq = (ln.bus >= 0) && (lane != net->slack_lane);
-    ln.g = net->g[lane];
-    ln.b = net->b[lane];
-    ln.gd = net->gd[lane];
-    ln.bd = net->bd[lane];
+    constexpr int LW = FLEX_WAVE / EPW;
+    const int l = lane & (LW - 1), base = lane - l;
+    ln.lane = lane; ln.l = l; ln.base = base; ln.grp = lane / LW;
+    ln.bus = net->bus_of_lane[l];
+    ln.par = net->par_lane[l] + base;
+    ln.par_slack = net->par_slack[l] != 0;
+    ln.lev = net->level[l];
+    ln.agent = net->agent_of_lane[l];
+    ln.pq = ln.bus >= 0;
+    ln.g = net->g[l]; ln.b = net->b[l]; ln.gd = net->gd[l]; ln.bd = net->bd[l];
+    ln.r = net->r[l]; ln.x = net->x[l];
 #pragma unroll
-    for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) ln.ch[k] = net->child_lane[k][lane];
-    ln.r = net->r[lane];
-    ln.x = net->x[lane];
-    ln.sub_end = net->sub_end[lane];
-    ln.seg_par = net->seg_par[lane];
-    ln.seg_depth = net->seg_depth[lane];
-    const int ss = net->seg_start[lane], row = lane >> 4;
+    for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) {
+        const int c = net->child_lane[k][l];
+        ln.ch[k] = c >= 0 ? c + base : -1;
+    }
+    ln.sub_end = net->sub_end[l] + base;
+    ln.seg_par = net->seg_par[l] + base;
+    ln.seg_depth = net->seg_depth[l];
+    const int ss = net->seg_start[l], row = l >> 4;
     const int one = 0x3FF00000;
-    ln.mk[0] = (lane - 1 >= ss) ? one : 0;
-    ln.mk[1] = (lane - 2 >= ss) ? one : 0;
-    ln.mk[2] = (lane - 4 >= ss) ? one : 0;
-    ln.mk[3] = (lane - 8 >= ss) ? one : 0;
-    ln.mk[4] = (ss <= 16 * row - 1) ? one : 0;     // row_bcast:15 into rows 1,3
-    ln.mk[5] = (ss <= 31) ? one : 0;               // row_bcast:31 into rows 2,3
+    ln.mk[0] = (l - 1 >= ss) ? one : 0;
+    ln.mk[1] = (l - 2 >= ss) ? one : 0;
+    ln.mk[2] = (l - 4 >= ss) ? one : 0;
+    ln.mk[3] = (l - 8 >= ss) ? one : 0;
+    ln.mk[4] = (ss <= 16 * row - 1) ? one : 0;     // row_bcast:15 into the odd rows
+    ln.mk[5] = (ss <= 31) ? one : 0;               // row_bcast:31 into rows 2,3 (LW = 64 only)
 }
 
-// ---- wavefront scans and reductions on the DPP path (no LDS traffic) -----------------------------
+// ---- group-wide scans and reductions on the DPP path (no LDS traffic) ------------------------------
 // gfx9 DPP controls: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
 template <int CTRL, int ROW_MASK, bool BOUND_CTRL>
 __device__ __forceinline__ double dpp_mov_f64(double x) {
@@ -89,42 +97,54 @@ __device__ __forceinline__ double dpp_mov_f64(double x) {
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, BOUND_CTRL);
     return __hiloint2double(hi, lo);
 }
-// inclusive prefix sum over the 64 lanes (lanes that must not contribute pass 0)
-__device__ __forceinline__ double wave_scan_sum(double x) {
+// inclusive prefix sum over the lanes of each group (lanes that must not contribute pass 0)
+template <int EPW>
+__device__ __forceinline__ double grp_scan_sum(double x) {
     x += dpp_mov_f64<0x111, 0xF, true>(x);
     x += dpp_mov_f64<0x112, 0xF, true>(x);
     x += dpp_mov_f64<0x114, 0xF, true>(x);
     x += dpp_mov_f64<0x118, 0xF, true>(x);
     x += dpp_mov_f64<0x142, 0xA, false>(x);   // lane 15 of rows 0,2 -> rows 1,3
-    x += dpp_mov_f64<0x143, 0xC, false>(x);   // lane 31 -> rows 2,3
+    if constexpr (EPW == 1) x += dpp_mov_f64<0x143, 0xC, false>(x);   // lane 31 -> rows 2,3
+    return x;
+}
+// the same, restarted at every chain segment: step masks are 1.0 where the source lane lies in the same
+// segment, 0.0 elsewhere (precomputed per lane, off the critical path)
+template <int EPW>
+__device__ __forceinline__ double grp_segscan_sum(double x, const int (&mk)[6]) {
+    x = fma(dpp_mov_f64<0x111, 0xF, true>(x), __hiloint2double(mk[0], 0), x);
+    x = fma(dpp_mov_f64<0x112, 0xF, true>(x), __hiloint2double(mk[1], 0), x);
+    x = fma(dpp_mov_f64<0x114, 0xF, true>(x), __hiloint2double(mk[2], 0), x);
+    x = fma(dpp_mov_f64<0x118, 0xF, true>(x), __hiloint2double(mk[3], 0), x);
+    x = fma(dpp_mov_f64<0x142, 0xA, false>(x), __hiloint2double(mk[4], 0), x);
+    if constexpr (EPW == 1) x = fma(dpp_mov_f64<0x143, 0xC, false>(x), __hiloint2double(mk[5], 0), x);
     return x;
 }
 __device__ __forceinline__ double readlane_f64(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
                             __builtin_amdgcn_readlane(__double2loint(x), l));
 }
-__device__ __forceinline__ double wave_sum(double v) { return readlane_f64(wave_scan_sum(v), 63); }
-// max over lanes of NON-NEGATIVE values (0 is the identity the DPP fill provides)
-__device__ __forceinline__ double wave_max(double x) {
-    x = fmax(x, dpp_mov_f64<0x111, 0xF, true>(x));
-    x = fmax(x, dpp_mov_f64<0x112, 0xF, true>(x));
-    x = fmax(x, dpp_mov_f64<0x114, 0xF, true>(x));
-    x = fmax(x, dpp_mov_f64<0x118, 0xF, true>(x));
-    x = fmax(x, dpp_mov_f64<0x142, 0xA, false>(x));
-    x = fmax(x, dpp_mov_f64<0x143, 0xC, false>(x));
-    return readlane_f64(x, 63);
+// sum over the lanes of each group, returned in every lane of that group
+template <int EPW>
+__device__ __forceinline__ double grp_sum(double v, int grp) {
+    const double s = grp_scan_sum<EPW>(v);
+    if constexpr (EPW == 1) {
+        return readlane_f64(s, 63);
+    } else {
+        const double t0 = readlane_f64(s, 31), t1 = readlane_f64(s, 63);
+        return grp ? t1 : t0;
+    }
 }
-
-// inclusive prefix sum restarted at every chain segment: step masks are 1.0 where the source lane
-// lies in the same segment, 0.0 elsewhere (precomputed per lane, off the critical path)
-__device__ __forceinline__ double wave_segscan_sum(double x, const int (&mk)[6]) {
-    x = fma(dpp_mov_f64<0x111, 0xF, true>(x), __hiloint2double(mk[0], 0), x);
-    x = fma(dpp_mov_f64<0x112, 0xF, true>(x), __hiloint2double(mk[1], 0), x);
-    x = fma(dpp_mov_f64<0x114, 0xF, true>(x), __hiloint2double(mk[2], 0), x);
-    x = fma(dpp_mov_f64<0x118, 0xF, true>(x), __hiloint2double(mk[3], 0), x);
-    x = fma(dpp_mov_f64<0x142, 0xA, false>(x), __hiloint2double(mk[4], 0), x);
-    x = fma(dpp_mov_f64<0x143, 0xC, false>(x), __hiloint2double(mk[5], 0), x);
-    return x;
+// "does any lane of MY group raise the flag", plus the wavefront-wide answer for loop control
+template <int EPW>
+__device__ __forceinline__ bool grp_any(bool p, int grp, bool& wave_any) {
+    const unsigned long long m = __ballot(p);
+    wave_any = m != 0ull;
+    if constexpr (EPW == 1) {
+        return wave_any;
+    } else {
+        return (grp ? (unsigned)(m >> 32) : (unsigned)m) != 0u;
+    }
 }
 
 // 1/d from v_rcp_f64 plus one Newton step: ~3 dependent instructions instead of the ~15 of an
@@ -141,12 +161,15 @@ __device__ __forceinline__ double clipd(double v, double lo, double hi) { return
 // SURVEY.md App. B):   R_i = sum_k Y_ik V_k - conj(S_i / V_i),   S_i = -(Pnet_i + j Qnet_i).
 // On a radial feeder row i of the Ybus couples bus i to its parent and its children only, so the
 // injected current is formed from branch currents J_i = y_i (V_parent - V_i): one pull from the
-// parent lane, one per child slot.  The Jacobian's off-diagonal 2x2 blocks are the constant
-// [[g,-b],[b,g]] of each line; only the diagonal block depends on V.  The Newton step solves
-// J dV = -R exactly by leaf->root block elimination (no fill-in on a tree) and root->leaf
-// back-substitution.  Convergence is tested on the POWER mismatch inf-norm (wavefront max).
+// parent lane (the constant 1∠0 when the parent is the slack), one per child slot.  The Jacobian's
+// off-diagonal 2x2 blocks are the constant [[g,-b],[b,g]] of each line; only the diagonal block
+// depends on V.  The Newton step solves J dV = -R exactly by leaf->root block elimination (no
+// fill-in on a tree) and root->leaf back-substitution.  Convergence is tested on the POWER mismatch
+// inf-norm per environment: "does any lane of my group still miss the tolerance" (a ballot, no
+// reduction).  A group that has converged keeps stepping harmlessly while its neighbour finishes.
 //
-// Returns true when converged; `iters` = Newton steps taken.
+// Returns (per group) true when converged; `iters` = Newton steps taken until then.
+template <int EPW>
 __device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, const LaneNet& ln,
                                                double pnet, double qnet, double& e, double& f,
                                                double tol, int max_iter, int& iters) {
@@ -154,10 +177,11 @@ __device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, c
     const double ps = -pnet, qs = -qnet;
     const int lane = ln.lane;
     bool ok = false;
-    int it = 0;
-    for (;; ++it) {
-        // branch current from the parent into this bus (zero for slack/idle: g = b = 0)
-        const double ep = __shfl(e, ln.par, FLEX_WAVE), fp = __shfl(f, ln.par, FLEX_WAVE);
+    iters = max_iter;
+    for (int it = 0;; ++it) {
+        // branch current from the parent into this bus
+        const double ep0 = __shfl(e, ln.par, FLEX_WAVE), fp0 = __shfl(f, ln.par, FLEX_WAVE);
+        const double ep = ln.par_slack ? 1.0 : ep0, fp = ln.par_slack ? 0.0 : fp0;
         const double de = ep - e, df = fp - f;
         const double jr = ln.g * de - ln.b * df, ji = ln.b * de + ln.g * df;
         double ir = -jr, ii = -ji;   // current injected at this bus = children's inflow - own inflow
@@ -171,12 +195,14 @@ __device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, c
                 ii += has ? ti : 0.0;
             }
         }
-        // power mismatch  S_calc - S_spec,  S_calc = V conj(I)
+        // power mismatch  S_calc - S_spec,  S_calc = V conj(I);  NaN counts as a miss
         const double dP = e * ir + f * ii - ps;
         const double dQ = f * ir - e * ii - qs;
-        // inf-norm test without a reduction: does ANY lane still miss the tolerance?  (NaN counts as a miss)
         const bool miss = ln.pq && !(fmax(fabs(dP), fabs(dQ)) < tol);
-        if (!__any(miss)) { ok = true; break; }
+        bool wave_miss;
+        const bool grp_miss = grp_any<EPW>(miss, ln.grp, wave_miss);
+        if (!grp_miss && !ok) { ok = true; iters = it; }
+        if (!wave_miss) break;
         if (it >= max_iter) break;
 
         // specified current conj(S/V) and its derivative wrt (e, f)
@@ -189,7 +215,7 @@ __device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, c
         double d22 = ln.gd - (ps - 2.0 * f * isi) * inv_d;
 
         // leaf -> root: D_p -= Yb D_c^-1 Yb ; rhs_p += Yb D_c^-1 rhs_c   (Yb = [[g,-b],[b,g]])
-        for (int L = n_levels - 1; L >= 1; --L) {
+        for (int L = n_levels - 1; L >= 2; --L) {
             const double idet = fast_rcp(d11 * d22 - d12 * d21);
             const double i11 = d22 * idet, i12 = -d12 * idet, i21 = -d21 * idet, i22 = d11 * idet;
             const double t11 = ln.g * i11 - ln.b * i21, t12 = ln.g * i12 - ln.b * i22;
@@ -201,7 +227,7 @@ __device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, c
 #pragma unroll
             for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) {
                 if (k < nslots) {
-                    const bool has = (ln.ch[k] >= 0) && (ln.lev == L - 1) && ln.pq;
+                    const bool has = (ln.ch[k] >= 0) && (ln.lev == L - 1);
                     const int src = (ln.ch[k] >= 0) ? ln.ch[k] : lane;
                     const double a11 = __shfl(s11, src, FLEX_WAVE), a12 = __shfl(s12, src, FLEX_WAVE);
                     const double a21 = __shfl(s21, src, FLEX_WAVE), a22 = __shfl(s22, src, FLEX_WAVE);
@@ -218,24 +244,23 @@ __device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, c
         const double i11 = d22 * idet, i12 = -d12 * idet, i21 = -d21 * idet, i22 = d11 * idet;
         double dx0 = 0.0, dx1 = 0.0;
         for (int L = 1; L < n_levels; ++L) {
-            const double p0 = __shfl(dx0, ln.par, FLEX_WAVE), p1 = __shfl(dx1, ln.par, FLEX_WAVE);
+            const double q0 = __shfl(dx0, ln.par, FLEX_WAVE), q1 = __shfl(dx1, ln.par, FLEX_WAVE);
+            const double p0 = ln.par_slack ? 0.0 : q0, p1 = ln.par_slack ? 0.0 : q1;
             const double w0 = rhs0 + ln.g * p0 - ln.b * p1, w1 = rhs1 + ln.b * p0 + ln.g * p1;
-            if (ln.lev == L && ln.pq) {
+            if (ln.lev == L) {
                 dx0 = i11 * w0 + i12 * w1;
                 dx1 = i21 * w0 + i22 * w1;
             }
         }
-        e += dx0;
-        f += dx1;
+        if (ln.pq) { e += dx0; f += dx1; }
     }
-    iters = it;
     return ok;
 }
 
 // ---- backward/forward sweep (Z-bus Gauss) on the radial feeder ------------------------------------
 // The same equations as the Newton path, iterated as a fixed point:  V <- V_slack - Z * conj(S/V).
 // On a tree Z is "subtree sum, times the line impedance, path sum".  With lanes in DFS preorder
-//   * the subtree sum is one inclusive wavefront scan (DPP) plus one pull at the subtree's last lane;
+//   * the subtree sum is one inclusive group scan (DPP) plus one pull at the subtree's last lane;
 //   * the path sum is a scan restarted at every chain segment (DPP) plus one pull per level of
 //     segment nesting (1 on the 33-bus feeder); trees with deep nesting use pointer jumping over
 //     precomputed 2^k-th ancestors instead.
@@ -246,51 +271,58 @@ __device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, c
 // needs no reduction.  The caller always hands the result to pf_newton_tree, which re-evaluates the
 // true Ybus mismatch and either confirms it (0 Newton steps) or finishes the job — so the
 // convergence criterion and the failure semantics are those of the Newton path.
+// Returns (per group) the number of sweeps until its local test passed, or max_sweeps.
+template <int EPW>
 __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const LaneNet& ln, double pnet,
                                         double qnet, double& e, double& f, double tol, int max_sweeps) {
     const int seg_rounds = net->n_seg_rounds, jump_rounds = net->n_jump_rounds;
     const bool use_seg = seg_rounds <= 2;
     const double ps = ln.pq ? -pnet : 0.0, qs = ln.pq ? -qnet : 0.0;
     double pir = 0.0, pii = 0.0;
-    int it = 0;
-    for (; it < max_sweeps; ++it) {
+    int mine = max_sweeps;
+    for (int it = 0; it < max_sweeps; ++it) {
         const double inv_d = fast_rcp(e * e + f * f);
         const double ir = (ps * e + qs * f) * inv_d, ii = (ps * f - qs * e) * inv_d;   // conj(S/V)
         if (it > 0) {
             const double dr = pir - ir, di = pii - ii;
             const bool miss = !(fmax(fabs(e * dr + f * di), fabs(f * dr - e * di)) < tol);
-            if (!__any(miss)) break;
+            bool wave_miss;
+            const bool grp_miss = grp_any<EPW>(miss, ln.grp, wave_miss);
+            if (!grp_miss && mine == max_sweeps) mine = it;
+            if (!wave_miss) break;
         }
         pir = ir; pii = ii;
         // sum of injected currents over each subtree
-        const double sr = wave_scan_sum(ir), si = wave_scan_sum(ii);
+        const double sr = grp_scan_sum<EPW>(ir), si = grp_scan_sum<EPW>(ii);
         const double tr = __shfl(sr, ln.sub_end, FLEX_WAVE) - (sr - ir);
         const double ti = __shfl(si, ln.sub_end, FLEX_WAVE) - (si - ii);
         // voltage rise along the own line: -z*J with J = -(subtree injection)  =>  z * t
         double ar = ln.r * tr - ln.x * ti, ai = ln.r * ti + ln.x * tr;
         // path sum slack -> bus
         if (use_seg) {
-            ar = wave_segscan_sum(ar, ln.mk);
-            ai = wave_segscan_sum(ai, ln.mk);
+            ar = grp_segscan_sum<EPW>(ar, ln.mk);
+            ai = grp_segscan_sum<EPW>(ai, ln.mk);
             for (int d = 1; d <= seg_rounds; ++d) {
                 const double br = __shfl(ar, ln.seg_par, FLEX_WAVE), bi = __shfl(ai, ln.seg_par, FLEX_WAVE);
                 if (ln.seg_depth == d) { ar += br; ai += bi; }
             }
         } else {
             for (int k = 0; k < jump_rounds; ++k) {
-                const int anc = net->anc[k][ln.lane];
-                const double br = __shfl(ar, anc, FLEX_WAVE), bi = __shfl(ai, anc, FLEX_WAVE);
-                ar += br; ai += bi;
+                const int anc = net->anc[k][ln.l];
+                const int src = anc >= 0 ? anc + ln.base : ln.lane;
+                const double br = __shfl(ar, src, FLEX_WAVE), bi = __shfl(ai, src, FLEX_WAVE);
+                if (anc >= 0) { ar += br; ai += bi; }
             }
         }
         e = 1.0 + ar;
         f = ai;
     }
-    return it;
+    return mine;
 }
 
 #define FLEX_MAX_SWEEPS 40
-// One power-flow solve with the configured solver.  Returns converged?; iters = Newton steps, sweeps = sweeps.
+// One power-flow solve per group with the configured solver.  Returns converged?; iters = Newton steps, sweeps = sweeps.
+template <int EPW>
 __device__ __forceinline__ bool pf_solve(const DevNet* __restrict__ net, const LaneNet& ln, int solver, double pnet,
                                          double qnet, double& e, double& f, double tol, int max_iter, int& iters,
                                          int& sweeps) {
@@ -298,10 +330,10 @@ __device__ __forceinline__ bool pf_solve(const DevNet* __restrict__ net, const L
     if (solver == FLEX_SOLVER_SWEEP) {
         // sweeps stop on their LOCAL mismatch estimate at tol/4 so that the Ybus re-evaluation below (different
         // rounding) confirms it at tol instead of spending a full Newton step on a borderline case
-        sweeps = pf_sweep(net, ln, pnet, qnet, e, f, 0.25 * tol, FLEX_MAX_SWEEPS);
+        sweeps = pf_sweep<EPW>(net, ln, pnet, qnet, e, f, 0.25 * tol, FLEX_MAX_SWEEPS);
         if (sweeps >= FLEX_MAX_SWEEPS) { e = 1.0; f = 0.0; }   // sweeps stalled: Newton from a flat start
     }
-    return pf_newton_tree(net, ln, pnet, qnet, e, f, tol, max_iter, iters);
+    return pf_newton_tree<EPW>(net, ln, pnet, qnet, e, f, tol, max_iter, iters);
 }
 
 // ---- per-building action handling (env:262-293, 621-677) -----------------------------------------

@@ -21,7 +21,7 @@ enum { IF_STEPS = 0, IF_START, IF_ROW, IF_OBSCNT, IF_EPISODE, IF_ITERS, IF_SWEEP
 
 struct DevState {
     double* vm;        // [N, n_bus]   |V| in BUS order           (current_voltage, env:146,310)
-    double* ve;        // [N, 64]      Re V in LANE order          (warm start)
+    double* ve;        // [N, 64]      Re V in group-LANE order    (warm start)
     double* vf;        // [N, 64]      Im V in LANE order
     double* agent;     // [N, AF_COUNT, FLEX_MAX_AGENTS]
     double* cumrew;    // [N]
@@ -43,10 +43,10 @@ struct FlexEnv {
 #ifdef FLEX_STAMPS
 #define FLEX_STAMP(slot) do { unsigned long long _t; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-    if (a.stamps && lane == 0) a.stamps[(int64_t)env * 8 + (slot)] = _t; } while (0)
+    if (a.stamps && (lane & (64 / EPW - 1)) == 0) a.stamps[(int64_t)env * 8 + (slot)] = _t; } while (0)
 #define FLEX_STAMP_RT(slot) do { unsigned long long _t; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-    if (a.stamps && lane == 0) a.stamps[(int64_t)env * 8 + (slot)] = _t; } while (0)
+    if (a.stamps && (lane & (64 / EPW - 1)) == 0) a.stamps[(int64_t)env * 8 + (slot)] = _t; } while (0)
 #else
 #define FLEX_STAMP(slot) do { } while (0)
 #define FLEX_STAMP_RT(slot) do { } while (0)
@@ -68,74 +68,70 @@ __device__ __forceinline__ double load_action(const void* p, int dtype, int64_t 
 
 __device__ __forceinline__ int64_t clamp_row(int64_t r, int64_t rows) { return r < 0 ? 0 : (r >= rows ? rows - 1 : r); }
 
-// Reward terms, env:679-706.  Building terms live in building lanes, voltages in all bus lanes.
+// Which environment does this lane group serve?  `valid` is false for the spare group of an odd batch; such a
+// group computes on environment n_envs-1's inputs (no out-of-bounds reads) and stores nothing.
+template <int EPW>
+struct EnvSlot {
+    int lane, env;
+    bool valid;
+    __device__ __forceinline__ EnvSlot(int n_envs) {
+        constexpr int LW = FLEX_WAVE / EPW;
+        lane = threadIdx.x & 63;
+        const int wave = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+        const int e = wave * EPW + lane / LW;
+        valid = e < n_envs;
+        env = valid ? e : n_envs - 1;
+    }
+    // true when the whole wavefront has nothing to do
+    __device__ __forceinline__ bool wave_idle(int n_envs) const {
+        const int wave = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+        return wave * EPW >= n_envs;
+    }
+};
+
+// Reward terms, env:679-706.  Building terms live in building lanes, voltages in PQ lanes; the slack bus
+// (|V| = 1 exactly) contributes max(0, 1 - v_max, v_min - 1) to the penalty over ALL buses.
 struct RewardOut { double reward, revenue, der, ess, disc, vpen; };
-__device__ __forceinline__ RewardOut reward_terms(const FlexCfg& c, bool is_bld, bool is_bus, double price,
+template <int EPW>
+__device__ __forceinline__ RewardOut reward_terms(const FlexCfg& c, const LaneNet& ln, bool is_bld, double price,
                                                   double pred, double ch, double dis, double q, double v) {
     RewardOut r;
-    r.revenue = wave_sum(is_bld ? price * pred : 0.0);
-    r.der = wave_sum(is_bld ? c.pv_cost * q : 0.0);                       // signed: SURVEY A6
-    r.ess = wave_sum(is_bld ? c.ess_cost * (ch + dis) : 0.0);
-    r.disc = wave_sum(is_bld ? c.discomfort_coeff * pred * pred : 0.0);
-    r.vpen = wave_sum(is_bus ? c.voltage_coeff * fmax(0.0, fmax(v - c.v_max, c.v_min - v)) : 0.0);  // all buses: A7
+    r.revenue = grp_sum<EPW>(is_bld ? price * pred : 0.0, ln.grp);
+    r.der = grp_sum<EPW>(is_bld ? c.pv_cost * q : 0.0, ln.grp);                       // signed: SURVEY A6
+    r.ess = grp_sum<EPW>(is_bld ? c.ess_cost * (ch + dis) : 0.0, ln.grp);
+    r.disc = grp_sum<EPW>(is_bld ? c.discomfort_coeff * pred * pred : 0.0, ln.grp);
+    const double slack_pen = c.voltage_coeff * fmax(0.0, fmax(1.0 - c.v_max, c.v_min - 1.0));
+    r.vpen = grp_sum<EPW>(ln.pq ? c.voltage_coeff * fmax(0.0, fmax(v - c.v_max, c.v_min - v)) : 0.0, ln.grp) + slack_pen;
     r.reward = r.revenue - r.der - r.ess - r.disc - r.vpen;
     return r;
 }
 
-// get_obs (env:370-403): push this step's 6 features per agent into the ring and emit the
-// stacked [n_agents, history*6] observation with zero left-padding (A16).  Called by one wavefront.
-template <typename OutT>
-__device__ __forceinline__ void push_and_emit_obs(const KArgs& a, int env, int lane, const LaneNet& ln, int k,
-                                                  double pd, double qd, double ppv, double v, double price,
-                                                  double e, OutT* __restrict__ out) {
-    // k = observations already pushed this episode (read by the caller before it wrote any state)
-    const int H = a.cfg.history, na = a.cfg.n_agents;
-    int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
-    const int slot = k % H;
-    float* ring = a.st.ring + (int64_t)env * na * H * 6;
-    OutT* o = out ? out + (int64_t)env * na * H * 6 : nullptr;
-    // history part: entries k-(H-1) .. k-1 come from the ring, older ones are zeros
-    const int total = na * H * 6;
-    for (int idx = lane; idx < total; idx += FLEX_WAVE) {
-        const int ag = idx / (H * 6), rem = idx - ag * (H * 6), h = rem / 6, ft = rem - h * 6;
-        if (h == H - 1 || !o) continue;
-        const int src = k - (H - 1) + h;
-        float val = 0.0f;
-        if (src >= 0) val = ring[(ag * H + (src % H)) * 6 + ft];
-        o[idx] = (OutT)val;
+// get_obs (env:370-403): the stacked [n_agents, history*6] observation is a rotated copy of the ring of the last
+// `history` feature rows with zero left-padding (A16), plus this step's row.  The history part does not depend
+// on this step's solve, so its ring reads are issued BEFORE the solve (float2 units held in registers) and
+// only stores remain on the critical path afterwards.  One lane group per environment.
+template <int EPW>
+struct ObsIter {              // walks units u = l + LW*j without a division per unit
+    int ag, rem, q, r, H3;
+    __device__ __forceinline__ ObsIter(int l, int H) {
+        constexpr int LW = FLEX_WAVE / EPW;
+        H3 = H * 3; ag = l / H3; rem = l - ag * H3; q = LW / H3; r = LW - q * H3;
     }
-    if (ln.agent >= 0) {
-        const double feat[6] = {pd, qd, ppv, v, price, e};   // env:377-382
-        float* r = ring + (ln.agent * H + slot) * 6;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            r[t] = (float)feat[t];
-            if (o) o[(ln.agent * H + (H - 1)) * 6 + t] = (OutT)feat[t];
-        }
-    }
-    if (lane == 0) ie[IF_OBSCNT] = k + 1;
-}
-
-// Fast path of the same get_obs(): the history part of the stacked observation does not depend on
-// this step's solve, so its ring reads are issued BEFORE the solve (as float2 units held in
-// registers) and only the stores remain on the wave's critical path afterwards.
-#define FLEX_OBS_UNITS 9     // float2 units per lane: 64*9 = 576 >= 8 agents * 24 history * 3
-struct ObsIter {             // walks units u = lane + 64*j without a division per unit
-    int ag, rem, q64, r64, H3;
-    __device__ __forceinline__ ObsIter(int lane, int H) {
-        H3 = H * 3; ag = lane / H3; rem = lane - ag * H3; q64 = 64 / H3; r64 = 64 - q64 * H3;
-    }
-    __device__ __forceinline__ void next() { ag += q64; rem += r64; if (rem >= H3) { rem -= H3; ++ag; } }
+    __device__ __forceinline__ void next() { ag += q; rem += r; if (rem >= H3) { rem -= H3; ++ag; } }
 };
+#define FLEX_OBS_CAP 576      // float2 units per environment that fit the register path: 8 agents * 24 history * 3
 
-__device__ __forceinline__ void obs_prefetch(const KArgs& a, int env, int lane, int k, float2 (&buf)[FLEX_OBS_UNITS]) {
+template <int EPW>
+__device__ __forceinline__ void obs_prefetch(const KArgs& a, int env, const LaneNet& ln, int k,
+                                             float2 (&buf)[FLEX_OBS_CAP * EPW / FLEX_WAVE]) {
+    constexpr int LW = FLEX_WAVE / EPW, UNITS = FLEX_OBS_CAP / LW;
     const int H = a.cfg.history, na = a.cfg.n_agents, total = na * H * 3;
     const int s1 = (k % H) + 1;                       // slot of history entry h is (s1 + h) mod H
     const float* ring = a.st.ring + (int64_t)env * na * H * 6;
-    ObsIter it(lane, H);
+    ObsIter<EPW> it(ln.l, H);
 #pragma unroll
-    for (int j = 0; j < FLEX_OBS_UNITS; ++j) {
-        const int u = lane + 64 * j, h = it.rem / 3, c = it.rem - 3 * h;
+    for (int j = 0; j < UNITS; ++j) {
+        const int u = ln.l + LW * j, h = it.rem / 3, c = it.rem - 3 * h;
         float2 v = make_float2(0.0f, 0.0f);
         if (u < total && h < H - 1 && k - (H - 1) + h >= 0) {
             int slot = s1 + h; if (slot >= H) slot -= H;
@@ -146,19 +142,20 @@ __device__ __forceinline__ void obs_prefetch(const KArgs& a, int env, int lane, 
     }
 }
 
-template <typename OutT>
-__device__ __forceinline__ void obs_store(const KArgs& a, int env, int lane, const LaneNet& ln, int k,
-                                          const float2 (&buf)[FLEX_OBS_UNITS], double pd, double qd, double ppv,
-                                          double v, double price, double e, OutT* __restrict__ out) {
+template <int EPW, typename OutT>
+__device__ __forceinline__ void obs_store(const KArgs& a, int env, bool valid, const LaneNet& ln, int k,
+                                          const float2 (&buf)[FLEX_OBS_CAP * EPW / FLEX_WAVE], double pd, double qd,
+                                          double ppv, double v, double price, double e, OutT* __restrict__ out) {
+    constexpr int LW = FLEX_WAVE / EPW, UNITS = FLEX_OBS_CAP / LW;
     const int H = a.cfg.history, na = a.cfg.n_agents, total = na * H * 3;
     int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
     float* ring = a.st.ring + (int64_t)env * na * H * 6;
     OutT* o = out + (int64_t)env * na * H * 6;
-    ObsIter it(lane, H);
+    ObsIter<EPW> it(ln.l, H);
 #pragma unroll
-    for (int j = 0; j < FLEX_OBS_UNITS; ++j) {
-        const int u = lane + 64 * j, h = it.rem / 3;
-        if (u < total && h < H - 1) {
+    for (int j = 0; j < UNITS; ++j) {
+        const int u = ln.l + LW * j, h = it.rem / 3;
+        if (valid && u < total && h < H - 1) {
             if constexpr (sizeof(OutT) == 4) {
                 *reinterpret_cast<float2*>(o + 2 * u) = buf[j];
             } else {
@@ -167,7 +164,7 @@ __device__ __forceinline__ void obs_store(const KArgs& a, int env, int lane, con
         }
         it.next();
     }
-    if (ln.agent >= 0) {
+    if (valid && ln.agent >= 0) {
         const double feat[6] = {pd, qd, ppv, v, price, e};   // env:377-382
         float* r = ring + (ln.agent * H + (k % H)) * 6;
 #pragma unroll
@@ -176,27 +173,62 @@ __device__ __forceinline__ void obs_store(const KArgs& a, int env, int lane, con
             o[(ln.agent * H + (H - 1)) * 6 + t] = (OutT)feat[t];
         }
     }
-    if (lane == 0) ie[IF_OBSCNT] = k + 1;
+    if (valid && ln.l == 0) ie[IF_OBSCNT] = k + 1;
+}
+
+// General path (history/agent counts beyond the register budget, or no output wanted): same result, ring reads late.
+template <int EPW, typename OutT>
+__device__ __forceinline__ void push_and_emit_obs(const KArgs& a, int env, bool valid, const LaneNet& ln, int k,
+                                                  double pd, double qd, double ppv, double v, double price,
+                                                  double e, OutT* __restrict__ out) {
+    constexpr int LW = FLEX_WAVE / EPW;
+    const int H = a.cfg.history, na = a.cfg.n_agents;
+    int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
+    const int slot = k % H;
+    float* ring = a.st.ring + (int64_t)env * na * H * 6;
+    OutT* o = out ? out + (int64_t)env * na * H * 6 : nullptr;
+    const int total = na * H * 6;
+    for (int idx = ln.l; idx < total; idx += LW) {
+        const int ag = idx / (H * 6), rem = idx - ag * (H * 6), h = rem / 6, ft = rem - h * 6;
+        if (h == H - 1 || !o || !valid) continue;
+        const int src = k - (H - 1) + h;
+        float val = 0.0f;
+        if (src >= 0) val = ring[(ag * H + (src % H)) * 6 + ft];
+        o[idx] = (OutT)val;
+    }
+    if (valid && ln.agent >= 0) {
+        const double feat[6] = {pd, qd, ppv, v, price, e};
+        float* r = ring + (ln.agent * H + slot) * 6;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            r[t] = (float)feat[t];
+            if (o) o[(ln.agent * H + (H - 1)) * 6 + t] = (OutT)feat[t];
+        }
+    }
+    if (valid && ln.l == 0) ie[IF_OBSCNT] = k + 1;
 }
 
 // -------------------------------------------------------------------------------------------------
-// step(): env:241-356 for one environment per wavefront, get_obs() optionally fused (model.py:220-223)
+// step(): env:241-356 for one environment per lane group, get_obs() optionally fused (model.py:220-223)
 // -------------------------------------------------------------------------------------------------
-// 4096 envs = 16 wavefronts per CU = 4 per SIMD: the whole batch must be co-resident (<= 128 VGPRs),
-// otherwise the last blocks start only when the first ones retire and the launch takes twice as long.
-template <typename ObsT>
-__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, 4)
+// Residency: 4096 envs are 2048 wavefronts at EPW = 2 (2 per SIMD, <= 256 VGPRs) or 4096 at EPW = 1 (4 per SIMD,
+// <= 128 VGPRs); in both cases the whole batch must be co-resident, otherwise the last blocks start only when the
+// first ones retire and the launch takes twice as long (measured: profiles/).
+template <int EPW, typename ObsT>
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, (EPW == 1 ? 4 : 2))
 void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, double* __restrict__ reward,
                       uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
                       ObsT* __restrict__ obs, int want_obs) {
-    const int lane = threadIdx.x & 63;
-    const int env = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (env >= a.n_envs) return;
+    EnvSlot<EPW> slot(a.n_envs);
+    if (slot.wave_idle(a.n_envs)) return;
+    const int lane = slot.lane, env = slot.env;
+    const bool valid = slot.valid;
     FLEX_STAMP_RT(5);
     FLEX_STAMP(0);
     const FlexCfg& c = a.cfg;
     LaneNet ln;
-    load_lane_net(a.net, lane, ln);
+    load_lane_net<EPW>(a.net, lane, ln);
+    ln.pq = ln.pq && valid;
     const int nb = a.n_bus, na = c.n_agents;
     int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
     const int steps = ie[IF_STEPS], start = ie[IF_START], obs_cnt = ie[IF_OBSCNT];
@@ -220,13 +252,13 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
     const int64_t new_row = clamp_row((int64_t)start + steps, a.rows);
     const double* nr = a.series + new_row * a.cols;
     double n_pd = 0.0, n_qd = 0.0, n_ppv = 0.0, n_price = 0.0;
-    float2 hist[FLEX_OBS_UNITS];
-    const bool obs_fast = want_obs && (na * c.history * 3 <= 64 * FLEX_OBS_UNITS);
+    float2 hist[FLEX_OBS_CAP * EPW / FLEX_WAVE];
+    const bool obs_fast = want_obs && (na * c.history * 3 <= FLEX_OBS_CAP);
     if (want_obs) {
         n_pd = is_bus ? nr[ln.bus] : 0.0; n_qd = is_bus ? nr[nb + ln.bus] : 0.0;
         n_ppv = is_bld ? nr[2 * nb + ag] : 0.0; n_price = nr[2 * nb + na];
     }
-    if (obs_fast) obs_prefetch(a, env, lane, obs_cnt, hist);
+    if (obs_fast) obs_prefetch<EPW>(a, env, ln, obs_cnt, hist);
 
     // actions -> physical set-points (env:260-293)
     FlexAct act = {0, 0, 0, 0, 0};
@@ -242,14 +274,14 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
 
     // power flow (pf.py:10-113)
     double e = 1.0, f = 0.0;
-    if (c.warm_start) { e = a.st.ve[(int64_t)env * 64 + lane]; f = a.st.vf[(int64_t)env * 64 + lane]; }
+    if (c.warm_start && ln.pq) { e = a.st.ve[(int64_t)env * 64 + ln.l]; f = a.st.vf[(int64_t)env * 64 + ln.l]; }
     int iters = 0, sweeps = 0;
 #ifdef FLEX_STAMPS
     asm volatile("" :: "v"(pnet), "v"(qnet), "v"(e), "v"(f));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     FLEX_STAMP(1);
-    const bool ok = pf_solve(a.net, ln, c.solver, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters, sweeps);
+    const bool ok = pf_solve<EPW>(a.net, ln, c.solver, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters, sweeps);
 #ifdef FLEX_STAMPS
     asm volatile("" :: "v"(e), "v"(f));
 #endif
@@ -260,10 +292,12 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
         v = sqrt(e * e + f * f);                                                       // pf.py:108
         pred = act.pred; ch = act.ch; dis = act.dis; q = act.q;
         e_new = e_init + c.dt * (c.eta_ch * ch - (1.0 / c.eta_dis) * dis);             // pf.py:96-98
-        if (is_bus) a.st.vm[(int64_t)env * nb + ln.bus] = v;
-        a.st.ve[(int64_t)env * 64 + lane] = e;
-        a.st.vf[(int64_t)env * 64 + lane] = f;
-        if (is_bld) {
+        if (ln.pq) {
+            a.st.vm[(int64_t)env * nb + ln.bus] = v;
+            a.st.ve[(int64_t)env * 64 + ln.l] = e;
+            a.st.vf[(int64_t)env * 64 + ln.l] = f;
+        }
+        if (is_bld && valid) {
             agst[AF_PRED * FLEX_MAX_AGENTS + ag] = pred;
             agst[AF_CH * FLEX_MAX_AGENTS + ag] = ch;
             agst[AF_DIS * FLEX_MAX_AGENTS + ag] = dis;
@@ -277,19 +311,19 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
         q = is_bld ? agst[AF_Q * FLEX_MAX_AGENTS + ag] : 0.0;
         e_new = e_cur;
     }
-    if (is_bld) {
+    if (is_bld && valid) {
         agst[AF_PCT * FLEX_MAX_AGENTS + ag] = act.pct;
         agst[AF_E * FLEX_MAX_AGENTS + ag] = e_new;
         agst[AF_EINIT * FLEX_MAX_AGENTS + ag] = e_new;                                 // env:354
     }
 
-    RewardOut rw = reward_terms(c, is_bld, is_bus, price, pred, ch, dis, q, v);         // env:330-335
+    RewardOut rw = reward_terms<EPW>(c, ln, is_bld, price, pred, ch, dis, q, v);        // env:330-335
     const double cum_before = a.st.cumrew[env];
     double rwd = rw.reward;
     if (!ok) rwd -= c.fail_penalty;                                                    // env:336
     const int new_steps = steps + 1;                                                   // env:342
     const bool term = (new_steps >= c.episode_limit) || !ok;                           // env:345
-    if (lane == 0) {
+    if (ln.l == 0 && valid) {
         reward[env] = rwd;
         done[env] = term ? 1 : 0;
         if (failed) failed[env] = ok ? 0 : 1;
@@ -300,7 +334,7 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
         }
         a.st.cumrew[env] = cum_before + rwd;                                           // env:343
         ie[IF_STEPS] = new_steps;
-        ie[IF_ROW] = (int32_t)new_row;
+        ie[IF_ROW] = (int32_t)new_row;                                                 // env:340 reads row `steps` (A2)
         ie[IF_ITERS] = iters;
         ie[IF_SWEEPS] = sweeps;
     }
@@ -309,8 +343,8 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
 #endif
     FLEX_STAMP(3);
     if (want_obs) {
-        if (obs_fast) obs_store<ObsT>(a, env, lane, ln, obs_cnt, hist, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
-        else push_and_emit_obs<ObsT>(a, env, lane, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
+        if (obs_fast) obs_store<EPW, ObsT>(a, env, valid, ln, obs_cnt, hist, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
+        else push_and_emit_obs<EPW, ObsT>(a, env, valid, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
     }
 #ifdef FLEX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -322,26 +356,27 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
 // -------------------------------------------------------------------------------------------------
 // get_obs(): env:370-403 standalone
 // -------------------------------------------------------------------------------------------------
-template <typename ObsT>
+template <int EPW, typename ObsT>
 __global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
 void flex_obs_kernel(KArgs a, ObsT* __restrict__ obs) {
-    const int lane = threadIdx.x & 63;
-    const int env = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (env >= a.n_envs) return;
+    EnvSlot<EPW> slot(a.n_envs);
+    if (slot.wave_idle(a.n_envs)) return;
+    const int lane = slot.lane, env = slot.env;
     LaneNet ln;
-    load_lane_net(a.net, lane, ln);
+    load_lane_net<EPW>(a.net, lane, ln);
     const int nb = a.n_bus, na = a.cfg.n_agents;
     const int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
     const double* sr = a.series + clamp_row(ie[IF_ROW], a.rows) * a.cols;
     const bool is_bus = ln.bus >= 0, is_bld = ln.agent >= 0;
     const int ag = is_bld ? ln.agent : 0;
     const double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
-    push_and_emit_obs<ObsT>(a, env, lane, ln, ie[IF_OBSCNT], is_bus ? sr[ln.bus] : 0.0, is_bus ? sr[nb + ln.bus] : 0.0,
-                            is_bld ? sr[2 * nb + ag] : 0.0, is_bus ? a.st.vm[(int64_t)env * nb + ln.bus] : 0.0,
-                            sr[2 * nb + na], is_bld ? agst[AF_E * FLEX_MAX_AGENTS + ag] : 0.0, obs);
+    push_and_emit_obs<EPW, ObsT>(a, env, slot.valid, ln, ie[IF_OBSCNT], is_bus ? sr[ln.bus] : 0.0,
+                                 is_bus ? sr[nb + ln.bus] : 0.0, is_bld ? sr[2 * nb + ag] : 0.0,
+                                 is_bus ? a.st.vm[(int64_t)env * nb + ln.bus] : 0.0, sr[2 * nb + na],
+                                 is_bld ? agst[AF_E * FLEX_MAX_AGENTS + ag] : 0.0, obs);
 }
 
-// get_state(): env:358-368  [Pd | Qd | Ppv | V | price | E]
+// get_state(): env:358-368  [Pd | Qd | Ppv | V | price | E]   (one wavefront per environment; not a hot kernel)
 __global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
 void flex_state_kernel(KArgs a, double* __restrict__ state) {
     const int lane = threadIdx.x & 63;
@@ -366,25 +401,30 @@ void flex_state_kernel(KArgs a, double* __restrict__ state) {
 // -------------------------------------------------------------------------------------------------
 // reset()/manual_reset(): env:74-155, 157-239
 // -------------------------------------------------------------------------------------------------
-// draw d of the reset stream lives in lane d/2 (u0 for even d, u1 for odd d)
-__device__ __forceinline__ double flex_draw(double u0, double u1, int d) {
-    const double a = __shfl(u0, d >> 1, FLEX_WAVE), b = __shfl(u1, d >> 1, FLEX_WAVE);
+// draw d of the reset stream lives in group lane d/2 (u0 for even d, u1 for odd d).  Both halves are pulled
+// unconditionally and selected afterwards — a shuffle inside a lane-divergent branch would read lanes that are
+// masked off there.
+__device__ __forceinline__ double flex_draw(double u0, double u1, int d, int base) {
+    const double a = __shfl(u0, (d >> 1) + base, FLEX_WAVE), b = __shfl(u1, (d >> 1) + base, FLEX_WAVE);
     return (d & 1) ? b : a;
 }
 
 struct DevResetSpec { const int32_t *day, *hour, *interval; const double *e0, *a0; };
 
-template <typename ObsT>
+template <int EPW, typename ObsT>
 __global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
 void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec inj, ObsT* __restrict__ obs,
                        int want_obs, uint8_t* __restrict__ failed) {
-    const int lane = threadIdx.x & 63;
-    const int env = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (env >= a.n_envs) return;
-    if (mask && !mask[env]) return;
+    EnvSlot<EPW> slot(a.n_envs);
+    if (slot.wave_idle(a.n_envs)) return;
+    const int lane = slot.lane, env = slot.env;
+    // a group takes part when its env exists and is selected; the wavefront leaves when no group does
+    const bool valid = slot.valid && (!mask || mask[env] != 0);
+    if (__ballot(valid) == 0ull) return;
     const FlexCfg& c = a.cfg;
     LaneNet ln;
-    load_lane_net(a.net, lane, ln);
+    load_lane_net<EPW>(a.net, lane, ln);
+    ln.pq = ln.pq && valid;
     const int nb = a.n_bus, na = c.n_agents;
     int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
     const bool is_bus = ln.bus >= 0, is_bld = ln.agent >= 0;
@@ -399,49 +439,60 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
     int64_t row = 0;
     double e = 1.0, f = 0.0, e0 = 0.0, pd = 0.0, qd = 0.0, ppv = 0.0, price = 0.0, e_new = 0.0;
     FlexAct act = {0, 0, 0, 0, 0};
-    for (int attempt = 0; attempt < max_attempts && !ok; ++attempt, ++episode) {
-        // lane j holds Philox block j of this attempt: draws 2j and 2j+1
+    for (int attempt = 0; attempt < max_attempts; ++attempt) {
+        // groups that already hold a solvable episode sit out the re-draw (env:83,150-153)
+        const bool need = valid && !ok;
+        if (__ballot(need) == 0ull) break;
+        // group lane j holds Philox block j of this attempt: draws 2j and 2j+1
         double u0, u1;
-        philox_pair((uint32_t)lane, episode, (uint32_t)env, c.seed, u0, u1);
-        // draw d lives in lane d/2, component d%2
-        // NOTE: both halves are pulled unconditionally and selected afterwards — a shuffle inside a
-        // lane-divergent branch would read lanes that are masked off there.
-        #define FLEX_DRAW(d) flex_draw(u0, u1, (d))
-        int hour = inj.hour ? inj.hour[env] : (int)(FLEX_DRAW(0) * 24.0);                      // env:85,412
-        int day = inj.day ? inj.day[env] : (int)(FLEX_DRAW(1) * (double)c.n_start_days);       // env:86,424
-        int interval = inj.interval ? inj.interval[env] : (int)(FLEX_DRAW(2) * (double)c.per_hour);  // env:87,416
-        start = interval + hour * c.per_hour + day * 24 * c.per_hour;                          // env:477
-        row = clamp_row((int64_t)start + 1, a.rows);                                           // steps = 1: env:76,98
-        const double* sr = a.series + row * a.cols;
-        pd = is_bus ? sr[ln.bus] : 0.0;
-        qd = is_bus ? sr[nb + ln.bus] : 0.0;
-        ppv = is_bld ? sr[2 * nb + ag] : 0.0;
-        price = sr[2 * nb + na];
-        const double lo = 0.9 * (c.e_max / 2), hi = 1.1 * (c.e_max / 2);                        // env:100
+        philox_pair((uint32_t)ln.l, episode, (uint32_t)env, c.seed, u0, u1);
+        const double uh = flex_draw(u0, u1, 0, ln.base), ud = flex_draw(u0, u1, 1, ln.base);
+        const double ui = flex_draw(u0, u1, 2, ln.base);
         const int de = 3 + ag, da = 3 + na + 4 * ag;
-        const double ue = flex_draw(u0, u1, de);
-        const double ua0 = flex_draw(u0, u1, da), ua1 = flex_draw(u0, u1, da + 1);
-        const double ua2 = flex_draw(u0, u1, da + 2), ua3 = flex_draw(u0, u1, da + 3);
+        const double ue = flex_draw(u0, u1, de, ln.base);
+        const double ua0 = flex_draw(u0, u1, da, ln.base), ua1 = flex_draw(u0, u1, da + 1, ln.base);
+        const double ua2 = flex_draw(u0, u1, da + 2, ln.base), ua3 = flex_draw(u0, u1, da + 3, ln.base);
+        const int hour = inj.hour ? inj.hour[env] : (int)(uh * 24.0);                          // env:85,412
+        const int day = inj.day ? inj.day[env] : (int)(ud * (double)c.n_start_days);           // env:86,424
+        const int interval = inj.interval ? inj.interval[env] : (int)(ui * (double)c.per_hour);  // env:87,416
+        const int start_n = interval + hour * c.per_hour + day * 24 * c.per_hour;               // env:477
+        const int64_t row_n = clamp_row((int64_t)start_n + 1, a.rows);                          // steps = 1: env:76,98
+        const double* sr = a.series + row_n * a.cols;
+        const double pd_n = is_bus ? sr[ln.bus] : 0.0, qd_n = is_bus ? sr[nb + ln.bus] : 0.0;
+        const double ppv_n = is_bld ? sr[2 * nb + ag] : 0.0, price_n = sr[2 * nb + na];
+        const double lo = 0.9 * (c.e_max / 2), hi = 1.1 * (c.e_max / 2);                        // env:100
+        double e0_n = 0.0;
+        FlexAct act_n = {0, 0, 0, 0, 0};
         if (is_bld) {
-            e0 = inj.e0 ? inj.e0[(int64_t)env * na + ag] : lo + (hi - lo) * ue;
+            e0_n = inj.e0 ? inj.e0[(int64_t)env * na + ag] : lo + (hi - lo) * ue;
             const double* ia = inj.a0 ? inj.a0 + ((int64_t)env * na + ag) * 4 : nullptr;
             const double span = c.action_high - c.action_low;                                   // env:716-719
             const double av0 = ia ? ia[0] : c.action_low + span * ua0, av1 = ia ? ia[1] : c.action_low + span * ua1;
             const double av2 = ia ? ia[2] : c.action_low + span * ua2, av3 = ia ? ia[3] : c.action_low + span * ua3;
-            act = parse_actions(c, false, av0, av1, av2, av3, pd, ppv, e0);                     // env:113-130
+            act_n = parse_actions(c, false, av0, av1, av2, av3, pd_n, ppv_n, e0_n);             // env:113-130
         }
-        const double pnet = pd - act.pred - ppv + act.ch - act.dis;
-        const double qnet = qd - act.q;
-        e = 1.0; f = 0.0;
-        ok = pf_solve(a.net, ln, c.solver, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters, sweeps);  // env:134-144
-        e_new = e0 + c.dt * (c.eta_ch * act.ch - (1.0 / c.eta_dis) * act.dis);                  // pf.py:96-98
-        #undef FLEX_DRAW
+        const double pnet = pd_n - act_n.pred - ppv_n + act_n.ch - act_n.dis;
+        const double qnet = qd_n - act_n.q;
+        double e_n = 1.0, f_n = 0.0;
+        int it_n = 0, sw_n = 0;
+        LaneNet lt = ln;
+        lt.pq = ln.pq && need;                       // finished groups do not hold up the convergence ballot
+        const bool ok_n = pf_solve<EPW>(a.net, lt, c.solver, need ? pnet : 0.0, need ? qnet : 0.0, e_n, f_n, c.pf_tol,
+                                        c.pf_max_iter, it_n, sw_n);                             // env:134-144
+        if (need) {
+            ok = ok_n; start = start_n; row = row_n; pd = pd_n; qd = qd_n; ppv = ppv_n; price = price_n;
+            e0 = e0_n; act = act_n; e = e_n; f = f_n; iters = it_n; sweeps = sw_n;
+            e_new = e0_n + c.dt * (c.eta_ch * act_n.ch - (1.0 / c.eta_dis) * act_n.dis);        // pf.py:96-98
+            ++episode;
+        }
     }
     const double v = sqrt(e * e + f * f);
-    if (is_bus) a.st.vm[(int64_t)env * nb + ln.bus] = v;
-    a.st.ve[(int64_t)env * 64 + lane] = ok ? e : 1.0;
-    a.st.vf[(int64_t)env * 64 + lane] = ok ? f : 0.0;
-    if (is_bld) {
+    if (ln.pq) {
+        a.st.vm[(int64_t)env * nb + ln.bus] = v;
+        a.st.ve[(int64_t)env * 64 + ln.l] = ok ? e : 1.0;
+        a.st.vf[(int64_t)env * 64 + ln.l] = ok ? f : 0.0;
+    }
+    if (is_bld && valid) {
         agst[AF_E * FLEX_MAX_AGENTS + ag] = e_new;          // env:147
         agst[AF_EINIT * FLEX_MAX_AGENTS + ag] = e0;         // A5: stays the pre-solve draw
         agst[AF_PRED * FLEX_MAX_AGENTS + ag] = act.pred;
@@ -450,7 +501,8 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
         agst[AF_Q * FLEX_MAX_AGENTS + ag] = act.q;
         agst[AF_PCT * FLEX_MAX_AGENTS + ag] = act.pct;
     }
-    if (lane == 0) {
+    if (ln.l == 0 && valid) {
+        a.st.vm[(int64_t)env * nb + a.net->slack_bus] = 1.0;   // pf.py:53: Vsqr[slack] = 1
         a.st.cumrew[env] = 0.0;                             // env:77
         ie[IF_STEPS] = 1;                                   // env:76
         ie[IF_START] = start;
@@ -461,31 +513,33 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
         ie[IF_SWEEPS] = sweeps;
         if (failed) failed[env] = ok ? 0 : 1;
     }
-    if (want_obs) push_and_emit_obs<ObsT>(a, env, lane, ln, 0, pd, qd, ppv, v, price, e_new, obs);
+    if (want_obs) push_and_emit_obs<EPW, ObsT>(a, env, valid, ln, 0, pd, qd, ppv, v, price, e_new, obs);
 }
 
 // -------------------------------------------------------------------------------------------------
 // power_flow_solver_simplified on a batch: utils/pf.py:115-192
 // -------------------------------------------------------------------------------------------------
+template <int EPW>
 __global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
 void pf_batch_kernel(const DevNet* __restrict__ net, int n, int nb, const double* __restrict__ pnet,
                      const double* __restrict__ qnet, double* __restrict__ v, double* __restrict__ isqr,
                      double* __restrict__ pl, double* __restrict__ ql, int32_t* __restrict__ iters_out,
                      uint8_t* __restrict__ failed, double tol, int max_iter, int solver) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (i >= n) return;
+    EnvSlot<EPW> slot(n);
+    if (slot.wave_idle(n)) return;
+    const int lane = slot.lane, i = slot.env;
     LaneNet ln;
-    load_lane_net(net, lane, ln);
-    const bool is_bus = ln.bus >= 0;
-    const double p = is_bus ? pnet[(int64_t)i * nb + ln.bus] : 0.0;
-    const double q = is_bus ? qnet[(int64_t)i * nb + ln.bus] : 0.0;
+    load_lane_net<EPW>(net, lane, ln);
+    ln.pq = ln.pq && slot.valid;
+    const double p = ln.pq ? pnet[(int64_t)i * nb + ln.bus] : 0.0;
+    const double q = ln.pq ? qnet[(int64_t)i * nb + ln.bus] : 0.0;
     double e = 1.0, f = 0.0;
     int iters = 0, sweeps = 0;
-    const bool ok = pf_solve(net, ln, solver, p, q, e, f, tol, max_iter, iters, sweeps);
+    const bool ok = pf_solve<EPW>(net, ln, solver, p, q, e, f, tol, max_iter, iters, sweeps);
     // line quantities in the receiving-end convention of pf.py:85-88
-    const double ep = __shfl(e, ln.par, FLEX_WAVE), fp = __shfl(f, ln.par, FLEX_WAVE);
-    if (is_bus) {
+    const double ep0 = __shfl(e, ln.par, FLEX_WAVE), fp0 = __shfl(f, ln.par, FLEX_WAVE);
+    if (ln.pq) {
+        const double ep = ln.par_slack ? 1.0 : ep0, fp = ln.par_slack ? 0.0 : fp0;
         v[(int64_t)i * nb + ln.bus] = sqrt(e * e + f * f);
         const double de = ep - e, df = fp - f;
         const double jr = ln.g * de - ln.b * df, ji = ln.b * de + ln.g * df;
@@ -493,7 +547,12 @@ void pf_batch_kernel(const DevNet* __restrict__ net, int n, int nb, const double
         if (pl) pl[(int64_t)i * nb + ln.bus] = e * jr + f * ji;
         if (ql) ql[(int64_t)i * nb + ln.bus] = f * jr - e * ji;
     }
-    if (lane == 0) {
+    if (ln.l == 0 && slot.valid) {
+        const int sb = net->slack_bus;
+        v[(int64_t)i * nb + sb] = 1.0;
+        if (isqr) isqr[(int64_t)i * nb + sb] = 0.0;
+        if (pl) pl[(int64_t)i * nb + sb] = 0.0;
+        if (ql) ql[(int64_t)i * nb + sb] = 0.0;
         if (iters_out) iters_out[i] = iters + 1000 * sweeps;   // Newton steps + 1000 * sweeps
         if (failed) failed[i] = ok ? 0 : 1;
     }
@@ -597,48 +656,55 @@ static int build_devnet(const NetFix* nf, int n_agents, DevNet* dn) {
     if (nf->max_children < 1 || nf->max_children > FLEX_MAX_CHILDREN) return FLEX_EINVAL;
     if (nf->slack < 0 || nf->slack >= n) return FLEX_EINVAL;
     memset(dn, 0, sizeof(*dn));
-    dn->n_bus = n; dn->n_levels = nf->n_levels; dn->max_children = nf->max_children; dn->n_agents = n_agents;
-    // depth-first preorder from the slack: the first child of a bus lands in the next lane
+    const int npq = n - 1;
+    dn->n_bus = n; dn->n_pq = npq; dn->n_levels = nf->n_levels; dn->n_agents = n_agents; dn->slack_bus = nf->slack;
+    dn->epw = (npq <= FLEX_WAVE / 2) ? 2 : 1;
+    // depth-first preorder of the PQ buses (the slack gets no lane): the first child of a bus lands in the next lane
     std::vector<int> order, stack;
-    stack.push_back(nf->slack);
+    for (int k = nf->max_children - 1; k >= 0; --k) {
+        const int cidx = nf->child[nf->slack * nf->max_children + k];
+        if (cidx >= 0) { if (cidx >= n) return FLEX_EINVAL; stack.push_back(cidx); }
+    }
     while (!stack.empty()) {
-        int u = stack.back(); stack.pop_back();
+        const int u = stack.back(); stack.pop_back();
         order.push_back(u);
+        if ((int)order.size() > npq) return FLEX_EINVAL;
         for (int k = nf->max_children - 1; k >= 0; --k) {
-            int cidx = nf->child[u * nf->max_children + k];
-            if (cidx >= 0) { if (cidx >= n) return FLEX_EINVAL; stack.push_back(cidx); }
+            const int cidx = nf->child[u * nf->max_children + k];
+            if (cidx >= 0) { if (cidx >= n || cidx == nf->slack) return FLEX_EINVAL; stack.push_back(cidx); }
         }
-        if ((int)order.size() > n) return FLEX_EINVAL;
     }
-    if ((int)order.size() != n) return FLEX_EINVAL;
+    if ((int)order.size() != npq) return FLEX_EINVAL;
     for (int l = 0; l < FLEX_MAX_BUS; ++l) {
-        dn->bus_of_lane[l] = -1; dn->lane_of_bus[l] = -1; dn->par_lane[l] = l; dn->level[l] = -1;
-        dn->agent_of_lane[l] = -1; dn->gd[l] = 1.0;
+        dn->bus_of_lane[l] = -1; dn->lane_of_bus[l] = -1; dn->par_lane[l] = l; dn->par_slack[l] = 0; dn->level[l] = -1;
+        dn->agent_of_lane[l] = -1; dn->gd[l] = 1.0; dn->sub_end[l] = l;
+        dn->seg_start[l] = l; dn->seg_par[l] = l; dn->seg_depth[l] = 0;
         for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) dn->child_lane[k][l] = -1;
+        for (int k = 0; k < FLEX_JUMP_ROUNDS; ++k) dn->anc[k][l] = -1;
     }
-    for (int l = 0; l < n; ++l) { dn->bus_of_lane[l] = order[l]; dn->lane_of_bus[order[l]] = l; }
-    dn->slack_lane = dn->lane_of_bus[nf->slack];
+    for (int l = 0; l < npq; ++l) { dn->bus_of_lane[l] = order[l]; dn->lane_of_bus[order[l]] = l; }
+    if (nf->parent[nf->slack] != -1 || nf->level[nf->slack] != 0) return FLEX_EINVAL;
     int maxlev = 0;
-    for (int l = 0; l < n; ++l) {
-        const int b = order[l];
-        const int p = nf->parent[b];
-        dn->level[l] = nf->level[b];
-        if (nf->level[b] < 0 || nf->level[b] >= FLEX_MAX_BUS) return FLEX_EINVAL;
-        if (nf->level[b] > maxlev) maxlev = nf->level[b];
-        if (b == nf->slack) {
-            if (p != -1 || nf->level[b] != 0) return FLEX_EINVAL;
-            continue;
-        }
+    for (int l = 0; l < npq; ++l) {
+        const int b = order[l], p = nf->parent[b];
+        if (nf->level[b] < 1 || nf->level[b] >= FLEX_MAX_BUS) return FLEX_EINVAL;
         if (p < 0 || p >= n || nf->level[p] != nf->level[b] - 1) return FLEX_EINVAL;
-        dn->par_lane[l] = dn->lane_of_bus[p];
+        dn->level[l] = nf->level[b];
+        if (nf->level[b] > maxlev) maxlev = nf->level[b];
+        if (p == nf->slack) { dn->par_slack[l] = 1; dn->par_lane[l] = l; }
+        else {
+            dn->par_lane[l] = dn->lane_of_bus[p];
+            if (dn->par_lane[l] >= l) return FLEX_EINVAL;     // preorder: parents come first
+        }
         const double r = nf->r[b], x = nf->x[b], z2 = r * r + x * x;
         if (!(z2 > 0.0)) return FLEX_EINVAL;
         dn->r[l] = r; dn->x[l] = x;
         dn->g[l] = r / z2; dn->b[l] = -x / z2;
     }
     if (maxlev + 1 != nf->n_levels) return FLEX_EINVAL;
-    for (int l = 0; l < n; ++l) { dn->gd[l] = dn->g[l]; dn->bd[l] = dn->b[l]; }
-    for (int l = 0; l < n; ++l) {
+    for (int l = 0; l < npq; ++l) { dn->gd[l] = dn->g[l]; dn->bd[l] = dn->b[l]; }
+    int maxc = 1;
+    for (int l = 0; l < npq; ++l) {
         const int b = order[l];
         int used = 0;
         for (int k = 0; k < nf->max_children; ++k) {
@@ -649,36 +715,41 @@ static int build_devnet(const NetFix* nf, int n_agents, DevNet* dn) {
             dn->child_lane[used++][l] = cl;
             dn->gd[l] += dn->g[cl]; dn->bd[l] += dn->b[cl];
         }
+        if (used > maxc) maxc = used;
         const int lev = dn->level[l];
-        if (lev + 1 < FLEX_MAX_BUS && used > dn->slots_at_level[lev + 1] && l != dn->slack_lane)
-            dn->slots_at_level[lev + 1] = used;
+        if (lev + 1 < FLEX_MAX_BUS && used > dn->slots_at_level[lev + 1]) dn->slots_at_level[lev + 1] = used;
     }
-    // sweep-solver tables: subtree ranges (preorder => contiguous) and 2^k-th ancestors
+    dn->max_children = maxc;
+    // sweep-solver tables: subtree ranges (preorder => contiguous), chain segments, 2^k-th ancestors
     {
         std::vector<int> size(FLEX_MAX_BUS, 1);
-        for (int l = n - 1; l >= 1; --l) size[dn->par_lane[l]] += (dn->par_lane[l] != l) ? size[l] : 0;
-        for (int l = 0; l < FLEX_MAX_BUS; ++l) {
-            dn->sub_end[l] = (l < n) ? l + size[l] - 1 : l;
-            dn->anc[0][l] = (l < n) ? dn->par_lane[l] : l;   // slack: itself
-        }
-        for (int k = 1; k < FLEX_JUMP_ROUNDS; ++k)
-            for (int l = 0; l < FLEX_MAX_BUS; ++l) dn->anc[k][l] = dn->anc[k - 1][dn->anc[k - 1][l]];
-        // chain segments
+        for (int l = npq - 1; l >= 0; --l) if (!dn->par_slack[l]) size[dn->par_lane[l]] += size[l];
         int max_depth = 0;
-        for (int l = 0; l < FLEX_MAX_BUS; ++l) {
-            const bool cont = (l > 0) && (l < n) && (dn->par_lane[l] == l - 1);
-            dn->seg_start[l] = cont ? dn->seg_start[l - 1] : l;
-            if (cont) { dn->seg_par[l] = dn->seg_par[l - 1]; dn->seg_depth[l] = dn->seg_depth[l - 1]; }
-            else if (l == 0 || l >= n) { dn->seg_par[l] = l; dn->seg_depth[l] = 0; }
-            else { dn->seg_par[l] = dn->par_lane[l]; dn->seg_depth[l] = dn->seg_depth[dn->par_lane[l]] + 1; }
+        for (int l = 0; l < npq; ++l) {
+            dn->sub_end[l] = l + size[l] - 1;
+            const bool cont = (l > 0) && !dn->par_slack[l] && (dn->par_lane[l] == l - 1);
+            if (cont) {
+                dn->seg_start[l] = dn->seg_start[l - 1]; dn->seg_par[l] = dn->seg_par[l - 1];
+                dn->seg_depth[l] = dn->seg_depth[l - 1];
+            } else if (dn->par_slack[l]) {
+                dn->seg_start[l] = l; dn->seg_par[l] = l; dn->seg_depth[l] = 0;
+            } else {
+                dn->seg_start[l] = l; dn->seg_par[l] = dn->par_lane[l];
+                dn->seg_depth[l] = dn->seg_depth[dn->par_lane[l]] + 1;
+            }
             if (dn->seg_depth[l] > max_depth) max_depth = dn->seg_depth[l];
+            dn->anc[0][l] = dn->par_slack[l] ? -1 : dn->par_lane[l];
         }
         dn->n_seg_rounds = max_depth;
+        for (int k = 1; k < FLEX_JUMP_ROUNDS; ++k)
+            for (int l = 0; l < npq; ++l) {
+                const int h = dn->anc[k - 1][l];
+                dn->anc[k][l] = (h >= 0) ? dn->anc[k - 1][h] : -1;
+            }
         int rounds = 0;
         while ((1 << rounds) < nf->n_levels - 1) ++rounds;
         dn->n_jump_rounds = rounds;
         if (rounds > FLEX_JUMP_ROUNDS) return FLEX_EINVAL;
-        if (dn->slack_lane != 0) return FLEX_EINVAL;   // preorder from the slack puts it in lane 0
     }
     for (int a = 0; a < n_agents; ++a) {
         const int b = nf->agent_bus[a];
@@ -701,7 +772,11 @@ static KArgs make_args(const FlexEnv* e) {
     return k;
 }
 
-static inline dim3 env_grid(int n) { return dim3((n + FLEX_WAVES_PER_BLOCK - 1) / FLEX_WAVES_PER_BLOCK); }
+// n environments at `epw` environments per wavefront, FLEX_WAVES_PER_BLOCK wavefronts per block
+static inline dim3 env_grid(int n, int epw = 1) {
+    const int waves = (n + epw - 1) / epw;
+    return dim3((waves + FLEX_WAVES_PER_BLOCK - 1) / FLEX_WAVES_PER_BLOCK);
+}
 static inline dim3 env_block() { return dim3(FLEX_WAVE * FLEX_WAVES_PER_BLOCK); }
 
 extern "C" {
@@ -768,10 +843,17 @@ int flexenv_reset(FlexEnv* e, const uint8_t* mask, const ResetSpec* inj, void* o
     if (inj) { d.day = inj->day; d.hour = inj->hour; d.interval = inj->interval; d.e0 = inj->e0; d.a0 = inj->a0; }
     KArgs k = make_args(e);
     hipStream_t s = (hipStream_t)stream;
-    if (obs && obs_dtype == FLEX_F64)
-        hipLaunchKernelGGL(flex_reset_kernel<double>, env_grid(e->n_envs), env_block(), 0, s, k, mask, d, (double*)obs, 1, failed);
-    else
-        hipLaunchKernelGGL(flex_reset_kernel<float>, env_grid(e->n_envs), env_block(), 0, s, k, mask, d, (float*)obs, obs ? 1 : 0, failed);
+    const int epw = e->hnet.epw;
+    const dim3 grid = env_grid(e->n_envs, epw);
+    const bool f64 = obs && obs_dtype == FLEX_F64;
+    const int want = obs ? 1 : 0;
+    if (epw == 2) {
+        if (f64) hipLaunchKernelGGL((flex_reset_kernel<2, double>), grid, env_block(), 0, s, k, mask, d, (double*)obs, want, failed);
+        else hipLaunchKernelGGL((flex_reset_kernel<2, float>), grid, env_block(), 0, s, k, mask, d, (float*)obs, want, failed);
+    } else {
+        if (f64) hipLaunchKernelGGL((flex_reset_kernel<1, double>), grid, env_block(), 0, s, k, mask, d, (double*)obs, want, failed);
+        else hipLaunchKernelGGL((flex_reset_kernel<1, float>), grid, env_block(), 0, s, k, mask, d, (float*)obs, want, failed);
+    }
     HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }
@@ -783,12 +865,17 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     if (obs && obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64) return FLEX_EINVAL;
     KArgs k = make_args(e);
     hipStream_t s = (hipStream_t)stream;
-    if (obs && obs_dtype == FLEX_F64)
-        hipLaunchKernelGGL(flex_step_kernel<double>, env_grid(e->n_envs), env_block(), 0, s, k, actions, act_dtype,
-                           reward, done, info, failed, (double*)obs, 1);
-    else
-        hipLaunchKernelGGL(flex_step_kernel<float>, env_grid(e->n_envs), env_block(), 0, s, k, actions, act_dtype,
-                           reward, done, info, failed, (float*)obs, obs ? 1 : 0);
+    const int epw = e->hnet.epw;
+    const dim3 grid = env_grid(e->n_envs, epw);
+    const bool f64 = obs && obs_dtype == FLEX_F64;
+    const int want = obs ? 1 : 0;
+    if (epw == 2) {
+        if (f64) hipLaunchKernelGGL((flex_step_kernel<2, double>), grid, env_block(), 0, s, k, actions, act_dtype, reward, done, info, failed, (double*)obs, want);
+        else hipLaunchKernelGGL((flex_step_kernel<2, float>), grid, env_block(), 0, s, k, actions, act_dtype, reward, done, info, failed, (float*)obs, want);
+    } else {
+        if (f64) hipLaunchKernelGGL((flex_step_kernel<1, double>), grid, env_block(), 0, s, k, actions, act_dtype, reward, done, info, failed, (double*)obs, want);
+        else hipLaunchKernelGGL((flex_step_kernel<1, float>), grid, env_block(), 0, s, k, actions, act_dtype, reward, done, info, failed, (float*)obs, want);
+    }
     HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }
@@ -797,10 +884,15 @@ int flexenv_obs(FlexEnv* e, void* obs, int32_t obs_dtype, void* stream) {
     if (!e || !obs || (obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64)) return FLEX_EINVAL;
     KArgs k = make_args(e);
     hipStream_t s = (hipStream_t)stream;
-    if (obs_dtype == FLEX_F64)
-        hipLaunchKernelGGL(flex_obs_kernel<double>, env_grid(e->n_envs), env_block(), 0, s, k, (double*)obs);
-    else
-        hipLaunchKernelGGL(flex_obs_kernel<float>, env_grid(e->n_envs), env_block(), 0, s, k, (float*)obs);
+    const int epw = e->hnet.epw;
+    const dim3 grid = env_grid(e->n_envs, epw);
+    if (epw == 2) {
+        if (obs_dtype == FLEX_F64) hipLaunchKernelGGL((flex_obs_kernel<2, double>), grid, env_block(), 0, s, k, (double*)obs);
+        else hipLaunchKernelGGL((flex_obs_kernel<2, float>), grid, env_block(), 0, s, k, (float*)obs);
+    } else {
+        if (obs_dtype == FLEX_F64) hipLaunchKernelGGL((flex_obs_kernel<1, double>), grid, env_block(), 0, s, k, (double*)obs);
+        else hipLaunchKernelGGL((flex_obs_kernel<1, float>), grid, env_block(), 0, s, k, (float*)obs);
+    }
     HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }
@@ -897,8 +989,12 @@ int pf_solve_batch(const NetFix* net, int32_t n, const double* pnet, const doubl
     HIP_TRY(hipMallocAsync((void**)&d, sizeof(DevNet), s));
     HIP_TRY(hipMemcpyAsync(d, &h, sizeof(DevNet), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));   // h is a stack object
-    hipLaunchKernelGGL(pf_batch_kernel, env_grid(n), env_block(), 0, s, d, n, net->n_bus, pnet, qnet, v, isqr, pl, ql,
-                       iters, failed, tol, max_iter, solver);
+    if (h.epw == 2)
+        hipLaunchKernelGGL(pf_batch_kernel<2>, env_grid(n, 2), env_block(), 0, s, d, n, net->n_bus, pnet, qnet, v, isqr, pl, ql,
+                           iters, failed, tol, max_iter, solver);
+    else
+        hipLaunchKernelGGL(pf_batch_kernel<1>, env_grid(n, 1), env_block(), 0, s, d, n, net->n_bus, pnet, qnet, v, isqr, pl, ql,
+                           iters, failed, tol, max_iter, solver);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipFreeAsync(d, s));
     return FLEX_OK;

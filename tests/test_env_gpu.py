@@ -41,7 +41,7 @@ def test_full_episode_matches_oracle(net, series_small, action_range, solver, wa
     reference actually delivers; (0,1) exercises the ESS clipping branches."""
     import torch
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
-    n, na = 48, 5
+    n, na = 47, 5     # odd on purpose: the last wavefront has a spare lane group
     rng = np.random.default_rng(3)
     vec = VecFlexProvisionEnv({}, n, series=series_small, net=net, solver=solver, warm_start=warm)
     oracles = _oracle_envs(net, series_small, n)
@@ -159,7 +159,7 @@ def test_philox_reset_stream_matches_restatement(net, series_small):
     """Device-drawn episodes (no injection) equal the oracle's restatement of the Philox stream."""
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
     from oracle.env_oracle import reset_draws, DEFAULT_CFG
-    n = 40
+    n = 41            # odd on purpose: the last wavefront has a spare lane group
     vec = VecFlexProvisionEnv({}, n, series=series_small, net=net, seed=1234)
     obs = vec.reset().cpu().numpy()
     oracles = _oracle_envs(net, series_small, n)
