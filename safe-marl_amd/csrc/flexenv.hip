@@ -60,6 +60,7 @@ struct KArgs {
     const double* series;
     int64_t rows;
     int32_t cols, n_envs, n_bus;
+    int32_t ring_bytes;        // size of the observation ring, 0 when it does not fit a 32-bit buffer descriptor
 };
 
 __device__ __forceinline__ double load_action(const void* p, int dtype, int64_t i) {
@@ -111,34 +112,50 @@ __device__ __forceinline__ RewardOut reward_terms(const FlexCfg& c, const LaneNe
 // on this step's solve, so its ring reads are issued BEFORE the solve (float2 units held in registers) and
 // only stores remain on the critical path afterwards.  One lane group per environment.
 template <int EPW>
-struct ObsIter {              // walks units u = l + LW*j without a division per unit
-    int ag, rem, q, r, H3;
-    __device__ __forceinline__ ObsIter(int l, int H) {
+struct ObsPlan {
+    // Unit u = l + LW*j is the float2 at output offset 2u of this env's [n_agents, history, 6] observation.  With
+    // rem = u mod (3*history) its history index is h = rem/3, and the ring holds that entry at float offset
+    // 2u + 6*s1 - (h + s1 >= history ? 6*history : 0), s1 = (k mod history) + 1: the observation is the ring rotated
+    // by s1 rows.  Everything is decided by comparing `rem` with three thresholds — no division per unit.
+    int total, units, H3, rem, step_rem, wrap_at, lo, hi, shift, sixH;
+    __device__ __forceinline__ ObsPlan(int l, int H, int na, int k) {
         constexpr int LW = FLEX_WAVE / EPW;
-        H3 = H * 3; ag = l / H3; rem = l - ag * H3; q = LW / H3; r = LW - q * H3;
+        H3 = 3 * H; total = na * H3; units = (total + LW - 1) / LW;
+        rem = l % H3; step_rem = LW % H3;
+        const int s1 = (k % H) + 1;
+        wrap_at = 3 * (H - s1);                      // rem >= wrap_at: the ring slot wrapped around
+        lo = 3 * (H - 1 - k > 0 ? H - 1 - k : 0);    // rem <  lo: before the episode began -> zero padding (A16)
+        hi = 3 * (H - 1);                            // rem >= hi: this step's own row, written by the building lanes
+        shift = 6 * s1; sixH = 6 * H;
     }
-    __device__ __forceinline__ void next() { ag += q; rem += r; if (rem >= H3) { rem -= H3; ++ag; } }
+    __device__ __forceinline__ void next() { rem += step_rem; if (rem >= H3) rem -= H3; }
+    __device__ __forceinline__ bool from_ring(int u) const { return u < total && rem >= lo && rem < hi; }
+    __device__ __forceinline__ bool writes(int u) const { return u < total && rem < hi; }
+    __device__ __forceinline__ int src(int u) const { return 2 * u + shift - (rem >= wrap_at ? sixH : 0); }
 };
 #define FLEX_OBS_CAP 576      // float2 units per environment that fit the register path: 8 agents * 24 history * 3
 
+typedef int flex_v2i __attribute__((ext_vector_type(2)));
+
+// The ring reads go through a buffer descriptor over the whole ring array: a raw buffer load is never turned
+// into a branch by the compiler (a conditional global_load is, with a full s_waitcnt behind every one of them),
+// the loads issue back to back, and an out-of-range offset returns zeros — which is exactly the zero padding.
 template <int EPW>
 __device__ __forceinline__ void obs_prefetch(const KArgs& a, int env, const LaneNet& ln, int k,
                                              float2 (&buf)[FLEX_OBS_CAP * EPW / FLEX_WAVE]) {
     constexpr int LW = FLEX_WAVE / EPW, UNITS = FLEX_OBS_CAP / LW;
-    const int H = a.cfg.history, na = a.cfg.n_agents, total = na * H * 3;
-    const int s1 = (k % H) + 1;                       // slot of history entry h is (s1 + h) mod H
-    const float* ring = a.st.ring + (int64_t)env * na * H * 6;
-    ObsIter<EPW> it(ln.l, H);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.st.ring, 0, a.ring_bytes, 0x00020000);
+    const int env_off = env * (a.cfg.n_agents * a.cfg.history * 6 * 4);      // bytes
+    ObsPlan<EPW> pl(ln.l, a.cfg.history, a.cfg.n_agents, k);
+    // no branch of any kind around the loads (hipcc waits for every pending load at a control-flow join that
+    // merges its destination register); units beyond the env's size are out-of-range loads, which cost nothing
 #pragma unroll
     for (int j = 0; j < UNITS; ++j) {
-        const int u = ln.l + LW * j, h = it.rem / 3, c = it.rem - 3 * h;
-        float2 v = make_float2(0.0f, 0.0f);
-        if (u < total && h < H - 1 && k - (H - 1) + h >= 0) {
-            int slot = s1 + h; if (slot >= H) slot -= H;
-            v = *reinterpret_cast<const float2*>(ring + (it.ag * H + slot) * 6 + 2 * c);
-        }
-        buf[j] = v;
-        it.next();
+        const int u = ln.l + LW * j;
+        const int off = pl.from_ring(u) ? env_off + 4 * pl.src(u) : -1;   // -1 = 0xFFFFFFFF: out of range -> 0
+        const flex_v2i r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+        buf[j] = make_float2(__int_as_float(r.x), __int_as_float(r.y));
+        pl.next();
     }
 }
 
@@ -147,22 +164,24 @@ __device__ __forceinline__ void obs_store(const KArgs& a, int env, bool valid, c
                                           const float2 (&buf)[FLEX_OBS_CAP * EPW / FLEX_WAVE], double pd, double qd,
                                           double ppv, double v, double price, double e, OutT* __restrict__ out) {
     constexpr int LW = FLEX_WAVE / EPW, UNITS = FLEX_OBS_CAP / LW;
-    const int H = a.cfg.history, na = a.cfg.n_agents, total = na * H * 3;
+    const int H = a.cfg.history, na = a.cfg.n_agents;
     int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
     float* ring = a.st.ring + (int64_t)env * na * H * 6;
     OutT* o = out + (int64_t)env * na * H * 6;
-    ObsIter<EPW> it(ln.l, H);
+    ObsPlan<EPW> pl(ln.l, H, na, k);
 #pragma unroll
     for (int j = 0; j < UNITS; ++j) {
-        const int u = ln.l + LW * j, h = it.rem / 3;
-        if (valid && u < total && h < H - 1) {
-            if constexpr (sizeof(OutT) == 4) {
-                *reinterpret_cast<float2*>(o + 2 * u) = buf[j];
-            } else {
-                *reinterpret_cast<double2*>(o + 2 * u) = make_double2((double)buf[j].x, (double)buf[j].y);
+        if (j < pl.units) {
+            const int u = ln.l + LW * j;
+            if (valid && pl.writes(u)) {
+                if constexpr (sizeof(OutT) == 4) {
+                    *reinterpret_cast<float2*>(o + 2 * u) = buf[j];
+                } else {
+                    *reinterpret_cast<double2*>(o + 2 * u) = make_double2((double)buf[j].x, (double)buf[j].y);
+                }
             }
+            pl.next();
         }
-        it.next();
     }
     if (valid && ln.agent >= 0) {
         const double feat[6] = {pd, qd, ppv, v, price, e};   // env:377-382
@@ -214,9 +233,9 @@ __device__ __forceinline__ void push_and_emit_obs(const KArgs& a, int env, bool 
 // Residency: 4096 envs are 2048 wavefronts at EPW = 2 (2 per SIMD, <= 256 VGPRs) or 4096 at EPW = 1 (4 per SIMD,
 // <= 128 VGPRs); in both cases the whole batch must be co-resident, otherwise the last blocks start only when the
 // first ones retire and the launch takes twice as long (measured: profiles/).
-template <int EPW, typename ObsT>
+template <int EPW, typename ObsT, typename ActT>
 __global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, (EPW == 1 ? 4 : 2))
-void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, double* __restrict__ reward,
+void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restrict__ reward,
                       uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
                       ObsT* __restrict__ obs, int want_obs) {
     EnvSlot<EPW> slot(a.n_envs);
@@ -231,50 +250,53 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
     ln.pq = ln.pq && valid;
     const int nb = a.n_bus, na = c.n_agents;
     int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
-    const int steps = ie[IF_STEPS], start = ie[IF_START], obs_cnt = ie[IF_OBSCNT];
-    const int64_t row = clamp_row(ie[IF_ROW], a.rows);
+    const int4 iv = *reinterpret_cast<const int4*>(ie);           // steps, start, row, obs_cnt in one load
+    const int steps = iv.x, start = iv.y, obs_cnt = iv.w;
+    const int64_t row = clamp_row(iv.z, a.rows);
     const bool is_bus = ln.bus >= 0, is_bld = ln.agent >= 0;
-    const int ag = is_bld ? ln.agent : 0;
+    const int ag = is_bld ? ln.agent : 0, busi = is_bus ? ln.bus : 0;
 
-    // current data row (loaded by the previous step / reset: env:340, A2)
+    // Every load below uses an address that is valid in EVERY lane (idle lanes read bus 0 / agent 0) and is
+    // issued unconditionally: a conditional load compiles to a branch with a full s_waitcnt behind it, and a
+    // handful of those in a row serialise the prologue into as many memory round trips.
+    // 1) what the solve needs: current data row (env:340, A2), ESS state, actions, previous voltages
     const double* sr = a.series + row * a.cols;
-    const double pd = is_bus ? sr[ln.bus] : 0.0;
-    const double qd = is_bus ? sr[nb + ln.bus] : 0.0;
-    const double ppv = is_bld ? sr[2 * nb + ag] : 0.0;
-    const double price = sr[2 * nb + na];
-
+    const double pd_r = sr[busi], qd_r = sr[nb + busi], ppv_r = sr[2 * nb + ag], price = sr[2 * nb + na];
     double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
-    const double e_cur = is_bld ? agst[AF_E * FLEX_MAX_AGENTS + ag] : 0.0;
-    const double e_init = is_bld ? agst[AF_EINIT * FLEX_MAX_AGENTS + ag] : 0.0;
-
-    // everything the get_obs() epilogue needs that does not depend on the solve is requested now:
-    // the row env:340 will load (start + steps, A2) and the history part of the stacked observation
+    const double e_cur_r = agst[AF_E * FLEX_MAX_AGENTS + ag], e_init_r = agst[AF_EINIT * FLEX_MAX_AGENTS + ag];
+    const ActT* ap = actions + ((int64_t)env * na + ag) * 4;
+    ActT av[4];
+    if constexpr (sizeof(ActT) == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(ap);
+        av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+    } else {
+        const double2 t0 = *reinterpret_cast<const double2*>(ap), t1 = *reinterpret_cast<const double2*>(ap + 2);
+        av[0] = t0.x; av[1] = t0.y; av[2] = t1.x; av[3] = t1.y;
+    }
+    const double we = a.st.ve[(int64_t)env * 64 + ln.l], wf = a.st.vf[(int64_t)env * 64 + ln.l];
+    // 2) what only the get_obs() epilogue needs, requested behind the above so that it never delays the solve:
+    //    the row env:340 will load (start + steps, A2) and the history part of the stacked observation
     const int64_t new_row = clamp_row((int64_t)start + steps, a.rows);
     const double* nr = a.series + new_row * a.cols;
-    double n_pd = 0.0, n_qd = 0.0, n_ppv = 0.0, n_price = 0.0;
+    double n_pd = nr[busi], n_qd = nr[nb + busi], n_ppv = nr[2 * nb + ag];
+    const double n_price = nr[2 * nb + na];
     float2 hist[FLEX_OBS_CAP * EPW / FLEX_WAVE];
-    const bool obs_fast = want_obs && (na * c.history * 3 <= FLEX_OBS_CAP);
-    if (want_obs) {
-        n_pd = is_bus ? nr[ln.bus] : 0.0; n_qd = is_bus ? nr[nb + ln.bus] : 0.0;
-        n_ppv = is_bld ? nr[2 * nb + ag] : 0.0; n_price = nr[2 * nb + na];
-    }
-    if (obs_fast) obs_prefetch<EPW>(a, env, ln, obs_cnt, hist);
+    const bool obs_fast = want_obs && (na * c.history * 3 <= FLEX_OBS_CAP) && a.ring_bytes > 0;
+    obs_prefetch<EPW>(a, env, ln, obs_cnt, hist);      // always issued: with ring_bytes == 0 every load is out of range
+    const bool warm = c.warm_start != 0 && ln.pq;
+    double e = warm ? we : 1.0, f = warm ? wf : 0.0;
 
-    // actions -> physical set-points (env:260-293)
-    FlexAct act = {0, 0, 0, 0, 0};
-    if (is_bld) {
-        const int64_t base = ((int64_t)env * na + ag) * 4;
-        act = parse_actions(c, c.raw_actions != 0, load_action(actions, act_dtype, base),
-                            load_action(actions, act_dtype, base + 1), load_action(actions, act_dtype, base + 2),
-                            load_action(actions, act_dtype, base + 3), pd, ppv, e_cur);
-    }
+    const double pd = is_bus ? pd_r : 0.0, qd = is_bus ? qd_r : 0.0, ppv = is_bld ? ppv_r : 0.0;
+    const double e_cur = is_bld ? e_cur_r : 0.0, e_init = is_bld ? e_init_r : 0.0;
+    // actions -> physical set-points (env:260-293); computed in every lane, kept in building lanes
+    FlexAct act = parse_actions(c, c.raw_actions != 0, (double)av[0], (double)av[1], (double)av[2], (double)av[3],
+                                pd, ppv, e_cur);
+    if (!is_bld) { act.pct = 0.0; act.pred = 0.0; act.ch = 0.0; act.dis = 0.0; act.q = 0.0; }
     // net load per bus (pf.py:69-73, 81-82)
     const double pnet = pd - act.pred - ppv + act.ch - act.dis;
     const double qnet = qd - act.q;
 
     // power flow (pf.py:10-113)
-    double e = 1.0, f = 0.0;
-    if (c.warm_start && ln.pq) { e = a.st.ve[(int64_t)env * 64 + ln.l]; f = a.st.vf[(int64_t)env * 64 + ln.l]; }
     int iters = 0, sweeps = 0;
 #ifdef FLEX_STAMPS
     asm volatile("" :: "v"(pnet), "v"(qnet), "v"(e), "v"(f));
@@ -343,6 +365,7 @@ void flex_step_kernel(KArgs a, const void* __restrict__ actions, int act_dtype, 
 #endif
     FLEX_STAMP(3);
     if (want_obs) {
+        n_pd = is_bus ? n_pd : 0.0; n_qd = is_bus ? n_qd : 0.0; n_ppv = is_bld ? n_ppv : 0.0;
         if (obs_fast) obs_store<EPW, ObsT>(a, env, valid, ln, obs_cnt, hist, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
         else push_and_emit_obs<EPW, ObsT>(a, env, valid, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
     }
@@ -769,6 +792,8 @@ static KArgs make_args(const FlexEnv* e) {
     k.stamps = g_stamps;
     k.cfg = e->cfg; k.net = e->net; k.st = e->st; k.series = e->series.table;
     k.rows = e->series.rows; k.cols = e->series.cols; k.n_envs = e->n_envs; k.n_bus = e->n_bus;
+    const int64_t rb = (int64_t)e->n_envs * e->cfg.n_agents * e->cfg.history * 6 * (int64_t)sizeof(float);
+    k.ring_bytes = rb < (1LL << 31) ? (int32_t)rb : 0;
     return k;
 }
 
@@ -869,13 +894,20 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     const dim3 grid = env_grid(e->n_envs, epw);
     const bool f64 = obs && obs_dtype == FLEX_F64;
     const int want = obs ? 1 : 0;
-    if (epw == 2) {
-        if (f64) hipLaunchKernelGGL((flex_step_kernel<2, double>), grid, env_block(), 0, s, k, actions, act_dtype, reward, done, info, failed, (double*)obs, want);
-        else hipLaunchKernelGGL((flex_step_kernel<2, float>), grid, env_block(), 0, s, k, actions, act_dtype, reward, done, info, failed, (float*)obs, want);
-    } else {
-        if (f64) hipLaunchKernelGGL((flex_step_kernel<1, double>), grid, env_block(), 0, s, k, actions, act_dtype, reward, done, info, failed, (double*)obs, want);
-        else hipLaunchKernelGGL((flex_step_kernel<1, float>), grid, env_block(), 0, s, k, actions, act_dtype, reward, done, info, failed, (float*)obs, want);
+#define FLEX_LAUNCH_STEP(EPW_, OBS_, ACT_) hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_>), grid, env_block(), 0, s, k, \
+        (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want)
+    const int variant = (epw == 2 ? 4 : 0) + (f64 ? 2 : 0) + (act_dtype == FLEX_F64 ? 1 : 0);
+    switch (variant) {
+        case 0: FLEX_LAUNCH_STEP(1, float, float); break;
+        case 1: FLEX_LAUNCH_STEP(1, float, double); break;
+        case 2: FLEX_LAUNCH_STEP(1, double, float); break;
+        case 3: FLEX_LAUNCH_STEP(1, double, double); break;
+        case 4: FLEX_LAUNCH_STEP(2, float, float); break;
+        case 5: FLEX_LAUNCH_STEP(2, float, double); break;
+        case 6: FLEX_LAUNCH_STEP(2, double, float); break;
+        default: FLEX_LAUNCH_STEP(2, double, double); break;
     }
+#undef FLEX_LAUNCH_STEP
     HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }
