@@ -3,8 +3,8 @@
 
 A "step" is ONE vector step of the hot path over one batch of synthetic input: for every one of the
 4096 environments of this GPU, `flexenv_step` (action parse -> 33-bus AC power flow -> ESS update ->
-reward, with the `get_obs()` that always follows it fused in) followed by the masked auto-reset of the
-environments that just terminated.  Inputs (series table, action pool) are resident in HBM before the
+reward, with the `get_obs()` that always follows it fused in, and the restart of the environments that just
+terminated) — one kernel launch.  Inputs (series table, action pool) are resident in HBM before the
 timed region starts; nothing crosses PCIe inside it.
 
     python bench.py --gpus N --steps K --warmup W
@@ -112,8 +112,8 @@ def main():
     env.reset()
 
     def one_step(k):
-        env.step(pool[k % ACTION_POOL], fuse_obs=True)
-        env.reset(mask=env.done)                             # auto-reset of the envs that just terminated
+        # ONE launch: step + get_obs; envs that terminate restart inside the same launch (FLEX_STEP_AUTORESET)
+        env.step(pool[k % ACTION_POOL], fuse_obs=True, auto_reset=True)
 
     for k in range(a.warmup):
         one_step(k)
@@ -145,9 +145,8 @@ def main():
     torch.cuda.synchronize()
     for k, (s, e) in enumerate(evs):
         s.record()
-        env.step(pool[k % ACTION_POOL], fuse_obs=True)
+        env.step(pool[k % ACTION_POOL], fuse_obs=True, auto_reset=True)
         e.record()
-        env.reset(mask=env.done)
     torch.cuda.synchronize()
     durs = sorted(s.elapsed_time(e) for s, e in evs)
     kern_ms = sum(durs) / len(durs)
@@ -180,9 +179,9 @@ def main():
             "data": "synthetic (stand-in IEEE-33 Baran-Wu network, SURVEY.md App. C; generated series, SURVEY.md §8d)",
             "config": {
                 "workload": "flex_provision.step()+get_obs() batched, 4096 envs/GPU, 33-bus AC power flow (fp64 NR, tol 1e-12), "
-                            "5 agents, masked auto-reset each step",
+                            "5 agents, in-launch auto-reset",
                 "envs_per_gpu": a.envs, "n_agents": env.n_agents, "n_bus": env.n_bus,
-                "warm_start": bool(a.warm_start), "launches_per_step": 2,
+                "warm_start": bool(a.warm_start), "launches_per_step": 1,
                 "device_ms_per_step": dev_ms / a.steps, "solver": a.solver, "pf_newton_iters_mean": iters_mean, "pf_sweeps_mean": sweeps_mean,
                 "solver_failed_frac": failed_frac,
             },

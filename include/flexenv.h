@@ -146,10 +146,12 @@ int flexenv_reset(FlexEnv* env, const uint8_t* mask /*dev [N] or NULL*/, const R
  * hands float32 values that NumPy 1.26 promotes to float64 before any arithmetic, util.py:184 +
  * env:278).  If `obs` is non-NULL the get_obs() that model.py:223 issues right after step() is fused
  * into the same launch. */
+#define FLEX_STEP_AUTORESET 1   /* an env that terminates in this step restarts (Philox stream) inside the same
+                                  launch; its `obs` row then holds the FIRST observation of the new episode */
 int flexenv_step(FlexEnv* env, const void* actions, int32_t act_dtype,
                  double* reward /*dev [N]*/, uint8_t* done /*dev [N]*/,
                  double* info /*dev [N, FLEX_INFO_W] or NULL*/, uint8_t* failed /*dev [N] or NULL*/,
-                 void* obs /*dev [N, n_agents, 6*history] or NULL*/, int32_t obs_dtype, void* stream);
+                 void* obs /*dev [N, n_agents, 6*history] or NULL*/, int32_t obs_dtype, int32_t flags, void* stream);
 
 /* Replaces get_obs() (env:370-403): stateful, appends to the history on every call. */
 int flexenv_obs(FlexEnv* env, void* obs /*dev [N, n_agents, 6*history]*/, int32_t obs_dtype, void* stream);

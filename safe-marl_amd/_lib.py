@@ -14,6 +14,7 @@ FLEX_MAX_AGENTS = 8
 FLEX_MAX_CHILDREN = 8
 FLEX_INFO_W = 7
 FLEX_F64, FLEX_F32 = 0, 1
+FLEX_STEP_AUTORESET = 1
 FLEX_SOLVER_TREE, FLEX_SOLVER_DENSE, FLEX_SOLVER_SWEEP = 0, 1, 2
 
 PEEK = dict(V=0, E=1, E_INIT=2, PRED=3, CH=4, DIS=5, QPV=6, PCT=7, CUMREW=8, STEPS=9, ROW=10, START=11,
@@ -95,7 +96,7 @@ def load():
     lib.flexenv_destroy.restype = None
     lib.flexenv_reset.argtypes = [vp, vp, C.POINTER(ResetSpec), vp, i32, vp, vp]
     lib.flexenv_reset.restype = C.c_int
-    lib.flexenv_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp]
+    lib.flexenv_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.flexenv_step.restype = C.c_int
     lib.flexenv_obs.argtypes = [vp, vp, i32, vp]
     lib.flexenv_obs.restype = C.c_int

@@ -228,6 +228,134 @@ __device__ __forceinline__ void push_and_emit_obs(const KArgs& a, int env, bool 
 }
 
 // -------------------------------------------------------------------------------------------------
+// reset()/manual_reset(): env:74-155, 157-239
+// -------------------------------------------------------------------------------------------------
+// draw d of the reset stream lives in group lane d/2 (u0 for even d, u1 for odd d).  Both halves are pulled
+// unconditionally and selected afterwards — a shuffle inside a lane-divergent branch would read lanes that are
+// masked off there.
+__device__ __forceinline__ double flex_draw(double u0, double u1, int d, int base) {
+    const double a = __shfl(u0, (d >> 1) + base, FLEX_WAVE), b = __shfl(u1, (d >> 1) + base, FLEX_WAVE);
+    return (d & 1) ? b : a;
+}
+
+struct DevResetSpec { const int32_t *day, *hour, *interval; const double *e0, *a0; };
+
+// The episode (re)start of the lane groups flagged `valid`; shared by the reset kernel and by the step kernel's
+// auto-reset tail.  `ln0` is the group's LaneNet with pq not yet masked.
+template <int EPW, typename ObsT>
+__device__ __forceinline__ void flex_reset_body(const KArgs& a, int env, bool valid, const LaneNet& ln0,
+                                                const DevResetSpec& inj, ObsT* __restrict__ obs, int want_obs,
+                                                uint8_t* __restrict__ failed, bool or_failed) {
+    const FlexCfg& c = a.cfg;
+    LaneNet ln = ln0;
+    ln.pq = ln.pq && valid;
+    const int nb = a.n_bus, na = c.n_agents;
+    int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
+    const bool is_bus = ln.bus >= 0, is_bld = ln.agent >= 0;
+    const int ag = is_bld ? ln.agent : 0;
+    double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
+    const bool all_injected = inj.day && inj.hour && inj.interval && inj.e0 && inj.a0;
+    const int max_attempts = all_injected ? 1 : 8;
+    uint32_t episode = (uint32_t)ie[IF_EPISODE];
+
+    bool ok = false;
+    int start = 0, iters = 0, sweeps = 0;
+    int64_t row = 0;
+    double e = 1.0, f = 0.0, e0 = 0.0, pd = 0.0, qd = 0.0, ppv = 0.0, price = 0.0, e_new = 0.0;
+    FlexAct act = {0, 0, 0, 0, 0};
+    for (int attempt = 0; attempt < max_attempts; ++attempt) {
+        // groups that already hold a solvable episode sit out the re-draw (env:83,150-153)
+        const bool need = valid && !ok;
+        if (__ballot(need) == 0ull) break;
+        // group lane j holds Philox block j of this attempt: draws 2j and 2j+1
+        double u0, u1;
+        philox_pair((uint32_t)ln.l, episode, (uint32_t)env, c.seed, u0, u1);
+        const double uh = flex_draw(u0, u1, 0, ln.base), ud = flex_draw(u0, u1, 1, ln.base);
+        const double ui = flex_draw(u0, u1, 2, ln.base);
+        const int de = 3 + ag, da = 3 + na + 4 * ag;
+        const double ue = flex_draw(u0, u1, de, ln.base);
+        const double ua0 = flex_draw(u0, u1, da, ln.base), ua1 = flex_draw(u0, u1, da + 1, ln.base);
+        const double ua2 = flex_draw(u0, u1, da + 2, ln.base), ua3 = flex_draw(u0, u1, da + 3, ln.base);
+        const int hour = inj.hour ? inj.hour[env] : (int)(uh * 24.0);                          // env:85,412
+        const int day = inj.day ? inj.day[env] : (int)(ud * (double)c.n_start_days);           // env:86,424
+        const int interval = inj.interval ? inj.interval[env] : (int)(ui * (double)c.per_hour);  // env:87,416
+        const int start_n = interval + hour * c.per_hour + day * 24 * c.per_hour;               // env:477
+        const int64_t row_n = clamp_row((int64_t)start_n + 1, a.rows);                          // steps = 1: env:76,98
+        const double* sr = a.series + row_n * a.cols;
+        const double pd_n = is_bus ? sr[ln.bus] : 0.0, qd_n = is_bus ? sr[nb + ln.bus] : 0.0;
+        const double ppv_n = is_bld ? sr[2 * nb + ag] : 0.0, price_n = sr[2 * nb + na];
+        const double lo = 0.9 * (c.e_max / 2), hi = 1.1 * (c.e_max / 2);                        // env:100
+        double e0_n = 0.0;
+        FlexAct act_n = {0, 0, 0, 0, 0};
+        if (is_bld) {
+            e0_n = inj.e0 ? inj.e0[(int64_t)env * na + ag] : lo + (hi - lo) * ue;
+            const double* ia = inj.a0 ? inj.a0 + ((int64_t)env * na + ag) * 4 : nullptr;
+            const double span = c.action_high - c.action_low;                                   // env:716-719
+            const double av0 = ia ? ia[0] : c.action_low + span * ua0, av1 = ia ? ia[1] : c.action_low + span * ua1;
+            const double av2 = ia ? ia[2] : c.action_low + span * ua2, av3 = ia ? ia[3] : c.action_low + span * ua3;
+            act_n = parse_actions(c, false, av0, av1, av2, av3, pd_n, ppv_n, e0_n);             // env:113-130
+        }
+        const double pnet = pd_n - act_n.pred - ppv_n + act_n.ch - act_n.dis;
+        const double qnet = qd_n - act_n.q;
+        double e_n = 1.0, f_n = 0.0;
+        int it_n = 0, sw_n = 0;
+        LaneNet lt = ln;
+        lt.pq = ln.pq && need;                       // finished groups do not hold up the convergence ballot
+        const bool ok_n = pf_solve<EPW>(a.net, lt, c.solver, need ? pnet : 0.0, need ? qnet : 0.0, e_n, f_n, c.pf_tol,
+                                        c.pf_max_iter, it_n, sw_n);                             // env:134-144
+        if (need) {
+            ok = ok_n; start = start_n; row = row_n; pd = pd_n; qd = qd_n; ppv = ppv_n; price = price_n;
+            e0 = e0_n; act = act_n; e = e_n; f = f_n; iters = it_n; sweeps = sw_n;
+            e_new = e0_n + c.dt * (c.eta_ch * act_n.ch - (1.0 / c.eta_dis) * act_n.dis);        // pf.py:96-98
+            ++episode;
+        }
+    }
+    const double v = sqrt(e * e + f * f);
+    if (ln.pq) {
+        a.st.vm[(int64_t)env * nb + ln.bus] = v;
+        a.st.ve[(int64_t)env * 64 + ln.l] = ok ? e : 1.0;
+        a.st.vf[(int64_t)env * 64 + ln.l] = ok ? f : 0.0;
+    }
+    if (is_bld && valid) {
+        agst[AF_E * FLEX_MAX_AGENTS + ag] = e_new;          // env:147
+        agst[AF_EINIT * FLEX_MAX_AGENTS + ag] = e0;         // A5: stays the pre-solve draw
+        agst[AF_PRED * FLEX_MAX_AGENTS + ag] = act.pred;
+        agst[AF_CH * FLEX_MAX_AGENTS + ag] = act.ch;
+        agst[AF_DIS * FLEX_MAX_AGENTS + ag] = act.dis;
+        agst[AF_Q * FLEX_MAX_AGENTS + ag] = act.q;
+        agst[AF_PCT * FLEX_MAX_AGENTS + ag] = act.pct;
+    }
+    if (ln.l == 0 && valid) {
+        a.st.vm[(int64_t)env * nb + a.net->slack_bus] = 1.0;   // pf.py:53: Vsqr[slack] = 1
+        a.st.cumrew[env] = 0.0;                             // env:77
+        ie[IF_STEPS] = 1;                                   // env:76
+        ie[IF_START] = start;
+        ie[IF_ROW] = (int32_t)row;
+        ie[IF_OBSCNT] = 0;                                  // env:79-80
+        ie[IF_EPISODE] = (int32_t)episode;
+        ie[IF_ITERS] = iters;
+        ie[IF_SWEEPS] = sweeps;
+        if (failed) { if (or_failed) { if (!ok) failed[env] = 1; } else failed[env] = ok ? 0 : 1; }
+    }
+    if (want_obs) push_and_emit_obs<EPW, ObsT>(a, env, valid, ln, 0, pd, qd, ppv, v, price, e_new, obs);
+}
+
+template <int EPW, typename ObsT>
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
+void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec inj, ObsT* __restrict__ obs,
+                       int want_obs, uint8_t* __restrict__ failed) {
+    EnvSlot<EPW> slot(a.n_envs);
+    if (slot.wave_idle(a.n_envs)) return;
+    // a group takes part when its env exists and is selected; the wavefront leaves when no group does
+    const bool valid = slot.valid && (!mask || mask[slot.env] != 0);
+    if (__ballot(valid) == 0ull) return;
+    LaneNet ln;
+    load_lane_net<EPW>(a.net, slot.lane, ln);
+    flex_reset_body<EPW, ObsT>(a, slot.env, valid, ln, inj, obs, want_obs, failed, false);
+}
+
+
+// -------------------------------------------------------------------------------------------------
 // step(): env:241-356 for one environment per lane group, get_obs() optionally fused (model.py:220-223)
 // -------------------------------------------------------------------------------------------------
 // Residency: 4096 envs are 2048 wavefronts at EPW = 2 (2 per SIMD, <= 256 VGPRs) or 4096 at EPW = 1 (4 per SIMD,
@@ -237,7 +365,7 @@ template <int EPW, typename ObsT, typename ActT>
 __global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, (EPW == 1 ? 4 : 2))
 void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restrict__ reward,
                       uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
-                      ObsT* __restrict__ obs, int want_obs) {
+                      ObsT* __restrict__ obs, int want_obs, int auto_reset) {
     EnvSlot<EPW> slot(a.n_envs);
     if (slot.wave_idle(a.n_envs)) return;
     const int lane = slot.lane, env = slot.env;
@@ -364,10 +492,20 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     FLEX_STAMP(3);
+    // FLEX_STEP_AUTORESET: an environment that just terminated restarts inside this launch; its observation row
+    // then holds the first observation of the new episode (the terminal observation is not materialised)
+    const bool restart = auto_reset && term && valid;
     if (want_obs) {
         n_pd = is_bus ? n_pd : 0.0; n_qd = is_bus ? n_qd : 0.0; n_ppv = is_bld ? n_ppv : 0.0;
-        if (obs_fast) obs_store<EPW, ObsT>(a, env, valid, ln, obs_cnt, hist, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
-        else push_and_emit_obs<EPW, ObsT>(a, env, valid, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
+        const bool emit = valid && !restart;
+        if (obs_fast) obs_store<EPW, ObsT>(a, env, emit, ln, obs_cnt, hist, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
+        else push_and_emit_obs<EPW, ObsT>(a, env, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
+    }
+    if (auto_reset && __ballot(restart) != 0ull) {       // wavefront-uniform, taken once per episode
+        LaneNet ln0;
+        load_lane_net<EPW>(a.net, lane, ln0);
+        const DevResetSpec none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        flex_reset_body<EPW, ObsT>(a, env, restart, ln0, none, obs, want_obs, failed, true);
     }
 #ifdef FLEX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -419,124 +557,6 @@ void flex_state_kernel(KArgs a, double* __restrict__ state) {
         else v = agst[AF_E * FLEX_MAX_AGENTS + (i - 3 * nb - na - 1)];
         o[i] = v;
     }
-}
-
-// -------------------------------------------------------------------------------------------------
-// reset()/manual_reset(): env:74-155, 157-239
-// -------------------------------------------------------------------------------------------------
-// draw d of the reset stream lives in group lane d/2 (u0 for even d, u1 for odd d).  Both halves are pulled
-// unconditionally and selected afterwards — a shuffle inside a lane-divergent branch would read lanes that are
-// masked off there.
-__device__ __forceinline__ double flex_draw(double u0, double u1, int d, int base) {
-    const double a = __shfl(u0, (d >> 1) + base, FLEX_WAVE), b = __shfl(u1, (d >> 1) + base, FLEX_WAVE);
-    return (d & 1) ? b : a;
-}
-
-struct DevResetSpec { const int32_t *day, *hour, *interval; const double *e0, *a0; };
-
-template <int EPW, typename ObsT>
-__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK)
-void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec inj, ObsT* __restrict__ obs,
-                       int want_obs, uint8_t* __restrict__ failed) {
-    EnvSlot<EPW> slot(a.n_envs);
-    if (slot.wave_idle(a.n_envs)) return;
-    const int lane = slot.lane, env = slot.env;
-    // a group takes part when its env exists and is selected; the wavefront leaves when no group does
-    const bool valid = slot.valid && (!mask || mask[env] != 0);
-    if (__ballot(valid) == 0ull) return;
-    const FlexCfg& c = a.cfg;
-    LaneNet ln;
-    load_lane_net<EPW>(a.net, lane, ln);
-    ln.pq = ln.pq && valid;
-    const int nb = a.n_bus, na = c.n_agents;
-    int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
-    const bool is_bus = ln.bus >= 0, is_bld = ln.agent >= 0;
-    const int ag = is_bld ? ln.agent : 0;
-    double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
-    const bool all_injected = inj.day && inj.hour && inj.interval && inj.e0 && inj.a0;
-    const int max_attempts = all_injected ? 1 : 8;
-    uint32_t episode = (uint32_t)ie[IF_EPISODE];
-
-    bool ok = false;
-    int start = 0, iters = 0, sweeps = 0;
-    int64_t row = 0;
-    double e = 1.0, f = 0.0, e0 = 0.0, pd = 0.0, qd = 0.0, ppv = 0.0, price = 0.0, e_new = 0.0;
-    FlexAct act = {0, 0, 0, 0, 0};
-    for (int attempt = 0; attempt < max_attempts; ++attempt) {
-        // groups that already hold a solvable episode sit out the re-draw (env:83,150-153)
-        const bool need = valid && !ok;
-        if (__ballot(need) == 0ull) break;
-        // group lane j holds Philox block j of this attempt: draws 2j and 2j+1
-        double u0, u1;
-        philox_pair((uint32_t)ln.l, episode, (uint32_t)env, c.seed, u0, u1);
-        const double uh = flex_draw(u0, u1, 0, ln.base), ud = flex_draw(u0, u1, 1, ln.base);
-        const double ui = flex_draw(u0, u1, 2, ln.base);
-        const int de = 3 + ag, da = 3 + na + 4 * ag;
-        const double ue = flex_draw(u0, u1, de, ln.base);
-        const double ua0 = flex_draw(u0, u1, da, ln.base), ua1 = flex_draw(u0, u1, da + 1, ln.base);
-        const double ua2 = flex_draw(u0, u1, da + 2, ln.base), ua3 = flex_draw(u0, u1, da + 3, ln.base);
-        const int hour = inj.hour ? inj.hour[env] : (int)(uh * 24.0);                          // env:85,412
-        const int day = inj.day ? inj.day[env] : (int)(ud * (double)c.n_start_days);           // env:86,424
-        const int interval = inj.interval ? inj.interval[env] : (int)(ui * (double)c.per_hour);  // env:87,416
-        const int start_n = interval + hour * c.per_hour + day * 24 * c.per_hour;               // env:477
-        const int64_t row_n = clamp_row((int64_t)start_n + 1, a.rows);                          // steps = 1: env:76,98
-        const double* sr = a.series + row_n * a.cols;
-        const double pd_n = is_bus ? sr[ln.bus] : 0.0, qd_n = is_bus ? sr[nb + ln.bus] : 0.0;
-        const double ppv_n = is_bld ? sr[2 * nb + ag] : 0.0, price_n = sr[2 * nb + na];
-        const double lo = 0.9 * (c.e_max / 2), hi = 1.1 * (c.e_max / 2);                        // env:100
-        double e0_n = 0.0;
-        FlexAct act_n = {0, 0, 0, 0, 0};
-        if (is_bld) {
-            e0_n = inj.e0 ? inj.e0[(int64_t)env * na + ag] : lo + (hi - lo) * ue;
-            const double* ia = inj.a0 ? inj.a0 + ((int64_t)env * na + ag) * 4 : nullptr;
-            const double span = c.action_high - c.action_low;                                   // env:716-719
-            const double av0 = ia ? ia[0] : c.action_low + span * ua0, av1 = ia ? ia[1] : c.action_low + span * ua1;
-            const double av2 = ia ? ia[2] : c.action_low + span * ua2, av3 = ia ? ia[3] : c.action_low + span * ua3;
-            act_n = parse_actions(c, false, av0, av1, av2, av3, pd_n, ppv_n, e0_n);             // env:113-130
-        }
-        const double pnet = pd_n - act_n.pred - ppv_n + act_n.ch - act_n.dis;
-        const double qnet = qd_n - act_n.q;
-        double e_n = 1.0, f_n = 0.0;
-        int it_n = 0, sw_n = 0;
-        LaneNet lt = ln;
-        lt.pq = ln.pq && need;                       // finished groups do not hold up the convergence ballot
-        const bool ok_n = pf_solve<EPW>(a.net, lt, c.solver, need ? pnet : 0.0, need ? qnet : 0.0, e_n, f_n, c.pf_tol,
-                                        c.pf_max_iter, it_n, sw_n);                             // env:134-144
-        if (need) {
-            ok = ok_n; start = start_n; row = row_n; pd = pd_n; qd = qd_n; ppv = ppv_n; price = price_n;
-            e0 = e0_n; act = act_n; e = e_n; f = f_n; iters = it_n; sweeps = sw_n;
-            e_new = e0_n + c.dt * (c.eta_ch * act_n.ch - (1.0 / c.eta_dis) * act_n.dis);        // pf.py:96-98
-            ++episode;
-        }
-    }
-    const double v = sqrt(e * e + f * f);
-    if (ln.pq) {
-        a.st.vm[(int64_t)env * nb + ln.bus] = v;
-        a.st.ve[(int64_t)env * 64 + ln.l] = ok ? e : 1.0;
-        a.st.vf[(int64_t)env * 64 + ln.l] = ok ? f : 0.0;
-    }
-    if (is_bld && valid) {
-        agst[AF_E * FLEX_MAX_AGENTS + ag] = e_new;          // env:147
-        agst[AF_EINIT * FLEX_MAX_AGENTS + ag] = e0;         // A5: stays the pre-solve draw
-        agst[AF_PRED * FLEX_MAX_AGENTS + ag] = act.pred;
-        agst[AF_CH * FLEX_MAX_AGENTS + ag] = act.ch;
-        agst[AF_DIS * FLEX_MAX_AGENTS + ag] = act.dis;
-        agst[AF_Q * FLEX_MAX_AGENTS + ag] = act.q;
-        agst[AF_PCT * FLEX_MAX_AGENTS + ag] = act.pct;
-    }
-    if (ln.l == 0 && valid) {
-        a.st.vm[(int64_t)env * nb + a.net->slack_bus] = 1.0;   // pf.py:53: Vsqr[slack] = 1
-        a.st.cumrew[env] = 0.0;                             // env:77
-        ie[IF_STEPS] = 1;                                   // env:76
-        ie[IF_START] = start;
-        ie[IF_ROW] = (int32_t)row;
-        ie[IF_OBSCNT] = 0;                                  // env:79-80
-        ie[IF_EPISODE] = (int32_t)episode;
-        ie[IF_ITERS] = iters;
-        ie[IF_SWEEPS] = sweeps;
-        if (failed) failed[env] = ok ? 0 : 1;
-    }
-    if (want_obs) push_and_emit_obs<EPW, ObsT>(a, env, valid, ln, 0, pd, qd, ppv, v, price, e_new, obs);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -884,7 +904,8 @@ int flexenv_reset(FlexEnv* e, const uint8_t* mask, const ResetSpec* inj, void* o
 }
 
 int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* reward, uint8_t* done, double* info,
-                 uint8_t* failed, void* obs, int32_t obs_dtype, void* stream) {
+                 uint8_t* failed, void* obs, int32_t obs_dtype, int32_t flags, void* stream) {
+    const int auto_reset = (flags & FLEX_STEP_AUTORESET) ? 1 : 0;
     if (!e || !actions || !reward || !done) return FLEX_EINVAL;
     if (act_dtype != FLEX_F32 && act_dtype != FLEX_F64) return FLEX_EINVAL;
     if (obs && obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64) return FLEX_EINVAL;
@@ -895,7 +916,7 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     const bool f64 = obs && obs_dtype == FLEX_F64;
     const int want = obs ? 1 : 0;
 #define FLEX_LAUNCH_STEP(EPW_, OBS_, ACT_) hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_>), grid, env_block(), 0, s, k, \
-        (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want)
+        (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset)
     const int variant = (epw == 2 ? 4 : 0) + (f64 ? 2 : 0) + (act_dtype == FLEX_F64 ? 1 : 0);
     switch (variant) {
         case 0: FLEX_LAUNCH_STEP(1, float, float); break;

@@ -176,7 +176,9 @@ class VecFlexProvisionEnv:
                                           _ptr(self.failed), _stream()), "flexenv_reset")
         return out
 
-    def step(self, actions, obs_out=None, fuse_obs=False):
+    def step(self, actions, obs_out=None, fuse_obs=False, auto_reset=False):
+        """auto_reset: environments that terminate in this step restart inside the same launch (their row of the
+        fused observation is then the first observation of the new episode)."""
         if actions.device != self.device:
             actions = actions.to(self.device)
         actions = actions.contiguous()
@@ -187,7 +189,8 @@ class VecFlexProvisionEnv:
             out = self.obs if obs_out is None else obs_out
         _lib.check(self.lib.flexenv_step(self.handle, _ptr(actions), self._dtype_tag(actions), _ptr(self.reward),
                                          _ptr(self.done), _ptr(self.info), _ptr(self.failed), _ptr(out),
-                                         self._dtype_tag(out) if out is not None else 0, _stream()), "flexenv_step")
+                                         self._dtype_tag(out) if out is not None else 0,
+                                         _lib.FLEX_STEP_AUTORESET if auto_reset else 0, _stream()), "flexenv_step")
         return self.reward, self.done, self.info
 
     def get_obs(self, obs_out=None):

@@ -193,7 +193,9 @@ class Model(nn.Module):
                                                                           actions_avail=avail, target=False,
                                                                           last_hid=last_hid)
                 actual = self.env_action(action)
-            reward, done, info = env.step(actual, fuse_obs=True)
+            # one launch: step + get_obs, and envs that terminate restart in place (their row of env.obs is then
+            # the first observation of the new episode; the terminal transition is masked by `done` in the loss)
+            reward, done, info = env.step(actual, fuse_obs=True, auto_reset=True)
             next_obs = env.obs
             donef = done.float()
             last_step = donef if t < horizon - 1 else th.ones_like(donef)       # model.py:229
@@ -206,9 +208,8 @@ class Model(nn.Module):
             rew_sum += reward.sum()
             fail_sum += env.failed.sum()
             trainer.steps += 1
-            # next iteration: terminated envs restart from a fresh episode with a zero hidden state
+            # next iteration: terminated envs have restarted; they get a zero hidden state
             obs = next_obs.clone()
-            env.reset(mask=done, obs_out=obs)
             last_hid = hid * (1.0 - donef).view(N, 1, 1)
         trainer.episodes += 1
         denom = float(N * horizon)
@@ -269,12 +270,11 @@ class Model(nn.Module):
                 action, _, _, _, hid = self.get_actions(obs, status="test", exploration=False, actions_avail=avail,
                                                         target=False, last_hid=last_hid)
                 actual = self.env_action(action)
-            reward, done, info = env.step(actual, fuse_obs=True)
+            reward, done, info = env.step(actual, fuse_obs=True, auto_reset=True)
             info_sum += info.sum(0)
             rew_sum += reward.sum()
             donef = done.float()
             obs = env.obs.clone()
-            env.reset(mask=done, obs_out=obs)
             last_hid = hid * (1.0 - donef).view(N, 1, 1)
         vals = th.cat([info_sum, rew_sum.view(1)]).cpu().numpy() / float(N * horizon)
         from ._lib import INFO_KEYS

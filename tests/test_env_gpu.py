@@ -212,3 +212,28 @@ def test_three_agent_variant(net, series_small):
             assert abs(r - reward[i].item()) < TOL
             assert np.allclose(np.stack(o.get_obs()).astype(np.float32), obs[i], rtol=2e-7, atol=0)
     assert obs.shape == (n, 3, 144)
+
+
+def test_auto_reset_in_launch_equals_step_then_masked_reset(net, series_small):
+    """FLEX_STEP_AUTORESET: the fused restart gives the same state, observations and reset-stream position as
+    flexenv_step followed by flexenv_reset(mask=done)."""
+    import torch
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    n = 37
+    rng = np.random.default_rng(23)
+    args = {"episode_limit": 7}                     # 6 steps per episode: several restarts in a short run
+    a = VecFlexProvisionEnv(args, n, series=series_small, net=net, seed=77)
+    b = VecFlexProvisionEnv(args, n, series=series_small, net=net, seed=77)
+    assert torch.equal(a.reset(), b.reset())
+    restarts = 0
+    for t in range(20):
+        acts = torch.from_numpy(rng.uniform(0.5, 1, (n, 5, 4))).cuda()
+        ra, da, ia = a.step(acts, fuse_obs=True, auto_reset=True)
+        rb, db, ib = b.step(acts, fuse_obs=True)
+        b.reset(mask=db, obs_out=b.obs)
+        restarts += int(db.sum().item())
+        assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(ia, ib)
+        assert torch.equal(a.obs, b.obs)
+        for k in ("V", "E", "E_INIT", "PRED", "STEPS", "ROW", "START", "EPISODE", "CUMREW"):
+            assert torch.equal(a.peek(k), b.peek(k)), (t, k)
+    assert restarts == 3 * n
