@@ -120,6 +120,31 @@ __device__ __forceinline__ double grp_segscan_sum(double x, const int (&mk)[6]) 
     if constexpr (EPW == 1) x = fma(dpp_mov_f64<0x143, 0xC, false>(x), __hiloint2double(mk[5], 0), x);
     return x;
 }
+// Two independent scans advanced step by step: the DPP move -> add chain of one component fills the
+// dependency bubbles of the other (issued back to back they would run one after the other).
+template <int EPW>
+__device__ __forceinline__ void grp_scan_sum2(double& x, double& y) {
+#define FLEX_SCAN2_STEP(CTRL, RM, BC) { const double tx = dpp_mov_f64<CTRL, RM, BC>(x), ty = dpp_mov_f64<CTRL, RM, BC>(y); x += tx; y += ty; }
+    FLEX_SCAN2_STEP(0x111, 0xF, true)
+    FLEX_SCAN2_STEP(0x112, 0xF, true)
+    FLEX_SCAN2_STEP(0x114, 0xF, true)
+    FLEX_SCAN2_STEP(0x118, 0xF, true)
+    FLEX_SCAN2_STEP(0x142, 0xA, false)
+    if constexpr (EPW == 1) FLEX_SCAN2_STEP(0x143, 0xC, false)
+#undef FLEX_SCAN2_STEP
+}
+template <int EPW>
+__device__ __forceinline__ void grp_segscan_sum2(double& x, double& y, const int (&mk)[6]) {
+#define FLEX_SEG2_STEP(CTRL, RM, BC, K) { const double m = __hiloint2double(mk[K], 0); \
+    const double tx = dpp_mov_f64<CTRL, RM, BC>(x), ty = dpp_mov_f64<CTRL, RM, BC>(y); x = fma(tx, m, x); y = fma(ty, m, y); }
+    FLEX_SEG2_STEP(0x111, 0xF, true, 0)
+    FLEX_SEG2_STEP(0x112, 0xF, true, 1)
+    FLEX_SEG2_STEP(0x114, 0xF, true, 2)
+    FLEX_SEG2_STEP(0x118, 0xF, true, 3)
+    FLEX_SEG2_STEP(0x142, 0xA, false, 4)
+    if constexpr (EPW == 1) FLEX_SEG2_STEP(0x143, 0xC, false, 5)
+#undef FLEX_SEG2_STEP
+}
 __device__ __forceinline__ double readlane_f64(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
                             __builtin_amdgcn_readlane(__double2loint(x), l));
@@ -293,15 +318,15 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
         }
         pir = ir; pii = ii;
         // sum of injected currents over each subtree
-        const double sr = grp_scan_sum<EPW>(ir), si = grp_scan_sum<EPW>(ii);
+        double sr = ir, si = ii;
+        grp_scan_sum2<EPW>(sr, si);
         const double tr = __shfl(sr, ln.sub_end, FLEX_WAVE) - (sr - ir);
         const double ti = __shfl(si, ln.sub_end, FLEX_WAVE) - (si - ii);
         // voltage rise along the own line: -z*J with J = -(subtree injection)  =>  z * t
         double ar = ln.r * tr - ln.x * ti, ai = ln.r * ti + ln.x * tr;
         // path sum slack -> bus
         if (use_seg) {
-            ar = grp_segscan_sum<EPW>(ar, ln.mk);
-            ai = grp_segscan_sum<EPW>(ai, ln.mk);
+            grp_segscan_sum2<EPW>(ar, ai, ln.mk);
             for (int d = 1; d <= seg_rounds; ++d) {
                 const double br = __shfl(ar, ln.seg_par, FLEX_WAVE), bi = __shfl(ai, ln.seg_par, FLEX_WAVE);
                 if (ln.seg_depth == d) { ar += br; ai += bi; }
