@@ -98,3 +98,30 @@ def from_frames(net, active, reactive, pv, price, time_delta=15) -> SeriesTable:
         raise ValueError("load tables need one column per non-slack bus")
     return SeriesTable(np.ascontiguousarray(np.hstack([z, active, z, reactive, pv, price])),
                        n_bus, pv.shape[1], time_delta)
+
+
+def load_csv_dir(net, data_path, env_args=None) -> SeriesTable:
+    """The reference's on-disk format (env:431-471): ``load_active.csv``, ``load_reactive.csv``,
+    ``pv_active.csv``, ``prices.csv``, each with a time column followed by one column per non-slack bus /
+    per PV / the price.  Scaled by demand_scale / reactive_scale / pv_scale (env:437,446,455), resampled to
+    ``sample_interval`` by mean and linearly interpolated (env:467-471) — with pandas, exactly as the reference does.
+    """
+    import os
+    import pandas as pd
+    a = dict(pv_scale=0.15, demand_scale=1.0, reactive_scale=1.0, sample_interval="15min")
+    a.update(env_args or {})
+
+    def load(name, scale):
+        df = pd.read_csv(os.path.join(data_path, name), index_col=None)
+        df.index = pd.to_datetime(df.iloc[:, 0])
+        df.index.name = "time"
+        df = df.iloc[::1, 1:] * scale
+        return df.resample(a["sample_interval"]).mean().interpolate(method="linear")
+
+    active = load("load_active.csv", a["demand_scale"])
+    reactive = load("load_reactive.csv", a["reactive_scale"])
+    pv = load("pv_active.csv", a["pv_scale"])
+    price = load("prices.csv", 1.0)
+    n = min(len(active), len(reactive), len(pv), len(price))
+    time_delta = int((pv.index[1] - pv.index[0]).seconds // 60)             # env:422
+    return from_frames(net, active.values[:n], reactive.values[:n], pv.values[:n], price.values[:n], time_delta)

@@ -1,0 +1,71 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every function include/flexenv.h declares.
+No compute call is made here (there is no GPU); argument validation that happens before any HIP call is checked."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from safe_marl_amd import build, _lib
+    build.build()                       # hipcc cross-compiles without a GPU
+    return _lib.load()
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "flexenv.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|void|int32_t|const char\*)\s+\*?(flexenv_\w+|pf_solve_batch)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from safe_marl_amd import _lib
+    names = _declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(_lib.SYMBOLS)
+    assert b"gfx950" in lib.flexenv_version()
+
+
+def test_struct_layouts_match_the_header():
+    from safe_marl_amd import _lib
+    assert C.sizeof(_lib.FlexCfg) == 200          # 10 x int32 + 19 x double + uint64
+    assert C.sizeof(_lib.NetFix) == 16 + 6 * 8
+    assert C.sizeof(_lib.SeriesTab) == 24 and C.sizeof(_lib.ResetSpec) == 40
+
+
+def test_bad_arguments_are_rejected_before_any_device_work(lib, net):
+    from safe_marl_amd import _lib
+    h = C.c_void_p()
+    assert lib.flexenv_create(None, None, None, 4, 0, C.byref(h)) == -22            # FLEX_EINVAL
+    cfg = _lib.FlexCfg()
+    cfg.n_agents, cfg.history, cfg.episode_limit, cfg.solver = 5, 24, 96, 1        # FLEX_SOLVER_DENSE is not built
+    nf = _lib.NetFix()
+    st = _lib.SeriesTab(1, 10, 72)
+    assert lib.flexenv_create(C.byref(cfg), C.byref(nf), C.byref(st), 4, 0, C.byref(h)) == -22
+    assert lib.flexenv_step(None, None, 0, None, None, None, None, None, 0, 0, None) == -22
+    assert lib.flexenv_num_envs(None) == 0
+
+
+def test_product_path_fails_loudly_without_the_library(monkeypatch, tmp_path):
+    from safe_marl_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(_lib.FlexLibraryError):
+        _lib.load()
+
+
+def test_no_product_module_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under safe-marl_amd/ may import it."""
+    pkg = os.path.join(ROOT, "safe-marl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "flexenv_oracle" not in text, f
