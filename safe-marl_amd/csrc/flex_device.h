@@ -181,6 +181,43 @@ __device__ __forceinline__ double fast_rcp(double d) {
 
 __device__ __forceinline__ double clipd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
+// The local (per-bus) part of one Newton step, shared by the tree and the dense linear solvers:
+// injected current from branch currents, power mismatch test, right-hand side I_spec - I_calc and the diagonal
+// 2x2 Jacobian block  Yd - d(conj(S/V))/d(e,f).
+struct NewtonLocal { double rhs0, rhs1, d11, d12, d21, d22; bool miss; };
+__device__ __forceinline__ NewtonLocal newton_local(const LaneNet& ln, int maxc, double ps, double qs, double e,
+                                                    double f, double tol) {
+    NewtonLocal o;
+    const double ep0 = __shfl(e, ln.par, FLEX_WAVE), fp0 = __shfl(f, ln.par, FLEX_WAVE);
+    const double ep = ln.par_slack ? 1.0 : ep0, fp = ln.par_slack ? 0.0 : fp0;
+    const double de = ep - e, df = fp - f;
+    const double jr = ln.g * de - ln.b * df, ji = ln.b * de + ln.g * df;   // branch current parent -> bus
+    double ir = -jr, ii = -ji;   // current injected at this bus = children's inflow - own inflow
+#pragma unroll
+    for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) {
+        if (k < maxc) {
+            const bool has = ln.ch[k] >= 0;
+            const int src = has ? ln.ch[k] : ln.lane;
+            const double tr = __shfl(jr, src, FLEX_WAVE), ti = __shfl(ji, src, FLEX_WAVE);
+            ir += has ? tr : 0.0;
+            ii += has ? ti : 0.0;
+        }
+    }
+    // power mismatch  S_calc - S_spec,  S_calc = V conj(I);  NaN counts as a miss
+    const double dP = e * ir + f * ii - ps;
+    const double dQ = f * ir - e * ii - qs;
+    o.miss = ln.pq && !(fmax(fabs(dP), fabs(dQ)) < tol);
+    // specified current conj(S/V) and its derivative wrt (e, f)
+    const double inv_d = fast_rcp(e * e + f * f);
+    const double isr = (ps * e + qs * f) * inv_d, isi = (ps * f - qs * e) * inv_d;
+    o.rhs0 = isr - ir; o.rhs1 = isi - ii;
+    o.d11 = ln.gd - (ps - 2.0 * e * isr) * inv_d;
+    o.d12 = -ln.bd - (qs - 2.0 * f * isr) * inv_d;
+    o.d21 = ln.bd - (-qs - 2.0 * e * isi) * inv_d;
+    o.d22 = ln.gd - (ps - 2.0 * f * isi) * inv_d;
+    return o;
+}
+
 // ---- Newton-Raphson on the Ybus, current-mismatch form, rectangular coordinates ---------------
 // Unknowns per PQ bus: V = e + jf.  Residual per bus (utils/pf.py:65-94 restated on the Ybus,
 // SURVEY.md App. B):   R_i = sum_k Y_ik V_k - conj(S_i / V_i),   S_i = -(Pnet_i + j Qnet_i).
@@ -204,40 +241,13 @@ __device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, c
     bool ok = false;
     iters = max_iter;
     for (int it = 0;; ++it) {
-        // branch current from the parent into this bus
-        const double ep0 = __shfl(e, ln.par, FLEX_WAVE), fp0 = __shfl(f, ln.par, FLEX_WAVE);
-        const double ep = ln.par_slack ? 1.0 : ep0, fp = ln.par_slack ? 0.0 : fp0;
-        const double de = ep - e, df = fp - f;
-        const double jr = ln.g * de - ln.b * df, ji = ln.b * de + ln.g * df;
-        double ir = -jr, ii = -ji;   // current injected at this bus = children's inflow - own inflow
-#pragma unroll
-        for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) {
-            if (k < maxc) {
-                const bool has = ln.ch[k] >= 0;
-                const int src = has ? ln.ch[k] : lane;
-                const double tr = __shfl(jr, src, FLEX_WAVE), ti = __shfl(ji, src, FLEX_WAVE);
-                ir += has ? tr : 0.0;
-                ii += has ? ti : 0.0;
-            }
-        }
-        // power mismatch  S_calc - S_spec,  S_calc = V conj(I);  NaN counts as a miss
-        const double dP = e * ir + f * ii - ps;
-        const double dQ = f * ir - e * ii - qs;
-        const bool miss = ln.pq && !(fmax(fabs(dP), fabs(dQ)) < tol);
+        NewtonLocal nl = newton_local(ln, maxc, ps, qs, e, f, tol);
         bool wave_miss;
-        const bool grp_miss = grp_any<EPW>(miss, ln.grp, wave_miss);
+        const bool grp_miss = grp_any<EPW>(nl.miss, ln.grp, wave_miss);
         if (!grp_miss && !ok) { ok = true; iters = it; }
         if (!wave_miss) break;
         if (it >= max_iter) break;
-
-        // specified current conj(S/V) and its derivative wrt (e, f)
-        const double inv_d = fast_rcp(e * e + f * f);
-        const double isr = (ps * e + qs * f) * inv_d, isi = (ps * f - qs * e) * inv_d;
-        double rhs0 = isr - ir, rhs1 = isi - ii;
-        double d11 = ln.gd - (ps - 2.0 * e * isr) * inv_d;
-        double d12 = -ln.bd - (qs - 2.0 * f * isr) * inv_d;
-        double d21 = ln.bd - (-qs - 2.0 * e * isi) * inv_d;
-        double d22 = ln.gd - (ps - 2.0 * f * isi) * inv_d;
+        double rhs0 = nl.rhs0, rhs1 = nl.rhs1, d11 = nl.d11, d12 = nl.d12, d21 = nl.d21, d22 = nl.d22;
 
         // leaf -> root: D_p -= Yb D_c^-1 Yb ; rhs_p += Yb D_c^-1 rhs_c   (Yb = [[g,-b],[b,g]])
         for (int L = n_levels - 1; L >= 2; --L) {
@@ -343,6 +353,68 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
         f = ai;
     }
     return mine;
+}
+
+// ---- Newton-Raphson with a DENSE LU of the 2n x 2n Jacobian (the north-star's "small batched dense solve") ----
+// Kept as the reference variant for the measurement table: O(n^3) work where the tree elimination does O(n).
+// One environment per wavefront; row r = 2*bus + component lives in lane r, the matrix sits column-major in
+// LDS (32 KB per wavefront: conflict-free column accesses, broadcast pivot-row reads), Gaussian elimination
+// without pivoting in bus order (the 2x2 diagonal blocks dominate), rhs carried in registers.
+// fp64 MFMA would run at the fp64 vector rate on gfx950 (MI355X_MICROARCH.md), so there is no matrix-core path.
+__device__ __forceinline__ bool pf_newton_dense(const DevNet* __restrict__ net, const LaneNet& ln, double pnet,
+                                                double qnet, double& e, double& f, double tol, int max_iter,
+                                                int& iters, double* __restrict__ A /* LDS [64*64] */) {
+    const int maxc = net->max_children, lane = ln.lane, nrow = 2 * net->n_pq;
+    const double ps = -pnet, qs = -qnet;
+    bool ok = false;
+    iters = max_iter;
+    for (int it = 0;; ++it) {
+        const NewtonLocal nl = newton_local(ln, maxc, ps, qs, e, f, tol);
+        if (!__any(nl.miss)) { ok = true; iters = it; break; }
+        if (it >= max_iter) break;
+        // assemble: zero, then every bus lane writes its diagonal block and the two blocks it shares with its parent
+        for (int c = 0; c < 64; ++c) A[c * 64 + lane] = 0.0;
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        if (ln.pq) {
+            const int r0 = 2 * ln.l;
+            A[(r0) * 64 + r0] = nl.d11; A[(r0 + 1) * 64 + r0] = nl.d12;
+            A[(r0) * 64 + r0 + 1] = nl.d21; A[(r0 + 1) * 64 + r0 + 1] = nl.d22;
+            if (!ln.par_slack) {
+                const int p0 = 2 * (ln.par - ln.base);
+                // -Yb = -[[g,-b],[b,g]] couples (bus, parent) both ways
+                A[(p0) * 64 + r0] = -ln.g;     A[(p0 + 1) * 64 + r0] = ln.b;
+                A[(p0) * 64 + r0 + 1] = -ln.b; A[(p0 + 1) * 64 + r0 + 1] = -ln.g;
+                A[(r0) * 64 + p0] = -ln.g;     A[(r0 + 1) * 64 + p0] = ln.b;
+                A[(r0) * 64 + p0 + 1] = -ln.b; A[(r0 + 1) * 64 + p0 + 1] = -ln.g;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        // rhs of row `lane`: bus lane>>1, component lane&1
+        const double r0v = __shfl(nl.rhs0, (lane >> 1) + ln.base, FLEX_WAVE), r1v = __shfl(nl.rhs1, (lane >> 1) + ln.base, FLEX_WAVE);
+        double rhs = (lane & 1) ? r1v : r0v;
+        if (lane >= nrow) rhs = 0.0;
+        // forward elimination
+        for (int k = 0; k < nrow - 1; ++k) {
+            const double piv = A[k * 64 + k];
+            const double m = (lane > k && lane < nrow) ? A[k * 64 + lane] * fast_rcp(piv) : 0.0;
+            const double rk = readlane_f64(rhs, k);
+            rhs -= m * rk;
+            for (int j = k + 1; j < nrow; ++j) {
+                const double akj = A[j * 64 + k];               // pivot row, broadcast
+                A[j * 64 + lane] -= m * akj;                    // own row, conflict-free column access
+            }
+        }
+        // back substitution
+        double x = 0.0;
+        for (int k = nrow - 1; k >= 0; --k) {
+            const double xk = readlane_f64(rhs, k) * fast_rcp(A[k * 64 + k]);
+            if (lane == k) x = xk;
+            if (lane < k) rhs -= A[k * 64 + lane] * xk;
+        }
+        const double dx0 = __shfl(x, 2 * ln.l + ln.base, FLEX_WAVE), dx1 = __shfl(x, 2 * ln.l + 1 + ln.base, FLEX_WAVE);
+        if (ln.pq) { e += dx0; f += dx1; }
+    }
+    return ok;
 }
 
 #define FLEX_MAX_SWEEPS 40

@@ -8,6 +8,7 @@
 #include <vector>
 #include "flex_device.h"
 
+#define FLEX_MAX_DEVICES 16
 #define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { \
     fprintf(stderr, "[flexenv] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
     return FLEX_EHIP; } } while (0)
@@ -601,6 +602,30 @@ void pf_batch_kernel(const DevNet* __restrict__ net, int n, int nb, const double
     }
 }
 
+// The dense-LU Newton variant of the same solve (FLEX_SOLVER_DENSE): one wavefront per environment, the 64 x 64
+// Jacobian in 32 KB of LDS.  Reference variant for the measurement table only.
+__global__ __launch_bounds__(FLEX_WAVE)
+void pf_batch_dense_kernel(const DevNet* __restrict__ net, int n, int nb, const double* __restrict__ pnet,
+                           const double* __restrict__ qnet, double* __restrict__ v, int32_t* __restrict__ iters_out,
+                           uint8_t* __restrict__ failed, double tol, int max_iter) {
+    __shared__ double A[64 * 64];
+    const int lane = threadIdx.x & 63, i = blockIdx.x;
+    if (i >= n) return;
+    LaneNet ln;
+    load_lane_net<1>(net, lane, ln);
+    const double p = ln.pq ? pnet[(int64_t)i * nb + ln.bus] : 0.0;
+    const double q = ln.pq ? qnet[(int64_t)i * nb + ln.bus] : 0.0;
+    double e = 1.0, f = 0.0;
+    int iters = 0;
+    const bool ok = pf_newton_dense(net, ln, p, q, e, f, tol, max_iter, iters, A);
+    if (ln.pq) v[(int64_t)i * nb + ln.bus] = sqrt(e * e + f * f);
+    if (lane == 0) {
+        v[(int64_t)i * nb + net->slack_bus] = 1.0;
+        if (iters_out) iters_out[i] = iters;
+        if (failed) failed[i] = ok ? 0 : 1;
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // Safety layer, madrl/models/safemaddpg.py:142-299, one lane per (env, building).
 // with V_pred(bus) = sP*P_net[bus] + sQ*Q_net[bus] + beta (own-bus only,
@@ -1028,7 +1053,9 @@ int flexenv_poke(FlexEnv* e, int32_t field, const void* dev_in, void* stream) {
 int pf_solve_batch(const NetFix* net, int32_t n, const double* pnet, const double* qnet, double* v, double* isqr,
                    double* pl, double* ql, int32_t* iters, uint8_t* failed, double tol, int32_t max_iter,
                    int32_t solver, void* stream) {
-    if (!net || n < 1 || !pnet || !qnet || !v || (solver != FLEX_SOLVER_TREE && solver != FLEX_SOLVER_SWEEP)) return FLEX_EINVAL;
+    if (!net || n < 1 || !pnet || !qnet || !v) return FLEX_EINVAL;
+    if (solver != FLEX_SOLVER_TREE && solver != FLEX_SOLVER_SWEEP && solver != FLEX_SOLVER_DENSE) return FLEX_EINVAL;
+    if (solver == FLEX_SOLVER_DENSE && (net->n_bus - 1 > 32 || isqr || pl || ql)) return FLEX_EINVAL;   // 64 x 64 Jacobian, |V| only
     DevNet h;
     int32_t dummy_agent = -1;
     // agents are irrelevant for a bare solve: give build_devnet one placeholder building off the slack
@@ -1038,18 +1065,30 @@ int pf_solve_batch(const NetFix* net, int32_t n, const double* pnet, const doubl
     int rc = build_devnet(&nf, 1, &h);
     if (rc != FLEX_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    DevNet* d = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&d, sizeof(DevNet), s));
-    HIP_TRY(hipMemcpyAsync(d, &h, sizeof(DevNet), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));   // h is a stack object
-    if (h.epw == 2)
+    // the device copy of the network tables is cached per device: repeated solves on the same feeder (the normal
+    // case) pay no allocation, copy or synchronisation
+    static DevNet cached_host[FLEX_MAX_DEVICES];
+    static DevNet* cached_dev[FLEX_MAX_DEVICES] = {nullptr};
+    int dev_id = 0;
+    HIP_TRY(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= FLEX_MAX_DEVICES) return FLEX_EINVAL;
+    if (!cached_dev[dev_id] || memcmp(&cached_host[dev_id], &h, sizeof(DevNet)) != 0) {
+        if (!cached_dev[dev_id]) HIP_TRY(hipMalloc((void**)&cached_dev[dev_id], sizeof(DevNet)));
+        HIP_TRY(hipStreamSynchronize(s));                 // nothing in flight may still read the old tables
+        HIP_TRY(hipMemcpy(cached_dev[dev_id], &h, sizeof(DevNet), hipMemcpyHostToDevice));
+        cached_host[dev_id] = h;
+    }
+    DevNet* d = cached_dev[dev_id];
+    if (solver == FLEX_SOLVER_DENSE)
+        hipLaunchKernelGGL(pf_batch_dense_kernel, dim3(n), dim3(FLEX_WAVE), 0, s, d, n, net->n_bus, pnet, qnet, v, iters,
+                           failed, tol, max_iter);
+    else if (h.epw == 2)
         hipLaunchKernelGGL(pf_batch_kernel<2>, env_grid(n, 2), env_block(), 0, s, d, n, net->n_bus, pnet, qnet, v, isqr, pl, ql,
                            iters, failed, tol, max_iter, solver);
     else
         hipLaunchKernelGGL(pf_batch_kernel<1>, env_grid(n, 1), env_block(), 0, s, d, n, net->n_bus, pnet, qnet, v, isqr, pl, ql,
                            iters, failed, tol, max_iter, solver);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipFreeAsync(d, s));
     return FLEX_OK;
 }
 

@@ -117,3 +117,20 @@ def test_other_topology_star_and_chain():
     for solver in SOLVERS:
         out = _solve(net9, p[None], q[None], solver=solver)
         assert np.abs(out["v"][0] - sol["vm"]).max() < TOL_V
+
+
+def test_dense_lu_newton_variant_matches_oracle(net, base_loads):
+    """FLEX_SOLVER_DENSE: Newton with a dense LU of the 64 x 64 Jacobian in LDS (the north-star's reference variant)."""
+    from oracle import pf_oracle
+    p, q = base_loads
+    rng = np.random.default_rng(5)
+    n = 96
+    P = p[None] * rng.uniform(0.0, 1.6, (n, len(p)))
+    Q = q[None] * rng.uniform(-0.5, 1.6, (n, len(p)))
+    out = _solve(net, P, Q, solver=1)
+    assert out["failed"].sum() == 0 and out["iters"].max() <= 6
+    for i in range(0, n, 8):
+        assert np.abs(pf_oracle.nr_polar(net, P[i], Q[i])[0] - out["v"][i]).max() < TOL_V
+    tree = _solve(net, P, Q, solver=0)
+    assert np.array_equal(out["iters"], tree["iters"] % 1000)          # same Newton iteration, different linear solver
+    assert np.abs(out["v"] - tree["v"]).max() < 1e-13
