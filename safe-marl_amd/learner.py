@@ -182,16 +182,25 @@ class Model(nn.Module):
         horizon = min(args.max_steps, env.episode_limit - 1)
         obs = env.reset().clone()
         last_hid = th.zeros(N, self.n_, self.hid_dim, device=self.device)
-        avail = th.ones(N, self.n_, self.act_dim, device=self.device)
-        zeros_v = th.zeros(N, self.n_, 1, device=self.device)
         info_sum = th.zeros(env.info.shape[1], dtype=th.float64, device=self.device)
         rew_sum = th.zeros((), dtype=th.float64, device=self.device)
         fail_sum = th.zeros((), dtype=th.float64, device=self.device)
+        buf = trainer.replay_buffer
+        buf.const_shapes = {"log_prob_a": (self.n_, self.act_dim), "value": (self.n_, 1), "next_value": (self.n_, 1),
+                            "action_avail": (self.n_, self.act_dim)}
+        std = float(self.args.fixed_policy_std)
         for t in range(horizon):
             with th.no_grad():
-                action, action_pol, log_prob_a, _, hid = self.get_actions(obs, status="train", exploration=True,
-                                                                          actions_avail=avail, target=False,
-                                                                          last_hid=last_hid)
+                # exploration of select_action (util.py:57-64): tanh(N(mean, std)); every action is available
+                # (env:721-730), so the restore mask is the identity and log_prob — unused by the DDPG losses — is
+                # not formed.  SAFEMADDPG routes through get_actions for its safety layer.
+                if type(self).get_actions is MADDPG.get_actions and self.args.action_enforcebound:
+                    means, _, hid = self.policy(obs, last_hid=last_hid)
+                    action = action_pol = th.tanh(means + std * th.randn_like(means))
+                else:
+                    avail = th.ones(N, self.n_, self.act_dim, device=self.device)
+                    action, action_pol, _, _, hid = self.get_actions(obs, status="train", exploration=True,
+                                                                     actions_avail=avail, target=False, last_hid=last_hid)
                 actual = self.env_action(action)
             # one launch: step + get_obs, and envs that terminate restart in place (their row of env.obs is then
             # the first observation of the new episode; the terminal transition is masked by `done` in the loss)
@@ -199,10 +208,9 @@ class Model(nn.Module):
             next_obs = env.obs
             donef = done.float()
             last_step = donef if t < horizon - 1 else th.ones_like(donef)       # model.py:229
-            trainer.replay_buffer.add_batch(
-                state=obs, action=action_pol, log_prob_a=log_prob_a, value=zeros_v, next_value=zeros_v,
-                reward=reward.float().unsqueeze(1).expand(N, self.n_), next_state=next_obs, done=donef,
-                last_step=last_step, action_avail=avail, last_hid=last_hid, hid=hid)
+            buf.add_batch(state=obs, action=action_pol, log_prob_a=0.0, value=0.0, next_value=0.0,
+                          reward=reward.float().unsqueeze(1).expand(N, self.n_), next_state=next_obs, done=donef,
+                          last_step=last_step, action_avail=1.0, last_hid=last_hid, hid=hid)
             self.transition_update(trainer, None, stat)
             info_sum += info.sum(0)
             rew_sum += reward.sum()
@@ -351,26 +359,33 @@ class MADDPG(Model):
         restore_actions = restore_mask * actions
         return actions, restore_actions, log_prob_a, (means, log_stds), hiddens
 
-    def get_loss(self, batch):
-        """maddpg.py:100-123: policy_loss = -Q(s, pi(s)).mean(); value_loss = (r + gamma (1-done) Q'(s', pi(s')) - Q(s,a))^2.mean()."""
+    def get_loss(self, batch, need="both"):
+        """maddpg.py:100-123: policy_loss = -Q(s, pi(s)).mean(); value_loss = (r + gamma (1-done) Q'(s', pi(s')) - Q(s,a))^2.mean().
+
+        The reference evaluates both losses in every sub-update and uses one (trainer.py:84,101).  ``need`` =
+        "value" / "policy" evaluates only the graph that loss needs — same loss value, same gradients, about half
+        the forward work and no backward through the unused half; "both" is the reference's call."""
         state, actions, _, _, _, rewards, next_state, done, _, actions_avail, last_hids, hids = self.unpack_data(batch)
-        _, actions_pol, _, action_out, _ = self.get_actions(state, status="train", exploration=False,
-                                                            actions_avail=actions_avail, target=False, last_hid=last_hids)
-        _, next_actions, _, _, _ = self.get_actions(next_state, status="train", exploration=False,
-                                                    actions_avail=actions_avail, target=not self.args.double_q,
-                                                    last_hid=hids)
-        values_pol = self.value(state, actions_pol).view(-1, self.n_)
-        values = self.value(state, actions).view(-1, self.n_)
-        next_values = self.target_net.value(next_state, next_actions.detach()).view(-1, self.n_)
-        assert values_pol.size() == next_values.size()
-        returns = rewards + self.args.gamma * (1 - done) * next_values.detach()
-        assert returns.size() == values.size()
-        deltas = returns - values
-        advantages = values_pol
-        if self.args.normalize_advantages:
-            advantages = self.batchnorm(advantages)
-        policy_loss = (-advantages).mean()
-        value_loss = deltas.pow(2).mean()
+        policy_loss = value_loss = None
+        action_out = None
+        if need in ("both", "policy"):
+            _, actions_pol, _, action_out, _ = self.get_actions(state, status="train", exploration=False,
+                                                                actions_avail=actions_avail, target=False,
+                                                                last_hid=last_hids)
+            advantages = self.value(state, actions_pol).view(-1, self.n_)
+            if self.args.normalize_advantages:
+                advantages = self.batchnorm(advantages)
+            policy_loss = (-advantages).mean()
+        if need in ("both", "value"):
+            with th.no_grad():          # the bootstrap target carries no gradient (maddpg.py:110,115: .detach())
+                _, next_actions, _, _, _ = self.get_actions(next_state, status="train", exploration=False,
+                                                            actions_avail=actions_avail, target=not self.args.double_q,
+                                                            last_hid=hids)
+                next_values = self.target_net.value(next_state, next_actions).view(-1, self.n_)
+            values = self.value(state, actions).view(-1, self.n_)
+            returns = rewards + self.args.gamma * (1 - done) * next_values
+            assert returns.size() == values.size()
+            value_loss = (returns - values).pow(2).mean()
         return policy_loss, value_loss, action_out
 
 

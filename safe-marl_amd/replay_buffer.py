@@ -44,6 +44,8 @@ class DeviceReplayBuffer:
         self.head = 0              # physical slot of the oldest transition
         self.length = 0
         self.buffer = _LenView(self)
+        self.consts = {}           # field -> python float, for fields that are never stored
+        self.const_shapes = {}     # field -> trailing shape of the broadcast view
 
     # -- allocation on first use (shapes come from the first transition) ---------------------
     def _alloc(self, shapes):
@@ -61,10 +63,15 @@ class DeviceReplayBuffer:
         return start
 
     def add_batch(self, **fields):
-        """One transition per row: every field is a tensor [B, ...] already on the device."""
+        """One transition per row: every field is a tensor [B, ...] already on the device.  Fields given as a
+        python float are constants (e.g. action_avail = 1.0, the unused value/next_value = 0.0): nothing is stored
+        for them, ``window`` hands out a broadcast view with the shape given in ``const_shapes``."""
+        consts = {k: v for k, v in fields.items() if not isinstance(v, th.Tensor)}
+        fields = {k: v for k, v in fields.items() if isinstance(v, th.Tensor)}
         b = next(iter(fields.values())).shape[0]
         if self.store is None:
             self._alloc({k: v.shape[1:] for k, v in fields.items()})
+            self.consts = dict(consts)
         start = self._slots(b)
         first = min(b, self.size - start)
         for k, v in fields.items():
@@ -106,10 +113,16 @@ class DeviceReplayBuffer:
     def window(self, start, batch_size):
         """Device tensors of logical transitions [start, start+batch_size)."""
         p0 = (self.head + start) % self.size
+        out = {}
+        for k, c in self.consts.items():
+            shape = self.const_shapes.get(k, ())
+            out[k] = th.full((1,) + tuple(1 for _ in shape), float(c), device=self.device).expand((batch_size,) + tuple(shape))
         if p0 + batch_size <= self.size:
-            return Transition(**{k: self.store[k][p0:p0 + batch_size] for k in FIELDS})
-        idx = (p0 + th.arange(batch_size, device=self.device)) % self.size
-        return Transition(**{k: self.store[k].index_select(0, idx) for k in FIELDS})
+            out.update({k: v[p0:p0 + batch_size] for k, v in self.store.items()})
+        else:
+            idx = (p0 + th.arange(batch_size, device=self.device)) % self.size
+            out.update({k: v.index_select(0, idx) for k, v in self.store.items()})
+        return Transition(**out)
 
     def get_batch_tensors(self, batch_size):
         return self.window(self.sample_start(batch_size), batch_size)

@@ -60,8 +60,8 @@ class PGTrainer(object):
     def effective_batch_size(self):
         return self.args.batch_size * self.batch_scale
 
-    def get_loss(self, batch):
-        return self.behaviour_net.get_loss(batch)                                # trainer.py:43-45
+    def get_loss(self, batch, need="both"):
+        return self.behaviour_net.get_loss(batch, need=need)                     # trainer.py:43-45
 
     def _sample(self):
         return self.replay_buffer.get_batch_tensors(self.effective_batch_size())   # trainer.py:67,72
@@ -81,7 +81,7 @@ class PGTrainer(object):
 
     def policy_transition_process(self, stat, trans):
         """trainer.py:81-97 (continuous branch), incl. the constant entropy term of trainer.py:47-57."""
-        policy_loss, _, logits = self.get_loss(trans)
+        policy_loss, _, logits = self.get_loss(trans, need="policy")
         means, log_stds = logits
         self.policy_optimizer.zero_grad()
         if self.entr > 0:
@@ -96,7 +96,7 @@ class PGTrainer(object):
 
     def value_transition_process(self, stat, trans):
         """trainer.py:99-108."""
-        _, value_loss, _ = self.get_loss(trans)
+        _, value_loss, _ = self.get_loss(trans, need="value")
         self.value_optimizer.zero_grad()
         value_loss.backward()
         params = self.value_optimizer.param_groups[0]["params"]

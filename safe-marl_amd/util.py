@@ -18,7 +18,7 @@ def convert(dictionary):
 
 def normal_entropy(mean, std):
     """util.py:35-36"""
-    return Normal(mean, std).entropy().mean()
+    return Normal(mean, std, validate_args=False).entropy().mean()
 
 
 def select_action(args, logits, status="train", exploration=True, info={}):
@@ -36,12 +36,12 @@ def select_action(args, logits, status="train", exploration=True, info={}):
         if not exploration:
             return act_mean, None
         if args.action_enforcebound:
-            normal = Normal(act_mean, act_std)
+            normal = Normal(act_mean, act_std, validate_args=False)   # validation is a device reduction + host sync
             x_t = normal.rsample()
             y_t = th.tanh(x_t)
             log_prob = normal.log_prob(x_t) - th.log(1 - y_t.pow(2) + 1e-6)
             return y_t, log_prob
-        normal = Normal(th.zeros_like(act_mean), act_std)
+        normal = Normal(th.zeros_like(act_mean), act_std, validate_args=False)
         x_t = normal.rsample()
         log_prob = normal.log_prob(x_t)
         if info.get("clip", False):
