@@ -22,4 +22,7 @@ def __getattr__(name):
     if name == "PGTrainer":
         from . import trainer
         return trainer.PGTrainer
+    if name == "PGTester":
+        from . import tester
+        return tester.PGTester
     raise AttributeError(name)

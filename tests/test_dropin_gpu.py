@@ -126,3 +126,40 @@ def test_safemaddpg_actions_pass_through_the_hip_safety_layer(net, series_small)
     stat = {}
     model.train_process(stat, trainer)
     assert trainer.steps == 95 and np.isfinite(stat["mean_train_reward"])
+
+
+def test_tester_record_format_and_resimulation(net, series_small):
+    """utils/tester.py:16-70 record keys; the batched record re-simulates exactly on the CPU oracle."""
+    import torch as th
+    from safe_marl_amd.flex_env import FlexibilityProvisionEnv, VecFlexProvisionEnv
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.tester import PGTester, RECORD_KEYS
+    from oracle.env_oracle import FlexEnvOracle
+    th.manual_seed(0)
+    args = _args()
+    model = MADDPG(args, MADDPG(args))
+    n = 5
+    vec = VecFlexProvisionEnv({}, n, net=net, series=series_small)
+    rng = np.random.default_rng(4)
+    e0, a0 = rng.uniform(0.01125, 0.01375, (n, 5)), rng.uniform(0, 1, (n, 20))
+    days, hours, quarters = [3, 4, 5, 6, 7], [0, 6, 12, 18, 23], [0, 1, 2, 3, 0]
+    rec = PGTester(args, model, vec).run(days, hours, quarters, e0=e0, a0=a0)
+    for k in RECORD_KEYS:
+        assert len(rec[k]) == 96, k                       # reset + 95 steps (tester.py:35-61)
+    assert rec["bus_voltage"][0].shape == (n, 33) and rec["price"][0].shape == (n, 1)
+    assert rec["pv_active"][0].shape == (n, 5) and rec["bus_active"][0].shape == (n, 33)
+    for i in range(n):
+        o = FlexEnvOracle(net, {}, series_small.active, series_small.reactive, series_small.pv, series_small.price)
+        o.reset(spec=(days[i], hours[i], quarters[i], e0[i], a0[i]))
+        assert np.abs(rec["bus_voltage"][0][i] - o.current_voltage).max() < 1e-10
+        for t in range(95):
+            o.step(rec["actions"][t][i].astype(np.float64))
+            o.get_obs()
+            assert np.abs(rec["bus_voltage"][t + 1][i] - o.current_voltage).max() < 1e-10
+            assert np.abs(rec["ess_energy"][t + 1][i] - np.array(o.current_ess_energy)).max() < 1e-10
+            assert np.abs(rec["power_reduction"][t + 1][i] - np.array(o.power_reduction)).max() < 1e-10
+            assert np.abs(rec["bus_active"][t + 1][i] - o.cur_pd).max() == 0
+    # the N=1 drop-in env yields the reference's 1-D entries
+    env = FlexibilityProvisionEnv({"seed": 2}, net=net, series=series_small)
+    rec1 = PGTester(args, model, env).run(3, 0, 0)
+    assert set(RECORD_KEYS) <= set(rec1) and rec1["bus_voltage"][0].shape == (33,) and len(rec1["price"]) == 96
