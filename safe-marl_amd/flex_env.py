@@ -372,7 +372,24 @@ class FlexibilityProvisionEnv:
         return rwd, terminated, info_d
 
     # -- mirrors of the reference's mutable attributes (safemaddpg.py:143-172,237,251) ---------
+    # They are fetched from the device only when somebody reads one (tester.py, safemaddpg.py, run_env.py do;
+    # the MADDPG training loop does not), so a plain step() costs one launch and one small device->host copy.
+    _MIRRORED = ("current_active_demand", "current_reactive_demand", "current_pv_power", "current_price",
+                 "current_voltage", "current_ess_energy", "initial_ess_energy", "power_reduction", "ess_charging",
+                 "ess_discharging", "q_pv", "percentage_reduction", "steps", "cumulative_reward")
+
+    def __getattr__(self, name):
+        if name in FlexibilityProvisionEnv._MIRRORED and "vec" in self.__dict__:
+            self._refresh_now()
+            return self.__dict__[name]
+        raise AttributeError(name)
+
     def _refresh(self):
+        """Invalidate the mirrors; the next attribute read refetches them."""
+        for k in FlexibilityProvisionEnv._MIRRORED:
+            self.__dict__.pop(k, None)
+
+    def _refresh_now(self):
         v = self.vec
         row = int(v.peek("ROW").item())
         data = v.series.table[row]
