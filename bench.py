@@ -52,12 +52,25 @@ def parse_args():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box
+    shows 256 CPUs but grants 16; 256 OpenMP threads on a 16-CPU quota run 10x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(net, series, seconds):
     """The oracle's C restatement timed on this box's host cores (rank 0, N=1 only)."""
     import numpy as np
     from oracle import c_oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     n = 64 * cores
     rng = np.random.default_rng(1234)
     env = c_oracle.COracleEnv(net, series.table, n)
