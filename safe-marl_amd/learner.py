@@ -389,6 +389,85 @@ class MADDPG(Model):
         return policy_loss, value_loss, action_out
 
 
+class MATD3(MADDPG):
+    """madrl/models/matd3.py:8-149: twin centralised critics realised as ONE shared network with
+    a trailing 0/1 input flag (matd3.py:64-67), clipped-double-Q target min(Q1', Q2') (matd3.py:139-140) and a
+    value loss averaged over the twins (matd3.py:148).  Bug-compatible with the reference's action selection, which
+    sums the policy means over the AGENT axis before sampling (matd3.py:92-97)."""
+
+    def construct_value_net(self):
+        """matd3.py:18-27: the MADDPG critic input plus the twin flag."""
+        input_shape = (self.obs_dim + self.act_dim) * self.n_ + 1 + (self.n_ if self.args.agent_id else 0)
+        count = 1 if self.args.shared_params else self.n_
+        self.value_dicts = nn.ModuleList([MLPCritic(input_shape, 1, self.args) for _ in range(count)])
+
+    def value(self, obs, act):
+        """matd3.py:33-86: returns cat([Q1, Q2], dim=0) of shape [2b, n, 1].  Same column-block evaluation as
+        MADDPG.value; the twin flag only adds fc1.weight's last column to the second head's pre-activation."""
+        if not self.args.shared_params:
+            raise NotImplementedError("MATD3 is built for shared_params (default.yaml:26)")
+        b, n, o, a = obs.size(0), self.n_, self.obs_dim, self.act_dim
+        net = self.value_dicts[0]
+        W, bias = net.fc1.weight, net.fc1.bias
+        act_det = act.detach()
+        own = act - act_det
+        off = n * o
+        h = obs.reshape(b, n * o) @ W[:, :off].t() + bias
+        h = h.unsqueeze(1).expand(b, n, -1)
+        if self.args.agent_id:
+            h = h + W[:, off:off + n].t().unsqueeze(0)
+            off += n
+        W_act = W[:, off:off + n * a]
+        h = h + (act_det.reshape(b, n * a) @ W_act.t()).unsqueeze(1) + th.einsum("bia,hia->bih", own, W_act.view(-1, n, a))
+        flag = W[:, off + n * a]                                            # column of the 0/1 twin flag
+        v1, _ = net.forward_from_hidden(h.reshape(b * n, -1))
+        v2, _ = net.forward_from_hidden((h + flag).reshape(b * n, -1))
+        return th.cat([v1.view(b, n, 1), v2.view(b, n, 1)], dim=0)
+
+    def get_actions(self, obs, status, exploration, actions_avail, target=False, last_hid=None, clip=False):
+        """matd3.py:88-111 (continuous branch)."""
+        pol = self.target_net.policy if (target and self.args.target) else self.policy
+        means, log_stds, hiddens = pol(obs, last_hid=last_hid)
+        avail = actions_avail.to(means.device)
+        means = means.masked_fill(avail == 0, 0.0)
+        log_stds = log_stds.masked_fill(avail == 0, 0.0)
+        if means.size(-1) > 1:                                              # matd3.py:94-96: sum over dim=1 (agents)
+            means_, log_stds_ = means.sum(dim=1, keepdim=True), log_stds.sum(dim=1, keepdim=True)
+        else:
+            means_, log_stds_ = means, log_stds
+        actions, log_prob_a = select_action(self.args, means_, status=status, exploration=exploration,
+                                            info={"clip": clip, "log_std": log_stds_})
+        restore_actions = (1.0 - (avail == 0).float()) * actions
+        return actions, restore_actions, log_prob_a, (means, log_stds), hiddens
+
+    def get_loss(self, batch, need="both"):
+        """matd3.py:113-149."""
+        state, actions, _, _, _, rewards, next_state, done, _, actions_avail, last_hids, hids = self.unpack_data(batch)
+        b = state.size(0)
+        policy_loss = value_loss = action_out = None
+        if need in ("both", "policy"):
+            _, actions_pol, _, action_out, _ = self.get_actions(state, status="train", exploration=False,
+                                                                actions_avail=actions_avail, target=False,
+                                                                last_hid=last_hids)
+            advantages = self.value(state, actions_pol)[:b].reshape(-1, self.n_)          # first head only
+            if self.args.normalize_advantages:
+                advantages = self.batchnorm(advantages)
+            policy_loss = (-advantages).mean()
+        if need in ("both", "value"):
+            with th.no_grad():
+                _, next_actions, _, _, _ = self.get_actions(next_state, status="train", exploration=True,
+                                                            actions_avail=actions_avail, target=not self.args.double_q,
+                                                            last_hid=hids, clip=True)
+                nxt = self.target_net.value(next_state, next_actions)
+                next_min = th.min(nxt[:b].reshape(-1, self.n_), nxt[b:].reshape(-1, self.n_))
+            cur = self.value(state, actions)
+            values1, values2 = cur[:b].reshape(-1, self.n_), cur[b:].reshape(-1, self.n_)
+            returns = rewards + self.args.gamma * (1 - done) * next_min
+            assert returns.size() == values1.size() == values2.size()
+            value_loss = 0.5 * ((returns - values1).pow(2).mean() + (returns - values2).pow(2).mean())
+        return policy_loss, value_loss, action_out
+
+
 class SAFEMADDPG(MADDPG):
     """safemaddpg.py:14-299: MADDPG whose get_actions passes the proposed action through the safety layer.
 

@@ -186,6 +186,29 @@ def main():
     g["sched_calls"] = np.array(st.log)
     g["sched_target"] = np.array(n_target)
 
+    # (8) MATD3 (madrl/models/matd3.py): value(), get_loss and grads with a seeded state_dict
+    from madrl.models.matd3 import MATD3
+    th.manual_seed(4321)
+    t3 = MATD3(args)
+    m3 = MATD3(args, t3)
+    np.savez_compressed(os.path.join(OUT, "matd3_state_dict.npz"),
+                        **sd_to_np({k: v.detach().clone() for k, v in m3.state_dict().items()}))
+    up = m3.unpack_data(batch)
+    g["matd3_value"] = m3.value(up[0], up[1]).detach().numpy()
+    th.manual_seed(99)
+    pl, vl, _ = m3.get_loss(batch)
+    g["matd3_policy_loss"], g["matd3_value_loss"] = pl.item(), vl.item()
+    m3.zero_grad()
+    vl.backward()
+    for k, p_ in m3.value_dicts.named_parameters():
+        g["matd3_vgrad." + k] = p_.grad.numpy().copy()
+    th.manual_seed(99)
+    pl2, _, _ = m3.get_loss(batch)
+    m3.zero_grad()
+    pl2.backward()
+    for k, p_ in m3.policy_dicts.named_parameters():
+        g["matd3_pgrad." + k] = p_.grad.numpy().copy()
+
     np.savez_compressed(os.path.join(OUT, "learner_golden.npz"), **g)
     print("wrote", sorted(os.listdir(OUT)))
 

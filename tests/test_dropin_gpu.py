@@ -82,15 +82,17 @@ def test_maddpg_trains_on_the_drop_in_env(net, series_small):
     assert any(k.startswith("target_net.") for k in sd)      # checkpoint format of train_agent.py:144-147
 
 
-def test_maddpg_trains_on_the_vectorised_env(net, series_small):
+@pytest.mark.parametrize("alg", ["maddpg", "matd3"])
+def test_maddpg_trains_on_the_vectorised_env(net, series_small, alg):
     import torch as th
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
-    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd import learner
+    MADDPG = {"maddpg": learner.MADDPG, "matd3": learner.MATD3}[alg]
     from safe_marl_amd.trainer import PGTrainer
     th.manual_seed(0)
     n = 256
     env = VecFlexProvisionEnv({}, n, net=net, series=series_small, seed=3)
-    args = _args(behaviour_update_freq=30, target_update_freq=60)
+    args = _args(behaviour_update_freq=30, target_update_freq=60, alg=alg)
     trainer = PGTrainer(args, MADDPG, env, None, batch_scale=8, replay_capacity=n * 128)
     stat = {}
     trainer.behaviour_net.train_process(stat, trainer)

@@ -206,3 +206,37 @@ def test_critic_block_form_equals_explicit_input(args):
     v2, _ = model.value_dicts[0](rows2.reshape(b * n, -1), None)
     g2, = th.autograd.grad(v2.sum(), act2)
     assert th.allclose(g, g2, atol=1e-5)
+
+
+def test_matd3_matches_reference(gold, args):
+    """madrl/models/matd3.py: twin-flag critic, min-of-twins target, agent-summed action quirk."""
+    from safe_marl_amd.learner import MATD3
+    target = MATD3(args)
+    model = MATD3(args, target)
+    res = model.load_state_dict(_load_sd("matd3_state_dict.npz"), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert model.value_dicts[0].fc1.in_features == 746
+    batch = _batch()
+    v = model.value(batch.state, batch.action)
+    assert v.shape == (64, 5, 1) and np.allclose(v.detach().numpy(), gold["matd3_value"], atol=1e-5)
+    th.manual_seed(99)
+    pl, vl, _ = model.get_loss(batch)
+    assert abs(pl.item() - gold["matd3_policy_loss"]) < 2e-6
+    assert abs(vl.item() - gold["matd3_value_loss"]) < 1e-5 * max(1.0, abs(gold["matd3_value_loss"]))
+    model.zero_grad()
+    vl.backward()
+    for k, p in model.value_dicts.named_parameters():
+        ref = gold["matd3_vgrad." + k]
+        assert np.allclose(p.grad.numpy(), ref, atol=2e-6 + 1e-4 * np.abs(ref).max()), k
+    th.manual_seed(99)
+    pl2, _, _ = model.get_loss(batch)
+    model.zero_grad()
+    pl2.backward()
+    for k, p in model.policy_dicts.named_parameters():
+        ref = gold["matd3_pgrad." + k]
+        assert np.allclose(p.grad.numpy(), ref, atol=2e-7 + 1e-4 * np.abs(ref).max()), k
+    # the single-loss evaluations the trainer uses give the same numbers
+    th.manual_seed(99)
+    _, vl_only, _ = model.get_loss(batch, need="value")
+    pl_only, _, _ = model.get_loss(batch, need="policy")
+    assert abs(vl_only.item() - vl.item()) < 1e-6 and abs(pl_only.item() - pl.item()) < 1e-7
