@@ -229,8 +229,13 @@ class Model(nn.Module):
         stat["mean_train_solver_failed"] = float(vals[-1])
 
     def env_action(self, action):
-        """translate_action (util.py:121-130) kept on the device: [N, n, a] in the env's range."""
-        return scale_action(self.args, action.detach()).view(-1, self.n_, self.act_dim)
+        """translate_action (util.py:121-130) kept on the device: [N, n, a] in the env's range.  MATD3 samples ONE
+        action from the agent-summed mean (matd3.py:92-97) — in the reference that [1,1,a] tensor cannot even be
+        reshaped by env:260; here every agent receives it, which is what its restore_actions broadcast implies."""
+        action = action.detach()
+        if action.dim() == 3 and action.size(1) == 1 and self.n_ > 1:
+            action = action.expand(-1, self.n_, -1)
+        return scale_action(self.args, action).reshape(-1, self.n_, self.act_dim)
 
     def evaluation(self, stat, trainer):
         """model.py:269-306 (test-mode rollouts; next-row f1 of SURVEY §8f)."""
