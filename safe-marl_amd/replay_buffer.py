@@ -37,6 +37,8 @@ class _LenView:
 
 
 class DeviceReplayBuffer:
+    EXACT_STREAM_MAX = 16384       # the reference's buffer holds 5000 transitions (default.yaml:23)
+
     def __init__(self, size, device="cpu"):
         self.size = int(size)
         self.device = th.device(device)
@@ -108,7 +110,12 @@ class DeviceReplayBuffer:
         sample_range = self.length - batch_size + 1
         if sample_range < 1:
             raise ValueError("not enough transitions for a batch")
-        return int(np.random.choice(sample_range, 1, replace=False)[0])      # replay_buffer.py:18-19
+        if sample_range <= self.EXACT_STREAM_MAX:
+            # replay_buffer.py:18-19 verbatim, so that np.random.seed reproduces the reference's index sequence;
+            # NumPy draws it as the head of a full permutation of `sample_range` elements
+            return int(np.random.choice(sample_range, 1, replace=False)[0])
+        # vectorised buffers hold 10^5..10^7 slots: the same uniform start without an O(n) permutation per sample
+        return int(np.random.randint(sample_range))
 
     def window(self, start, batch_size):
         """Device tensors of logical transitions [start, start+batch_size)."""
