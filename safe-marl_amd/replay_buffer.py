@@ -54,6 +54,31 @@ class DeviceReplayBuffer:
         self.store = {k: th.zeros((self.size,) + tuple(s), dtype=th.float32, device=self.device)
                       for k, s in shapes.items()}
 
+    def alloc_packed(self, shapes):
+        """One [size, D] tensor holding every stored field side by side; ``store[field]`` are strided views into it.
+        A whole transition batch then lands with ONE copy (``add_packed``) — what a graph-captured rollout needs —
+        while ``add_batch`` / ``window`` keep working field by field."""
+        widths = {k: int(np.prod(sh)) if len(sh) else 1 for k, sh in shapes.items()}
+        self.packed_cols, off = {}, 0
+        for k, w in widths.items():
+            self.packed_cols[k] = (off, off + w, tuple(shapes[k]))
+            off += w
+        self.store2d = th.zeros(self.size, off, dtype=th.float32, device=self.device)
+        self.store = {k: self.store2d[:, c0:c1].view((self.size,) + sh) for k, (c0, c1, sh) in self.packed_cols.items()}
+
+    def record_views(self, rec):
+        """Field views of a packed [B, D] staging record with the same column layout."""
+        return {k: rec[:, c0:c1].view((rec.shape[0],) + sh) for k, (c0, c1, sh) in self.packed_cols.items()}
+
+    def add_packed(self, rec):
+        b = rec.shape[0]
+        start = self._slots(b)
+        first = min(b, self.size - start)
+        self.store2d[start:start + first].copy_(rec[:first])
+        if first < b:
+            self.store2d[:b - first].copy_(rec[first:])
+        return start
+
     def _slots(self, count):
         """Physical slots for ``count`` new transitions, dropping the oldest when full."""
         if count > self.size:

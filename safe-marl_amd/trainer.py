@@ -29,13 +29,14 @@ _RMSPROP = dict(alpha=0.99, eps=1e-5)       # trainer.py:34-35
 
 
 class PGTrainer(object):
-    def __init__(self, args, model, env, logger, batch_scale=None, replay_capacity=None):
+    def __init__(self, args, model, env, logger, batch_scale=None, replay_capacity=None, graph_rollout=True):
         if args.episodic:
             raise NotImplementedError("episodic replay is outside the MADDPG hot path (default.yaml:9)")
         self.args, self.env, self.logger = args, env, logger
         self.episodic = False
         self.device = th.device("cuda" if th.cuda.is_available() and args.cuda else "cpu")
         self.steps = self.episodes = 0
+        self.graph_rollout = graph_rollout      # vectorised envs: replay each rollout step as one HIP graph
         self.entr = args.entr
         self.world = fdist.world_size()
 
