@@ -270,3 +270,49 @@ def test_env_on_a_45_bus_feeder_one_env_per_wavefront():
     state = vec.get_state().cpu().numpy()
     for i, o in enumerate(oracles):
         assert np.abs(state[i] - o.get_state()).max() < TOL
+
+
+def test_full_size_batch_4096_envs_against_c_oracle(net):
+    """BASELINE.json config 2 at full size: 4096 envs x one whole episode, every step compared with the C restatement
+    (OpenMP over envs), plus the size-independent property that the batch result does not depend on batch position."""
+    import torch
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from oracle import c_oracle
+    s = make_synthetic_series(net, n_days=40)
+    n = 4096
+    rng = np.random.default_rng(101)
+    spec = _spec(rng, n, s, 5)
+    vec = VecFlexProvisionEnv({}, n, series=s, net=net, warm_start=True)
+    obs = vec.reset(spec=spec).cpu().numpy()
+    cenv = c_oracle.COracleEnv(net, s.table, n)
+    start = spec["interval"] + spec["hour"] * 4 + spec["day"] * 96
+    cobs = cenv.reset(start, spec["e0"], spec["a0"])
+    assert cenv.failed.sum() == 0 and vec.failed.sum().item() == 0
+    assert np.allclose(cobs, obs, rtol=2e-7, atol=0)
+    worst_r = worst_v = worst_e = 0.0
+    for t in range(95):
+        acts = rng.uniform(0.0, 1.0, (n, 5, 4)).astype(np.float32)
+        reward, done, info = vec.step(torch.from_numpy(acts).cuda(), fuse_obs=True)
+        r2, d2, i2 = cenv.step(acts.astype(np.float64))
+        worst_r = max(worst_r, np.abs(reward.cpu().numpy() - r2).max())
+        assert np.array_equal(done.cpu().numpy(), d2)
+        assert np.abs(info.cpu().numpy() - i2).max() < 1e-9
+        if t % 8 == 0 or t == 94:
+            worst_v = max(worst_v, np.abs(vec.peek("V").cpu().numpy() - cenv.V).max())
+            worst_e = max(worst_e, np.abs(vec.peek("E").cpu().numpy() - cenv.E).max())
+            assert np.allclose(vec.obs.cpu().numpy(), cenv.obs, rtol=2e-7, atol=0)
+    assert worst_r < TOL and worst_v < TOL and worst_e < TOL
+    assert done.all()
+    # batch-position independence: env i of a 4096-batch equals the same episode run alone
+    k = 1234
+    one = VecFlexProvisionEnv({}, 1, series=s, net=net, warm_start=True)
+    one.reset(spec={key: val[k:k + 1] for key, val in spec.items()})
+    vec.reset(spec=spec)
+    rng2 = np.random.default_rng(7)
+    for t in range(10):
+        acts = rng2.uniform(0.0, 1.0, (n, 5, 4)).astype(np.float32)
+        r_all, _, _ = vec.step(torch.from_numpy(acts).cuda())
+        r_one, _, _ = one.step(torch.from_numpy(acts[k:k + 1]).cuda())
+        assert r_all[k].item() == r_one[0].item()
+    assert torch.equal(vec.peek("V")[k], one.peek("V")[0])

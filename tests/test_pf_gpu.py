@@ -170,3 +170,35 @@ def test_other_feeders_one_env_per_wavefront_path(n_bus, seed):
         for i in range(9):
             sol = pf_oracle.solve_pf(netx, P[i], Q[i])
             assert np.abs(out["v"][i] - sol["vm"]).max() < TOL_V
+
+
+def test_full_size_batch_satisfies_reference_constraints(net, base_loads):
+    """4096 solves at once: the reference's own DistFlow constraints (pf.py:65-94) evaluated in vectorised NumPy on the
+    GPU outputs — a size-independent residual — and linearity of the loss-free part (sum of injections = slack power - losses)."""
+    from safe_marl_amd.network import build_tables
+    p, q = base_loads
+    rng = np.random.default_rng(9)
+    n = 4096
+    P = p[None] * rng.uniform(0.0, 1.5, (n, 33))
+    Q = q[None] * rng.uniform(-0.3, 1.5, (n, 33))
+    out = _solve(net, P, Q, want_branch=True)
+    assert out["failed"].sum() == 0
+    t = build_tables(net)
+    vs = out["v"] ** 2
+    par = t.parent
+    ch = [np.where(par == b)[0] for b in range(t.n_bus)]
+    R, X = t.r[None], t.x[None]
+    pl, ql, isq = out["pl"], out["ql"], out["isqr"]
+    worst = 0.0
+    for b in range(t.n_bus):
+        if b == t.slack:
+            continue
+        # pf.py:65-83 at bus b: inflow - sum_out (flow + loss) - net load = 0
+        rp = pl[:, b] - sum(pl[:, c] + t.r[c] * isq[:, c] for c in ch[b]) - P[:, b]
+        rq = ql[:, b] - sum(ql[:, c] + t.x[c] * isq[:, c] for c in ch[b]) - Q[:, b]
+        worst = max(worst, np.abs(rp).max(), np.abs(rq).max())
+        # pf.py:85-94 on the line parent(b) -> b
+        worst = max(worst, np.abs(isq[:, b] * vs[:, b] - (pl[:, b] ** 2 + ql[:, b] ** 2)).max())
+        worst = max(worst, np.abs(vs[:, par[b]] - 2 * (t.r[b] * pl[:, b] + t.x[b] * ql[:, b])
+                                  - (t.r[b] ** 2 + t.x[b] ** 2) * isq[:, b] - vs[:, b]).max())
+    assert worst < 1e-11

@@ -18,10 +18,10 @@ lib=_lib.load()
 stamps=torch.zeros(N,8,dtype=torch.int64,device='cuda')
 pool=(0.5+0.5*torch.rand(8,N,5,4,device='cuda')).float()
 env.reset()
-for k in range(30): env.step(pool[k%8], fuse_obs=True)
+for k in range(30): env.step(pool[k%8], fuse_obs=True, auto_reset=True)
 lib.flexenv_debug_set_stamps.argtypes=[C.c_void_p]
 lib.flexenv_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
-env.step(pool[0], fuse_obs=True)
+env.step(pool[0], fuse_obs=True, auto_reset=True)
 torch.cuda.synchronize()
 st=stamps.cpu().numpy().astype(np.float64)
 t0=st[:,0].min()
