@@ -134,17 +134,20 @@ struct ObsPlan {
     __device__ __forceinline__ bool writes(int u) const { return u < total && rem < hi; }
     __device__ __forceinline__ int src(int u) const { return 2 * u + shift - (rem >= wrap_at ? sixH : 0); }
 };
-#define FLEX_OBS_CAP 576      // float2 units per environment that fit the register path: 8 agents * 24 history * 3
+// float2 units per environment held in registers by the fast path: OBS_CAP = 384 covers the reference's 5 agents x
+// 24 history x 3 = 360 units without spending address arithmetic on units that do not exist, 576 covers 8 agents.
+#define FLEX_OBS_CAP_SMALL 384
+#define FLEX_OBS_CAP_LARGE 576
 
 typedef int flex_v2i __attribute__((ext_vector_type(2)));
 
 // The ring reads go through a buffer descriptor over the whole ring array: a raw buffer load is never turned
 // into a branch by the compiler (a conditional global_load is, with a full s_waitcnt behind every one of them),
 // the loads issue back to back, and an out-of-range offset returns zeros — which is exactly the zero padding.
-template <int EPW>
+template <int EPW, int OBS_CAP>
 __device__ __forceinline__ void obs_prefetch(const KArgs& a, int env, const LaneNet& ln, int k,
-                                             float2 (&buf)[FLEX_OBS_CAP * EPW / FLEX_WAVE]) {
-    constexpr int LW = FLEX_WAVE / EPW, UNITS = FLEX_OBS_CAP / LW;
+                                             float2 (&buf)[OBS_CAP * EPW / FLEX_WAVE]) {
+    constexpr int LW = FLEX_WAVE / EPW, UNITS = OBS_CAP / LW;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.st.ring, 0, a.ring_bytes, 0x00020000);
     const int env_off = env * (a.cfg.n_agents * a.cfg.history * 6 * 4);      // bytes
     ObsPlan<EPW> pl(ln.l, a.cfg.history, a.cfg.n_agents, k);
@@ -160,11 +163,11 @@ __device__ __forceinline__ void obs_prefetch(const KArgs& a, int env, const Lane
     }
 }
 
-template <int EPW, typename OutT>
+template <int EPW, int OBS_CAP, typename OutT>
 __device__ __forceinline__ void obs_store(const KArgs& a, int env, bool valid, const LaneNet& ln, int k,
-                                          const float2 (&buf)[FLEX_OBS_CAP * EPW / FLEX_WAVE], double pd, double qd,
+                                          const float2 (&buf)[OBS_CAP * EPW / FLEX_WAVE], double pd, double qd,
                                           double ppv, double v, double price, double e, OutT* __restrict__ out) {
-    constexpr int LW = FLEX_WAVE / EPW, UNITS = FLEX_OBS_CAP / LW;
+    constexpr int LW = FLEX_WAVE / EPW, UNITS = OBS_CAP / LW;
     const int H = a.cfg.history, na = a.cfg.n_agents;
     int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
     float* ring = a.st.ring + (int64_t)env * na * H * 6;
@@ -362,7 +365,7 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
 // Residency: 4096 envs are 2048 wavefronts at EPW = 2 (2 per SIMD, <= 256 VGPRs) or 4096 at EPW = 1 (4 per SIMD,
 // <= 128 VGPRs); in both cases the whole batch must be co-resident, otherwise the last blocks start only when the
 // first ones retire and the launch takes twice as long (measured: profiles/).
-template <int EPW, typename ObsT, typename ActT>
+template <int EPW, typename ObsT, typename ActT, int OBS_CAP>
 __global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, (EPW == 1 ? 4 : 2))
 void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restrict__ reward,
                       uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
@@ -409,9 +412,9 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     const double* nr = a.series + new_row * a.cols;
     double n_pd = nr[busi], n_qd = nr[nb + busi], n_ppv = nr[2 * nb + ag];
     const double n_price = nr[2 * nb + na];
-    float2 hist[FLEX_OBS_CAP * EPW / FLEX_WAVE];
-    const bool obs_fast = want_obs && (na * c.history * 3 <= FLEX_OBS_CAP) && a.ring_bytes > 0;
-    obs_prefetch<EPW>(a, env, ln, obs_cnt, hist);      // always issued: with ring_bytes == 0 every load is out of range
+    float2 hist[OBS_CAP * EPW / FLEX_WAVE];
+    const bool obs_fast = want_obs && (na * c.history * 3 <= OBS_CAP) && a.ring_bytes > 0;
+    obs_prefetch<EPW, OBS_CAP>(a, env, ln, obs_cnt, hist);      // always issued: with ring_bytes == 0 every load is out of range
     const bool warm = c.warm_start != 0 && ln.pq;
     double e = warm ? we : 1.0, f = warm ? wf : 0.0;
 
@@ -499,7 +502,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     if (want_obs) {
         n_pd = is_bus ? n_pd : 0.0; n_qd = is_bus ? n_qd : 0.0; n_ppv = is_bld ? n_ppv : 0.0;
         const bool emit = valid && !restart;
-        if (obs_fast) obs_store<EPW, ObsT>(a, env, emit, ln, obs_cnt, hist, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
+        if (obs_fast) obs_store<EPW, OBS_CAP, ObsT>(a, env, emit, ln, obs_cnt, hist, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
         else push_and_emit_obs<EPW, ObsT>(a, env, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
     }
     if (auto_reset && __ballot(restart) != 0ull) {       // wavefront-uniform, taken once per episode
@@ -940,8 +943,12 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     const dim3 grid = env_grid(e->n_envs, epw);
     const bool f64 = obs && obs_dtype == FLEX_F64;
     const int want = obs ? 1 : 0;
-#define FLEX_LAUNCH_STEP(EPW_, OBS_, ACT_) hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_>), grid, env_block(), 0, s, k, \
-        (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset)
+#define FLEX_LAUNCH_STEP(EPW_, OBS_, ACT_) do { \
+        if (small_obs) hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_CAP_SMALL>), grid, env_block(), 0, s, k, \
+            (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset); \
+        else hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_CAP_LARGE>), grid, env_block(), 0, s, k, \
+            (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset); } while (0)
+    const bool small_obs = e->cfg.n_agents * e->cfg.history * 3 <= FLEX_OBS_CAP_SMALL;
     const int variant = (epw == 2 ? 4 : 0) + (f64 ? 2 : 0) + (act_dtype == FLEX_F64 ? 1 : 0);
     switch (variant) {
         case 0: FLEX_LAUNCH_STEP(1, float, float); break;
