@@ -874,24 +874,33 @@ int flexenv_create(const FlexCfg* cfg, const NetFix* net, const SeriesTab* serie
     e->cfg = *cfg; e->n_envs = n_envs; e->n_bus = net->n_bus; e->device = device; e->series = *series;
     int rc = build_devnet(net, cfg->n_agents, &e->hnet);
     if (rc != FLEX_OK) { delete e; return rc; }
-    HIP_TRY(hipSetDevice(device));
+    // allocate everything or nothing
     const int64_t N = n_envs;
-    HIP_TRY(hipMalloc(&e->net, sizeof(DevNet)));
-    HIP_TRY(hipMemcpy(e->net, &e->hnet, sizeof(DevNet), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&e->st.vm, N * net->n_bus * sizeof(double)));
-    HIP_TRY(hipMalloc(&e->st.ve, N * 64 * sizeof(double)));
-    HIP_TRY(hipMalloc(&e->st.vf, N * 64 * sizeof(double)));
-    HIP_TRY(hipMalloc(&e->st.agent, N * AF_COUNT * FLEX_MAX_AGENTS * sizeof(double)));
-    HIP_TRY(hipMalloc(&e->st.cumrew, N * sizeof(double)));
-    HIP_TRY(hipMalloc(&e->st.ienv, N * IF_COUNT * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&e->st.ring, N * cfg->n_agents * cfg->history * 6 * sizeof(float)));
-    HIP_TRY(hipMemset(e->st.vm, 0, N * net->n_bus * sizeof(double)));
-    HIP_TRY(hipMemset(e->st.ve, 0, N * 64 * sizeof(double)));
-    HIP_TRY(hipMemset(e->st.vf, 0, N * 64 * sizeof(double)));
-    HIP_TRY(hipMemset(e->st.agent, 0, N * AF_COUNT * FLEX_MAX_AGENTS * sizeof(double)));
-    HIP_TRY(hipMemset(e->st.cumrew, 0, N * sizeof(double)));
-    HIP_TRY(hipMemset(e->st.ienv, 0, N * IF_COUNT * sizeof(int32_t)));
-    HIP_TRY(hipMemset(e->st.ring, 0, N * cfg->n_agents * cfg->history * 6 * sizeof(float)));
+    const size_t sz_vm = N * net->n_bus * sizeof(double), sz_v = N * 64 * sizeof(double);
+    const size_t sz_ag = N * AF_COUNT * FLEX_MAX_AGENTS * sizeof(double), sz_cr = N * sizeof(double);
+    const size_t sz_ie = N * IF_COUNT * sizeof(int32_t), sz_ring = N * cfg->n_agents * cfg->history * 6 * sizeof(float);
+    hipError_t err = hipSetDevice(device);
+    if (err == hipSuccess) err = hipMalloc(&e->net, sizeof(DevNet));
+    if (err == hipSuccess) err = hipMemcpy(e->net, &e->hnet, sizeof(DevNet), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMalloc(&e->st.vm, sz_vm);
+    if (err == hipSuccess) err = hipMalloc(&e->st.ve, sz_v);
+    if (err == hipSuccess) err = hipMalloc(&e->st.vf, sz_v);
+    if (err == hipSuccess) err = hipMalloc(&e->st.agent, sz_ag);
+    if (err == hipSuccess) err = hipMalloc(&e->st.cumrew, sz_cr);
+    if (err == hipSuccess) err = hipMalloc(&e->st.ienv, sz_ie);
+    if (err == hipSuccess) err = hipMalloc(&e->st.ring, sz_ring);
+    if (err == hipSuccess) err = hipMemset(e->st.vm, 0, sz_vm);
+    if (err == hipSuccess) err = hipMemset(e->st.ve, 0, sz_v);
+    if (err == hipSuccess) err = hipMemset(e->st.vf, 0, sz_v);
+    if (err == hipSuccess) err = hipMemset(e->st.agent, 0, sz_ag);
+    if (err == hipSuccess) err = hipMemset(e->st.cumrew, 0, sz_cr);
+    if (err == hipSuccess) err = hipMemset(e->st.ienv, 0, sz_ie);
+    if (err == hipSuccess) err = hipMemset(e->st.ring, 0, sz_ring);
+    if (err != hipSuccess) {
+        fprintf(stderr, "[flexenv] flexenv_create: %s\n", hipGetErrorString(err));
+        flexenv_destroy(e);            // frees whatever was allocated (null pointers are skipped)
+        return err == hipErrorOutOfMemory ? FLEX_ENOMEM : FLEX_EHIP;
+    }
     *out = e;
     return FLEX_OK;
 }
@@ -899,8 +908,8 @@ int flexenv_create(const FlexCfg* cfg, const NetFix* net, const SeriesTab* serie
 void flexenv_destroy(FlexEnv* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    (void)hipFree(e->net); (void)hipFree(e->st.vm); (void)hipFree(e->st.ve); (void)hipFree(e->st.vf);
-    (void)hipFree(e->st.agent); (void)hipFree(e->st.cumrew); (void)hipFree(e->st.ienv); (void)hipFree(e->st.ring);
+    void* ptrs[] = {e->net, e->st.vm, e->st.ve, e->st.vf, e->st.agent, e->st.cumrew, e->st.ienv, e->st.ring};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
 }
 
