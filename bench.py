@@ -191,7 +191,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "env-steps/sec (33-bus, 4096 envs/GPU)",
+            # BASELINE.json's metric string verbatim; the "+ PF-kernel HBM GB/s" half is `roofline.achieved`
+            "metric": "env-steps/sec (33-bus, 4096 envs/GPU) at 1/2/4/8 MI355X + PF-kernel HBM GB/s",
             "value": total_env_steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
