@@ -34,7 +34,7 @@ DEFAULT_ALG_ARGS = dict(  # madrl/args/default.yaml merged with alg_args/maddpg.
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--alg", choices=["maddpg", "safemaddpg", "matd3"], default="maddpg")
+    ap.add_argument("--alg", choices=["maddpg", "safemaddpg", "matd3", "iddpg"], default="maddpg")
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--episodes", type=int, default=3)
     ap.add_argument("--agents", type=int, default=5, choices=[3, 5])
@@ -44,7 +44,7 @@ def main():
     import torch
     import safe_marl_amd  # noqa: F401
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
-    from safe_marl_amd.learner import MADDPG, MATD3, SAFEMADDPG
+    from safe_marl_amd.learner import IDDPG, MADDPG, MATD3, SAFEMADDPG
     from safe_marl_amd.network import create_network
     from safe_marl_amd.series import make_synthetic_series
     from safe_marl_amd.trainer import PGTrainer
@@ -72,7 +72,7 @@ def main():
                action_dim=4, v_min=0.9, v_max=1.1)
     args = convert(alg)
     torch.manual_seed(0)
-    trainer = PGTrainer(args, {"maddpg": MADDPG, "safemaddpg": SAFEMADDPG, "matd3": MATD3}[a.alg], env, None,
+    trainer = PGTrainer(args, {"maddpg": MADDPG, "safemaddpg": SAFEMADDPG, "matd3": MATD3, "iddpg": IDDPG}[a.alg], env, None,
                         batch_scale=a.batch_scale, replay_capacity=a.envs * 96 * 2)
     stat = {}
     trainer.behaviour_net.train_process(stat, trainer)          # warm-up episode (allocations, rocBLAS plans)

@@ -16,7 +16,7 @@ def __getattr__(name):
     if name in ("TransReplayBuffer", "DeviceReplayBuffer"):
         from . import replay_buffer
         return getattr(replay_buffer, name)
-    if name in ("MADDPG", "SAFEMADDPG", "MATD3", "Model"):
+    if name in ("MADDPG", "SAFEMADDPG", "MATD3", "IDDPG", "Model"):
         from . import learner
         return getattr(learner, name)
     if name == "PGTrainer":

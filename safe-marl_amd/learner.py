@@ -582,6 +582,43 @@ class MATD3(MADDPG):
         return policy_loss, value_loss, action_out
 
 
+class IDDPG(MADDPG):
+    """madrl/models/iddpg.py:7-83 with the loss of madrl/learning_algorithms/ddpg.py:14-37:
+    independent critics Q_i(o_i, a_i) on the agent's own observation and action (plus its one-hot id), the same
+    DDPG losses as MADDPG, and the agent-summed action selection it shares with MATD3 (iddpg.py:66-71)."""
+
+    def construct_value_net(self):
+        """iddpg.py:17-26"""
+        input_shape = self.obs_dim + self.act_dim + (self.n_ if self.args.agent_id else 0)
+        count = 1 if self.args.shared_params else self.n_
+        self.value_dicts = nn.ModuleList([MLPCritic(input_shape, 1, self.args) for _ in range(count)])
+
+    def value(self, obs, act):
+        """iddpg.py:32-59: rows [o_i | onehot(i) | a_i] -> [b, n, 1]."""
+        b = obs.size(0)
+        if self.args.agent_id:
+            ids = th.eye(self.n_, device=obs.device, dtype=obs.dtype).expand(b, -1, -1)
+            obs = th.cat((obs, ids), dim=-1)
+        inputs = th.cat((obs, act), dim=-1)
+        if self.args.shared_params:
+            v, _ = self.value_dicts[0](inputs.reshape(b * self.n_, -1), None)
+            return v.view(b, self.n_, -1)
+        return th.stack([net(inputs[:, i, :], None)[0] for i, net in enumerate(self.value_dicts)], dim=1)
+
+    def get_actions(self, state, status, exploration, actions_avail, target=False, last_hid=None):
+        """iddpg.py:61-83 (continuous branch): the means are summed over the agent axis before sampling."""
+        pol = self.target_net.policy if (target and self.args.target) else self.policy
+        means, log_stds, hiddens = pol(state, last_hid=last_hid)
+        if means.size(-1) > 1:
+            means_, log_stds_ = means.sum(dim=1, keepdim=True), log_stds.sum(dim=1, keepdim=True)
+        else:
+            means_, log_stds_ = means, log_stds
+        actions, log_prob_a = select_action(self.args, means_, status=status, exploration=exploration,
+                                            info={"log_std": log_stds_})
+        restore_actions = (1.0 - (actions_avail.to(means.device) == 0).float()) * actions
+        return actions, restore_actions, log_prob_a, (means, log_stds), hiddens
+
+
 class SAFEMADDPG(MADDPG):
     """safemaddpg.py:14-299: MADDPG whose get_actions passes the proposed action through the safety layer.
 

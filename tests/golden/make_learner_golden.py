@@ -209,6 +209,27 @@ def main():
     for k, p_ in m3.policy_dicts.named_parameters():
         g["matd3_pgrad." + k] = p_.grad.numpy().copy()
 
+    # (9) IDDPG (madrl/models/iddpg.py + learning_algorithms/ddpg.py): value(), losses and grads
+    from madrl.models.iddpg import IDDPG
+    th.manual_seed(2468)
+    ti = IDDPG(args)
+    mi = IDDPG(args, ti)
+    np.savez_compressed(os.path.join(OUT, "iddpg_state_dict.npz"),
+                        **sd_to_np({k: v.detach().clone() for k, v in mi.state_dict().items()}))
+    up = mi.unpack_data(batch)
+    g["iddpg_value"] = mi.value(up[0], up[1]).detach().numpy()
+    pl, vl, _ = mi.rl.get_loss(batch, mi, mi.target_net)
+    g["iddpg_policy_loss"], g["iddpg_value_loss"] = pl.item(), vl.item()
+    mi.zero_grad()
+    vl.backward()
+    for k, p_ in mi.value_dicts.named_parameters():
+        g["iddpg_vgrad." + k] = p_.grad.numpy().copy()
+    pl2, _, _ = mi.rl.get_loss(batch, mi, mi.target_net)
+    mi.zero_grad()
+    pl2.backward()
+    for k, p_ in mi.policy_dicts.named_parameters():
+        g["iddpg_pgrad." + k] = p_.grad.numpy().copy()
+
     np.savez_compressed(os.path.join(OUT, "learner_golden.npz"), **g)
     print("wrote", sorted(os.listdir(OUT)))
 

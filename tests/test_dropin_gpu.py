@@ -82,12 +82,12 @@ def test_maddpg_trains_on_the_drop_in_env(net, series_small):
     assert any(k.startswith("target_net.") for k in sd)      # checkpoint format of train_agent.py:144-147
 
 
-@pytest.mark.parametrize("alg", ["maddpg", "matd3"])
+@pytest.mark.parametrize("alg", ["maddpg", "matd3", "iddpg"])
 def test_maddpg_trains_on_the_vectorised_env(net, series_small, alg):
     import torch as th
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
     from safe_marl_amd import learner
-    MADDPG = {"maddpg": learner.MADDPG, "matd3": learner.MATD3}[alg]
+    MADDPG = {"maddpg": learner.MADDPG, "matd3": learner.MATD3, "iddpg": learner.IDDPG}[alg]
     from safe_marl_amd.trainer import PGTrainer
     th.manual_seed(0)
     n = 256

@@ -240,3 +240,29 @@ def test_matd3_matches_reference(gold, args):
     _, vl_only, _ = model.get_loss(batch, need="value")
     pl_only, _, _ = model.get_loss(batch, need="policy")
     assert abs(vl_only.item() - vl.item()) < 1e-6 and abs(pl_only.item() - pl.item()) < 1e-7
+
+
+def test_iddpg_matches_reference(gold, args):
+    """madrl/models/iddpg.py + learning_algorithms/ddpg.py: independent critics on (o_i, id_i, a_i)."""
+    from safe_marl_amd.learner import IDDPG
+    model = IDDPG(args, IDDPG(args))
+    res = model.load_state_dict(_load_sd("iddpg_state_dict.npz"), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert model.value_dicts[0].fc1.in_features == 144 + 4 + 5
+    batch = _batch()
+    v = model.value(batch.state, batch.action)
+    assert np.allclose(v.detach().numpy(), gold["iddpg_value"], atol=1e-5)
+    pl, vl, _ = model.get_loss(batch)
+    assert abs(pl.item() - gold["iddpg_policy_loss"]) < 2e-6
+    assert abs(vl.item() - gold["iddpg_value_loss"]) < 1e-5 * max(1.0, abs(gold["iddpg_value_loss"]))
+    model.zero_grad()
+    vl.backward()
+    for k, p in model.value_dicts.named_parameters():
+        ref = gold["iddpg_vgrad." + k]
+        assert np.allclose(p.grad.numpy(), ref, atol=2e-6 + 1e-4 * np.abs(ref).max()), k
+    pl2, _, _ = model.get_loss(batch)
+    model.zero_grad()
+    pl2.backward()
+    for k, p in model.policy_dicts.named_parameters():
+        ref = gold["iddpg_pgrad." + k]
+        assert np.allclose(p.grad.numpy(), ref, atol=2e-7 + 1e-4 * np.abs(ref).max()), k
