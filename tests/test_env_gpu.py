@@ -316,3 +316,50 @@ def test_full_size_batch_4096_envs_against_c_oracle(net):
         r_one, _, _ = one.step(torch.from_numpy(acts[k:k + 1]).cuda())
         assert r_all[k].item() == r_one[0].item()
     assert torch.equal(vec.peek("V")[k], one.peek("V")[0])
+
+
+@pytest.mark.parametrize("cfg,blds", [
+    ({"history": 1}, [5, 10, 15, 20, 25]),                                            # no stacking (env:387)
+    ({"history": 3, "episode_limit": 12}, [5, 10, 15, 20, 25]),
+    ({"eta_ch": 0.95, "eta_dis": 0.85, "e_max": 0.03, "e_min": 0.002, "p_ch_max": 0.008, "p_dis_max": 0.004,
+      "v_min": 0.95, "v_max": 1.02, "cos_phi_max": 0.9, "max_power_reduction": 0.3, "pv_cost": 0.08, "ess_cost": 0.01,
+      "discomfort_coeff": 0.4, "voltage_coeff": 2.5}, [5, 10, 15, 20, 25]),           # every yaml scalar moved
+    ({}, [18]),                                                                       # one agent, at the feeder's end
+    ({"history": 30}, [2, 6, 12, 18, 22, 25, 30, 33]),                                # 8 agents x 30 history: beyond the register path
+])
+def test_non_default_configurations(net, cfg, blds):
+    import torch
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from oracle.env_oracle import FlexEnvOracle
+    args = dict(cfg, buildings=blds, pv_nodes=blds, ess_nodes=blds)
+    netx = create_network(args)
+    sx = make_synthetic_series(netx, n_days=8)
+    na, n = len(blds), 11
+    rng = np.random.default_rng(41)
+    vec = VecFlexProvisionEnv(args, n, series=sx, net=netx)
+    H = cfg.get("history", 24)
+    assert vec.obs_size == 6 * H and vec.obs.shape == (n, na, 6 * H)
+    spec = _spec(rng, n, sx, na, e_max=cfg.get("e_max", 0.025))
+    spec["day"] = rng.integers(0, sx.n_start_days(cfg.get("episode_limit", 96)), n).astype(np.int32)
+    obs = vec.reset(spec=spec).cpu().numpy()
+    oracles = [FlexEnvOracle(netx, cfg, sx.active, sx.reactive, sx.pv, sx.price) for _ in range(n)]
+    for i, o in enumerate(oracles):
+        oo, _ = o.reset(spec=(spec["day"][i], spec["hour"][i], spec["interval"][i], spec["e0"][i], spec["a0"][i]))
+        assert np.allclose(np.stack(oo).astype(np.float32), obs[i], rtol=2e-7, atol=0)
+    vp_seen = 0.0
+    for t in range(14):
+        acts = rng.uniform(0, 1, (n, na, 4))
+        reward, done, info = vec.step(torch.from_numpy(acts).cuda(), fuse_obs=(t % 2 == 0))
+        obs = (vec.obs if t % 2 == 0 else vec.get_obs()).cpu().numpy()
+        info = info.cpu().numpy()
+        for i, o in enumerate(oracles):
+            r, d, inf = o.step(acts[i])
+            assert abs(r - reward[i].item()) < TOL and d == bool(done[i].item())
+            assert abs(inf["voltage_penalty"] - info[i, 5]) < TOL and abs(inf["der_cost"] - info[i, 2]) < TOL
+            assert np.allclose(np.stack(o.get_obs()).astype(np.float32), obs[i], rtol=2e-7, atol=0)
+            vp_seen = max(vp_seen, inf["voltage_penalty"])
+    _compare_state(vec, oracles, str(cfg))
+    if "v_min" in cfg:
+        assert vp_seen > 0          # the tightened band really produced penalties
