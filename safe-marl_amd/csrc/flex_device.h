@@ -160,6 +160,31 @@ __device__ __forceinline__ double grp_sum(double v, int grp) {
         return grp ? t1 : t0;
     }
 }
+// Five independent group sums advanced step by step (the reward's five terms): issued one after the other each
+// scan is a chain of dependent DPP moves and adds; interleaved, the chains hide each other's latency.
+template <int EPW>
+__device__ __forceinline__ void grp_sum5(double (&v)[5], int grp) {
+#define FLEX_SUM5_STEP(CTRL, RM, BC) { double t[5]; \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i) t[i] = dpp_mov_f64<CTRL, RM, BC>(v[i]); \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i) v[i] += t[i]; }
+    FLEX_SUM5_STEP(0x111, 0xF, true)
+    FLEX_SUM5_STEP(0x112, 0xF, true)
+    FLEX_SUM5_STEP(0x114, 0xF, true)
+    FLEX_SUM5_STEP(0x118, 0xF, true)
+    FLEX_SUM5_STEP(0x142, 0xA, false)
+    if constexpr (EPW == 1) FLEX_SUM5_STEP(0x143, 0xC, false)
+#undef FLEX_SUM5_STEP
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        if constexpr (EPW == 1) {
+            v[i] = readlane_f64(v[i], 63);
+        } else {
+            const double t0 = readlane_f64(v[i], 31), t1 = readlane_f64(v[i], 63);
+            v[i] = grp ? t1 : t0;
+        }
+    }
+}
+
 // "does any lane of MY group raise the flag", plus the wavefront-wide answer for loop control
 template <int EPW>
 __device__ __forceinline__ bool grp_any(bool p, int grp, bool& wave_any) {

@@ -98,12 +98,14 @@ template <int EPW>
 __device__ __forceinline__ RewardOut reward_terms(const FlexCfg& c, const LaneNet& ln, bool is_bld, double price,
                                                   double pred, double ch, double dis, double q, double v) {
     RewardOut r;
-    r.revenue = grp_sum<EPW>(is_bld ? price * pred : 0.0, ln.grp);
-    r.der = grp_sum<EPW>(is_bld ? c.pv_cost * q : 0.0, ln.grp);                       // signed: SURVEY A6
-    r.ess = grp_sum<EPW>(is_bld ? c.ess_cost * (ch + dis) : 0.0, ln.grp);
-    r.disc = grp_sum<EPW>(is_bld ? c.discomfort_coeff * pred * pred : 0.0, ln.grp);
+    double t[5] = {is_bld ? price * pred : 0.0,
+                   is_bld ? c.pv_cost * q : 0.0,                                    // signed: SURVEY A6
+                   is_bld ? c.ess_cost * (ch + dis) : 0.0,
+                   is_bld ? c.discomfort_coeff * pred * pred : 0.0,
+                   ln.pq ? c.voltage_coeff * fmax(0.0, fmax(v - c.v_max, c.v_min - v)) : 0.0};
+    grp_sum5<EPW>(t, ln.grp);
     const double slack_pen = c.voltage_coeff * fmax(0.0, fmax(1.0 - c.v_max, c.v_min - 1.0));
-    r.vpen = grp_sum<EPW>(ln.pq ? c.voltage_coeff * fmax(0.0, fmax(v - c.v_max, c.v_min - v)) : 0.0, ln.grp) + slack_pen;
+    r.revenue = t[0]; r.der = t[1]; r.ess = t[2]; r.disc = t[3]; r.vpen = t[4] + slack_pen;
     r.reward = r.revenue - r.der - r.ess - r.disc - r.vpen;
     return r;
 }
@@ -118,12 +120,19 @@ struct ObsPlan {
     // rem = u mod (3*history) its history index is h = rem/3, and the ring holds that entry at float offset
     // 2u + 6*s1 - (h + s1 >= history ? 6*history : 0), s1 = (k mod history) + 1: the observation is the ring rotated
     // by s1 rows.  Everything is decided by comparing `rem` with three thresholds — no division per unit.
-    int total, units, H3, rem, step_rem, wrap_at, lo, hi, shift, sixH;
+    int total, units, H3, rem, step_rem, wrap_at, lo, hi, shift, sixH, slot;
+    // x mod m for small non-negative x (< 2^20): one float multiply and a correction instead of an integer division
+    static __device__ __forceinline__ int small_mod(int x, int m) {
+        int r = x - (int)((float)x * (1.0f / (float)m)) * m;
+        r = r < 0 ? r + m : r;
+        return r >= m ? r - m : r;
+    }
     __device__ __forceinline__ ObsPlan(int l, int H, int na, int k) {
         constexpr int LW = FLEX_WAVE / EPW;
         H3 = 3 * H; total = na * H3; units = (total + LW - 1) / LW;
-        rem = l % H3; step_rem = LW % H3;
-        const int s1 = (k % H) + 1;
+        rem = small_mod(l, H3); step_rem = small_mod(LW, H3);
+        slot = small_mod(k, H);
+        const int s1 = slot + 1;
         wrap_at = 3 * (H - s1);                      // rem >= wrap_at: the ring slot wrapped around
         lo = 3 * (H - 1 - k > 0 ? H - 1 - k : 0);    // rem <  lo: before the episode began -> zero padding (A16)
         hi = 3 * (H - 1);                            // rem >= hi: this step's own row, written by the building lanes
@@ -188,12 +197,17 @@ __device__ __forceinline__ void obs_store(const KArgs& a, int env, bool valid, c
         }
     }
     if (valid && ln.agent >= 0) {
-        const double feat[6] = {pd, qd, ppv, v, price, e};   // env:377-382
-        float* r = ring + (ln.agent * H + (k % H)) * 6;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            r[t] = (float)feat[t];
-            o[(ln.agent * H + (H - 1)) * 6 + t] = (OutT)feat[t];
+        // this step's row [Pd, Qd, Ppv, V, price, E] (env:377-382): 24 contiguous bytes, three 8-byte stores each
+        float2* r = reinterpret_cast<float2*>(ring + (ln.agent * H + pl.slot) * 6);
+        r[0] = make_float2((float)pd, (float)qd); r[1] = make_float2((float)ppv, (float)v);
+        r[2] = make_float2((float)price, (float)e);
+        OutT* on = o + (ln.agent * H + (H - 1)) * 6;
+        if constexpr (sizeof(OutT) == 4) {
+            float2* w = reinterpret_cast<float2*>(on);
+            w[0] = r[0]; w[1] = r[1]; w[2] = r[2];
+        } else {
+            double2* w = reinterpret_cast<double2*>(on);
+            w[0] = make_double2(pd, qd); w[1] = make_double2(ppv, v); w[2] = make_double2(price, e);
         }
     }
     if (valid && ln.l == 0) ie[IF_OBSCNT] = k + 1;
