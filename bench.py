@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--warm-start", type=int, default=1)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a one-GPU box together with FLEX_BENCH_ONE_DEVICE=1)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--solver", choices=["sweep", "newton"], default="sweep",
                     help="sweep: backward/forward sweeps + Newton verification; newton: NR with tree elimination")
     return ap.parse_args()
@@ -136,8 +137,36 @@ def main():
         # ONE launch: step + get_obs; envs that terminate restart inside the same launch (FLEX_STEP_AUTORESET)
         env.step(pool[k % ACTION_POOL], fuse_obs=True, auto_reset=True)
 
-    for k in range(a.warmup):
-        one_step(k)
+    # The loop is launch-issue sensitive (9 us of Python + ctypes per launch against a 16 us kernel), so ACTION_POOL
+    # consecutive steps are captured once as a HIP graph and replayed; the steps that do not fill a graph run eagerly.
+    # Work per step is identical either way (one flexenv_step launch); `--no-graph` keeps everything eager.
+    graph = None
+    if not a.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                one_step(0)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for j in range(ACTION_POOL):
+                    one_step(j)
+            graph = g
+        except Exception as exc:                      # capture not available: eager launches
+            print(f"[bench] HIP graph capture failed ({exc}); eager launches", file=sys.stderr)
+            graph = None
+
+    def run_steps(count, first):
+        done_steps = 0
+        if graph is not None:
+            while count - done_steps >= ACTION_POOL:
+                graph.replay()
+                done_steps += ACTION_POOL
+        for k in range(done_steps, count):
+            one_step(first + k)
+
+    run_steps(a.warmup, 0)
 
     def barrier():
         if distributed:
@@ -148,8 +177,7 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for k in range(a.steps):
-        one_step(a.warmup + k)
+    run_steps(a.steps, a.warmup)                          # exactly K steps
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -208,7 +236,7 @@ def main():
                 "workload": "flex_provision.step()+get_obs() batched, 4096 envs/GPU, 33-bus AC power flow (fp64 NR, tol 1e-12), "
                             "5 agents, in-launch auto-reset",
                 "envs_per_gpu": a.envs, "n_agents": env.n_agents, "n_bus": env.n_bus,
-                "warm_start": bool(a.warm_start), "launches_per_step": 1,
+                "warm_start": bool(a.warm_start), "launches_per_step": 1, "hip_graph": graph is not None,
                 "device_ms_per_step": dev_ms / a.steps, "solver": a.solver, "pf_newton_iters_mean": iters_mean, "pf_sweeps_mean": sweeps_mean,
                 "solver_failed_frac": failed_frac,
             },
