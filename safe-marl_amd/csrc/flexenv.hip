@@ -44,10 +44,10 @@ struct FlexEnv {
 #ifdef FLEX_STAMPS
 #define FLEX_STAMP(slot) do { unsigned long long _t; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-    if (a.stamps && (lane & (64 / EPW - 1)) == 0) a.stamps[(int64_t)env * 8 + (slot)] = _t; } while (0)
+    if (a.stamps && (lane & (64 / EPW - 1)) == 0) a.stamps[(int64_t)env * 16 + (slot)] = _t; } while (0)
 #define FLEX_STAMP_RT(slot) do { unsigned long long _t; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-    if (a.stamps && (lane & (64 / EPW - 1)) == 0) a.stamps[(int64_t)env * 8 + (slot)] = _t; } while (0)
+    if (a.stamps && (lane & (64 / EPW - 1)) == 0) a.stamps[(int64_t)env * 16 + (slot)] = _t; } while (0)
 #else
 #define FLEX_STAMP(slot) do { } while (0)
 #define FLEX_STAMP_RT(slot) do { } while (0)
@@ -150,61 +150,87 @@ struct ObsPlan {
 
 typedef int flex_v2i __attribute__((ext_vector_type(2)));
 
-// The ring reads go through a buffer descriptor over the whole ring array: a raw buffer load is never turned
-// into a branch by the compiler (a conditional global_load is, with a full s_waitcnt behind every one of them),
-// the loads issue back to back, and an out-of-range offset returns zeros — which is exactly the zero padding.
-template <int EPW, int OBS_CAP>
-__device__ __forceinline__ void obs_prefetch(const KArgs& a, int env, const LaneNet& ln, int k,
-                                             float2 (&buf)[OBS_CAP * EPW / FLEX_WAVE]) {
+// Per-step results and state are written with nontemporal stores: this launch never reads them back, and lines
+// that do not sit dirty in the per-XCD L2s shorten the write-back that ends the launch (measured: +6 % env-steps/s).
+template <typename T> __device__ __forceinline__ void st_nt(T* p, T v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_nt2(float2* p, float2 v) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(p));
+}
+#define ST_STATE(lhs, v) st_nt(&(lhs), (v))
+#define ST_OUT(lhs, v) st_nt(&(lhs), (v))
+
+
+// History part of the stacked observation: everything except this step's own row, i.e. the ring rotated into place.
+// It depends on nothing the solve produces, so it is copied BEFORE the solve and drains to HBM underneath it.
+// Both directions go through buffer descriptors that cover just this wavefront's environments: a raw buffer access
+// is never turned into a branch by the compiler (a conditional global access is — for a load with a full s_waitcnt
+// behind every one of them), an out-of-range offset reads zeros (exactly the zero padding) or drops the store, and
+// the 32-bit range limit of a descriptor applies per wavefront, not to the whole batch.  The stores are
+// nontemporal: nothing in this launch reads them back, and lines that do not sit dirty in the L2s shorten the
+// write-back at the end of the launch.
+typedef int flex_v4i __attribute__((ext_vector_type(4)));
+#define FLEX_BUF_FLAGS 0x00020000
+#define FLEX_AUX_NT 2            // gfx940+ cache policy: bit 1 = nt
+
+template <int EPW, int OBS_CAP, typename OutT>
+__device__ __forceinline__ void obs_copy_hist(const KArgs& a, int env, bool valid, bool enable, const LaneNet& ln,
+                                              int k, OutT* __restrict__ out) {
     constexpr int LW = FLEX_WAVE / EPW, UNITS = OBS_CAP / LW;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.st.ring, 0, a.ring_bytes, 0x00020000);
-    const int env_off = env * (a.cfg.n_agents * a.cfg.history * 6 * 4);      // bytes
-    ObsPlan<EPW> pl(ln.l, a.cfg.history, a.cfg.n_agents, k);
-    // no branch of any kind around the loads (hipcc waits for every pending load at a control-flow join that
-    // merges its destination register); units beyond the env's size are out-of-range loads, which cost nothing
+    const int H = a.cfg.history, na = a.cfg.n_agents;
+    const int env_floats = na * H * 6;
+    const int env0 = __builtin_amdgcn_readfirstlane(env - ln.grp);              // first environment of the wavefront
+    const int span = enable ? EPW * env_floats : 0;                             // `enable` is launch-uniform
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.st.ring + (int64_t)env0 * env_floats), 0, span * 4, FLEX_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(out + (int64_t)env0 * env_floats), 0, span * (int)sizeof(OutT), FLEX_BUF_FLAGS);
+    const int in_base = ln.grp * env_floats * 4, out_base = ln.grp * env_floats * (int)sizeof(OutT);
+    ObsPlan<EPW> pl(ln.l, H, na, k);
+    float2 buf[UNITS];
+    int dst[UNITS];
 #pragma unroll
     for (int j = 0; j < UNITS; ++j) {
         const int u = ln.l + LW * j;
-        const int off = pl.from_ring(u) ? env_off + 4 * pl.src(u) : -1;   // -1 = 0xFFFFFFFF: out of range -> 0
-        const flex_v2i r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+        const int src = (valid && pl.from_ring(u)) ? in_base + 4 * pl.src(u) : -1;          // -1: out of range -> 0
+        dst[j] = (valid && pl.writes(u)) ? out_base + 2 * (int)sizeof(OutT) * u : -1;       // -1: store dropped
+        const flex_v2i r = __builtin_amdgcn_raw_buffer_load_b64(rin, src, 0, 0);
         buf[j] = make_float2(__int_as_float(r.x), __int_as_float(r.y));
         pl.next();
     }
+#pragma unroll
+    for (int j = 0; j < UNITS; ++j) {
+        if constexpr (sizeof(OutT) == 4) {
+            flex_v2i w; w.x = __float_as_int(buf[j].x); w.y = __float_as_int(buf[j].y);
+            __builtin_amdgcn_raw_buffer_store_b64(w, rout, dst[j], 0, FLEX_AUX_NT);
+        } else {
+            const double dx = (double)buf[j].x, dy = (double)buf[j].y;
+            flex_v4i w; w.x = __double2loint(dx); w.y = __double2hiint(dx); w.z = __double2loint(dy); w.w = __double2hiint(dy);
+            __builtin_amdgcn_raw_buffer_store_b128(w, rout, dst[j], 0, FLEX_AUX_NT);
+        }
+    }
 }
 
-template <int EPW, int OBS_CAP, typename OutT>
-__device__ __forceinline__ void obs_store(const KArgs& a, int env, bool valid, const LaneNet& ln, int k,
-                                          const float2 (&buf)[OBS_CAP * EPW / FLEX_WAVE], double pd, double qd,
-                                          double ppv, double v, double price, double e, OutT* __restrict__ out) {
-    constexpr int LW = FLEX_WAVE / EPW, UNITS = OBS_CAP / LW;
+// This step's row [Pd, Qd, Ppv, V, price, E] (env:377-382) into the ring and the newest slot of the observation.
+template <int EPW, typename OutT>
+__device__ __forceinline__ void obs_store_new(const KArgs& a, int env, bool valid, const LaneNet& ln, int k, double pd,
+                                              double qd, double ppv, double v, double price, double e,
+                                              OutT* __restrict__ out) {
     const int H = a.cfg.history, na = a.cfg.n_agents;
     int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
     float* ring = a.st.ring + (int64_t)env * na * H * 6;
     OutT* o = out + (int64_t)env * na * H * 6;
-    ObsPlan<EPW> pl(ln.l, H, na, k);
-#pragma unroll
-    for (int j = 0; j < UNITS; ++j) {
-        if (j < pl.units) {
-            const int u = ln.l + LW * j;
-            if (valid && pl.writes(u)) {
-                if constexpr (sizeof(OutT) == 4) {
-                    *reinterpret_cast<float2*>(o + 2 * u) = buf[j];
-                } else {
-                    *reinterpret_cast<double2*>(o + 2 * u) = make_double2((double)buf[j].x, (double)buf[j].y);
-                }
-            }
-            pl.next();
-        }
-    }
+    const int slot = ObsPlan<EPW>::small_mod(k, H);
     if (valid && ln.agent >= 0) {
-        // this step's row [Pd, Qd, Ppv, V, price, E] (env:377-382): 24 contiguous bytes, three 8-byte stores each
-        float2* r = reinterpret_cast<float2*>(ring + (ln.agent * H + pl.slot) * 6);
-        r[0] = make_float2((float)pd, (float)qd); r[1] = make_float2((float)ppv, (float)v);
-        r[2] = make_float2((float)price, (float)e);
+        // 24 contiguous bytes, three 8-byte stores each
+        float2* r = reinterpret_cast<float2*>(ring + (ln.agent * H + slot) * 6);
+        const float2 r0 = make_float2((float)pd, (float)qd), r1 = make_float2((float)ppv, (float)v);
+        const float2 r2 = make_float2((float)price, (float)e);
+        st_nt2(r, r0); st_nt2(r + 1, r1); st_nt2(r + 2, r2);
         OutT* on = o + (ln.agent * H + (H - 1)) * 6;
         if constexpr (sizeof(OutT) == 4) {
             float2* w = reinterpret_cast<float2*>(on);
-            w[0] = r[0]; w[1] = r[1]; w[2] = r[2];
+            st_nt2(w, r0); st_nt2(w + 1, r1); st_nt2(w + 2, r2);
         } else {
             double2* w = reinterpret_cast<double2*>(on);
             w[0] = make_double2(pd, qd); w[1] = make_double2(ppv, v); w[2] = make_double2(price, e);
@@ -426,9 +452,10 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     const double* nr = a.series + new_row * a.cols;
     double n_pd = nr[busi], n_qd = nr[nb + busi], n_ppv = nr[2 * nb + ag];
     const double n_price = nr[2 * nb + na];
-    float2 hist[OBS_CAP * EPW / FLEX_WAVE];
-    const bool obs_fast = want_obs && (na * c.history * 3 <= OBS_CAP) && a.ring_bytes > 0;
-    obs_prefetch<EPW, OBS_CAP>(a, env, ln, obs_cnt, hist);      // always issued: with ring_bytes == 0 every load is out of range
+    const bool obs_fast = want_obs && (na * c.history * 3 <= OBS_CAP);
+    // the history part of the observation is copied now; an environment that turns out to restart below rewrites
+    // its whole observation afterwards (same wavefront, program order)
+    obs_copy_hist<EPW, OBS_CAP, ObsT>(a, env, valid, obs_fast, ln, obs_cnt, obs);
     const bool warm = c.warm_start != 0 && ln.pq;
     double e = warm ? we : 1.0, f = warm ? wf : 0.0;
 
@@ -461,15 +488,15 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
         pred = act.pred; ch = act.ch; dis = act.dis; q = act.q;
         e_new = e_init + c.dt * (c.eta_ch * ch - (1.0 / c.eta_dis) * dis);             // pf.py:96-98
         if (ln.pq) {
-            a.st.vm[(int64_t)env * nb + ln.bus] = v;
-            a.st.ve[(int64_t)env * 64 + ln.l] = e;
-            a.st.vf[(int64_t)env * 64 + ln.l] = f;
+            ST_STATE(a.st.vm[(int64_t)env * nb + ln.bus], v);
+            ST_STATE(a.st.ve[(int64_t)env * 64 + ln.l], e);
+            ST_STATE(a.st.vf[(int64_t)env * 64 + ln.l], f);
         }
         if (is_bld && valid) {
-            agst[AF_PRED * FLEX_MAX_AGENTS + ag] = pred;
-            agst[AF_CH * FLEX_MAX_AGENTS + ag] = ch;
-            agst[AF_DIS * FLEX_MAX_AGENTS + ag] = dis;
-            agst[AF_Q * FLEX_MAX_AGENTS + ag] = q;
+            ST_STATE(agst[AF_PRED * FLEX_MAX_AGENTS + ag], pred);
+            ST_STATE(agst[AF_CH * FLEX_MAX_AGENTS + ag], ch);
+            ST_STATE(agst[AF_DIS * FLEX_MAX_AGENTS + ag], dis);
+            ST_STATE(agst[AF_Q * FLEX_MAX_AGENTS + ag], q);
         }
     } else {                                                                           // env:314-328
         v = is_bus ? a.st.vm[(int64_t)env * nb + ln.bus] : 1.0;
@@ -480,9 +507,9 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
         e_new = e_cur;
     }
     if (is_bld && valid) {
-        agst[AF_PCT * FLEX_MAX_AGENTS + ag] = act.pct;
-        agst[AF_E * FLEX_MAX_AGENTS + ag] = e_new;
-        agst[AF_EINIT * FLEX_MAX_AGENTS + ag] = e_new;                                 // env:354
+        ST_STATE(agst[AF_PCT * FLEX_MAX_AGENTS + ag], act.pct);
+        ST_STATE(agst[AF_E * FLEX_MAX_AGENTS + ag], e_new);
+        ST_STATE(agst[AF_EINIT * FLEX_MAX_AGENTS + ag], e_new);                                 // env:354
     }
 
     RewardOut rw = reward_terms<EPW>(c, ln, is_bld, price, pred, ch, dis, q, v);        // env:330-335
@@ -492,15 +519,15 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     const int new_steps = steps + 1;                                                   // env:342
     const bool term = (new_steps >= c.episode_limit) || !ok;                           // env:345
     if (ln.l == 0 && valid) {
-        reward[env] = rwd;
+        ST_OUT(reward[env], rwd);
         done[env] = term ? 1 : 0;
         if (failed) failed[env] = ok ? 0 : 1;
         if (info) {
             double* io = info + (int64_t)env * FLEX_INFO_W;
-            io[0] = rw.reward; io[1] = rw.revenue; io[2] = rw.der; io[3] = rw.ess;
-            io[4] = rw.disc; io[5] = rw.vpen; io[6] = cum_before;                      // A9
+            ST_OUT(io[0], rw.reward); ST_OUT(io[1], rw.revenue); ST_OUT(io[2], rw.der); ST_OUT(io[3], rw.ess);
+            ST_OUT(io[4], rw.disc); ST_OUT(io[5], rw.vpen); ST_OUT(io[6], cum_before);                      // A9
         }
-        a.st.cumrew[env] = cum_before + rwd;                                           // env:343
+        ST_STATE(a.st.cumrew[env], cum_before + rwd);                                           // env:343
         ie[IF_STEPS] = new_steps;
         ie[IF_ROW] = (int32_t)new_row;                                                 // env:340 reads row `steps` (A2)
         ie[IF_ITERS] = iters;
@@ -516,7 +543,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     if (want_obs) {
         n_pd = is_bus ? n_pd : 0.0; n_qd = is_bus ? n_qd : 0.0; n_ppv = is_bld ? n_ppv : 0.0;
         const bool emit = valid && !restart;
-        if (obs_fast) obs_store<EPW, OBS_CAP, ObsT>(a, env, emit, ln, obs_cnt, hist, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
+        if (obs_fast) obs_store_new<EPW, ObsT>(a, env, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
         else push_and_emit_obs<EPW, ObsT>(a, env, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
     }
     if (auto_reset && __ballot(restart) != 0ull) {       // wavefront-uniform, taken once per episode
