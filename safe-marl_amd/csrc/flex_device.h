@@ -462,14 +462,17 @@ __device__ __forceinline__ bool pf_solve(const DevNet* __restrict__ net, const L
 struct FlexAct { double pct, pred, ch, dis, q; };
 
 // _clip_power_charging_discharging, env:628-661 (note env:634 has no dt: SURVEY A4)
-__device__ __forceinline__ void clip_charge(const FlexCfg& c, double& ch, double& dis, double e_now) {
+// `inv_ch`, `inv_dis` are 1/eta_ch and 1/eta_dis computed once on the host (the reference divides, env:634-655;
+// the last-bit difference is far below the parity tolerance and saves four fp64 divisions per lane and step)
+__device__ __forceinline__ void clip_charge(const FlexCfg& c, double inv_ch, double inv_dis, double& ch, double& dis,
+                                            double e_now) {
     ch = clipd(ch, 0.0, c.p_ch_max);
     dis = clipd(dis, 0.0, c.p_dis_max);
-    const double e_next = e_now + c.eta_ch * ch - (1.0 / c.eta_dis) * dis;
+    const double e_next = e_now + c.eta_ch * ch - inv_dis * dis;
     if (e_next > c.e_max) {
         const double excess = e_next - c.e_max;
-        if (ch > excess / c.eta_ch) {
-            ch -= excess / c.eta_ch;
+        if (ch > excess * inv_ch) {
+            ch -= excess * inv_ch;
         } else {
             dis += (excess - ch * c.eta_ch) * c.eta_dis;
             ch = 0.0;
@@ -479,7 +482,7 @@ __device__ __forceinline__ void clip_charge(const FlexCfg& c, double& ch, double
         if (dis > lack * c.eta_dis) {
             dis -= lack * c.eta_dis;
         } else {
-            ch += (lack - dis / c.eta_dis) / c.eta_ch;
+            ch += (lack - dis * inv_dis) * inv_ch;
             dis = 0.0;
         }
     }
@@ -487,8 +490,9 @@ __device__ __forceinline__ void clip_charge(const FlexCfg& c, double& ch, double
     dis = clipd(dis, 0.0, c.p_dis_max);
 }
 
-__device__ __forceinline__ FlexAct parse_actions(const FlexCfg& c, bool raw, double a0, double a1, double a2,
-                                                 double a3, double pd, double ppv, double e_clip) {
+__device__ __forceinline__ FlexAct parse_actions(const FlexCfg& c, double inv_ch, double inv_dis, bool raw, double a0,
+                                                 double a1, double a2, double a3, double pd, double ppv,
+                                                 double e_clip) {
     FlexAct o;
     double pr, ch, dis, q;
     if (raw) {                                   // env:268-274
@@ -505,7 +509,7 @@ __device__ __forceinline__ FlexAct parse_actions(const FlexCfg& c, bool raw, dou
         if (ch > dis) { ch -= dis; dis = 0.0; }
         else { dis -= ch; ch = 0.0; }
     }
-    clip_charge(c, ch, dis, e_clip);             // env:289-290
+    clip_charge(c, inv_ch, inv_dis, ch, dis, e_clip);             // env:289-290
     o.pct = pr; o.ch = ch; o.dis = dis; o.q = q;
     o.pred = pd * pr;                            // env:293
     return o;

@@ -61,7 +61,10 @@ struct KArgs {
     const double* series;
     int64_t rows;
     int32_t cols, n_envs, n_bus;
-    int32_t ring_bytes;        // size of the observation ring, 0 when it does not fit a 32-bit buffer descriptor
+    // derived on the host once per launch so that no lane spends a division on them
+    int32_t row_bytes;         // cols * 8; the series table is addressed with 32-bit byte offsets (checked at create)
+    float inv_h, inv_h3;       // 1/history, 1/(3*history) for the observation plan's small_mod
+    double inv_eta_ch, inv_eta_dis;
 };
 
 __device__ __forceinline__ double load_action(const void* p, int dtype, int64_t i) {
@@ -110,46 +113,6 @@ __device__ __forceinline__ RewardOut reward_terms(const FlexCfg& c, const LaneNe
     return r;
 }
 
-// get_obs (env:370-403): the stacked [n_agents, history*6] observation is a rotated copy of the ring of the last
-// `history` feature rows with zero left-padding (A16), plus this step's row.  The history part does not depend
-// on this step's solve, so its ring reads are issued BEFORE the solve (float2 units held in registers) and
-// only stores remain on the critical path afterwards.  One lane group per environment.
-template <int EPW>
-struct ObsPlan {
-    // Unit u = l + LW*j is the float2 at output offset 2u of this env's [n_agents, history, 6] observation.  With
-    // rem = u mod (3*history) its history index is h = rem/3, and the ring holds that entry at float offset
-    // 2u + 6*s1 - (h + s1 >= history ? 6*history : 0), s1 = (k mod history) + 1: the observation is the ring rotated
-    // by s1 rows.  Everything is decided by comparing `rem` with three thresholds — no division per unit.
-    int total, units, H3, rem, step_rem, wrap_at, lo, hi, shift, sixH, slot;
-    // x mod m for small non-negative x (< 2^20): one float multiply and a correction instead of an integer division
-    static __device__ __forceinline__ int small_mod(int x, int m) {
-        int r = x - (int)((float)x * (1.0f / (float)m)) * m;
-        r = r < 0 ? r + m : r;
-        return r >= m ? r - m : r;
-    }
-    __device__ __forceinline__ ObsPlan(int l, int H, int na, int k) {
-        constexpr int LW = FLEX_WAVE / EPW;
-        H3 = 3 * H; total = na * H3; units = (total + LW - 1) / LW;
-        rem = small_mod(l, H3); step_rem = small_mod(LW, H3);
-        slot = small_mod(k, H);
-        const int s1 = slot + 1;
-        wrap_at = 3 * (H - s1);                      // rem >= wrap_at: the ring slot wrapped around
-        lo = 3 * (H - 1 - k > 0 ? H - 1 - k : 0);    // rem <  lo: before the episode began -> zero padding (A16)
-        hi = 3 * (H - 1);                            // rem >= hi: this step's own row, written by the building lanes
-        shift = 6 * s1; sixH = 6 * H;
-    }
-    __device__ __forceinline__ void next() { rem += step_rem; if (rem >= H3) rem -= H3; }
-    __device__ __forceinline__ bool from_ring(int u) const { return u < total && rem >= lo && rem < hi; }
-    __device__ __forceinline__ bool writes(int u) const { return u < total && rem < hi; }
-    __device__ __forceinline__ int src(int u) const { return 2 * u + shift - (rem >= wrap_at ? sixH : 0); }
-};
-// float2 units per environment held in registers by the fast path: OBS_CAP = 384 covers the reference's 5 agents x
-// 24 history x 3 = 360 units without spending address arithmetic on units that do not exist, 576 covers 8 agents.
-#define FLEX_OBS_CAP_SMALL 384
-#define FLEX_OBS_CAP_LARGE 576
-
-typedef int flex_v2i __attribute__((ext_vector_type(2)));
-
 // Per-step results and state are written with nontemporal stores: this launch never reads them back, and lines
 // that do not sit dirty in the per-XCD L2s shorten the write-back that ends the launch (measured: +6 % env-steps/s).
 template <typename T> __device__ __forceinline__ void st_nt(T* p, T v) { __builtin_nontemporal_store(v, p); }
@@ -157,86 +120,131 @@ __device__ __forceinline__ void st_nt2(float2* p, float2 v) {
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(p));
 }
-#define ST_STATE(lhs, v) st_nt(&(lhs), (v))
-#define ST_OUT(lhs, v) st_nt(&(lhs), (v))
 
+// Addressing: everything a wavefront touches hangs off a handful of wavefront-uniform base pointers (scalar
+// registers, computed on the scalar unit from the kernel arguments and the wavefront's first environment) plus a
+// 32-bit per-lane byte offset — one `global_load v, v_off, s[base]` per access instead of a 64-bit multiply-add
+// chain per lane and access.
+template <typename T> __device__ __forceinline__ T ld_at(const void* base, uint32_t off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + off);
+}
+template <typename T> __device__ __forceinline__ void st_at(void* base, uint32_t off, T v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<T*>(reinterpret_cast<char*>(base) + off));
+}
+__device__ __forceinline__ void st_at2(void* base, uint32_t off, float2 v) {
+    st_nt2(reinterpret_cast<float2*>(reinterpret_cast<char*>(base) + off), v);
+}
+__device__ __forceinline__ int clamp_row32(int r, int rows) { return r < 0 ? 0 : (r >= rows ? rows - 1 : r); }
 
-// History part of the stacked observation: everything except this step's own row, i.e. the ring rotated into place.
-// It depends on nothing the solve produces, so it is copied BEFORE the solve and drains to HBM underneath it.
+// get_obs (env:370-403): the stacked [n_agents, history*6] observation is, per agent, the ring of the last `history`
+// feature rows rotated into place, with zero left-padding (A16), plus this step's row.
+// x mod m for small non-negative x (< 2^20): one float multiply by the host's 1/m and a correction.
+__device__ __forceinline__ int small_mod(int x, int m, float inv_m) {
+    int r = x - (int)((float)x * inv_m) * m;
+    r = r < 0 ? r + m : r;
+    return r >= m ? r - m : r;
+}
+
+// History part of the stacked observation: everything except this step's own row.  It depends on nothing the solve
+// produces, so it is copied BEFORE the solve and drains to HBM underneath it.
+//
+// Work split: in float2 units an agent's block is 3*history units long; group lane l owns the units l, l+LW, l+2LW
+// of EVERY agent's block (FLEX_OBS_CLASSES = 3 covers history <= LW, i.e. 32 rows at two environments per wavefront).
+// With s1 = (k mod history) + 1 the unit `rem` of the output comes from ring unit rem + 3*s1, minus one block length
+// if that runs past the block's end — the same three offsets for every agent, so the per-lane address arithmetic is
+// done three times per step and the agent index only moves the scalar offset of the access.
+//
 // Both directions go through buffer descriptors that cover just this wavefront's environments: a raw buffer access
 // is never turned into a branch by the compiler (a conditional global access is — for a load with a full s_waitcnt
-// behind every one of them), an out-of-range offset reads zeros (exactly the zero padding) or drops the store, and
-// the 32-bit range limit of a descriptor applies per wavefront, not to the whole batch.  The stores are
-// nontemporal: nothing in this launch reads them back, and lines that do not sit dirty in the L2s shorten the
-// write-back at the end of the launch.
+// behind every one of them), an out-of-range offset (-1) reads zeros — exactly the zero padding — or drops the
+// store, and the 32-bit range limit of a descriptor applies per wavefront, not to the whole batch.  The slots of
+// this step's own row are written too (with whatever the ring holds there): obs_store_new overwrites them
+// afterwards, in program order.  The stores are nontemporal: nothing in this launch reads them back, and lines that
+// do not sit dirty in the L2s shorten the write-back at the end of the launch.
+typedef int flex_v2i __attribute__((ext_vector_type(2)));
 typedef int flex_v4i __attribute__((ext_vector_type(4)));
 #define FLEX_BUF_FLAGS 0x00020000
 #define FLEX_AUX_NT 2            // gfx940+ cache policy: bit 1 = nt
+#define FLEX_OBS_CLASSES 3
+#define FLEX_OBS_AGENTS_SMALL 5  // the reference's five buildings: agent loop without a per-agent predicate
+#define FLEX_OBS_AGENTS_LARGE FLEX_MAX_AGENTS
 
-template <int EPW, int OBS_CAP, typename OutT>
-__device__ __forceinline__ void obs_copy_hist(const KArgs& a, int env, bool valid, bool enable, const LaneNet& ln,
-                                              int k, OutT* __restrict__ out) {
-    constexpr int LW = FLEX_WAVE / EPW, UNITS = OBS_CAP / LW;
-    const int H = a.cfg.history, na = a.cfg.n_agents;
+template <int EPW, int NA_CAP, typename OutT>
+__device__ __forceinline__ void obs_copy_hist(const KArgs& a, int env0, int g, bool valid, bool enable,
+                                              const LaneNet& ln, int k, OutT* __restrict__ out) {
+    constexpr int LW = FLEX_WAVE / EPW, CLS = FLEX_OBS_CLASSES;
+    constexpr bool NA_EXACT = NA_CAP == FLEX_OBS_AGENTS_SMALL;                   // host dispatch guarantees na == NA_CAP
+    const int H = a.cfg.history, na = a.cfg.n_agents, H3 = 3 * H;
     const int env_floats = na * H * 6;
-    const int env0 = __builtin_amdgcn_readfirstlane(env - ln.grp);              // first environment of the wavefront
     const int span = enable ? EPW * env_floats : 0;                             // `enable` is launch-uniform
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.st.ring + (int64_t)env0 * env_floats), 0, span * 4, FLEX_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(out + (int64_t)env0 * env_floats), 0, span * (int)sizeof(OutT), FLEX_BUF_FLAGS);
-    const int in_base = ln.grp * env_floats * 4, out_base = ln.grp * env_floats * (int)sizeof(OutT);
-    ObsPlan<EPW> pl(ln.l, H, na, k);
-    float2 buf[UNITS];
-    int dst[UNITS];
+    const int s1 = small_mod(k, H, a.inv_h) + 1;
+    const int wrap_at = 3 * (H - s1);                    // rem >= wrap_at: the ring slot wrapped around
+    const int lo = 3 * (H - 1 - k > 0 ? H - 1 - k : 0);  // rem <  lo: before the episode began -> zero padding (A16)
+    int src[CLS], dst[CLS];
 #pragma unroll
-    for (int j = 0; j < UNITS; ++j) {
-        const int u = ln.l + LW * j;
-        const int src = (valid && pl.from_ring(u)) ? in_base + 4 * pl.src(u) : -1;          // -1: out of range -> 0
-        dst[j] = (valid && pl.writes(u)) ? out_base + 2 * (int)sizeof(OutT) * u : -1;       // -1: store dropped
-        const flex_v2i r = __builtin_amdgcn_raw_buffer_load_b64(rin, src, 0, 0);
-        buf[j] = make_float2(__int_as_float(r.x), __int_as_float(r.y));
-        pl.next();
+    for (int i = 0; i < CLS; ++i) {
+        const int rem = ln.l + LW * i;
+        const bool have = valid && rem < H3;
+        src[i] = (have && rem >= lo) ? g * env_floats * 4 + 8 * (rem + 3 * s1) - (rem >= wrap_at ? 8 * H3 : 0) : -1;
+        dst[i] = have ? g * env_floats * (int)sizeof(OutT) + 2 * (int)sizeof(OutT) * rem : -1;
+    }
+    float2 buf[NA_CAP][CLS];
+#pragma unroll
+    for (int ag = 0; ag < NA_CAP; ++ag) {
+        const bool live = NA_EXACT || ag < na;           // scalar
+#pragma unroll
+        for (int i = 0; i < CLS; ++i) {
+            const flex_v2i r = __builtin_amdgcn_raw_buffer_load_b64(rin, live ? src[i] : -1, ag * H3 * 8, 0);
+            buf[ag][i] = make_float2(__int_as_float(r.x), __int_as_float(r.y));
+        }
     }
 #pragma unroll
-    for (int j = 0; j < UNITS; ++j) {
-        if constexpr (sizeof(OutT) == 4) {
-            flex_v2i w; w.x = __float_as_int(buf[j].x); w.y = __float_as_int(buf[j].y);
-            __builtin_amdgcn_raw_buffer_store_b64(w, rout, dst[j], 0, FLEX_AUX_NT);
-        } else {
-            const double dx = (double)buf[j].x, dy = (double)buf[j].y;
-            flex_v4i w; w.x = __double2loint(dx); w.y = __double2hiint(dx); w.z = __double2loint(dy); w.w = __double2hiint(dy);
-            __builtin_amdgcn_raw_buffer_store_b128(w, rout, dst[j], 0, FLEX_AUX_NT);
+    for (int ag = 0; ag < NA_CAP; ++ag) {
+        const bool live = NA_EXACT || ag < na;
+#pragma unroll
+        for (int i = 0; i < CLS; ++i) {
+            const int d = live ? dst[i] : -1;
+            if constexpr (sizeof(OutT) == 4) {
+                flex_v2i w; w.x = __float_as_int(buf[ag][i].x); w.y = __float_as_int(buf[ag][i].y);
+                __builtin_amdgcn_raw_buffer_store_b64(w, rout, d, ag * H3 * 8, FLEX_AUX_NT);
+            } else {
+                const double dx = (double)buf[ag][i].x, dy = (double)buf[ag][i].y;
+                flex_v4i w; w.x = __double2loint(dx); w.y = __double2hiint(dx); w.z = __double2loint(dy); w.w = __double2hiint(dy);
+                __builtin_amdgcn_raw_buffer_store_b128(w, rout, d, ag * H3 * 16, FLEX_AUX_NT);
+            }
         }
     }
 }
 
 // This step's row [Pd, Qd, Ppv, V, price, E] (env:377-382) into the ring and the newest slot of the observation.
 template <int EPW, typename OutT>
-__device__ __forceinline__ void obs_store_new(const KArgs& a, int env, bool valid, const LaneNet& ln, int k, double pd,
-                                              double qd, double ppv, double v, double price, double e,
+__device__ __forceinline__ void obs_store_new(const KArgs& a, int env0, int g, bool valid, const LaneNet& ln, int k,
+                                              double pd, double qd, double ppv, double v, double price, double e,
                                               OutT* __restrict__ out) {
     const int H = a.cfg.history, na = a.cfg.n_agents;
-    int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
-    float* ring = a.st.ring + (int64_t)env * na * H * 6;
-    OutT* o = out + (int64_t)env * na * H * 6;
-    const int slot = ObsPlan<EPW>::small_mod(k, H);
+    const int env_floats = na * H * 6;
+    float* const ring = a.st.ring + (int64_t)env0 * env_floats;          // wavefront-uniform bases
+    OutT* const o = out + (int64_t)env0 * env_floats;
+    const int slot = small_mod(k, H, a.inv_h);
     if (valid && ln.agent >= 0) {
         // 24 contiguous bytes, three 8-byte stores each
-        float2* r = reinterpret_cast<float2*>(ring + (ln.agent * H + slot) * 6);
         const float2 r0 = make_float2((float)pd, (float)qd), r1 = make_float2((float)ppv, (float)v);
         const float2 r2 = make_float2((float)price, (float)e);
-        st_nt2(r, r0); st_nt2(r + 1, r1); st_nt2(r + 2, r2);
-        OutT* on = o + (ln.agent * H + (H - 1)) * 6;
+        const uint32_t ro = (uint32_t)(g * env_floats + (ln.agent * H + slot) * 6) * 4;
+        st_at2(ring, ro, r0); st_at2(ring, ro + 8, r1); st_at2(ring, ro + 16, r2);
+        const uint32_t oo = (uint32_t)(g * env_floats + (ln.agent * H + (H - 1)) * 6) * (uint32_t)sizeof(OutT);
         if constexpr (sizeof(OutT) == 4) {
-            float2* w = reinterpret_cast<float2*>(on);
-            st_nt2(w, r0); st_nt2(w + 1, r1); st_nt2(w + 2, r2);
+            st_at2(o, oo, r0); st_at2(o, oo + 8, r1); st_at2(o, oo + 16, r2);
         } else {
-            double2* w = reinterpret_cast<double2*>(on);
-            w[0] = make_double2(pd, qd); w[1] = make_double2(ppv, v); w[2] = make_double2(price, e);
+            st_at<double>(o, oo, pd); st_at<double>(o, oo + 8, qd); st_at<double>(o, oo + 16, ppv);
+            st_at<double>(o, oo + 24, v); st_at<double>(o, oo + 32, price); st_at<double>(o, oo + 40, e);
         }
     }
-    if (valid && ln.l == 0) ie[IF_OBSCNT] = k + 1;
+    if (valid && ln.l == 0) st_at<int>(a.st.ienv + (int64_t)env0 * IF_COUNT, (uint32_t)(g * IF_COUNT + IF_OBSCNT) * 4, k + 1);
 }
 
 // General path (history/agent counts beyond the register budget, or no output wanted): same result, ring reads late.
@@ -337,7 +345,7 @@ __device__ __forceinline__ void flex_reset_body(const KArgs& a, int env, bool va
             const double span = c.action_high - c.action_low;                                   // env:716-719
             const double av0 = ia ? ia[0] : c.action_low + span * ua0, av1 = ia ? ia[1] : c.action_low + span * ua1;
             const double av2 = ia ? ia[2] : c.action_low + span * ua2, av3 = ia ? ia[3] : c.action_low + span * ua3;
-            act_n = parse_actions(c, false, av0, av1, av2, av3, pd_n, ppv_n, e0_n);             // env:113-130
+            act_n = parse_actions(c, a.inv_eta_ch, a.inv_eta_dis, false, av0, av1, av2, av3, pd_n, ppv_n, e0_n);             // env:113-130
         }
         const double pnet = pd_n - act_n.pred - ppv_n + act_n.ch - act_n.dis;
         const double qnet = qd_n - act_n.q;
@@ -405,15 +413,20 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
 // Residency: 4096 envs are 2048 wavefronts at EPW = 2 (2 per SIMD, <= 256 VGPRs) or 4096 at EPW = 1 (4 per SIMD,
 // <= 128 VGPRs); in both cases the whole batch must be co-resident, otherwise the last blocks start only when the
 // first ones retire and the launch takes twice as long (measured: profiles/).
-template <int EPW, typename ObsT, typename ActT, int OBS_CAP>
+template <int EPW, typename ObsT, typename ActT, int NA_CAP>
 __global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, (EPW == 1 ? 4 : 2))
 void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restrict__ reward,
                       uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
                       ObsT* __restrict__ obs, int want_obs, int auto_reset) {
-    EnvSlot<EPW> slot(a.n_envs);
-    if (slot.wave_idle(a.n_envs)) return;
-    const int lane = slot.lane, env = slot.env;
-    const bool valid = slot.valid;
+    constexpr int LW = FLEX_WAVE / EPW;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    const int env0 = wave * EPW;                               // first environment of this wavefront
+    if (env0 >= a.n_envs) return;
+    // the spare group of an odd batch computes on env0's inputs (no out-of-bounds reads) and stores nothing
+    const bool valid = env0 + lane / LW < a.n_envs;
+    const int g = valid ? lane / LW : 0;
+    const int env = env0 + g;
     FLEX_STAMP_RT(5);
     FLEX_STAMP(0);
     const FlexCfg& c = a.cfg;
@@ -421,49 +434,63 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     load_lane_net<EPW>(a.net, lane, ln);
     ln.pq = ln.pq && valid;
     const int nb = a.n_bus, na = c.n_agents;
-    int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
-    const int4 iv = *reinterpret_cast<const int4*>(ie);           // steps, start, row, obs_cnt in one load
-    const int steps = iv.x, start = iv.y, obs_cnt = iv.w;
-    const int64_t row = clamp_row(iv.z, a.rows);
     const bool is_bus = ln.bus >= 0, is_bld = ln.agent >= 0;
     const int ag = is_bld ? ln.agent : 0, busi = is_bus ? ln.bus : 0;
+
+    // wavefront-uniform bases and per-lane byte offsets
+    int32_t* const b_ienv = a.st.ienv + (int64_t)env0 * IF_COUNT;
+    double* const b_agent = a.st.agent + (int64_t)env0 * (AF_COUNT * FLEX_MAX_AGENTS);
+    double* const b_ve = a.st.ve + (int64_t)env0 * 64;
+    double* const b_vf = a.st.vf + (int64_t)env0 * 64;
+    double* const b_vm = a.st.vm + (int64_t)env0 * nb;
+    const ActT* const b_act = actions + (int64_t)env0 * (na * 4);
+    const uint32_t o_ienv = g * (IF_COUNT * 4);
+    const uint32_t o_agent = (g * (AF_COUNT * FLEX_MAX_AGENTS) + ag) * 8;          // + field * FLEX_MAX_AGENTS * 8
+    const uint32_t o_volt = (g * 64 + ln.l) * 8;
+    const uint32_t o_bus = busi * 8, o_qbus = (nb + busi) * 8, o_pv = (2 * nb + ag) * 8, o_price = (2 * nb + na) * 8;
+    constexpr uint32_t AFB = FLEX_MAX_AGENTS * 8;                                    // bytes between agent fields
+
+    const int4 iv = ld_at<int4>(b_ienv, o_ienv);                  // steps, start, row, obs_cnt in one load
+    const int steps = iv.x, start = iv.y, obs_cnt = iv.w;
+    const int rows = (int)a.rows;
+    const uint32_t row_off = (uint32_t)clamp_row32(iv.z, rows) * (uint32_t)a.row_bytes;
 
     // Every load below uses an address that is valid in EVERY lane (idle lanes read bus 0 / agent 0) and is
     // issued unconditionally: a conditional load compiles to a branch with a full s_waitcnt behind it, and a
     // handful of those in a row serialise the prologue into as many memory round trips.
     // 1) what the solve needs: current data row (env:340, A2), ESS state, actions, previous voltages
-    const double* sr = a.series + row * a.cols;
-    const double pd_r = sr[busi], qd_r = sr[nb + busi], ppv_r = sr[2 * nb + ag], price = sr[2 * nb + na];
-    double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
-    const double e_cur_r = agst[AF_E * FLEX_MAX_AGENTS + ag], e_init_r = agst[AF_EINIT * FLEX_MAX_AGENTS + ag];
-    const ActT* ap = actions + ((int64_t)env * na + ag) * 4;
+    const double pd_r = ld_at<double>(a.series, row_off + o_bus), qd_r = ld_at<double>(a.series, row_off + o_qbus);
+    const double ppv_r = ld_at<double>(a.series, row_off + o_pv), price = ld_at<double>(a.series, row_off + o_price);
+    const double e_cur_r = ld_at<double>(b_agent, o_agent + AF_E * AFB);
+    const double e_init_r = ld_at<double>(b_agent, o_agent + AF_EINIT * AFB);
+    const uint32_t o_act = (g * na + ag) * (4 * (uint32_t)sizeof(ActT));
     ActT av[4];
     if constexpr (sizeof(ActT) == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(ap);
+        const float4 t = ld_at<float4>(b_act, o_act);
         av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
     } else {
-        const double2 t0 = *reinterpret_cast<const double2*>(ap), t1 = *reinterpret_cast<const double2*>(ap + 2);
+        const double2 t0 = ld_at<double2>(b_act, o_act), t1 = ld_at<double2>(b_act, o_act + 16);
         av[0] = t0.x; av[1] = t0.y; av[2] = t1.x; av[3] = t1.y;
     }
-    const double we = a.st.ve[(int64_t)env * 64 + ln.l], wf = a.st.vf[(int64_t)env * 64 + ln.l];
-    // 2) what only the get_obs() epilogue needs, requested behind the above so that it never delays the solve:
-    //    the row env:340 will load (start + steps, A2) and the history part of the stacked observation
-    const int64_t new_row = clamp_row((int64_t)start + steps, a.rows);
-    const double* nr = a.series + new_row * a.cols;
-    double n_pd = nr[busi], n_qd = nr[nb + busi], n_ppv = nr[2 * nb + ag];
-    const double n_price = nr[2 * nb + na];
-    const bool obs_fast = want_obs && (na * c.history * 3 <= OBS_CAP);
-    // the history part of the observation is copied now; an environment that turns out to restart below rewrites
-    // its whole observation afterwards (same wavefront, program order)
-    obs_copy_hist<EPW, OBS_CAP, ObsT>(a, env, valid, obs_fast, ln, obs_cnt, obs);
+    const double we = ld_at<double>(b_ve, o_volt), wf = ld_at<double>(b_vf, o_volt);
+    // 2) what only get_obs() needs: the row env:340 will load (start + steps, A2) and the history part of the
+    //    stacked observation, which is copied right away and drains underneath the solve; an environment that
+    //    turns out to restart below rewrites its whole observation afterwards (same wavefront, program order)
+    const int new_row = clamp_row32(start + steps, rows);
+    const uint32_t nrow_off = (uint32_t)new_row * (uint32_t)a.row_bytes;
+    double n_pd = ld_at<double>(a.series, nrow_off + o_bus), n_qd = ld_at<double>(a.series, nrow_off + o_qbus);
+    double n_ppv = ld_at<double>(a.series, nrow_off + o_pv);
+    const double n_price = ld_at<double>(a.series, nrow_off + o_price);
+    const bool obs_fast = want_obs && na <= NA_CAP && 3 * c.history <= FLEX_OBS_CLASSES * LW;
+    obs_copy_hist<EPW, NA_CAP, ObsT>(a, env0, g, valid, obs_fast, ln, obs_cnt, obs);
     const bool warm = c.warm_start != 0 && ln.pq;
     double e = warm ? we : 1.0, f = warm ? wf : 0.0;
 
     const double pd = is_bus ? pd_r : 0.0, qd = is_bus ? qd_r : 0.0, ppv = is_bld ? ppv_r : 0.0;
     const double e_cur = is_bld ? e_cur_r : 0.0, e_init = is_bld ? e_init_r : 0.0;
     // actions -> physical set-points (env:260-293); computed in every lane, kept in building lanes
-    FlexAct act = parse_actions(c, c.raw_actions != 0, (double)av[0], (double)av[1], (double)av[2], (double)av[3],
-                                pd, ppv, e_cur);
+    FlexAct act = parse_actions(c, a.inv_eta_ch, a.inv_eta_dis, c.raw_actions != 0, (double)av[0], (double)av[1],
+                                (double)av[2], (double)av[3], pd, ppv, e_cur);
     if (!is_bld) { act.pct = 0.0; act.pred = 0.0; act.ch = 0.0; act.dis = 0.0; act.q = 0.0; }
     // net load per bus (pf.py:69-73, 81-82)
     const double pnet = pd - act.pred - ppv + act.ch - act.dis;
@@ -482,56 +509,60 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
 #endif
     FLEX_STAMP(2);
 
+    const uint32_t o_vm = (g * nb + busi) * 8;
     double v, pred, ch, dis, q, e_new;
     if (ok) {
         v = sqrt(e * e + f * f);                                                       // pf.py:108
         pred = act.pred; ch = act.ch; dis = act.dis; q = act.q;
-        e_new = e_init + c.dt * (c.eta_ch * ch - (1.0 / c.eta_dis) * dis);             // pf.py:96-98
+        e_new = e_init + c.dt * (c.eta_ch * ch - a.inv_eta_dis * dis);                 // pf.py:96-98
         if (ln.pq) {
-            ST_STATE(a.st.vm[(int64_t)env * nb + ln.bus], v);
-            ST_STATE(a.st.ve[(int64_t)env * 64 + ln.l], e);
-            ST_STATE(a.st.vf[(int64_t)env * 64 + ln.l], f);
+            st_at<double>(b_vm, o_vm, v);
+            st_at<double>(b_ve, o_volt, e);
+            st_at<double>(b_vf, o_volt, f);
         }
         if (is_bld && valid) {
-            ST_STATE(agst[AF_PRED * FLEX_MAX_AGENTS + ag], pred);
-            ST_STATE(agst[AF_CH * FLEX_MAX_AGENTS + ag], ch);
-            ST_STATE(agst[AF_DIS * FLEX_MAX_AGENTS + ag], dis);
-            ST_STATE(agst[AF_Q * FLEX_MAX_AGENTS + ag], q);
+            st_at<double>(b_agent, o_agent + AF_PRED * AFB, pred);
+            st_at<double>(b_agent, o_agent + AF_CH * AFB, ch);
+            st_at<double>(b_agent, o_agent + AF_DIS * AFB, dis);
+            st_at<double>(b_agent, o_agent + AF_Q * AFB, q);
         }
     } else {                                                                           // env:314-328
-        v = is_bus ? a.st.vm[(int64_t)env * nb + ln.bus] : 1.0;
-        pred = is_bld ? agst[AF_PRED * FLEX_MAX_AGENTS + ag] : 0.0;
-        ch = is_bld ? agst[AF_CH * FLEX_MAX_AGENTS + ag] : 0.0;
-        dis = is_bld ? agst[AF_DIS * FLEX_MAX_AGENTS + ag] : 0.0;
-        q = is_bld ? agst[AF_Q * FLEX_MAX_AGENTS + ag] : 0.0;
+        v = is_bus ? ld_at<double>(b_vm, o_vm) : 1.0;
+        pred = is_bld ? ld_at<double>(b_agent, o_agent + AF_PRED * AFB) : 0.0;
+        ch = is_bld ? ld_at<double>(b_agent, o_agent + AF_CH * AFB) : 0.0;
+        dis = is_bld ? ld_at<double>(b_agent, o_agent + AF_DIS * AFB) : 0.0;
+        q = is_bld ? ld_at<double>(b_agent, o_agent + AF_Q * AFB) : 0.0;
         e_new = e_cur;
     }
     if (is_bld && valid) {
-        ST_STATE(agst[AF_PCT * FLEX_MAX_AGENTS + ag], act.pct);
-        ST_STATE(agst[AF_E * FLEX_MAX_AGENTS + ag], e_new);
-        ST_STATE(agst[AF_EINIT * FLEX_MAX_AGENTS + ag], e_new);                                 // env:354
+        st_at<double>(b_agent, o_agent + AF_PCT * AFB, act.pct);
+        st_at<double>(b_agent, o_agent + AF_E * AFB, e_new);
+        st_at<double>(b_agent, o_agent + AF_EINIT * AFB, e_new);                       // env:354
     }
 
     RewardOut rw = reward_terms<EPW>(c, ln, is_bld, price, pred, ch, dis, q, v);        // env:330-335
-    const double cum_before = a.st.cumrew[env];
+    double* const b_cum = a.st.cumrew + env0;
+    const double cum_before = ld_at<double>(b_cum, g * 8);
     double rwd = rw.reward;
     if (!ok) rwd -= c.fail_penalty;                                                    // env:336
     const int new_steps = steps + 1;                                                   // env:342
     const bool term = (new_steps >= c.episode_limit) || !ok;                           // env:345
     if (ln.l == 0 && valid) {
-        ST_OUT(reward[env], rwd);
+        st_at<double>(reward + env0, g * 8, rwd);
         done[env] = term ? 1 : 0;
         if (failed) failed[env] = ok ? 0 : 1;
         if (info) {
-            double* io = info + (int64_t)env * FLEX_INFO_W;
-            ST_OUT(io[0], rw.reward); ST_OUT(io[1], rw.revenue); ST_OUT(io[2], rw.der); ST_OUT(io[3], rw.ess);
-            ST_OUT(io[4], rw.disc); ST_OUT(io[5], rw.vpen); ST_OUT(io[6], cum_before);                      // A9
+            double* const io = info + (int64_t)env0 * FLEX_INFO_W;
+            const uint32_t oi = g * (FLEX_INFO_W * 8);
+            st_at<double>(io, oi, rw.reward); st_at<double>(io, oi + 8, rw.revenue); st_at<double>(io, oi + 16, rw.der);
+            st_at<double>(io, oi + 24, rw.ess); st_at<double>(io, oi + 32, rw.disc); st_at<double>(io, oi + 40, rw.vpen);
+            st_at<double>(io, oi + 48, cum_before);                                    // A9
         }
-        ST_STATE(a.st.cumrew[env], cum_before + rwd);                                           // env:343
-        ie[IF_STEPS] = new_steps;
-        ie[IF_ROW] = (int32_t)new_row;                                                 // env:340 reads row `steps` (A2)
-        ie[IF_ITERS] = iters;
-        ie[IF_SWEEPS] = sweeps;
+        st_at<double>(b_cum, g * 8, cum_before + rwd);                                 // env:343
+        st_at<int>(b_ienv, o_ienv + IF_STEPS * 4, new_steps);
+        st_at<int>(b_ienv, o_ienv + IF_ROW * 4, new_row);                              // env:340 reads row `steps` (A2)
+        st_at<int>(b_ienv, o_ienv + IF_ITERS * 4, iters);
+        st_at<int>(b_ienv, o_ienv + IF_SWEEPS * 4, sweeps);
     }
 #ifdef FLEX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -543,7 +574,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     if (want_obs) {
         n_pd = is_bus ? n_pd : 0.0; n_qd = is_bus ? n_qd : 0.0; n_ppv = is_bld ? n_ppv : 0.0;
         const bool emit = valid && !restart;
-        if (obs_fast) obs_store_new<EPW, ObsT>(a, env, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
+        if (obs_fast) obs_store_new<EPW, ObsT>(a, env0, g, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
         else push_and_emit_obs<EPW, ObsT>(a, env, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
     }
     if (auto_reset && __ballot(restart) != 0ull) {       // wavefront-uniform, taken once per episode
@@ -743,7 +774,7 @@ __global__ void flex_safety_kernel(KArgs a, const void* __restrict__ proposed, i
     const double e_cur = agst[AF_E * FLEX_MAX_AGENTS + ag];
     const int64_t base = ((int64_t)env * na + ag) * 4;
     // parse_actions, safemaddpg.py:142-174: always the scaled branch, clip vs current_ess_energy
-    FlexAct p = parse_actions(c, false, load_action(proposed, dtype, base), load_action(proposed, dtype, base + 1),
+    FlexAct p = parse_actions(c, a.inv_eta_ch, a.inv_eta_dis, false, load_action(proposed, dtype, base), load_action(proposed, dtype, base + 1),
                               load_action(proposed, dtype, base + 2), load_action(proposed, dtype, base + 3),
                               pd, ppv, e_cur);
     const double x0[4] = {p.pct, p.ch, p.dis, p.q};
@@ -881,8 +912,9 @@ static KArgs make_args(const FlexEnv* e) {
     k.stamps = g_stamps;
     k.cfg = e->cfg; k.net = e->net; k.st = e->st; k.series = e->series.table;
     k.rows = e->series.rows; k.cols = e->series.cols; k.n_envs = e->n_envs; k.n_bus = e->n_bus;
-    const int64_t rb = (int64_t)e->n_envs * e->cfg.n_agents * e->cfg.history * 6 * (int64_t)sizeof(float);
-    k.ring_bytes = rb < (1LL << 31) ? (int32_t)rb : 0;
+    k.row_bytes = e->series.cols * 8;
+    k.inv_h = 1.0f / (float)e->cfg.history; k.inv_h3 = 1.0f / (float)(3 * e->cfg.history);
+    k.inv_eta_ch = 1.0 / e->cfg.eta_ch; k.inv_eta_dis = 1.0 / e->cfg.eta_dis;
     return k;
 }
 
@@ -994,11 +1026,11 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     const bool f64 = obs && obs_dtype == FLEX_F64;
     const int want = obs ? 1 : 0;
 #define FLEX_LAUNCH_STEP(EPW_, OBS_, ACT_) do { \
-        if (small_obs) hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_CAP_SMALL>), grid, env_block(), 0, s, k, \
+        if (small_obs) hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_AGENTS_SMALL>), grid, env_block(), 0, s, k, \
             (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset); \
-        else hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_CAP_LARGE>), grid, env_block(), 0, s, k, \
+        else hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_AGENTS_LARGE>), grid, env_block(), 0, s, k, \
             (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset); } while (0)
-    const bool small_obs = e->cfg.n_agents * e->cfg.history * 3 <= FLEX_OBS_CAP_SMALL;
+    const bool small_obs = e->cfg.n_agents == FLEX_OBS_AGENTS_SMALL && 3 * e->cfg.history <= FLEX_OBS_CLASSES * (FLEX_WAVE / epw);
     const int variant = (epw == 2 ? 4 : 0) + (f64 ? 2 : 0) + (act_dtype == FLEX_F64 ? 1 : 0);
     switch (variant) {
         case 0: FLEX_LAUNCH_STEP(1, float, float); break;
