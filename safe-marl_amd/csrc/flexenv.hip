@@ -121,6 +121,15 @@ __device__ __forceinline__ void st_nt2(float2* p, float2 v) {
     v2f t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(p));
 }
 
+// The kernel's first parameter (KArgs, by value) sits at offset 0 of the kernarg segment.  Re-deriving its address
+// through an opaque asm makes later reads fresh scalar loads at the point of use instead of values kept live
+// (and spilled to VGPR lanes) from kernel entry.
+template <typename T> __device__ __forceinline__ const T* relaunder_kernarg() {
+    unsigned long long v = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(v));
+    return (const T*)(const __attribute__((address_space(4))) T*)v;
+}
+
 // Addressing: everything a wavefront touches hangs off a handful of wavefront-uniform base pointers (scalar
 // registers, computed on the scalar unit from the kernel arguments and the wavefront's first environment) plus a
 // 32-bit per-lane byte offset — one `global_load v, v_off, s[base]` per access instead of a 64-bit multiply-add
@@ -509,44 +518,52 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
 #endif
     FLEX_STAMP(2);
 
-    const uint32_t o_vm = (g * nb + busi) * 8;
+    // the epilogue re-reads its configuration and rebuilds its bases from fresh kernarg loads (see relaunder_kernarg)
+    const KArgs& z = *relaunder_kernarg<KArgs>();
+    const FlexCfg& cz = z.cfg;
+    double* const e_agent = z.st.agent + (int64_t)env0 * (AF_COUNT * FLEX_MAX_AGENTS);
+    double* const e_ve = z.st.ve + (int64_t)env0 * 64;
+    double* const e_vf = z.st.vf + (int64_t)env0 * 64;
+    double* const e_vm = z.st.vm + (int64_t)env0 * z.n_bus;
+    int32_t* const e_ienv = z.st.ienv + (int64_t)env0 * IF_COUNT;
+    const uint32_t o_vm = (g * z.n_bus + busi) * 8;
     double v, pred, ch, dis, q, e_new;
     if (ok) {
         v = sqrt(e * e + f * f);                                                       // pf.py:108
         pred = act.pred; ch = act.ch; dis = act.dis; q = act.q;
-        e_new = e_init + c.dt * (c.eta_ch * ch - a.inv_eta_dis * dis);                 // pf.py:96-98
+        e_new = e_init + cz.dt * (cz.eta_ch * ch - z.inv_eta_dis * dis);                 // pf.py:96-98
         if (ln.pq) {
-            st_at<double>(b_vm, o_vm, v);
-            st_at<double>(b_ve, o_volt, e);
-            st_at<double>(b_vf, o_volt, f);
+            st_at<double>(e_vm, o_vm, v);
+            st_at<double>(e_ve, o_volt, e);
+            st_at<double>(e_vf, o_volt, f);
         }
         if (is_bld && valid) {
-            st_at<double>(b_agent, o_agent + AF_PRED * AFB, pred);
-            st_at<double>(b_agent, o_agent + AF_CH * AFB, ch);
-            st_at<double>(b_agent, o_agent + AF_DIS * AFB, dis);
-            st_at<double>(b_agent, o_agent + AF_Q * AFB, q);
+            st_at<double>(e_agent, o_agent + AF_PRED * AFB, pred);
+            st_at<double>(e_agent, o_agent + AF_CH * AFB, ch);
+            st_at<double>(e_agent, o_agent + AF_DIS * AFB, dis);
+            st_at<double>(e_agent, o_agent + AF_Q * AFB, q);
         }
     } else {                                                                           // env:314-328
-        v = is_bus ? ld_at<double>(b_vm, o_vm) : 1.0;
-        pred = is_bld ? ld_at<double>(b_agent, o_agent + AF_PRED * AFB) : 0.0;
-        ch = is_bld ? ld_at<double>(b_agent, o_agent + AF_CH * AFB) : 0.0;
-        dis = is_bld ? ld_at<double>(b_agent, o_agent + AF_DIS * AFB) : 0.0;
-        q = is_bld ? ld_at<double>(b_agent, o_agent + AF_Q * AFB) : 0.0;
+        v = is_bus ? ld_at<double>(e_vm, o_vm) : 1.0;
+        pred = is_bld ? ld_at<double>(e_agent, o_agent + AF_PRED * AFB) : 0.0;
+        ch = is_bld ? ld_at<double>(e_agent, o_agent + AF_CH * AFB) : 0.0;
+        dis = is_bld ? ld_at<double>(e_agent, o_agent + AF_DIS * AFB) : 0.0;
+        q = is_bld ? ld_at<double>(e_agent, o_agent + AF_Q * AFB) : 0.0;
         e_new = e_cur;
     }
     if (is_bld && valid) {
-        st_at<double>(b_agent, o_agent + AF_PCT * AFB, act.pct);
-        st_at<double>(b_agent, o_agent + AF_E * AFB, e_new);
-        st_at<double>(b_agent, o_agent + AF_EINIT * AFB, e_new);                       // env:354
+        st_at<double>(e_agent, o_agent + AF_PCT * AFB, act.pct);
+        st_at<double>(e_agent, o_agent + AF_E * AFB, e_new);
+        st_at<double>(e_agent, o_agent + AF_EINIT * AFB, e_new);                       // env:354
     }
 
-    RewardOut rw = reward_terms<EPW>(c, ln, is_bld, price, pred, ch, dis, q, v);        // env:330-335
-    double* const b_cum = a.st.cumrew + env0;
+    RewardOut rw = reward_terms<EPW>(cz, ln, is_bld, price, pred, ch, dis, q, v);        // env:330-335
+    double* const b_cum = z.st.cumrew + env0;
     const double cum_before = ld_at<double>(b_cum, g * 8);
     double rwd = rw.reward;
-    if (!ok) rwd -= c.fail_penalty;                                                    // env:336
+    if (!ok) rwd -= cz.fail_penalty;                                                    // env:336
     const int new_steps = steps + 1;                                                   // env:342
-    const bool term = (new_steps >= c.episode_limit) || !ok;                           // env:345
+    const bool term = (new_steps >= cz.episode_limit) || !ok;                           // env:345
     if (ln.l == 0 && valid) {
         st_at<double>(reward + env0, g * 8, rwd);
         done[env] = term ? 1 : 0;
@@ -559,10 +576,10 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
             st_at<double>(io, oi + 48, cum_before);                                    // A9
         }
         st_at<double>(b_cum, g * 8, cum_before + rwd);                                 // env:343
-        st_at<int>(b_ienv, o_ienv + IF_STEPS * 4, new_steps);
-        st_at<int>(b_ienv, o_ienv + IF_ROW * 4, new_row);                              // env:340 reads row `steps` (A2)
-        st_at<int>(b_ienv, o_ienv + IF_ITERS * 4, iters);
-        st_at<int>(b_ienv, o_ienv + IF_SWEEPS * 4, sweeps);
+        st_at<int>(e_ienv, o_ienv + IF_STEPS * 4, new_steps);
+        st_at<int>(e_ienv, o_ienv + IF_ROW * 4, new_row);                              // env:340 reads row `steps` (A2)
+        st_at<int>(e_ienv, o_ienv + IF_ITERS * 4, iters);
+        st_at<int>(e_ienv, o_ienv + IF_SWEEPS * 4, sweeps);
     }
 #ifdef FLEX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -574,14 +591,17 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     if (want_obs) {
         n_pd = is_bus ? n_pd : 0.0; n_qd = is_bus ? n_qd : 0.0; n_ppv = is_bld ? n_ppv : 0.0;
         const bool emit = valid && !restart;
-        if (obs_fast) obs_store_new<EPW, ObsT>(a, env0, g, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
-        else push_and_emit_obs<EPW, ObsT>(a, env, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
+        if (obs_fast) obs_store_new<EPW, ObsT>(z, env0, g, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
+        else push_and_emit_obs<EPW, ObsT>(z, env, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
     }
     if (auto_reset && __ballot(restart) != 0ull) {       // wavefront-uniform, taken once per episode
         LaneNet ln0;
         load_lane_net<EPW>(a.net, lane, ln0);
         const DevResetSpec none = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        flex_reset_body<EPW, ObsT>(a, env, restart, ln0, none, obs, want_obs, failed, true);
+        // the restart reads its configuration through a freshly "discovered" kernarg pointer: otherwise the compiler
+        // loads every field the (rare) restart needs at kernel entry and carries them — spilled — across the hot path
+        const KArgs& ar = *relaunder_kernarg<KArgs>();
+        flex_reset_body<EPW, ObsT>(ar, env, restart, ln0, none, obs, want_obs, failed, true);
     }
 #ifdef FLEX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
