@@ -145,6 +145,36 @@ __device__ __forceinline__ void grp_segscan_sum2(double& x, double& y, const int
     if constexpr (EPW == 1) FLEX_SEG2_STEP(0x143, 0xC, false, 5)
 #undef FLEX_SEG2_STEP
 }
+// fp32 flavours for the sweep solver's increments: one 32-bit DPP operand per step, which the compiler folds into
+// the add / fma itself (v_add_f32_dpp, v_fmac_f32_dpp) — one instruction per component and step where the fp64
+// scans need three.
+template <int CTRL, int ROW_MASK, bool BOUND_CTRL>
+__device__ __forceinline__ float dpp_mov_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, BOUND_CTRL));
+}
+template <int EPW>
+__device__ __forceinline__ void grp_scan_sum2_f32(float& x, float& y) {
+#define FLEX_SCAN2F_STEP(CTRL, RM, BC) { const float tx = dpp_mov_f32<CTRL, RM, BC>(x), ty = dpp_mov_f32<CTRL, RM, BC>(y); x += tx; y += ty; }
+    FLEX_SCAN2F_STEP(0x111, 0xF, true)
+    FLEX_SCAN2F_STEP(0x112, 0xF, true)
+    FLEX_SCAN2F_STEP(0x114, 0xF, true)
+    FLEX_SCAN2F_STEP(0x118, 0xF, true)
+    FLEX_SCAN2F_STEP(0x142, 0xA, false)
+    if constexpr (EPW == 1) FLEX_SCAN2F_STEP(0x143, 0xC, false)
+#undef FLEX_SCAN2F_STEP
+}
+template <int EPW>
+__device__ __forceinline__ void grp_segscan_sum2_f32(float& x, float& y, const float (&m)[6]) {
+#define FLEX_SEG2F_STEP(CTRL, RM, BC, K) { const float tx = dpp_mov_f32<CTRL, RM, BC>(x), ty = dpp_mov_f32<CTRL, RM, BC>(y); \
+    x = fmaf(tx, m[K], x); y = fmaf(ty, m[K], y); }
+    FLEX_SEG2F_STEP(0x111, 0xF, true, 0)
+    FLEX_SEG2F_STEP(0x112, 0xF, true, 1)
+    FLEX_SEG2F_STEP(0x114, 0xF, true, 2)
+    FLEX_SEG2F_STEP(0x118, 0xF, true, 3)
+    FLEX_SEG2F_STEP(0x142, 0xA, false, 4)
+    if constexpr (EPW == 1) FLEX_SEG2F_STEP(0x143, 0xC, false, 5)
+#undef FLEX_SEG2F_STEP
+}
 __device__ __forceinline__ double readlane_f64(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
                             __builtin_amdgcn_readlane(__double2loint(x), l));
@@ -331,51 +361,131 @@ __device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, c
 // needs no reduction.  The caller always hands the result to pf_newton_tree, which re-evaluates the
 // true Ybus mismatch and either confirms it (0 Newton steps) or finishes the job — so the
 // convergence criterion and the failure semantics are those of the Newton path.
+//
+// Mixed precision.  Z (subtree sum, line impedance, path sum) is linear, so the iteration can be carried in
+// increments against an ANCHOR: one fp64 sweep from the present voltages gives currents I_a and voltages
+// V_a = V_slack + Z I_a exactly; with I_b = I(V_a) every later iterate is V_a + d,
+//     d_1 = c = Z (I_b - I_a),      d_{k+1} = c + Z delta(d_k),      delta(d) = I(V_a + d) - I_b = -conj(S d / (V V_a)).
+// delta is formed from d directly (no cancellation) and shrinks by ~rho every sweep, so the whole inner iteration —
+// currents, scans, convergence test — runs in fp32: half the DPP traffic, one instruction per scan step
+// (v_add_f32_dpp / packed fma), shorter dependent latencies.  fp32 leaves the iterate ~1e-7 |d| away from the fp64
+// fixed point, so once the local mismatch is below FLEX_SWEEP_COARSE the iterate is re-anchored (one more fp64
+// sweep); after that |d| ~ 1e-9 and the fp32 increments are exact to fp64 round-off.  Typical step: fp64 sweep,
+// ~5 fp32, fp64 sweep, 2-3 fp32.  A re-anchor is also forced every FLEX_SWEEP_REANCHOR increments, so a run that
+// cannot reach the coarse threshold (heavy loading, cold start) still ends on fp64-exact footing.
+// After a sweep the network equations hold exactly for (V_new, I_old), so the power mismatch at V_new is
+// V_new * conj(I_old - I_new) — between anchors I_old - I_new = delta_{k-1} - delta_k: a purely local quantity.
 // Returns (per group) the number of sweeps until its local test passed, or max_sweeps.
+#define FLEX_SWEEP_COARSE 1e-9
+#ifndef FLEX_SWEEP_REANCHOR
+#define FLEX_SWEEP_REANCHOR 8
+#endif
+
+// x <- Z x on the lanes of each group (x = per-bus current injections, result = voltage rise slack -> bus)
+template <int EPW>
+__device__ __forceinline__ void zbus_apply_f64(const DevNet* __restrict__ net, const LaneNet& ln, bool use_seg,
+                                               int seg_rounds, int jump_rounds, double& xr, double& xi) {
+    double sr = xr, si = xi;
+    grp_scan_sum2<EPW>(sr, si);                                   // sum of injections over each subtree
+    const double tr = __shfl(sr, ln.sub_end, FLEX_WAVE) - (sr - xr);
+    const double ti = __shfl(si, ln.sub_end, FLEX_WAVE) - (si - xi);
+    // voltage rise along the own line: -z*J with J = -(subtree injection)  =>  z * t
+    double ar = ln.r * tr - ln.x * ti, ai = ln.r * ti + ln.x * tr;
+    if (use_seg) {                                                // path sum slack -> bus
+        grp_segscan_sum2<EPW>(ar, ai, ln.mk);
+        for (int d = 1; d <= seg_rounds; ++d) {
+            const double br = __shfl(ar, ln.seg_par, FLEX_WAVE), bi = __shfl(ai, ln.seg_par, FLEX_WAVE);
+            if (ln.seg_depth == d) { ar += br; ai += bi; }
+        }
+    } else {
+        for (int k = 0; k < jump_rounds; ++k) {
+            const int anc = net->anc[k][ln.l];
+            const int src = anc >= 0 ? anc + ln.base : ln.lane;
+            const double br = __shfl(ar, src, FLEX_WAVE), bi = __shfl(ai, src, FLEX_WAVE);
+            if (anc >= 0) { ar += br; ai += bi; }
+        }
+    }
+    xr = ar; xi = ai;
+}
+template <int EPW>
+__device__ __forceinline__ void zbus_apply_f32(const LaneNet& ln, const float (&mkf)[6], float rf, float xf,
+                                               int seg_rounds, float& xr, float& xi) {
+    float sr = xr, si = xi;
+    grp_scan_sum2_f32<EPW>(sr, si);
+    const float tr = __shfl(sr, ln.sub_end, FLEX_WAVE) - (sr - xr);
+    const float ti = __shfl(si, ln.sub_end, FLEX_WAVE) - (si - xi);
+    float ar = rf * tr - xf * ti, ai = rf * ti + xf * tr;
+    grp_segscan_sum2_f32<EPW>(ar, ai, mkf);
+    for (int d = 1; d <= seg_rounds; ++d) {
+        const float br = __shfl(ar, ln.seg_par, FLEX_WAVE), bi = __shfl(ai, ln.seg_par, FLEX_WAVE);
+        if (ln.seg_depth == d) { ar += br; ai += bi; }
+    }
+    xr = ar; xi = ai;
+}
+
 template <int EPW>
 __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const LaneNet& ln, double pnet,
                                         double qnet, double& e, double& f, double tol, int max_sweeps) {
     const int seg_rounds = net->n_seg_rounds, jump_rounds = net->n_jump_rounds;
-    const bool use_seg = seg_rounds <= 2;
+    const bool use_seg = seg_rounds <= 2;       // deeper segment nesting: pointer jumping, fp64 sweeps only
     const double ps = ln.pq ? -pnet : 0.0, qs = ln.pq ? -qnet : 0.0;
-    double pir = 0.0, pii = 0.0;
-    int mine = max_sweeps;
-    for (int it = 0; it < max_sweeps; ++it) {
-        const double inv_d = fast_rcp(e * e + f * f);
-        const double ir = (ps * e + qs * f) * inv_d, ii = (ps * f - qs * e) * inv_d;   // conj(S/V)
-        if (it > 0) {
-            const double dr = pir - ir, di = pii - ii;
-            const bool miss = !(fmax(fabs(e * dr + f * di), fabs(f * dr - e * di)) < tol);
+    const float psf = (float)ps, qsf = (float)qs, rf = (float)ln.r, xf = (float)ln.x;
+    const float tolf = (float)tol, coarsef = (float)FLEX_SWEEP_COARSE;
+    float mkf[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) mkf[k] = ln.mk[k] ? 1.0f : 0.0f;
+    int mine = max_sweeps, it = 0;
+    bool fine = false;                          // re-anchored below the coarse threshold already
+    while (it < max_sweeps) {
+        // ---- anchor: one fp64 sweep from (e, f)
+        double inv_d = fast_rcp(e * e + f * f);
+        const double iar = (ps * e + qs * f) * inv_d, iai = (ps * f - qs * e) * inv_d;      // conj(S/V)
+        double ar = iar, ai = iai;
+        zbus_apply_f64<EPW>(net, ln, use_seg, seg_rounds, jump_rounds, ar, ai);
+        e = 1.0 + ar; f = ai;
+        ++it;
+        // currents at the anchor, and the anchor's own mismatch
+        inv_d = fast_rcp(e * e + f * f);
+        const double ibr = (ps * e + qs * f) * inv_d, ibi = (ps * f - qs * e) * inv_d;
+        {
+            const double dr = iar - ibr, di = iai - ibi;
+            const double m = fmax(fabs(e * dr + f * di), fabs(f * dr - e * di));
             bool wave_miss;
-            const bool grp_miss = grp_any<EPW>(miss, ln.grp, wave_miss);
+            const bool grp_miss = grp_any<EPW>(!(m < tol), ln.grp, wave_miss);
             if (!grp_miss && mine == max_sweeps) mine = it;
             if (!wave_miss) break;
+            if (!use_seg) continue;
+            if (!fine && __ballot(!(m < FLEX_SWEEP_COARSE)) == 0ull) fine = true;
         }
-        pir = ir; pii = ii;
-        // sum of injected currents over each subtree
-        double sr = ir, si = ii;
-        grp_scan_sum2<EPW>(sr, si);
-        const double tr = __shfl(sr, ln.sub_end, FLEX_WAVE) - (sr - ir);
-        const double ti = __shfl(si, ln.sub_end, FLEX_WAVE) - (si - ii);
-        // voltage rise along the own line: -z*J with J = -(subtree injection)  =>  z * t
-        double ar = ln.r * tr - ln.x * ti, ai = ln.r * ti + ln.x * tr;
-        // path sum slack -> bus
-        if (use_seg) {
-            grp_segscan_sum2<EPW>(ar, ai, ln.mk);
-            for (int d = 1; d <= seg_rounds; ++d) {
-                const double br = __shfl(ar, ln.seg_par, FLEX_WAVE), bi = __shfl(ai, ln.seg_par, FLEX_WAVE);
-                if (ln.seg_depth == d) { ar += br; ai += bi; }
-            }
-        } else {
-            for (int k = 0; k < jump_rounds; ++k) {
-                const int anc = net->anc[k][ln.l];
-                const int src = anc >= 0 ? anc + ln.base : ln.lane;
-                const double br = __shfl(ar, src, FLEX_WAVE), bi = __shfl(ai, src, FLEX_WAVE);
-                if (anc >= 0) { ar += br; ai += bi; }
-            }
+        // ---- increments against the anchor, fp32
+        const double ea = e, fa = f;
+        const float ear = (float)ea, eai = (float)fa;
+        float cr = (float)(ibr - iar), ci = (float)(ibi - iai);
+        zbus_apply_f32<EPW>(ln, mkf, rf, xf, seg_rounds, cr, ci);                           // c = Z (I_b - I_a)
+        ++it;
+        float dr = cr, di = ci, pdr = 0.0f, pdi = 0.0f;
+        bool done = false;
+        for (int k = 0; k < FLEX_SWEEP_REANCHOR && it < max_sweeps; ++k) {
+            const float vr = ear + dr, vi = eai + di;                                       // V = V_a + d
+            const float pr = vr * ear - vi * eai, pi = vr * eai + vi * ear;                 // P = V V_a
+            const float rr = __builtin_amdgcn_rcpf(pr * pr + pi * pi);
+            const float tr = psf * dr - qsf * di, ti = psf * di + qsf * dr;                 // S d
+            const float ur = tr * pr + ti * pi, ui = ti * pr - tr * pi;                     // S d conj(P)
+            float xr = -ur * rr, xi = ui * rr;                                              // delta = -conj(S d / P)
+            const float gr = pdr - xr, gi = pdi - xi;
+            const float m = fmaxf(fabsf(vr * gr + vi * gi), fabsf(vi * gr - vr * gi));
+            bool wave_miss;
+            const bool grp_miss = grp_any<EPW>(!(m < tolf), ln.grp, wave_miss);
+            if (!grp_miss && mine == max_sweeps) mine = it;
+            if (!wave_miss) { done = true; break; }
+            if (!fine && __ballot(!(m < coarsef)) == 0ull) { fine = true; break; }          // re-anchor now
+            pdr = xr; pdi = xi;
+            zbus_apply_f32<EPW>(ln, mkf, rf, xf, seg_rounds, xr, xi);
+            dr = cr + xr; di = ci + xi;
+            ++it;
         }
-        e = 1.0 + ar;
-        f = ai;
+        e = ea + (double)dr; f = fa + (double)di;
+        if (done) break;
     }
     return mine;
 }

@@ -30,8 +30,6 @@ d=np.diff(st[:,:5],axis=1)
 print('solver',solver,'phase cycles (memtime ticks @100MHz?) mean/median/max:')
 for i,nm in enumerate(names): print(f'  {nm:16s} {d[:,i].mean():9.1f} {np.median(d[:,i]):9.1f} {d[:,i].max():9.1f}')
 rt0, rt1 = st[:,5], st[:,6]
-if st[:,8].max()>0:
-    for nm,aa,bb in (('entry->ienv',0,8),('ienv->inputs',8,9),('inputs->ring',9,10),('ring->parsed',10,11),('parsed->hist stored',11,1)): print(f'  {nm:22s} {(st[:,bb]-st[:,aa]).mean():9.1f}')
 print('  wave lifetime cycles', (st[:,4]-st[:,0]).mean(), ' realtime ticks(100MHz) per wave', (rt1-rt0).mean(), ' => clock GHz', ((st[:,4]-st[:,0])/(rt1-rt0)).mean()*0.1)
 print('  kernel span us (realtime)', (rt1.max()-rt0.min())/100.0, ' start spread us', (rt0.max()-rt0.min())/100.0, ' end spread us', (rt1.max()-rt1.min())/100.0)
 print('  sweeps', env.peek('PF_SWEEPS').float().mean().item(), 'newton', env.peek('PF_ITERS').float().mean().item())
