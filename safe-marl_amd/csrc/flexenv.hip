@@ -179,55 +179,63 @@ typedef int flex_v4i __attribute__((ext_vector_type(4)));
 #define FLEX_OBS_AGENTS_LARGE FLEX_MAX_AGENTS
 
 template <int EPW, int NA_CAP, typename OutT>
-__device__ __forceinline__ void obs_copy_hist(const KArgs& a, int env0, int g, bool valid, bool enable,
-                                              const LaneNet& ln, int k, OutT* __restrict__ out) {
-    constexpr int LW = FLEX_WAVE / EPW, CLS = FLEX_OBS_CLASSES;
-    constexpr bool NA_EXACT = NA_CAP == FLEX_OBS_AGENTS_SMALL;                   // host dispatch guarantees na == NA_CAP
-    const int H = a.cfg.history, na = a.cfg.n_agents, H3 = 3 * H;
-    const int env_floats = na * H * 6;
-    const int span = enable ? EPW * env_floats : 0;                             // `enable` is launch-uniform
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.st.ring + (int64_t)env0 * env_floats), 0, span * 4, FLEX_BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(out + (int64_t)env0 * env_floats), 0, span * (int)sizeof(OutT), FLEX_BUF_FLAGS);
-    const int s1 = small_mod(k, H, a.inv_h) + 1;
-    const int wrap_at = 3 * (H - s1);                    // rem >= wrap_at: the ring slot wrapped around
-    const int lo = 3 * (H - 1 - k > 0 ? H - 1 - k : 0);  // rem <  lo: before the episode began -> zero padding (A16)
-    int src[CLS], dst[CLS];
-#pragma unroll
-    for (int i = 0; i < CLS; ++i) {
-        const int rem = ln.l + LW * i;
-        const bool have = valid && rem < H3;
-        src[i] = (have && rem >= lo) ? g * env_floats * 4 + 8 * (rem + 3 * s1) - (rem >= wrap_at ? 8 * H3 : 0) : -1;
-        dst[i] = have ? g * env_floats * (int)sizeof(OutT) + 2 * (int)sizeof(OutT) * rem : -1;
-    }
+struct ObsHist {
+    static constexpr int LW = FLEX_WAVE / EPW, CLS = FLEX_OBS_CLASSES;
+    static constexpr bool NA_EXACT = NA_CAP == FLEX_OBS_AGENTS_SMALL;            // host dispatch guarantees na == NA_CAP
     float2 buf[NA_CAP][CLS];
-#pragma unroll
-    for (int ag = 0; ag < NA_CAP; ++ag) {
-        const bool live = NA_EXACT || ag < na;           // scalar
+    int dst[CLS];
+
+    __device__ __forceinline__ void load(const KArgs& a, int env0, int g, bool valid, bool enable, const LaneNet& ln, int k) {
+        const int H = a.cfg.history, na = a.cfg.n_agents, H3 = 3 * H;
+        const int env_floats = na * H * 6;
+        const int span = enable ? EPW * env_floats : 0;                         // `enable` is launch-uniform
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.st.ring + (int64_t)env0 * env_floats), 0, span * 4, FLEX_BUF_FLAGS);
+        const int s1 = small_mod(k, H, a.inv_h) + 1;
+        const int wrap_at = 3 * (H - s1);                    // rem >= wrap_at: the ring slot wrapped around
+        const int lo = 3 * (H - 1 - k > 0 ? H - 1 - k : 0);  // rem <  lo: before the episode began -> zero padding (A16)
+        int src[CLS];
 #pragma unroll
         for (int i = 0; i < CLS; ++i) {
-            const flex_v2i r = __builtin_amdgcn_raw_buffer_load_b64(rin, live ? src[i] : -1, ag * H3 * 8, 0);
-            buf[ag][i] = make_float2(__int_as_float(r.x), __int_as_float(r.y));
+            const int rem = ln.l + LW * i;
+            const bool have = valid && rem < H3;
+            src[i] = (have && rem >= lo) ? g * env_floats * 4 + 8 * (rem + 3 * s1) - (rem >= wrap_at ? 8 * H3 : 0) : -1;
+            dst[i] = have ? g * env_floats * (int)sizeof(OutT) + 2 * (int)sizeof(OutT) * rem : -1;
         }
-    }
 #pragma unroll
-    for (int ag = 0; ag < NA_CAP; ++ag) {
-        const bool live = NA_EXACT || ag < na;
+        for (int ag = 0; ag < NA_CAP; ++ag) {
+            const bool live = NA_EXACT || ag < na;           // scalar
 #pragma unroll
-        for (int i = 0; i < CLS; ++i) {
-            const int d = live ? dst[i] : -1;
-            if constexpr (sizeof(OutT) == 4) {
-                flex_v2i w; w.x = __float_as_int(buf[ag][i].x); w.y = __float_as_int(buf[ag][i].y);
-                __builtin_amdgcn_raw_buffer_store_b64(w, rout, d, ag * H3 * 8, FLEX_AUX_NT);
-            } else {
-                const double dx = (double)buf[ag][i].x, dy = (double)buf[ag][i].y;
-                flex_v4i w; w.x = __double2loint(dx); w.y = __double2hiint(dx); w.z = __double2loint(dy); w.w = __double2hiint(dy);
-                __builtin_amdgcn_raw_buffer_store_b128(w, rout, d, ag * H3 * 16, FLEX_AUX_NT);
+            for (int i = 0; i < CLS; ++i) {
+                const flex_v2i r = __builtin_amdgcn_raw_buffer_load_b64(rin, live ? src[i] : -1, ag * H3 * 8, 0);
+                buf[ag][i] = make_float2(__int_as_float(r.x), __int_as_float(r.y));
             }
         }
     }
-}
+    __device__ __forceinline__ void store(const KArgs& a, int env0, bool enable, OutT* __restrict__ out) const {
+        const int H = a.cfg.history, na = a.cfg.n_agents, H3 = 3 * H;
+        const int env_floats = na * H * 6;
+        const int span = enable ? EPW * env_floats : 0;
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(out + (int64_t)env0 * env_floats), 0, span * (int)sizeof(OutT), FLEX_BUF_FLAGS);
+#pragma unroll
+        for (int ag = 0; ag < NA_CAP; ++ag) {
+            const bool live = NA_EXACT || ag < na;
+#pragma unroll
+            for (int i = 0; i < CLS; ++i) {
+                const int d = live ? dst[i] : -1;
+                if constexpr (sizeof(OutT) == 4) {
+                    flex_v2i w; w.x = __float_as_int(buf[ag][i].x); w.y = __float_as_int(buf[ag][i].y);
+                    __builtin_amdgcn_raw_buffer_store_b64(w, rout, d, ag * H3 * 8, FLEX_AUX_NT);
+                } else {
+                    const double dx = (double)buf[ag][i].x, dy = (double)buf[ag][i].y;
+                    flex_v4i w; w.x = __double2loint(dx); w.y = __double2hiint(dx); w.z = __double2loint(dy); w.w = __double2hiint(dy);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rout, d, ag * H3 * 16, FLEX_AUX_NT);
+                }
+            }
+        }
+    }
+};
 
 // This step's row [Pd, Qd, Ppv, V, price, E] (env:377-382) into the ring and the newest slot of the observation.
 template <int EPW, typename OutT>
@@ -491,7 +499,10 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     double n_ppv = ld_at<double>(a.series, nrow_off + o_pv);
     const double n_price = ld_at<double>(a.series, nrow_off + o_price);
     const bool obs_fast = want_obs && na <= NA_CAP && 3 * c.history <= FLEX_OBS_CLASSES * LW;
-    obs_copy_hist<EPW, NA_CAP, ObsT>(a, env0, g, valid, obs_fast, ln, obs_cnt, obs);
+    ObsHist<EPW, NA_CAP, ObsT> hist;
+    hist.load(a, env0, g, valid, obs_fast, ln, obs_cnt);
+    hist.store(a, env0, obs_fast, obs);
+
     const bool warm = c.warm_start != 0 && ln.pq;
     double e = warm ? we : 1.0, f = warm ? wf : 0.0;
 
@@ -957,6 +968,8 @@ int flexenv_create(const FlexCfg* cfg, const NetFix* net, const SeriesTab* serie
     if (cfg->solver != FLEX_SOLVER_TREE && cfg->solver != FLEX_SOLVER_SWEEP) return FLEX_EINVAL;
     if (series->cols != 2 * net->n_bus + cfg->n_agents + 1 || series->rows < 2 || !series->table) return FLEX_EINVAL;
     if (cfg->per_hour < 1 || cfg->n_start_days < 1) return FLEX_EINVAL;
+    // the step kernel addresses the series table with 32-bit byte offsets (4 GB = two centuries of 15-minute rows)
+    if (series->rows >= (1LL << 31) || (int64_t)series->rows * series->cols * 8 >= (1LL << 32)) return FLEX_EINVAL;
     // every reachable row must exist: start + 1 + (episode_limit + history)
     const int64_t max_start = (int64_t)(cfg->per_hour - 1) + 23LL * cfg->per_hour +
                               (int64_t)(cfg->n_start_days - 1) * 24 * cfg->per_hour;
