@@ -1,0 +1,439 @@
+"""Multi-period OPF comparator on the device: ``utils/opf.py:13-192`` re-designed as a batched solve.
+
+The reference builds one Pyomo MIQCP per day (T = episode_limit periods x {DistFlow state of 33 buses, 20 controls,
+5 storage binaries}) and hands it to Gurobi.  Here the same program is solved for MANY days at once:
+
+  * the network state is not a variable: for given controls the DistFlow equalities opf.py:96-129 ARE a power flow,
+    so every period's state comes from the HIP power-flow kernel (``pf_solve_batch``, one lane per bus), B*T solves
+    per launch;
+  * sensitivities of Vsqr, Isqr and the losses to the 4*n controls of a period come from the same kernel by central
+    differences — 40 more solves per period in the SAME launch (a control of period t only moves period t), which
+    costs microseconds on this hardware and needs no adjoint code;
+  * with those, each outer iteration solves a convex QP in the controls of the whole horizon (concave separable
+    revenue/discomfort terms, a positive-semidefinite loss model 2*Re(Zbus) around the exact loss gradient,
+    linearised voltage/current limits, box limits and the storage energy chain opf.py:139-148) by a batched dense
+    primal-dual interior-point method: one Cholesky of an (n x n) matrix per instance and iteration
+    (n = 20 T = 1920 at T = 96; 29.5 MB per instance — 288 GB of HBM hold thousands of days), LP-like bang-bang
+    structure included;
+  * the outer loop (sequential convex programming) repeats until the controls stop moving; at that point the
+    linearisation is exact, so the result satisfies the reference's nonlinear constraints to solver tolerance.
+
+The storage binaries opf.py:150-156 are relaxed: with ess_cost > 0 simultaneous charging and discharging only burns
+energy and money; the solution reports ``min(Pesc, Pesd)`` and the indicator ``Pesc > Pesd``.
+
+Boundary: ``opf_model(network_data, flex_price, active_power_demand, reactive_power_demand, pv_active_power,
+initial_ess_energy)`` has the reference's signature and returns its solution dict (opf.py:160-189);
+``BatchedOPF.solve`` is the tensor interface underneath.  Needs the HIP library (no CPU path).
+"""
+from __future__ import annotations
+
+from math import acos, tan
+
+import numpy as np
+import torch as th
+
+from .flex_env import pf_solve_batch
+from .network import build_tables
+
+ENV_DEFAULTS = dict(episode_limit=96, v_min=0.9, v_max=1.1, pv_cost=0.05, ess_cost=0.03, discomfort_coeff=0.15,
+                    eta_ch=0.9, eta_dis=0.9, max_power_reduction=0.5, e_min=0.0, e_max=0.025, p_ch_max=0.005,
+                    p_dis_max=0.005, cos_phi_max=0.95)           # flex_provision.yaml:4-27, read at opf.py:10-11
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# batched dense primal-dual interior point for   min 1/2 x'Qx + c'x   s.t.  rows of three structured blocks
+# ---------------------------------------------------------------------------------------------------------------
+class _Rows:
+    """One block of inequality rows  A x <= u  (and/or  A x >= l) with a structured A."""
+
+    def apply(self, x):            # [B, n] -> [B, m]
+        raise NotImplementedError
+
+    def apply_t(self, y):          # [B, m] -> [B, n]
+        raise NotImplementedError
+
+    def add_gram(self, N, d):      # N[B, n, n] += A' diag(d) A
+        raise NotImplementedError
+
+
+class _Identity(_Rows):
+    def apply(self, x):
+        return x
+
+    def apply_t(self, y):
+        return y
+
+    def add_gram(self, N, d):
+        N.diagonal(dim1=1, dim2=2).add_(d)
+
+
+class _PeriodBlocks(_Rows):
+    """Rows that only see the controls of their own period: J[B, T, R, w], x viewed as [B, T, w]."""
+
+    def __init__(self, J):
+        self.J = J
+        self.B, self.T, self.R, self.w = J.shape
+
+    def apply(self, x):
+        return th.einsum("btrw,btw->btr", self.J, x.view(self.B, self.T, self.w)).reshape(self.B, -1)
+
+    def apply_t(self, y):
+        return th.einsum("btrw,btr->btw", self.J, y.view(self.B, self.T, self.R)).reshape(self.B, -1)
+
+    def add_gram(self, N, d):
+        blk = th.einsum("btrv,btr,btrw->btvw", self.J, d.view(self.B, self.T, self.R), self.J)
+        # the diagonal (t, t) blocks of N as one strided view [B, w, w, T]
+        N.view(self.B, self.T, self.w, self.T, self.w).diagonal(dim1=1, dim2=3).add_(blk.permute(0, 2, 3, 1))
+
+
+class _Shared(_Rows):
+    """The same dense matrix C[m, n] for every instance (the storage energy chain)."""
+
+    def __init__(self, C):
+        self.C = C
+
+    def apply(self, x):
+        return x @ self.C.T
+
+    def apply_t(self, y):
+        return y @ self.C
+
+    def add_gram(self, N, d):
+        N += th.einsum("mi,bm,mj->bij", self.C, d, self.C)
+
+
+def qp_ipm(Qblk, c, blocks, x0, free=None, max_iter=80, tol=1e-11, reg=1e-12, verbose=False):
+    """Mehrotra predictor-corrector on a batch of convex QPs.
+
+    Qblk [B, T, w, w]: block-diagonal Hessian;  c [B, n];  blocks: list of (rows, lower [B, m] or None,
+    upper [B, m] or None);  x0 [B, n] start;  free [B, n] bool: variables that may move (the others stay at x0 —
+    their rows and columns leave the Newton system).  Returns x [B, n] and a dict with the duality measures.
+    Instances that have converged are frozen (zero step) while the slowest ones finish: pushing a converged
+    instance further only ruins the conditioning of its normal matrix."""
+    B, T, w, _ = Qblk.shape
+    n = T * w
+    dev, dt = c.device, c.dtype
+    # one-sided row sets: (rows, sign, bound) meaning  sign * (A x) <= sign * bound
+    sets = []
+    for rows, lo, hi in blocks:
+        if hi is not None:
+            sets.append((rows, 1.0, hi))
+        if lo is not None:
+            sets.append((rows, -1.0, -lo))
+    fmask = th.ones(B, n, dtype=dt, device=dev) if free is None else free.to(dt)
+
+    def Qx(x):
+        return th.einsum("btvw,btw->btv", Qblk, x.view(B, T, w)).reshape(B, n)
+
+    x = x0.clone()
+    s = [th.clamp(h - sg * rows.apply(x), min=1e-3) for rows, sg, h in sets]
+    z = [th.ones_like(si) for si in s]
+    m_tot = sum(si.shape[1] for si in s)
+    info = {}
+    done = th.zeros(B, dtype=th.bool, device=dev)
+    for it in range(max_iter):
+        r_d = Qx(x) + c
+        for (rows, sg, h), zi in zip(sets, z):
+            r_d = r_d + sg * rows.apply_t(zi)
+        r_d = r_d * fmask
+        r_p = [sg * rows.apply(x) + si - h for (rows, sg, h), si in zip(sets, s)]
+        mu = sum((si * zi).sum(1) for si, zi in zip(s, z)) / m_tot                      # [B]
+        res_d = r_d.abs().amax(1)
+        res_p = th.stack([rp.abs().amax(1) for rp in r_p]).amax(0)
+        # the dual residual floors near 1e-8 once z/s spans twenty decades (conditioning of the normal matrix)
+        done = done | ((mu < tol) & (res_p < 1e-8) & (res_d < 1e-6)) | (mu < 1e-4 * tol)
+        info = dict(iters=it, mu=mu, res_d=res_d, res_p=res_p, converged=done)
+        if verbose:
+            print(f"  ipm {it:2d} mu {mu.max().item():.2e} rd {res_d.max().item():.2e} rp {res_p.max().item():.2e} "
+                  f"done {int(done.sum())}/{B}")
+        if bool(done.all()):
+            break
+        # normal matrix  Q + sum A' diag(z/s) A, with the pinned variables' rows and columns replaced by identity
+        N = th.zeros(B, n, n, dtype=dt, device=dev)
+        N.view(B, T, w, T, w).diagonal(dim1=1, dim2=3).add_(Qblk.permute(0, 2, 3, 1))
+        for (rows, sg, h), si, zi in zip(sets, s, z):
+            rows.add_gram(N, zi / si)
+        N *= fmask.unsqueeze(1) * fmask.unsqueeze(2)
+        diag = N.diagonal(dim1=1, dim2=2)
+        diag.add_(reg * diag.amax(1, keepdim=True) + (1.0 - fmask))
+        L, fail = th.linalg.cholesky_ex(N)
+        bump = 1e-10
+        while bool((fail > 0).any()) and bump < 1e-3:                # round-off lost positive definiteness: regularise
+            diag.add_((bump * diag.amax(1, keepdim=True)) * (fail > 0).to(dt).unsqueeze(1))
+            L, fail = th.linalg.cholesky_ex(N)
+            bump *= 100.0
+        if bool((fail > 0).any()):
+            # the iterates of an infeasible program diverge until the factorisation breaks down; the reference raises
+            # 'Solver failed to find a solution' in that case (opf.py:155-157)
+            raise RuntimeError("Solver failed to find a solution (QP infeasible, or its normal matrix lost definiteness)")
+
+        def newton(r_c):
+            rhs = -r_d
+            for (rows, sg, h), si, zi, rp, rc in zip(sets, s, z, r_p, r_c):
+                rhs = rhs - sg * rows.apply_t((zi * rp - rc) / si)
+            rhs = rhs * fmask
+            # two batched triangular solves (rocBLAS trsm); hipSOLVER's batched potrs faulted at n = 1920, batch 32
+            y = th.linalg.solve_triangular(L, rhs.unsqueeze(-1), upper=False)
+            dx = th.linalg.solve_triangular(L.transpose(1, 2), y, upper=True).squeeze(-1) * fmask
+            ds, dz = [], []
+            for (rows, sg, h), si, zi, rp, rc in zip(sets, s, z, r_p, r_c):
+                dsi = -rp - sg * rows.apply(dx)
+                ds.append(dsi)
+                dz.append((-rc - zi * dsi) / si)
+            return dx, ds, dz
+
+        def step_len(v, dv):
+            ratio = th.where(dv < 0, -v / dv, th.full_like(v, float("inf")))
+            return ratio.amin(1)
+
+        # predictor
+        dx_a, ds_a, dz_a = newton([si * zi for si, zi in zip(s, z)])
+        a_p = th.stack([step_len(si, d) for si, d in zip(s, ds_a)]).amin(0).clamp(max=1.0)
+        a_d = th.stack([step_len(zi, d) for zi, d in zip(z, dz_a)]).amin(0).clamp(max=1.0)
+        mu_a = sum(((si + a_p[:, None] * d1) * (zi + a_d[:, None] * d2)).sum(1)
+                   for si, zi, d1, d2 in zip(s, z, ds_a, dz_a)) / m_tot
+        sigma = (mu_a / mu).clamp(min=0.0, max=1.0) ** 3
+        # corrector
+        r_c = [si * zi + d1 * d2 - (sigma * mu)[:, None] for si, zi, d1, d2 in zip(s, z, ds_a, dz_a)]
+        dx, ds, dz = newton(r_c)
+        live = (~done).to(dt)
+        a_p = (0.995 * th.stack([step_len(si, d) for si, d in zip(s, ds)]).amin(0)).clamp(max=1.0) * live
+        a_d = (0.995 * th.stack([step_len(zi, d) for zi, d in zip(z, dz)]).amin(0)).clamp(max=1.0) * live
+        x = x + a_p[:, None] * dx
+        s = [si + a_p[:, None] * d for si, d in zip(s, ds)]
+        z = [zi + a_d[:, None] * d for zi, d in zip(z, dz)]
+    info["duals"] = z
+    if not bool(done.all()) and bool((info["res_p"][~done] > 1e-6).any()):
+        raise RuntimeError("Solver failed to find a solution (constraints cannot be met)")           # opf.py:155-157
+    return x, info
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the OPF itself
+# ---------------------------------------------------------------------------------------------------------------
+class BatchedOPF:
+    """B independent days x T periods of opf.py's program on one device."""
+
+    CTRL = 4                                   # Pred, Qpv, Pesc, Pesd per building (opf.py:54-58)
+
+    def __init__(self, net, env_args=None, device="cuda:0"):
+        self.net = net
+        self.cfg = dict(ENV_DEFAULTS)
+        self.cfg.update({k: v for k, v in (env_args or {}).items() if k in ENV_DEFAULTS})
+        self.device = th.device(device)
+        t = build_tables(net)
+        if not all(t.line_forward[i] for i in range(t.n_bus) if t.line_of_bus[i] is not None):
+            raise ValueError("opf.py:96-129 assume every line is keyed (from, to) away from the substation")
+        self.tables = t
+        self.n_bus = t.n_bus
+        buses = list(net["bus_numbers"])
+        self.bld = [buses.index(b) for b in net["buildings"]]
+        if list(net["PVs_at_buildings"]) != list(net["buildings"]) or list(net["ESSs_at_buildings"]) != list(net["buildings"]):
+            raise ValueError("PVs and ESSs are expected at the buildings (flex_provision.yaml:28-30)")
+        self.na = len(self.bld)
+        self.w = self.CTRL * self.na
+        f64 = dict(dtype=th.float64, device=self.device)
+        self.nonslack = th.tensor([i for i in range(t.n_bus) if i != t.slack], device=self.device)
+        self.r_line = th.tensor(t.r, **f64)                                     # by child bus
+        imax = np.array([net["max_line_currents"][k] if k is not None else np.inf for k in t.line_of_bus])
+        self.imax2 = th.tensor(imax[[i for i in range(t.n_bus) if i != t.slack]] ** 2, **f64)
+        self.tanphi = tan(acos(self.cfg["cos_phi_max"]))
+        self.dt = 24.0 / self.cfg["episode_limit"]                              # opf.py:27-28
+        # loss model Hessian: losses ~ p' Re(Z) p + q' Re(Z) q in the net loads (V ~ 1), Z = path-intersection matrix
+        rbb = np.zeros((self.na, self.na))
+        paths = []
+        for b in self.bld:
+            p, i = set(), b
+            while t.parent[i] >= 0:
+                p.add(i)
+                i = t.parent[i]
+            paths.append(p)
+        for a in range(self.na):
+            for b in range(self.na):
+                rbb[a, b] = sum(t.r[k] for k in paths[a] & paths[b])
+        # controls -> net-load change of the buildings: dp = -Pred + Pesc - Pesd, dq = -Qpv   (opf.py:96-116)
+        M = np.zeros((2 * self.na, self.w))
+        for k in range(self.na):
+            M[k, 0 * self.na + k] = -1.0
+            M[k, 2 * self.na + k] = 1.0
+            M[k, 3 * self.na + k] = -1.0
+            M[self.na + k, 1 * self.na + k] = -1.0
+        H = np.zeros((2 * self.na, 2 * self.na))
+        H[:self.na, :self.na] = 2 * rbb
+        H[self.na:, self.na:] = 2 * rbb
+        self.loss_hess = th.tensor(M.T @ H @ M, **f64)                           # [w, w], PSD
+
+    # -- network response --------------------------------------------------------------------------------------
+    def _net_loads(self, pd, qd, ppv, x):
+        """x [..., 4, na] -> (pnet, qnet) [..., n_bus] (pd, qd, ppv broadcast against x's leading dimensions)"""
+        lead = th.broadcast_shapes(x.shape[:-2], pd.shape[:-1])
+        pnet, qnet = pd.expand(*lead, self.n_bus).clone(), qd.expand(*lead, self.n_bus).clone()
+        pnet[..., self.bld] += -x[..., 0, :] - ppv + x[..., 2, :] - x[..., 3, :]
+        qnet[..., self.bld] += -x[..., 1, :]
+        return pnet, qnet
+
+    def _pf(self, pnet, qnet, want_branch=False):
+        shape = pnet.shape[:-1]
+        out = pf_solve_batch(self.net, pnet.reshape(-1, self.n_bus), qnet.reshape(-1, self.n_bus), want_branch=True)
+        if bool(out["failed"].any()):
+            raise RuntimeError("power flow failed inside the OPF (voltage collapse at a trial point)")
+        v2 = (out["v"] ** 2).reshape(*shape, self.n_bus)
+        i2 = out["isqr"].reshape(*shape, self.n_bus)
+        res = dict(v2=v2, i2=i2, loss=(i2 * self.r_line).sum(-1))
+        if want_branch:
+            res.update(pl=out["pl"].reshape(*shape, self.n_bus), ql=out["ql"].reshape(*shape, self.n_bus))
+        return res
+
+    def linearise(self, pd, qd, ppv, x, h=5e-5):
+        """State at x [B, T, 4, na] and central-difference sensitivities, all in ONE power-flow launch of
+        (1 + 2 w) B T solves.  h balances the O(h^2) truncation (~1e-9) against the power-flow tolerance (1e-12 in
+        the state, /h in the derivative)."""
+        B, T = x.shape[:2]
+        w = self.w
+        xf = x.reshape(B, T, w)
+        eye = th.eye(w, dtype=x.dtype, device=x.device) * h
+        trial = th.cat([xf.unsqueeze(2), xf.unsqueeze(2) + eye, xf.unsqueeze(2) - eye], 2)     # [B, T, 1+2w, w]
+        pnet, qnet = self._net_loads(pd.unsqueeze(2), qd.unsqueeze(2), ppv.unsqueeze(2), trial.view(B, T, 1 + 2 * w, 4, self.na))
+        s = self._pf(pnet, qnet)
+        v2 = s["v2"][..., self.nonslack]
+        i2 = s["i2"][..., self.nonslack]
+        jv = ((v2[:, :, 1:1 + w] - v2[:, :, 1 + w:]) / (2 * h)).transpose(2, 3)               # [B, T, rows, w]
+        ji = ((i2[:, :, 1:1 + w] - i2[:, :, 1 + w:]) / (2 * h)).transpose(2, 3)
+        gl = (s["loss"][:, :, 1:1 + w] - s["loss"][:, :, 1 + w:]) / (2 * h)                   # [B, T, w]
+        # measured diagonal curvature of the losses -> one scale per period for the model Hessian 2 Re(Zbus)
+        # (voltages below 1 pu and the losses' own feedback make the true curvature 10-40 % larger)
+        d2 = (s["loss"][:, :, 1:1 + w] - 2 * s["loss"][:, :, :1] + s["loss"][:, :, 1 + w:]) / (h * h)
+        kappa = (d2.sum(-1) / self.loss_hess.diagonal().sum()).clamp(0.5, 3.0)                # [B, T]
+        return dict(v2=v2[:, :, 0], i2=i2[:, :, 0], loss=s["loss"][:, :, 0], jv=jv, ji=ji, gloss=gl, kappa=kappa)
+
+    # -- objective and chain -----------------------------------------------------------------------------------
+    def energy(self, e0, x):
+        """opf.py:139-148: E[1] = E_init; E[t] = E[t-1] + dt (eta_ch Pesc[t] - Pesd[t]/eta_dis)."""
+        inc = self.dt * (self.cfg["eta_ch"] * x[:, :, 2] - x[:, :, 3] / self.cfg["eta_dis"])
+        inc = th.cat([th.zeros_like(inc[:, :1]), inc[:, 1:]], 1)
+        return e0[:, None, :] + inc.cumsum(1)
+
+    def objective(self, price, x, loss):
+        c = self.cfg
+        per = (price[:, :, None] * x[:, :, 0] - c["pv_cost"] * x[:, :, 1] - c["ess_cost"] * (x[:, :, 2] + x[:, :, 3])
+               - c["discomfort_coeff"] * x[:, :, 0] ** 2).sum(-1) - loss
+        return self.dt * per.sum(1)                                               # opf.py:80-93
+
+    def bounds(self, pd, ppv):
+        c = self.cfg
+        B, T = pd.shape[:2]
+        lo = th.zeros(B, T, 4, self.na, dtype=pd.dtype, device=pd.device)
+        hi = th.zeros_like(lo)
+        hi[:, :, 0] = pd[..., self.bld] * c["max_power_reduction"]                # opf.py:46,54
+        lo[:, :, 1], hi[:, :, 1] = -self.tanphi * ppv, self.tanphi * ppv          # opf.py:118-120
+        hi[:, :, 2], hi[:, :, 3] = c["p_ch_max"], c["p_dis_max"]                  # opf.py:56-57
+        return lo, hi
+
+    def _energy_matrix(self, T, dtype):
+        """E (stacked [T, na]) = e0 + C x."""
+        C = th.zeros(T, self.na, T, 4, self.na, dtype=dtype, device=self.device)
+        for k in range(self.na):
+            for s in range(1, T):
+                C[s:, k, s, 2, k] = self.dt * self.cfg["eta_ch"]
+                C[s:, k, s, 3, k] = -self.dt / self.cfg["eta_dis"]
+        return C.view(T * self.na, T * self.w)
+
+    # -- the solve ---------------------------------------------------------------------------------------------
+    def solve(self, price, pd, qd, ppv, e0, max_outer=12, tol=1e-6, verbose=False):
+        """price [B, T], pd/qd [B, T, n_bus], ppv [B, T, na], e0 [B, na] (device f64).  Returns a dict of tensors.
+        Stops when no control moved by more than ``tol`` pu (1e-6 pu = 1 W on the 1 MVA base) in an outer iteration."""
+        c = self.cfg
+        f64 = dict(dtype=th.float64, device=self.device)
+        price, pd, qd, ppv, e0 = (th.as_tensor(a, **f64) for a in (price, pd, qd, ppv, e0))
+        B, T = price.shape
+        w, n = self.w, T * self.w
+        lo, hi = self.bounds(pd, ppv)
+        x = lo.clone()
+        x[:, :, 0] = th.minimum(price[:, :, None] / (2 * c["discomfort_coeff"]), hi[:, :, 0])
+        C = self._energy_matrix(T, th.float64)
+        history = []
+        for outer in range(max_outer):
+            lin = self.linearise(pd, qd, ppv, x)
+            xk = x.reshape(B, n)
+            # model:  minimise  -dt [ price Pred - pv Qpv - ess (ch + dis) - disc Pred^2 - loss_k - g'(x-xk) - 1/2 (x-xk)' H (x-xk) ]
+            hess = lin["kappa"][:, :, None, None] * self.loss_hess                             # [B, T, w, w]
+            Qblk = self.dt * hess
+            idx = th.arange(self.na, device=self.device)
+            Qblk[:, :, idx, idx] += 2 * self.dt * c["discomfort_coeff"]
+            lin_c = th.zeros(B, T, 4, self.na, **f64)
+            lin_c[:, :, 0] = -price[:, :, None]
+            lin_c[:, :, 1] = c["pv_cost"]
+            lin_c[:, :, 2] = c["ess_cost"]
+            lin_c[:, :, 3] = c["ess_cost"]
+            hk = th.einsum("btvw,btw->btv", hess, x.reshape(B, T, w))
+            cvec = (self.dt * (lin_c.reshape(B, T, w) + lin["gloss"] - hk)).reshape(B, n)
+            # linearised network limits in x:  J x <= u - g_k + J x_k
+            jvx = th.einsum("btrw,btw->btr", lin["jv"], x.reshape(B, T, w))
+            jix = th.einsum("btrw,btw->btr", lin["ji"], x.reshape(B, T, w))
+            v_lo = (c["v_min"] ** 2 - lin["v2"] + jvx).reshape(B, -1)
+            v_hi = (c["v_max"] ** 2 - lin["v2"] + jvx).reshape(B, -1)
+            i_hi = (self.imax2 - lin["i2"] + jix).reshape(B, -1)
+            e_lo = (c["e_min"] - e0)[:, None, :].expand(B, T, self.na).reshape(B, -1)
+            e_hi = (c["e_max"] - e0)[:, None, :].expand(B, T, self.na).reshape(B, -1)
+            # a control whose box is a point (Qpv at night) is pinned: it leaves the Newton system, and its box rows are
+            # widened so that they stay inactive (the QP keeps an interior)
+            free = ((hi - lo) >= 1e-9).reshape(B, n)
+            pin = (~free).to(lo.dtype).reshape(B, T, 4, self.na)
+            blocks = [(_Identity(), (lo - pin).reshape(B, n), (hi + pin).reshape(B, n)),
+                      (_PeriodBlocks(lin["jv"]), v_lo, v_hi),
+                      (_PeriodBlocks(lin["ji"]), None, i_hi),
+                      (_Shared(C), e_lo, e_hi)]
+            x0 = th.where(free, 0.5 * (lo + hi).reshape(B, n), lo.reshape(B, n))
+            xn, info = qp_ipm(Qblk, cvec, blocks, x0, free=free, verbose=verbose)
+            xn = th.minimum(th.maximum(xn.view(B, T, 4, self.na), lo), hi)
+            move = (xn - x).abs().amax().item()                                    # pu
+            obj = self.objective(price, x, lin["loss"])
+            history.append(dict(outer=outer, move=move, objective=obj.clone(), ipm_iters=info["iters"]))
+            if verbose:
+                print(f"outer {outer}: objective {obj.mean().item():+.9f}  max move {move:.2e}  ipm iters {info['iters']}")
+            x = xn
+            if move < tol:
+                break
+        fin_p, fin_q = self._net_loads(pd, qd, ppv, x)
+        st = self._pf(fin_p, fin_q, want_branch=True)
+        e = self.energy(e0, x)
+        return dict(x=x, Pred=x[:, :, 0], Qpv=x[:, :, 1], Pesc=x[:, :, 2], Pesd=x[:, :, 3], E=e, Vsqr=st["v2"],
+                    Isqr=st["i2"], Pl=st["pl"], Ql=st["ql"], loss=st["loss"], objective=self.objective(price, x, st["loss"]),
+                    outer_iters=len(history), history=history, duals=info.get("duals"))
+
+
+def opf_model(network_data, flex_price, active_power_demand, reactive_power_demand, pv_active_power,
+              initial_ess_energy, env_args=None, device="cuda:0"):
+    """Drop-in for ``utils/opf.py:13`` (same arguments, same solution dict; ``run_opf.py:71`` is the caller).
+    ``flex_price`` {t: price} with t = 1..T; demands {bus: [T]}; PV {bus: [T]}; initial energy {bus: E}."""
+    buses = list(network_data["bus_numbers"])
+    T = len(flex_price)
+    price = np.array([flex_price[t + 1] for t in range(T)])
+    pd = np.array([[active_power_demand[b][t] for b in buses] for t in range(T)])
+    qd = np.array([[reactive_power_demand[b][t] for b in buses] for t in range(T)])
+    ppv = np.array([[pv_active_power[g][t] for g in network_data["PVs_at_buildings"]] for t in range(T)])
+    e0 = np.array([initial_ess_energy[k] for k in network_data["ESSs_at_buildings"]])
+    solver = BatchedOPF(network_data, env_args, device)
+    r = solver.solve(price[None], pd[None], qd[None], ppv[None], e0[None])
+    tb = solver.tables
+    B_, G_, K_ = network_data["buildings"], network_data["PVs_at_buildings"], network_data["ESSs_at_buildings"]
+    cpu = {k: v[0].cpu().numpy() for k, v in r.items() if isinstance(v, th.Tensor)}
+    lines = [(i, tb.line_of_bus[i]) for i in range(tb.n_bus) if tb.line_of_bus[i] is not None]
+    sol = {key: {} for key in ("Power Reduction", "PV Reactive Power", "ESS Charging", "ESS Discharging", "Voltage Squared",
+                               "Active Power Flow", "Reactive Power Flow", "Current Squared", "ESS Energy",
+                               "Charging Indicator", "Active Power Load", "Reactive Power Load", "PV Active Power")}
+    for t in range(T):
+        sol["Power Reduction"][t + 1] = {b: float(cpu["Pred"][t, i]) for i, b in enumerate(B_)}
+        sol["PV Reactive Power"][t + 1] = {g: float(cpu["Qpv"][t, i]) for i, g in enumerate(G_)}
+        sol["ESS Charging"][t + 1] = {k: float(cpu["Pesc"][t, i]) for i, k in enumerate(K_)}
+        sol["ESS Discharging"][t + 1] = {k: float(cpu["Pesd"][t, i]) for i, k in enumerate(K_)}
+        sol["Voltage Squared"][t + 1] = {b: float(cpu["Vsqr"][t, i]) for i, b in enumerate(buses)}
+        sol["Active Power Flow"][t + 1] = {key: float(cpu["Pl"][t, i]) for i, key in lines}
+        sol["Reactive Power Flow"][t + 1] = {key: float(cpu["Ql"][t, i]) for i, key in lines}
+        sol["Current Squared"][t + 1] = {key: float(cpu["Isqr"][t, i]) for i, key in lines}
+        sol["ESS Energy"][t + 1] = {k: float(cpu["E"][t, i]) for i, k in enumerate(K_)}
+        sol["Charging Indicator"][t + 1] = {k: float(cpu["Pesc"][t, i] > cpu["Pesd"][t, i]) for i, k in enumerate(K_)}
+        sol["Active Power Load"][t + 1] = {b: float(pd[t, i]) for i, b in enumerate(buses)}
+        sol["Reactive Power Load"][t + 1] = {b: float(qd[t, i]) for i, b in enumerate(buses)}
+        sol["PV Active Power"][t + 1] = {g: float(ppv[t, i]) for i, g in enumerate(G_)}
+    return sol

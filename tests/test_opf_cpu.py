@@ -1,0 +1,107 @@
+"""CPU coverage of the OPF comparator: the oracle against the reference's own expressions, and the
+batched interior-point QP (pure torch, runs on the CPU) against SciPy."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import opf_oracle as oo
+from safe_marl_amd.network import create_network
+from safe_marl_amd.series import make_synthetic_series
+
+
+def _instance(net, T, day=3, first=40, n_days=6):
+    s = make_synthetic_series(net, n_days=n_days)
+    rows = np.asarray(s.table)[96 * day + first:96 * day + first + T]
+    return rows[:, 71], rows[:, :33], rows[:, 33:66], rows[:, 66:71], np.full(5, 0.0125)
+
+
+def test_oracle_solution_zeroes_the_reference_expressions():
+    net = create_network()
+    price, pd, qd, ppv, e0 = _instance(net, 2)
+    x, f, info = oo.solve_reduced(net, {}, price, pd, qd, ppv, e0)
+    assert info["success"]
+    sol = oo.solution_dict(net, {}, pd, qd, ppv, e0, x)
+    res = oo.opf_residuals(net, {}, pd, qd, ppv, e0, sol)
+    for k in ("active", "reactive", "vdrop", "current_def", "energy", "slack_v"):
+        assert res[k] < 1e-10, (k, res[k])                     # equalities opf.py:96-129,139-148
+    for k in ("current_lim", "v_lim", "qpv_lim", "e_lim", "box"):
+        assert res[k] < 1e-9, (k, res[k])                      # inequalities opf.py:54-65,118-137
+    assert res["simultaneous"] < 1e-9                          # relaxed binaries opf.py:150-156 are tight
+    assert abs(oo.opf_objective(net, {}, price, sol) - f) < 1e-12
+    assert oo.first_order_gap(net, {}, price, pd, qd, ppv, e0, x) < 1e-9
+    # better than the separable guess (flexibility at its unconstrained optimum, nothing else)
+    x0 = np.zeros_like(x)
+    x0[:, 0] = np.minimum(price[:, None] / 0.3, pd[:, [4, 9, 14, 19, 24]] * 0.5)
+    f0 = oo.opf_objective(net, {}, price, oo.solution_dict(net, {}, pd, qd, ppv, e0, x0))
+    assert f >= f0 - 1e-12
+
+
+def test_first_period_storage_never_reaches_the_energy_balance():
+    """opf.py:140-142: E[k,1] = E_init whatever Pesc[k,1], Pesd[k,1] are."""
+    net = create_network()
+    price, pd, qd, ppv, e0 = _instance(net, 2)
+    P = oo.ReducedOPF(net, {}, price, pd, qd, ppv, e0)
+    x = np.zeros((2, 4, 5))
+    x[0, 3] = 0.005
+    x[1, 2] = 0.004
+    e = P.energy(x.ravel())
+    assert np.allclose(e[0], e0) and np.allclose(e[1], e0 + 0.25 * 0.9 * 0.004)
+
+
+def test_batched_interior_point_matches_scipy():
+    from scipy.optimize import minimize
+    from safe_marl_amd.opf import _Identity, _PeriodBlocks, _Shared, qp_ipm
+
+    rng = np.random.default_rng(5)
+    B, T, w, R, mE = 3, 4, 6, 5, 7
+    n = T * w
+    A = rng.normal(size=(B, T, w, w))
+    Q = A @ A.transpose(0, 1, 3, 2) * 0.1                      # PSD blocks, some nearly singular
+    Q[:, :, 0, :] = 0
+    Q[:, :, :, 0] = 0                                          # an LP-like direction
+    c = rng.normal(size=(B, n))
+    lo, hi = -np.ones((B, n)), np.ones((B, n))
+    lo[:, 3] = hi[:, 3] = 0.25                                 # a pinned variable
+    J = rng.normal(size=(B, T, R, w))
+    ju = np.abs(rng.normal(size=(B, T * R))) + 0.2
+    C = rng.normal(size=(mE, n))
+    cl, cu = -np.abs(rng.normal(size=(B, mE))) - 0.1, np.abs(rng.normal(size=(B, mE))) + 0.1
+    t = lambda a: torch.tensor(a, dtype=torch.float64)
+    free = t(hi - lo) >= 1e-9
+    pin = (~free).double()
+    blocks = [(_Identity(), t(lo) - pin, t(hi) + pin), (_PeriodBlocks(t(J)), None, t(ju)), (_Shared(t(C)), t(cl), t(cu))]
+    x0 = torch.where(free, t(0.5 * (lo + hi)), t(lo))
+    x, info = qp_ipm(t(Q), t(c), blocks, x0, free=free)
+    assert bool(info["converged"].all())
+    # (1) KKT certificate from the solver's own multipliers: sufficient for a convex QP, independent of any other solver.
+    # duals come per one-sided row set in the order (upper, lower) of each block
+    z = [d.numpy() for d in info["duals"]]
+    xs = x.numpy()
+    for b in range(B):
+        Qd = np.zeros((n, n))
+        Jd = np.zeros((T * R, n))
+        for k in range(T):
+            Qd[k * w:(k + 1) * w, k * w:(k + 1) * w] = Q[b, k]
+            Jd[k * R:(k + 1) * R, k * w:(k + 1) * w] = J[b, k]
+        xb = xs[b]
+        fr = (hi[b] - lo[b]) >= 1e-9
+        rows = [(np.eye(n), (hi[b] + ~fr), +1), (np.eye(n), (lo[b] - ~fr), -1), (Jd, ju[b], +1), (C, cu[b], +1), (C, cl[b], -1)]
+        grad = Qd @ xb + c[b]
+        for (Am, bound, sg), zz in zip(rows, z):
+            zb = zz[b]
+            assert zb.min() >= 0
+            slack = sg * (bound - Am @ xb)
+            assert slack.min() > -1e-8                                  # primal feasibility
+            assert np.abs(zb * slack).max() < 1e-7                      # complementarity
+            grad = grad + sg * (Am.T @ zb)
+        assert np.abs(grad[fr]).max() < 2e-5 * max(1.0, np.abs(c[b]).max())   # stationarity on the free variables (the dual residual floors with the conditioning)
+        assert abs(xb[3] - 0.25) < 1e-12                                # the pinned one never moved
+        # (2) and SciPy agrees on the optimal value
+        from scipy.optimize import Bounds, LinearConstraint
+        ref = minimize(lambda v: 0.5 * v @ Qd @ v + c[b] @ v, np.clip(np.zeros(n), lo[b], hi[b]), jac=lambda v: Qd @ v + c[b],
+                       hess=lambda v: Qd, bounds=Bounds(lo[b], hi[b]), method="trust-constr",
+                       constraints=[LinearConstraint(Jd, -np.inf, ju[b]), LinearConstraint(C, cl[b], cu[b])],
+                       options=dict(gtol=1e-10, xtol=1e-12, maxiter=3000))
+        f_ipm = 0.5 * xb @ Qd @ xb + c[b] @ xb
+        assert f_ipm <= ref.fun + 1e-6 * max(1.0, abs(ref.fun))
+        assert abs(f_ipm - ref.fun) < 1e-4 * max(1.0, abs(ref.fun))
