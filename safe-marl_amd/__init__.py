@@ -25,4 +25,7 @@ def __getattr__(name):
     if name == "PGTester":
         from . import tester
         return tester.PGTester
+    if name in ("opf_model", "BatchedOPF"):
+        from . import opf
+        return getattr(opf, name)
     raise AttributeError(name)

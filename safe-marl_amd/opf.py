@@ -102,6 +102,46 @@ class _Shared(_Rows):
         N += th.einsum("mi,bm,mj->bij", self.C, d, self.C)
 
 
+class _EnergyChain(_Rows):
+    """The storage energy chain opf.py:139-148 as an operator: row (t, k) is E[t, k] - E_init[k] =
+    sum_{1 <= s <= t} (a Pesc[s, k] - b Pesd[s, k]) with a = dt eta_ch, b = dt / eta_dis (period 0 contributes nothing).
+    Same rows as ``_Shared(C)`` with the explicit matrix, but apply / transpose are cumulative sums and the Gram
+    matrix is a gather of suffix sums: C' diag(d) C [s, s'] = coef coef' sum_{t >= max(s, s')} d[t]."""
+
+    def __init__(self, T, na, a, b):
+        self.T, self.na, self.a, self.b = T, na, a, b
+
+    def apply(self, x):
+        x = x.view(x.shape[0], self.T, 4, self.na)
+        inc = self.a * x[:, :, 2] - self.b * x[:, :, 3]
+        inc = th.cat([th.zeros_like(inc[:, :1]), inc[:, 1:]], 1)
+        return inc.cumsum(1).reshape(x.shape[0], -1)
+
+    def _suffix(self, y):
+        y = y.view(y.shape[0], self.T, self.na)
+        s = y.flip(1).cumsum(1).flip(1)
+        return th.cat([th.zeros_like(s[:, :1]), s[:, 1:]], 1)           # period 0 has no coefficient
+
+    def apply_t(self, y):
+        s = self._suffix(y)
+        out = th.zeros(y.shape[0], self.T, 4, self.na, dtype=y.dtype, device=y.device)
+        out[:, :, 2] = self.a * s
+        out[:, :, 3] = -self.b * s
+        return out.reshape(y.shape[0], -1)
+
+    def add_gram(self, N, d):
+        B = d.shape[0]
+        s = self._suffix(d)                                              # [B, T, na]
+        idx = th.arange(self.T, device=d.device)
+        g = s[:, th.maximum(idx[:, None], idx[None, :])]                 # [B, T, T, na]: suffix sum at max(s, s')
+        g = g * ((idx[:, None] > 0) & (idx[None, :] > 0)).to(d.dtype)[None, :, :, None]
+        blk = N.view(B, self.T, 4, self.na, self.T, 4, self.na).diagonal(dim1=3, dim2=6)     # [B, T, 4, T, 4, na]
+        blk[:, :, 2, :, 2] += (self.a * self.a) * g
+        blk[:, :, 2, :, 3] -= (self.a * self.b) * g
+        blk[:, :, 3, :, 2] -= (self.a * self.b) * g
+        blk[:, :, 3, :, 3] += (self.b * self.b) * g
+
+
 def qp_ipm(Qblk, c, blocks, x0, free=None, max_iter=80, tol=1e-11, reg=1e-12, verbose=False):
     """Mehrotra predictor-corrector on a batch of convex QPs.
 
@@ -350,7 +390,6 @@ class BatchedOPF:
         lo, hi = self.bounds(pd, ppv)
         x = lo.clone()
         x[:, :, 0] = th.minimum(price[:, :, None] / (2 * c["discomfort_coeff"]), hi[:, :, 0])
-        C = self._energy_matrix(T, th.float64)
         history = []
         for outer in range(max_outer):
             lin = self.linearise(pd, qd, ppv, x)
@@ -382,7 +421,7 @@ class BatchedOPF:
             blocks = [(_Identity(), (lo - pin).reshape(B, n), (hi + pin).reshape(B, n)),
                       (_PeriodBlocks(lin["jv"]), v_lo, v_hi),
                       (_PeriodBlocks(lin["ji"]), None, i_hi),
-                      (_Shared(C), e_lo, e_hi)]
+                      (_EnergyChain(T, self.na, self.dt * c["eta_ch"], self.dt / c["eta_dis"]), e_lo, e_hi)]
             x0 = th.where(free, 0.5 * (lo + hi).reshape(B, n), lo.reshape(B, n))
             xn, info = qp_ipm(Qblk, cvec, blocks, x0, free=free, verbose=verbose)
             xn = th.minimum(th.maximum(xn.view(B, T, 4, self.na), lo), hi)

@@ -105,3 +105,28 @@ def test_batched_interior_point_matches_scipy():
         f_ipm = 0.5 * xb @ Qd @ xb + c[b] @ xb
         assert f_ipm <= ref.fun + 1e-6 * max(1.0, abs(ref.fun))
         assert abs(f_ipm - ref.fun) < 1e-4 * max(1.0, abs(ref.fun))
+
+
+def test_energy_chain_operator_equals_its_matrix():
+    """opf.py:139-148 as cumulative sums vs the explicit [T*na, T*4*na] matrix."""
+    from safe_marl_amd.opf import BatchedOPF, _EnergyChain, _Shared
+    net = create_network()
+    opf = BatchedOPF(net, device="cpu")
+    T, B = 6, 2
+    C = opf._energy_matrix(T, torch.float64)
+    op, ref = _EnergyChain(T, opf.na, opf.dt * 0.9, opf.dt / 0.9), _Shared(C)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T * opf.w, dtype=torch.float64, generator=g)
+    y = torch.randn(B, T * opf.na, dtype=torch.float64, generator=g)
+    d = torch.rand(B, T * opf.na, dtype=torch.float64, generator=g)
+    assert torch.allclose(op.apply(x), ref.apply(x), atol=1e-14)
+    assert torch.allclose(op.apply_t(y), ref.apply_t(y), atol=1e-14)
+    n = T * opf.w
+    N1, N2 = torch.zeros(B, n, n, dtype=torch.float64), torch.zeros(B, n, n, dtype=torch.float64)
+    op.add_gram(N1, d)
+    ref.add_gram(N2, d)
+    assert torch.allclose(N1, N2, atol=1e-14)
+    # and it is the chain: E = e0 + C x
+    xx = torch.rand(B, T, 4, opf.na, dtype=torch.float64, generator=g)
+    e0 = torch.full((B, opf.na), 0.0125, dtype=torch.float64)
+    assert torch.allclose(opf.energy(e0, xx), e0[:, None, :] + op.apply(xx.reshape(B, -1)).view(B, T, opf.na), atol=1e-15)
