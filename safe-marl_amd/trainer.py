@@ -99,8 +99,12 @@ class PGTrainer(object):
                 stat["mean_train_entropy"] = entropy.detach()
         else:
             loss = value_loss
-        loss.backward()
+        # gradients of THIS optimiser's parameters only: a plain backward() would also fill the other network's
+        # .grad (the critic's first-layer weight gradient is the largest GEMM of a policy step) just to have it
+        # zeroed by that optimiser's next zero_grad (trainer.py:82,100)
         params = opt.param_groups[0]["params"]
+        for p, g in zip(params, th.autograd.grad(loss, params, allow_unused=True)):
+            p.grad = g
         if self.world > 1:
             fdist.allreduce_grads(params)
         grad_norm = get_grad_norm(self.args, params)          # after the all-reduce
