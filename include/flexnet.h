@@ -1,0 +1,63 @@
+/* flexnet.h — C ABI of the learner-side kernels of the flexibility-provision hot path (gfx950).
+ *
+ * The reference's actor is a PyTorch module evaluated once per environment step and agent:
+ *     madrl/agents/rnn_agent.py:13-33  RNNAgent: fc1 -> LayerNorm -> ReLU -> GRUCell -> fc2
+ *     madrl/models/model.py:102-140    Model.policy: obs (+ one-hot agent id) -> means, hidden
+ * flexnet_actor_forward is that forward pass (inference: no autograd graph) for a whole batch of rows in ONE launch:
+ * row r is agent r % n_agents of sample r / n_agents, exactly the [b * n, .] reshape of model.py:110-112.
+ * Weights are passed in the layout of the reference's state_dict (row-major [out, in]); the kernel re-lays them out
+ * in LDS itself, so a state_dict loaded from the reference works unchanged.
+ *
+ * Plain pointers and sizes only; every pointer is DEVICE memory (fp32); asynchronous on `stream` (a hipStream_t).
+ * Return 0 or a negative FLEXNET_E* code for API errors.
+ */
+#ifndef FLEXNET_H
+#define FLEXNET_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLEXNET_OK 0
+#define FLEXNET_EINVAL (-1)
+#define FLEXNET_EHIP (-2)
+#define FLEXNET_EUNSUPPORTED (-3)  /* shape outside what the fused kernel holds in LDS: the caller keeps its own path */
+
+#define FLEXNET_HID 64             /* hid_size of madrl/args/default.yaml:33; the kernel maps one lane to one unit */
+#define FLEXNET_MAX_OBS 144        /* obs_size = 6 * history (env:370-403), history <= 24 */
+#define FLEXNET_MAX_AGENTS 8
+#define FLEXNET_MAX_ACT 8
+
+typedef struct {
+    int32_t rows;              /* b * n_agents */
+    int32_t n_agents;
+    int32_t obs_dim;           /* <= FLEXNET_MAX_OBS */
+    int32_t act_dim;           /* <= FLEXNET_MAX_ACT */
+    int32_t agent_id;          /* 1: fc1 has n_agents one-hot id columns after the obs_dim observation columns (model.py:105-108) */
+    int32_t layernorm;         /* args.layernorm (rnn_agent.py:19-20,27-28) */
+    float ln_eps;              /* nn.LayerNorm default 1e-5 */
+    float pad0;
+    const float* obs;          /* [rows, obs_dim] */
+    const float* hidden_in;    /* [rows, 64] */
+    const float* fc1_w;        /* [64, obs_dim (+ n_agents)] */
+    const float* fc1_b;        /* [64] */
+    const float* ln_w;         /* [64] (ignored without layernorm) */
+    const float* ln_b;         /* [64] */
+    const float* w_ih;         /* [192, 64]  GRUCell.weight_ih, gate order r, z, n */
+    const float* w_hh;         /* [192, 64] */
+    const float* b_ih;         /* [192] */
+    const float* b_hh;         /* [192] */
+    const float* fc2_w;        /* [act_dim, 64] */
+    const float* fc2_b;        /* [act_dim] */
+    float* means;              /* out [rows, act_dim]  (fc2 output: the action mean, rnn_agent.py:32) */
+    float* hidden_out;         /* out [rows, 64]       (GRU state, rnn_agent.py:31) */
+} FlexActorArgs;
+
+/* rnn_agent.py:25-33 + model.py:102-116 for all rows. */
+int flexnet_actor_forward(const FlexActorArgs* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

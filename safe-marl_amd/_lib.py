@@ -59,7 +59,18 @@ SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
+    "flexnet_actor_forward",
 )
+
+class FlexActorArgs(C.Structure):
+    """include/flexnet.h"""
+    _fields_ = [("rows", C.c_int32), ("n_agents", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32),
+                ("agent_id", C.c_int32), ("layernorm", C.c_int32), ("ln_eps", C.c_float), ("pad0", C.c_float)] + \
+               [(k, C.c_void_p) for k in ("obs", "hidden_in", "fc1_w", "fc1_b", "ln_w", "ln_b", "w_ih", "w_hh", "b_ih",
+                                          "b_hh", "fc2_w", "fc2_b", "means", "hidden_out")]
+
+
+FLEXNET_EUNSUPPORTED = -3
 
 _lib = None
 
@@ -92,6 +103,8 @@ def load():
     lib.flexenv_create.argtypes = [C.POINTER(FlexCfg), C.POINTER(NetFix), C.POINTER(SeriesTab), i32, i32,
                                    C.POINTER(vp)]
     lib.flexenv_create.restype = C.c_int
+    lib.flexnet_actor_forward.argtypes = [C.POINTER(FlexActorArgs), vp]
+    lib.flexnet_actor_forward.restype = C.c_int
     lib.flexenv_destroy.argtypes = [vp]
     lib.flexenv_destroy.restype = None
     lib.flexenv_reset.argtypes = [vp, vp, C.POINTER(ResetSpec), vp, i32, vp, vp]

@@ -8,8 +8,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "flexenv.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", "flex_device.h"), os.path.join(ROOT, "include", "flexenv.h")]
+SRC = [os.path.join(HERE, "csrc", "flexenv.hip"), os.path.join(HERE, "csrc", "actor.hip")]
+DEPS = SRC + [os.path.join(HERE, "csrc", "flex_device.h"), os.path.join(ROOT, "include", "flexenv.h"),
+              os.path.join(ROOT, "include", "flexnet.h")]
 OUT = os.path.join(HERE, "libflexenv_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",

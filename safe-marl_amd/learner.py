@@ -19,7 +19,7 @@ import numpy as np
 import torch as th
 import torch.nn as nn
 
-from .nets import MLPAgent, MLPCritic, RNNAgent
+from .nets import MLPAgent, MLPCritic, RNNAgent, fused_actor_forward
 from .replay_buffer import Transition
 from .util import prep_obs, scale_action, select_action, translate_action
 
@@ -103,6 +103,7 @@ class Model(nn.Module):
         self.act_dim = self.args.action_dim
         self.Transition = Transition
         self.batchnorm = nn.BatchNorm1d(self.n_)
+        self.fused_inference = True      # no-grad policy passes on the GPU go through csrc/actor.hip
 
     # -- construction ------------------------------------------------------------------------------
     def construct_policy_net(self):
@@ -141,6 +142,15 @@ class Model(nn.Module):
     def policy(self, obs, schedule=None, last_act=None, last_hid=None, info={}, stat={}):
         """model.py:102-140. obs [b, n, o] -> means [b, n, a], log_stds, hiddens [b, n, hid]."""
         b = obs.size(0)
+        fused = None
+        if self.args.shared_params and obs.is_cuda and not th.is_grad_enabled() and self.fused_inference:
+            # rollout steps and bootstrap targets: one HIP launch instead of the module's ten kernels
+            fused = fused_actor_forward(self.policy_dicts[0], obs, last_hid, self.n_, self.args.agent_id)
+        if fused is not None:
+            means = fused[0].view(b, self.n_, -1)
+            hiddens = fused[1].view(b, self.n_, -1)
+            log_stds = th.full_like(means, float(np.log(self.args.fixed_policy_std)))
+            return means, log_stds, hiddens
         if self.args.agent_id:
             ids = th.eye(self.n_, device=obs.device, dtype=obs.dtype).expand(b, -1, -1)
             obs = th.cat((obs, ids), dim=-1)

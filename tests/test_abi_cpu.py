@@ -17,15 +17,19 @@ def lib():
 
 
 def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "flexenv.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|void|int32_t|const char\*)\s+\*?(flexenv_\w+|pf_solve_batch)\s*\(", src)))
+    names = set()
+    for header in ("flexenv.h", "flexnet.h"):                      # every header under include/
+        src = open(os.path.join(ROOT, "include", header)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(?:int|void|int32_t|const char\*)\s+\*?(flexenv_\w+|flexnet_\w+|pf_solve_batch)\s*\(", src))
+    return sorted(names)
 
 
 def test_every_declared_symbol_is_exported(lib):
     from safe_marl_amd import _lib
     names = _declared_functions()
-    assert len(names) >= 14
+    assert len(names) >= 15
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["flexenv.h", "flexnet.h"]
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_lib.SYMBOLS)
@@ -37,6 +41,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.FlexCfg) == 200          # 10 x int32 + 19 x double + uint64
     assert C.sizeof(_lib.NetFix) == 16 + 6 * 8
     assert C.sizeof(_lib.SeriesTab) == 24 and C.sizeof(_lib.ResetSpec) == 40
+    assert C.sizeof(_lib.FlexActorArgs) == 8 * 4 + 14 * 8     # include/flexnet.h
 
 
 def test_bad_arguments_are_rejected_before_any_device_work(lib, net):
@@ -50,6 +55,10 @@ def test_bad_arguments_are_rejected_before_any_device_work(lib, net):
     assert lib.flexenv_create(C.byref(cfg), C.byref(nf), C.byref(st), 4, 0, C.byref(h)) == -22
     assert lib.flexenv_step(None, None, 0, None, None, None, None, None, 0, 0, None) == -22
     assert lib.flexenv_num_envs(None) == 0
+    assert lib.flexnet_actor_forward(None, None) == -1                                  # FLEXNET_EINVAL
+    a = _lib.FlexActorArgs()
+    a.rows = 8
+    assert lib.flexnet_actor_forward(C.byref(a), None) == -1                            # null tensors
 
 
 def test_product_path_fails_loudly_without_the_library(monkeypatch, tmp_path):

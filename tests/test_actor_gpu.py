@@ -1,0 +1,79 @@
+"""The fused actor inference kernel (csrc/actor.hip, include/flexnet.h) against the PyTorch module it replaces,
+which carries the reference's parameter names and arithmetic (rnn_agent.py:13-33; golden parity of that module with
+the imported reference is tests/test_learner_cpu.py).  fp32; tolerance 2e-5 absolute on O(1) activations (the
+summation order differs from rocBLAS)."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _agent(obs_dim, n_agents, act_dim, layernorm=True, agent_id=True, seed=0):
+    from safe_marl_amd.nets import RNNAgent
+    torch.manual_seed(seed)
+    args = types.SimpleNamespace(hid_size=64, layernorm=layernorm, action_dim=act_dim, agent_num=n_agents,
+                                 hid_activation="relu")
+    agent = RNNAgent(obs_dim + (n_agents if agent_id else 0), args).cuda()
+    with torch.no_grad():                      # not the tiny init of init_std: make every term matter
+        for p in agent.parameters():
+            p.copy_(torch.randn_like(p) * 0.3)
+    return agent
+
+
+def _reference(agent, obs, hidden, n_agents, agent_id):
+    b = obs.shape[0]
+    x = obs
+    if agent_id:
+        x = torch.cat((obs, torch.eye(n_agents, device=obs.device).expand(b, -1, -1)), -1)     # model.py:105-108
+    with torch.no_grad():
+        means, _, h = agent(x.reshape(b * n_agents, -1), hidden.reshape(b * n_agents, -1))
+    return means, h
+
+
+@pytest.mark.parametrize("b,n,obs_dim,act,ln,aid", [(4096, 5, 144, 4, True, True), (3, 5, 144, 4, True, True),
+                                                    (1, 1, 144, 4, True, False), (37, 3, 72, 2, False, True),
+                                                    (130, 8, 6, 8, True, True), (1001, 5, 144, 4, True, True)])
+def test_matches_module(b, n, obs_dim, act, ln, aid):
+    from safe_marl_amd.nets import fused_actor_forward
+    agent = _agent(obs_dim, n, act, layernorm=ln, agent_id=aid)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    obs = torch.randn(b, n, obs_dim, device="cuda", generator=g)
+    hid = torch.randn(b, n, 64, device="cuda", generator=g)
+    out = fused_actor_forward(agent, obs, hid, n, aid)
+    assert out is not None
+    ref_m, ref_h = _reference(agent, obs, hid, n, aid)
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()
+    assert (out[1] - ref_h).abs().max().item() < 2e-5
+    assert (out[0] - ref_m).abs().max().item() < 5e-5 * max(1.0, ref_m.abs().max().item())
+
+
+def test_unsupported_shapes_fall_back():
+    from safe_marl_amd.nets import fused_actor_forward
+    agent = _agent(200, 5, 4)                                             # obs wider than the kernel stages
+    obs = torch.randn(2, 5, 200, device="cuda")
+    assert fused_actor_forward(agent, obs, torch.zeros(2, 5, 64, device="cuda"), 5, True) is None
+
+
+def test_policy_uses_the_kernel_without_grad_and_the_module_with():
+    """Model.policy: same numbers either way; the fused path only where no graph is needed."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.util import convert
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="maddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4)
+    torch.manual_seed(3)
+    m = MADDPG(convert(alg)).cuda()
+    obs = torch.randn(64, 5, 144, device="cuda")
+    hid = torch.randn(64, 5, 64, device="cuda")
+    with torch.no_grad():
+        f_means, _, f_hid = m.policy(obs, last_hid=hid)
+        m.fused_inference = False
+        t_means, _, t_hid = m.policy(obs, last_hid=hid)
+        m.fused_inference = True
+    assert (f_means - t_means).abs().max().item() < 1e-5 and (f_hid - t_hid).abs().max().item() < 1e-5
+    g_means, _, _ = m.policy(obs, last_hid=hid)                            # grad enabled: the module, with a graph
+    assert g_means.requires_grad

@@ -1,0 +1,31 @@
+"""Fused actor inference (csrc/actor.hip) vs the PyTorch module it replaces, on the rollout's and the update's row
+counts.  HIP-event timed, 200 launches each."""
+import os, sys, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import safe_marl_amd  # noqa: F401
+from safe_marl_amd.nets import RNNAgent, fused_actor_forward
+
+args = types.SimpleNamespace(hid_size=64, layernorm=True, action_dim=4, agent_num=5, hid_activation="relu")
+agent = RNNAgent(149, args).cuda()
+ids = torch.eye(5, device="cuda")
+
+
+def timed(fn, n=200):
+    for _ in range(20):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+for b in (4096, 32768):
+    obs = torch.randn(b, 5, 144, device="cuda"); hid = torch.randn(b, 5, 64, device="cuda")
+    with torch.no_grad():
+        t_f = timed(lambda: fused_actor_forward(agent, obs, hid, 5, True))
+        t_m = timed(lambda: agent(torch.cat((obs, ids.expand(b, -1, -1)), -1).reshape(b * 5, -1), hid.reshape(b * 5, -1)))
+    macs = b * 5 * (144 * 64 + 2 * 192 * 64 + 64 * 4)
+    print(f"{b * 5:7d} rows: fused {t_f:7.1f} us ({2 * macs / t_f / 1e6:5.1f} TFLOP/s fp32)   module {t_m:7.1f} us   x{t_m / t_f:.1f}")
