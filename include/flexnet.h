@@ -57,6 +57,43 @@ typedef struct {
 /* rnn_agent.py:25-33 + model.py:102-116 for all rows. */
 int flexnet_actor_forward(const FlexActorArgs* args, void* stream);
 
+/* The centralised critic (madrl/critics/mlp_critic.py:5-34: fc1 -> LayerNorm -> ReLU -> fc2 -> ReLU -> fc3) AFTER its
+ * first layer: the caller forms fc1's output z1 from column blocks (maddpg.py:38-54 repeats every agent's observation
+ * n times in fc1's input; one GEMM per sample instead of n), these two entry points do the rest — forward, and the
+ * backward pass that autograd would otherwise spread over some fifteen kernels.  One lane per hidden unit.
+ * Gradient outputs of the backward call are ACCUMULATED into (atomics): the caller zeroes them. */
+typedef struct {
+    int32_t rows;              /* b * n_agents */
+    int32_t layernorm;         /* args.layernorm (mlp_critic.py:12-13,27-28) */
+    float ln_eps;
+    int32_t pad0;
+    const float* z1;           /* [rows, 64]  fc1 output */
+    const float* ln_w;         /* [64] */
+    const float* ln_b;         /* [64] */
+    const float* fc2_w;        /* [64, 64] */
+    const float* fc2_b;        /* [64] */
+    const float* fc3_w;        /* [1, 64] */
+    const float* fc3_b;        /* [1] */
+    float* q;                  /* out [rows]  (mlp_critic.py:31: v) */
+    /* backward only (NULL for the forward call) */
+    const float* dq;           /* [rows]      dLoss/dq */
+    float* dz1;                /* out [rows, 64] */
+    float* d_ln_w;             /* += [64] */
+    float* d_ln_b;             /* += [64] */
+    float* d_fc2_w;            /* += [64, 64] */
+    float* d_fc2_b;            /* += [64] */
+    float* d_fc3_w;            /* += [64] */
+    float* d_fc3_b;            /* += [1] */
+    float* workspace;          /* backward: scratch for the per-block partial sums, or NULL */
+    int64_t workspace_floats;  /* >= FLEXNET_CRITIC_WS_FLOATS: the parameter gradients are then reduced in a fixed order
+                                * (bit-reproducible) by a second small launch; otherwise with atomics */
+} FlexCriticTailArgs;
+
+#define FLEXNET_CRITIC_WS_FLOATS (1024 * 4416)
+
+int flexnet_critic_tail_forward(const FlexCriticTailArgs* args, void* stream);
+int flexnet_critic_tail_backward(const FlexCriticTailArgs* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

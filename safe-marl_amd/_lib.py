@@ -59,7 +59,7 @@ SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
-    "flexnet_actor_forward",
+    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward",
 )
 
 class FlexActorArgs(C.Structure):
@@ -68,6 +68,17 @@ class FlexActorArgs(C.Structure):
                 ("agent_id", C.c_int32), ("layernorm", C.c_int32), ("ln_eps", C.c_float), ("pad0", C.c_float)] + \
                [(k, C.c_void_p) for k in ("obs", "hidden_in", "fc1_w", "fc1_b", "ln_w", "ln_b", "w_ih", "w_hh", "b_ih",
                                           "b_hh", "fc2_w", "fc2_b", "means", "hidden_out")]
+
+
+class FlexCriticTailArgs(C.Structure):
+    """include/flexnet.h"""
+    _fields_ = [("rows", C.c_int32), ("layernorm", C.c_int32), ("ln_eps", C.c_float), ("pad0", C.c_int32)] + \
+               [(k, C.c_void_p) for k in ("z1", "ln_w", "ln_b", "fc2_w", "fc2_b", "fc3_w", "fc3_b", "q", "dq", "dz1",
+                                          "d_ln_w", "d_ln_b", "d_fc2_w", "d_fc2_b", "d_fc3_w", "d_fc3_b", "workspace")] + \
+               [("workspace_floats", C.c_int64)]
+
+
+FLEXNET_CRITIC_WS_FLOATS = 1024 * 4416
 
 
 FLEXNET_EUNSUPPORTED = -3
@@ -105,6 +116,9 @@ def load():
     lib.flexenv_create.restype = C.c_int
     lib.flexnet_actor_forward.argtypes = [C.POINTER(FlexActorArgs), vp]
     lib.flexnet_actor_forward.restype = C.c_int
+    for fn in (lib.flexnet_critic_tail_forward, lib.flexnet_critic_tail_backward):
+        fn.argtypes = [C.POINTER(FlexCriticTailArgs), vp]
+        fn.restype = C.c_int
     lib.flexenv_destroy.argtypes = [vp]
     lib.flexenv_destroy.restype = None
     lib.flexenv_reset.argtypes = [vp, vp, C.POINTER(ResetSpec), vp, i32, vp, vp]

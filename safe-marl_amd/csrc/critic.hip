@@ -1,0 +1,311 @@
+// critic.hip — the centralised critic after its first layer, forward and backward (gfx950).  Boundary: include/flexnet.h.
+//
+// madrl/critics/mlp_critic.py:25-33:  x = fc1(inputs); x = LayerNorm(x); h = relu(fc2(relu(x))); v = fc3(h).
+// The caller forms z1 = fc1(inputs) from column blocks (learner.MADDPG.value); everything behind it is 64 wide, so
+// one lane per hidden unit again: a wavefront takes four rows at a time, reads fc2.weight from LDS (transposed for
+// z2 = W2 a1, as stored for da1 = W2^T dz2; odd row pitch, conflict-free both ways), and exchanges the rows'
+// activations through a per-wavefront LDS staging area read back as broadcasts.  LayerNorm statistics are wavefront reductions.  The backward kernel
+// recomputes the forward from z1 instead of reading saved activations (z1 is the only [rows, 64] tensor either pass
+// reads), accumulates dW2 as 64 register accumulators per lane, folds the block's wavefronts in LDS and adds to the
+// caller's gradient buffers with one atomic per element and block.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "flexnet.h"
+
+#define HID FLEXNET_HID
+#define CRT 4                      // rows per wavefront tile
+#define CW 4                       // wavefronts per block
+
+
+// sum over the 64 lanes, returned in every lane: DPP row shifts / broadcasts (no LDS traffic) and one v_readlane
+template <int CTRL, int ROW_MASK, bool BC>
+__device__ __forceinline__ float cdpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, BC));
+}
+__device__ __forceinline__ float cwave_sum(float v) {
+    v += cdpp<0x111, 0xF, true>(v);            // row_shr:1
+    v += cdpp<0x112, 0xF, true>(v);            // row_shr:2
+    v += cdpp<0x114, 0xF, true>(v);            // row_shr:4
+    v += cdpp<0x118, 0xF, true>(v);            // row_shr:8   -> lane 15 of each row holds the row sum
+    v += cdpp<0x142, 0xA, false>(v);           // row_bcast:15 into rows 1, 3
+    v += cdpp<0x143, 0xC, false>(v);           // row_bcast:31 into rows 2, 3 -> lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+struct CriticRow { float xhat, rstd, y, a1; };
+
+// LayerNorm + ReLU of one row held one unit per lane (mlp_critic.py:27-29)
+__device__ __forceinline__ CriticRow critic_ln_relu(float z1, bool layernorm, float eps, float g, float b) {
+    CriticRow o;
+    if (layernorm) {
+        const float mean = cwave_sum(z1) * (1.0f / HID);
+        const float d = z1 - mean;
+        const float var = cwave_sum(d * d) * (1.0f / HID);
+        o.rstd = rsqrtf(var + eps);
+        o.xhat = d * o.rstd;
+        o.y = o.xhat * g + b;
+    } else {
+        o.rstd = 1.0f; o.xhat = z1; o.y = z1;
+    }
+    o.a1 = fmaxf(o.y, 0.0f);
+    return o;
+}
+
+// ---- forward: q = fc3(relu(fc2(relu(LayerNorm(z1)))))  (mlp_critic.py:27-31) ---------------------------------
+__global__ __launch_bounds__(64 * CW, 2) void critic_tail_fwd_kernel(FlexCriticTailArgs a) {
+    __shared__ float stage[CW][HID * CRT];               // per wavefront: a1 as [i][row]
+    __shared__ float w2t[HID * (HID + 1)];               // w2t[i][j] = W2[j][i]: lane j reads its row of W2 along i
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < HID * HID; idx += 64 * CW) {
+        const int j = idx / HID, i = idx - j * HID;
+        w2t[i * (HID + 1) + j] = a.fc2_w[idx];
+    }
+    __syncthreads();
+    float* sa = stage[wave];
+    const float g = a.layernorm ? a.ln_w[lane] : 1.0f, be = a.layernorm ? a.ln_b[lane] : 0.0f;
+    const float b2 = a.fc2_b[lane], w3 = a.fc3_w[lane], b3 = a.fc3_b[0];
+    const int n_tiles = (a.rows + CRT - 1) / CRT;
+    for (int tile = blockIdx.x * CW + wave; tile < n_tiles; tile += gridDim.x * CW) {
+        const int r0 = tile * CRT;
+        float a1v[CRT];
+#pragma unroll
+        for (int r = 0; r < CRT; ++r) {
+            const int rr = min(r0 + r, a.rows - 1);
+            a1v[r] = critic_ln_relu(a.z1[(int64_t)rr * HID + lane], a.layernorm != 0, a.ln_eps, g, be).a1;
+        }
+        *reinterpret_cast<float4*>(sa + lane * CRT) = make_float4(a1v[0], a1v[1], a1v[2], a1v[3]);
+        __builtin_amdgcn_wave_barrier();
+        float z2[CRT] = {b2, b2, b2, b2};
+#pragma unroll 8
+        for (int i = 0; i < HID; ++i) {
+            const float w = w2t[i * (HID + 1) + lane];
+            const float4 v = *reinterpret_cast<const float4*>(sa + i * CRT);
+            z2[0] = fmaf(w, v.x, z2[0]); z2[1] = fmaf(w, v.y, z2[1]);
+            z2[2] = fmaf(w, v.z, z2[2]); z2[3] = fmaf(w, v.w, z2[3]);
+        }
+#pragma unroll
+        for (int r = 0; r < CRT; ++r) {
+            const float qv = cwave_sum(fmaxf(z2[r], 0.0f) * w3) + b3;
+            if (lane == 0 && r0 + r < a.rows) a.q[r0 + r] = qv;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------
+// A block takes CW * CRT = 16 rows at a time.  Each wavefront recomputes the forward of its four rows, forms dz2,
+// da1 = W2^T dz2, the ReLU / LayerNorm backward and writes dz1; the rows' a1 and dz2 sit in block-shared staging, and
+// after a barrier wavefront w accumulates ITS 16 columns of dW2 (dW2[j][i] += sum_r dz2[r][j] a1[r][i], i in
+// [16 w, 16 w + 16)) over all 16 rows — 16 register accumulators per lane instead of 64, no fold across wavefronts.
+#define BT (CW * CRT)
+#define CRITIC_WS_PITCH 4416                // floats per block in the workspace (4353 used)
+__global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticTailArgs a) {
+    __shared__ float sa[HID * BT];                       // a1  as [i][row of the block tile]
+    __shared__ float sd[HID * BT];                       // dz2 as [j][row]
+    __shared__ float w2t[HID * (HID + 1)];               // w2t[i][j] = W2[j][i]
+    __shared__ float w2n[HID * (HID + 1)];               // w2n[j][i] = W2[j][i]: lane i reads its column along j
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < HID * HID; idx += 64 * CW) {
+        const int j = idx / HID, i = idx - j * HID;
+        const float w = a.fc2_w[idx];
+        w2t[i * (HID + 1) + j] = w;
+        w2n[j * (HID + 1) + i] = w;
+    }
+    __syncthreads();
+    const float g = a.layernorm ? a.ln_w[lane] : 1.0f, be = a.layernorm ? a.ln_b[lane] : 0.0f;
+    const float b2 = a.fc2_b[lane], w3 = a.fc3_w[lane];
+    float acc_w2[BT];
+#pragma unroll
+    for (int c = 0; c < BT; ++c) acc_w2[c] = 0.0f;
+    float acc_g = 0.0f, acc_b = 0.0f, acc_b2 = 0.0f, acc_w3 = 0.0f, acc_b3 = 0.0f;
+    const int n_tiles = (a.rows + BT - 1) / BT;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {          // block-uniform trip count
+        const int r0 = tile * BT + wave * CRT;
+        CriticRow row[CRT];
+        float a1v[CRT];
+#pragma unroll
+        for (int r = 0; r < CRT; ++r) {
+            const int rr = min(r0 + r, a.rows - 1);
+            row[r] = critic_ln_relu(a.z1[(int64_t)rr * HID + lane], a.layernorm != 0, a.ln_eps, g, be);
+            a1v[r] = row[r].a1;
+        }
+        float* my_a = sa + wave * CRT;                   // this wavefront's four columns of the [i][16] staging
+        float* my_d = sd + wave * CRT;
+        *reinterpret_cast<float4*>(my_a + lane * BT) = make_float4(a1v[0], a1v[1], a1v[2], a1v[3]);
+        __builtin_amdgcn_wave_barrier();
+        float z2[CRT] = {b2, b2, b2, b2};
+#pragma unroll 8
+        for (int i = 0; i < HID; ++i) {
+            const float w = w2t[i * (HID + 1) + lane];
+            const float4 v = *reinterpret_cast<const float4*>(my_a + i * BT);
+            z2[0] = fmaf(w, v.x, z2[0]); z2[1] = fmaf(w, v.y, z2[1]);
+            z2[2] = fmaf(w, v.z, z2[2]); z2[3] = fmaf(w, v.w, z2[3]);
+        }
+        float dz2[CRT];
+#pragma unroll
+        for (int r = 0; r < CRT; ++r) {
+            const float dq = r0 + r < a.rows ? a.dq[r0 + r] : 0.0f;              // spare rows of the last tile contribute nothing
+            acc_w3 = fmaf(dq, fmaxf(z2[r], 0.0f), acc_w3);
+            acc_b3 += dq;
+            dz2[r] = z2[r] > 0.0f ? dq * w3 : 0.0f;
+            acc_b2 += dz2[r];
+        }
+        *reinterpret_cast<float4*>(my_d + lane * BT) = make_float4(dz2[0], dz2[1], dz2[2], dz2[3]);
+        __builtin_amdgcn_wave_barrier();
+        float da1[CRT] = {0.0f, 0.0f, 0.0f, 0.0f};      // da1_i = sum_j W2[j][i] dz2_j, this lane is unit i
+#pragma unroll 8
+        for (int j = 0; j < HID; ++j) {
+            const float wc = w2n[j * (HID + 1) + lane];
+            const float4 dv = *reinterpret_cast<const float4*>(my_d + j * BT);
+            da1[0] = fmaf(wc, dv.x, da1[0]); da1[1] = fmaf(wc, dv.y, da1[1]);
+            da1[2] = fmaf(wc, dv.z, da1[2]); da1[3] = fmaf(wc, dv.w, da1[3]);
+        }
+#pragma unroll
+        for (int r = 0; r < CRT; ++r) {                  // ReLU and LayerNorm backward
+            const float dy = row[r].y > 0.0f ? da1[r] : 0.0f;
+            float dz1 = dy;
+            if (a.layernorm) {
+                acc_g = fmaf(dy, row[r].xhat, acc_g);
+                acc_b += dy;
+                const float dxh = dy * g;
+                const float m1 = cwave_sum(dxh) * (1.0f / HID);
+                const float m2 = cwave_sum(dxh * row[r].xhat) * (1.0f / HID);
+                dz1 = row[r].rstd * (dxh - m1 - row[r].xhat * m2);
+            }
+            if (r0 + r < a.rows) a.dz1[(int64_t)(r0 + r) * HID + lane] = dz1;
+        }
+        __syncthreads();                                 // all 16 rows' a1 and dz2 are staged
+        float dzr[BT];                                   // dz2 of THIS unit for the 16 rows
+#pragma unroll
+        for (int q = 0; q < BT / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(sd + lane * BT + 4 * q);
+            dzr[4 * q] = t.x; dzr[4 * q + 1] = t.y; dzr[4 * q + 2] = t.z; dzr[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int c = 0; c < BT; ++c) {
+            const float* col = sa + (wave * BT + c) * BT;                       // a1 of unit i = 16 w + c, 16 rows (broadcast)
+            float sum = acc_w2[c];
+#pragma unroll
+            for (int q = 0; q < BT / 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(col + 4 * q);
+                sum = fmaf(dzr[4 * q], t.x, fmaf(dzr[4 * q + 1], t.y, fmaf(dzr[4 * q + 2], t.z, fmaf(dzr[4 * q + 3], t.w, sum))));
+            }
+            acc_w2[c] = sum;
+        }
+        __syncthreads();                                 // staging may be overwritten
+    }
+    // the small vectors: fold the block's four wavefronts through LDS (staging is free now)
+    __syncthreads();
+    float* vs = sa;                                      // [4 vectors + 1][CW][64]
+    vs[(0 * CW + wave) * HID + lane] = acc_b2;
+    vs[(1 * CW + wave) * HID + lane] = acc_w3;
+    vs[(2 * CW + wave) * HID + lane] = acc_g;
+    vs[(3 * CW + wave) * HID + lane] = acc_b;
+    if (lane == 0) vs[4 * CW * HID + wave] = acc_b3;
+    __syncthreads();
+    float vec = 0.0f, b3sum = 0.0f;                       // wavefront w finishes vector w
+#pragma unroll
+    for (int k = 0; k < CW; ++k) { vec += vs[(wave * CW + k) * HID + lane]; b3sum += vs[4 * CW * HID + k]; }
+    if (a.workspace) {
+        // deterministic path: this block's partial sums as one row [dW2 4096 | db2 | dw3 | dg | db | db3], reduced over
+        // blocks in a fixed order by critic_reduce_kernel
+        float* out = a.workspace + (int64_t)blockIdx.x * CRITIC_WS_PITCH;
+#pragma unroll
+        for (int c = 0; c < BT; ++c) out[lane * HID + wave * BT + c] = acc_w2[c];
+        out[HID * HID + wave * HID + lane] = vec;
+        if (tid == 0) out[HID * HID + 4 * HID] = b3sum;
+    } else {
+        // one atomic per element and block (wavefront w owns columns 16 w .. 16 w + 15 of dW2)
+#pragma unroll
+        for (int c = 0; c < BT; ++c) unsafeAtomicAdd(&a.d_fc2_w[lane * HID + wave * BT + c], acc_w2[c]);
+        float* dst = wave == 0 ? a.d_fc2_b : wave == 1 ? a.d_fc3_w : wave == 2 ? a.d_ln_w : a.d_ln_b;
+        if (wave < 2 || a.layernorm) unsafeAtomicAdd(&dst[lane], vec);
+        if (tid == 0) unsafeAtomicAdd(&a.d_fc3_b[0], b3sum);
+    }
+}
+
+// second stage of the deterministic path: element e of every block's partial row, summed in a fixed order, ADDED to
+// the caller's gradient tensor.  64 elements x 16 block groups per thread block: each thread walks its group's rows
+// with eight loads in flight, the 16 group sums are folded through LDS in index order.
+#define RED_G 16
+__global__ __launch_bounds__(64 * RED_G) void critic_reduce_kernel(FlexCriticTailArgs a, int blocks) {
+    __shared__ float part[RED_G][64];
+    const int ex = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + ex;
+    const int n_el = HID * HID + 4 * HID + 1;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (e < n_el) {
+        const float* src = a.workspace + e;
+        int b = gy;
+        for (; b + 3 * RED_G < blocks; b += 4 * RED_G) {
+            s0 += src[(int64_t)b * CRITIC_WS_PITCH];
+            s1 += src[(int64_t)(b + RED_G) * CRITIC_WS_PITCH];
+            s2 += src[(int64_t)(b + 2 * RED_G) * CRITIC_WS_PITCH];
+            s3 += src[(int64_t)(b + 3 * RED_G) * CRITIC_WS_PITCH];
+        }
+        for (; b < blocks; b += RED_G) s0 += src[(int64_t)b * CRITIC_WS_PITCH];
+    }
+    part[gy][ex] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (gy != 0 || e >= n_el) return;
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < RED_G; ++k) sum += part[k][ex];
+    if (e < HID * HID) a.d_fc2_w[e] += sum;
+    else if (e < HID * HID + HID) a.d_fc2_b[e - HID * HID] += sum;
+    else if (e < HID * HID + 2 * HID) a.d_fc3_w[e - HID * HID - HID] += sum;
+    else if (e < HID * HID + 3 * HID) { if (a.layernorm) a.d_ln_w[e - HID * HID - 2 * HID] += sum; }
+    else if (e < HID * HID + 4 * HID) { if (a.layernorm) a.d_ln_b[e - HID * HID - 3 * HID] += sum; }
+    else a.d_fc3_b[0] += sum;
+}
+
+static int critic_check(const FlexCriticTailArgs* a, bool backward) {
+    if (!a || a->rows < 0) return FLEXNET_EINVAL;
+    if (!a->z1 || !a->fc2_w || !a->fc2_b || !a->fc3_w || !a->fc3_b || (a->layernorm && (!a->ln_w || !a->ln_b)))
+        return FLEXNET_EINVAL;
+    if (!backward && !a->q) return FLEXNET_EINVAL;
+    if (backward && (!a->dq || !a->dz1 || !a->d_fc2_w || !a->d_fc2_b || !a->d_fc3_w || !a->d_fc3_b ||
+                     (a->layernorm && (!a->d_ln_w || !a->d_ln_b))))
+        return FLEXNET_EINVAL;
+    return FLEXNET_OK;
+}
+
+static int critic_grid(int rows, int per_cu) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+            return -1;
+        cus = n;
+    }
+    const int want = (rows + CW * CRT - 1) / (CW * CRT);
+    return want < cus * per_cu ? want : cus * per_cu;
+}
+
+extern "C" int flexnet_critic_tail_forward(const FlexCriticTailArgs* a, void* stream) {
+    const int rc = critic_check(a, false);
+    if (rc != FLEXNET_OK) return rc;
+    if (a->rows == 0) return FLEXNET_OK;
+    const int blocks = critic_grid(a->rows, 8);
+    if (blocks < 1) return FLEXNET_EHIP;
+    hipLaunchKernelGGL(critic_tail_fwd_kernel, dim3(blocks), dim3(64 * CW), 0, (hipStream_t)stream, *a);
+    return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}
+
+extern "C" int flexnet_critic_tail_backward(const FlexCriticTailArgs* a, void* stream) {
+    const int rc = critic_check(a, true);
+    if (rc != FLEXNET_OK) return rc;
+    if (a->rows == 0) return FLEXNET_OK;
+    FlexCriticTailArgs k = *a;
+    const bool two_stage = k.workspace && k.workspace_floats >= FLEXNET_CRITIC_WS_FLOATS;
+    if (!two_stage) k.workspace = nullptr;
+    // deterministic path: up to 1024 blocks of partial sums; atomic path: one block per CU (each ends with 4 k atomics)
+    const int blocks = critic_grid(k.rows, two_stage ? 4 : 1);
+    if (blocks < 1 || blocks > 1024) return FLEXNET_EHIP;
+    hipLaunchKernelGGL(critic_tail_bwd_kernel, dim3(blocks), dim3(64 * CW), 0, (hipStream_t)stream, k);
+    if (two_stage)
+        hipLaunchKernelGGL(critic_reduce_kernel, dim3((HID * HID + 4 * HID + 1 + 63) / 64), dim3(64 * RED_G), 0, (hipStream_t)stream, k, blocks);
+    return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}

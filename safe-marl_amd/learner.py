@@ -466,7 +466,7 @@ class MADDPG(Model):
             if self.args.agent_id:
                 h = h + W_id.t().unsqueeze(0)                             # [1, n, hid]
             h = h + th.einsum("bia,hia->bih", own, W_act.view(-1, n, a))
-            v, _ = net.forward_from_hidden(h.reshape(b * n, -1))
+            v, _ = net.forward_from_hidden(h.reshape(b * n, -1), need_hidden=False)
             return v.view(b, n, 1)
         for i, net in enumerate(nets):                                    # non-shared critics: plain input rows
             acts_i = act_det.clone()
@@ -548,8 +548,8 @@ class MATD3(MADDPG):
         W_act = W[:, off:off + n * a]
         h = h + (act_det.reshape(b, n * a) @ W_act.t()).unsqueeze(1) + th.einsum("bia,hia->bih", own, W_act.view(-1, n, a))
         flag = W[:, off + n * a]                                            # column of the 0/1 twin flag
-        v1, _ = net.forward_from_hidden(h.reshape(b * n, -1))
-        v2, _ = net.forward_from_hidden((h + flag).reshape(b * n, -1))
+        v1, _ = net.forward_from_hidden(h.reshape(b * n, -1), need_hidden=False)
+        v2, _ = net.forward_from_hidden((h + flag).reshape(b * n, -1), need_hidden=False)
         return th.cat([v1.view(b, n, 1), v2.view(b, n, 1)], dim=0)
 
     def get_actions(self, obs, status, exploration, actions_avail, target=False, last_hid=None, clip=False):

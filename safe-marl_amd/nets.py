@@ -86,7 +86,11 @@ class MLPCritic(nn.Module):
     def init_hidden(self):
         return self.fc1.weight.new_zeros(1, self.args.hid_size)
 
-    def forward_from_hidden(self, x):
+    def forward_from_hidden(self, x, need_hidden=True):
+        """``need_hidden=False`` (the MADDPG losses only use v): on the GPU the whole tail — LayerNorm, ReLU, fc2, ReLU,
+        fc3 and, when a graph is recorded, their backward — is two HIP launches (csrc/critic.hip)."""
+        if not need_hidden and critic_tail_supported(self, x):
+            return CriticTail.apply(x, self), None
         if self.args.layernorm:
             x = self.layernorm(x)
         h = self._act(self.fc2(self._act(x)))
@@ -133,3 +137,83 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id):
         return None
     _lib.check(rc, "flexnet_actor_forward")
     return means, hid_out
+
+
+def critic_tail_supported(critic, x):
+    a = critic.args
+    return (x.is_cuda and x.dtype == th.float32 and x.dim() == 2 and x.shape[1] == 64 and a.hid_size == 64
+            and a.hid_activation == "relu" and critic.fc3.out_features == 1 and getattr(critic, "fused_tail", True))
+
+
+def _critic_args(z1, ln_w, ln_b, w2, b2, w3, b3, eps):
+    from . import _lib
+    a = _lib.FlexCriticTailArgs()
+    a.rows, a.layernorm, a.ln_eps = z1.shape[0], int(ln_w is not None), float(eps)
+    a.z1 = z1.data_ptr()
+    if ln_w is not None:
+        a.ln_w, a.ln_b = ln_w.data_ptr(), ln_b.data_ptr()
+    a.fc2_w, a.fc2_b, a.fc3_w, a.fc3_b = w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr()
+    return a
+
+
+_CRITIC_WS = {}
+
+
+def _critic_workspace(device):
+    """Per-device scratch for the backward kernel's per-block partial sums (18 MB, allocated once)."""
+    from . import _lib
+    if device not in _CRITIC_WS:
+        _CRITIC_WS[device] = th.empty(_lib.FLEXNET_CRITIC_WS_FLOATS, dtype=th.float32, device=device)
+    return _CRITIC_WS[device]
+
+
+class _CriticTailFn(th.autograd.Function):
+    """q = fc3(relu(fc2(relu(LayerNorm(z1))))) (mlp_critic.py:27-31) with a hand-written backward: gradients for z1 and
+    for the six parameter tensors of the tail."""
+
+    @staticmethod
+    def forward(ctx, z1, ln_w, ln_b, w2, b2, w3, b3, eps):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        z1 = z1.contiguous()
+        q = th.empty(z1.shape[0], 1, dtype=th.float32, device=z1.device)
+        args = _critic_args(z1, ln_w, ln_b, w2, b2, w3, b3, eps)
+        args.q = q.data_ptr()
+        _lib.check(lib.flexnet_critic_tail_forward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_critic_tail_forward")
+        ctx.eps = eps
+        ctx.save_for_backward(z1, ln_w, ln_b, w2, b2, w3, b3)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        z1, ln_w, ln_b, w2, b2, w3, b3 = ctx.saved_tensors
+        dq = dq.contiguous()
+        dz1 = th.empty_like(z1)
+        grads = th.zeros(64 * 64 + 64 * 4 + 1, dtype=th.float32, device=z1.device)      # one zero-fill for all six
+        d_w2, d_b2, d_w3 = grads[:4096].view(64, 64), grads[4096:4160], grads[4160:4224].view(1, 64)
+        d_g, d_b, d_b3 = grads[4224:4288], grads[4288:4352], grads[4352:4353]
+        args = _critic_args(z1, ln_w, ln_b, w2, b2, w3, b3, ctx.eps)
+        args.dq, args.dz1 = dq.data_ptr(), dz1.data_ptr()
+        args.d_fc2_w, args.d_fc2_b, args.d_fc3_w, args.d_fc3_b = d_w2.data_ptr(), d_b2.data_ptr(), d_w3.data_ptr(), d_b3.data_ptr()
+        if ln_w is not None:
+            args.d_ln_w, args.d_ln_b = d_g.data_ptr(), d_b.data_ptr()
+        ws = _critic_workspace(z1.device)
+        args.workspace, args.workspace_floats = ws.data_ptr(), ws.numel()
+        _lib.check(lib.flexnet_critic_tail_backward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_critic_tail_backward")
+        has_ln = ln_w is not None
+        return dz1, (d_g if has_ln else None), (d_b if has_ln else None), d_w2, d_b2, d_w3, d_b3, None
+
+
+class CriticTail:
+    @staticmethod
+    def apply(z1, critic):
+        ln = critic.layernorm if critic.args.layernorm else None
+        return _CriticTailFn.apply(z1, None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                   critic.fc2.weight, critic.fc2.bias, critic.fc3.weight, critic.fc3.bias,
+                                   1e-5 if ln is None else ln.eps)

@@ -1,0 +1,73 @@
+"""The fused critic tail (csrc/critic.hip, include/flexnet.h: LayerNorm -> ReLU -> fc2 -> ReLU -> fc3, forward and
+backward) against the PyTorch module and autograd it replaces (mlp_critic.py:25-33; that module's golden parity with
+the imported reference is tests/test_learner_cpu.py).  fp32; gradients are sums over up to 163 840 rows accumulated
+with atomics, hence relative tolerances."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _critic(layernorm=True, seed=0):
+    from safe_marl_amd.nets import MLPCritic
+    torch.manual_seed(seed)
+    args = types.SimpleNamespace(hid_size=64, layernorm=layernorm, hid_activation="relu")
+    c = MLPCritic(745, 1, args).cuda()
+    with torch.no_grad():
+        for p in c.parameters():
+            p.copy_(torch.randn_like(p) * 0.2)
+    return c
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(1e-6, b.abs().max().item())
+
+
+@pytest.mark.parametrize("rows,ln", [(163840, True), (20480, True), (5, True), (1, True), (37, False), (4099, True)])
+def test_forward_and_backward_match_autograd(rows, ln):
+    c = _critic(layernorm=ln)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    z = torch.randn(rows, 64, device="cuda", generator=g)
+    w = torch.randn(rows, 1, device="cuda", generator=g)          # arbitrary upstream gradient
+    params = [p for n, p in c.named_parameters() if not n.startswith("fc1")]
+    z_f = z.clone().requires_grad_(True)
+    q_f, none = c.forward_from_hidden(z_f, need_hidden=False)
+    assert none is None and q_f.shape == (rows, 1)
+    g_f = torch.autograd.grad((q_f * w).sum(), [z_f] + params)
+    c.fused_tail = False
+    z_t = z.clone().requires_grad_(True)
+    q_t, _ = c.forward_from_hidden(z_t, need_hidden=False)
+    g_t = torch.autograd.grad((q_t * w).sum(), [z_t] + params)
+    assert _rel(q_f, q_t) < 2e-6
+    assert _rel(g_f[0], g_t[0]) < 2e-5                               # dz1
+    for a, b, p in zip(g_f[1:], g_t[1:], params):
+        assert a.shape == p.shape
+        assert _rel(a, b) < 2e-4, (p.shape, _rel(a, b))
+
+
+def test_no_grad_call_and_value_function_agree():
+    """MADDPG.value through the fused tail equals the module path, with and without a graph."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.util import convert
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="maddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4)
+    torch.manual_seed(5)
+    m = MADDPG(convert(alg)).cuda()
+    obs = torch.randn(300, 5, 144, device="cuda")
+    act = torch.rand(300, 5, 4, device="cuda", requires_grad=True)
+    v_f = m.value(obs, act)
+    ga_f = torch.autograd.grad(v_f.sum(), act)[0]
+    for net in m.value_dicts:
+        net.fused_tail = False
+    v_t = m.value(obs, act)
+    ga_t = torch.autograd.grad(v_t.sum(), act)[0]
+    assert _rel(v_f, v_t) < 5e-6 and _rel(ga_f, ga_t) < 5e-5
+    with torch.no_grad():
+        for net in m.value_dicts:
+            net.fused_tail = True
+        assert _rel(m.value(obs, act), v_t) < 5e-6
