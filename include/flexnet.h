@@ -52,6 +52,12 @@ typedef struct {
     const float* fc2_b;        /* [act_dim] */
     float* means;              /* out [rows, act_dim]  (fc2 output: the action mean, rnn_agent.py:32) */
     float* hidden_out;         /* out [rows, 64]       (GRU state, rnn_agent.py:31) */
+    /* optional exploration epilogue (all three NULL to skip): utils/util.py:57-64 select_action in training mode with
+     * the fixed std of model.py:121-123, and utils/util.py:125-128 translate_action's arithmetic */
+    const float* noise;        /* [rows, act_dim] standard normal draws */
+    float* action;             /* out [rows, act_dim]  tanh(mean + std * noise) */
+    float* env_action;         /* out [rows, act_dim]  0.5 * (clamp(action, low, high) + 1) * (high - low) + low */
+    float std, action_low, action_high, pad1;
 } FlexActorArgs;
 
 /* rnn_agent.py:25-33 + model.py:102-116 for all rows. */
@@ -93,6 +99,36 @@ typedef struct {
 
 int flexnet_critic_tail_forward(const FlexCriticTailArgs* args, void* stream);
 int flexnet_critic_tail_backward(const FlexCriticTailArgs* args, void* stream);
+
+/* One vector step's bookkeeping of the rollout (madrl/models/model.py:230-262 per environment, utils/replay_buffer.py:
+ * 23-27): the transition record [state | action | reward | next_state | done | last_step | last_hid | hid] lands in a
+ * packed staging row per environment (the replay ring takes it with one copy), the observation and the hidden state are
+ * handed over to the next step (hidden state zeroed where the episode ended, model.py:255-258), and the episode
+ * statistics are accumulated — one launch instead of some twenty pointwise kernels. */
+typedef struct {
+    int32_t n_envs, n_agents, obs_dim, act_dim;
+    int32_t rec_stride;        /* floats per record row */
+    int32_t col_state, col_action, col_reward, col_next_state, col_done, col_last_step, col_last_hid, col_hid;
+    int32_t info_w;            /* columns of `info` (7) */
+    int32_t pad0, pad1;
+    const float* obs_prev;     /* [N, n, obs_dim] */
+    const float* action;       /* [N, n, act_dim] */
+    const double* reward;      /* [N]   one reward per environment, stored once per agent */
+    const float* obs_next;     /* [N, n, obs_dim] */
+    const uint8_t* done;       /* [N] */
+    const float* hid_prev;     /* [N, n, 64] */
+    const float* hid_new;      /* [N, n, 64] */
+    const double* info;        /* [N, info_w] or NULL */
+    const uint8_t* failed;     /* [N] or NULL */
+    float* rec;                /* out [N, rec_stride] */
+    float* obs_state;          /* out [N, n, obs_dim] <- obs_next            (may be obs_prev) */
+    float* hid_state;          /* out [N, n, 64]      <- hid_new * (1 - done) (may be hid_prev) */
+    double* info_sum;          /* += [info_w] or NULL */
+    double* rew_sum;           /* += [1] */
+    double* fail_sum;          /* += [1] or NULL */
+} FlexRolloutPackArgs;
+
+int flexnet_rollout_pack(const FlexRolloutPackArgs* args, void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,7 +59,7 @@ SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
-    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward",
+    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack",
 )
 
 class FlexActorArgs(C.Structure):
@@ -67,7 +67,8 @@ class FlexActorArgs(C.Structure):
     _fields_ = [("rows", C.c_int32), ("n_agents", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32),
                 ("agent_id", C.c_int32), ("layernorm", C.c_int32), ("ln_eps", C.c_float), ("pad0", C.c_float)] + \
                [(k, C.c_void_p) for k in ("obs", "hidden_in", "fc1_w", "fc1_b", "ln_w", "ln_b", "w_ih", "w_hh", "b_ih",
-                                          "b_hh", "fc2_w", "fc2_b", "means", "hidden_out")]
+                                          "b_hh", "fc2_w", "fc2_b", "means", "hidden_out", "noise", "action", "env_action")] + \
+               [("std", C.c_float), ("action_low", C.c_float), ("action_high", C.c_float), ("pad1", C.c_float)]
 
 
 class FlexCriticTailArgs(C.Structure):
@@ -79,6 +80,15 @@ class FlexCriticTailArgs(C.Structure):
 
 
 FLEXNET_CRITIC_WS_FLOATS = 1024 * 4416
+
+
+class FlexRolloutPackArgs(C.Structure):
+    """include/flexnet.h"""
+    _fields_ = [(k, C.c_int32) for k in ("n_envs", "n_agents", "obs_dim", "act_dim", "rec_stride", "col_state", "col_action",
+                                         "col_reward", "col_next_state", "col_done", "col_last_step", "col_last_hid",
+                                         "col_hid", "info_w", "pad0", "pad1")] + \
+               [(k, C.c_void_p) for k in ("obs_prev", "action", "reward", "obs_next", "done", "hid_prev", "hid_new", "info",
+                                          "failed", "rec", "obs_state", "hid_state", "info_sum", "rew_sum", "fail_sum")]
 
 
 FLEXNET_EUNSUPPORTED = -3
@@ -116,6 +126,8 @@ def load():
     lib.flexenv_create.restype = C.c_int
     lib.flexnet_actor_forward.argtypes = [C.POINTER(FlexActorArgs), vp]
     lib.flexnet_actor_forward.restype = C.c_int
+    lib.flexnet_rollout_pack.argtypes = [C.POINTER(FlexRolloutPackArgs), vp]
+    lib.flexnet_rollout_pack.restype = C.c_int
     for fn in (lib.flexnet_critic_tail_forward, lib.flexnet_critic_tail_backward):
         fn.argtypes = [C.POINTER(FlexCriticTailArgs), vp]
         fn.restype = C.c_int

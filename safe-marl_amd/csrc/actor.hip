@@ -176,7 +176,15 @@ __global__ __launch_bounds__(64 * AW, 1) void actor_forward_kernel(FlexActorArgs
             const int r = e / ad, k = e - r * ad;
             float o = s.b2[k];
             for (int i = 0; i < HID; ++i) o = fmaf(s.w2[k * HID + i], st[i * RT + r], o);
-            if (r0 + r < a.rows) a.means[(int64_t)(r0 + r) * ad + k] = o;
+            if (r0 + r < a.rows) {
+                const int64_t at = (int64_t)(r0 + r) * ad + k;
+                a.means[at] = o;
+                if (a.noise) {                                                    // util.py:57-64, 125-128
+                    const float act = tanhf(o + a.std * a.noise[at]);
+                    a.action[at] = act;
+                    a.env_action[at] = 0.5f * (fminf(fmaxf(act, a.action_low), a.action_high) + 1.0f) * (a.action_high - a.action_low) + a.action_low;
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -186,7 +194,8 @@ extern "C" int flexnet_actor_forward(const FlexActorArgs* a, void* stream) {
     if (!a || a->rows < 0) return FLEXNET_EINVAL;
     if (a->rows == 0) return FLEXNET_OK;
     if (!a->obs || !a->hidden_in || !a->fc1_w || !a->fc1_b || !a->w_ih || !a->w_hh || !a->b_ih || !a->b_hh || !a->fc2_w ||
-        !a->fc2_b || !a->means || !a->hidden_out || (a->layernorm && (!a->ln_w || !a->ln_b)))
+        !a->fc2_b || !a->means || !a->hidden_out || (a->layernorm && (!a->ln_w || !a->ln_b)) ||
+        (a->noise && (!a->action || !a->env_action)))
         return FLEXNET_EINVAL;
     if (a->obs_dim < 1 || a->obs_dim > FLEXNET_MAX_OBS || a->n_agents < 1 || a->n_agents > FLEXNET_MAX_AGENTS ||
         a->act_dim < 1 || a->act_dim > FLEXNET_MAX_ACT)

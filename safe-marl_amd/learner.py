@@ -53,10 +53,43 @@ class RolloutGraph:
         self.fail_sum = th.zeros((), dtype=th.float64, device=dev)
         self.std = float(model.args.fixed_policy_std)
         self.graph = None
+        # plain MADDPG on the GPU: policy + exploration in one HIP launch, packing + hand-over + statistics in another
+        self.fast = (type(model).__name__ == "MADDPG" and model.fused_inference and model.args.shared_params
+                     and self.obs.is_cuda and model.args.agent_type == "rnn" and h == 64 and o <= 144)
+        self.cols = {k: buf.packed_cols[k][0] for k in self.STORED}
+
+    def _pack(self, action, hid):
+        """model.py:230-262 for every environment in one launch (include/flexnet.h: flexnet_rollout_pack)."""
+        import ctypes as C
+        from . import _lib
+        m, env = self.model, self.env
+        a = _lib.FlexRolloutPackArgs()
+        a.n_envs, a.n_agents, a.obs_dim, a.act_dim = env.n_envs, m.n_, m.obs_dim, m.act_dim
+        a.rec_stride, a.info_w = self.rec.shape[1], env.info.shape[1]
+        for k in self.STORED:
+            setattr(a, "col_" + k, self.cols[k])
+        for name, t in (("obs_prev", self.obs), ("action", action), ("reward", env.reward), ("obs_next", env.obs),
+                        ("done", env.done), ("hid_prev", self.hid), ("hid_new", hid), ("info", env.info),
+                        ("failed", env.failed), ("rec", self.rec), ("obs_state", self.obs), ("hid_state", self.hid),
+                        ("info_sum", self.info_sum), ("rew_sum", self.rew_sum), ("fail_sum", self.fail_sum)):
+            assert t.is_contiguous()
+            setattr(a, name, t.data_ptr())
+        _lib.check(_lib.load().flexnet_rollout_pack(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_rollout_pack")
 
     def body(self):
         m, env, f = self.model, self.env, self.f
         N = env.n_envs
+        if self.fast:
+            with th.no_grad():
+                noise = th.randn(N, m.n_, m.act_dim, device=self.obs.device)
+                out = fused_actor_forward(m.policy_dicts[0], self.obs, self.hid, m.n_, m.args.agent_id, noise=noise,
+                                          std=self.std, low=m.args.action_low, high=m.args.action_high)
+                if out is not None:
+                    _, hid, action, env_action = out
+                    env.step(env_action.view(N, m.n_, m.act_dim), fuse_obs=True, auto_reset=True)
+                    self._pack(action, hid)
+                    return
         with th.no_grad():
             means, _, hid = m.policy(self.obs, last_hid=self.hid)
             action = th.tanh(means + self.std * th.randn_like(means))          # util.py:57-64

@@ -100,12 +100,14 @@ class MLPCritic(nn.Module):
         return self.forward_from_hidden(self.fc1(inputs))
 
 
-def fused_actor_forward(agent, obs, hidden, n_agents, agent_id):
+def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=1.0, low=0.0, high=1.0):
     """rnn_agent.py:25-33 + model.py:102-116 without an autograd graph, in one HIP launch.
 
     ``obs`` [b, n, obs_dim] fp32 on the GPU WITHOUT the one-hot id columns (the kernel adds fc1's id column of
     row r % n itself), ``hidden`` [b, n, 64] or [b * n, 64].  Returns (means [b * n, act], hidden [b * n, 64]) or
-    None when the configuration is not one the kernel covers (the caller then uses the module)."""
+    None when the configuration is not one the kernel covers (the caller then uses the module).  With ``noise``
+    [b, n, act] (standard normal draws) the exploration epilogue runs in the same launch and two more tensors come
+    back: action = tanh(mean + std * noise) (util.py:57-64) and the environment's action (util.py:125-128)."""
     import ctypes as C
     from . import _lib
     a = agent.args
@@ -121,6 +123,11 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id):
     args = _lib.FlexActorArgs()
     args.rows, args.n_agents, args.obs_dim, args.act_dim = rows, n_agents, obs.shape[-1], a.action_dim
     args.agent_id, args.layernorm, args.ln_eps = int(bool(agent_id)), int(bool(a.layernorm)), 1e-5
+    action = env_action = None
+    if noise is not None:
+        noise = noise.reshape(rows, a.action_dim).to(th.float32).contiguous()
+        action, env_action = th.empty_like(means), th.empty_like(means)
+        args.std, args.action_low, args.action_high = float(std), float(low), float(high)
     ln = agent.layernorm if a.layernorm else None
     if ln is not None:
         args.ln_eps = float(ln.eps)
@@ -128,7 +135,8 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id):
                     ("ln_w", ln.weight if ln is not None else None), ("ln_b", ln.bias if ln is not None else None),
                     ("w_ih", agent.rnn.weight_ih), ("w_hh", agent.rnn.weight_hh), ("b_ih", agent.rnn.bias_ih),
                     ("b_hh", agent.rnn.bias_hh), ("fc2_w", agent.fc2.weight), ("fc2_b", agent.fc2.bias),
-                    ("means", means), ("hidden_out", hid_out)):
+                    ("means", means), ("hidden_out", hid_out), ("noise", noise), ("action", action),
+                    ("env_action", env_action)):
         if t is not None and not t.is_contiguous():
             return None
         setattr(args, name, None if t is None else t.data_ptr())
@@ -136,7 +144,7 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id):
     if rc == _lib.FLEXNET_EUNSUPPORTED:
         return None
     _lib.check(rc, "flexnet_actor_forward")
-    return means, hid_out
+    return (means, hid_out) if noise is None else (means, hid_out, action, env_action)
 
 
 def critic_tail_supported(critic, x):

@@ -41,7 +41,9 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.FlexCfg) == 200          # 10 x int32 + 19 x double + uint64
     assert C.sizeof(_lib.NetFix) == 16 + 6 * 8
     assert C.sizeof(_lib.SeriesTab) == 24 and C.sizeof(_lib.ResetSpec) == 40
-    assert C.sizeof(_lib.FlexActorArgs) == 8 * 4 + 14 * 8     # include/flexnet.h
+    assert C.sizeof(_lib.FlexActorArgs) == 8 * 4 + 17 * 8 + 4 * 4     # include/flexnet.h
+    assert C.sizeof(_lib.FlexCriticTailArgs) == 4 * 4 + 17 * 8 + 8
+    assert C.sizeof(_lib.FlexRolloutPackArgs) == 16 * 4 + 15 * 8
 
 
 def test_bad_arguments_are_rejected_before_any_device_work(lib, net):
