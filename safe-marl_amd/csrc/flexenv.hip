@@ -158,7 +158,7 @@ __device__ __forceinline__ int small_mod(int x, int m, float inv_m) {
 // produces, so it is copied BEFORE the solve and drains to HBM underneath it.
 //
 // Work split: in float2 units an agent's block is 3*history units long; group lane l owns the units l, l+LW, l+2LW
-// of EVERY agent's block (FLEX_OBS_CLASSES = 3 covers history <= LW, i.e. 32 rows at two environments per wavefront).
+// of EVERY agent's block (three classes of 32 lanes, or two of 64, cover history <= 32 resp. 42 rows).
 // With s1 = (k mod history) + 1 the unit `rem` of the output comes from ring unit rem + 3*s1, minus one block length
 // if that runs past the block's end — the same three offsets for every agent, so the per-lane address arithmetic is
 // done three times per step and the agent index only moves the scalar offset of the access.
@@ -174,13 +174,13 @@ typedef int flex_v2i __attribute__((ext_vector_type(2)));
 typedef int flex_v4i __attribute__((ext_vector_type(4)));
 #define FLEX_BUF_FLAGS 0x00020000
 #define FLEX_AUX_NT 2            // gfx940+ cache policy: bit 1 = nt
-#define FLEX_OBS_CLASSES 3
+#define FLEX_OBS_CLASSES(EPW_) ((EPW_) == 2 ? 3 : 2)
 #define FLEX_OBS_AGENTS_SMALL 5  // the reference's five buildings: agent loop without a per-agent predicate
 #define FLEX_OBS_AGENTS_LARGE FLEX_MAX_AGENTS
 
 template <int EPW, int NA_CAP, typename OutT>
 struct ObsHist {
-    static constexpr int LW = FLEX_WAVE / EPW, CLS = FLEX_OBS_CLASSES;
+    static constexpr int LW = FLEX_WAVE / EPW, CLS = FLEX_OBS_CLASSES(EPW);
     static constexpr bool NA_EXACT = NA_CAP == FLEX_OBS_AGENTS_SMALL;            // host dispatch guarantees na == NA_CAP
     float2 buf[NA_CAP][CLS];
     int dst[CLS];
@@ -498,7 +498,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     double n_pd = ld_at<double>(a.series, nrow_off + o_bus), n_qd = ld_at<double>(a.series, nrow_off + o_qbus);
     double n_ppv = ld_at<double>(a.series, nrow_off + o_pv);
     const double n_price = ld_at<double>(a.series, nrow_off + o_price);
-    const bool obs_fast = want_obs && na <= NA_CAP && 3 * c.history <= FLEX_OBS_CLASSES * LW;
+    const bool obs_fast = want_obs && na <= NA_CAP && 3 * c.history <= FLEX_OBS_CLASSES(EPW) * LW;
     ObsHist<EPW, NA_CAP, ObsT> hist;
     hist.load(a, env0, g, valid, obs_fast, ln, obs_cnt);
     hist.store(a, env0, obs_fast, obs);
@@ -1063,7 +1063,7 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
             (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset); \
         else hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_AGENTS_LARGE>), grid, env_block(), 0, s, k, \
             (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset); } while (0)
-    const bool small_obs = e->cfg.n_agents == FLEX_OBS_AGENTS_SMALL && 3 * e->cfg.history <= FLEX_OBS_CLASSES * (FLEX_WAVE / epw);
+    const bool small_obs = e->cfg.n_agents == FLEX_OBS_AGENTS_SMALL && 3 * e->cfg.history <= FLEX_OBS_CLASSES(epw) * (FLEX_WAVE / epw);
     const int variant = (epw == 2 ? 4 : 0) + (f64 ? 2 : 0) + (act_dtype == FLEX_F64 ? 1 : 0);
     switch (variant) {
         case 0: FLEX_LAUNCH_STEP(1, float, float); break;

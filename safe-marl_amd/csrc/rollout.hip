@@ -7,7 +7,7 @@
 #include "flexnet.h"
 
 #define PACK_THREADS 256
-#define PACK_ENVS 16               // environments per block (their statistics leave as one atomic per quantity)
+#define PACK_ENVS 2                // environments per block (their statistics leave as one atomic per quantity and block)
 
 __global__ __launch_bounds__(PACK_THREADS) void rollout_pack_kernel(FlexRolloutPackArgs a) {
     __shared__ double stat[PACK_ENVS][10];
