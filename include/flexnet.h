@@ -37,7 +37,7 @@ typedef struct {
     int32_t agent_id;          /* 1: fc1 has n_agents one-hot id columns after the obs_dim observation columns (model.py:105-108) */
     int32_t layernorm;         /* args.layernorm (rnn_agent.py:19-20,27-28) */
     float ln_eps;              /* nn.LayerNorm default 1e-5 */
-    float pad0;
+    int32_t variant;           /* 0: matrix-core kernel (v_mfma_f32_32x32x2_f32); 1: the VALU kernel (kept as cross-check) */
     const float* obs;          /* [rows, obs_dim] */
     const float* hidden_in;    /* [rows, 64] */
     const float* fc1_w;        /* [64, obs_dim (+ n_agents)] */

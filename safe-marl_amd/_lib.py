@@ -65,7 +65,7 @@ SYMBOLS = (
 class FlexActorArgs(C.Structure):
     """include/flexnet.h"""
     _fields_ = [("rows", C.c_int32), ("n_agents", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32),
-                ("agent_id", C.c_int32), ("layernorm", C.c_int32), ("ln_eps", C.c_float), ("pad0", C.c_float)] + \
+                ("agent_id", C.c_int32), ("layernorm", C.c_int32), ("ln_eps", C.c_float), ("variant", C.c_int32)] + \
                [(k, C.c_void_p) for k in ("obs", "hidden_in", "fc1_w", "fc1_b", "ln_w", "ln_b", "w_ih", "w_hh", "b_ih",
                                           "b_hh", "fc2_w", "fc2_b", "means", "hidden_out", "noise", "action", "env_action")] + \
                [("std", C.c_float), ("action_low", C.c_float), ("action_high", C.c_float), ("pad1", C.c_float)]

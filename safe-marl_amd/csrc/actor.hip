@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64 * AW, 1) void actor_forward_kernel(FlexActorArgs
 
     float* st = s.stage[wave];
     const int n_tiles = (a.rows + RT - 1) / RT;
-    for (int tile = blockIdx.x * AW + wave; tile < n_tiles; tile += gridDim.x * AW) {
+    for (int tile = wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * AW) {
         const int r0 = tile * RT;
         int row[RT];
 #pragma unroll
@@ -190,6 +190,253 @@ __global__ __launch_bounds__(64 * AW, 1) void actor_forward_kernel(FlexActorArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Matrix-core version.  v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = twice v_fma_f32) computes
+// D[32 x 32] += A[32 x 2] B[2 x 32]; here A = WEIGHTS (rows = output units) and B = ACTIVATIONS (columns = the 32
+// batch rows of a wavefront's tile), i.e. every layer is evaluated transposed, D[unit][row].  That choice makes the
+// layers chain THROUGH REGISTERS: lane (row r, half h) ends a layer holding units 8q + 4h + j (reg = 4q + j) of
+// its row — exactly what the next layer's B operand wants if the k-pair of MFMA step (q, j) is taken as
+// (8q + j, 8q + 4 + j) instead of two consecutive inputs, and the A operand (weights, from LDS) is read in the
+// matching order.  Only the network inputs are staged through LDS (16 observation columns at a time) to get from
+// row-major memory into "one batch row per lane"; LayerNorm is an in-lane sum plus one exchange between the halves.
+// Per 32 rows: 144 + 384 MFMAs (36 k cycles of a SIMD at the issue rate), two wavefronts per SIMD.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MW 8                       // wavefronts per block
+#define MCH 16                     // observation columns staged at a time
+#define MSP (MCH + 1)              // staging pitch (floats)
+
+struct ActorLdsM {
+    float w1t[FLEXNET_MAX_OBS * P1];
+    float wih[HID * PG];
+    float whh[HID * PG];
+    float b1[HID], lnw[HID], lnb[HID];
+    float w1id[FLEXNET_MAX_AGENTS * HID];
+    float bih[3 * HID], bhh[3 * HID];
+    float w2[FLEXNET_MAX_ACT * HID];
+    float b2[FLEXNET_MAX_ACT];
+    float stage[MW][32 * MSP];
+};
+
+// v_exp_f32 / v_rcp_f32 forms (about 1 ulp each): sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(x) = 1 - 2 / (2^(2x log2 e) + 1)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float xc = fminf(fmaxf(x, -15.0f), 15.0f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.88539008f * xc) + 1.0f);
+}
+#define DU0(i) (8 * ((i) >> 2) + ((i) & 3))       // unit of accumulator register i within a 32-unit tile, without the half's + 4 hf
+#define MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
+// unit held in accumulator register i of half hf within a 32-unit tile (C/D map of the 32x32 MFMA)
+#define DUNIT(i, hf) (8 * ((i) >> 2) + 4 * (hf) + ((i) & 3))
+
+__global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActorArgs a) {
+    __shared__ ActorLdsM s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rb = lane & 31, hf = lane >> 5;
+    const int od = a.obs_dim, na = a.n_agents, ad = a.act_dim;
+    const int ld1 = od + (a.agent_id ? na : 0);
+#pragma unroll 6
+    for (int idx = tid; idx < HID * od; idx += 64 * MW) {
+        const int j = idx / od, i = idx - j * od;
+        s.w1t[i * P1 + j] = a.fc1_w[(int64_t)j * ld1 + i];
+    }
+#pragma unroll 8
+    for (int idx = tid; idx < 3 * HID * HID; idx += 64 * MW) {
+        const int gj = idx / HID, i = idx - gj * HID;
+        s.wih[i * PG + gj] = a.w_ih[idx];
+        s.whh[i * PG + gj] = a.w_hh[idx];
+    }
+    for (int idx = tid; idx < 3 * HID; idx += 64 * MW) { s.bih[idx] = a.b_ih[idx]; s.bhh[idx] = a.b_hh[idx]; }
+    if (tid < HID) {
+        s.b1[tid] = a.fc1_b[tid];
+        s.lnw[tid] = a.layernorm ? a.ln_w[tid] : 1.0f;
+        s.lnb[tid] = a.layernorm ? a.ln_b[tid] : 0.0f;
+    }
+    for (int idx = tid; idx < FLEXNET_MAX_AGENTS * HID; idx += 64 * MW) {
+        const int ag = idx / HID, j = idx - ag * HID;
+        s.w1id[idx] = (a.agent_id && ag < na) ? a.fc1_w[(int64_t)j * ld1 + od + ag] : 0.0f;
+    }
+    for (int idx = tid; idx < ad * HID; idx += 64 * MW) s.w2[idx] = a.fc2_w[idx];
+    if (tid < ad) s.b2[tid] = a.fc2_b[tid];
+    __syncthreads();
+
+    float* st = s.stage[wave];
+    // Lane-dependent parts of every LDS index go into a base pointer per array, the rest is a compile-time constant that
+    // fits the 16-bit offset field of the ds_read: otherwise the compiler materialises one address register per
+    // unrolled access, hoists all of them out of the tile loop and spills.
+    const float* wi_l = s.wih + (4 * hf) * PG + rb;
+    const float* wh_l = s.whh + (4 * hf) * PG + rb;
+    const float* bih_l = s.bih + 4 * hf;
+    const float* bhh_l = s.bhh + 4 * hf;
+    const float* b1_l = s.b1 + 4 * hf;
+    const float* lnw_l = s.lnw + 4 * hf;
+    const float* lnb_l = s.lnb + 4 * hf;
+    const float* w2_l = s.w2 + 4 * hf;
+    const float* st_l = st + rb * MSP + hf;
+    const int n_tiles = (a.rows + 31) / 32;
+    // tile t goes to block t % grid, wavefront (t / grid) % MW: a small batch spreads over all CUs first
+    for (int tile = wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * MW) {
+        const int r0 = tile * 32;
+        const int row = min(r0 + rb, a.rows - 1);                    // this lane's batch row (both halves share it)
+        // ---- fc1: z1[unit][row], observation columns staged MCH at a time -------------------------------------
+        f32x16 z1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z1[u][i] = 0.0f;
+        // (the next chunk's observations are requested before this chunk's MFMAs: a lone wavefront per SIMD — small
+        // batches — would otherwise expose one global-memory round trip per chunk)
+        constexpr int NLD = 32 * MCH / 64;
+        int64_t ldoff[NLD];
+        int ldcol[NLD], stoff[NLD];
+#pragma unroll
+        for (int t = 0; t < NLD; ++t) {
+            const int e = lane + 64 * t, rr = e / MCH, cc = e - rr * MCH;
+            ldoff[t] = (int64_t)min(r0 + rr, a.rows - 1) * od + cc;
+            ldcol[t] = cc;
+            stoff[t] = rr * MSP + cc;
+        }
+        float cur[NLD];
+#pragma unroll
+        for (int t = 0; t < NLD; ++t) cur[t] = ldcol[t] < od ? a.obs[ldoff[t]] : 0.0f;
+        for (int c0 = 0; c0 < od; c0 += MCH) {
+#pragma unroll
+            for (int t = 0; t < NLD; ++t) st[stoff[t]] = cur[t];
+            __builtin_amdgcn_wave_barrier();
+            if (c0 + MCH < od) {
+#pragma unroll
+                for (int t = 0; t < NLD; ++t) cur[t] = c0 + MCH + ldcol[t] < od ? a.obs[ldoff[t] + c0 + MCH] : 0.0f;
+            }
+            const float* w1_l = s.w1t + (c0 + hf) * P1 + rb;
+#pragma unroll
+            for (int kk = 0; kk < MCH; kk += 2) {
+                const float b = st_l[kk];
+                const bool in = c0 + kk + hf < od;
+                const float a0 = in ? w1_l[kk * P1] : 0.0f, a1 = in ? w1_l[kk * P1 + 32] : 0.0f;
+                z1[0] = MFMA(a0, b, z1[0]);
+                z1[1] = MFMA(a1, b, z1[1]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- + bias (+ id column), LayerNorm over the row's 64 units (32 here, 32 in the other half), ReLU ----
+        const int ag = row % na;
+        const float* w1id_l = s.w1id + ag * HID + 4 * hf;
+        float sum = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int cu = 32 * u + DU0(i);                            // + 4 hf is in the base pointers
+                z1[u][i] += b1_l[cu] + w1id_l[cu];
+                sum += z1[u][i];
+            }
+        if (a.layernorm) {
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum * (1.0f / HID);
+            float var = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const float d = z1[u][i] - mean; var = fmaf(d, d, var); }
+            var += __shfl_xor(var, 32, 64);
+            const float rstd = rsqrtf(var * (1.0f / HID) + a.ln_eps);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int cu = 32 * u + DU0(i);
+                    z1[u][i] = (z1[u][i] - mean) * rstd * lnw_l[cu] + lnb_l[cu];
+                }
+        }
+        // previous hidden state of this row in the same register layout
+        f32x16 hv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(a.hidden_in + (int64_t)row * HID + 32 * u + 8 * q + 4 * hf);
+                hv[u][4 * q] = t.x; hv[u][4 * q + 1] = t.y; hv[u][4 * q + 2] = t.z; hv[u][4 * q + 3] = t.w;
+            }
+        // ---- GRUCell: six gate products, x part and h part, chained through registers; one 32-unit output tile at a
+        //      time (64 accumulator registers live instead of 128), gates and fc2 partial sums right behind it ----------
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z1[u][i] = fmaxf(z1[u][i], 0.0f);     // x = ReLU(LayerNorm(z1))
+        float part[FLEXNET_MAX_ACT];
+#pragma unroll
+        for (int k = 0; k < FLEXNET_MAX_ACT; ++k) part[k] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 ar, az, gin, ghn, hnew;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ar[i] = 0.0f; az[i] = 0.0f; gin[i] = 0.0f; ghn[i] = 0.0f; }
+            // software pipeline: the six weights of step s + 1 are requested before the MFMAs of step s; the scheduling
+            // barrier keeps the compiler from hoisting ALL 192 LDS reads above the loop (it spilled doing so)
+            float w[6];
+            {
+                const int o = DU0(0) * PG + 32 * t;
+                w[0] = wi_l[o]; w[1] = wi_l[o + HID]; w[2] = wi_l[o + 2 * HID];
+                w[3] = wh_l[o]; w[4] = wh_l[o + HID]; w[5] = wh_l[o + 2 * HID];
+            }
+#pragma unroll
+            for (int st_ = 0; st_ < 32; ++st_) {
+                const int u = st_ >> 4, i = st_ & 15;
+                float wn[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                if (st_ + 1 < 32) {
+                    const int o = (32 * ((st_ + 1) >> 4) + DU0((st_ + 1) & 15)) * PG + 32 * t;
+                    wn[0] = wi_l[o]; wn[1] = wi_l[o + HID]; wn[2] = wi_l[o + 2 * HID];
+                    wn[3] = wh_l[o]; wn[4] = wh_l[o + HID]; wn[5] = wh_l[o + 2 * HID];
+                }
+                const float bx = z1[u][i], bh = hv[u][i];               // this half's input unit 32 u + DU0(i) + 4 hf
+                ar = MFMA(w[0], bx, ar);
+                az = MFMA(w[1], bx, az);
+                gin = MFMA(w[2], bx, gin);
+                ar = MFMA(w[3], bh, ar);
+                az = MFMA(w[4], bh, az);
+                ghn = MFMA(w[5], bh, ghn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) w[e] = wn[e];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int cu = 32 * t + DU0(i);
+                const float rg = fast_sigmoid(ar[i] + bih_l[cu] + bhh_l[cu]);
+                const float zg = fast_sigmoid(az[i] + bih_l[HID + cu] + bhh_l[HID + cu]);
+                const float ng = fast_tanh(gin[i] + bih_l[2 * HID + cu] + rg * (ghn[i] + bhh_l[2 * HID + cu]));
+                const float hn = ng + zg * (hv[t][i] - ng);
+                hnew[i] = hn;
+#pragma unroll
+                for (int k = 0; k < FLEXNET_MAX_ACT; ++k)
+                    if (k < ad) part[k] = fmaf(w2_l[k * HID + cu], hn, part[k]);
+            }
+            if (r0 + rb < a.rows) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(a.hidden_out + (int64_t)(r0 + rb) * HID + 32 * t + 8 * q + 4 * hf) =
+                        make_float4(hnew[4 * q], hnew[4 * q + 1], hnew[4 * q + 2], hnew[4 * q + 3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FLEXNET_MAX_ACT; ++k) {
+            if (k < ad) {
+                const float o = part[k] + __shfl_xor(part[k], 32, 64) + s.b2[k];
+                if (hf == 0 && r0 + rb < a.rows) {
+                    const int64_t at = (int64_t)(r0 + rb) * ad + k;
+                    a.means[at] = o;
+                    if (a.noise) {                                            // util.py:57-64, 125-128
+                        const float act = tanhf(o + a.std * a.noise[at]);
+                        a.action[at] = act;
+                        a.env_action[at] = 0.5f * (fminf(fmaxf(act, a.action_low), a.action_high) + 1.0f) * (a.action_high - a.action_low) + a.action_low;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 extern "C" int flexnet_actor_forward(const FlexActorArgs* a, void* stream) {
     if (!a || a->rows < 0) return FLEXNET_EINVAL;
     if (a->rows == 0) return FLEXNET_OK;
@@ -208,9 +455,15 @@ extern "C" int flexnet_actor_forward(const FlexActorArgs* a, void* stream) {
             return FLEXNET_EHIP;
         cus = n;
     }
-    const int tiles = (a->rows + RT - 1) / RT;
-    const int blocks = (tiles + AW - 1) / AW < cus ? (tiles + AW - 1) / AW : cus;
-    hipLaunchKernelGGL(actor_forward_kernel, dim3(blocks), dim3(64 * AW), 0, (hipStream_t)stream, *a);
+    if (a->variant == 0) {
+        const int tiles = (a->rows + 31) / 32;
+        const int blocks = tiles < cus ? tiles : cus;
+        hipLaunchKernelGGL(actor_forward_mfma_kernel, dim3(blocks), dim3(64 * MW), 0, (hipStream_t)stream, *a);
+    } else {
+        const int tiles = (a->rows + RT - 1) / RT;
+        const int blocks = tiles < cus ? tiles : cus;
+        hipLaunchKernelGGL(actor_forward_kernel, dim3(blocks), dim3(64 * AW), 0, (hipStream_t)stream, *a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         fprintf(stderr, "[flexnet] actor_forward launch failed: %s\n", hipGetErrorString(e));

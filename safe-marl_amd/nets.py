@@ -100,7 +100,7 @@ class MLPCritic(nn.Module):
         return self.forward_from_hidden(self.fc1(inputs))
 
 
-def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=1.0, low=0.0, high=1.0):
+def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=1.0, low=0.0, high=1.0, variant=0):
     """rnn_agent.py:25-33 + model.py:102-116 without an autograd graph, in one HIP launch.
 
     ``obs`` [b, n, obs_dim] fp32 on the GPU WITHOUT the one-hot id columns (the kernel adds fc1's id column of
@@ -123,6 +123,7 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
     args = _lib.FlexActorArgs()
     args.rows, args.n_agents, args.obs_dim, args.act_dim = rows, n_agents, obs.shape[-1], a.action_dim
     args.agent_id, args.layernorm, args.ln_eps = int(bool(agent_id)), int(bool(a.layernorm)), 1e-5
+    args.variant = int(variant)
     action = env_action = None
     if noise is not None:
         noise = noise.reshape(rows, a.action_dim).to(th.float32).contiguous()

@@ -35,13 +35,14 @@ def _reference(agent, obs, hidden, n_agents, agent_id):
 @pytest.mark.parametrize("b,n,obs_dim,act,ln,aid", [(4096, 5, 144, 4, True, True), (3, 5, 144, 4, True, True),
                                                     (1, 1, 144, 4, True, False), (37, 3, 72, 2, False, True),
                                                     (130, 8, 6, 8, True, True), (1001, 5, 144, 4, True, True)])
-def test_matches_module(b, n, obs_dim, act, ln, aid):
+@pytest.mark.parametrize("variant", [0, 1])          # 0: matrix-core kernel, 1: VALU kernel
+def test_matches_module(b, n, obs_dim, act, ln, aid, variant):
     from safe_marl_amd.nets import fused_actor_forward
     agent = _agent(obs_dim, n, act, layernorm=ln, agent_id=aid)
     g = torch.Generator(device="cuda").manual_seed(1)
     obs = torch.randn(b, n, obs_dim, device="cuda", generator=g)
     hid = torch.randn(b, n, 64, device="cuda", generator=g)
-    out = fused_actor_forward(agent, obs, hid, n, aid)
+    out = fused_actor_forward(agent, obs, hid, n, aid, variant=variant)
     assert out is not None
     ref_m, ref_h = _reference(agent, obs, hid, n, aid)
     assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()

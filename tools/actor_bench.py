@@ -26,6 +26,8 @@ for b in (4096, 32768):
     obs = torch.randn(b, 5, 144, device="cuda"); hid = torch.randn(b, 5, 64, device="cuda")
     with torch.no_grad():
         t_f = timed(lambda: fused_actor_forward(agent, obs, hid, 5, True))
+        t_v = timed(lambda: fused_actor_forward(agent, obs, hid, 5, True, variant=1))
         t_m = timed(lambda: agent(torch.cat((obs, ids.expand(b, -1, -1)), -1).reshape(b * 5, -1), hid.reshape(b * 5, -1)))
     macs = b * 5 * (144 * 64 + 2 * 192 * 64 + 64 * 4)
-    print(f"{b * 5:7d} rows: fused {t_f:7.1f} us ({2 * macs / t_f / 1e6:5.1f} TFLOP/s fp32)   module {t_m:7.1f} us   x{t_m / t_f:.1f}")
+    print(f"{b * 5:7d} rows: MFMA kernel {t_f:7.1f} us ({2 * macs / t_f / 1e6:5.1f} TFLOP/s fp32)   VALU kernel {t_v:7.1f} us   "
+          f"module {t_m:7.1f} us   x{t_m / t_f:.1f}")
