@@ -29,7 +29,8 @@ _RMSPROP = dict(alpha=0.99, eps=1e-5)       # trainer.py:34-35
 
 
 class PGTrainer(object):
-    def __init__(self, args, model, env, logger, batch_scale=None, replay_capacity=None, graph_rollout=True):
+    def __init__(self, args, model, env, logger, batch_scale=None, replay_capacity=None, graph_rollout=True,
+                 graph_updates=True):
         if args.episodic:
             raise NotImplementedError("episodic replay is outside the MADDPG hot path (default.yaml:9)")
         self.args, self.env, self.logger = args, env, logger
@@ -37,6 +38,8 @@ class PGTrainer(object):
         self.device = th.device("cuda" if th.cuda.is_available() and args.cuda else "cpu")
         self.steps = self.episodes = 0
         self.graph_rollout = graph_rollout      # vectorised envs: replay each rollout step as one HIP graph
+        self.graph_updates = graph_updates      # ... and each sub-update (packed replay on the GPU, one rank)
+        self._update_graphs = {}
         self.entr = args.entr
         self.world = fdist.world_size()
 
@@ -49,8 +52,9 @@ class PGTrainer(object):
         if self.world > 1:                      # identical replicas: rank 0's weights everywhere
             fdist.broadcast_module(self.behaviour_net)
         net = self.behaviour_net
-        self.policy_optimizer = RMSprop(net.policy_dicts.parameters(), lr=args.policy_lrate, **_RMSPROP)
-        self.value_optimizer = RMSprop(net.value_dicts.parameters(), lr=args.value_lrate, **_RMSPROP)
+        cap = dict(capturable=True) if self.device.type == "cuda" else {}       # optimiser steps inside HIP graphs
+        self.policy_optimizer = RMSprop(net.policy_dicts.parameters(), lr=args.policy_lrate, **_RMSPROP, **cap)
+        self.value_optimizer = RMSprop(net.value_dicts.parameters(), lr=args.value_lrate, **_RMSPROP, **cap)
         self.init_action = th.zeros(1, args.agent_num, args.action_dim, device=self.device)
 
         # replay memory sized for the number of environments feeding it
@@ -71,10 +75,79 @@ class PGTrainer(object):
         return self.behaviour_net.get_loss(batch, need=need)
 
     def policy_replay_process(self, stat):      # model.py:50
-        self._sub_update("policy", stat, self.replay_buffer.get_batch_tensors(self.effective_batch_size()))
+        if not self._graphed_sub_update("policy", stat):
+            self._sub_update("policy", stat, self.replay_buffer.get_batch_tensors(self.effective_batch_size()))
 
     def value_replay_process(self, stat):       # model.py:48
-        self._sub_update("value", stat, self.replay_buffer.get_batch_tensors(self.effective_batch_size()))
+        if not self._graphed_sub_update("value", stat):
+            self._sub_update("value", stat, self.replay_buffer.get_batch_tensors(self.effective_batch_size()))
+
+    # ---- a sub-update as one HIP graph -----------------------------------------------------------------------
+    def _graphed_sub_update(self, which, stat):
+        """A sub-update is ~120 kernel launches that take the host longer to issue (1.6 ms) than the GPU to run; with
+        the replay ring in its packed layout the sampled window is copied into a static batch (one copy) and the whole
+        step — losses, backward, gradient clip, RMSprop — is replayed as one HIP graph.  Returns False when this
+        configuration does not qualify (the caller then runs the eager step)."""
+        buf = self.replay_buffer
+        if not (self.graph_updates and self.device.type == "cuda" and self.world == 1 and hasattr(buf, "store2d")):
+            return False
+        bs = self.effective_batch_size()
+        g = self._update_graphs.get(which)
+        if g is None or g["bs"] != bs or g["buf"] is not buf:
+            try:
+                g = self._capture_sub_update(which, bs)
+            except Exception as exc:                  # capture not possible here: stay eager from now on
+                import warnings
+                warnings.warn(f"sub-update graph capture failed ({exc}); using eager sub-updates")
+                self.graph_updates = False
+                return False
+            self._update_graphs[which] = g
+        start = buf.sample_start(bs)
+        p0 = (buf.head + start) % buf.size
+        first = min(bs, buf.size - p0)
+        g["batch2d"][:first].copy_(buf.store2d[p0:p0 + first])
+        if first < bs:
+            g["batch2d"][first:].copy_(buf.store2d[:bs - first])
+        g["graph"].replay()
+        stat.update(g["stat"])
+        return True
+
+    def _capture_sub_update(self, which, bs):
+        from .replay_buffer import Transition
+        buf = self.replay_buffer
+        batch2d = th.zeros(bs, buf.store2d.shape[1], dtype=th.float32, device=self.device)
+        batch2d.copy_(buf.store2d[:bs] if buf.length >= bs else buf.store2d[:bs].clone())
+        fields = buf.record_views(batch2d)
+        for k, c in buf.consts.items():
+            shape = buf.const_shapes.get(k, ())
+            fields[k] = th.full((1,) + tuple(1 for _ in shape), float(c), device=self.device).expand((bs,) + tuple(shape))
+        batch = Transition(**fields)
+        out = {}
+        # the warm-up steps are real optimiser steps: everything they touch is put back afterwards, IN PLACE (the graph
+        # has the addresses baked in), so that capturing does not add updates to the schedule of model.py:43-50
+        opt = self.policy_optimizer if which == "policy" else self.value_optimizer
+        net_snap = {k: v.clone() for k, v in self.behaviour_net.state_dict().items()}
+        had_state = {p: {k: (v.clone() if th.is_tensor(v) else v) for k, v in opt.state[p].items()}
+                     for p in opt.param_groups[0]["params"] if p in opt.state}
+        side = th.cuda.Stream()
+        side.wait_stream(th.cuda.current_stream())
+        with th.cuda.stream(side):
+            for _ in range(2):                        # warm-up off the capturing stream (allocator, rocBLAS handles)
+                self._sub_update(which, out, batch)
+        th.cuda.current_stream().wait_stream(side)
+        graph = th.cuda.CUDAGraph()
+        out = {}
+        with th.cuda.graph(graph):
+            self._sub_update(which, out, batch)
+        with th.no_grad():
+            for k, v in self.behaviour_net.state_dict().items():
+                v.copy_(net_snap[k])
+            for p in opt.param_groups[0]["params"]:
+                for k, v in opt.state.get(p, {}).items():
+                    if th.is_tensor(v):
+                        old = had_state.get(p, {}).get(k)
+                        v.copy_(old) if old is not None else v.zero_()
+        return dict(graph=graph, batch2d=batch2d, stat=out, bs=bs, buf=buf)
 
     # kept for callers that hand over a batch themselves (trainer.py:81,99)
     def policy_transition_process(self, stat, trans):
