@@ -19,7 +19,7 @@ import numpy as np
 import torch as th
 import torch.nn as nn
 
-from .nets import MLPAgent, MLPCritic, RNNAgent, fused_actor_forward
+from .nets import MLPAgent, MLPCritic, RNNAgent, fused_actor_forward, wide_batch_linear
 from .replay_buffer import Transition
 from .util import prep_obs, scale_action, select_action, translate_action
 
@@ -494,7 +494,7 @@ class MADDPG(Model):
                 W_id = W[:, off:off + n]                                  # [hid, n]
                 off += n
             W_act = W[:, off:off + n * a]
-            shared = obs.reshape(b, n * o) @ W_obs.t() + act_det.reshape(b, n * a) @ W_act.t() + bias   # [b, hid]
+            shared = wide_batch_linear(obs.reshape(b, n * o), W_obs) + act_det.reshape(b, n * a) @ W_act.t() + bias   # [b, hid]
             h = shared.unsqueeze(1).expand(b, n, -1)
             if self.args.agent_id:
                 h = h + W_id.t().unsqueeze(0)                             # [1, n, hid]
@@ -573,7 +573,7 @@ class MATD3(MADDPG):
         act_det = act.detach()
         own = act - act_det
         off = n * o
-        h = obs.reshape(b, n * o) @ W[:, :off].t() + bias
+        h = wide_batch_linear(obs.reshape(b, n * o), W[:, :off]) + bias
         h = h.unsqueeze(1).expand(b, n, -1)
         if self.args.agent_id:
             h = h + W[:, off:off + n].t().unsqueeze(0)
