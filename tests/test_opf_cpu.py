@@ -130,3 +130,30 @@ def test_energy_chain_operator_equals_its_matrix():
     xx = torch.rand(B, T, 4, opf.na, dtype=torch.float64, generator=g)
     e0 = torch.full((B, opf.na), 0.0125, dtype=torch.float64)
     assert torch.allclose(opf.energy(e0, xx), e0[:, None, :] + op.apply(xx.reshape(B, -1)).view(B, T, opf.na), atol=1e-15)
+
+
+def test_block_elimination_equals_the_dense_normal_equations():
+    """qp_ipm's structured factorisation (per-period elimination of the controls the energy chain does not touch, Schur
+    complement on the storage controls) solves the same system as the dense one, pinned variables included."""
+    from safe_marl_amd import opf
+    torch.manual_seed(0)
+    B, T, na = 2, 5, 3
+    w = 4 * na
+    n = T * w
+    A = torch.randn(B, T, w, w, dtype=torch.float64)
+    Q = A @ A.transpose(2, 3) * 0.1
+    J = torch.randn(B, T, 7, w, dtype=torch.float64)
+    chain = opf._EnergyChain(T, na, 0.2, 0.3)
+    sets = [(opf._Identity(), 1.0, None), (opf._Identity(), -1.0, None), (opf._PeriodBlocks(J), 1.0, None),
+            (chain, 1.0, None), (chain, -1.0, None)]
+    sizes = (n, n, T * 7, T * na, T * na)
+    s = [torch.rand(B, m, dtype=torch.float64) + 0.1 for m in sizes]
+    z = [torch.rand(B, m, dtype=torch.float64) * 10 ** torch.randint(-6, 3, (B, m)).double() + 1e-9 for m in sizes]
+    fm = torch.ones(B, n, dtype=torch.float64)
+    fm[:, 5] = 0
+    fm[:, 2 * na + 1] = 0                                        # a pinned local and a pinned storage control
+    rhs = torch.randn(B, n, dtype=torch.float64) * fm
+    x1 = opf._factor_dense(Q, sets, s, z, fm, 1e-12)(rhs)
+    x2 = opf._factor_structured(Q, sets, s, z, fm, 1e-12)(rhs)
+    assert (x1 - x2).abs().max().item() < 1e-9 * max(1.0, x1.abs().max().item())
+    assert x2[:, 5].abs().max().item() == 0.0
