@@ -54,8 +54,12 @@ class RolloutGraph:
         self.std = float(model.args.fixed_policy_std)
         self.graph = None
         # plain MADDPG on the GPU: policy + exploration in one HIP launch, packing + hand-over + statistics in another
-        self.fast = (type(model).__name__ == "MADDPG" and model.fused_inference and model.args.shared_params
-                     and self.obs.is_cuda and model.args.agent_type == "rnn" and h == 64 and o <= 144)
+        self.safe = type(model).__name__ == "SAFEMADDPG"       # + the safety projection between policy and env
+        self.fast = (type(model).__name__ in ("MADDPG", "SAFEMADDPG") and model.fused_inference
+                     and model.args.shared_params and self.obs.is_cuda and model.args.agent_type == "rnn" and h == 64
+                     and o <= 144)
+        if self.safe:
+            self.predictor = tuple(th.as_tensor(x, dtype=th.float64, device=dev).contiguous() for x in model.predictor)
         self.cols = {k: buf.packed_cols[k][0] for k in self.STORED}
 
     def _pack(self, action, hid):
@@ -87,6 +91,12 @@ class RolloutGraph:
                                           std=self.std, low=m.args.action_low, high=m.args.action_high)
                 if out is not None:
                     _, hid, action, env_action = out
+                    if self.safe:
+                        # safemaddpg.py:90-111: the proposed action goes through the safety layer (HIP closed form,
+                        # flexenv_safety_project); the replay keeps the policy's own action (model.py:232)
+                        vec = env.vec if hasattr(env, "vec") else env
+                        adjusted, _ = vec.safety_project(action.view(N, m.n_, m.act_dim), *self.predictor, m.V_min, m.V_max)
+                        env_action = m.env_action(adjusted.to(th.float32))
                     env.step(env_action.view(N, m.n_, m.act_dim), fuse_obs=True, auto_reset=True)
                     self._pack(action, hid)
                     return
@@ -344,11 +354,13 @@ class Model(nn.Module):
         stat["mean_train_solver_failed"] = float(vals[-1])
 
     def _use_rollout_graph(self, trainer):
-        """HIP-graph rollout: plain DDPG-style exploration only (SAFEMADDPG's safety layer and MATD3's action quirk go
-        through get_actions), CUDA device, and not switched off by the trainer."""
+        """HIP-graph rollout: plain DDPG-style exploration, with or without SAFEMADDPG's safety projection (MATD3's and
+        IDDPG's action quirk go through get_actions), CUDA device, and not switched off by the trainer."""
         if not getattr(trainer, "graph_rollout", True) or self.device.type != "cuda":
             return False
-        return type(self).get_actions is MADDPG.get_actions and bool(self.args.action_enforcebound)
+        plain = type(self).get_actions is MADDPG.get_actions
+        safe = type(self).__name__ == "SAFEMADDPG" and type(self).get_actions is SAFEMADDPG.get_actions
+        return (plain or safe) and bool(self.args.action_enforcebound)
 
     def _train_process_graph(self, stat, trainer, horizon):
         env, buf = trainer.env, trainer.replay_buffer

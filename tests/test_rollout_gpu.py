@@ -72,3 +72,59 @@ def test_graph_capture_with_the_fused_step():
     torch.cuda.synchronize()
     assert not torch.equal(before, fast.obs) and torch.isfinite(fast.rec).all()
     assert torch.equal(fast.obs, fast.env.obs)
+
+
+def test_safemaddpg_fused_step_applies_the_safety_layer():
+    """SAFEMADDPG in the graph rollout: policy kernel -> flexenv_safety_project -> env kernel -> pack, against the
+    reference's order of operations (safemaddpg.py:90-111, model.py:211-232) spelled out with the PyTorch module."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.learner import SAFEMADDPG, RolloutGraph
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.replay_buffer import TransReplayBuffer
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.util import convert
+    net = create_network()
+    series = make_synthetic_series(net, n_days=30)
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="safemaddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4, v_min=0.9, v_max=1.1)
+    N = 48
+    envs = [VecFlexProvisionEnv({"alg": "safemaddpg"}, N, net=net, series=series, seed=9, warm_start=True) for _ in range(2)]
+    # a voltage predictor that makes the layer intervene on part of the batch
+    pred = (torch.full((5,), -0.08, dtype=torch.float64), torch.full((5,), -0.05, dtype=torch.float64),
+            torch.full((5,), 0.915, dtype=torch.float64))
+    models = []
+    for env in envs:
+        torch.manual_seed(21)
+        m = SAFEMADDPG(convert(alg), env, predictor=pred).cuda()
+        with torch.no_grad():
+            for p in m.policy_dicts.parameters():
+                p.mul_(10.0)
+        models.append(m)
+    rg = RolloutGraph(models[0], envs[0], TransReplayBuffer(N * 8, device="cuda"))
+    assert rg.fast and rg.safe
+    rg.start_episode(envs[0].reset())
+    obs = envs[1].reset().clone()
+    hid = torch.zeros(N, 5, 64, device="cuda")
+    m = models[1]
+    m.fused_inference = False
+    hits = 0
+    for step in range(3):
+        torch.manual_seed(300 + step)
+        rg.body()
+        torch.manual_seed(300 + step)
+        with torch.no_grad():
+            noise = torch.randn(N, 5, 4, device="cuda")
+            means, _, new_hid = m.policy(obs, last_hid=hid)
+            action = torch.tanh(means + noise)
+            adjusted = m.safety_layer_optimization(action).to(torch.float32)
+            hits += int(m._last_intervened.sum())
+            envs[1].step(m.env_action(adjusted), fuse_obs=True, auto_reset=True)
+        torch.cuda.synchronize()
+        assert (rg.f["action"] - action).abs().max().item() < 2e-4            # the replay keeps the policy's own action
+        assert (envs[0].reward - envs[1].reward).abs().max().item() < 1e-4 * max(1.0, envs[1].reward.abs().max().item())
+        assert (rg.obs - envs[1].obs).abs().max().item() < 5e-4
+        obs = envs[1].obs.clone()
+        hid = new_hid * (1.0 - envs[1].done.float()).view(N, 1, 1)
+    assert hits > 0                                                           # the layer really acted in this test
