@@ -133,12 +133,12 @@ class PGTrainer(object):
         side.wait_stream(th.cuda.current_stream())
         with th.cuda.stream(side):
             for _ in range(2):                        # warm-up off the capturing stream (allocator, rocBLAS handles)
-                self._sub_update(which, out, batch)
+                self._sub_update(which, out, batch, fresh_leaves=True)
         th.cuda.current_stream().wait_stream(side)
         graph = th.cuda.CUDAGraph()
         out = {}
         with th.cuda.graph(graph):
-            self._sub_update(which, out, batch)
+            self._sub_update(which, out, batch, fresh_leaves=True)
         with th.no_grad():
             for k, v in self.behaviour_net.state_dict().items():
                 v.copy_(net_snap[k])
@@ -157,11 +157,29 @@ class PGTrainer(object):
         self._sub_update("value", stat, trans)
 
     # ---- one gradient step -----------------------------------------------------------------------
-    def _sub_update(self, which, stat, batch):
+    def _sub_update(self, which, stat, batch, fresh_leaves=False):
         """zero_grad -> loss -> backward -> (all-reduce) -> clip_grad_norm_(1.0) -> RMSprop (trainer.py:81-108).
-        The policy loss carries the entropy bonus of trainer.py:47-57, a constant under the fixed std."""
+        The policy loss carries the entropy bonus of trainer.py:47-57, a constant under the fixed std.
+
+        ``fresh_leaves`` (graph capture): the loss is formed on detached aliases of the parameters.  Autograd keeps one
+        gradient accumulator per parameter, bound to the stream it was first used on; if the caller still holds a
+        graph built eagerly on the default stream (an evaluated policy output, say), backward would synchronise the
+        capturing stream with the default stream — illegal during capture, and fatal in the HIP runtime.  Aliases are
+        new leaves with accumulators of their own; their gradients ARE the parameters' gradients."""
         opt = self.policy_optimizer if which == "policy" else self.value_optimizer
-        policy_loss, value_loss, dist_params = self.get_loss(batch, need=which)
+        params = opt.param_groups[0]["params"]
+        leaves = params
+        if fresh_leaves:
+            from torch.nn.utils.stateless import _reparametrize_module
+            net = self.behaviour_net
+            own = {id(p) for p in params}
+            alias = {name: p.detach().requires_grad_(id(p) in own) for name, p in net.named_parameters()}
+            by_param = {id(p): alias[name] for name, p in net.named_parameters()}
+            leaves = [by_param[id(p)] for p in params]
+            with _reparametrize_module(net, alias):
+                policy_loss, value_loss, dist_params = self.get_loss(batch, need=which)
+        else:
+            policy_loss, value_loss, dist_params = self.get_loss(batch, need=which)
         opt.zero_grad()
         if which == "policy":
             loss = policy_loss
@@ -175,8 +193,7 @@ class PGTrainer(object):
         # gradients of THIS optimiser's parameters only: a plain backward() would also fill the other network's
         # .grad (the critic's first-layer weight gradient is the largest GEMM of a policy step) just to have it
         # zeroed by that optimiser's next zero_grad (trainer.py:82,100)
-        params = opt.param_groups[0]["params"]
-        for p, g in zip(params, th.autograd.grad(loss, params, allow_unused=True)):
+        for p, g in zip(params, th.autograd.grad(loss, leaves, allow_unused=True)):
             p.grad = g
         if self.world > 1:
             fdist.allreduce_grads(params)
