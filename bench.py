@@ -245,7 +245,7 @@ def main():
                 "solver_failed_frac": failed_frac,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "flex_step_kernel<2,float,float>",
+                "bound": "hbm", "kernel": "flex_step_kernel<2, float, float, 5>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_env_step": B_ALG_WITH_OBS, "algorithmic_bytes_per_env_step_no_obs": B_ALG_CORE,

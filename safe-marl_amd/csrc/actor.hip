@@ -226,8 +226,6 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 #define DU0(i) (8 * ((i) >> 2) + ((i) & 3))       // unit of accumulator register i within a 32-unit tile, without the half's + 4 hf
 #define MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
-// unit held in accumulator register i of half hf within a 32-unit tile (C/D map of the 32x32 MFMA)
-#define DUNIT(i, hf) (8 * ((i) >> 2) + 4 * (hf) + ((i) & 3))
 
 __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActorArgs a) {
     __shared__ ActorLdsM s;
