@@ -72,6 +72,15 @@ def test_graph_capture_with_the_fused_step():
     torch.cuda.synchronize()
     assert not torch.equal(before, fast.obs) and torch.isfinite(fast.rec).all()
     assert torch.equal(fast.obs, fast.env.obs)
+    # the exploration noise is drawn anew on every replay (graph-safe Philox offsets), not frozen at capture
+    o0, h0 = fast.obs.clone(), fast.hid.clone()
+    acts = []
+    for _ in range(2):
+        fast.obs.copy_(o0); fast.hid.copy_(h0)
+        fast.graph.replay()
+        torch.cuda.synchronize()
+        acts.append(fast.f["action"].clone())
+    assert (acts[0] - acts[1]).abs().mean().item() > 1e-3
 
 
 def test_safemaddpg_fused_step_applies_the_safety_layer():
