@@ -447,6 +447,10 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     FLEX_STAMP_RT(5);
     FLEX_STAMP(0);
     const FlexCfg& c = a.cfg;
+    // the head of the only dependent chain (ienv -> series row) goes out before the 19 table loads
+    int32_t* const b_ienv = a.st.ienv + (int64_t)env0 * IF_COUNT;
+    const uint32_t o_ienv = g * (IF_COUNT * 4);
+    const int4 iv = ld_at<int4>(b_ienv, o_ienv);                  // steps, start, row, obs_cnt in one load
     LaneNet ln;
     load_lane_net<EPW>(a.net, lane, ln);
     ln.pq = ln.pq && valid;
@@ -455,19 +459,16 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     const int ag = is_bld ? ln.agent : 0, busi = is_bus ? ln.bus : 0;
 
     // wavefront-uniform bases and per-lane byte offsets
-    int32_t* const b_ienv = a.st.ienv + (int64_t)env0 * IF_COUNT;
     double* const b_agent = a.st.agent + (int64_t)env0 * (AF_COUNT * FLEX_MAX_AGENTS);
     double* const b_ve = a.st.ve + (int64_t)env0 * 64;
     double* const b_vf = a.st.vf + (int64_t)env0 * 64;
     double* const b_vm = a.st.vm + (int64_t)env0 * nb;
     const ActT* const b_act = actions + (int64_t)env0 * (na * 4);
-    const uint32_t o_ienv = g * (IF_COUNT * 4);
     const uint32_t o_agent = (g * (AF_COUNT * FLEX_MAX_AGENTS) + ag) * 8;          // + field * FLEX_MAX_AGENTS * 8
     const uint32_t o_volt = (g * 64 + ln.l) * 8;
     const uint32_t o_bus = busi * 8, o_qbus = (nb + busi) * 8, o_pv = (2 * nb + ag) * 8, o_price = (2 * nb + na) * 8;
     constexpr uint32_t AFB = FLEX_MAX_AGENTS * 8;                                    // bytes between agent fields
 
-    const int4 iv = ld_at<int4>(b_ienv, o_ienv);                  // steps, start, row, obs_cnt in one load
     const int steps = iv.x, start = iv.y, obs_cnt = iv.w;
     const int rows = (int)a.rows;
     const uint32_t row_off = (uint32_t)clamp_row32(iv.z, rows) * (uint32_t)a.row_bytes;
