@@ -510,7 +510,8 @@ class MADDPG(Model):
             h = shared.unsqueeze(1).expand(b, n, -1)
             if self.args.agent_id:
                 h = h + W_id.t().unsqueeze(0)                             # [1, n, hid]
-            h = h + th.einsum("bia,hia->bih", own, W_act.view(-1, n, a))
+            if act.requires_grad:      # zero-valued term that only carries d/d act_i: nothing to add for replayed actions
+                h = h + th.einsum("bia,hia->bih", own, W_act.view(-1, n, a))
             v, _ = net.forward_from_hidden(h.reshape(b * n, -1), need_hidden=False)
             return v.view(b, n, 1)
         for i, net in enumerate(nets):                                    # non-shared critics: plain input rows
@@ -591,7 +592,9 @@ class MATD3(MADDPG):
             h = h + W[:, off:off + n].t().unsqueeze(0)
             off += n
         W_act = W[:, off:off + n * a]
-        h = h + (act_det.reshape(b, n * a) @ W_act.t()).unsqueeze(1) + th.einsum("bia,hia->bih", own, W_act.view(-1, n, a))
+        h = h + (act_det.reshape(b, n * a) @ W_act.t()).unsqueeze(1)
+        if act.requires_grad:
+            h = h + th.einsum("bia,hia->bih", own, W_act.view(-1, n, a))
         flag = W[:, off + n * a]                                            # column of the 0/1 twin flag
         v1, _ = net.forward_from_hidden(h.reshape(b * n, -1), need_hidden=False)
         v2, _ = net.forward_from_hidden((h + flag).reshape(b * n, -1), need_hidden=False)
