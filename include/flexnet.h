@@ -73,7 +73,7 @@ typedef struct {
     int32_t layernorm;         /* args.layernorm (mlp_critic.py:12-13,27-28) */
     float ln_eps;
     int32_t pad0;
-    const float* z1;           /* [rows, 64]  fc1 output */
+    const float* z1;           /* [rows, 64]  fc1 output; or NULL: z1[r] = z_shared[r / n_agents] + z_id[r % n_agents] */
     const float* ln_w;         /* [64] */
     const float* ln_b;         /* [64] */
     const float* fc2_w;        /* [64, 64] */
@@ -90,6 +90,10 @@ typedef struct {
     float* d_fc2_b;            /* += [64] */
     float* d_fc3_w;            /* += [64] */
     float* d_fc3_b;            /* += [1] */
+    const float* z_shared;     /* [rows / n_agents, 64]  the part of fc1's output all agents of a sample share (maddpg.py:38-54) */
+    const float* z_id;         /* [n_agents, 64]         fc1's one-hot id columns, transposed */
+    int32_t n_agents;          /* used with z_shared */
+    int32_t pad1;
     float* workspace;          /* backward: scratch for the per-block partial sums, or NULL */
     int64_t workspace_floats;  /* >= FLEXNET_CRITIC_WS_FLOATS: the parameter gradients are then reduced in a fixed order
                                 * (bit-reproducible) by a second small launch; otherwise with atomics */

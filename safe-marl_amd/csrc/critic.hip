@@ -35,6 +35,13 @@ __device__ __forceinline__ float cwave_sum(float v) {
 
 struct CriticRow { float xhat, rstd, y, a1; };
 
+// fc1's output of row r for this lane's unit: stored, or composed from the per-sample part and the agent's id column
+__device__ __forceinline__ float critic_z1(const FlexCriticTailArgs& a, int r, int lane) {
+    if (a.z1) return a.z1[(int64_t)r * HID + lane];
+    const int b = r / a.n_agents, i = r - b * a.n_agents;
+    return a.z_shared[(int64_t)b * HID + lane] + a.z_id[i * HID + lane];
+}
+
 // LayerNorm + ReLU of one row held one unit per lane (mlp_critic.py:27-29)
 __device__ __forceinline__ CriticRow critic_ln_relu(float z1, bool layernorm, float eps, float g, float b) {
     CriticRow o;
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_fwd_kernel(FlexCriticT
 #pragma unroll
         for (int r = 0; r < CRT; ++r) {
             const int rr = min(r0 + r, a.rows - 1);
-            a1v[r] = critic_ln_relu(a.z1[(int64_t)rr * HID + lane], a.layernorm != 0, a.ln_eps, g, be).a1;
+            a1v[r] = critic_ln_relu(critic_z1(a, rr, lane), a.layernorm != 0, a.ln_eps, g, be).a1;
         }
         *reinterpret_cast<float4*>(sa + lane * CRT) = make_float4(a1v[0], a1v[1], a1v[2], a1v[3]);
         __builtin_amdgcn_wave_barrier();
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticT
 #pragma unroll
         for (int r = 0; r < CRT; ++r) {
             const int rr = min(r0 + r, a.rows - 1);
-            row[r] = critic_ln_relu(a.z1[(int64_t)rr * HID + lane], a.layernorm != 0, a.ln_eps, g, be);
+            row[r] = critic_ln_relu(critic_z1(a, rr, lane), a.layernorm != 0, a.ln_eps, g, be);
             a1v[r] = row[r].a1;
         }
         float* my_a = sa + wave * CRT;                   // this wavefront's four columns of the [i][16] staging
@@ -262,8 +269,9 @@ __global__ __launch_bounds__(64 * RED_G) void critic_reduce_kernel(FlexCriticTai
 
 static int critic_check(const FlexCriticTailArgs* a, bool backward) {
     if (!a || a->rows < 0) return FLEXNET_EINVAL;
-    if (!a->z1 || !a->fc2_w || !a->fc2_b || !a->fc3_w || !a->fc3_b || (a->layernorm && (!a->ln_w || !a->ln_b)))
+    if (!a->fc2_w || !a->fc2_b || !a->fc3_w || !a->fc3_b || (a->layernorm && (!a->ln_w || !a->ln_b)))
         return FLEXNET_EINVAL;
+    if (!a->z1 && (!a->z_shared || !a->z_id || a->n_agents < 1 || a->rows % a->n_agents != 0)) return FLEXNET_EINVAL;
     if (!backward && !a->q) return FLEXNET_EINVAL;
     if (backward && (!a->dq || !a->dz1 || !a->d_fc2_w || !a->d_fc2_b || !a->d_fc3_w || !a->d_fc3_b ||
                      (a->layernorm && (!a->d_ln_w || !a->d_ln_b))))

@@ -255,7 +255,64 @@ class _CriticTailFn(th.autograd.Function):
         return dz1, (d_g if has_ln else None), (d_b if has_ln else None), d_w2, d_b2, d_w3, d_b3, None
 
 
+class _CriticTailComposedFn(th.autograd.Function):
+    """The same tail on z1[b, i] = shared[b] + id_cols[i] (the critic's first-layer output when no agent's own-action
+    gradient is needed, maddpg.py:38-54) without materialising the [b * n, 64] tensor on the way in."""
+
+    @staticmethod
+    def forward(ctx, shared, id_cols, ln_w, ln_b, w2, b2, w3, b3, eps):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        shared, id_cols = shared.contiguous(), id_cols.contiguous()
+        n = id_cols.shape[0]
+        rows = shared.shape[0] * n
+        q = th.empty(rows, 1, dtype=th.float32, device=shared.device)
+        args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, eps)
+        args.rows, args.z1, args.z_shared, args.z_id, args.n_agents = rows, None, shared.data_ptr(), id_cols.data_ptr(), n
+        args.q = q.data_ptr()
+        _lib.check(lib.flexnet_critic_tail_forward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_critic_tail_forward")
+        ctx.eps = eps
+        ctx.save_for_backward(shared, id_cols, ln_w, ln_b, w2, b2, w3, b3)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        shared, id_cols, ln_w, ln_b, w2, b2, w3, b3 = ctx.saved_tensors
+        n = id_cols.shape[0]
+        rows = shared.shape[0] * n
+        dq = dq.contiguous()
+        dz1 = th.empty(rows, 64, dtype=th.float32, device=shared.device)
+        grads = th.zeros(64 * 64 + 64 * 4 + 1, dtype=th.float32, device=shared.device)
+        d_w2, d_b2, d_w3 = grads[:4096].view(64, 64), grads[4096:4160], grads[4160:4224].view(1, 64)
+        d_g, d_b, d_b3 = grads[4224:4288], grads[4288:4352], grads[4352:4353]
+        args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, ctx.eps)
+        args.rows, args.z1, args.z_shared, args.z_id, args.n_agents = rows, None, shared.data_ptr(), id_cols.data_ptr(), n
+        args.dq, args.dz1 = dq.data_ptr(), dz1.data_ptr()
+        args.d_fc2_w, args.d_fc2_b, args.d_fc3_w, args.d_fc3_b = d_w2.data_ptr(), d_b2.data_ptr(), d_w3.data_ptr(), d_b3.data_ptr()
+        if ln_w is not None:
+            args.d_ln_w, args.d_ln_b = d_g.data_ptr(), d_b.data_ptr()
+        ws = _critic_workspace(shared.device)
+        args.workspace, args.workspace_floats = ws.data_ptr(), ws.numel()
+        _lib.check(lib.flexnet_critic_tail_backward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_critic_tail_backward")
+        dz = dz1.view(-1, n, 64)
+        has_ln = ln_w is not None
+        return (dz.sum(1), dz.sum(0), (d_g if has_ln else None), (d_b if has_ln else None), d_w2, d_b2, d_w3, d_b3, None)
+
+
 class CriticTail:
+    @staticmethod
+    def apply_composed(shared, id_cols, critic):
+        ln = critic.layernorm if critic.args.layernorm else None
+        return _CriticTailComposedFn.apply(shared, id_cols, None if ln is None else ln.weight,
+                                           None if ln is None else ln.bias, critic.fc2.weight, critic.fc2.bias,
+                                           critic.fc3.weight, critic.fc3.bias, 1e-5 if ln is None else ln.eps)
+
     @staticmethod
     def apply(z1, critic):
         ln = critic.layernorm if critic.args.layernorm else None
