@@ -104,6 +104,27 @@ typedef struct {
 int flexnet_critic_tail_forward(const FlexCriticTailArgs* args, void* stream);
 int flexnet_critic_tail_backward(const FlexCriticTailArgs* args, void* stream);
 
+/* Weight gradient of a linear layer over a tall batch: C[m, n] = sum_k A[k, m] * B[k, n] (A = dLoss/dY, B = the
+ * layer's input, k = the batch rows) — what loss.backward() of madrl/utils/trainer.py:62-111 computes for fc1 / the
+ * GRUCell / fc2 of rnn_agent.py:13-33 and fc1 of mlp_critic.py:5-34.  fp32 products and sums on the matrix cores
+ * (v_mfma_f32_32x32x2_f32), summed over k in a fixed order: bit-reproducible.  m <= 192; else FLEXNET_EUNSUPPORTED. */
+typedef struct {
+    int64_t k;                 /* rows summed over */
+    int64_t lda, ldb;          /* row pitch of A and B in floats (>= m, n): column slices of wider records are fine */
+    int64_t workspace_floats;  /* >= FLEXNET_WGRAD_WS_FLOATS */
+    int32_t m, n;
+    int32_t accumulate;        /* 1: C += result */
+    int32_t pad0;
+    const float* a;            /* [k, m] */
+    const float* b;            /* [k, n] */
+    float* c;                  /* out [m, n], dense */
+    float* workspace;
+} FlexWgradArgs;
+
+#define FLEXNET_WGRAD_WS_FLOATS (520 * 12288)
+
+int flexnet_wgrad(const FlexWgradArgs* args, void* stream);
+
 /* One vector step's bookkeeping of the rollout (madrl/models/model.py:230-262 per environment, utils/replay_buffer.py:
  * 23-27): the transition record [state | action | reward | next_state | done | last_step | last_hid | hid] lands in a
  * packed staging row per environment (the replay ring takes it with one copy), the observation and the hidden state are

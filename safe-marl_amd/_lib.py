@@ -59,7 +59,7 @@ SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
-    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack",
+    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad",
 )
 
 class FlexActorArgs(C.Structure):
@@ -80,6 +80,15 @@ class FlexCriticTailArgs(C.Structure):
 
 
 FLEXNET_CRITIC_WS_FLOATS = 1024 * 4416
+
+
+class FlexWgradArgs(C.Structure):
+    _fields_ = [("k", C.c_int64), ("lda", C.c_int64), ("ldb", C.c_int64), ("workspace_floats", C.c_int64),
+                ("m", C.c_int32), ("n", C.c_int32), ("accumulate", C.c_int32), ("pad0", C.c_int32),
+                ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("workspace", C.c_void_p)]
+
+
+FLEXNET_WGRAD_WS_FLOATS = 520 * 12288
 
 
 class FlexRolloutPackArgs(C.Structure):
@@ -128,6 +137,8 @@ def load():
     lib.flexnet_actor_forward.restype = C.c_int
     lib.flexnet_rollout_pack.argtypes = [C.POINTER(FlexRolloutPackArgs), vp]
     lib.flexnet_rollout_pack.restype = C.c_int
+    lib.flexnet_wgrad.argtypes = [C.POINTER(FlexWgradArgs), vp]
+    lib.flexnet_wgrad.restype = C.c_int
     for fn in (lib.flexnet_critic_tail_forward, lib.flexnet_critic_tail_backward):
         fn.argtypes = [C.POINTER(FlexCriticTailArgs), vp]
         fn.restype = C.c_int

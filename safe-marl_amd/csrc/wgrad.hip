@@ -1,0 +1,232 @@
+// wgrad.hip — weight gradients of the learner's linear layers: C[m, n] = sum_k A[k, m] * B[k, n] with k = the batch
+// (gfx950).  Boundary: include/flexnet.h (flexnet_wgrad).
+//
+// The reference's update (madrl/utils/trainer.py:62-111 -> loss.backward()) spends its GEMM time on exactly this
+// shape: dW = dY^T X for fc1 / GRUCell / fc2 of rnn_agent.py:13-33 and fc1 of mlp_critic.py:5-34, where the summed
+// dimension is the batch (32 768 samples, x agents = 163 840 rows) and the output is at most 192 x 745.  Library
+// split-K kernels reach 10-15 TFLOP/s there.  Here both operands are read in their stored [k, .] layout straight
+// into the operand registers of v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation): lane l of a
+// wavefront supplies row k0 + (l >> 5) and columns MT * (l & 31) .. + MT - 1 of A — one vector load, coalesced over
+// the half-wavefront — so register t of that load is the A operand of M-tile t (the tile's row index i is column
+// MT * i + t: a permutation undone when the result is written).  B alike.  A wavefront owns the whole
+// [32 MT, 32 NT] output block over its share of k, so every element of A and B is read once per column chunk and the
+// kernel runs at the HBM / matrix-core balance point (7 loaded floats per 10 MFMAs for [64, 160]).
+// Partial blocks are folded over the thread block's four wavefronts in LDS (fixed order), written as register images
+// to the workspace and summed over thread blocks in a fixed order by wgrad_reduce_kernel: bit-reproducible.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "flexnet.h"
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define WG_WAVES 4
+#define WG_UNROLL(MT, NT) ((MT) * (NT) >= 10 ? 2 : 4)   // k steps (2 rows each) whose loads are issued together
+#define WG_IMG(MT, NT) ((MT) * (NT) * 1024)
+
+struct WgradK {
+    const float* a;
+    const float* b;
+    float* c;
+    float* ws;
+    int64_t k, lda, ldb, a_floats, b_floats;
+    int32_t m, n, rows_per_block, slabs, accumulate, pad;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const float* base, int64_t floats) {
+    const int64_t bytes = floats * 4;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)bytes, 0x00027000);
+}
+
+// W consecutive floats at byte offset `off` (out of range: zeros)
+template <int W>
+__device__ __forceinline__ void wg_load(__amdgpu_buffer_rsrc_t r, int off, float* out) {
+    if constexpr (W == 1) {
+        out[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    } else if constexpr (W == 2) {
+        const v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+        out[0] = v.x; out[1] = v.y;
+    } else if constexpr (W >= 4) {
+        const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        if constexpr (W > 4) wg_load<W - 4>(r, off + 16, out + 4);
+    } else {
+        wg_load<2>(r, off, out);
+        wg_load<1>(r, off + 8, out + 2);
+    }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
+    __shared__ float fold[WG_IMG(MT, NT)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t k0 = (int64_t)blockIdx.x * p.rows_per_block;
+    const int64_t left = p.k - k0;
+    const int rows = left < p.rows_per_block ? (int)left : p.rows_per_block;
+    const int n0 = blockIdx.y * (32 * NT);
+    // buffer views of this block's rows: anything past them (other blocks' rows, the end of the allocation) reads 0
+    int64_t fa = (int64_t)rows * p.lda, fb = (int64_t)rows * p.ldb - n0;
+    const int64_t ea = p.a_floats - k0 * p.lda, eb = p.b_floats - k0 * p.ldb - n0;
+    if (ea < fa) fa = ea;
+    if (eb < fb) fb = eb;
+    const __amdgpu_buffer_rsrc_t ra = wg_rsrc(p.a + k0 * p.lda, fa);
+    const __amdgpu_buffer_rsrc_t rb = wg_rsrc(p.b + k0 * p.ldb + n0, fb);
+
+    v16f acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // step s of the block: rows 2 s, 2 s + 1; wavefront w takes steps w, w + 4, ...
+    const int col = lane & 31, half = lane >> 5;
+    const int steps = (rows + 1) >> 1;
+    const int lda4 = (int)p.lda * 4, ldb4 = (int)p.ldb * 4;
+    int offa = (2 * wave + half) * lda4 + col * (MT * 4);
+    int offb = (2 * wave + half) * ldb4 + col * (NT * 4);
+    const int stepa = 2 * WG_WAVES * lda4, stepb = 2 * WG_WAVES * ldb4;
+    const int mine = steps > wave ? (steps - wave + WG_WAVES - 1) / WG_WAVES : 0;
+
+    constexpr int U = WG_UNROLL(MT, NT);
+    float av[2][U][MT], bv[2][U][NT];
+    auto issue = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            wg_load<MT>(ra, offa, av[buf][u]);
+            wg_load<NT>(rb, offb, bv[buf][u]);
+            offa += stepa; offb += stepb;
+        }
+    };
+    auto multiply = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][i], bv[buf][u][j], acc[i][j], 0, 0, 0);
+    };
+    // rows past the block's end lie outside the buffer views and contribute 0 * 0, so the trip count is rounded up
+    const int groups = (mine + U - 1) / U;
+    if (groups > 0) {
+        issue(0);
+        int g = 0;
+        for (; g + 2 < groups; g += 2) {
+            issue(1); multiply(0);
+            issue(0); multiply(1);
+        }
+        if (g + 1 < groups) { issue(1); multiply(0); multiply(1); }
+        else multiply(0);
+    }
+
+    // fold the four wavefronts' register images in LDS, wavefront 0 first
+#pragma unroll
+    for (int w = 0; w < WG_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int e = ((i * NT + j) * 16 + r) * 64 + lane;
+                        if (w == 0) fold[e] = acc[i][j][r];
+                        else if (w < WG_WAVES - 1) fold[e] += acc[i][j][r];
+                        else acc[i][j][r] += fold[e];
+                    }
+        }
+        __syncthreads();
+    }
+    if (wave != WG_WAVES - 1) return;
+    float* out = p.ws + ((int64_t)blockIdx.y * p.slabs + blockIdx.x) * WG_IMG(MT, NT);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[((i * NT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+}
+
+// element e of the slabs' register images, summed in a fixed order, stored at its place in C
+#define WG_RED 16
+template <int MT, int NT>
+__global__ __launch_bounds__(64 * WG_RED) void wgrad_reduce_kernel(WgradK p) {
+    __shared__ float part[WG_RED][64];
+    const int ex = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + ex;                       // < WG_IMG: the grid covers it exactly
+    const float* src = p.ws + (int64_t)blockIdx.y * p.slabs * WG_IMG(MT, NT) + e;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = gy;
+    for (; b + 3 * WG_RED < p.slabs; b += 4 * WG_RED) {
+        s0 += src[(int64_t)b * WG_IMG(MT, NT)];
+        s1 += src[(int64_t)(b + WG_RED) * WG_IMG(MT, NT)];
+        s2 += src[(int64_t)(b + 2 * WG_RED) * WG_IMG(MT, NT)];
+        s3 += src[(int64_t)(b + 3 * WG_RED) * WG_IMG(MT, NT)];
+    }
+    for (; b < p.slabs; b += WG_RED) s0 += src[(int64_t)b * WG_IMG(MT, NT)];
+    part[gy][ex] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (gy != 0) return;
+    float sum = 0.0f;
+#pragma unroll
+    for (int g = 0; g < WG_RED; ++g) sum += part[g][ex];
+    // register image -> matrix position (v_mfma_f32_32x32x2_f32 result layout, tile rows / columns interleaved)
+    const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
+    const int ti = t / NT, tj = t - ti * NT;
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
+    const int m = MT * i + ti, n = blockIdx.y * (32 * NT) + NT * j + tj;
+    if (m < p.m && n < p.n) {
+        float* dst = p.c + (int64_t)m * p.n + n;
+        *dst = p.accumulate ? *dst + sum : sum;
+    }
+}
+
+template <int MT, int NT>
+static int wgrad_launch(WgradK p, int chunks, hipStream_t s) {
+    hipLaunchKernelGGL((wgrad_kernel<MT, NT>), dim3(p.slabs, chunks), dim3(64 * WG_WAVES), 0, s, p);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<MT, NT>), dim3(WG_IMG(MT, NT) / 64, chunks), dim3(64 * WG_RED), 0, s, p);
+    return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}
+
+extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) {
+    if (!a || !a->a || !a->b || !a->c || !a->workspace || a->k < 0 || a->m < 1 || a->n < 1) return FLEXNET_EINVAL;
+    if (a->lda < a->m || a->ldb < a->n) return FLEXNET_EINVAL;
+    if (a->m > 192 || a->lda >= (1 << 24) || a->ldb >= (1 << 24)) return FLEXNET_EUNSUPPORTED;
+    const int mt = a->m <= 32 ? 1 : a->m <= 64 ? 2 : 6;
+    const int nt = a->n <= 32 ? 1 : a->n <= 64 ? 2 : (mt == 6 ? 2 : 5);
+    const int chunks = (a->n + 32 * nt - 1) / (32 * nt);
+    const int64_t img = (int64_t)mt * nt * 1024;
+    // thread blocks: about two per CU over all column chunks, at least 64 rows each, within the workspace
+    if (a->workspace_floats < chunks * img) return FLEXNET_EINVAL;
+    int64_t slabs = (a->k + 63) / 64;
+    const int64_t want = (512 + chunks - 1) / chunks;
+    if (slabs > want) slabs = want;
+    if (slabs * chunks * img > a->workspace_floats) slabs = a->workspace_floats / (chunks * img);
+    if (slabs < 1) slabs = 1;
+    int64_t rpb = (a->k + slabs - 1) / slabs;
+    rpb = (rpb + 7) & ~(int64_t)7;
+    if (rpb < 8) rpb = 8;
+    if (rpb * (a->lda > a->ldb ? a->lda : a->ldb) * 4 >= 0x7fffffffll) return FLEXNET_EUNSUPPORTED;
+    slabs = a->k > 0 ? (a->k + rpb - 1) / rpb : 1;
+    WgradK p;
+    p.a = a->a; p.b = a->b; p.c = a->c; p.ws = a->workspace;
+    p.k = a->k; p.lda = a->lda; p.ldb = a->ldb;
+    p.a_floats = a->k > 0 ? (a->k - 1) * a->lda + a->m : 0;
+    p.b_floats = a->k > 0 ? (a->k - 1) * a->ldb + a->n : 0;
+    p.m = a->m; p.n = a->n; p.rows_per_block = (int)rpb; p.slabs = (int)slabs; p.accumulate = a->accumulate; p.pad = 0;
+    hipStream_t s = (hipStream_t)stream;
+    switch (mt * 10 + nt) {
+        case 11: return wgrad_launch<1, 1>(p, chunks, s);
+        case 12: return wgrad_launch<1, 2>(p, chunks, s);
+        case 15: return wgrad_launch<1, 5>(p, chunks, s);
+        case 21: return wgrad_launch<2, 1>(p, chunks, s);
+        case 22: return wgrad_launch<2, 2>(p, chunks, s);
+        case 25: return wgrad_launch<2, 5>(p, chunks, s);
+        case 61: return wgrad_launch<6, 1>(p, chunks, s);
+        case 62: return wgrad_launch<6, 2>(p, chunks, s);
+    }
+    return FLEXNET_EUNSUPPORTED;
+}

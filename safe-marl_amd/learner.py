@@ -508,7 +508,8 @@ class MADDPG(Model):
                 W_id = W[:, off:off + n]                                  # [hid, n]
                 off += n
             W_act = W[:, off:off + n * a]
-            shared = wide_batch_linear(obs.reshape(b, n * o), W_obs) + act_det.reshape(b, n * a) @ W_act.t() + bias   # [b, hid]
+            act_cols = act_det.reshape(b, n * a)
+            shared = wide_batch_linear(obs.reshape(b, n * o), W_obs) + wide_batch_linear(act_cols, W_act) + bias   # [b, hid]
             if not act.requires_grad and self.args.agent_id and critic_tail_supported(net, shared):
                 # replayed actions (value loss, bootstrap target): every row is shared[b] + the agent's id column; the
                 # fused tail composes it on the fly instead of reading a materialised [b * n, hid] tensor

@@ -9,6 +9,17 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _find_fused_gru():
+    """ATen's pointwise GRU cell, what nn.GRUCell dispatches to on the GPU after its two gate GEMMs (ATen RNN.cpp)."""
+    try:
+        return th.ops.aten._thnn_fused_gru_cell.default
+    except (AttributeError, RuntimeError):
+        return None
+
+
+_FUSED_GRU = _find_fused_gru()
+
+
 def _activation(name):
     if name == "relu":
         return F.relu
@@ -41,7 +52,15 @@ class RNNAgent(nn.Module):
             x = self.fc1(inputs)
         if self.args.layernorm:
             x = self.layernorm(x)
-        h = self.rnn(self._act(x), hidden_state.reshape(-1, self.args.hid_size))
+        x, hx = self._act(x), hidden_state.reshape(-1, self.args.hid_size)
+        if (th.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS
+                and x.dtype == th.float32 and _FUSED_GRU is not None):
+            # update batches (163 840 rows): the GRUCell as PyTorch composes it on the GPU — two gate GEMMs and the
+            # fused pointwise cell — with the three weight gradients (W_ih, W_hh, fc2) from csrc/wgrad.hip
+            r = self.rnn
+            h = _FUSED_GRU(tall_linear(x, r.weight_ih), tall_linear(hx, r.weight_hh), hx, r.bias_ih, r.bias_hh)[0]
+            return tall_linear(h, self.fc2.weight, self.fc2.bias), None, h
+        h = self.rnn(x, hx)
         return self.fc2(h), None, h
 
 
@@ -151,6 +170,71 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
     return (means, hid_out) if noise is None else (means, hid_out, action, env_action)
 
 
+_WGRAD_WS = {}
+WGRAD_MIN_ROWS = 2048          # below this the library GEMM is launch-bound either way
+
+
+def tall_wgrad_supported(dy, x):
+    return (dy.is_cuda and x.is_cuda and dy.dtype == th.float32 and x.dtype == th.float32 and dy.dim() == 2
+            and x.dim() == 2 and dy.shape[0] == x.shape[0] and 1 <= dy.shape[1] <= 192 and x.shape[1] >= 1
+            and (dy.shape[0] <= 1 or (dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) >= dy.shape[1]
+                                      and x.stride(0) >= x.shape[1] and max(dy.stride(0), x.stride(0)) < (1 << 24))))
+
+
+def tall_wgrad(dy, x, out=None, accumulate=False):
+    """dW[m, n] = sum_k dy[k, m] * x[k, n] (csrc/wgrad.hip: include/flexnet.h flexnet_wgrad) — the weight gradient of
+    y = x @ W.T over a tall batch.  Row-strided views (column slices of the packed replay rows) are read in place.
+    The workspace is per device: calls are expected on one stream at a time (the update's)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    k, m = dy.shape
+    n = x.shape[1]
+    if k <= 1:
+        dy, x = dy.contiguous(), x.contiguous()
+    if out is None:
+        out = th.empty(m, n, dtype=th.float32, device=dy.device)
+    if dy.device not in _WGRAD_WS:
+        _WGRAD_WS[dy.device] = th.empty(_lib.FLEXNET_WGRAD_WS_FLOATS, dtype=th.float32, device=dy.device)
+    ws = _WGRAD_WS[dy.device]
+    a = _lib.FlexWgradArgs()
+    a.k, a.m, a.n = k, m, n
+    a.lda, a.ldb = (dy.stride(0), x.stride(0)) if k > 1 else (m, n)
+    a.a, a.b, a.c = dy.data_ptr(), x.data_ptr(), out.data_ptr()
+    a.workspace, a.workspace_floats, a.accumulate = ws.data_ptr(), ws.numel(), int(accumulate)
+    _lib.check(lib.flexnet_wgrad(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_wgrad")
+    return out
+
+
+class _TallLinear(th.autograd.Function):
+    """y = x @ W.T (+ b) for a tall x: the library GEMM forward and for dx, csrc/wgrad.hip for dW."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return th.addmm(b, x, w.t()) if b is not None else x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = tall_wgrad(dy, x) if tall_wgrad_supported(dy, x) else dy.t() @ x
+        if ctx.needs_input_grad[0]:
+            dx = dy @ w
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db
+
+
+def tall_linear(x, w, b=None):
+    """F.linear for [rows, in] inputs; rows >= WGRAD_MIN_ROWS on the GPU take the hand-written weight gradient."""
+    if x.is_cuda and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS and w.shape[0] <= 192 and x.dtype == th.float32:
+        return _TallLinear.apply(x, w, b)
+    return F.linear(x, w, b)
+
+
 class _WideBatchLinear(th.autograd.Function):
     """y = x @ W.T for a tall x [B, K] (B ~ 1e4..1e5) and a small W [N, K], x without gradient.  The weight gradient
     dW = dy.T @ x has only N*K/tile output tiles (23 workgroups for 64 x 720) and a reduction over the whole batch:
@@ -171,7 +255,9 @@ class _WideBatchLinear(th.autograd.Function):
         if ctx.needs_input_grad[1]:
             b = x.shape[0]
             s = _WideBatchLinear.SLABS
-            if b % s == 0 and b >= 4096:
+            if b >= WGRAD_MIN_ROWS and tall_wgrad_supported(dy, x):
+                dw = tall_wgrad(dy, x)
+            elif b % s == 0 and b >= 4096:
                 dw = th.bmm(dy.reshape(s, b // s, -1).transpose(1, 2), x.reshape(s, b // s, -1)).sum(0)
             else:
                 dw = dy.t() @ x

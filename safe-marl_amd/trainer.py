@@ -147,7 +147,9 @@ class PGTrainer(object):
                     if th.is_tensor(v):
                         old = had_state.get(p, {}).get(k)
                         v.copy_(old) if old is not None else v.zero_()
-        return dict(graph=graph, batch2d=batch2d, stat=out, bs=bs, buf=buf)
+        # `batch` stays referenced: its constant fields (action_avail, ...) were allocated eagerly and are baked into the
+        # graph by address; released, the allocator would hand their memory to the next eager tensor
+        return dict(graph=graph, batch2d=batch2d, stat=out, bs=bs, buf=buf, batch=batch)
 
     # kept for callers that hand over a batch themselves (trainer.py:81,99)
     def policy_transition_process(self, stat, trans):

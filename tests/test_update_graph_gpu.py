@@ -37,7 +37,7 @@ def test_graphed_sub_updates_equal_eager_ones():
     for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
         assert torch.equal(va, vb), ka                           # same start
     assert torch.equal(a.replay_buffer.store2d, b.replay_buffer.store2d)
-    for which in ("value", "value", "policy", "value"):
+    for which in ("value", "value", "policy", "policy", "value", "policy"):
         for tr in (a, b):
             np.random.seed(11)                                   # the same replay window
             st = {}

@@ -1,0 +1,136 @@
+"""csrc/wgrad.hip (include/flexnet.h: flexnet_wgrad) — dW = dY^T X over a tall batch, the weight gradients that
+loss.backward() forms in the reference's update (madrl/utils/trainer.py:62-111) for fc1 / GRUCell / fc2 of
+rnn_agent.py:13-33 and fc1 of mlp_critic.py:5-34 — against an fp64 product of the same operands.  fp32 products and
+sums: the tolerance is relative to the largest entry and grows with the square root of the batch."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    (163840, 64, 149),      # actor fc1 at the update batch (32 768 samples x 5 agents)
+    (163840, 192, 64),      # GRUCell weight_ih / weight_hh
+    (163840, 4, 64),        # actor fc2
+    (32768, 64, 720),       # critic fc1, observation columns (five column chunks)
+    (32768, 64, 20),        # critic fc1, action columns
+    (4099, 64, 149), (2051, 192, 33), (1000, 33, 161), (777, 100, 64), (64, 1, 1), (5, 3, 7), (1, 64, 64), (2, 192, 745),
+]
+
+
+def _ref(dy, x):
+    return dy.double().t() @ x.double()
+
+
+def _close(got, want, k):
+    scale = max(want.abs().max().item(), 1e-30)
+    return (got.double() - want).abs().max().item() / scale < 3e-7 * max(1.0, k ** 0.5)
+
+
+@pytest.mark.parametrize("k,m,n", SHAPES)
+def test_matches_fp64_product(k, m, n):
+    from safe_marl_amd.nets import tall_wgrad, tall_wgrad_supported
+    g = torch.Generator(device="cuda").manual_seed(k + m + n)
+    dy = torch.randn(k, m, device="cuda", generator=g)
+    x = torch.randn(k, n, device="cuda", generator=g)
+    assert tall_wgrad_supported(dy, x)
+    got = tall_wgrad(dy, x)
+    assert got.shape == (m, n)
+    assert _close(got, _ref(dy, x), k)
+    assert torch.equal(got, tall_wgrad(dy, x))                   # fixed summation order
+
+
+@pytest.mark.parametrize("k", [32768, 1003])
+def test_row_strided_operands_are_read_in_place(k):
+    """Column slices of wider records (the packed replay rows); neighbours hold NaN to prove nothing else is used."""
+    from safe_marl_amd.nets import tall_wgrad, tall_wgrad_supported
+    g = torch.Generator(device="cuda").manual_seed(7)
+    rec_a = torch.full((k, 100), float("nan"), device="cuda")
+    rec_b = torch.full((k, 400), float("nan"), device="cuda")
+    dy, x = rec_a[:, 17:81], rec_b[:, 33:182]
+    dy.copy_(torch.randn(k, 64, device="cuda", generator=g))
+    x.copy_(torch.randn(k, 149, device="cuda", generator=g))
+    assert tall_wgrad_supported(dy, x) and not x.is_contiguous()
+    got = tall_wgrad(dy, x)
+    assert torch.isfinite(got).all()
+    assert _close(got, _ref(dy, x), k)
+
+
+def test_accumulate_and_out():
+    from safe_marl_amd.nets import tall_wgrad
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dy = torch.randn(5000, 64, device="cuda", generator=g)
+    x = torch.randn(5000, 70, device="cuda", generator=g)
+    out = torch.ones(64, 70, device="cuda")
+    same = tall_wgrad(dy, x, out=out, accumulate=True)
+    assert same is out
+    assert _close(out - 1.0, _ref(dy, x), 5000)
+
+
+def test_tall_linear_gradients_match_the_library():
+    """tall_linear is F.linear with the hand-written weight gradient."""
+    from safe_marl_amd.nets import tall_linear
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(20480, 64, device="cuda", generator=g)
+    w = torch.randn(192, 64, device="cuda", generator=g) * 0.1
+    b = torch.randn(192, device="cuda", generator=g)
+    up = torch.randn(20480, 192, device="cuda", generator=g)
+    outs = []
+    for fn in (tall_linear, F.linear):
+        xs, ws, bs = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = fn(xs, ws, bs)
+        outs.append((y,) + torch.autograd.grad((y * up).sum(), [xs, ws, bs]))
+    for a, e in zip(*outs):
+        assert (a - e).abs().max().item() <= 2e-4 * max(1.0, e.abs().max().item())
+
+
+def test_unsupported_shapes_are_refused():
+    import ctypes as C
+    from safe_marl_amd import _lib
+    from safe_marl_amd.nets import tall_wgrad_supported
+    dy = torch.randn(100, 200, device="cuda")
+    x = torch.randn(100, 8, device="cuda")
+    assert not tall_wgrad_supported(dy, x)                        # m > 192
+    assert not tall_wgrad_supported(dy[:, :64].t().t()[:, ::2], x)   # column stride 2
+    lib = _lib.load()
+    a = _lib.FlexWgradArgs()
+    a.k, a.m, a.n, a.lda, a.ldb = 100, 200, 8, 200, 8
+    out = torch.empty(200, 8, device="cuda")
+    ws = torch.empty(_lib.FLEXNET_WGRAD_WS_FLOATS, device="cuda")
+    a.a, a.b, a.c, a.workspace, a.workspace_floats = dy.data_ptr(), x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel()
+    assert lib.flexnet_wgrad(C.byref(a), None) == _lib.FLEXNET_EUNSUPPORTED
+    a.m, a.lda = 64, 32
+    assert lib.flexnet_wgrad(C.byref(a), None) == -1      # FLEXNET_EINVAL
+
+
+def test_actor_update_pass_matches_the_module_path():
+    """RNNAgent.forward at an update batch (GRUCell composed from the gate GEMMs + ATen's fused cell, weight gradients
+    from csrc/wgrad.hip) against the plain nn.GRUCell / nn.Linear path: same outputs, gradients to fp32 accuracy."""
+    import types
+    from safe_marl_amd import nets
+    torch.manual_seed(0)
+    args = types.SimpleNamespace(hid_size=64, layernorm=True, hid_activation="relu", action_dim=4, agent_num=5)
+    agent = nets.RNNAgent(149, args).cuda()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rows = 20480
+    obs = torch.randn(rows, 149, device="cuda", generator=g)
+    hid = torch.randn(rows, 64, device="cuda", generator=g)
+    up_a = torch.randn(rows, 4, device="cuda", generator=g)
+    up_h = torch.randn(rows, 64, device="cuda", generator=g)
+    params = list(agent.parameters())
+
+    def run():
+        h0 = hid.clone().requires_grad_(True)
+        a, _, h = agent(obs, h0)
+        return (a, h) + torch.autograd.grad((a * up_a).sum() + (h * up_h).sum(), [h0] + params)
+
+    assert nets._FUSED_GRU is not None
+    fast = run()
+    saved, nets._FUSED_GRU, nets.WGRAD_MIN_ROWS = (nets._FUSED_GRU, nets.WGRAD_MIN_ROWS), None, 1 << 30
+    try:
+        plain = run()
+    finally:
+        nets._FUSED_GRU, nets.WGRAD_MIN_ROWS = saved
+    assert torch.equal(fast[0], plain[0]) and torch.equal(fast[1], plain[1])
+    for a, e in zip(fast[2:], plain[2:]):
+        assert (a - e).abs().max().item() <= 1e-4 * max(1.0, e.abs().max().item())
