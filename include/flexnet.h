@@ -125,6 +125,35 @@ typedef struct {
 
 int flexnet_wgrad(const FlexWgradArgs* args, void* stream);
 
+/* The actor's first-layer epilogue at update batches (rnn_agent.py:25-29 with the one-hot id columns of
+ * model.py:105-108 folded in): out = relu(LayerNorm(z + bias + id_cols[r % n_agents])) for z = obs @ W_obs^T, and the
+ * backward of that chain with its four parameter gradients (OVERWRITTEN, summed in a fixed order). */
+typedef struct {
+    int32_t rows, n_agents;
+    int32_t layernorm;         /* args.layernorm */
+    float ln_eps;
+    const float* z;            /* [rows, 64] */
+    const float* bias;         /* [64] or NULL */
+    const float* id_cols;      /* [n_agents, 64] (fc1.weight[:, obs:obs+n] transposed) or NULL */
+    const float* ln_w;         /* [64] */
+    const float* ln_b;         /* [64] */
+    float* out;                /* forward: [rows, 64] */
+    /* backward only */
+    const float* dout;         /* [rows, 64] */
+    float* dz;                 /* out [rows, 64] */
+    float* d_bias;             /* out [64] or NULL */
+    float* d_id;               /* out [n_agents, 64] or NULL */
+    float* d_ln_w;             /* out [64] or NULL */
+    float* d_ln_b;             /* out [64] or NULL */
+    float* workspace;
+    int64_t workspace_floats;  /* >= FLEXNET_LNRELU_WS_FLOATS */
+} FlexLnReluArgs;
+
+#define FLEXNET_LNRELU_WS_FLOATS (1024 * 704)
+
+int flexnet_lnrelu_forward(const FlexLnReluArgs* args, void* stream);
+int flexnet_lnrelu_backward(const FlexLnReluArgs* args, void* stream);
+
 /* One vector step's bookkeeping of the rollout (madrl/models/model.py:230-262 per environment, utils/replay_buffer.py:
  * 23-27): the transition record [state | action | reward | next_state | done | last_step | last_hid | hid] lands in a
  * packed staging row per environment (the replay ring takes it with one copy), the observation and the hidden state are

@@ -59,7 +59,7 @@ SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
-    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad",
+    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward",
 )
 
 class FlexActorArgs(C.Structure):
@@ -89,6 +89,15 @@ class FlexWgradArgs(C.Structure):
 
 
 FLEXNET_WGRAD_WS_FLOATS = 520 * 12288
+
+
+class FlexLnReluArgs(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("n_agents", C.c_int32), ("layernorm", C.c_int32), ("ln_eps", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("z", "bias", "id_cols", "ln_w", "ln_b", "out", "dout", "dz", "d_bias", "d_id",
+                                          "d_ln_w", "d_ln_b", "workspace")] + [("workspace_floats", C.c_int64)]
+
+
+FLEXNET_LNRELU_WS_FLOATS = 1024 * 704
 
 
 class FlexRolloutPackArgs(C.Structure):
@@ -139,6 +148,9 @@ def load():
     lib.flexnet_rollout_pack.restype = C.c_int
     lib.flexnet_wgrad.argtypes = [C.POINTER(FlexWgradArgs), vp]
     lib.flexnet_wgrad.restype = C.c_int
+    for fn in (lib.flexnet_lnrelu_forward, lib.flexnet_lnrelu_backward):
+        fn.argtypes = [C.POINTER(FlexLnReluArgs), vp]
+        fn.restype = C.c_int
     for fn in (lib.flexnet_critic_tail_forward, lib.flexnet_critic_tail_backward):
         fn.argtypes = [C.POINTER(FlexCriticTailArgs), vp]
         fn.restype = C.c_int

@@ -19,7 +19,8 @@ import numpy as np
 import torch as th
 import torch.nn as nn
 
-from .nets import CriticTail, MLPAgent, MLPCritic, RNNAgent, critic_tail_supported, fused_actor_forward, wide_batch_linear
+from .nets import (WGRAD_MIN_ROWS, CriticTail, MLPAgent, MLPCritic, RNNAgent, critic_tail_supported, fused_actor_forward,
+                   wide_batch_linear)
 from .replay_buffer import Transition
 from .util import prep_obs, scale_action, select_action, translate_action
 
@@ -194,6 +195,13 @@ class Model(nn.Module):
             hiddens = fused[1].view(b, self.n_, -1)
             log_stds = th.full_like(means, float(np.log(self.args.fixed_policy_std)))
             return means, log_stds, hiddens
+        if (self.args.shared_params and obs.is_cuda and th.is_grad_enabled() and self.fused_inference
+                and b * self.n_ >= WGRAD_MIN_ROWS and isinstance(self.policy_dicts[0], RNNAgent)):
+            # update batches: no id concat (the id block of fc1 is an addend per agent), fused LayerNorm/ReLU pass
+            out = self.policy_dicts[0].forward_update(obs.reshape(b * self.n_, -1), last_hid, self.n_, self.args.agent_id)
+            if out is not None:
+                means, hiddens = out[0].view(b, self.n_, -1), out[2].view(b, self.n_, -1)
+                return means, th.full_like(means, float(np.log(self.args.fixed_policy_std))), hiddens
         if self.args.agent_id:
             ids = th.eye(self.n_, device=obs.device, dtype=obs.dtype).expand(b, -1, -1)
             obs = th.cat((obs, ids), dim=-1)

@@ -63,6 +63,23 @@ class RNNAgent(nn.Module):
         h = self.rnn(x, hx)
         return self.fc2(h), None, h
 
+    def forward_update(self, obs, hidden_state, n_agents, agent_id):
+        """The same forward for an update batch on the GPU, from observations WITHOUT the one-hot id columns: row r is
+        agent r % n_agents (model.py:110-112), fc1's id block enters as a per-agent addend.  Returns None when the
+        configuration is outside what csrc/lnrelu.hip covers (the caller concatenates the ids and calls forward)."""
+        o = obs.shape[1]
+        W = self.fc1.weight
+        if not (lnrelu_supported(self, obs.new_empty(0, 64), n_agents) and W.shape[1] == o + (n_agents if agent_id else 0)
+                and _FUSED_GRU is not None and obs.shape[0] % n_agents == 0):
+            return None
+        z = wide_batch_linear(obs, W[:, :o]) if not obs.requires_grad else tall_linear(obs, W[:, :o])
+        ln = self.layernorm if self.args.layernorm else None
+        x = _LnReluFn.apply(z, self.fc1.bias, W[:, o:].t() if agent_id else None, None if ln is None else ln.weight,
+                            None if ln is None else ln.bias, 1e-5 if ln is None else ln.eps, n_agents)
+        r, hx = self.rnn, hidden_state.reshape(-1, self.args.hid_size)
+        h = _FUSED_GRU(tall_linear(x, r.weight_ih), tall_linear(hx, r.weight_hh), hx, r.bias_ih, r.bias_hh)[0]
+        return tall_linear(h, self.fc2.weight, self.fc2.bias), None, h
+
 
 class MLPAgent(nn.Module):
     """madrl/agents/mlp_agent.py:5-32 (agent_type: mlp)."""
@@ -233,6 +250,74 @@ def tall_linear(x, w, b=None):
     if x.is_cuda and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS and w.shape[0] <= 192 and x.dtype == th.float32:
         return _TallLinear.apply(x, w, b)
     return F.linear(x, w, b)
+
+
+_LNRELU_WS = {}
+
+
+def _lnrelu_args(z, bias, id_cols, ln_w, ln_b, eps, n_agents):
+    from . import _lib
+    a = _lib.FlexLnReluArgs()
+    a.rows, a.n_agents, a.layernorm, a.ln_eps = z.shape[0], n_agents, int(ln_w is not None), float(eps)
+    a.z = z.data_ptr()
+    a.bias = None if bias is None else bias.data_ptr()
+    a.id_cols = None if id_cols is None else id_cols.data_ptr()
+    if ln_w is not None:
+        a.ln_w, a.ln_b = ln_w.data_ptr(), ln_b.data_ptr()
+    return a
+
+
+class _LnReluFn(th.autograd.Function):
+    """relu(LayerNorm(z + bias + id_cols[r % n])) (rnn_agent.py:25-29 after the fc1 GEMM) with a hand-written backward
+    (csrc/lnrelu.hip): dz and the gradients of bias, id columns and the LayerNorm pair in two launches."""
+
+    @staticmethod
+    def forward(ctx, z, bias, id_cols, ln_w, ln_b, eps, n_agents):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        z = z.contiguous()
+        id_cols = None if id_cols is None else id_cols.contiguous()
+        out = th.empty_like(z)
+        a = _lnrelu_args(z, bias, id_cols, ln_w, ln_b, eps, n_agents)
+        a.out = out.data_ptr()
+        _lib.check(lib.flexnet_lnrelu_forward(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_lnrelu_forward")
+        ctx.eps, ctx.n_agents = eps, n_agents
+        ctx.save_for_backward(z, bias, id_cols, ln_w, ln_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        z, bias, id_cols, ln_w, ln_b = ctx.saved_tensors
+        dout = dout.contiguous()
+        dz = th.empty_like(z)
+        small = th.empty(3 + ctx.n_agents, 64, dtype=th.float32, device=z.device)
+        a = _lnrelu_args(z, bias, id_cols, ln_w, ln_b, ctx.eps, ctx.n_agents)
+        a.dout, a.dz = dout.data_ptr(), dz.data_ptr()
+        if ln_w is not None:
+            a.d_ln_w, a.d_ln_b = small[0].data_ptr(), small[1].data_ptr()
+        if bias is not None:
+            a.d_bias = small[2].data_ptr()
+        if id_cols is not None:
+            a.d_id = small[3:].data_ptr()
+        if z.device not in _LNRELU_WS:
+            _LNRELU_WS[z.device] = th.empty(_lib.FLEXNET_LNRELU_WS_FLOATS, dtype=th.float32, device=z.device)
+        ws = _LNRELU_WS[z.device]
+        a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
+        _lib.check(lib.flexnet_lnrelu_backward(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_lnrelu_backward")
+        return (dz, None if bias is None else small[2], None if id_cols is None else small[3:],
+                None if ln_w is None else small[0], None if ln_w is None else small[1], None, None)
+
+
+def lnrelu_supported(agent, z, n_agents):
+    a = agent.args
+    return (z.is_cuda and z.dtype == th.float32 and z.dim() == 2 and z.shape[1] == 64 and a.hid_size == 64
+            and a.hid_activation == "relu" and 1 <= n_agents <= 8 and getattr(agent, "fused_epilogue", True))
 
 
 class _WideBatchLinear(th.autograd.Function):
