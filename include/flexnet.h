@@ -84,7 +84,7 @@ typedef struct {
     /* backward only (NULL for the forward call) */
     const float* dq;           /* [rows]      dLoss/dq */
     float* dz1;                /* out [rows, 64] */
-    float* d_ln_w;             /* += [64] */
+    float* d_ln_w;             /* += [64]   (d_fc2_w == NULL: no parameter gradients at all, dz1 only) */
     float* d_ln_b;             /* += [64] */
     float* d_fc2_w;            /* += [64, 64] */
     float* d_fc2_b;            /* += [64] */
@@ -119,9 +119,10 @@ typedef struct {
     const float* b;            /* [k, n] */
     float* c;                  /* out [m, n], dense */
     float* workspace;
+    float* colsum;             /* out [m] = sum_k A[k, m] (the layer's bias gradient), or NULL */
 } FlexWgradArgs;
 
-#define FLEXNET_WGRAD_WS_FLOATS (520 * 12288)
+#define FLEXNET_WGRAD_WS_FLOATS (520 * 12288 + 520 * 192)
 
 int flexnet_wgrad(const FlexWgradArgs* args, void* stream);
 

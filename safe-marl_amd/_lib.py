@@ -85,10 +85,11 @@ FLEXNET_CRITIC_WS_FLOATS = 1024 * 4416
 class FlexWgradArgs(C.Structure):
     _fields_ = [("k", C.c_int64), ("lda", C.c_int64), ("ldb", C.c_int64), ("workspace_floats", C.c_int64),
                 ("m", C.c_int32), ("n", C.c_int32), ("accumulate", C.c_int32), ("pad0", C.c_int32),
-                ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("workspace", C.c_void_p)]
+                ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("workspace", C.c_void_p),
+                ("colsum", C.c_void_p)]
 
 
-FLEXNET_WGRAD_WS_FLOATS = 520 * 12288
+FLEXNET_WGRAD_WS_FLOATS = 520 * 12288 + 520 * 192
 
 
 class FlexLnReluArgs(C.Structure):

@@ -107,6 +107,8 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_fwd_kernel(FlexCriticT
 // [16 w, 16 w + 16)) over all 16 rows — 16 register accumulators per lane instead of 64, no fold across wavefronts.
 #define BT (CW * CRT)
 #define CRITIC_WS_PITCH 4416                // floats per block in the workspace (4353 used)
+// PGRAD = false: dz1 only (the policy loss differentiates THROUGH the critic; its parameters take no step there).
+template <bool PGRAD>
 __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticTailArgs a) {
     __shared__ float sa[HID * BT];                       // a1  as [i][row of the block tile]
     __shared__ float sd[HID * BT];                       // dz2 as [j][row]
@@ -153,10 +155,12 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticT
 #pragma unroll
         for (int r = 0; r < CRT; ++r) {
             const float dq = r0 + r < a.rows ? a.dq[r0 + r] : 0.0f;              // spare rows of the last tile contribute nothing
-            acc_w3 = fmaf(dq, fmaxf(z2[r], 0.0f), acc_w3);
-            acc_b3 += dq;
             dz2[r] = z2[r] > 0.0f ? dq * w3 : 0.0f;
-            acc_b2 += dz2[r];
+            if (PGRAD) {
+                acc_w3 = fmaf(dq, fmaxf(z2[r], 0.0f), acc_w3);
+                acc_b3 += dq;
+                acc_b2 += dz2[r];
+            }
         }
         *reinterpret_cast<float4*>(my_d + lane * BT) = make_float4(dz2[0], dz2[1], dz2[2], dz2[3]);
         __builtin_amdgcn_wave_barrier();
@@ -173,14 +177,20 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticT
             const float dy = row[r].y > 0.0f ? da1[r] : 0.0f;
             float dz1 = dy;
             if (a.layernorm) {
-                acc_g = fmaf(dy, row[r].xhat, acc_g);
-                acc_b += dy;
+                if (PGRAD) {
+                    acc_g = fmaf(dy, row[r].xhat, acc_g);
+                    acc_b += dy;
+                }
                 const float dxh = dy * g;
                 const float m1 = cwave_sum(dxh) * (1.0f / HID);
                 const float m2 = cwave_sum(dxh * row[r].xhat) * (1.0f / HID);
                 dz1 = row[r].rstd * (dxh - m1 - row[r].xhat * m2);
             }
             if (r0 + r < a.rows) a.dz1[(int64_t)(r0 + r) * HID + lane] = dz1;
+        }
+        if (!PGRAD) {                                    // staging is per wavefront on this path: no block barrier
+            __builtin_amdgcn_wave_barrier();
+            continue;
         }
         __syncthreads();                                 // all 16 rows' a1 and dz2 are staged
         float dzr[BT];                                   // dz2 of THIS unit for the 16 rows
@@ -202,6 +212,7 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticT
         }
         __syncthreads();                                 // staging may be overwritten
     }
+    if (!PGRAD) return;
     // the small vectors: fold the block's four wavefronts through LDS (staging is free now)
     __syncthreads();
     float* vs = sa;                                      // [4 vectors + 1][CW][64]
@@ -273,8 +284,9 @@ static int critic_check(const FlexCriticTailArgs* a, bool backward) {
         return FLEXNET_EINVAL;
     if (!a->z1 && (!a->z_shared || !a->z_id || a->n_agents < 1 || a->rows % a->n_agents != 0)) return FLEXNET_EINVAL;
     if (!backward && !a->q) return FLEXNET_EINVAL;
-    if (backward && (!a->dq || !a->dz1 || !a->d_fc2_w || !a->d_fc2_b || !a->d_fc3_w || !a->d_fc3_b ||
-                     (a->layernorm && (!a->d_ln_w || !a->d_ln_b))))
+    if (backward && (!a->dq || !a->dz1)) return FLEXNET_EINVAL;
+    // parameter gradients: all of them, or none (d_fc2_w == NULL: dz1 only)
+    if (backward && a->d_fc2_w && (!a->d_fc2_b || !a->d_fc3_w || !a->d_fc3_b || (a->layernorm && (!a->d_ln_w || !a->d_ln_b))))
         return FLEXNET_EINVAL;
     return FLEXNET_OK;
 }
@@ -307,12 +319,18 @@ extern "C" int flexnet_critic_tail_backward(const FlexCriticTailArgs* a, void* s
     if (rc != FLEXNET_OK) return rc;
     if (a->rows == 0) return FLEXNET_OK;
     FlexCriticTailArgs k = *a;
+    if (!k.d_fc2_w) {
+        const int nb = critic_grid(k.rows, 4);
+        if (nb < 1) return FLEXNET_EHIP;
+        hipLaunchKernelGGL(critic_tail_bwd_kernel<false>, dim3(nb), dim3(64 * CW), 0, (hipStream_t)stream, k);
+        return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+    }
     const bool two_stage = k.workspace && k.workspace_floats >= FLEXNET_CRITIC_WS_FLOATS;
     if (!two_stage) k.workspace = nullptr;
     // deterministic path: up to 1024 blocks of partial sums; atomic path: one block per CU (each ends with 4 k atomics)
     const int blocks = critic_grid(k.rows, two_stage ? 4 : 1);
     if (blocks < 1 || blocks > 1024) return FLEXNET_EHIP;
-    hipLaunchKernelGGL(critic_tail_bwd_kernel, dim3(blocks), dim3(64 * CW), 0, (hipStream_t)stream, k);
+    hipLaunchKernelGGL(critic_tail_bwd_kernel<true>, dim3(blocks), dim3(64 * CW), 0, (hipStream_t)stream, k);
     if (two_stage)
         hipLaunchKernelGGL(critic_reduce_kernel, dim3((HID * HID + 4 * HID + 1 + 63) / 64), dim3(64 * RED_G), 0, (hipStream_t)stream, k, blocks);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;

@@ -25,11 +25,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define WG_UNROLL(MT, NT) ((MT) * (NT) >= 10 ? 2 : 4)   // k steps (2 rows each) whose loads are issued together
 #define WG_IMG(MT, NT) ((MT) * (NT) * 1024)
 
+#define WG_CS_FLOATS (520 * 192)      // head of the workspace: per-block column sums of A
+
 struct WgradK {
     const float* a;
     const float* b;
     float* c;
-    float* ws;
+    float* ws;                       // register images, after the column-sum area
+    float* cs;                       // column-sum partials [slabs][32 MT], or NULL
+    float* colsum;
     int64_t k, lda, ldb, a_floats, b_floats;
     int32_t m, n, rows_per_block, slabs, accumulate, pad;
 };
@@ -57,7 +61,7 @@ __device__ __forceinline__ void wg_load(__amdgpu_buffer_rsrc_t r, int off, float
     }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, bool CS>
 __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
     __shared__ float fold[WG_IMG(MT, NT)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -92,6 +96,10 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
 
     constexpr int U = WG_UNROLL(MT, NT);
     float av[2][U][MT], bv[2][U][NT];
+    float csum[MT];                  // this lane's share of sum_k A[k, MT * col + i] (the bias gradient)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) csum[i] = 0.0f;
+    const bool want_cs = CS && blockIdx.y == 0;
     auto issue = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -108,6 +116,12 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][i], bv[buf][u][j], acc[i][j], 0, 0, 0);
+        if (CS) {                    // (every column chunk adds; only chunk 0 stores)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) csum[i] += av[buf][u][i];
+        }
     };
     // rows past the block's end lie outside the buffer views and contribute 0 * 0, so the trip count is rounded up
     const int groups = (mine + U - 1) / U;
@@ -120,6 +134,22 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
         }
         if (g + 1 < groups) { issue(1); multiply(0); multiply(1); }
         else multiply(0);
+    }
+
+    if (want_cs) {                   // lanes l and l + 32 hold the same columns; then the four wavefronts in order
+        __shared__ float cfold[WG_WAVES][32 * MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const float s = csum[i] + __shfl_xor(csum[i], 32);
+            if (half == 0) cfold[wave][col * MT + i] = s;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 32 * MT; e += 64 * WG_WAVES) {
+            float s = cfold[0][e];
+#pragma unroll
+            for (int w = 1; w < WG_WAVES; ++w) s += cfold[w][e];
+            p.cs[(int64_t)blockIdx.x * (32 * MT) + e] = s;
+        }
     }
 
     // fold the four wavefronts' register images in LDS, wavefront 0 first
@@ -184,10 +214,37 @@ __global__ __launch_bounds__(64 * WG_RED) void wgrad_reduce_kernel(WgradK p) {
     }
 }
 
+// column sums: element m of every block's partial row, in the same fixed order
+__global__ __launch_bounds__(64 * WG_RED) void wgrad_colsum_kernel(WgradK p, int pitch) {
+    __shared__ float part[WG_RED][64];
+    const int ex = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int m = blockIdx.x * 64 + ex;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (m < pitch) {
+        const float* src = p.cs + m;
+        int b = gy;
+        for (; b + WG_RED < p.slabs; b += 2 * WG_RED) {
+            s0 += src[(int64_t)b * pitch];
+            s1 += src[(int64_t)(b + WG_RED) * pitch];
+        }
+        if (b < p.slabs) s0 += src[(int64_t)b * pitch];
+    }
+    part[gy][ex] = s0 + s1;
+    __syncthreads();
+    if (gy != 0 || m >= p.m) return;
+    float sum = 0.0f;
+#pragma unroll
+    for (int g = 0; g < WG_RED; ++g) sum += part[g][ex];
+    p.colsum[m] = p.accumulate ? p.colsum[m] + sum : sum;
+}
+
 template <int MT, int NT>
 static int wgrad_launch(WgradK p, int chunks, hipStream_t s) {
-    hipLaunchKernelGGL((wgrad_kernel<MT, NT>), dim3(p.slabs, chunks), dim3(64 * WG_WAVES), 0, s, p);
+    if (p.cs) hipLaunchKernelGGL((wgrad_kernel<MT, NT, true>), dim3(p.slabs, chunks), dim3(64 * WG_WAVES), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<MT, NT, false>), dim3(p.slabs, chunks), dim3(64 * WG_WAVES), 0, s, p);
     hipLaunchKernelGGL((wgrad_reduce_kernel<MT, NT>), dim3(WG_IMG(MT, NT) / 64, chunks), dim3(64 * WG_RED), 0, s, p);
+    if (p.cs)
+        hipLaunchKernelGGL(wgrad_colsum_kernel, dim3((32 * MT + 63) / 64), dim3(64 * WG_RED), 0, s, p, 32 * MT);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 
@@ -200,11 +257,13 @@ extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) {
     const int chunks = (a->n + 32 * nt - 1) / (32 * nt);
     const int64_t img = (int64_t)mt * nt * 1024;
     // thread blocks: about two per CU over all column chunks, at least 64 rows each, within the workspace
-    if (a->workspace_floats < chunks * img) return FLEXNET_EINVAL;
+    const int64_t ws_floats = a->workspace_floats - WG_CS_FLOATS;
+    if (ws_floats < chunks * img) return FLEXNET_EINVAL;
     int64_t slabs = (a->k + 63) / 64;
     const int64_t want = (512 + chunks - 1) / chunks;
     if (slabs > want) slabs = want;
-    if (slabs * chunks * img > a->workspace_floats) slabs = a->workspace_floats / (chunks * img);
+    if (slabs * chunks * img > ws_floats) slabs = ws_floats / (chunks * img);
+    if (slabs > 520) slabs = 520;
     if (slabs < 1) slabs = 1;
     int64_t rpb = (a->k + slabs - 1) / slabs;
     rpb = (rpb + 7) & ~(int64_t)7;
@@ -212,7 +271,8 @@ extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) {
     if (rpb * (a->lda > a->ldb ? a->lda : a->ldb) * 4 >= 0x7fffffffll) return FLEXNET_EUNSUPPORTED;
     slabs = a->k > 0 ? (a->k + rpb - 1) / rpb : 1;
     WgradK p;
-    p.a = a->a; p.b = a->b; p.c = a->c; p.ws = a->workspace;
+    p.a = a->a; p.b = a->b; p.c = a->c; p.ws = a->workspace + WG_CS_FLOATS;
+    p.cs = a->colsum ? a->workspace : nullptr; p.colsum = a->colsum;
     p.k = a->k; p.lda = a->lda; p.ldb = a->ldb;
     p.a_floats = a->k > 0 ? (a->k - 1) * a->lda + a->m : 0;
     p.b_floats = a->k > 0 ? (a->k - 1) * a->ldb + a->n : 0;

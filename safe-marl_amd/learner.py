@@ -492,6 +492,12 @@ class MADDPG(Model):
         count = 1 if self.args.shared_params else self.n_
         self.value_dicts = nn.ModuleList([MLPCritic(input_shape, 1, self.args) for _ in range(count)])
 
+    # replay fields each loss reads (get_loss below; MATD3 and SAFEMADDPG read the same ones): a graphed sub-update
+    # refreshes only these columns of its static batch
+    # (reward in both: unpack_data's batch-norm running statistics move on every get_loss call, model.py:308-323)
+    update_fields = {"policy": ("state", "reward", "last_hid"),
+                     "value": ("state", "action", "reward", "next_state", "done", "hid")}
+
     def construct_model(self):
         self.construct_value_net()
         self.construct_policy_net()

@@ -20,6 +20,15 @@ def _find_fused_gru():
 _FUSED_GRU = _find_fused_gru()
 
 
+def _gru_cell(x, hx, rnn):
+    """nn.GRUCell as ATen composes it on the GPU, for update batches: the biases ride the gate GEMMs (their gradients
+    are then column sums taken inside csrc/wgrad.hip's pass over the gate gradients) instead of entering the pointwise
+    cell, whose backward would reduce them with two more passes over [rows, 192]."""
+    gi = tall_linear(x, rnn.weight_ih, rnn.bias_ih)
+    gh = tall_linear(hx, rnn.weight_hh, rnn.bias_hh)
+    return _FUSED_GRU(gi, gh, hx, None, None)[0]
+
+
 def _activation(name):
     if name == "relu":
         return F.relu
@@ -58,7 +67,7 @@ class RNNAgent(nn.Module):
             # update batches (163 840 rows): the GRUCell as PyTorch composes it on the GPU — two gate GEMMs and the
             # fused pointwise cell — with the three weight gradients (W_ih, W_hh, fc2) from csrc/wgrad.hip
             r = self.rnn
-            h = _FUSED_GRU(tall_linear(x, r.weight_ih), tall_linear(hx, r.weight_hh), hx, r.bias_ih, r.bias_hh)[0]
+            h = _gru_cell(x, hx, r)
             return tall_linear(h, self.fc2.weight, self.fc2.bias), None, h
         h = self.rnn(x, hx)
         return self.fc2(h), None, h
@@ -77,7 +86,7 @@ class RNNAgent(nn.Module):
         x = _LnReluFn.apply(z, self.fc1.bias, W[:, o:].t() if agent_id else None, None if ln is None else ln.weight,
                             None if ln is None else ln.bias, 1e-5 if ln is None else ln.eps, n_agents)
         r, hx = self.rnn, hidden_state.reshape(-1, self.args.hid_size)
-        h = _FUSED_GRU(tall_linear(x, r.weight_ih), tall_linear(hx, r.weight_hh), hx, r.bias_ih, r.bias_hh)[0]
+        h = _gru_cell(x, hx, r)
         return tall_linear(h, self.fc2.weight, self.fc2.bias), None, h
 
 
@@ -198,7 +207,7 @@ def tall_wgrad_supported(dy, x):
                                       and x.stride(0) >= x.shape[1] and max(dy.stride(0), x.stride(0)) < (1 << 24))))
 
 
-def tall_wgrad(dy, x, out=None, accumulate=False):
+def tall_wgrad(dy, x, out=None, accumulate=False, colsum=None):
     """dW[m, n] = sum_k dy[k, m] * x[k, n] (csrc/wgrad.hip: include/flexnet.h flexnet_wgrad) — the weight gradient of
     y = x @ W.T over a tall batch.  Row-strided views (column slices of the packed replay rows) are read in place.
     The workspace is per device: calls are expected on one stream at a time (the update's)."""
@@ -219,6 +228,8 @@ def tall_wgrad(dy, x, out=None, accumulate=False):
     a.lda, a.ldb = (dy.stride(0), x.stride(0)) if k > 1 else (m, n)
     a.a, a.b, a.c = dy.data_ptr(), x.data_ptr(), out.data_ptr()
     a.workspace, a.workspace_floats, a.accumulate = ws.data_ptr(), ws.numel(), int(accumulate)
+    if colsum is not None:          # [m] <- sum_k dy[k, :], the bias gradient, from the same pass over dy
+        a.colsum = colsum.data_ptr()
     _lib.check(lib.flexnet_wgrad(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_wgrad")
     return out
 
@@ -236,11 +247,17 @@ class _TallLinear(th.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = tall_wgrad(dy, x) if tall_wgrad_supported(dy, x) else dy.t() @ x
+            if tall_wgrad_supported(dy, x):
+                if want_db:
+                    db = th.empty(dy.shape[1], dtype=th.float32, device=dy.device)
+                dw = tall_wgrad(dy, x, colsum=db)
+            else:
+                dw = dy.t() @ x
         if ctx.needs_input_grad[0]:
             dx = dy @ w
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_db and db is None:
             db = dy.sum(0)
         return dx, dw, db
 
@@ -410,11 +427,16 @@ class _CriticTailFn(th.autograd.Function):
         z1, ln_w, ln_b, w2, b2, w3, b3 = ctx.saved_tensors
         dq = dq.contiguous()
         dz1 = th.empty_like(z1)
+        args = _critic_args(z1, ln_w, ln_b, w2, b2, w3, b3, ctx.eps)
+        args.dq, args.dz1 = dq.data_ptr(), dz1.data_ptr()
+        if not any(ctx.needs_input_grad[1:7]):
+            # the policy loss differentiates through a critic whose parameters take no step: dz1 only
+            _lib.check(lib.flexnet_critic_tail_backward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                       "flexnet_critic_tail_backward")
+            return (dz1,) + (None,) * 7
         grads = th.zeros(64 * 64 + 64 * 4 + 1, dtype=th.float32, device=z1.device)      # one zero-fill for all six
         d_w2, d_b2, d_w3 = grads[:4096].view(64, 64), grads[4096:4160], grads[4160:4224].view(1, 64)
         d_g, d_b, d_b3 = grads[4224:4288], grads[4288:4352], grads[4352:4353]
-        args = _critic_args(z1, ln_w, ln_b, w2, b2, w3, b3, ctx.eps)
-        args.dq, args.dz1 = dq.data_ptr(), dz1.data_ptr()
         args.d_fc2_w, args.d_fc2_b, args.d_fc3_w, args.d_fc3_b = d_w2.data_ptr(), d_b2.data_ptr(), d_w3.data_ptr(), d_b3.data_ptr()
         if ln_w is not None:
             args.d_ln_w, args.d_ln_b = d_g.data_ptr(), d_b.data_ptr()

@@ -105,9 +105,10 @@ class PGTrainer(object):
         start = buf.sample_start(bs)
         p0 = (buf.head + start) % buf.size
         first = min(bs, buf.size - p0)
-        g["batch2d"][:first].copy_(buf.store2d[p0:p0 + first])
-        if first < bs:
-            g["batch2d"][first:].copy_(buf.store2d[:bs - first])
+        for c0, c1 in g["cols"]:                   # only the record columns this sub-update reads
+            g["batch2d"][:first, c0:c1].copy_(buf.store2d[p0:p0 + first, c0:c1])
+            if first < bs:
+                g["batch2d"][first:, c0:c1].copy_(buf.store2d[:bs - first, c0:c1])
         g["graph"].replay()
         stat.update(g["stat"])
         return True
@@ -149,7 +150,16 @@ class PGTrainer(object):
                         v.copy_(old) if old is not None else v.zero_()
         # `batch` stays referenced: its constant fields (action_avail, ...) were allocated eagerly and are baked into the
         # graph by address; released, the allocator would hand their memory to the next eager tensor
-        return dict(graph=graph, batch2d=batch2d, stat=out, bs=bs, buf=buf, batch=batch)
+        # columns to refresh per replay: the fields the model declares for this loss (all of them if it does not)
+        names = (getattr(self.behaviour_net, "update_fields", None) or {}).get(which)
+        spans = sorted(buf.packed_cols[k][:2] for k in (names or buf.packed_cols) if k in buf.packed_cols)
+        cols = []
+        for c0, c1 in spans:
+            if cols and cols[-1][1] == c0:
+                cols[-1] = (cols[-1][0], c1)
+            else:
+                cols.append((c0, c1))
+        return dict(graph=graph, batch2d=batch2d, stat=out, bs=bs, buf=buf, batch=batch, cols=cols)
 
     # kept for callers that hand over a batch themselves (trainer.py:81,99)
     def policy_transition_process(self, stat, trans):

@@ -100,3 +100,19 @@ def test_composed_first_layer_matches_the_materialised_one(b, n, ln):
     assert _rel(g1[1], g2[1]) < 1e-4           # a sum over b rows in two different orders
     for a, e in zip(g1[2:], g2[2:]):
         assert torch.equal(a, e)                # fixed-order reduction: bit-reproducible
+
+
+def test_backward_without_parameter_gradients():
+    """Frozen critic (the policy loss differentiates through it): the dz1-only kernel gives the same dz1."""
+    from safe_marl_amd.nets import CriticTail
+    c = _critic()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    z = torch.randn(20481, 64, device="cuda", generator=g)
+    w = torch.randn(20481, 1, device="cuda", generator=g)
+    z1 = z.clone().requires_grad_(True)
+    full = torch.autograd.grad((CriticTail.apply(z1, c) * w).sum(), [z1] + [p for n, p in c.named_parameters() if not n.startswith("fc1")])[0]
+    for p in c.parameters():
+        p.requires_grad_(False)
+    z2 = z.clone().requires_grad_(True)
+    only = torch.autograd.grad((CriticTail.apply(z2, c) * w).sum(), [z2])[0]
+    assert torch.equal(full, only)
