@@ -85,7 +85,7 @@ class PGTrainer(object):
     # ---- a sub-update as one HIP graph -----------------------------------------------------------------------
     def _graphed_sub_update(self, which, stat):
         """A sub-update is ~120 kernel launches that take the host longer to issue (1.6 ms) than the GPU to run; with
-        the replay ring in its packed layout the sampled window is copied into a static batch (one copy) and the whole
+        the replay ring in its packed layout the sampled window is copied into a static batch (one copy per field read) and the whole
         step — losses, backward, gradient clip, RMSprop — is replayed as one HIP graph.  Returns False when this
         configuration does not qualify (the caller then runs the eager step)."""
         buf = self.replay_buffer
@@ -105,10 +105,12 @@ class PGTrainer(object):
         start = buf.sample_start(bs)
         p0 = (buf.head + start) % buf.size
         first = min(bs, buf.size - p0)
-        for c0, c1 in g["cols"]:                   # only the record columns this sub-update reads
-            g["batch2d"][:first, c0:c1].copy_(buf.store2d[p0:p0 + first, c0:c1])
+        for k, dst in g["static"].items():         # only the record columns this sub-update reads
+            c0, c1 = buf.packed_cols[k][:2]
+            flat = dst.view(bs, c1 - c0)
+            flat[:first].copy_(buf.store2d[p0:p0 + first, c0:c1])
             if first < bs:
-                g["batch2d"][first:, c0:c1].copy_(buf.store2d[:bs - first, c0:c1])
+                flat[first:].copy_(buf.store2d[:bs - first, c0:c1])
         g["graph"].replay()
         stat.update(g["stat"])
         return True
@@ -116,9 +118,18 @@ class PGTrainer(object):
     def _capture_sub_update(self, which, bs):
         from .replay_buffer import Transition
         buf = self.replay_buffer
+        # static batch: the fields this loss reads as CONTIGUOUS tensors of their own (the per-replay refresh
+        # de-interleaves the packed rows, so no reshape of a field costs a copy inside the graph); the others, never
+        # read, as views of one spare packed row block
+        names = (getattr(self.behaviour_net, "update_fields", None) or {}).get(which) or tuple(buf.packed_cols)
         batch2d = th.zeros(bs, buf.store2d.shape[1], dtype=th.float32, device=self.device)
-        batch2d.copy_(buf.store2d[:bs] if buf.length >= bs else buf.store2d[:bs].clone())
         fields = buf.record_views(batch2d)
+        static = {}
+        for k in names:
+            c0, c1, shape = buf.packed_cols[k]
+            static[k] = th.zeros((bs,) + tuple(shape), dtype=th.float32, device=self.device)
+            static[k].view(bs, c1 - c0).copy_(buf.store2d[:bs, c0:c1])
+            fields[k] = static[k]
         for k, c in buf.consts.items():
             shape = buf.const_shapes.get(k, ())
             fields[k] = th.full((1,) + tuple(1 for _ in shape), float(c), device=self.device).expand((bs,) + tuple(shape))
@@ -150,16 +161,7 @@ class PGTrainer(object):
                         v.copy_(old) if old is not None else v.zero_()
         # `batch` stays referenced: its constant fields (action_avail, ...) were allocated eagerly and are baked into the
         # graph by address; released, the allocator would hand their memory to the next eager tensor
-        # columns to refresh per replay: the fields the model declares for this loss (all of them if it does not)
-        names = (getattr(self.behaviour_net, "update_fields", None) or {}).get(which)
-        spans = sorted(buf.packed_cols[k][:2] for k in (names or buf.packed_cols) if k in buf.packed_cols)
-        cols = []
-        for c0, c1 in spans:
-            if cols and cols[-1][1] == c0:
-                cols[-1] = (cols[-1][0], c1)
-            else:
-                cols.append((c0, c1))
-        return dict(graph=graph, batch2d=batch2d, stat=out, bs=bs, buf=buf, batch=batch, cols=cols)
+        return dict(graph=graph, static=static, stat=out, bs=bs, buf=buf, batch=batch)
 
     # kept for callers that hand over a batch themselves (trainer.py:81,99)
     def policy_transition_process(self, stat, trans):
