@@ -72,7 +72,7 @@ typedef struct {
     int32_t rows;              /* b * n_agents */
     int32_t layernorm;         /* args.layernorm (mlp_critic.py:12-13,27-28) */
     float ln_eps;
-    int32_t pad0;
+    int32_t variant;           /* 0: matrix-core kernels for the forward and the dz1-only backward; 1: the VALU kernels */
     const float* z1;           /* [rows, 64]  fc1 output; or NULL: z1[r] = z_shared[r / n_agents] + z_id[r % n_agents] */
     const float* ln_w;         /* [64] */
     const float* ln_b;         /* [64] */

@@ -78,8 +78,8 @@ class RNNAgent(nn.Module):
         configuration is outside what csrc/lnrelu.hip covers (the caller concatenates the ids and calls forward)."""
         o = obs.shape[1]
         W = self.fc1.weight
-        if not (lnrelu_supported(self, obs.new_empty(0, 64), n_agents) and W.shape[1] == o + (n_agents if agent_id else 0)
-                and _FUSED_GRU is not None and obs.shape[0] % n_agents == 0):
+        if not (obs.is_cuda and obs.dtype == th.float32 and lnrelu_supported(self, n_agents) and _FUSED_GRU is not None
+                and W.shape[1] == o + (n_agents if agent_id else 0) and obs.shape[0] % n_agents == 0):
             return None
         z = wide_batch_linear(obs, W[:, :o]) if not obs.requires_grad else tall_linear(obs, W[:, :o])
         ln = self.layernorm if self.args.layernorm else None
@@ -331,10 +331,11 @@ class _LnReluFn(th.autograd.Function):
                 None if ln_w is None else small[0], None if ln_w is None else small[1], None, None)
 
 
-def lnrelu_supported(agent, z, n_agents):
+def lnrelu_supported(agent, n_agents):
+    """Configurations csrc/lnrelu.hip covers: 64 hidden units, ReLU, at most FLEXNET_MAX_AGENTS id columns."""
     a = agent.args
-    return (z.is_cuda and z.dtype == th.float32 and z.dim() == 2 and z.shape[1] == 64 and a.hid_size == 64
-            and a.hid_activation == "relu" and 1 <= n_agents <= 8 and getattr(agent, "fused_epilogue", True))
+    return (a.hid_size == 64 and a.hid_activation == "relu" and 1 <= n_agents <= 8
+            and getattr(agent, "fused_epilogue", True))
 
 
 class _WideBatchLinear(th.autograd.Function):
@@ -378,10 +379,13 @@ def critic_tail_supported(critic, x):
             and a.hid_activation == "relu" and critic.fc3.out_features == 1 and getattr(critic, "fused_tail", True))
 
 
+CRITIC_VARIANT = 0              # 0: matrix-core forward / dz1-only backward (csrc/critic.hip); 1: the VALU kernels
+
+
 def _critic_args(z1, ln_w, ln_b, w2, b2, w3, b3, eps):
     from . import _lib
     a = _lib.FlexCriticTailArgs()
-    a.rows, a.layernorm, a.ln_eps = z1.shape[0], int(ln_w is not None), float(eps)
+    a.rows, a.layernorm, a.ln_eps, a.variant = z1.shape[0], int(ln_w is not None), float(eps), CRITIC_VARIANT
     a.z1 = z1.data_ptr()
     if ln_w is not None:
         a.ln_w, a.ln_b = ln_w.data_ptr(), ln_b.data_ptr()

@@ -115,4 +115,31 @@ def test_backward_without_parameter_gradients():
         p.requires_grad_(False)
     z2 = z.clone().requires_grad_(True)
     only = torch.autograd.grad((CriticTail.apply(z2, c) * w).sum(), [z2])[0]
-    assert torch.equal(full, only)
+    assert _rel(only, full) < 2e-5               # matrix-core dz1-only kernel vs the VALU kernel with parameter gradients
+
+
+@pytest.mark.parametrize("rows,ln,composed", [(163840, True, False), (163840, True, True), (65536 + 37, False, False),
+                                              (65540, True, True), (4099, True, False)])
+def test_matrix_core_and_valu_kernels_agree(rows, ln, composed):
+    """variant 0 (v_mfma_f32_32x32x2_f32, exact fp32 products) against variant 1 (VALU): forward q and the dz1-only
+    backward, stored and composed first-layer input."""
+    from safe_marl_amd import nets
+    c = _critic(layernorm=ln)
+    for p in c.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    n = 5 if composed else 1
+    shared = torch.randn(rows // n if composed else rows, 64, device="cuda", generator=g)
+    ids = torch.randn(n, 64, device="cuda", generator=g)
+    w = torch.randn(shared.shape[0] * n if composed else rows, 1, device="cuda", generator=g)
+    res = []
+    for variant in (0, 1):
+        nets.CRITIC_VARIANT = variant
+        try:
+            x = shared.clone().requires_grad_(True)
+            q = nets.CriticTail.apply_composed(x, ids, c) if composed else nets.CriticTail.apply(x, c)
+            res.append((q, torch.autograd.grad((q * w).sum(), [x])[0]))
+        finally:
+            nets.CRITIC_VARIANT = 0
+    assert _rel(res[0][0], res[1][0]) < 2e-6
+    assert _rel(res[0][1], res[1][1]) < 2e-5

@@ -40,3 +40,44 @@ for rows in (20480, 163840):
         out.append((timed(fwd), timed(fwdbwd)))
     print(f"{rows:7d} rows: forward fused {out[0][0]:6.1f} us / module {out[1][0]:6.1f} us;  forward+backward fused "
           f"{out[0][1]:6.1f} us / autograd {out[1][1]:6.1f} us")
+
+# matrix-core (variant 0) vs VALU (variant 1) kernels: forward and the dz1-only backward, HIP-graph replays
+from safe_marl_amd import nets
+for p in c.parameters():
+    p.requires_grad_(False)
+c.fused_tail = True
+
+
+def graph_timed(fn, reps=20):
+    for _ in range(3):
+        fn()
+    g = torch.cuda.CUDAGraph(); s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        fn()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(reps):
+                fn()
+    import time
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(10):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / (10 * reps) * 1e6
+
+
+for rows in (20480, 163840):
+    z = torch.randn(rows, 64, device="cuda", requires_grad=True)
+    w = torch.randn(rows, 1, device="cuda")
+    for variant in (0, 1):
+        nets.CRITIC_VARIANT = variant
+
+        def fwd():
+            with torch.no_grad():
+                nets.CriticTail.apply(z, c)
+
+        def both():
+            torch.autograd.grad((nets.CriticTail.apply(z, c) * w).sum(), [z])
+
+        tf, tb = graph_timed(fwd), graph_timed(both)
+        print(f"{rows:7d} rows, variant {variant}: forward {tf:6.1f} us, forward + dz1-only backward {tb:6.1f} us")
+    nets.CRITIC_VARIANT = 0
