@@ -472,7 +472,7 @@ static int critic_mfma_grid(int rows) {
         cus = n;
     }
     const int tiles = (rows + 31) / 32;
-    return tiles < 2 * cus ? tiles : 2 * cus;            // tiles spread over blocks first, then over a block's wavefronts
+    return tiles < cus ? tiles : cus;                    // one block per CU (it stages W2 once); tiles spread over blocks first
 }
 
 static int critic_check(const FlexCriticTailArgs* a, bool backward) {
