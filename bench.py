@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--warm-start", type=int, default=1)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a one-GPU box together with FLEX_BENCH_ONE_DEVICE=1)")
+    ap.add_argument("--pf-tol", type=float, default=1e-12, help="power-flow convergence threshold (inf-norm power "
+                    "mismatch, pu); 1e-12 is the headline setting, the parity bar is 1e-6 on voltages and rewards")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--solver", choices=["sweep", "newton"], default="sweep",
                     help="sweep: backward/forward sweeps + Newton verification; newton: NR with tree elimination")
@@ -129,7 +131,7 @@ def main():
     net = create_network()
     series = make_synthetic_series(net)                      # 1096 days x 96 rows x 72 cols fp64 (60.6 MB)
     env = VecFlexProvisionEnv({}, a.envs, device=f"cuda:{local_rank}", net=net, series=series,
-                              seed=1234 + 1000 * rank, warm_start=bool(a.warm_start),
+                              seed=1234 + 1000 * rank, warm_start=bool(a.warm_start), pf_tol=a.pf_tol,
                               solver={"sweep": 2, "newton": 0}[a.solver])
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)
@@ -237,7 +239,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic (stand-in IEEE-33 Baran-Wu network, SURVEY.md App. C; generated series, SURVEY.md §8d)",
             "config": {
-                "workload": "flex_provision.step()+get_obs() batched, 4096 envs/GPU, 33-bus AC power flow (fp64 NR, tol 1e-12), "
+                "workload": "flex_provision.step()+get_obs() batched, 4096 envs/GPU, 33-bus AC power flow (fp64 NR, tol %g), " % a.pf_tol +
                             "5 agents, in-launch auto-reset",
                 "envs_per_gpu": a.envs, "n_agents": env.n_agents, "n_bus": env.n_bus,
                 "warm_start": bool(a.warm_start), "launches_per_step": 1, "hip_graph": graph is not None,
