@@ -155,6 +155,25 @@ typedef struct {
 int flexnet_lnrelu_forward(const FlexLnReluArgs* args, void* stream);
 int flexnet_lnrelu_backward(const FlexLnReluArgs* args, void* stream);
 
+/* clip_grad_norm_(params, max_norm) followed by torch.optim.RMSprop.step() (alpha, eps; no momentum, not centred, no
+ * weight decay — madrl/utils/trainer.py:34-35,86-90,103-107) for all tensors of one network in one launch. */
+#define FLEXNET_OPT_MAX_TENSORS 16
+#define FLEXNET_OPT_MAX_ELEMENTS (1 << 20)
+typedef struct {
+    int32_t n_tensors;         /* <= FLEXNET_OPT_MAX_TENSORS; tensors whose gradient is None are simply not listed */
+    float lr, alpha, eps;
+    float max_norm;            /* <= 0: no clipping */
+    int32_t pad0;
+    float* total_norm;         /* out [1]: the pre-clip 2-norm over all listed gradients, or NULL */
+    int64_t numel[FLEXNET_OPT_MAX_TENSORS];
+    float* param[FLEXNET_OPT_MAX_TENSORS];
+    float* grad[FLEXNET_OPT_MAX_TENSORS];        /* scaled in place by the clip factor, as clip_grad_norm_ does */
+    float* square_avg[FLEXNET_OPT_MAX_TENSORS];  /* RMSprop state */
+    float* step[FLEXNET_OPT_MAX_TENSORS];        /* RMSprop's per-tensor step counter (fp32 scalar, += 1) or NULL */
+} FlexClipRmspropArgs;
+
+int flexnet_clip_rmsprop(const FlexClipRmspropArgs* args, void* stream);
+
 /* One vector step's bookkeeping of the rollout (madrl/models/model.py:230-262 per environment, utils/replay_buffer.py:
  * 23-27): the transition record [state | action | reward | next_state | done | last_step | last_hid | hid] lands in a
  * packed staging row per environment (the replay ring takes it with one copy), the observation and the hidden state are

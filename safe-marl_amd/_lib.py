@@ -59,7 +59,7 @@ SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
-    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward",
+    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop",
 )
 
 class FlexActorArgs(C.Structure):
@@ -99,6 +99,18 @@ class FlexLnReluArgs(C.Structure):
 
 
 FLEXNET_LNRELU_WS_FLOATS = 1024 * 704
+
+
+FLEXNET_OPT_MAX_TENSORS = 16
+FLEXNET_OPT_MAX_ELEMENTS = 1 << 20
+
+
+class FlexClipRmspropArgs(C.Structure):
+    _fields_ = [("n_tensors", C.c_int32), ("lr", C.c_float), ("alpha", C.c_float), ("eps", C.c_float),
+                ("max_norm", C.c_float), ("pad0", C.c_int32), ("total_norm", C.c_void_p),
+                ("numel", C.c_int64 * FLEXNET_OPT_MAX_TENSORS), ("param", C.c_void_p * FLEXNET_OPT_MAX_TENSORS),
+                ("grad", C.c_void_p * FLEXNET_OPT_MAX_TENSORS), ("square_avg", C.c_void_p * FLEXNET_OPT_MAX_TENSORS),
+                ("step", C.c_void_p * FLEXNET_OPT_MAX_TENSORS)]
 
 
 class FlexRolloutPackArgs(C.Structure):
@@ -149,6 +161,8 @@ def load():
     lib.flexnet_rollout_pack.restype = C.c_int
     lib.flexnet_wgrad.argtypes = [C.POINTER(FlexWgradArgs), vp]
     lib.flexnet_wgrad.restype = C.c_int
+    lib.flexnet_clip_rmsprop.argtypes = [C.POINTER(FlexClipRmspropArgs), vp]
+    lib.flexnet_clip_rmsprop.restype = C.c_int
     for fn in (lib.flexnet_lnrelu_forward, lib.flexnet_lnrelu_backward):
         fn.argtypes = [C.POINTER(FlexLnReluArgs), vp]
         fn.restype = C.c_int

@@ -20,8 +20,9 @@ import torch as th
 from torch.optim import RMSprop
 
 from . import dist as fdist
+from .optim import clip_and_step
 from .replay_buffer import TransReplayBuffer
-from .util import get_grad_norm, normal_entropy
+from .util import normal_entropy
 
 train_logger = logging.getLogger("TrainLogger")
 
@@ -211,8 +212,8 @@ class PGTrainer(object):
             p.grad = g
         if self.world > 1:
             fdist.allreduce_grads(params)
-        grad_norm = get_grad_norm(self.args, params)          # after the all-reduce
-        opt.step()
+        # clip_grad_norm_ + RMSprop step (trainer.py:86-90,103-107), after the all-reduce; one HIP launch on the GPU
+        grad_norm = clip_and_step(opt, params, self.args.grad_clip_eps)
         stat[f"mean_train_{which}_grad_norm"] = grad_norm.detach()
         stat[f"mean_train_{which}_loss"] = loss.detach()
 
