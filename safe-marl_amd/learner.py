@@ -54,6 +54,8 @@ class RolloutGraph:
         self.fail_sum = th.zeros((), dtype=th.float64, device=dev)
         self.std = float(model.args.fixed_policy_std)
         self.graph = None
+        self.plain = type(model).get_actions is MADDPG.get_actions and bool(model.args.action_enforcebound)
+        self.avail = th.ones(N, n, a, device=dev)             # every action is available (env:721-730)
         # plain MADDPG on the GPU: policy + exploration in one HIP launch, packing + hand-over + statistics in another
         self.safe = type(model).__name__ == "SAFEMADDPG"       # + the safety projection between policy and env
         self.fast = (type(model).__name__ in ("MADDPG", "SAFEMADDPG") and model.fused_inference
@@ -102,11 +104,18 @@ class RolloutGraph:
                     self._pack(action, hid)
                     return
         with th.no_grad():
-            means, _, hid = m.policy(self.obs, last_hid=self.hid)
-            action = th.tanh(means + self.std * th.randn_like(means))          # util.py:57-64
+            if self.plain:
+                means, _, hid = m.policy(self.obs, last_hid=self.hid)
+                action = action_pol = th.tanh(means + self.std * th.randn_like(means))          # util.py:57-64
+            else:
+                # MATD3 / IDDPG (agent-summed action selection, matd3.py:88-111, iddpg.py:66-71): their own get_actions,
+                # exactly as the eager loop calls it; the replay keeps the restore-masked action (model.py:232)
+                action, action_pol, _, _, hid = m.get_actions(self.obs, status="train", exploration=True,
+                                                              actions_avail=self.avail, target=False, last_hid=self.hid)
+                action_pol = action_pol.expand(N, m.n_, m.act_dim)
             env.step(m.env_action(action), fuse_obs=True, auto_reset=True)
             donef = env.done.float()
-            f["state"].copy_(self.obs); f["action"].copy_(action); f["next_state"].copy_(env.obs)
+            f["state"].copy_(self.obs); f["action"].copy_(action_pol); f["next_state"].copy_(env.obs)
             f["reward"].copy_(env.reward.float().unsqueeze(1).expand(N, m.n_))
             f["done"].copy_(donef); f["last_step"].copy_(donef)
             f["last_hid"].copy_(self.hid); f["hid"].copy_(hid)
@@ -364,13 +373,13 @@ class Model(nn.Module):
         stat["mean_train_solver_failed"] = float(vals[-1])
 
     def _use_rollout_graph(self, trainer):
-        """HIP-graph rollout: plain DDPG-style exploration, with or without SAFEMADDPG's safety projection (MATD3's and
-        IDDPG's action quirk go through get_actions), CUDA device, and not switched off by the trainer."""
+        """HIP-graph rollout: CUDA device, not switched off by the trainer.  MADDPG and SAFEMADDPG take the fused two-kernel
+        body, MATD3 and IDDPG the general body around their own get_actions; if capture fails the eager loop runs."""
         if not getattr(trainer, "graph_rollout", True) or self.device.type != "cuda":
             return False
-        plain = type(self).get_actions is MADDPG.get_actions
-        safe = type(self).__name__ == "SAFEMADDPG" and type(self).get_actions is SAFEMADDPG.get_actions
-        return (plain or safe) and bool(self.args.action_enforcebound)
+        if type(self).__name__ == "SAFEMADDPG":          # the graph body knows the reference's safety-layer order only
+            return type(self).get_actions is SAFEMADDPG.get_actions and bool(self.args.action_enforcebound)
+        return True                                      # MADDPG: fused path; MATD3 / IDDPG / others: their get_actions
 
     def _train_process_graph(self, stat, trainer, horizon):
         env, buf = trainer.env, trainer.replay_buffer

@@ -137,3 +137,60 @@ def test_safemaddpg_fused_step_applies_the_safety_layer():
         obs = envs[1].obs.clone()
         hid = new_hid * (1.0 - envs[1].done.float()).view(N, 1, 1)
     assert hits > 0                                                           # the layer really acted in this test
+
+
+@pytest.mark.parametrize("alg", ["matd3", "iddpg"])
+def test_general_graph_body_follows_get_actions(alg):
+    """MATD3 / IDDPG in the graph rollout: the body calls their own get_actions (agent-summed action selection,
+    matd3.py:88-111, iddpg.py:66-71) exactly as the eager vector loop does; record, hand-over and statistics against
+    that loop spelled out here, then a captured replay."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd import learner
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.replay_buffer import TransReplayBuffer
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.util import convert
+    net = create_network()
+    series = make_synthetic_series(net, n_days=30)
+    a = dict(DEFAULT_ALG_ARGS)
+    a.update(alg=alg, agent_num=5, obs_size=144, state_size=110, action_dim=4)
+    cls = {"matd3": learner.MATD3, "iddpg": learner.IDDPG}[alg]
+    N = 40
+    envs = [VecFlexProvisionEnv({}, N, net=net, series=series, seed=4, warm_start=True) for _ in range(2)]
+    torch.manual_seed(8)
+    m = cls(convert(a)).cuda()
+    with torch.no_grad():
+        for p in m.policy_dicts.parameters():
+            p.mul_(10.0)
+    rg = learner.RolloutGraph(m, envs[0], TransReplayBuffer(N * 8, device="cuda"))
+    assert not rg.fast and not rg.plain
+    rg.start_episode(envs[0].reset())
+    obs = envs[1].reset().clone()
+    hid = torch.zeros(N, 5, 64, device="cuda")
+    avail = torch.ones(N, 5, 4, device="cuda")
+    for step in range(3):
+        torch.manual_seed(500 + step)
+        rg.body()
+        torch.manual_seed(500 + step)
+        with torch.no_grad():
+            action, action_pol, _, _, new_hid = m.get_actions(obs, status="train", exploration=True, actions_avail=avail,
+                                                              target=False, last_hid=hid)
+            envs[1].step(m.env_action(action), fuse_obs=True, auto_reset=True)
+        torch.cuda.synchronize()
+        assert torch.equal(rg.f["state"], obs)
+        assert torch.equal(rg.f["action"], action_pol.expand(N, 5, 4))
+        assert torch.equal(rg.f["hid"], new_hid) and torch.equal(rg.f["last_hid"], hid)
+        assert torch.equal(envs[0].reward, envs[1].reward)
+        assert torch.equal(rg.f["next_state"], envs[1].obs)
+        obs = envs[1].obs.clone()
+        hid = new_hid * (1.0 - envs[1].done.float()).view(N, 1, 1)
+        assert torch.equal(rg.obs, obs) and torch.equal(rg.hid, hid)
+    rg.capture()
+    rg.start_episode(envs[0].reset())
+    before = rg.obs.clone()
+    for _ in range(3):
+        rg.graph.replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(before, rg.obs) and torch.isfinite(rg.rec).all()
