@@ -114,10 +114,10 @@ typedef struct {
     int64_t workspace_floats;  /* >= FLEXNET_WGRAD_WS_FLOATS */
     int32_t m, n;
     int32_t accumulate;        /* 1: C += result */
-    int32_t pad0;
+    int32_t ldc;               /* row pitch of C in floats; 0 = n (dense).  A column block of a wider weight gradient works */
     const float* a;            /* [k, m] */
     const float* b;            /* [k, n] */
-    float* c;                  /* out [m, n], dense */
+    float* c;                  /* out [m, n] */
     float* workspace;
     float* colsum;             /* out [m] = sum_k A[k, m] (the layer's bias gradient), or NULL */
 } FlexWgradArgs;
@@ -156,15 +156,17 @@ int flexnet_lnrelu_forward(const FlexLnReluArgs* args, void* stream);
 int flexnet_lnrelu_backward(const FlexLnReluArgs* args, void* stream);
 
 /* clip_grad_norm_(params, max_norm) followed by torch.optim.RMSprop.step() (alpha, eps; no momentum, not centred, no
- * weight decay — madrl/utils/trainer.py:34-35,86-90,103-107) for all tensors of one network in one launch. */
+ * weight decay — madrl/utils/trainer.py:34-35,86-90,103-107) for all tensors of one network in two small launches. */
 #define FLEXNET_OPT_MAX_TENSORS 16
 #define FLEXNET_OPT_MAX_ELEMENTS (1 << 20)
+#define FLEXNET_OPT_WS_FLOATS 64
 typedef struct {
     int32_t n_tensors;         /* <= FLEXNET_OPT_MAX_TENSORS; tensors whose gradient is None are simply not listed */
     float lr, alpha, eps;
     float max_norm;            /* <= 0: no clipping */
     int32_t pad0;
     float* total_norm;         /* out [1]: the pre-clip 2-norm over all listed gradients, or NULL */
+    float* workspace;          /* FLEXNET_OPT_WS_FLOATS floats of scratch */
     int64_t numel[FLEXNET_OPT_MAX_TENSORS];
     float* param[FLEXNET_OPT_MAX_TENSORS];
     float* grad[FLEXNET_OPT_MAX_TENSORS];        /* scaled in place by the clip factor, as clip_grad_norm_ does */

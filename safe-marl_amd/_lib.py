@@ -84,7 +84,7 @@ FLEXNET_CRITIC_WS_FLOATS = 1024 * 4416
 
 class FlexWgradArgs(C.Structure):
     _fields_ = [("k", C.c_int64), ("lda", C.c_int64), ("ldb", C.c_int64), ("workspace_floats", C.c_int64),
-                ("m", C.c_int32), ("n", C.c_int32), ("accumulate", C.c_int32), ("pad0", C.c_int32),
+                ("m", C.c_int32), ("n", C.c_int32), ("accumulate", C.c_int32), ("ldc", C.c_int32),
                 ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("workspace", C.c_void_p),
                 ("colsum", C.c_void_p)]
 
@@ -107,7 +107,7 @@ FLEXNET_OPT_MAX_ELEMENTS = 1 << 20
 
 class FlexClipRmspropArgs(C.Structure):
     _fields_ = [("n_tensors", C.c_int32), ("lr", C.c_float), ("alpha", C.c_float), ("eps", C.c_float),
-                ("max_norm", C.c_float), ("pad0", C.c_int32), ("total_norm", C.c_void_p),
+                ("max_norm", C.c_float), ("pad0", C.c_int32), ("total_norm", C.c_void_p), ("workspace", C.c_void_p),
                 ("numel", C.c_int64 * FLEXNET_OPT_MAX_TENSORS), ("param", C.c_void_p * FLEXNET_OPT_MAX_TENSORS),
                 ("grad", C.c_void_p * FLEXNET_OPT_MAX_TENSORS), ("square_avg", C.c_void_p * FLEXNET_OPT_MAX_TENSORS),
                 ("step", C.c_void_p * FLEXNET_OPT_MAX_TENSORS)]

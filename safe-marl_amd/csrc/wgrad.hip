@@ -35,7 +35,7 @@ struct WgradK {
     float* cs;                       // column-sum partials [slabs][32 MT], or NULL
     float* colsum;
     int64_t k, lda, ldb, a_floats, b_floats;
-    int32_t m, n, rows_per_block, slabs, accumulate, pad;
+    int32_t m, n, rows_per_block, slabs, accumulate, ldc;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const float* base, int64_t floats) {
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * WG_RED) void wgrad_reduce_kernel(WgradK p) {
     const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
     const int m = MT * i + ti, n = blockIdx.y * (32 * NT) + NT * j + tj;
     if (m < p.m && n < p.n) {
-        float* dst = p.c + (int64_t)m * p.n + n;
+        float* dst = p.c + (int64_t)m * p.ldc + n;
         *dst = p.accumulate ? *dst + sum : sum;
     }
 }
@@ -250,7 +250,7 @@ static int wgrad_launch(WgradK p, int chunks, hipStream_t s) {
 
 extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) {
     if (!a || !a->a || !a->b || !a->c || !a->workspace || a->k < 0 || a->m < 1 || a->n < 1) return FLEXNET_EINVAL;
-    if (a->lda < a->m || a->ldb < a->n) return FLEXNET_EINVAL;
+    if (a->lda < a->m || a->ldb < a->n || (a->ldc != 0 && a->ldc < a->n)) return FLEXNET_EINVAL;
     if (a->m > 192 || a->lda >= (1 << 24) || a->ldb >= (1 << 24)) return FLEXNET_EUNSUPPORTED;
     const int mt = a->m <= 32 ? 1 : a->m <= 64 ? 2 : 6;
     const int nt = a->n <= 32 ? 1 : a->n <= 64 ? 2 : (mt == 6 ? 2 : 5);
@@ -276,7 +276,8 @@ extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) {
     p.k = a->k; p.lda = a->lda; p.ldb = a->ldb;
     p.a_floats = a->k > 0 ? (a->k - 1) * a->lda + a->m : 0;
     p.b_floats = a->k > 0 ? (a->k - 1) * a->ldb + a->n : 0;
-    p.m = a->m; p.n = a->n; p.rows_per_block = (int)rpb; p.slabs = (int)slabs; p.accumulate = a->accumulate; p.pad = 0;
+    p.m = a->m; p.n = a->n; p.rows_per_block = (int)rpb; p.slabs = (int)slabs; p.accumulate = a->accumulate;
+    p.ldc = a->ldc > 0 ? a->ldc : a->n;
     hipStream_t s = (hipStream_t)stream;
     switch (mt * 10 + nt) {
         case 11: return wgrad_launch<1, 1>(p, chunks, s);

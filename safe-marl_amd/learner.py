@@ -19,8 +19,8 @@ import numpy as np
 import torch as th
 import torch.nn as nn
 
-from .nets import (WGRAD_MIN_ROWS, CriticTail, MLPAgent, MLPCritic, RNNAgent, critic_tail_supported, fused_actor_forward,
-                   wide_batch_linear)
+from .nets import (WGRAD_MIN_ROWS, CriticTail, MLPAgent, MLPCritic, RNNAgent, critic_replayed_supported,
+                   critic_tail_supported, fused_actor_forward, wide_batch_linear)
 from .replay_buffer import Transition
 from .util import prep_obs, scale_action, select_action, translate_action
 
@@ -532,6 +532,11 @@ class MADDPG(Model):
                 off += n
             W_act = W[:, off:off + n * a]
             act_cols = act_det.reshape(b, n * a)
+            obs_cols = obs.reshape(b, n * o)
+            if (not act.requires_grad and self.args.agent_id and th.is_grad_enabled() and W.requires_grad
+                    and critic_replayed_supported(net, obs_cols, act_cols, n)):
+                # value loss on replayed actions: the whole critic as one autograd node (nets._CriticReplayedFn)
+                return CriticTail.apply_replayed(obs_cols, act_cols, n, net).view(b, n, 1)
             shared = wide_batch_linear(obs.reshape(b, n * o), W_obs) + wide_batch_linear(act_cols, W_act) + bias   # [b, hid]
             if not act.requires_grad and self.args.agent_id and critic_tail_supported(net, shared):
                 # replayed actions (value loss, bootstrap target): every row is shared[b] + the agent's id column; the

