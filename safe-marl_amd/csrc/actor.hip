@@ -19,6 +19,17 @@
 #include <stdio.h>
 #include "flexnet.h"
 
+// diagnostic build (-DACTOR_STAMPS): s_memtime at the phase boundaries of block 0's first wavefront (tools: scratch only)
+#ifdef ACTOR_STAMPS
+__device__ unsigned long long actor_stamps[8];
+#define ASTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) actor_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int flexnet_debug_actor_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(actor_stamps), sizeof(actor_stamps)) == hipSuccess ? 0 : -2;
+}
+#else
+#define ASTAMP(k) do { } while (0)
+#endif
+
 #define HID FLEXNET_HID
 #ifndef RT
 #define RT 4                       // rows per wavefront tile (multiple of 4)
@@ -229,20 +240,52 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActorArgs a) {
     __shared__ ActorLdsM s;
+    ASTAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rb = lane & 31, hf = lane >> 5;
     const int od = a.obs_dim, na = a.n_agents, ad = a.act_dim;
     const int ld1 = od + (a.agent_id ? na : 0);
-#pragma unroll 6
-    for (int idx = tid; idx < HID * od; idx += 64 * MW) {
-        const int j = idx / od, i = idx - j * od;
-        s.w1t[i * P1 + j] = a.fc1_w[(int64_t)j * ld1 + i];
-    }
-#pragma unroll 8
-    for (int idx = tid; idx < 3 * HID * HID; idx += 64 * MW) {
-        const int gj = idx / HID, i = idx - gj * HID;
-        s.wih[i * PG + gj] = a.w_ih[idx];
-        s.whh[i * PG + gj] = a.w_hh[idx];
+    // Weights -> LDS (transposed).  All global reads of a thread are issued before the first LDS write — 12 + up to 5
+    // 16-byte loads in one round trip instead of ~66 scalar loads in rounds of 6-8: the staging was a third of a
+    // rollout-sized call (20 480 rows: 37 -> 2x us).  fc1's rows (pitch ld1 floats, any dword alignment) go through a
+    // buffer descriptor, whose 16-byte loads need dword alignment only and return 0 past the end.
+    {
+        constexpr int NG = 3 * HID * HID / 4 / (64 * MW);                 // 6 float4 per thread and matrix
+        static_assert(NG * 4 * 64 * MW == 3 * HID * HID, "gate matrices split evenly");
+        float4 vi[NG], vh[NG];
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            vi[t] = reinterpret_cast<const float4*>(a.w_ih)[tid + 64 * MW * t];
+            vh[t] = reinterpret_cast<const float4*>(a.w_hh)[tid + 64 * MW * t];
+        }
+        constexpr int NF = (HID * FLEXNET_MAX_OBS / 4 + 64 * MW - 1) / (64 * MW);   // 5
+        const int q4 = (od + 3) >> 2;                                      // float4 groups per fc1 row (the last may be ragged)
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.fc1_w), 0, HID * ld1 * 4, 0x00027000);
+        typedef float v4f_ __attribute__((ext_vector_type(4)));
+        v4f_ vf[NF];
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            const int g = tid + 64 * MW * t, j = g / q4, i4 = g - j * q4;
+            vf[t] = __builtin_bit_cast(v4f_, __builtin_amdgcn_raw_buffer_load_b128(r1, j < HID ? (j * ld1 + 4 * i4) * 4 : -1, 0, 0));
+        }
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            const int idx = 4 * (tid + 64 * MW * t), gj = idx / HID, i = idx - gj * HID;
+            s.wih[i * PG + gj] = vi[t].x; s.wih[(i + 1) * PG + gj] = vi[t].y;
+            s.wih[(i + 2) * PG + gj] = vi[t].z; s.wih[(i + 3) * PG + gj] = vi[t].w;
+            s.whh[i * PG + gj] = vh[t].x; s.whh[(i + 1) * PG + gj] = vh[t].y;
+            s.whh[(i + 2) * PG + gj] = vh[t].z; s.whh[(i + 3) * PG + gj] = vh[t].w;
+        }
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            const int g = tid + 64 * MW * t, j = g / q4, i = 4 * (g - j * q4);
+            if (j < HID) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i + e < od) s.w1t[(i + e) * P1 + j] = vf[t][e];
+            }
+        }
     }
     for (int idx = tid; idx < 3 * HID; idx += 64 * MW) { s.bih[idx] = a.b_ih[idx]; s.bhh[idx] = a.b_hh[idx]; }
     if (tid < HID) {
@@ -257,6 +300,7 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
     for (int idx = tid; idx < ad * HID; idx += 64 * MW) s.w2[idx] = a.fc2_w[idx];
     if (tid < ad) s.b2[tid] = a.fc2_b[tid];
     __syncthreads();
+    ASTAMP(1);
 
     float* st = s.stage[wave];
     // Lane-dependent parts of every LDS index go into a base pointer per array, the rest is a compile-time constant that
@@ -316,6 +360,7 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
             }
             __builtin_amdgcn_wave_barrier();
         }
+        ASTAMP(2);
         // ---- + bias (+ id column), LayerNorm over the row's 64 units (32 here, 32 in the other half), ReLU ----
         const int ag = row % na;
         const float* w1id_l = s.w1id + ag * HID + 4 * hf;
@@ -364,6 +409,7 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
         float part[FLEXNET_MAX_ACT];
 #pragma unroll
         for (int k = 0; k < FLEXNET_MAX_ACT; ++k) part[k] = 0.0f;
+        ASTAMP(3);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 ar, az, gin, ghn, hnew;
@@ -416,6 +462,7 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
                         make_float4(hnew[4 * q], hnew[4 * q + 1], hnew[4 * q + 2], hnew[4 * q + 3]);
             }
         }
+        ASTAMP(4);
 #pragma unroll
         for (int k = 0; k < FLEXNET_MAX_ACT; ++k) {
             if (k < ad) {
@@ -432,6 +479,7 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
             }
         }
         __builtin_amdgcn_wave_barrier();
+        ASTAMP(5);
     }
 }
 
