@@ -208,14 +208,15 @@ __global__ __launch_bounds__(64 * AW, 1) void actor_forward_kernel(FlexActorArgs
 // layers chain THROUGH REGISTERS: lane (row r, half h) ends a layer holding units 8q + 4h + j (reg = 4q + j) of
 // its row — exactly what the next layer's B operand wants if the k-pair of MFMA step (q, j) is taken as
 // (8q + j, 8q + 4 + j) instead of two consecutive inputs, and the A operand (weights, from LDS) is read in the
-// matching order.  Only the network inputs are staged through LDS (16 observation columns at a time) to get from
-// row-major memory into "one batch row per lane"; LayerNorm is an in-lane sum plus one exchange between the halves.
-// Per 32 rows: 144 + 384 MFMAs (36 k cycles of a SIMD at the issue rate), two wavefronts per SIMD.
+// matching order.  The network inputs need no staging either: lane (row, half) reads columns 8q + 4 half .. + 3 of its
+// observation row (and units of its previous hidden state) with one 16-byte load per group of eight and uses them as
+// the B operands of steps (q, 0..3).  The gate biases are what the accumulators start from, fc2 is one more transposed
+// product (outputs padded to 32), so the gate epilogue touches no LDS; LayerNorm is an in-lane sum plus one exchange
+// between the halves.
+// Per 32 rows: 144 + 384 + 32 MFMAs (36 k cycles of a SIMD at the issue rate), two wavefronts per SIMD.
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MW 8                       // wavefronts per block
-#define MCH 16                     // observation columns staged at a time
-#define MSP (MCH + 1)              // staging pitch (floats)
 
 struct ActorLdsM {
     float w1t[FLEXNET_MAX_OBS * P1];
@@ -223,10 +224,9 @@ struct ActorLdsM {
     float whh[HID * PG];
     float b1[HID], lnw[HID], lnb[HID];
     float w1id[FLEXNET_MAX_AGENTS * HID];
-    float bih[3 * HID], bhh[3 * HID];
-    float w2[FLEXNET_MAX_ACT * HID];
+    float gb[4 * HID];                  // gate biases as the accumulators start from them: r, z (b_ih + b_hh), n_x, n_h
+    float w2p[HID * 32];                // fc2.weight transposed and padded to 32 outputs: w2p[unit][k], zero for k >= act_dim
     float b2[FLEXNET_MAX_ACT];
-    float stage[MW][32 * MSP];
 };
 
 // v_exp_f32 / v_rcp_f32 forms (about 1 ulp each): sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(x) = 1 - 2 / (2^(2x log2 e) + 1)
@@ -287,7 +287,14 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
             }
         }
     }
-    for (int idx = tid; idx < 3 * HID; idx += 64 * MW) { s.bih[idx] = a.b_ih[idx]; s.bhh[idx] = a.b_hh[idx]; }
+    if (tid < HID) {
+        s.gb[tid] = a.b_ih[tid] + a.b_hh[tid];
+        s.gb[HID + tid] = a.b_ih[HID + tid] + a.b_hh[HID + tid];
+        s.gb[2 * HID + tid] = a.b_ih[2 * HID + tid];
+        s.gb[3 * HID + tid] = a.b_hh[2 * HID + tid];
+    }
+    for (int idx = tid; idx < (((od + 7) & ~7) - od) * HID; idx += 64 * MW)        // fc1 runs over 8-column groups
+        s.w1t[(od + idx / HID) * P1 + (idx % HID)] = 0.0f;
     if (tid < HID) {
         s.b1[tid] = a.fc1_b[tid];
         s.lnw[tid] = a.layernorm ? a.ln_w[tid] : 1.0f;
@@ -297,68 +304,71 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
         const int ag = idx / HID, j = idx - ag * HID;
         s.w1id[idx] = (a.agent_id && ag < na) ? a.fc1_w[(int64_t)j * ld1 + od + ag] : 0.0f;
     }
-    for (int idx = tid; idx < ad * HID; idx += 64 * MW) s.w2[idx] = a.fc2_w[idx];
+    for (int idx = tid; idx < HID * 32; idx += 64 * MW) {
+        const int u = idx >> 5, k = idx & 31;
+        s.w2p[idx] = k < ad ? a.fc2_w[k * HID + u] : 0.0f;
+    }
     if (tid < ad) s.b2[tid] = a.fc2_b[tid];
     __syncthreads();
     ASTAMP(1);
 
-    float* st = s.stage[wave];
     // Lane-dependent parts of every LDS index go into a base pointer per array, the rest is a compile-time constant that
     // fits the 16-bit offset field of the ds_read: otherwise the compiler materialises one address register per
     // unrolled access, hoists all of them out of the tile loop and spills.
     const float* wi_l = s.wih + (4 * hf) * PG + rb;
     const float* wh_l = s.whh + (4 * hf) * PG + rb;
-    const float* bih_l = s.bih + 4 * hf;
-    const float* bhh_l = s.bhh + 4 * hf;
+    const float* gb_l = s.gb + 4 * hf;
     const float* b1_l = s.b1 + 4 * hf;
     const float* lnw_l = s.lnw + 4 * hf;
     const float* lnb_l = s.lnb + 4 * hf;
-    const float* w2_l = s.w2 + 4 * hf;
-    const float* st_l = st + rb * MSP + hf;
+    const float* w2p_l = s.w2p + (4 * hf) * 32 + rb;
+    const float* w1_l = s.w1t + (4 * hf) * P1 + rb;
+    // observations through a buffer descriptor: 16-byte loads at dword alignment, zeros past the end of the tensor
+    const int64_t obs_bytes = (int64_t)a.rows * od * 4;
+    const __amdgpu_buffer_rsrc_t robs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.obs), 0, obs_bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)obs_bytes, 0x00027000);
+    const int nq = (od + 7) >> 3;
     const int n_tiles = (a.rows + 31) / 32;
     // tile t goes to block t % grid, wavefront (t / grid) % MW: a small batch spreads over all CUs first
     for (int tile = wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * MW) {
         const int r0 = tile * 32;
         const int row = min(r0 + rb, a.rows - 1);                    // this lane's batch row (both halves share it)
-        // ---- fc1: z1[unit][row], observation columns staged MCH at a time -------------------------------------
+        // ---- fc1: z1[unit][row] ----------------------------------------------------------------------------------
         f32x16 z1[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int i = 0; i < 16; ++i) z1[u][i] = 0.0f;
-        // (the next chunk's observations are requested before this chunk's MFMAs: a lone wavefront per SIMD — small
-        // batches — would otherwise expose one global-memory round trip per chunk)
-        constexpr int NLD = 32 * MCH / 64;
-        int64_t ldoff[NLD];
-        int ldcol[NLD], stoff[NLD];
+        // Lane (row, half) reads columns 8q + 4 half .. + 3 of its row with ONE 16-byte load per group q — the k-pair of
+        // MFMA step (q, j) is (8q + j, 8q + 4 + j), as in the layers behind — so the observation goes from row-major memory
+        // straight into B operands: no LDS hand-over, no barriers.  Six groups (24 registers) in flight, the next six
+        // requested before the current ones are multiplied.
+        typedef float v4f_ __attribute__((ext_vector_type(4)));
+        constexpr int QB = 6;
+        const int xoff = (row * od + 4 * hf) * 4;
+        v4f_ xc[QB], xn[QB];
 #pragma unroll
-        for (int t = 0; t < NLD; ++t) {
-            const int e = lane + 64 * t, rr = e / MCH, cc = e - rr * MCH;
-            ldoff[t] = (int64_t)min(r0 + rr, a.rows - 1) * od + cc;
-            ldcol[t] = cc;
-            stoff[t] = rr * MSP + cc;
-        }
-        float cur[NLD];
+        for (int e = 0; e < QB; ++e)
+            xc[e] = __builtin_bit_cast(v4f_, __builtin_amdgcn_raw_buffer_load_b128(robs, e < nq ? xoff + 32 * e : -1, 0, 0));
+        for (int q0 = 0; q0 < nq; q0 += QB) {
 #pragma unroll
-        for (int t = 0; t < NLD; ++t) cur[t] = ldcol[t] < od ? a.obs[ldoff[t]] : 0.0f;
-        for (int c0 = 0; c0 < od; c0 += MCH) {
+            for (int e = 0; e < QB; ++e)
+                xn[e] = __builtin_bit_cast(v4f_, __builtin_amdgcn_raw_buffer_load_b128(
+                    robs, q0 + QB + e < nq ? xoff + 32 * (q0 + QB + e) : -1, 0, 0));
+            const float* wq = w1_l + (8 * q0) * P1;
 #pragma unroll
-            for (int t = 0; t < NLD; ++t) st[stoff[t]] = cur[t];
-            __builtin_amdgcn_wave_barrier();
-            if (c0 + MCH < od) {
+            for (int e = 0; e < QB; ++e) {
+                if (q0 + e < nq) {                                   // wavefront-uniform
 #pragma unroll
-                for (int t = 0; t < NLD; ++t) cur[t] = c0 + MCH + ldcol[t] < od ? a.obs[ldoff[t] + c0 + MCH] : 0.0f;
+                    for (int j = 0; j < 4; ++j) {
+                        const float a0 = wq[(8 * e + j) * P1], a1 = wq[(8 * e + j) * P1 + 32];
+                        z1[0] = MFMA(a0, xc[e][j], z1[0]);
+                        z1[1] = MFMA(a1, xc[e][j], z1[1]);
+                    }
+                }
             }
-            const float* w1_l = s.w1t + (c0 + hf) * P1 + rb;
 #pragma unroll
-            for (int kk = 0; kk < MCH; kk += 2) {
-                const float b = st_l[kk];
-                const bool in = c0 + kk + hf < od;
-                const float a0 = in ? w1_l[kk * P1] : 0.0f, a1 = in ? w1_l[kk * P1 + 32] : 0.0f;
-                z1[0] = MFMA(a0, b, z1[0]);
-                z1[1] = MFMA(a1, b, z1[1]);
-            }
-            __builtin_amdgcn_wave_barrier();
+            for (int e = 0; e < QB; ++e) xc[e] = xn[e];
         }
         ASTAMP(2);
         // ---- + bias (+ id column), LayerNorm over the row's 64 units (32 here, 32 in the other half), ReLU ----
@@ -406,15 +416,16 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int i = 0; i < 16; ++i) z1[u][i] = fmaxf(z1[u][i], 0.0f);     // x = ReLU(LayerNorm(z1))
-        float part[FLEXNET_MAX_ACT];
-#pragma unroll
-        for (int k = 0; k < FLEXNET_MAX_ACT; ++k) part[k] = 0.0f;
+        f32x16 hnew[2];
         ASTAMP(3);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x16 ar, az, gin, ghn, hnew;
+            f32x16 ar, az, gin, ghn;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { ar[i] = 0.0f; az[i] = 0.0f; gin[i] = 0.0f; ghn[i] = 0.0f; }
+            for (int i = 0; i < 16; ++i) {
+                const int cu = 32 * t + DU0(i);
+                ar[i] = gb_l[cu]; az[i] = gb_l[HID + cu]; gin[i] = gb_l[2 * HID + cu]; ghn[i] = gb_l[3 * HID + cu];
+            }
             // software pipeline: the six weights of step s + 1 are requested before the MFMAs of step s; the scheduling
             // barrier keeps the compiler from hoisting ALL 192 LDS reads above the loop (it spilled doing so)
             float w[6];
@@ -445,29 +456,33 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int cu = 32 * t + DU0(i);
-                const float rg = fast_sigmoid(ar[i] + bih_l[cu] + bhh_l[cu]);
-                const float zg = fast_sigmoid(az[i] + bih_l[HID + cu] + bhh_l[HID + cu]);
-                const float ng = fast_tanh(gin[i] + bih_l[2 * HID + cu] + rg * (ghn[i] + bhh_l[2 * HID + cu]));
-                const float hn = ng + zg * (hv[t][i] - ng);
-                hnew[i] = hn;
-#pragma unroll
-                for (int k = 0; k < FLEXNET_MAX_ACT; ++k)
-                    if (k < ad) part[k] = fmaf(w2_l[k * HID + cu], hn, part[k]);
+                const float rg = fast_sigmoid(ar[i]);
+                const float zg = fast_sigmoid(az[i]);
+                const float ng = fast_tanh(gin[i] + rg * ghn[i]);
+                hnew[t][i] = ng + zg * (hv[t][i] - ng);                  // (1 - z) n + z h
             }
             if (r0 + rb < a.rows) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     *reinterpret_cast<float4*>(a.hidden_out + (int64_t)(r0 + rb) * HID + 32 * t + 8 * q + 4 * hf) =
-                        make_float4(hnew[4 * q], hnew[4 * q + 1], hnew[4 * q + 2], hnew[4 * q + 3]);
+                        make_float4(hnew[t][4 * q], hnew[t][4 * q + 1], hnew[t][4 * q + 2], hnew[t][4 * q + 3]);
             }
         }
         ASTAMP(4);
+        // ---- fc2 (rnn_agent.py:32) as one more transposed product: means[k][row], k padded to 32; lane (row, half) ends
+        //      with actions 4 half .. 4 half + 3 of its row in the first four accumulator registers ----------------------
+        f32x16 mo;
 #pragma unroll
-        for (int k = 0; k < FLEXNET_MAX_ACT; ++k) {
-            if (k < ad) {
-                const float o = part[k] + __shfl_xor(part[k], 32, 64) + s.b2[k];
-                if (hf == 0 && r0 + rb < a.rows) {
+        for (int i = 0; i < 16; ++i) mo[i] = 0.0f;
+#pragma unroll
+        for (int st_ = 0; st_ < 32; ++st_)
+            mo = MFMA(w2p_l[(32 * (st_ >> 4) + DU0(st_ & 15)) * 32], hnew[st_ >> 4][st_ & 15], mo);
+        if (r0 + rb < a.rows) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * hf + r;
+                if (k < ad) {
+                    const float o = mo[r] + s.b2[k];
                     const int64_t at = (int64_t)(r0 + rb) * ad + k;
                     a.means[at] = o;
                     if (a.noise) {                                            // util.py:57-64, 125-128
@@ -493,6 +508,7 @@ extern "C" int flexnet_actor_forward(const FlexActorArgs* a, void* stream) {
     if (a->obs_dim < 1 || a->obs_dim > FLEXNET_MAX_OBS || a->n_agents < 1 || a->n_agents > FLEXNET_MAX_AGENTS ||
         a->act_dim < 1 || a->act_dim > FLEXNET_MAX_ACT)
         return FLEXNET_EUNSUPPORTED;
+    if ((int64_t)a->rows * a->obs_dim * 4 >= 0x7ffffff0ll) return FLEXNET_EUNSUPPORTED;   // observations are addressed with 32-bit byte offsets
     static int cus = 0;                                   // one block per CU owns that CU's LDS
     if (cus == 0) {
         int dev = 0, n = 0;
