@@ -58,6 +58,10 @@ typedef struct {
     float* action;             /* out [rows, act_dim]  tanh(mean + std * noise) */
     float* env_action;         /* out [rows, act_dim]  0.5 * (clamp(action, low, high) + 1) * (high - low) + low */
     float std, action_low, action_high, pad1;
+    /* Alternative to `noise` (leave that NULL): the kernel draws the standard normal numbers itself — Philox4x32-10 keyed
+     * by rng_state[0] (seed) with counter (row, action group, rng_state[1] = step), Box-Muller on 24-bit uniforms.  The
+     * caller (or flexnet_rollout_pack, given the same pointer) advances rng_state[1] between launches.  variant 0 only. */
+    const uint64_t* rng_state; /* device [2] or NULL */
 } FlexActorArgs;
 
 /* rnn_agent.py:25-33 + model.py:102-116 for all rows. */
@@ -202,6 +206,7 @@ typedef struct {
     double* info_sum;          /* += [info_w] or NULL */
     double* rew_sum;           /* += [1] */
     double* fail_sum;          /* += [1] or NULL */
+    uint64_t* rng_state;       /* device [2] or NULL: [1] += 1 (the step counter of flexnet_actor_forward's noise stream) */
 } FlexRolloutPackArgs;
 
 int flexnet_rollout_pack(const FlexRolloutPackArgs* args, void* stream);

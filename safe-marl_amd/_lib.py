@@ -68,7 +68,8 @@ class FlexActorArgs(C.Structure):
                 ("agent_id", C.c_int32), ("layernorm", C.c_int32), ("ln_eps", C.c_float), ("variant", C.c_int32)] + \
                [(k, C.c_void_p) for k in ("obs", "hidden_in", "fc1_w", "fc1_b", "ln_w", "ln_b", "w_ih", "w_hh", "b_ih",
                                           "b_hh", "fc2_w", "fc2_b", "means", "hidden_out", "noise", "action", "env_action")] + \
-               [("std", C.c_float), ("action_low", C.c_float), ("action_high", C.c_float), ("pad1", C.c_float)]
+               [("std", C.c_float), ("action_low", C.c_float), ("action_high", C.c_float), ("pad1", C.c_float),
+                ("rng_state", C.c_void_p)]
 
 
 class FlexCriticTailArgs(C.Structure):
@@ -119,7 +120,8 @@ class FlexRolloutPackArgs(C.Structure):
                                          "col_reward", "col_next_state", "col_done", "col_last_step", "col_last_hid",
                                          "col_hid", "info_w", "pad0", "pad1")] + \
                [(k, C.c_void_p) for k in ("obs_prev", "action", "reward", "obs_next", "done", "hid_prev", "hid_new", "info",
-                                          "failed", "rec", "obs_state", "hid_state", "info_sum", "rew_sum", "fail_sum")]
+                                          "failed", "rec", "obs_state", "hid_state", "info_sum", "rew_sum", "fail_sum",
+                                          "rng_state")]
 
 
 FLEXNET_EUNSUPPORTED = -3

@@ -235,6 +235,30 @@ __device__ __forceinline__ float fast_tanh(float x) {
     const float xc = fminf(fmaxf(x, -15.0f), 15.0f);
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.88539008f * xc) + 1.0f);
 }
+// Exploration noise drawn in the kernel (FlexActorArgs::rng_state): four standard normal numbers for actions
+// 4 group .. 4 group + 3 of one row.  Philox4x32-10 (the generator of the env's reset stream, flex_device.h), counter =
+// (row, group, step lo, tag ^ step hi), key = seed; uniforms from the top 24 bits, (x + 0.5) 2^-24 in (0, 1); Box-Muller.
+// Restated for the tests in tests/test_actor_gpu.py.
+#define ACTOR_NOISE_TAG 0xAC70A5E1u
+__device__ __forceinline__ void actor_noise4(uint64_t seed, uint64_t step, uint32_t row, uint32_t group, float* z) {
+    uint32_t c0 = row, c1 = group, c2 = (uint32_t)step, c3 = ACTOR_NOISE_TAG ^ (uint32_t)(step >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float s24 = 1.0f / 16777216.0f;
+    const float u0 = ((float)(c0 >> 8) + 0.5f) * s24, u1 = ((float)(c1 >> 8) + 0.5f) * s24;
+    const float u2 = ((float)(c2 >> 8) + 0.5f) * s24, u3 = ((float)(c3 >> 8) + 0.5f) * s24;
+    const float ra = sqrtf(-2.0f * logf(u0)), rb_ = sqrtf(-2.0f * logf(u2));
+    z[0] = ra * cospif(2.0f * u1); z[1] = ra * sinpif(2.0f * u1);
+    z[2] = rb_ * cospif(2.0f * u3); z[3] = rb_ * sinpif(2.0f * u3);
+}
+
 #define DU0(i) (8 * ((i) >> 2) + ((i) & 3))       // unit of accumulator register i within a 32-unit tile, without the half's + 4 hf
 #define MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
 
@@ -328,6 +352,7 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
     const __amdgpu_buffer_rsrc_t robs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.obs), 0, obs_bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)obs_bytes, 0x00027000);
     const int nq = (od + 7) >> 3;
+    const uint64_t rng_seed = a.rng_state ? a.rng_state[0] : 0ull, rng_step = a.rng_state ? a.rng_state[1] : 0ull;
     const int n_tiles = (a.rows + 31) / 32;
     // tile t goes to block t % grid, wavefront (t / grid) % MW: a small batch spreads over all CUs first
     for (int tile = wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * MW) {
@@ -478,6 +503,8 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
         for (int st_ = 0; st_ < 32; ++st_)
             mo = MFMA(w2p_l[(32 * (st_ >> 4) + DU0(st_ & 15)) * 32], hnew[st_ >> 4][st_ & 15], mo);
         if (r0 + rb < a.rows) {
+            float zr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (!a.noise && a.rng_state && 4 * hf < ad) actor_noise4(rng_seed, rng_step, (uint32_t)(r0 + rb), (uint32_t)hf, zr);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = 4 * hf + r;
@@ -485,8 +512,8 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
                     const float o = mo[r] + s.b2[k];
                     const int64_t at = (int64_t)(r0 + rb) * ad + k;
                     a.means[at] = o;
-                    if (a.noise) {                                            // util.py:57-64, 125-128
-                        const float act = tanhf(o + a.std * a.noise[at]);
+                    if (a.action) {                                           // util.py:57-64, 125-128
+                        const float act = tanhf(o + a.std * (a.noise ? a.noise[at] : zr[r]));
                         a.action[at] = act;
                         a.env_action[at] = 0.5f * (fminf(fmaxf(act, a.action_low), a.action_high) + 1.0f) * (a.action_high - a.action_low) + a.action_low;
                     }
@@ -503,8 +530,10 @@ extern "C" int flexnet_actor_forward(const FlexActorArgs* a, void* stream) {
     if (a->rows == 0) return FLEXNET_OK;
     if (!a->obs || !a->hidden_in || !a->fc1_w || !a->fc1_b || !a->w_ih || !a->w_hh || !a->b_ih || !a->b_hh || !a->fc2_w ||
         !a->fc2_b || !a->means || !a->hidden_out || (a->layernorm && (!a->ln_w || !a->ln_b)) ||
-        (a->noise && (!a->action || !a->env_action)))
+        ((a->noise || a->rng_state) && (!a->action || !a->env_action)))
         return FLEXNET_EINVAL;
+    if (!a->noise && !a->rng_state && a->action) return FLEXNET_EINVAL;      // exploration outputs need a noise source
+    if (a->rng_state && !a->noise && a->variant != 0) return FLEXNET_EUNSUPPORTED;
     if (a->obs_dim < 1 || a->obs_dim > FLEXNET_MAX_OBS || a->n_agents < 1 || a->n_agents > FLEXNET_MAX_AGENTS ||
         a->act_dim < 1 || a->act_dim > FLEXNET_MAX_ACT)
         return FLEXNET_EUNSUPPORTED;

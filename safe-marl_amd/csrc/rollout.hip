@@ -30,7 +30,7 @@ __global__ __launch_bounds__(PACK_THREADS) void rollout_pack_kernel(FlexRolloutP
         }
         if (t == 0) {
             if (is_info) a.info_sum[q] += red[0];
-            else if (q == 8) *a.rew_sum += red[0];
+            else if (q == 8) { *a.rew_sum += red[0]; if (a.rng_state) a.rng_state[1] += 1; }     // this block always runs
             else *a.fail_sum += red[0];
         }
         return;

@@ -54,6 +54,9 @@ class RolloutGraph:
         self.fail_sum = th.zeros((), dtype=th.float64, device=dev)
         self.std = float(model.args.fixed_policy_std)
         self.graph = None
+        self.torch_noise = False
+        self.rng_state = th.zeros(2, dtype=th.int64, device=dev)           # [seed, step] of the actor kernel's noise stream
+        self.rng_state[0] = int(th.randint(0, 2 ** 62, (1,)).item())
         self.plain = type(model).get_actions is MADDPG.get_actions and bool(model.args.action_enforcebound)
         self.avail = th.ones(N, n, a, device=dev)             # every action is available (env:721-730)
         # plain MADDPG on the GPU: policy + exploration in one HIP launch, packing + hand-over + statistics in another
@@ -81,6 +84,8 @@ class RolloutGraph:
                         ("info_sum", self.info_sum), ("rew_sum", self.rew_sum), ("fail_sum", self.fail_sum)):
             assert t.is_contiguous()
             setattr(a, name, t.data_ptr())
+        if not self.torch_noise:
+            a.rng_state = self.rng_state.data_ptr()       # next step of the actor kernel's noise stream
         _lib.check(_lib.load().flexnet_rollout_pack(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)),
                    "flexnet_rollout_pack")
 
@@ -89,9 +94,14 @@ class RolloutGraph:
         N = env.n_envs
         if self.fast:
             with th.no_grad():
-                noise = th.randn(N, m.n_, m.act_dim, device=self.obs.device)
+                # exploration noise: drawn by the actor kernel from its own Philox stream (seeded from torch's generator
+                # when this object was built; the pack kernel advances the step counter), or — torch_noise, used by the
+                # tests that compare with the PyTorch glue draw for draw — by torch.randn.  Inside a HIP graph torch.randn
+                # costs a launch plus two seed/offset fill kernels per replay.
+                noise = th.randn(N, m.n_, m.act_dim, device=self.obs.device) if self.torch_noise else None
                 out = fused_actor_forward(m.policy_dicts[0], self.obs, self.hid, m.n_, m.args.agent_id, noise=noise,
-                                          std=self.std, low=m.args.action_low, high=m.args.action_high)
+                                          std=self.std, low=m.args.action_low, high=m.args.action_high,
+                                          rng_state=None if self.torch_noise else self.rng_state)
                 if out is not None:
                     _, hid, action, env_action = out
                     if self.safe:

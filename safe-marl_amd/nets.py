@@ -148,14 +148,18 @@ class MLPCritic(nn.Module):
         return self.forward_from_hidden(self.fc1(inputs))
 
 
-def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=1.0, low=0.0, high=1.0, variant=0):
+def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=1.0, low=0.0, high=1.0, variant=0,
+                        rng_state=None):
     """rnn_agent.py:25-33 + model.py:102-116 without an autograd graph, in one HIP launch.
 
     ``obs`` [b, n, obs_dim] fp32 on the GPU WITHOUT the one-hot id columns (the kernel adds fc1's id column of
     row r % n itself), ``hidden`` [b, n, 64] or [b * n, 64].  Returns (means [b * n, act], hidden [b * n, 64]) or
     None when the configuration is not one the kernel covers (the caller then uses the module).  With ``noise``
     [b, n, act] (standard normal draws) the exploration epilogue runs in the same launch and two more tensors come
-    back: action = tanh(mean + std * noise) (util.py:57-64) and the environment's action (util.py:125-128)."""
+    back: action = tanh(mean + std * noise) (util.py:57-64) and the environment's action (util.py:125-128).  With
+    ``rng_state`` (int64 device tensor [seed, step]) instead of ``noise`` the kernel draws the normal numbers itself
+    (Philox4x32-10 + Box-Muller, csrc/actor.hip actor_noise4); the caller advances ``rng_state[1]`` per call —
+    flexnet_rollout_pack does when handed the same tensor."""
     import ctypes as C
     from . import _lib
     a = agent.args
@@ -173,8 +177,14 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
     args.agent_id, args.layernorm, args.ln_eps = int(bool(agent_id)), int(bool(a.layernorm)), 1e-5
     args.variant = int(variant)
     action = env_action = None
+    explore = noise is not None or rng_state is not None
     if noise is not None:
         noise = noise.reshape(rows, a.action_dim).to(th.float32).contiguous()
+    elif rng_state is not None:
+        if not (rng_state.is_cuda and rng_state.dtype == th.int64 and rng_state.numel() == 2 and rng_state.is_contiguous()):
+            raise ValueError("rng_state must be a contiguous int64 device tensor [seed, step]")
+        args.rng_state = rng_state.data_ptr()
+    if explore:
         action, env_action = th.empty_like(means), th.empty_like(means)
         args.std, args.action_low, args.action_high = float(std), float(low), float(high)
     ln = agent.layernorm if a.layernorm else None
@@ -193,7 +203,7 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
     if rc == _lib.FLEXNET_EUNSUPPORTED:
         return None
     _lib.check(rc, "flexnet_actor_forward")
-    return (means, hid_out) if noise is None else (means, hid_out, action, env_action)
+    return (means, hid_out, action, env_action) if explore else (means, hid_out)
 
 
 _WGRAD_WS = {}

@@ -78,3 +78,63 @@ def test_policy_uses_the_kernel_without_grad_and_the_module_with():
     assert (f_means - t_means).abs().max().item() < 1e-5 and (f_hid - t_hid).abs().max().item() < 1e-5
     g_means, _, _ = m.policy(obs, last_hid=hid)                            # grad enabled: the module, with a graph
     assert g_means.requires_grad
+
+
+def _agent_and_inputs(rows_b, act_dim):
+    agent = _agent(144, 5, act_dim)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    obs = torch.randn(rows_b, 5, 144, device="cuda", generator=g)
+    hid = torch.randn(rows_b, 5, 64, device="cuda", generator=g)
+    return agent, obs, hid
+
+
+def _noise_restatement(seed, step, rows, act_dim):
+    """csrc/actor.hip actor_noise4 in NumPy: Philox4x32-10 (oracle.env_oracle), counter (row, group, step lo,
+    tag ^ step hi), key = seed; 24-bit uniforms (x + 0.5) / 2^24; Box-Muller."""
+    import numpy as np
+    from oracle.env_oracle import philox4x32_10
+    z = np.zeros((rows, act_dim))
+    for row in range(rows):
+        for group in range((act_dim + 3) // 4):
+            x = philox4x32_10((row, group, step & 0xFFFFFFFF, 0xAC70A5E1 ^ (step >> 32)), (seed & 0xFFFFFFFF, seed >> 32))
+            u = [((v >> 8) + 0.5) / 16777216.0 for v in x]
+            ra, rb = np.sqrt(-2.0 * np.log(u[0])), np.sqrt(-2.0 * np.log(u[2]))
+            four = [ra * np.cos(2 * np.pi * u[1]), ra * np.sin(2 * np.pi * u[1]),
+                    rb * np.cos(2 * np.pi * u[3]), rb * np.sin(2 * np.pi * u[3])]
+            for r in range(4):
+                if 4 * group + r < act_dim:
+                    z[row, 4 * group + r] = four[r]
+    return z
+
+
+@pytest.mark.parametrize("act_dim,step", [(4, 0), (4, 123456789012), (6, 7)])
+def test_in_kernel_exploration_noise_matches_its_restatement(act_dim, step):
+    """rng_state mode: actions equal the explicit-noise mode fed with the NumPy restatement of the kernel's stream."""
+    from safe_marl_amd.nets import fused_actor_forward
+    agent, obs, hid = _agent_and_inputs(rows_b=13, act_dim=act_dim)
+    seed = 0x1234567890ABCDE
+    state = torch.tensor([seed, step], dtype=torch.int64, device="cuda")
+    with torch.no_grad():
+        m1, h1, a1, e1 = fused_actor_forward(agent, obs, hid, 5, True, rng_state=state, std=0.7, low=0.0, high=1.0)
+        z = torch.from_numpy(_noise_restatement(seed, step, 13 * 5, act_dim)).float().cuda()
+        m2, h2, a2, e2 = fused_actor_forward(agent, obs, hid, 5, True, noise=z.view(13, 5, act_dim), std=0.7, low=0.0, high=1.0)
+    assert torch.equal(m1, m2) and torch.equal(h1, h2)
+    assert (a1 - a2).abs().max().item() < 2e-5 and (e1 - e2).abs().max().item() < 2e-5
+    assert int(state[1].item()) == step                       # the actor call itself does not advance the stream
+
+
+def test_in_kernel_noise_is_standard_normal_and_moves_with_the_step():
+    from safe_marl_amd.nets import fused_actor_forward
+    agent, obs, hid = _agent_and_inputs(rows_b=8192, act_dim=4)
+    with torch.no_grad():
+        for p in agent.parameters():
+            p.zero_()                                          # means = 0: action = tanh(std * z)
+        outs = []
+        for step in (0, 1):
+            state = torch.tensor([99, step], dtype=torch.int64, device="cuda")
+            _, _, act, _ = fused_actor_forward(agent, obs, hid, 5, True, rng_state=state, std=1.0, low=0.0, high=1.0)
+            outs.append(torch.atanh(act.double().clamp(-1 + 1e-12, 1 - 1e-12)))
+    z = outs[0]
+    assert abs(z.mean().item()) < 0.01 and abs(z.var().item() - 1.0) < 0.02
+    assert abs((z[:, 0] * z[:, 1]).mean().item()) < 0.01 and abs((z[:-1, 0] * z[1:, 0]).mean().item()) < 0.01
+    assert abs((outs[0] * outs[1]).mean().item()) < 0.01       # consecutive steps are independent draws

@@ -39,6 +39,7 @@ def _setup(n_envs):
 def test_fast_step_equals_general_step(n_envs):
     fast, slow = _setup(n_envs)
     assert fast.fast
+    fast.torch_noise = True                        # the same torch.randn draws as the general path
     slow.fast = False
     slow.model.fused_inference = False             # general path end to end: the module, torch glue
     for rg in (fast, slow):
@@ -81,6 +82,22 @@ def test_graph_capture_with_the_fused_step():
         torch.cuda.synchronize()
         acts.append(fast.f["action"].clone())
     assert (acts[0] - acts[1]).abs().mean().item() > 1e-3
+    assert not fast.torch_noise and int(fast.rng_state[1].item()) >= 5        # the in-kernel stream: one step per replay
+
+
+def test_graph_replays_with_torch_noise_too():
+    fast, _ = _setup(64)
+    fast.torch_noise = True
+    fast.capture()
+    fast.start_episode(fast.env.reset())
+    o0, h0 = fast.obs.clone(), fast.hid.clone()
+    acts = []
+    for _ in range(2):
+        fast.obs.copy_(o0); fast.hid.copy_(h0)
+        fast.graph.replay()
+        torch.cuda.synchronize()
+        acts.append(fast.f["action"].clone())
+    assert (acts[0] - acts[1]).abs().mean().item() > 1e-3 and int(fast.rng_state[1].item()) == 0
 
 
 def test_safemaddpg_fused_step_applies_the_safety_layer():
@@ -113,6 +130,7 @@ def test_safemaddpg_fused_step_applies_the_safety_layer():
         models.append(m)
     rg = RolloutGraph(models[0], envs[0], TransReplayBuffer(N * 8, device="cuda"))
     assert rg.fast and rg.safe
+    rg.torch_noise = True
     rg.start_episode(envs[0].reset())
     obs = envs[1].reset().clone()
     hid = torch.zeros(N, 5, 64, device="cuda")
