@@ -459,6 +459,211 @@ __global__ __launch_bounds__(64 * CMW, 2) void critic_tail_mfma_kernel(FlexCriti
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward WITH parameter gradients on the matrix cores (variant 0, large batches).  Phase A per 32-row tile is the
+// dz1-only chain above (forward recompute, dz2, da1 = W2^T dz2, ReLU / LayerNorm backward, dz1 stored).  Phase B:
+// dW2[j][i] = sum_row dz2[row][j] a1[row][i] contracts over ROWS, the other operand layout, so the tile's a1 and dz2
+// pass through a per-wavefront LDS transpose (written as float4s in the accumulator's unit pattern, read back with
+// lanes = units, k = row pair) into 64 more MFMAs; db2 falls out of those A operands.  The three remaining vectors
+// (d ln_w, d ln_b, d fc3_w) are sums over rows of values a lane already holds: they accumulate per lane over all of the
+// wavefront's tiles and are transposed once, at the end.  ~330 registers per lane: ONE wavefront per SIMD (4 per CU),
+// which the 192-MFMA chain per tile keeps busy by itself.  Per-block partial rows go to the same workspace layout and
+// the same fixed-order second launch as the VALU kernel's.
+// ---------------------------------------------------------------------------------------------------------------
+#define CPW 4                                            // wavefronts per block
+#define CTP 68                                           // transpose pitch (floats): float4-aligned rows
+__global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(FlexCriticTailArgs a) {
+    __shared__ float w2t[HID * HID];
+    __shared__ float w2n[HID * HID];
+    __shared__ float vec[4][HID];
+    __shared__ float tr[CPW][2][32 * CTP];               // per wavefront: a1 tile, dz2 tile as [row][unit]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rb = lane & 31, hf = lane >> 5;
+    for (int idx = tid; idx < HID * HID; idx += 64 * CPW) {
+        const int j = idx / HID, k = idx - j * HID;
+        const float w = a.fc2_w[idx];
+        w2t[k * HID + j] = w;
+        w2n[idx] = w;
+    }
+    if (tid < HID) {
+        vec[0][tid] = a.layernorm ? a.ln_w[tid] : 1.0f;
+        vec[1][tid] = a.layernorm ? a.ln_b[tid] : 0.0f;
+        vec[2][tid] = a.fc2_b[tid];
+        vec[3][tid] = a.fc3_w[tid];
+    }
+    __syncthreads();
+    const float* w2t_l = w2t + (4 * hf) * HID + rb;
+    const float* w2n_l = w2n + (4 * hf) * HID + rb;
+    const float* g_l = vec[0] + 4 * hf;
+    const float* be_l = vec[1] + 4 * hf;
+    const float* b2_l = vec[2] + 4 * hf;
+    const float* w3_l = vec[3] + 4 * hf;
+    float* t1 = tr[wave][0];
+    float* t2 = tr[wave][1];
+    float* t1_w = t1 + rb * CTP + 4 * hf;                // this lane's row, its unit pattern (write side)
+    float* t2_w = t2 + rb * CTP + 4 * hf;
+    const float* t1_r = t1 + hf * CTP + rb;              // row pair 2s + hf, unit rb (+ 32): read side
+    const float* t2_r = t2 + hf * CTP + rb;
+    const bool ln = a.layernorm != 0;
+
+    cf32x16 dW[2][2];                                    // [tj][ti]: dW2 rows 32 tj.., columns 32 ti..
+    cf32x16 sg[2], sb[2], sw3[2];                        // per-lane (row) partial sums of dy xhat, dy, dq h2
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            dW[u][0][i] = 0.0f; dW[u][1][i] = 0.0f; sg[u][i] = 0.0f; sb[u][i] = 0.0f; sw3[u][i] = 0.0f;
+        }
+    float cs2[2] = {0.0f, 0.0f}, sb3 = 0.0f;
+
+    const int n_tiles = (a.rows + 31) / 32;
+    for (int tile = wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * CPW) {
+        const int r0 = tile * 32;
+        const int row = min(r0 + rb, a.rows - 1);
+        const bool live = r0 + rb < a.rows;
+        // ---- phase A ------------------------------------------------------------------------------------------
+        cf32x16 xh[2], a1[2];
+        critic_load_z1(a, row, hf, xh);
+        const float rstd = critic_ln_inplace(xh, ln, a.ln_eps);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int cu = 32 * u + CDU0(i);
+                a1[u][i] = fmaxf(ln ? fmaf(xh[u][i], g_l[cu], be_l[cu]) : xh[u][i], 0.0f);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(t1_w + 32 * u + 8 * q) =
+                    make_float4(a1[u][4 * q], a1[u][4 * q + 1], a1[u][4 * q + 2], a1[u][4 * q + 3]);
+        const float dq = live ? a.dq[r0 + rb] : 0.0f;       // spare rows of the last tile contribute nothing
+        if (hf == 0) sb3 += dq;
+        cf32x16 z2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            z2[t] = critic_mfma_tile(w2t_l, t, a1);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int cu = 32 * t + CDU0(i);
+                const float zz = z2[t][i] + b2_l[cu];
+                sw3[t][i] = fmaf(dq, fmaxf(zz, 0.0f), sw3[t][i]);
+                z2[t][i] = zz > 0.0f ? dq * w3_l[cu] : 0.0f;                                           // dz2
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(t2_w + 32 * t + 8 * q) =
+                    make_float4(z2[t][4 * q], z2[t][4 * q + 1], z2[t][4 * q + 2], z2[t][4 * q + 3]);
+        float m1 = 0.0f, m2 = 0.0f;
+        cf32x16 d[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            d[u] = critic_mfma_tile(w2n_l, u, z2);                                                        // da1
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int cu = 32 * u + CDU0(i);
+                const float dy = a1[u][i] > 0.0f ? d[u][i] : 0.0f;
+                if (ln) {
+                    sg[u][i] = fmaf(dy, xh[u][i], sg[u][i]);
+                    sb[u][i] += dy;
+                }
+                const float dxh = ln ? dy * g_l[cu] : dy;
+                d[u][i] = dxh;
+                m1 += dxh;
+                m2 = fmaf(dxh, xh[u][i], m2);
+            }
+        }
+        if (ln) {
+            m1 = (m1 + __shfl_xor(m1, 32, 64)) * (1.0f / HID);
+            m2 = (m2 + __shfl_xor(m2, 32, 64)) * (1.0f / HID);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) d[u][i] = rstd * (d[u][i] - m1 - xh[u][i] * m2);
+        }
+        if (live) {
+            float* out = a.dz1 + (int64_t)(r0 + rb) * HID + 4 * hf;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(out + 32 * u + 8 * q) =
+                        make_float4(d[u][4 * q], d[u][4 * q + 1], d[u][4 * q + 2], d[u][4 * q + 3]);
+        }
+        // ---- phase B: dW2 += dz2^T a1 over the tile's 32 rows (16 row pairs), db2 from the A operands -----------
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                    // lgkmcnt(0): the transposes have landed
+#pragma unroll
+        for (int sp = 0; sp < 16; ++sp) {
+            const float a0 = t2_r[(2 * sp) * CTP], a1v = t2_r[(2 * sp) * CTP + 32];
+            const float b0 = t1_r[(2 * sp) * CTP], b1v = t1_r[(2 * sp) * CTP + 32];
+            dW[0][0] = CMFMA(a0, b0, dW[0][0]);
+            dW[0][1] = CMFMA(a0, b1v, dW[0][1]);
+            dW[1][0] = CMFMA(a1v, b0, dW[1][0]);
+            dW[1][1] = CMFMA(a1v, b1v, dW[1][1]);
+            cs2[0] += a0; cs2[1] += a1v;
+        }
+        __builtin_amdgcn_wave_barrier();                                       // the next tile overwrites the transposes
+    }
+
+    // ---- the wavefront's sums -> the block's partial row [dW2 | db2 | dw3 | dg | db | db3] ---------------------------
+    __syncthreads();
+    float* fold = &tr[0][0][0];                                                // CRITIC_WS_PITCH floats, all tiles are done
+    for (int w = 0; w < CPW; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int e = (32 * tj + CDU0(r) + 4 * hf) * HID + 32 * ti + rb;       // dW2[j][i]
+                        fold[e] = (w == 0 ? 0.0f : fold[e]) + dW[tj][ti][r];
+                    }
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const float v = cs2[tj] + __shfl_xor(cs2[tj], 32, 64);
+                if (hf == 0) { const int e = HID * HID + 32 * tj + rb; fold[e] = (w == 0 ? 0.0f : fold[e]) + v; }
+            }
+            const float b3 = sb3;                                              // rows live in the hf == 0 lanes
+            float b3t = hf == 0 ? b3 : 0.0f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) b3t += __shfl_xor(b3t, off, 64);
+            if (lane == 0) { const int e = HID * HID + 4 * HID; fold[e] = (w == 0 ? 0.0f : fold[e]) + b3t; }
+        }
+        __syncthreads();
+    }
+    // the row-lane vectors: one [32 rows][64 units] image per vector and wavefront, column sums with lanes = units
+    float* img = &tr[0][0][0] + CRITIC_WS_PITCH;                                // behind the fold area
+    for (int v = 0; v < 3; ++v) {                                              // 0: dw3, 1: dg, 2: db  (fold order)
+        for (int w = 0; w < CPW; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float x = v == 0 ? sw3[u][i] : v == 1 ? sg[u][i] : sb[u][i];
+                        img[rb * HID + 32 * u + CDU0(i) + 4 * hf] = x;
+                    }
+            }
+            __syncthreads();
+            if (wave == w) {
+                float sum = 0.0f;
+                for (int r = 0; r < 32; ++r) sum += img[r * HID + lane];
+                const int e = HID * HID + (1 + v) * HID + lane;
+                fold[e] = (w == 0 ? 0.0f : fold[e]) + sum;
+            }
+            __syncthreads();
+        }
+    }
+    float* out = a.workspace + (int64_t)blockIdx.x * CRITIC_WS_PITCH;
+    for (int e = tid; e < HID * HID + 4 * HID + 1; e += 64 * CPW) out[e] = fold[e];
+}
+
 // below this the VALU kernels (4 rows per wavefront, 8 blocks per CU) spread a batch over the chip better than
 // 32-row MFMA tiles do: 8.5 vs 11.4 us forward at 20 480 rows, 43.5 vs 28.5 us at 163 840
 #define CRITIC_MFMA_MIN_ROWS 65536
@@ -535,6 +740,13 @@ extern "C" int flexnet_critic_tail_backward(const FlexCriticTailArgs* a, void* s
         return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
     }
     const bool two_stage = k.workspace && k.workspace_floats >= FLEXNET_CRITIC_WS_FLOATS;
+    if (two_stage && k.variant == 0 && k.rows >= CRITIC_MFMA_MIN_ROWS) {
+        const int nb = critic_mfma_grid(k.rows);
+        if (nb < 1 || nb > 1024) return FLEXNET_EHIP;
+        hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel, dim3(nb), dim3(64 * CPW), 0, (hipStream_t)stream, k);
+        hipLaunchKernelGGL(critic_reduce_kernel, dim3((HID * HID + 4 * HID + 1 + 63) / 64), dim3(64 * RED_G), 0, (hipStream_t)stream, k, nb);
+        return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+    }
     if (!two_stage) k.workspace = nullptr;
     // deterministic path: up to 1024 blocks of partial sums; atomic path: one block per CU (each ends with 4 k atomics)
     const int blocks = critic_grid(k.rows, two_stage ? 4 : 1);
