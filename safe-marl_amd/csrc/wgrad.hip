@@ -260,7 +260,9 @@ extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) {
     const int64_t ws_floats = a->workspace_floats - WG_CS_FLOATS;
     if (ws_floats < chunks * img) return FLEXNET_EINVAL;
     int64_t slabs = (a->k + 63) / 64;
-    const int64_t want = (512 + chunks - 1) / chunks;
+    // never more than two blocks per CU in total: with 515 blocks the last three ran as a second round (62 -> 3x us at
+    // [32 768, 64] x [32 768, 720])
+    const int64_t want = 512 / chunks > 0 ? 512 / chunks : 1;
     if (slabs > want) slabs = want;
     if (slabs * chunks * img > ws_floats) slabs = ws_floats / (chunks * img);
     if (slabs > 520) slabs = 520;
