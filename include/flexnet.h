@@ -98,6 +98,9 @@ typedef struct {
     const float* z_id;         /* [n_agents, 64]         fc1's one-hot id columns, transposed */
     int32_t n_agents;          /* used with z_shared */
     int32_t pad1;
+    float* d_z_shared;         /* backward, composed input: out [rows / n_agents, 64] = sum over a sample's agents of dz1, or NULL */
+    float* d_z_id;             /* backward, composed input: out [n_agents, 64] = sum over samples of dz1, or NULL (both or none;
+                                * needs the workspace) */
     float* workspace;          /* backward: scratch for the per-block partial sums, or NULL */
     int64_t workspace_floats;  /* >= FLEXNET_CRITIC_WS_FLOATS: the parameter gradients are then reduced in a fixed order
                                 * (bit-reproducible) by a second small launch; otherwise with atomics */

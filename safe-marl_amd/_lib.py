@@ -77,7 +77,8 @@ class FlexCriticTailArgs(C.Structure):
     _fields_ = [("rows", C.c_int32), ("layernorm", C.c_int32), ("ln_eps", C.c_float), ("variant", C.c_int32)] + \
                [(k, C.c_void_p) for k in ("z1", "ln_w", "ln_b", "fc2_w", "fc2_b", "fc3_w", "fc3_b", "q", "dq", "dz1",
                                           "d_ln_w", "d_ln_b", "d_fc2_w", "d_fc2_b", "d_fc3_w", "d_fc3_b", "z_shared", "z_id")] + \
-               [("n_agents", C.c_int32), ("pad1", C.c_int32), ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
+               [("n_agents", C.c_int32), ("pad1", C.c_int32), ("d_z_shared", C.c_void_p), ("d_z_id", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
 
 
 FLEXNET_CRITIC_WS_FLOATS = 1024 * 4416

@@ -680,6 +680,71 @@ static int critic_mfma_grid(int rows) {
     return tiles < cus ? tiles : cus;                    // one block per CU (it stages W2 once); tiles spread over blocks first
 }
 
+// ---- composed input: dz1 folded back onto its two sources in one pass over dz1 ---------------------------------------
+// d_z_shared[b] = sum_i dz1[b n + i] (stored), d_z_id[i] = sum_b dz1[b n + i] (per-block partial rows in the workspace,
+// then summed over blocks in a fixed order) — instead of two library reductions that each read dz1 again.
+#define DZF_W 4
+#define DZF_PITCH (FLEXNET_MAX_AGENTS * HID)
+__global__ __launch_bounds__(64 * DZF_W) void critic_dz_fold_kernel(FlexCriticTailArgs a) {
+    __shared__ float fold[DZF_W][DZF_PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = a.n_agents, samples = a.rows / n;
+    float acc[FLEXNET_MAX_AGENTS];
+#pragma unroll
+    for (int i = 0; i < FLEXNET_MAX_AGENTS; ++i) acc[i] = 0.0f;
+    for (int b = blockIdx.x * DZF_W + wave; b < samples; b += gridDim.x * DZF_W) {
+        const float* p = a.dz1 + (int64_t)b * n * HID + lane;
+        float v[FLEXNET_MAX_AGENTS];
+#pragma unroll
+        for (int i = 0; i < FLEXNET_MAX_AGENTS; ++i) v[i] = i < n ? p[i * HID] : 0.0f;
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < FLEXNET_MAX_AGENTS; ++i) { s += v[i]; acc[i] += v[i]; }
+        a.d_z_shared[(int64_t)b * HID + lane] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < FLEXNET_MAX_AGENTS; ++i) fold[wave][i * HID + lane] = acc[i];
+    __syncthreads();
+    float* out = a.workspace + (int64_t)blockIdx.x * DZF_PITCH;
+    for (int e = threadIdx.x; e < DZF_PITCH; e += 64 * DZF_W) {
+        float t = fold[0][e];
+#pragma unroll
+        for (int w = 1; w < DZF_W; ++w) t += fold[w][e];
+        out[e] = t;
+    }
+}
+
+__global__ __launch_bounds__(64 * RED_G) void critic_dz_reduce_kernel(FlexCriticTailArgs a, int blocks) {
+    __shared__ float part[RED_G][64];
+    const int ex = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + ex;                                   // agent blockIdx.x, unit ex
+    const float* src = a.workspace + e;
+    float s0 = 0.0f, s1 = 0.0f;
+    int b = gy;
+    for (; b + RED_G < blocks; b += 2 * RED_G) {
+        s0 += src[(int64_t)b * DZF_PITCH];
+        s1 += src[(int64_t)(b + RED_G) * DZF_PITCH];
+    }
+    if (b < blocks) s0 += src[(int64_t)b * DZF_PITCH];
+    part[gy][ex] = s0 + s1;
+    __syncthreads();
+    if (gy != 0) return;
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < RED_G; ++k) sum += part[k][ex];
+    a.d_z_id[e] = sum;
+}
+
+static int critic_dz_fold(const FlexCriticTailArgs& k, hipStream_t stream) {
+    const int samples = k.rows / k.n_agents;
+    int blocks = (samples + DZF_W - 1) / DZF_W;
+    if (blocks > 1024) blocks = 1024;
+    if ((int64_t)blocks * DZF_PITCH > k.workspace_floats) return FLEXNET_EINVAL;
+    hipLaunchKernelGGL(critic_dz_fold_kernel, dim3(blocks), dim3(64 * DZF_W), 0, stream, k);
+    hipLaunchKernelGGL(critic_dz_reduce_kernel, dim3(k.n_agents), dim3(64 * RED_G), 0, stream, k, blocks);
+    return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}
+
 static int critic_check(const FlexCriticTailArgs* a, bool backward) {
     if (!a || a->rows < 0) return FLEXNET_EINVAL;
     if (!a->fc2_w || !a->fc2_b || !a->fc3_w || !a->fc3_b || (a->layernorm && (!a->ln_w || !a->ln_b)))
@@ -687,6 +752,8 @@ static int critic_check(const FlexCriticTailArgs* a, bool backward) {
     if (!a->z1 && (!a->z_shared || !a->z_id || a->n_agents < 1 || a->rows % a->n_agents != 0)) return FLEXNET_EINVAL;
     if (!backward && !a->q) return FLEXNET_EINVAL;
     if (backward && (!a->dq || !a->dz1)) return FLEXNET_EINVAL;
+    if (backward && ((a->d_z_shared != nullptr) != (a->d_z_id != nullptr))) return FLEXNET_EINVAL;
+    if (backward && a->d_z_shared && (a->z1 || !a->workspace || a->n_agents > FLEXNET_MAX_AGENTS)) return FLEXNET_EINVAL;
     // parameter gradients: all of them, or none (d_fc2_w == NULL: dz1 only)
     if (backward && a->d_fc2_w && (!a->d_fc2_b || !a->d_fc3_w || !a->d_fc3_b || (a->layernorm && (!a->d_ln_w || !a->d_ln_b))))
         return FLEXNET_EINVAL;
@@ -722,10 +789,18 @@ extern "C" int flexnet_critic_tail_forward(const FlexCriticTailArgs* a, void* st
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 
+static int critic_tail_backward_main(const FlexCriticTailArgs* a, void* stream);
+
 extern "C" int flexnet_critic_tail_backward(const FlexCriticTailArgs* a, void* stream) {
     const int rc = critic_check(a, true);
     if (rc != FLEXNET_OK) return rc;
     if (a->rows == 0) return FLEXNET_OK;
+    const int rm = critic_tail_backward_main(a, stream);
+    if (rm != FLEXNET_OK || !a->d_z_shared) return rm;
+    return critic_dz_fold(*a, (hipStream_t)stream);        // after the main launches: it reuses their workspace
+}
+
+static int critic_tail_backward_main(const FlexCriticTailArgs* a, void* stream) {
     FlexCriticTailArgs k = *a;
     if (!k.d_fc2_w && k.variant == 0 && k.rows >= CRITIC_MFMA_MIN_ROWS) {
         const int nb = critic_mfma_grid(k.rows);

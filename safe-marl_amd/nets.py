@@ -508,11 +508,13 @@ class _CriticTailComposedFn(th.autograd.Function):
             args.d_ln_w, args.d_ln_b = d_g.data_ptr(), d_b.data_ptr()
         ws = _critic_workspace(shared.device)
         args.workspace, args.workspace_floats = ws.data_ptr(), ws.numel()
+        d_shared = th.empty_like(shared)
+        d_id = th.empty(n, 64, dtype=th.float32, device=shared.device)
+        args.d_z_shared, args.d_z_id = d_shared.data_ptr(), d_id.data_ptr()
         _lib.check(lib.flexnet_critic_tail_backward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
                    "flexnet_critic_tail_backward")
-        dz = dz1.view(-1, n, 64)
         has_ln = ln_w is not None
-        return (dz.sum(1), dz.sum(0), (d_g if has_ln else None), (d_b if has_ln else None), d_w2, d_b2, d_w3, d_b3, None)
+        return (d_shared, d_id, (d_g if has_ln else None), (d_b if has_ln else None), d_w2, d_b2, d_w3, d_b3, None)
 
 
 class _CriticReplayedFn(th.autograd.Function):
@@ -565,14 +567,15 @@ class _CriticReplayedFn(th.autograd.Function):
             args.d_ln_w, args.d_ln_b = d_g.data_ptr(), d_b.data_ptr()
         ws = _critic_workspace(shared.device)
         args.workspace, args.workspace_floats = ws.data_ptr(), ws.numel()
+        d_shared = th.empty_like(shared)                    # dz1 folded onto its two sources by the same call
+        d_id = th.empty(n, 64, dtype=th.float32, device=shared.device)
+        args.d_z_shared, args.d_z_id = d_shared.data_ptr(), d_id.data_ptr()
         _lib.check(lib.flexnet_critic_tail_backward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
                    "flexnet_critic_tail_backward")
-        dz = dz1.view(-1, n, 64)
-        d_shared = dz.sum(1)
         dW = th.empty_like(W)
         d_bias = th.empty(64, dtype=th.float32, device=W.device)
         tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias)
-        dW[:, no:no + n] = dz.sum(0).t()
+        dW[:, no:no + n] = d_id.t()
         tall_wgrad(d_shared, act2d, out=dW[:, no + n:no + n + na_])
         if W.shape[1] > no + n + na_:
             dW[:, no + n + na_:] = 0.0
