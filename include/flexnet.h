@@ -183,6 +183,32 @@ typedef struct {
 
 int flexnet_clip_rmsprop(const FlexClipRmspropArgs* args, void* stream);
 
+/* The value loss of madrl/models/maddpg.py:100-123 behind model.py:308-323's reward normalisation, and its gradient:
+ *     r = BatchNorm1d(n)(reward) [train mode];  ret = r + gamma (1 - done) next_q;  loss = mean((ret - q)^2);
+ *     dq = dLoss/dq = -2 (ret - q) / (rows n).   The module's running statistics move as nn.BatchNorm1d moves them. */
+typedef struct {
+    int32_t rows, n_agents;    /* [rows, n_agents] tensors; n_agents <= FLEXNET_MAX_AGENTS */
+    int32_t normalise;         /* args.reward_normalisation */
+    float gamma, bn_eps, bn_momentum;
+    const float* reward;       /* [rows, n] raw */
+    const float* done;         /* [rows] 0/1 */
+    const float* next_q;       /* [rows, n] bootstrap values (no gradient) */
+    const float* q;            /* [rows, n] */
+    const float* bn_weight;    /* [n] or NULL (1) */
+    const float* bn_bias;      /* [n] or NULL (0) */
+    float* running_mean;       /* [n] updated in place, or NULL */
+    float* running_var;        /* [n] */
+    int64_t* num_batches_tracked; /* += 1, or NULL */
+    float* dq;                 /* out [rows, n] */
+    float* loss;               /* out [1] */
+    float* workspace;          /* 8-byte aligned */
+    int64_t workspace_floats;  /* >= FLEXNET_TD_WS_FLOATS */
+} FlexTdLossArgs;
+
+#define FLEXNET_TD_WS_FLOATS (2 * (64 * 2 * 8 + 64))
+
+int flexnet_td_loss(const FlexTdLossArgs* args, void* stream);
+
 /* One vector step's bookkeeping of the rollout (madrl/models/model.py:230-262 per environment, utils/replay_buffer.py:
  * 23-27): the transition record [state | action | reward | next_state | done | last_step | last_hid | hid] lands in a
  * packed staging row per environment (the replay ring takes it with one copy), the observation and the hidden state are

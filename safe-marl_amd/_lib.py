@@ -59,7 +59,7 @@ SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
-    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop",
+    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss",
 )
 
 class FlexActorArgs(C.Structure):
@@ -115,6 +115,18 @@ class FlexClipRmspropArgs(C.Structure):
                 ("step", C.c_void_p * FLEXNET_OPT_MAX_TENSORS)]
 
 
+class FlexTdLossArgs(C.Structure):
+    """include/flexnet.h"""
+    _fields_ = [("rows", C.c_int32), ("n_agents", C.c_int32), ("normalise", C.c_int32), ("gamma", C.c_float),
+                ("bn_eps", C.c_float), ("bn_momentum", C.c_float)] + \
+               [(k, C.c_void_p) for k in ("reward", "done", "next_q", "q", "bn_weight", "bn_bias", "running_mean",
+                                          "running_var", "num_batches_tracked", "dq", "loss", "workspace")] + \
+               [("workspace_floats", C.c_int64)]
+
+
+FLEXNET_TD_WS_FLOATS = 2 * (64 * 2 * 8 + 64)
+
+
 class FlexRolloutPackArgs(C.Structure):
     """include/flexnet.h"""
     _fields_ = [(k, C.c_int32) for k in ("n_envs", "n_agents", "obs_dim", "act_dim", "rec_stride", "col_state", "col_action",
@@ -166,6 +178,8 @@ def load():
     lib.flexnet_wgrad.restype = C.c_int
     lib.flexnet_clip_rmsprop.argtypes = [C.POINTER(FlexClipRmspropArgs), vp]
     lib.flexnet_clip_rmsprop.restype = C.c_int
+    lib.flexnet_td_loss.argtypes = [C.POINTER(FlexTdLossArgs), vp]
+    lib.flexnet_td_loss.restype = C.c_int
     for fn in (lib.flexnet_lnrelu_forward, lib.flexnet_lnrelu_backward):
         fn.argtypes = [C.POINTER(FlexLnReluArgs), vp]
         fn.restype = C.c_int

@@ -20,7 +20,7 @@ import torch as th
 import torch.nn as nn
 
 from .nets import (WGRAD_MIN_ROWS, CriticTail, MLPAgent, MLPCritic, RNNAgent, critic_replayed_supported,
-                   critic_tail_supported, fused_actor_forward, wide_batch_linear)
+                   critic_tail_supported, fused_actor_forward, td_loss, td_loss_supported, wide_batch_linear)
 from .replay_buffer import Transition
 from .util import prep_obs, scale_action, select_action, translate_action
 
@@ -255,16 +255,18 @@ class Model(nn.Module):
             self.update_target()
 
     # -- batches -----------------------------------------------------------------------------------------
-    def unpack_data(self, batch):
+    def unpack_data(self, batch, normalise_reward=True):
         """model.py:308-323.  ``batch`` is a Transition of device tensors (replay_buffer.window) or, for
-        callers written against the reference, a Transition of per-sample tuples (trainer.py:68)."""
+        callers written against the reference, a Transition of per-sample tuples (trainer.py:68).
+        ``normalise_reward=False`` hands the raw reward on: the caller applies the BatchNorm itself (the fused value
+        loss does, together with the running-statistics update — exactly once per get_loss call either way)."""
         if not isinstance(batch.reward, th.Tensor):
             batch = Transition(*[th.stack([th.as_tensor(np.asarray(x), dtype=th.float32) for x in f]).to(self.device)
                                  for f in batch])
             # model.py:312-320 concatenates the [1, n, x] per-step arrays along axis 0
             batch = Transition(*[f.squeeze(1) if f.dim() == 4 else f for f in batch])
         reward = batch.reward.float()
-        if self.args.reward_normalisation:
+        if self.args.reward_normalisation and normalise_reward:
             # train-mode batch statistics (running stats still update).  The affine pair is in no optimiser
             # (trainer.py:34-35), so its gradient is never used: taking it out of the graph removes a
             # batch-norm backward over [batch, n] that cost 31 % of a value sub-update.
@@ -584,7 +586,11 @@ class MADDPG(Model):
         The reference evaluates both losses in every sub-update and uses one (trainer.py:84,101).  ``need`` =
         "value" / "policy" evaluates only the graph that loss needs — same loss value, same gradients, about half
         the forward work and no backward through the unused half; "both" is the reference's call."""
-        state, actions, _, _, _, rewards, next_state, done, _, actions_avail, last_hids, hids = self.unpack_data(batch)
+        # value loss alone on the GPU: reward normalisation, TD target, loss and dLoss/dQ are csrc/tdloss.hip
+        fused_td = (need == "value" and isinstance(batch.reward, th.Tensor) and batch.reward.is_cuda
+                    and self.fused_inference and th.is_grad_enabled())
+        state, actions, _, _, _, rewards, next_state, done, _, actions_avail, last_hids, hids = \
+            self.unpack_data(batch, normalise_reward=not fused_td)
         policy_loss = value_loss = None
         action_out = None
         if need in ("both", "policy"):
@@ -602,9 +608,16 @@ class MADDPG(Model):
                                                             last_hid=hids)
                 next_values = self.target_net.value(next_state, next_actions).view(-1, self.n_)
             values = self.value(state, actions).view(-1, self.n_)
-            returns = rewards + self.args.gamma * (1 - done) * next_values
-            assert returns.size() == values.size()
-            value_loss = (returns - values).pow(2).mean()
+            bn = self.batchnorm if self.args.reward_normalisation else None
+            if fused_td and td_loss_supported(values, next_values, rewards, done, bn):
+                value_loss = td_loss(values, next_values, rewards, done, self.args.gamma, bn)
+            else:
+                if fused_td and bn is not None:                 # the raw reward was handed on: normalise it here
+                    with th.no_grad():
+                        rewards = bn(rewards.contiguous())
+                returns = rewards + self.args.gamma * (1 - done) * next_values
+                assert returns.size() == values.size()
+                value_loss = (returns - values).pow(2).mean()
         return policy_loss, value_loss, action_out
 
 

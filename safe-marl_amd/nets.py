@@ -282,6 +282,67 @@ def tall_linear(x, w, b=None):
     return F.linear(x, w, b)
 
 
+_TD_WS = {}
+
+
+class _TdLossFn(th.autograd.Function):
+    """mean((BatchNorm(reward) + gamma (1 - done) next_q - q)^2) (maddpg.py:100-123 behind model.py:308-323) with its
+    gradient w.r.t. q, in three small launches (csrc/tdloss.hip); the BatchNorm module's running statistics are
+    updated in place as its own forward would."""
+
+    @staticmethod
+    def forward(ctx, q, next_q, reward, done, gamma, bn):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        rows, n = reward.shape
+        q2, nq, r, d = q.reshape(rows, n).contiguous(), next_q.reshape(rows, n).contiguous(), reward.contiguous(), \
+            done.reshape(rows).contiguous()
+        dq = th.empty_like(q2)
+        loss = th.empty((), dtype=th.float32, device=q.device)
+        if q.device not in _TD_WS:
+            _TD_WS[q.device] = th.empty(_lib.FLEXNET_TD_WS_FLOATS // 2, dtype=th.float64, device=q.device)
+        ws = _TD_WS[q.device]
+        a = _lib.FlexTdLossArgs()
+        a.rows, a.n_agents, a.normalise, a.gamma = rows, n, int(bn is not None), float(gamma)
+        a.reward, a.done, a.next_q, a.q = r.data_ptr(), d.data_ptr(), nq.data_ptr(), q2.data_ptr()
+        if bn is not None:
+            a.bn_eps, a.bn_momentum = float(bn.eps), float(bn.momentum)
+            if bn.affine:
+                a.bn_weight, a.bn_bias = bn.weight.data_ptr(), bn.bias.data_ptr()
+            if bn.track_running_stats:
+                a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                a.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+        a.dq, a.loss = dq.data_ptr(), loss.data_ptr()
+        a.workspace, a.workspace_floats = ws.data_ptr(), 2 * ws.numel()
+        _lib.check(lib.flexnet_td_loss(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_td_loss")
+        ctx.save_for_backward(dq)
+        ctx.q_shape = q.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (dq,) = ctx.saved_tensors
+        return (dq * grad_loss).view(ctx.q_shape), None, None, None, None, None
+
+
+def td_loss_supported(q, next_q, reward, done, bn):
+    """The fused value loss covers fp32 GPU tensors, up to 8 agents, and a BatchNorm1d in training mode with momentum
+    (or no normalisation at all)."""
+    ok = (q.is_cuda and q.dtype == th.float32 and next_q.dtype == th.float32 and reward.dtype == th.float32
+          and done.dtype == th.float32 and reward.dim() == 2 and 1 <= reward.shape[1] <= 8 and reward.shape[0] >= 1
+          and q.numel() == reward.numel() and next_q.numel() == reward.numel() and done.numel() == reward.shape[0]
+          and not next_q.requires_grad)
+    if bn is not None:
+        ok = ok and bn.training and bn.momentum is not None and isinstance(bn, nn.BatchNorm1d) \
+            and bn.num_features == reward.shape[1] and (not bn.track_running_stats or bn.running_mean.dtype == th.float32)
+    return bool(ok)
+
+
+def td_loss(q, next_q, reward, done, gamma, bn=None):
+    return _TdLossFn.apply(q, next_q, reward, done, gamma, bn)
+
+
 _LNRELU_WS = {}
 
 

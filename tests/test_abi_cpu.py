@@ -46,6 +46,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.FlexRolloutPackArgs) == 16 * 4 + 16 * 8
     assert C.sizeof(_lib.FlexWgradArgs) == 4 * 8 + 4 * 4 + 5 * 8
     assert C.sizeof(_lib.FlexLnReluArgs) == 4 * 4 + 13 * 8 + 8
+    assert C.sizeof(_lib.FlexTdLossArgs) == 6 * 4 + 12 * 8 + 8
     assert C.sizeof(_lib.FlexClipRmspropArgs) == 6 * 4 + 2 * 8 + 5 * 16 * 8
 
 

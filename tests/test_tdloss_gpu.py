@@ -1,0 +1,89 @@
+"""csrc/tdloss.hip (include/flexnet.h: flexnet_td_loss) — the value loss of maddpg.py:100-123 behind the reward
+normalisation of model.py:308-323, its gradient, and the BatchNorm running statistics — against PyTorch."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_loss(q, next_q, reward, done, gamma, bn):
+    r = reward
+    if bn is not None:
+        with torch.no_grad():
+            r = bn(reward)
+    ret = r + gamma * (1 - done.view(-1, 1)) * next_q
+    return (ret - q).pow(2).mean()
+
+
+@pytest.mark.parametrize("rows,n,norm", [(32768, 5, True), (4099, 3, True), (2, 8, True), (1000, 5, False), (1, 1, False)])
+def test_loss_gradient_and_running_statistics(rows, n, norm):
+    from safe_marl_amd.nets import td_loss, td_loss_supported
+    g = torch.Generator(device="cuda").manual_seed(rows + n)
+    reward = torch.randn(rows, n, device="cuda", generator=g) * 3.0 - 5.0
+    done = (torch.rand(rows, device="cuda", generator=g) < 0.1).float()
+    next_q = torch.randn(rows, n, device="cuda", generator=g)
+    q0 = torch.randn(rows, n, device="cuda", generator=g)
+    bns = []
+    for _ in range(2):
+        bn = None
+        if norm:
+            bn = torch.nn.BatchNorm1d(n).cuda()
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, n)); bn.bias.copy_(torch.linspace(-0.2, 0.2, n))
+                bn.running_mean.fill_(0.3); bn.running_var.fill_(2.0)
+        bns.append(bn)
+    qa, qb = q0.clone().requires_grad_(True), q0.clone().requires_grad_(True)
+    assert td_loss_supported(qa, next_q, reward, done, bns[0])
+    la = td_loss(qa, next_q, reward, done, 0.99, bns[0])
+    lb = _torch_loss(qb, next_q, reward, done, 0.99, bns[1])
+    ga, = torch.autograd.grad(la * 1.7, [qa])                  # an upstream factor, as a scaled loss would give
+    gb, = torch.autograd.grad(lb * 1.7, [qb])
+    assert abs(la.item() - lb.item()) <= 2e-5 * max(1.0, abs(lb.item()))
+    assert (ga - gb).abs().max().item() <= 2e-5 * max(1e-9, gb.abs().max().item())
+    if norm:
+        assert torch.allclose(bns[0].running_mean, bns[1].running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(bns[0].running_var, bns[1].running_var, rtol=1e-5, atol=1e-6)
+        assert bns[0].num_batches_tracked.item() == bns[1].num_batches_tracked.item() == 1
+
+
+def test_get_loss_value_branch_matches_the_pytorch_composition():
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd import learner
+    from safe_marl_amd.replay_buffer import Transition
+    from safe_marl_amd.util import convert
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="maddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4)
+    b = 4096
+    g = torch.Generator(device="cuda").manual_seed(12)
+    fields = dict(state=torch.randn(b, 5, 144, device="cuda", generator=g), action=torch.rand(b, 5, 4, device="cuda", generator=g),
+                  log_prob_a=torch.zeros(b, 5, 4, device="cuda"), value=torch.zeros(b, 5, 1, device="cuda"),
+                  next_value=torch.zeros(b, 5, 1, device="cuda"), reward=torch.randn(b, 5, device="cuda", generator=g),
+                  next_state=torch.randn(b, 5, 144, device="cuda", generator=g),
+                  done=(torch.rand(b, device="cuda", generator=g) < 0.05).float(), last_step=torch.zeros(b, device="cuda"),
+                  action_avail=torch.ones(b, 5, 4, device="cuda"), last_hid=torch.randn(b, 5, 64, device="cuda", generator=g),
+                  hid=torch.randn(b, 5, 64, device="cuda", generator=g))
+    batch = Transition(**fields)
+    out = []
+    for fused in (True, False):
+        torch.manual_seed(5)
+        m = learner.MADDPG(convert(alg), learner.MADDPG(convert(alg)).cuda()).cuda()
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn_like(p) * 0.1)
+        saved = learner.td_loss_supported
+        if not fused:
+            learner.td_loss_supported = lambda *a, **k: False
+        try:
+            _, vloss, _ = m.get_loss(batch, need="value")
+            grads = torch.autograd.grad(vloss, list(m.value_dicts.parameters()))
+        finally:
+            learner.td_loss_supported = saved
+        out.append((vloss.detach(), grads, m.batchnorm.running_mean.clone(), m.batchnorm.running_var.clone(),
+                    int(m.batchnorm.num_batches_tracked)))
+    assert abs(out[0][0].item() - out[1][0].item()) <= 1e-5 * max(1.0, abs(out[1][0].item()))
+    for a, e in zip(out[0][1], out[1][1]):
+        assert (a - e).abs().max().item() <= 1e-4 * max(1e-6, e.abs().max().item())
+    assert torch.allclose(out[0][2], out[1][2], rtol=1e-5, atol=1e-6) and torch.allclose(out[0][3], out[1][3], rtol=1e-5, atol=1e-6)
+    assert out[0][4] == out[1][4] == 1
