@@ -738,7 +738,7 @@ __global__ __launch_bounds__(64 * RED_G) void critic_dz_reduce_kernel(FlexCritic
 static int critic_dz_fold(const FlexCriticTailArgs& k, hipStream_t stream) {
     const int samples = k.rows / k.n_agents;
     int blocks = (samples + DZF_W - 1) / DZF_W;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;                      // one per CU: the second stage walks one partial row per block
     if ((int64_t)blocks * DZF_PITCH > k.workspace_floats) return FLEXNET_EINVAL;
     hipLaunchKernelGGL(critic_dz_fold_kernel, dim3(blocks), dim3(64 * DZF_W), 0, stream, k);
     hipLaunchKernelGGL(critic_dz_reduce_kernel, dim3(k.n_agents), dim3(64 * RED_G), 0, stream, k, blocks);

@@ -22,7 +22,6 @@
 #define TD_WS_SQ (TD_BLOCKS * 2 * TD_NA)
 
 __global__ __launch_bounds__(TD_THREADS) void td_stats_kernel(FlexTdLossArgs a) {
-    __shared__ double red[TD_THREADS];
     const int tid = threadIdx.x, n = a.n_agents;
     double s[TD_NA], ss[TD_NA];
 #pragma unroll
@@ -33,16 +32,22 @@ __global__ __launch_bounds__(TD_THREADS) void td_stats_kernel(FlexTdLossArgs a) 
         for (int j = 0; j < TD_NA; ++j)
             if (j < n) { const double v = (double)r[j]; s[j] += v; ss[j] += v * v; }
     }
-    double* ws = reinterpret_cast<double*>(a.workspace) + (int64_t)blockIdx.x * 2 * TD_NA;
-    for (int q = 0; q < 2 * TD_NA; ++q) {                        // sixteen block reductions: 650 KB of input, nobody is waiting
-        red[tid] = q < TD_NA ? s[q] : ss[q - TD_NA];
-        __syncthreads();
-        for (int sft = TD_THREADS / 2; sft > 0; sft >>= 1) {
-            if (tid < sft) red[tid] += red[tid + sft];
-            __syncthreads();
-        }
-        if (tid == 0) ws[q] = red[0];
-        __syncthreads();
+    // wavefront sums by shuffles (fixed tree), then the block's four wavefronts in index order
+    __shared__ double part[TD_THREADS / 64][2 * TD_NA];
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 2 * TD_NA; ++q) {
+        double v = q < TD_NA ? s[q < TD_NA ? q : 0] : ss[q < TD_NA ? 0 : q - TD_NA];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) part[wave][q] = v;
+    }
+    __syncthreads();
+    if (tid < 2 * TD_NA) {
+        double t = part[0][tid];
+#pragma unroll
+        for (int w = 1; w < TD_THREADS / 64; ++w) t += part[w][tid];
+        reinterpret_cast<double*>(a.workspace)[(int64_t)blockIdx.x * 2 * TD_NA + tid] = t;
     }
 }
 

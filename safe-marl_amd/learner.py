@@ -212,15 +212,14 @@ class Model(nn.Module):
         if fused is not None:
             means = fused[0].view(b, self.n_, -1)
             hiddens = fused[1].view(b, self.n_, -1)
-            log_stds = th.full_like(means, float(np.log(self.args.fixed_policy_std)))
-            return means, log_stds, hiddens
+            return means, self._log_stds_like(means), hiddens
         if (self.args.shared_params and obs.is_cuda and th.is_grad_enabled() and self.fused_inference
                 and b * self.n_ >= WGRAD_MIN_ROWS and isinstance(self.policy_dicts[0], RNNAgent)):
             # update batches: no id concat (the id block of fc1 is an addend per agent), fused LayerNorm/ReLU pass
             out = self.policy_dicts[0].forward_update(obs.reshape(b * self.n_, -1), last_hid, self.n_, self.args.agent_id)
             if out is not None:
                 means, hiddens = out[0].view(b, self.n_, -1), out[2].view(b, self.n_, -1)
-                return means, th.full_like(means, float(np.log(self.args.fixed_policy_std))), hiddens
+                return means, self._log_stds_like(means), hiddens
         if self.args.agent_id:
             ids = th.eye(self.n_, device=obs.device, dtype=obs.dtype).expand(b, -1, -1)
             obs = th.cat((obs, ids), dim=-1)
@@ -233,8 +232,16 @@ class Model(nn.Module):
             means = th.stack([o[0] for o in outs], dim=1)
             hiddens = th.stack([o[2] for o in outs], dim=1)
         # fixed_policy_std (model.py:121-123): log(1.0) = 0 at the default config
-        log_stds = th.full_like(means, float(np.log(self.args.fixed_policy_std)))
-        return means, log_stds, hiddens
+        return means, self._log_stds_like(means), hiddens
+
+    def _log_stds_like(self, means):
+        """fixed_policy_std (model.py:121-123) as a broadcast view of ONE cached element per device — a fill kernel per
+        policy call otherwise; nothing downstream writes into it."""
+        cache = self.__dict__.setdefault("_log_std_cache", {})
+        if means.device not in cache:
+            cache[means.device] = th.full((1,), float(np.log(self.args.fixed_policy_std)), dtype=means.dtype,
+                                          device=means.device)
+        return cache[means.device].expand_as(means)
 
     # -- update cadence (model.py:40-71) -----------------------------------------------------------
     def transition_update(self, trainer, trans, stat):
@@ -576,8 +583,11 @@ class MADDPG(Model):
         means, log_stds, hiddens = pol(state, last_hid=last_hid)
         actions, log_prob_a = select_action(self.args, means, status=status, exploration=exploration,
                                             info={"log_std": log_stds})
-        restore_mask = 1.0 - (actions_avail.to(means.device) == 0).float()
-        restore_actions = restore_mask * actions
+        if getattr(actions_avail, "_flex_const", None) == 1.0:      # every action available (env:721-730): the mask is 1
+            restore_actions = actions
+        else:
+            restore_mask = 1.0 - (actions_avail.to(means.device) == 0).float()
+            restore_actions = restore_mask * actions
         return actions, restore_actions, log_prob_a, (means, log_stds), hiddens
 
     def get_loss(self, batch, need="both"):

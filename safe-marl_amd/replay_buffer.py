@@ -149,6 +149,7 @@ class DeviceReplayBuffer:
         for k, c in self.consts.items():
             shape = self.const_shapes.get(k, ())
             out[k] = th.full((1,) + tuple(1 for _ in shape), float(c), device=self.device).expand((batch_size,) + tuple(shape))
+            out[k]._flex_const = float(c)          # readers may skip work that a known constant makes the identity
         if p0 + batch_size <= self.size:
             out.update({k: v[p0:p0 + batch_size] for k, v in self.store.items()})
         else:

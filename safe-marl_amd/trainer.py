@@ -134,6 +134,7 @@ class PGTrainer(object):
         for k, c in buf.consts.items():
             shape = buf.const_shapes.get(k, ())
             fields[k] = th.full((1,) + tuple(1 for _ in shape), float(c), device=self.device).expand((bs,) + tuple(shape))
+            fields[k]._flex_const = float(c)
         batch = Transition(**fields)
         out = {}
         # the warm-up steps are real optimiser steps: everything they touch is put back afterwards, IN PLACE (the graph

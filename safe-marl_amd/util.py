@@ -31,10 +31,10 @@ def select_action(args, logits, status="train", exploration=True, info={}):
     if not args.continuous:
         raise NotImplementedError("discrete control is outside the flexibility-provision hot path")
     act_mean = logits
-    act_std = info["log_std"].exp()
     if status == "train":
         if not exploration:
             return act_mean, None
+        act_std = info["log_std"].exp()
         if args.action_enforcebound:
             normal = Normal(act_mean, act_std, validate_args=False)   # validation is a device reduction + host sync
             x_t = normal.rsample()
