@@ -269,6 +269,26 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
     const int rb = lane & 31, hf = lane >> 5;
     const int od = a.obs_dim, na = a.n_agents, ad = a.act_dim;
     const int ld1 = od + (a.agent_id ? na : 0);
+    // observations through a buffer descriptor: 16-byte loads at dword alignment, zeros past the end of the tensor.
+    // The first tile's first six column groups are requested before the weights are staged, every later tile's at the
+    // end of the previous tile's fc1: the load latency never sits at the head of a tile.
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    constexpr int QB = 6;
+    const int64_t obs_bytes = (int64_t)a.rows * od * 4;
+    const __amdgpu_buffer_rsrc_t robs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.obs), 0, obs_bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)obs_bytes, 0x00027000);
+    const int nq = (od + 7) >> 3;
+    const int n_tiles = (a.rows + 31) / 32;
+    // tile t goes to block t % grid, wavefront (t / grid) % MW: a small batch spreads over all CUs first
+    int tile = wave * gridDim.x + blockIdx.x;
+    v4f_ xc[QB];
+    {
+        const int xoff0 = (min(tile * 32 + rb, a.rows - 1) * od + 4 * hf) * 4;
+#pragma unroll
+        for (int e = 0; e < QB; ++e)
+            xc[e] = __builtin_bit_cast(v4f_, __builtin_amdgcn_raw_buffer_load_b128(
+                robs, tile < n_tiles && e < nq ? xoff0 + 32 * e : -1, 0, 0));
+    }
     // Weights -> LDS (transposed).  All global reads of a thread are issued before the first LDS write — 12 + up to 5
     // 16-byte loads in one round trip instead of ~66 scalar loads in rounds of 6-8: the staging was a third of a
     // rollout-sized call (20 480 rows: 37 -> 2x us).  fc1's rows (pitch ld1 floats, any dword alignment) go through a
@@ -347,15 +367,8 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
     const float* lnb_l = s.lnb + 4 * hf;
     const float* w2p_l = s.w2p + (4 * hf) * 32 + rb;
     const float* w1_l = s.w1t + (4 * hf) * P1 + rb;
-    // observations through a buffer descriptor: 16-byte loads at dword alignment, zeros past the end of the tensor
-    const int64_t obs_bytes = (int64_t)a.rows * od * 4;
-    const __amdgpu_buffer_rsrc_t robs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.obs), 0, obs_bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)obs_bytes, 0x00027000);
-    const int nq = (od + 7) >> 3;
     const uint64_t rng_seed = a.rng_state ? a.rng_state[0] : 0ull, rng_step = a.rng_state ? a.rng_state[1] : 0ull;
-    const int n_tiles = (a.rows + 31) / 32;
-    // tile t goes to block t % grid, wavefront (t / grid) % MW: a small batch spreads over all CUs first
-    for (int tile = wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * MW) {
+    for (; tile < n_tiles; tile += gridDim.x * MW) {
         const int r0 = tile * 32;
         const int row = min(r0 + rb, a.rows - 1);                    // this lane's batch row (both halves share it)
         // ---- fc1: z1[unit][row] ----------------------------------------------------------------------------------
@@ -368,13 +381,8 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
         // MFMA step (q, j) is (8q + j, 8q + 4 + j), as in the layers behind — so the observation goes from row-major memory
         // straight into B operands: no LDS hand-over, no barriers.  Six groups (24 registers) in flight, the next six
         // requested before the current ones are multiplied.
-        typedef float v4f_ __attribute__((ext_vector_type(4)));
-        constexpr int QB = 6;
         const int xoff = (row * od + 4 * hf) * 4;
-        v4f_ xc[QB], xn[QB];
-#pragma unroll
-        for (int e = 0; e < QB; ++e)
-            xc[e] = __builtin_bit_cast(v4f_, __builtin_amdgcn_raw_buffer_load_b128(robs, e < nq ? xoff + 32 * e : -1, 0, 0));
+        v4f_ xn[QB];
         for (int q0 = 0; q0 < nq; q0 += QB) {
 #pragma unroll
             for (int e = 0; e < QB; ++e)
@@ -394,6 +402,14 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
             }
 #pragma unroll
             for (int e = 0; e < QB; ++e) xc[e] = xn[e];
+        }
+        {   // the NEXT tile's first six groups go out now and land underneath LayerNorm and the GRU
+            const int nt = tile + gridDim.x * MW;
+            const int nxoff = (min(nt * 32 + rb, a.rows - 1) * od + 4 * hf) * 4;
+#pragma unroll
+            for (int e = 0; e < QB; ++e)
+                xc[e] = __builtin_bit_cast(v4f_, __builtin_amdgcn_raw_buffer_load_b128(
+                    robs, nt < n_tiles && e < nq ? nxoff + 32 * e : -1, 0, 0));
         }
         ASTAMP(2);
         // ---- + bias (+ id column), LayerNorm over the row's 64 units (32 here, 32 in the other half), ReLU ----
