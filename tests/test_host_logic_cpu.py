@@ -78,13 +78,18 @@ def test_constant_action_avail_mask_is_the_identity_it_replaces():
     assert log_stds.shape == means.shape and float(log_stds.max()) == float(np.log(m.args.fixed_policy_std))
 
 
-def test_update_fields_cover_what_each_loss_reads():
+import pytest
+
+
+@pytest.mark.parametrize("alg", ["maddpg", "matd3", "iddpg"])
+def test_update_fields_cover_what_each_loss_reads(alg):
     """MADDPG.update_fields lists the replay fields a graphed sub-update refreshes: poisoning every OTHER field must not
     change the loss (reward is read by both through the BatchNorm running statistics)."""
-    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd import learner
     from safe_marl_amd.replay_buffer import Transition
     torch.manual_seed(2)
-    m = MADDPG(_alg_args(), MADDPG(_alg_args()))
+    cls = {"maddpg": learner.MADDPG, "matd3": learner.MATD3, "iddpg": learner.IDDPG}[alg]
+    m = cls(_alg_args(alg=alg), cls(_alg_args(alg=alg)))
     b = 16
     g = torch.Generator().manual_seed(3)
     base = dict(state=torch.randn(b, 3, 12, generator=g), action=torch.rand(b, 3, 4, generator=g),
@@ -101,6 +106,7 @@ def test_update_fields_cover_what_each_loss_reads():
                 for k in stored:
                     if k not in m.update_fields[which]:
                         f[k] = torch.full_like(f[k], 123.0)
+            torch.manual_seed(9)                        # MATD3 smooths its target with noise
             p, v, _ = m.get_loss(Transition(**f), need=which)
             losses.append((v if which == "value" else p).item())
         assert losses[0] == losses[1], which
