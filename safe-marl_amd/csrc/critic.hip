@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "flexnet.h"
+#include "flex_reduce.h"
 
 #define HID FLEXNET_HID
 #define CRT 4                      // rows per wavefront tile
@@ -246,30 +247,11 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticT
 // second stage of the deterministic path: element e of every block's partial row, summed in a fixed order, ADDED to
 // the caller's gradient tensor.  64 elements x 16 block groups per thread block: each thread walks its group's rows
 // with eight loads in flight, the 16 group sums are folded through LDS in index order.
-#define RED_G 16
+#define RED_G FLEX_RED_G
 __global__ __launch_bounds__(64 * RED_G) void critic_reduce_kernel(FlexCriticTailArgs a, int blocks) {
-    __shared__ float part[RED_G][64];
-    const int ex = threadIdx.x & 63, gy = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + ex;
-    const int n_el = HID * HID + 4 * HID + 1;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    if (e < n_el) {
-        const float* src = a.workspace + e;
-        int b = gy;
-        for (; b + 3 * RED_G < blocks; b += 4 * RED_G) {
-            s0 += src[(int64_t)b * CRITIC_WS_PITCH];
-            s1 += src[(int64_t)(b + RED_G) * CRITIC_WS_PITCH];
-            s2 += src[(int64_t)(b + 2 * RED_G) * CRITIC_WS_PITCH];
-            s3 += src[(int64_t)(b + 3 * RED_G) * CRITIC_WS_PITCH];
-        }
-        for (; b < blocks; b += RED_G) s0 += src[(int64_t)b * CRITIC_WS_PITCH];
-    }
-    part[gy][ex] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (gy != 0 || e >= n_el) return;
-    float sum = 0.0f;
-#pragma unroll
-    for (int k = 0; k < RED_G; ++k) sum += part[k][ex];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    float sum;
+    if (!flex_reduce_rows(a.workspace + e, CRITIC_WS_PITCH, blocks, e < HID * HID + 4 * HID + 1, sum)) return;
     if (e < HID * HID) a.d_fc2_w[e] += sum;
     else if (e < HID * HID + HID) a.d_fc2_b[e - HID * HID] += sum;
     else if (e < HID * HID + 2 * HID) a.d_fc3_w[e - HID * HID - HID] += sum;
@@ -715,23 +697,9 @@ __global__ __launch_bounds__(64 * DZF_W) void critic_dz_fold_kernel(FlexCriticTa
 }
 
 __global__ __launch_bounds__(64 * RED_G) void critic_dz_reduce_kernel(FlexCriticTailArgs a, int blocks) {
-    __shared__ float part[RED_G][64];
-    const int ex = threadIdx.x & 63, gy = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + ex;                                   // agent blockIdx.x, unit ex
-    const float* src = a.workspace + e;
-    float s0 = 0.0f, s1 = 0.0f;
-    int b = gy;
-    for (; b + RED_G < blocks; b += 2 * RED_G) {
-        s0 += src[(int64_t)b * DZF_PITCH];
-        s1 += src[(int64_t)(b + RED_G) * DZF_PITCH];
-    }
-    if (b < blocks) s0 += src[(int64_t)b * DZF_PITCH];
-    part[gy][ex] = s0 + s1;
-    __syncthreads();
-    if (gy != 0) return;
-    float sum = 0.0f;
-#pragma unroll
-    for (int k = 0; k < RED_G; ++k) sum += part[k][ex];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);                   // agent blockIdx.x, unit ex
+    float sum;
+    if (!flex_reduce_rows(a.workspace + e, DZF_PITCH, blocks, true, sum)) return;
     a.d_z_id[e] = sum;
 }
 

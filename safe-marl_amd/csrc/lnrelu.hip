@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "flexnet.h"
+#include "flex_reduce.h"
 
 #define HID FLEXNET_HID
 #define LW 4                       // wavefronts per block
@@ -139,27 +140,11 @@ __global__ __launch_bounds__(64 * LW) void lnrelu_bwd_kernel(FlexLnReluArgs a) {
 }
 
 // element e of every block's partial row, summed in a fixed order, stored in the caller's gradient tensor
-#define LRED 16
+#define LRED FLEX_RED_G
 __global__ __launch_bounds__(64 * LRED) void lnrelu_reduce_kernel(FlexLnReluArgs a, int blocks) {
-    __shared__ float part[LRED][64];
-    const int ex = threadIdx.x & 63, gy = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + ex;                      // LN_PITCH is a multiple of 64
-    const float* src = a.workspace + e;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int b = gy;
-    for (; b + 3 * LRED < blocks; b += 4 * LRED) {
-        s0 += src[(int64_t)b * LN_PITCH];
-        s1 += src[(int64_t)(b + LRED) * LN_PITCH];
-        s2 += src[(int64_t)(b + 2 * LRED) * LN_PITCH];
-        s3 += src[(int64_t)(b + 3 * LRED) * LN_PITCH];
-    }
-    for (; b < blocks; b += LRED) s0 += src[(int64_t)b * LN_PITCH];
-    part[gy][ex] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (gy != 0) return;
-    float sum = 0.0f;
-#pragma unroll
-    for (int k = 0; k < LRED; ++k) sum += part[k][ex];
+    const int ex = threadIdx.x & 63;
+    float sum;
+    if (!flex_reduce_rows(a.workspace + blockIdx.x * 64 + ex, LN_PITCH, blocks, true, sum)) return;   // LN_PITCH % 64 == 0
     const int vec = blockIdx.x;                               // one 64-element vector per block
     if (vec == 0) { if (a.layernorm && a.d_ln_w) a.d_ln_w[ex] = sum; }
     else if (vec == 1) { if (a.layernorm && a.d_ln_b) a.d_ln_b[ex] = sum; }

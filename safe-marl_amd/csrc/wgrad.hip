@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "flexnet.h"
+#include "flex_reduce.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -181,28 +182,12 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
 }
 
 // element e of the slabs' register images, summed in a fixed order, stored at its place in C
-#define WG_RED 16
+#define WG_RED FLEX_RED_G
 template <int MT, int NT>
 __global__ __launch_bounds__(64 * WG_RED) void wgrad_reduce_kernel(WgradK p) {
-    __shared__ float part[WG_RED][64];
-    const int ex = threadIdx.x & 63, gy = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + ex;                       // < WG_IMG: the grid covers it exactly
-    const float* src = p.ws + (int64_t)blockIdx.y * p.slabs * WG_IMG(MT, NT) + e;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int b = gy;
-    for (; b + 3 * WG_RED < p.slabs; b += 4 * WG_RED) {
-        s0 += src[(int64_t)b * WG_IMG(MT, NT)];
-        s1 += src[(int64_t)(b + WG_RED) * WG_IMG(MT, NT)];
-        s2 += src[(int64_t)(b + 2 * WG_RED) * WG_IMG(MT, NT)];
-        s3 += src[(int64_t)(b + 3 * WG_RED) * WG_IMG(MT, NT)];
-    }
-    for (; b < p.slabs; b += WG_RED) s0 += src[(int64_t)b * WG_IMG(MT, NT)];
-    part[gy][ex] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (gy != 0) return;
-    float sum = 0.0f;
-#pragma unroll
-    for (int g = 0; g < WG_RED; ++g) sum += part[g][ex];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);        // < WG_IMG: the grid covers it exactly
+    float sum;
+    if (!flex_reduce_rows(p.ws + (int64_t)blockIdx.y * p.slabs * WG_IMG(MT, NT) + e, WG_IMG(MT, NT), p.slabs, true, sum)) return;
     // register image -> matrix position (v_mfma_f32_32x32x2_f32 result layout, tile rows / columns interleaved)
     const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
     const int ti = t / NT, tj = t - ti * NT;
@@ -216,25 +201,9 @@ __global__ __launch_bounds__(64 * WG_RED) void wgrad_reduce_kernel(WgradK p) {
 
 // column sums: element m of every block's partial row, in the same fixed order
 __global__ __launch_bounds__(64 * WG_RED) void wgrad_colsum_kernel(WgradK p, int pitch) {
-    __shared__ float part[WG_RED][64];
-    const int ex = threadIdx.x & 63, gy = threadIdx.x >> 6;
-    const int m = blockIdx.x * 64 + ex;
-    float s0 = 0.0f, s1 = 0.0f;
-    if (m < pitch) {
-        const float* src = p.cs + m;
-        int b = gy;
-        for (; b + WG_RED < p.slabs; b += 2 * WG_RED) {
-            s0 += src[(int64_t)b * pitch];
-            s1 += src[(int64_t)(b + WG_RED) * pitch];
-        }
-        if (b < p.slabs) s0 += src[(int64_t)b * pitch];
-    }
-    part[gy][ex] = s0 + s1;
-    __syncthreads();
-    if (gy != 0 || m >= p.m) return;
-    float sum = 0.0f;
-#pragma unroll
-    for (int g = 0; g < WG_RED; ++g) sum += part[g][ex];
+    const int m = blockIdx.x * 64 + (threadIdx.x & 63);
+    float sum;
+    if (!flex_reduce_rows(p.cs + m, pitch, p.slabs, m < pitch, sum) || m >= p.m) return;
     p.colsum[m] = p.accumulate ? p.colsum[m] + sum : sum;
 }
 
