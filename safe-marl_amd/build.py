@@ -12,7 +12,8 @@ SRC = [os.path.join(HERE, "csrc", "flexenv.hip"), os.path.join(HERE, "csrc", "ac
        os.path.join(HERE, "csrc", "critic.hip"), os.path.join(HERE, "csrc", "rollout.hip"),
        os.path.join(HERE, "csrc", "wgrad.hip"), os.path.join(HERE, "csrc", "lnrelu.hip"),
        os.path.join(HERE, "csrc", "optim.hip"), os.path.join(HERE, "csrc", "tdloss.hip")]
-DEPS = SRC + [os.path.join(HERE, "csrc", "flex_device.h"), os.path.join(HERE, "csrc", "flex_reduce.h"), os.path.join(ROOT, "include", "flexenv.h"),
+DEPS = SRC + [os.path.join(HERE, "csrc", "flex_device.h"), os.path.join(HERE, "csrc", "flex_reduce.h"),
+              os.path.join(HERE, "csrc", "flex_launch.h"), os.path.join(ROOT, "include", "flexenv.h"),
               os.path.join(ROOT, "include", "flexnet.h")]
 OUT = os.path.join(HERE, "libflexenv_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

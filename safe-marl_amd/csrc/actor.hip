@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "flexnet.h"
+#include "flex_launch.h"
 
 // diagnostic build (-DACTOR_STAMPS): s_memtime at the phase boundaries of block 0's first wavefront (tools: scratch only)
 #ifdef ACTOR_STAMPS
@@ -554,14 +555,8 @@ extern "C" int flexnet_actor_forward(const FlexActorArgs* a, void* stream) {
         a->act_dim < 1 || a->act_dim > FLEXNET_MAX_ACT)
         return FLEXNET_EUNSUPPORTED;
     if ((int64_t)a->rows * a->obs_dim * 4 >= 0x7ffffff0ll) return FLEXNET_EUNSUPPORTED;   // observations are addressed with 32-bit byte offsets
-    static int cus = 0;                                   // one block per CU owns that CU's LDS
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
-            return FLEXNET_EHIP;
-        cus = n;
-    }
+    const int cus = flex_cu_count();                      // one block per CU owns that CU's LDS
+    if (cus < 1) return FLEXNET_EHIP;
     if (a->variant == 0) {
         const int tiles = (a->rows + 31) / 32;
         const int blocks = tiles < cus ? tiles : cus;

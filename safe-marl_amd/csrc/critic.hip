@@ -13,26 +13,12 @@
 #include <stdio.h>
 #include "flexnet.h"
 #include "flex_reduce.h"
+#include "flex_launch.h"
 
 #define HID FLEXNET_HID
 #define CRT 4                      // rows per wavefront tile
 #define CW 4                       // wavefronts per block
 
-
-// sum over the 64 lanes, returned in every lane: DPP row shifts / broadcasts (no LDS traffic) and one v_readlane
-template <int CTRL, int ROW_MASK, bool BC>
-__device__ __forceinline__ float cdpp(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, BC));
-}
-__device__ __forceinline__ float cwave_sum(float v) {
-    v += cdpp<0x111, 0xF, true>(v);            // row_shr:1
-    v += cdpp<0x112, 0xF, true>(v);            // row_shr:2
-    v += cdpp<0x114, 0xF, true>(v);            // row_shr:4
-    v += cdpp<0x118, 0xF, true>(v);            // row_shr:8   -> lane 15 of each row holds the row sum
-    v += cdpp<0x142, 0xA, false>(v);           // row_bcast:15 into rows 1, 3
-    v += cdpp<0x143, 0xC, false>(v);           // row_bcast:31 into rows 2, 3 -> lane 63 holds the total
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
 
 struct CriticRow { float xhat, rstd, y, a1; };
 
@@ -47,9 +33,9 @@ __device__ __forceinline__ float critic_z1(const FlexCriticTailArgs& a, int r, i
 __device__ __forceinline__ CriticRow critic_ln_relu(float z1, bool layernorm, float eps, float g, float b) {
     CriticRow o;
     if (layernorm) {
-        const float mean = cwave_sum(z1) * (1.0f / HID);
+        const float mean = flex_wave_sum(z1) * (1.0f / HID);
         const float d = z1 - mean;
-        const float var = cwave_sum(d * d) * (1.0f / HID);
+        const float var = flex_wave_sum(d * d) * (1.0f / HID);
         o.rstd = rsqrtf(var + eps);
         o.xhat = d * o.rstd;
         o.y = o.xhat * g + b;
@@ -94,7 +80,7 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_fwd_kernel(FlexCriticT
         }
 #pragma unroll
         for (int r = 0; r < CRT; ++r) {
-            const float qv = cwave_sum(fmaxf(z2[r], 0.0f) * w3) + b3;
+            const float qv = flex_wave_sum(fmaxf(z2[r], 0.0f) * w3) + b3;
             if (lane == 0 && r0 + r < a.rows) a.q[r0 + r] = qv;
         }
         __builtin_amdgcn_wave_barrier();
@@ -183,8 +169,8 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticT
                     acc_b += dy;
                 }
                 const float dxh = dy * g;
-                const float m1 = cwave_sum(dxh) * (1.0f / HID);
-                const float m2 = cwave_sum(dxh * row[r].xhat) * (1.0f / HID);
+                const float m1 = flex_wave_sum(dxh) * (1.0f / HID);
+                const float m2 = flex_wave_sum(dxh * row[r].xhat) * (1.0f / HID);
                 dz1 = row[r].rstd * (dxh - m1 - row[r].xhat * m2);
             }
             if (r0 + r < a.rows) a.dz1[(int64_t)(r0 + r) * HID + lane] = dz1;
@@ -650,14 +636,8 @@ __global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(Fle
 // 32-row MFMA tiles do: 8.5 vs 11.4 us forward at 20 480 rows, 43.5 vs 28.5 us at 163 840
 #define CRITIC_MFMA_MIN_ROWS 65536
 static int critic_mfma_grid(int rows) {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
-            return -1;
-        cus = n;
-    }
+    const int cus = flex_cu_count();
+    if (cus < 1) return -1;
     const int tiles = (rows + 31) / 32;
     return tiles < cus ? tiles : cus;                    // one block per CU (it stages W2 once); tiles spread over blocks first
 }
@@ -729,14 +709,8 @@ static int critic_check(const FlexCriticTailArgs* a, bool backward) {
 }
 
 static int critic_grid(int rows, int per_cu) {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
-            return -1;
-        cus = n;
-    }
+    const int cus = flex_cu_count();
+    if (cus < 1) return -1;
     const int want = (rows + CW * CRT - 1) / (CW * CRT);
     return want < cus * per_cu ? want : cus * per_cu;
 }

@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include "flexnet.h"
 #include "flex_reduce.h"
+#include "flex_launch.h"
 
 #define HID FLEXNET_HID
 #define LW 4                       // wavefronts per block
@@ -20,28 +21,14 @@
 #define LN_VECS (3 + FLEXNET_MAX_AGENTS)   // d_ln_w, d_ln_b, d_bias, d_id[8]
 #define LN_PITCH (LN_VECS * HID)
 
-template <int CTRL, int ROW_MASK, bool BC>
-__device__ __forceinline__ float ldpp(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, BC));
-}
-__device__ __forceinline__ float lwave_sum(float v) {
-    v += ldpp<0x111, 0xF, true>(v);
-    v += ldpp<0x112, 0xF, true>(v);
-    v += ldpp<0x114, 0xF, true>(v);
-    v += ldpp<0x118, 0xF, true>(v);
-    v += ldpp<0x142, 0xA, false>(v);
-    v += ldpp<0x143, 0xC, false>(v);
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
 struct LnRow { float xhat, rstd, y; };
 
 __device__ __forceinline__ LnRow ln_row(float x, bool layernorm, float eps, float g, float b) {
     LnRow o;
     if (layernorm) {
-        const float mean = lwave_sum(x) * (1.0f / HID);
+        const float mean = flex_wave_sum(x) * (1.0f / HID);
         const float d = x - mean;
-        const float var = lwave_sum(d * d) * (1.0f / HID);
+        const float var = flex_wave_sum(d * d) * (1.0f / HID);
         o.rstd = rsqrtf(var + eps);
         o.xhat = d * o.rstd;
         o.y = o.xhat * g + b;
@@ -112,8 +99,8 @@ __global__ __launch_bounds__(64 * LW) void lnrelu_bwd_kernel(FlexLnReluArgs a) {
                 acc_g = fmaf(dy, o.xhat, acc_g);
                 acc_b += dy;
                 const float dxh = dy * g;
-                const float m1 = lwave_sum(dxh) * (1.0f / HID);
-                const float m2 = lwave_sum(dxh * o.xhat) * (1.0f / HID);
+                const float m1 = flex_wave_sum(dxh) * (1.0f / HID);
+                const float m2 = flex_wave_sum(dxh * o.xhat) * (1.0f / HID);
                 dz = o.rstd * (dxh - m1 - o.xhat * m2);
             }
             if (r0 + r < a.rows) a.dz[(int64_t)(r0 + r) * HID + lane] = dz;
@@ -162,14 +149,8 @@ static int lnrelu_check(const FlexLnReluArgs* a, bool backward) {
 }
 
 static int lnrelu_grid(int rows, int per_cu, int cap) {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
-            return -1;
-        cus = n;
-    }
+    const int cus = flex_cu_count();
+    if (cus < 1) return -1;
     const int want = (rows + LW * LR - 1) / (LW * LR);
     int blocks = want < cus * per_cu ? want : cus * per_cu;
     return blocks < cap ? blocks : cap;
