@@ -22,7 +22,7 @@ import torch.nn as nn
 from .nets import (WGRAD_MIN_ROWS, CriticTail, MLPAgent, MLPCritic, RNNAgent, critic_replayed_supported,
                    critic_tail_supported, fused_actor_forward, td_loss, td_loss_supported, wide_batch_linear)
 from .replay_buffer import Transition
-from .util import prep_obs, scale_action, select_action, translate_action
+from .util import prep_obs, scale_action, select_action, translate_action, mean_all
 
 
 class RolloutGraph:
@@ -610,7 +610,7 @@ class MADDPG(Model):
             advantages = self.value(state, actions_pol).view(-1, self.n_)
             if self.args.normalize_advantages:
                 advantages = self.batchnorm(advantages)
-            policy_loss = (-advantages).mean()
+            policy_loss = mean_all(-advantages)
         if need in ("both", "value"):
             with th.no_grad():          # the bootstrap target carries no gradient (maddpg.py:110,115: .detach())
                 _, next_actions, _, _, _ = self.get_actions(next_state, status="train", exploration=False,
@@ -627,7 +627,7 @@ class MADDPG(Model):
                         rewards = bn(rewards.contiguous())
                 returns = rewards + self.args.gamma * (1 - done) * next_values
                 assert returns.size() == values.size()
-                value_loss = (returns - values).pow(2).mean()
+                value_loss = mean_all((returns - values).pow(2))
         return policy_loss, value_loss, action_out
 
 
@@ -696,7 +696,7 @@ class MATD3(MADDPG):
             advantages = self.value(state, actions_pol)[:b].reshape(-1, self.n_)          # first head only
             if self.args.normalize_advantages:
                 advantages = self.batchnorm(advantages)
-            policy_loss = (-advantages).mean()
+            policy_loss = mean_all(-advantages)
         if need in ("both", "value"):
             with th.no_grad():
                 _, next_actions, _, _, _ = self.get_actions(next_state, status="train", exploration=True,
@@ -708,7 +708,7 @@ class MATD3(MADDPG):
             values1, values2 = cur[:b].reshape(-1, self.n_), cur[b:].reshape(-1, self.n_)
             returns = rewards + self.args.gamma * (1 - done) * next_min
             assert returns.size() == values1.size() == values2.size()
-            value_loss = 0.5 * ((returns - values1).pow(2).mean() + (returns - values2).pow(2).mean())
+            value_loss = 0.5 * (mean_all((returns - values1).pow(2)) + mean_all((returns - values2).pow(2)))
         return policy_loss, value_loss, action_out
 
 

@@ -16,9 +16,21 @@ def convert(dictionary):
     return namedtuple("GenericDict", dictionary.keys())(**dictionary)
 
 
+def mean_all(x):
+    """``x.mean()`` over all elements.  On the GPU, large inputs are summed in two steps (rows of 256, then the row
+    sums): with this PyTorch-ROCm build a full ``mean`` / ``sum``-to-scalar of ~10^5+ elements is a multi-block kernel
+    with a global semaphore, and such a scalar captured into a HIP graph came back stale or as a partial sum on replay
+    (seen on the reported losses; the gradient of a mean is a broadcast and was never affected).  Same value up to
+    fp32 summation order, same gradient."""
+    n = x.numel()
+    if x.is_cuda and n >= 16384 and n % 256 == 0:
+        return x.reshape(-1, 256).sum(1).sum() / n
+    return x.mean()
+
+
 def normal_entropy(mean, std):
     """util.py:35-36"""
-    return Normal(mean, std, validate_args=False).entropy().mean()
+    return mean_all(Normal(mean, std, validate_args=False).entropy())
 
 
 def select_action(args, logits, status="train", exploration=True, info={}):

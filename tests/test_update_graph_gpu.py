@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _trainer(graph_updates):
+def _trainer(graph_updates, n_envs=256):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
     from train_maddpg import DEFAULT_ALG_ARGS
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
@@ -26,23 +26,30 @@ def _trainer(graph_updates):
                target_update_freq=10 ** 9)
     torch.manual_seed(7)
     np.random.seed(7)
-    env = VecFlexProvisionEnv({}, 256, net=net, series=series, seed=3, warm_start=True)
-    tr = PGTrainer(convert(alg), MADDPG, env, None, replay_capacity=256 * 96 * 2, graph_updates=graph_updates)
+    env = VecFlexProvisionEnv({}, n_envs, net=net, series=series, seed=3, warm_start=True)
+    tr = PGTrainer(convert(alg), MADDPG, env, None, replay_capacity=n_envs * 96 * 2, graph_updates=graph_updates)
     tr.behaviour_net.train_process({}, tr)                       # fill the replay (no updates: huge update period)
     return tr
 
 
-def test_graphed_sub_updates_equal_eager_ones():
-    a, b = _trainer(True), _trainer(False)
+@pytest.mark.parametrize("n_envs", [256, 4096])      # 4096: the update batch of the headline configuration (32 768 samples)
+def test_graphed_sub_updates_equal_eager_ones(n_envs):
+    a, b = _trainer(True, n_envs), _trainer(False, n_envs)
     for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
         assert torch.equal(va, vb), ka                           # same start
     assert torch.equal(a.replay_buffer.store2d, b.replay_buffer.store2d)
     for which in ("value", "value", "policy", "policy", "value", "policy"):
-        for tr in (a, b):
-            np.random.seed(11)                                   # the same replay window
+        stats = []
+        for k, tr in enumerate((a, b)):
+            np.random.seed(11 + 3 * len(which))                  # the same replay window for both, another one per kind
             st = {}
             (tr.value_replay_process if which == "value" else tr.policy_replay_process)(st)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            stats.append({key: float(v) for key, v in st.items()})
+        # the reported statistics are graph outputs too: they must be this replay's values, not stale ones
+        assert stats[0].keys() == stats[1].keys()
+        for key in stats[0]:
+            assert abs(stats[0][key] - stats[1][key]) <= 1e-4 * max(1.0, abs(stats[1][key])), (which, key, stats)
         assert a.graph_updates and which in a._update_graphs     # the graph path really ran
         for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
             if va.dtype.is_floating_point:
