@@ -523,6 +523,7 @@ class MADDPG(Model):
     # replay fields each loss reads (get_loss below; MATD3 and SAFEMADDPG read the same ones): a graphed sub-update
     # refreshes only these columns of its static batch
     # (reward in both: unpack_data's batch-norm running statistics move on every get_loss call, model.py:308-323)
+    graph_safe_updates = True       # trainer._graphed_sub_update: the gradient path uses no multi-block PyTorch reduction
     update_fields = {"policy": ("state", "reward", "last_hid"),
                      "value": ("state", "action", "reward", "next_state", "done", "hid")}
 
@@ -637,6 +638,8 @@ class MATD3(MADDPG):
     value loss averaged over the twins (matd3.py:148).  Bug-compatible with the reference's action selection, which
     sums the policy means over the AGENT axis before sampling (matd3.py:92-97)."""
 
+    graph_safe_updates = False      # value / policy losses go through PyTorch reductions: eager sub-updates
+
     def construct_value_net(self):
         """matd3.py:18-27: the MADDPG critic input plus the twin flag."""
         input_shape = (self.obs_dim + self.act_dim) * self.n_ + 1 + (self.n_ if self.args.agent_id else 0)
@@ -716,6 +719,8 @@ class IDDPG(MADDPG):
     """madrl/models/iddpg.py:7-83 with the loss of madrl/learning_algorithms/ddpg.py:14-37:
     independent critics Q_i(o_i, a_i) on the agent's own observation and action (plus its one-hot id), the same
     DDPG losses as MADDPG, and the agent-summed action selection it shares with MATD3 (iddpg.py:66-71)."""
+
+    graph_safe_updates = False      # value / policy losses go through PyTorch reductions: eager sub-updates
 
     def construct_value_net(self):
         """iddpg.py:17-26"""

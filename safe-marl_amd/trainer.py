@@ -92,6 +92,12 @@ class PGTrainer(object):
         buf = self.replay_buffer
         if not (self.graph_updates and self.device.type == "cuda" and self.world == 1 and hasattr(buf, "store2d")):
             return False
+        if not getattr(self.behaviour_net, "graph_safe_updates", False):
+            # Only models whose gradient path is free of PyTorch's multi-block reductions are replayed as graphs: with
+            # this PyTorch-ROCm build such a reduction (global semaphore + memset) captured into a HIP graph can come back
+            # stale or partial on replay.  MADDPG / SAFEMADDPG reduce with this project's fixed-order
+            # kernels and are checked against eager updates at full size; MATD3 / IDDPG keep eager sub-updates.
+            return False
         bs = self.effective_batch_size()
         g = self._update_graphs.get(which)
         if g is None or g["bs"] != bs or g["buf"] is not buf:
