@@ -185,7 +185,9 @@ int flexnet_clip_rmsprop(const FlexClipRmspropArgs* args, void* stream);
 
 /* The value loss of madrl/models/maddpg.py:100-123 behind model.py:308-323's reward normalisation, and its gradient:
  *     r = BatchNorm1d(n)(reward) [train mode];  ret = r + gamma (1 - done) next_q;  loss = mean((ret - q)^2);
- *     dq = dLoss/dq = -2 (ret - q) / (rows n).   The module's running statistics move as nn.BatchNorm1d moves them. */
+ *     dq = dLoss/dq = -2 (ret - q) / (rows n).   The module's running statistics move as nn.BatchNorm1d moves them.
+ * With q == NULL (and next_q, dq, loss NULL, normalise = 1) only the statistics pass runs: the running statistics are
+ * updated, nothing else — a get_loss call that does not use the value loss still owes the module that update. */
 typedef struct {
     int32_t rows, n_agents;    /* [rows, n_agents] tensors; n_agents <= FLEXNET_MAX_AGENTS */
     int32_t normalise;         /* args.reward_normalisation */

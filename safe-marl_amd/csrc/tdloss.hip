@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64) void td_finish_kernel(FlexTdLossArgs a) {
     if (lane == 0) {
         double t = 0.0;
         for (int b = 0; b < TD_BLOCKS; ++b) t += ws[TD_WS_SQ + b];
-        *a.loss = (float)(t / ((double)a.rows * a.n_agents));
+        if (a.loss) *a.loss = (float)(t / ((double)a.rows * a.n_agents));
         if (a.normalise && a.num_batches_tracked) *a.num_batches_tracked += 1;
     }
     if (a.normalise && lane < a.n_agents && a.running_mean && a.running_var) {      // nn.BatchNorm1d, train mode
@@ -117,14 +117,18 @@ __global__ __launch_bounds__(64) void td_finish_kernel(FlexTdLossArgs a) {
 }
 
 extern "C" int flexnet_td_loss(const FlexTdLossArgs* a, void* stream) {
-    if (!a || a->rows < 1 || a->n_agents < 1 || !a->reward || !a->done || !a->next_q || !a->q || !a->dq || !a->loss ||
-        !a->workspace || a->workspace_floats < FLEXNET_TD_WS_FLOATS)
+    if (!a || a->rows < 1 || a->n_agents < 1 || !a->reward || !a->workspace || a->workspace_floats < FLEXNET_TD_WS_FLOATS)
         return FLEXNET_EINVAL;
+    // statistics only (q == NULL): the running statistics move as a training-mode forward of the BatchNorm would move
+    // them, nothing else is computed — what a get_loss call that does not use the value loss still owes the module
+    const bool stats_only = !a->q;
+    if (stats_only && (!a->normalise || a->next_q || a->dq || a->loss)) return FLEXNET_EINVAL;
+    if (!stats_only && (!a->done || !a->next_q || !a->dq || !a->loss)) return FLEXNET_EINVAL;
     if (a->n_agents > TD_NA) return FLEXNET_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a->workspace) & 7) != 0) return FLEXNET_EINVAL;         // holds doubles
     hipStream_t s = (hipStream_t)stream;
     if (a->normalise) hipLaunchKernelGGL(td_stats_kernel, dim3(TD_BLOCKS), dim3(TD_THREADS), 0, s, *a);
-    hipLaunchKernelGGL(td_apply_kernel, dim3(TD_BLOCKS), dim3(TD_THREADS), 0, s, *a);
+    if (!stats_only) hipLaunchKernelGGL(td_apply_kernel, dim3(TD_BLOCKS), dim3(TD_THREADS), 0, s, *a);
     hipLaunchKernelGGL(td_finish_kernel, dim3(1), dim3(64), 0, s, *a);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }

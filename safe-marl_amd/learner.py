@@ -20,7 +20,8 @@ import torch as th
 import torch.nn as nn
 
 from .nets import (WGRAD_MIN_ROWS, CriticTail, MLPAgent, MLPCritic, RNNAgent, critic_replayed_supported,
-                   critic_tail_supported, fused_actor_forward, td_loss, td_loss_supported, wide_batch_linear)
+                   critic_tail_supported, fused_actor_forward, td_loss, td_loss_supported, wide_batch_linear,
+                   batchnorm_stats_supported, batchnorm_update_running_stats)
 from .replay_buffer import Transition
 from .util import prep_obs, scale_action, select_action, translate_action, mean_all
 
@@ -598,10 +599,16 @@ class MADDPG(Model):
         "value" / "policy" evaluates only the graph that loss needs — same loss value, same gradients, about half
         the forward work and no backward through the unused half; "both" is the reference's call."""
         # value loss alone on the GPU: reward normalisation, TD target, loss and dLoss/dQ are csrc/tdloss.hip
-        fused_td = (need == "value" and isinstance(batch.reward, th.Tensor) and batch.reward.is_cuda
-                    and self.fused_inference and th.is_grad_enabled())
+        on_gpu = (isinstance(batch.reward, th.Tensor) and batch.reward.is_cuda and self.fused_inference
+                  and th.is_grad_enabled())
+        fused_td = need == "value" and on_gpu
+        # the policy loss never reads the reward: all the normalisation owes is the module's running statistics
+        stats_only = (need == "policy" and on_gpu and self.args.reward_normalisation
+                      and batchnorm_stats_supported(self.batchnorm, batch.reward))
         state, actions, _, _, _, rewards, next_state, done, _, actions_avail, last_hids, hids = \
-            self.unpack_data(batch, normalise_reward=not fused_td)
+            self.unpack_data(batch, normalise_reward=not (fused_td or stats_only))
+        if stats_only:
+            batchnorm_update_running_stats(self.batchnorm, rewards)
         policy_loss = value_loss = None
         action_out = None
         if need in ("both", "policy"):

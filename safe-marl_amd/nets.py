@@ -339,6 +339,34 @@ def td_loss_supported(q, next_q, reward, done, bn):
     return bool(ok)
 
 
+def batchnorm_update_running_stats(bn, x):
+    """What a training-mode ``bn(x)`` does to ``running_mean`` / ``running_var`` / ``num_batches_tracked``, without the
+    normalised output (csrc/tdloss.hip statistics pass): for get_loss calls that normalise the reward only for the
+    module's bookkeeping (the policy loss never reads it, model.py:308-323)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    rows, n = x.shape
+    x = x.contiguous()
+    if x.device not in _TD_WS:
+        _TD_WS[x.device] = th.empty(_lib.FLEXNET_TD_WS_FLOATS // 2, dtype=th.float64, device=x.device)
+    ws = _TD_WS[x.device]
+    a = _lib.FlexTdLossArgs()
+    a.rows, a.n_agents, a.normalise = rows, n, 1
+    a.bn_eps, a.bn_momentum = float(bn.eps), float(bn.momentum)
+    a.reward = x.data_ptr()
+    a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+    a.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+    a.workspace, a.workspace_floats = ws.data_ptr(), 2 * ws.numel()
+    _lib.check(lib.flexnet_td_loss(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_td_loss")
+
+
+def batchnorm_stats_supported(bn, x):
+    return bool(x.is_cuda and x.dtype == th.float32 and x.dim() == 2 and 1 <= x.shape[1] <= 8 and x.shape[0] >= 1
+                and isinstance(bn, nn.BatchNorm1d) and bn.training and bn.momentum is not None and bn.track_running_stats
+                and bn.num_features == x.shape[1] and bn.running_mean.dtype == th.float32)
+
+
 def td_loss(q, next_q, reward, done, gamma, bn=None):
     return _TdLossFn.apply(q, next_q, reward, done, gamma, bn)
 

@@ -87,3 +87,20 @@ def test_get_loss_value_branch_matches_the_pytorch_composition():
         assert (a - e).abs().max().item() <= 1e-4 * max(1e-6, e.abs().max().item())
     assert torch.allclose(out[0][2], out[1][2], rtol=1e-5, atol=1e-6) and torch.allclose(out[0][3], out[1][3], rtol=1e-5, atol=1e-6)
     assert out[0][4] == out[1][4] == 1
+
+
+def test_statistics_only_pass_moves_the_running_statistics_like_a_forward():
+    from safe_marl_amd.nets import batchnorm_stats_supported, batchnorm_update_running_stats
+    g = torch.Generator(device="cuda").manual_seed(21)
+    a, b = torch.nn.BatchNorm1d(5).cuda(), torch.nn.BatchNorm1d(5).cuda()
+    for step in range(3):
+        x = torch.randn(32768, 5, device="cuda", generator=g) * (1 + step) + step
+        assert batchnorm_stats_supported(a, x)
+        batchnorm_update_running_stats(a, x)
+        with torch.no_grad():
+            b(x)
+        assert torch.allclose(a.running_mean, b.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(a.running_var, b.running_var, rtol=1e-5, atol=1e-6)
+        assert a.num_batches_tracked.item() == b.num_batches_tracked.item() == step + 1
+    a.eval()
+    assert not batchnorm_stats_supported(a, x)
