@@ -212,3 +212,27 @@ def test_general_graph_body_follows_get_actions(alg):
         rg.graph.replay()
     torch.cuda.synchronize()
     assert not torch.equal(before, rg.obs) and torch.isfinite(rg.rec).all()
+
+
+def test_graph_replays_equal_eager_steps_bit_for_bit():
+    """The captured rollout step against the same body run eagerly, from the same environment state, policy, hidden
+    state and noise-stream position: records, hand-over tensors and statistics identical over ten steps (in-launch
+    auto-resets excluded by the short horizon; both use the actor kernel's own noise stream)."""
+    import numpy as np
+    graph, eager = _setup(96)
+    graph.capture()                                   # warm-up + capture advance env, hidden state and the noise step
+    rng = np.random.default_rng(0)
+    n, na = 96, 5
+    spec = dict(day=rng.integers(0, 20, n).astype(np.int32), hour=rng.integers(0, 20, n).astype(np.int32),
+                interval=rng.integers(0, 4, n).astype(np.int32), e0=0.0125 + 0.001 * rng.random((n, na)),
+                a0=0.5 + 0.5 * rng.random((n, 4 * na)))
+    for rg in (graph, eager):
+        rg.start_episode(rg.env.reset(spec=spec))
+        rg.rng_state.copy_(torch.tensor([1234567, 42], dtype=torch.int64))
+    for step in range(10):
+        graph.graph.replay()
+        eager.body()
+        torch.cuda.synchronize()
+        for name in ("rec", "obs", "hid", "info_sum", "rew_sum", "fail_sum", "rng_state"):
+            assert torch.equal(getattr(graph, name), getattr(eager, name)), (step, name)
+    assert int(graph.rng_state[1]) == 52
