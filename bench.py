@@ -11,8 +11,22 @@ timed region starts; nothing crosses PCIe inside it.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Environments are independent, so ranks share nothing on the data path (weak scaling, no collective);
-the only collectives are the contract's barrier and the max-over-ranks of the elapsed time.
+Environments are independent, so ranks share nothing on the data path of the headline metric (weak scaling, no
+collective); the only collectives there are the contract's barrier and the max-over-ranks of the elapsed time.
+
+Next to the headline the same JSON line carries:
+  * `sustained`: the same env-only step over >= 2048 steps in this process (the driver's `--steps 20` is one or two graph
+    replays);
+  * `train`: the TRAINING loop of model.py:198-267 + model.py:40-71 — rollout (policy inference + env step + replay
+    write) and the 11 gradient steps per 60 vector steps — for BASELINE configs 3 (MADDPG, 5 and 3 agents, 4096 envs) and
+    4 (SAFEMADDPG, 8192 envs); with N > 1 ranks config 5: MADDPG at 4096 envs per GPU with the flat gradient bucket
+    all-reduced through RCCL before every clip + RMSprop step (`dist.allreduce_flat` between the two HIP graphs of a
+    sub-update);
+  * `train_kernel_shares`: per-kernel GPU time of one MADDPG training episode (torch.profiler in a child process started
+    before this process touches the GPU; null when it is unavailable, e.g. under rocprofv3).
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(`python -m torch.distributed.run ...` as a child process, before anything touches the GPU) and relays rank 0's line.
 """
 from __future__ import annotations
 
@@ -43,6 +57,11 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs", type=int, default=N_ENVS, help="envs per GPU (the metric is quoted at 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training legs (`train`)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2048-step env-only leg (`sustained`)")
+    ap.add_argument("--no-kernel-shares", action="store_true", help="skip the torch.profiler child (`train_kernel_shares`)")
+    ap.add_argument("--train-episodes", type=int, default=3, help="timed 95-step episodes per training leg (>= 2)")
+    ap.add_argument("--kernel-shares-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=1.5, help="stepping time of the CPU baseline sample (x cores = CPU work)")
     ap.add_argument("--warm-start", type=int, default=1)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
@@ -101,18 +120,168 @@ def cpu_baseline(net, series, seconds):
                       f"NR, OpenMP over envs, {cores} threads), {busy:.1f} s = {busy * cores:.0f} core-seconds"}
 
 
+TRAIN_ALG_ARGS = dict(  # madrl/args/default.yaml merged with alg_args/maddpg.yaml (examples/train_maddpg.py)
+    gumbel_softmax=False, epsilon_softmax=False, softmax_eps=None, episodic=False, cuda=True, grad_clip_eps=1.0,
+    save_model_freq=40, replay_warmup=0, policy_lrate=1.0e-4, value_lrate=1.0e-4, mixer_lrate=None, target=True,
+    target_lr=0.1, entr=1.0e-3, max_steps=240, batch_size=32, replay=True, replay_buffer_size=5.0e3, agent_type="rnn",
+    agent_id=True, shared_params=True, layernorm=True, mixer=False, gaussian_policy=False, LOG_STD_MIN=0.0,
+    LOG_STD_MAX=0.5, fixed_policy_std=1.0, hid_activation="relu", init_type="normal", init_std=0.1,
+    action_enforcebound=True, double_q=True, clip_c=1.0, gamma=0.99, hid_size=64, continuous=True,
+    normalize_advantages=False, train_episodes_num=400, behaviour_update_freq=60, target_update_freq=120,
+    policy_update_epochs=1, value_update_epochs=10, mixer_update_epochs=None, reward_normalisation=True, eval_freq=20,
+    num_eval_episodes=10, action_low=0, action_high=1.0, action_bias=0.0, action_scale=1.0,
+)
+
+
+def make_trainer(alg, n_agents, envs, rank, local_rank):
+    """PGTrainer(args, model, env, logger) as train_agent.py:67-107 builds it, on the vectorised HIP env."""
+    import torch
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.learner import MADDPG, SAFEMADDPG
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.trainer import PGTrainer
+    from safe_marl_amd.util import convert
+    blds = [5, 10, 15, 20, 25] if n_agents == 5 else [5, 15, 25]
+    env_args = {"buildings": blds, "pv_nodes": blds, "ess_nodes": blds}
+    if alg == "safemaddpg":
+        env_args["alg"] = "safemaddpg"
+    net = create_network(env_args)
+    series = make_synthetic_series(net, n_days=365)
+    env = VecFlexProvisionEnv(env_args, envs, device=f"cuda:{local_rank}", net=net, series=series,
+                              seed=1234 + 1000 * rank, warm_start=True)
+    d = dict(TRAIN_ALG_ARGS)
+    d.update(alg=alg, agent_num=env.n_agents, obs_size=env.obs_size, state_size=env.state_size, action_dim=4,
+             v_min=0.9, v_max=1.1)
+    torch.manual_seed(0)
+    trainer = PGTrainer(convert(d), {"maddpg": MADDPG, "safemaddpg": SAFEMADDPG}[alg], env, None,
+                        replay_capacity=envs * 96 * 2)
+    return trainer, env
+
+
+def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, max_over_ranks):
+    """One training configuration: a warm-up episode (allocations, HIP-graph captures, rocBLAS plans), then `episodes`
+    timed episodes of 95 vector steps each between barriers; whole-job env-steps/s = envs x world x steps / max-rank time."""
+    import torch
+    trainer, env = make_trainer(alg, n_agents, envs, rank, local_rank)
+    stat = {}
+    trainer.behaviour_net.train_process(stat, trainer)
+    barrier()
+    steps0 = trainer.steps
+    t0 = time.perf_counter()
+    for _ in range(episodes):
+        trainer.behaviour_net.train_process(stat, trainer)
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+    barrier()
+    dt = max_over_ranks(dt_local)
+    steps = trainer.steps - steps0
+    freq = trainer.args.behaviour_update_freq
+    events = sum(1 for st in range(steps0, trainer.steps) if st > 0 and st % freq == 0)
+    per_event = trainer.args.value_update_epochs + trainer.args.policy_update_epochs
+    rg = getattr(trainer.behaviour_net, "_rollout_graph", None)
+    out = {"alg": alg, "n_agents": env.n_agents, "envs_per_gpu": envs, "n_gpus": world, "episodes": episodes,
+           "vector_steps": steps, "ms_per_vector_step": dt / steps * 1e3,
+           "env_steps_per_s": envs * world * steps / dt, "grad_steps": events * per_event,
+           "batch_per_gpu": trainer.effective_batch_size(),
+           "rollout_graph": bool(rg is not None and rg.graph is not None), "rollout_fused": bool(rg is not None and rg.fast),
+           "graphed_updates": sorted(trainer._update_graphs), "split_update_graphs": bool(world > 1 and trainer._update_graphs),
+           "grad_allreduce": "rccl flat bucket (sum, 1/world inside graph B), before the clip" if world > 1 else None,
+           "mean_train_reward": float(stat.get("mean_train_reward", float("nan"))),
+           "mean_train_value_loss": float(stat.get("mean_train_value_loss", float("nan")))}
+    del trainer, env
+    torch.cuda.empty_cache()
+    return out
+
+
+def kernel_shares_child():
+    """Child process (started before the parent touches the GPU): per-kernel GPU time of one MADDPG training episode
+    (5 agents, 4096 envs) through torch.profiler; prints one JSON line."""
+    import torch
+    import safe_marl_amd  # noqa: F401
+    from torch.profiler import ProfilerActivity, profile
+    trainer, env = make_trainer("maddpg", 5, N_ENVS, 0, 0)
+    stat = {}
+    trainer.behaviour_net.train_process(stat, trainer)          # warm-up: graph captures
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        trainer.behaviour_net.train_process(stat, trainer)
+        torch.cuda.synchronize()
+    agg = {}
+    for ev in prof.key_averages():
+        if "cuda" not in str(getattr(ev, "device_type", "")).lower():
+            continue                                            # CPU-side rows repeat their kernels' time
+        t = float(getattr(ev, "self_device_time_total", 0.0) or 0.0)
+        if t <= 0:
+            continue
+        name = ev.key
+        cut = name.find("(")
+        name = name if cut < 0 else name[:cut]
+        e = agg.setdefault(name, [0.0, 0])
+        e[0] += t
+        e[1] += int(ev.count)
+    total = sum(v[0] for v in agg.values())
+    if total <= 0:
+        raise SystemExit("no device activity recorded")
+    top = sorted(agg.items(), key=lambda kv: -kv[1][0])[:16]
+    print(json.dumps({"episode": "MADDPG 5 agents x 4096 envs, 95 vector steps incl. one update event (11 sub-updates)",
+                      "gpu_ms_total": total / 1e3,
+                      "top": [{"kernel": k[:96], "calls": v[1], "ms": v[0] / 1e3, "share": v[0] / total} for k, v in top]}),
+          flush=True)
+
+
+def spawn_kernel_shares():
+    """Run kernel_shares_child() in a child started BEFORE this process initialises the GPU; None on any failure."""
+    import subprocess
+    if "rocprof" in (os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "")).lower():
+        return None                                             # a profiler is already attached to this process tree
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--kernel-shares-child"], capture_output=True,
+                           text=True, timeout=240)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+    except Exception as exc:
+        print(f"[bench] kernel-share child failed: {exc}", file=sys.stderr)
+    return None
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process tree (never exec from a
+    process that has touched the GPU — this one has not) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd)
+    sys.exit(r.returncode)
+
+
 def main():
     a = parse_args()
+    if a.kernel_shares_child:
+        return kernel_shares_child()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if a.gpus != world:
+        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: reporting n_gpus = {world}", file=sys.stderr)
+    shares = None
+    if rank == 0 and not distributed and not a.no_train and not a.no_kernel_shares:
+        shares = spawn_kernel_shares()                          # before this process touches the GPU
+
     import torch
     import safe_marl_amd  # noqa: F401
     from safe_marl_amd.network import create_network
     from safe_marl_amd.series import make_synthetic_series
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if os.environ.get("FLEX_BENCH_ONE_DEVICE") == "1":       # rehearsal only: every rank on cuda:0
@@ -143,10 +312,19 @@ def main():
         # ONE launch: step + get_obs; envs that terminate restart inside the same launch (FLEX_STEP_AUTORESET)
         env.step(pool[k % ACTION_POOL], fuse_obs=True, auto_reset=True)
 
-    # The loop is launch-issue sensitive (9 us of Python + ctypes per launch against a 16 us kernel), so ACTION_POOL
-    # consecutive steps are captured once as a HIP graph and replayed; the steps that do not fill a graph run eagerly.
-    # Work per step is identical either way (one flexenv_step launch); `--no-graph` keeps everything eager.
-    graph = None
+    # The loop is launch-issue sensitive (9 us of Python + ctypes per launch against a 14 us kernel), so consecutive steps
+    # are captured as HIP graphs and replayed: blocks of ACTION_POOL steps plus ONE graph for the remainder (K mod 16), so
+    # that short runs (the driver's --steps 20) are replays too.  Work per step is identical either way (one flexenv_step
+    # launch per step); `--no-graph` keeps everything eager.
+    graphs = {}
+
+    def capture(n_steps):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for j in range(n_steps):
+                one_step(j)
+        return g
+
     if not a.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -154,51 +332,70 @@ def main():
             with torch.cuda.stream(side):
                 one_step(0)
             torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                for j in range(ACTION_POOL):
-                    one_step(j)
-            graph = g
+            for n_steps in sorted({ACTION_POOL, a.steps % ACTION_POOL, a.warmup % ACTION_POOL} - {0}):
+                graphs[n_steps] = capture(n_steps)
         except Exception as exc:                      # capture not available: eager launches
             print(f"[bench] HIP graph capture failed ({exc}); eager launches", file=sys.stderr)
-            graph = None
+            graphs = {}
 
-    def run_steps(count, first):
+    def run_steps(count):
         done_steps = 0
-        if graph is not None:
+        if ACTION_POOL in graphs:
             while count - done_steps >= ACTION_POOL:
-                graph.replay()
+                graphs[ACTION_POOL].replay()
                 done_steps += ACTION_POOL
+        rest = count - done_steps
+        if rest and rest in graphs:
+            graphs[rest].replay()
+            done_steps += rest
         for k in range(done_steps, count):
-            one_step(first + k)
+            one_step(k)
 
-    run_steps(a.warmup, 0)
+    run_steps(a.warmup)
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if not distributed:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    run_steps(a.steps, a.warmup)                          # exactly K steps
+    run_steps(a.steps)                                    # exactly K steps
     ev1.record()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     dev_ms = ev0.elapsed_time(ev1)
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    # `sustained`: the same step over >= 2048 launches, HIP events on the launch stream around the whole region
+    sustained = None
+    if not a.no_sustained:
+        n_sus = max(2048, ACTION_POOL * (a.steps // ACTION_POOL))
+        barrier()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t1 = time.perf_counter()
+        s0.record()
+        run_steps(n_sus)
+        s1.record()
+        barrier()
+        sus_elapsed = max_over_ranks(time.perf_counter() - t1)
+        sustained = {"steps": n_sus, "value": a.envs * world * n_sus / sus_elapsed, "unit": "env-steps/s",
+                     "ms_per_step": sus_elapsed / n_sus * 1e3, "device_ms_per_step": s0.elapsed_time(s1) / n_sus}
 
     # roofline leg.  The timed region above is K back-to-back launches of ONE kernel (flex_step_kernel) on one
     # stream, bracketed by the HIP events ev0/ev1 on that stream: dev_ms / K is its average launch duration
     # (rocprofv3 --kernel-trace --stats of the same command agrees: profiles/).  A second pass brackets every
     # launch with its own event pair; that figure carries ~2 us of event overhead per launch and is reported
     # as `bracketed_launch_ms` only.
-    n_ev = min(a.steps, 400)
+    n_ev = min(max(a.steps, 64), 400)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     torch.cuda.synchronize()
     for k, (s, e) in enumerate(evs):
@@ -207,10 +404,29 @@ def main():
         e.record()
     torch.cuda.synchronize()
     durs = sorted(s.elapsed_time(e) for s, e in evs)
-    kern_ms = dev_ms / a.steps
+    # the kernel's average launch duration: from the longer of the two event-bracketed regions (a 20-step region is
+    # 0.3 ms, where the event pair's own ~5 us shows)
+    kern_ms = sustained["device_ms_per_step"] if sustained is not None and a.steps < 256 else dev_ms / a.steps
     failed_frac = float(env.failed.float().mean().item())
     iters_mean = float(env.peek("PF_ITERS").float().mean().item())
     sweeps_mean = float(env.peek("PF_SWEEPS").float().mean().item())
+    n_agents_env, n_bus_env, used_graph = env.n_agents, env.n_bus, bool(graphs)
+
+    # training legs (every rank takes part: with N > 1 the gradient bucket goes through RCCL)
+    train = None
+    if not a.no_train:
+        del env, pool, graphs
+        torch.cuda.empty_cache()
+        legs = [("maddpg", 5, N_ENVS)] if distributed else [("maddpg", 5, N_ENVS), ("maddpg", 3, N_ENVS), ("safemaddpg", 5, 2 * N_ENVS)]
+        train = []
+        for alg, n_ag, n_env in legs:
+            try:
+                train.append(train_leg(alg, n_ag, n_env, max(2, a.train_episodes), rank, local_rank, world, barrier,
+                                       max_over_ranks))
+            except Exception as exc:                  # a failed leg must not cost the headline line
+                if distributed:
+                    raise
+                train.append({"alg": alg, "n_agents": n_ag, "envs_per_gpu": n_env, "error": repr(exc)[:300]})
 
     if rank == 0:
         total_env_steps = a.envs * world * a.steps
@@ -241,19 +457,23 @@ def main():
             "config": {
                 "workload": "flex_provision.step()+get_obs() batched, 4096 envs/GPU, 33-bus AC power flow (fp64 NR, tol %g), " % a.pf_tol +
                             "5 agents, in-launch auto-reset",
-                "envs_per_gpu": a.envs, "n_agents": env.n_agents, "n_bus": env.n_bus,
-                "warm_start": bool(a.warm_start), "launches_per_step": 1, "hip_graph": graph is not None,
+                "envs_per_gpu": a.envs, "n_agents": n_agents_env, "n_bus": n_bus_env,
+                "warm_start": bool(a.warm_start), "launches_per_step": 1, "hip_graph": used_graph,
                 "device_ms_per_step": dev_ms / a.steps, "solver": a.solver, "pf_newton_iters_mean": iters_mean, "pf_sweeps_mean": sweeps_mean,
                 "solver_failed_frac": failed_frac,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "flex_step_kernel<2, float, float, 5>",
+                "bound": "hbm", "limiter": "latency (dependent chain of one wavefront at 2 waves/SIMD; DESIGN.md §4.7)",
+                "kernel": "flex_step_kernel<2, float, float, 5>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_env_step": B_ALG_WITH_OBS, "algorithmic_bytes_per_env_step_no_obs": B_ALG_CORE,
                 "avg_launch_ms": kern_ms, "bracketed_launch_ms": durs[len(durs) // 2],
                 "note": "latency/issue-bound fp64 kernel: ~4 KB per env-step cannot approach HBM peak (SURVEY.md §8d)",
             },
+            "sustained": sustained,
+            "train": train,
+            "train_kernel_shares": shares,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(net, series, a.cpu_seconds)

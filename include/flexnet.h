@@ -211,6 +211,24 @@ typedef struct {
 
 int flexnet_td_loss(const FlexTdLossArgs* args, void* stream);
 
+/* out[0] = scale * sum(x[0 .. n)) in a FIXED order (fp64 partial sums of 64 blocks, one-wavefront finish): the scalar
+ * means the losses report — policy_loss = -Q(s, pi(s)).mean() (madrl/models/maddpg.py:107), the entropy of
+ * utils/trainer.py:48-56 — without ATen's multi-block reduction, whose global semaphore does not survive a HIP-graph
+ * replay on this stack.  No memset, no atomics. */
+typedef struct {
+    int64_t n;                 /* elements, >= 1 */
+    float scale;               /* 1 / n for a mean */
+    int32_t pad0;
+    const float* x;            /* [n] contiguous */
+    float* out;                /* out [1] */
+    float* workspace;          /* 8-byte aligned, >= FLEXNET_SUM_WS_FLOATS floats */
+    int64_t workspace_floats;
+} FlexSumArgs;
+
+#define FLEXNET_SUM_WS_FLOATS (2 * 64)
+
+int flexnet_scaled_sum(const FlexSumArgs* args, void* stream);
+
 /* One vector step's bookkeeping of the rollout (madrl/models/model.py:230-262 per environment, utils/replay_buffer.py:
  * 23-27): the transition record [state | action | reward | next_state | done | last_step | last_hid | hid] lands in a
  * packed staging row per environment (the replay ring takes it with one copy), the observation and the hidden state are

@@ -60,6 +60,7 @@ SYMBOLS = (
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss",
+    "flexnet_scaled_sum",
 )
 
 class FlexActorArgs(C.Structure):
@@ -127,6 +128,15 @@ class FlexTdLossArgs(C.Structure):
 FLEXNET_TD_WS_FLOATS = 2 * (64 * 2 * 8 + 64)
 
 
+class FlexSumArgs(C.Structure):
+    """include/flexnet.h"""
+    _fields_ = [("n", C.c_int64), ("scale", C.c_float), ("pad0", C.c_int32), ("x", C.c_void_p), ("out", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
+
+
+FLEXNET_SUM_WS_FLOATS = 2 * 64
+
+
 class FlexRolloutPackArgs(C.Structure):
     """include/flexnet.h"""
     _fields_ = [(k, C.c_int32) for k in ("n_envs", "n_agents", "obs_dim", "act_dim", "rec_stride", "col_state", "col_action",
@@ -180,6 +190,8 @@ def load():
     lib.flexnet_clip_rmsprop.restype = C.c_int
     lib.flexnet_td_loss.argtypes = [C.POINTER(FlexTdLossArgs), vp]
     lib.flexnet_td_loss.restype = C.c_int
+    lib.flexnet_scaled_sum.argtypes = [C.POINTER(FlexSumArgs), vp]
+    lib.flexnet_scaled_sum.restype = C.c_int
     for fn in (lib.flexnet_lnrelu_forward, lib.flexnet_lnrelu_backward):
         fn.argtypes = [C.POINTER(FlexLnReluArgs), vp]
         fn.restype = C.c_int

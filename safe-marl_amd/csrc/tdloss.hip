@@ -132,3 +132,40 @@ extern "C" int flexnet_td_loss(const FlexTdLossArgs* a, void* stream) {
     hipLaunchKernelGGL(td_finish_kernel, dim3(1), dim3(64), 0, s, *a);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
+
+
+// ---- fixed-order scalar sum (flexnet_scaled_sum): the reported means of the losses, graph-replay safe -------------------
+__global__ __launch_bounds__(TD_THREADS) void sum_partial_kernel(FlexSumArgs a) {
+    __shared__ double red[TD_THREADS];
+    const int tid = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    int64_t i = (int64_t)blockIdx.x * TD_THREADS + tid;
+    const int64_t stride = (int64_t)TD_BLOCKS * TD_THREADS;
+    for (; i + stride < a.n; i += 2 * stride) { s0 += (double)a.x[i]; s1 += (double)a.x[i + stride]; }
+    if (i < a.n) s0 += (double)a.x[i];
+    red[tid] = s0 + s1;
+    __syncthreads();
+    for (int sft = TD_THREADS / 2; sft > 0; sft >>= 1) {
+        if (tid < sft) red[tid] += red[tid + sft];
+        __syncthreads();
+    }
+    if (tid == 0) reinterpret_cast<double*>(a.workspace)[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(64) void sum_finish_kernel(FlexSumArgs a) {
+    if (threadIdx.x != 0) return;
+    const double* ws = reinterpret_cast<const double*>(a.workspace);
+    double t = 0.0;
+    for (int b = 0; b < TD_BLOCKS; ++b) t += ws[b];
+    *a.out = (float)(t * (double)a.scale);
+}
+
+extern "C" int flexnet_scaled_sum(const FlexSumArgs* a, void* stream) {
+    if (!a || a->n < 1 || !a->x || !a->out || !a->workspace || a->workspace_floats < FLEXNET_SUM_WS_FLOATS ||
+        (reinterpret_cast<uintptr_t>(a->workspace) & 7) != 0)
+        return FLEXNET_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(TD_BLOCKS), dim3(TD_THREADS), 0, s, *a);
+    hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(64), 0, s, *a);
+    return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}

@@ -48,6 +48,12 @@ def allreduce_grads(params):
         off += n
 
 
+def allreduce_flat(flat):
+    """SUM over ranks of an already-flat gradient bucket, in place (the caller scales by 1/world — inside its HIP graph
+    when the update is graphed).  One ncclAllReduce on RCCL's stream, ordered after the current stream."""
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+
 def shard_envs(total_envs):
     """Contiguous block of environments for this rank."""
     w, r = world_size(), rank()

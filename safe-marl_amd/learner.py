@@ -62,9 +62,14 @@ class RolloutGraph:
         self.avail = th.ones(N, n, a, device=dev)             # every action is available (env:721-730)
         # plain MADDPG on the GPU: policy + exploration in one HIP launch, packing + hand-over + statistics in another
         self.safe = type(model).__name__ == "SAFEMADDPG"       # + the safety projection between policy and env
+        # (the actor kernel's exploration epilogue IS tanh(mean + std * noise), util.py:57-64: without action_enforcebound
+        # the reference adds unbounded noise, util.py:66-74, and the general body below runs select_action itself)
         self.fast = (type(model).__name__ in ("MADDPG", "SAFEMADDPG") and model.fused_inference
                      and model.args.shared_params and self.obs.is_cuda and model.args.agent_type == "rnn" and h == 64
-                     and o <= 144)
+                     and o <= 144 and bool(model.args.action_enforcebound))
+        # record packing / hand-over / statistics in ONE launch of this project's kernel (fixed-order block sums): no ATen
+        # reduction is ever captured into the rollout graph, whatever the algorithm
+        self.packable = self.obs.is_cuda and h == 64 and o <= 144 and n <= 8 and a <= 8
         if self.safe:
             self.predictor = tuple(th.as_tensor(x, dtype=th.float64, device=dev).contiguous() for x in model.predictor)
         self.cols = {k: buf.packed_cols[k][0] for k in self.STORED}
@@ -125,6 +130,10 @@ class RolloutGraph:
                                                               actions_avail=self.avail, target=False, last_hid=self.hid)
                 action_pol = action_pol.expand(N, m.n_, m.act_dim)
             env.step(m.env_action(action), fuse_obs=True, auto_reset=True)
+            if self.packable:
+                self._pack(action_pol.to(th.float32).contiguous(), hid.reshape(N, m.n_, -1).to(th.float32).contiguous())
+                return
+            # shapes outside the pack kernel (never captured as a graph: capture() refuses): plain tensor ops
             donef = env.done.float()
             f["state"].copy_(self.obs); f["action"].copy_(action_pol); f["next_state"].copy_(env.obs)
             f["reward"].copy_(env.reward.float().unsqueeze(1).expand(N, m.n_))
@@ -137,6 +146,13 @@ class RolloutGraph:
             self.hid.copy_(hid * (1.0 - donef).view(N, 1, 1))
 
     def capture(self):
+        import os
+        if not self.packable:
+            raise RuntimeError("observation / hidden sizes outside flexnet_rollout_pack: the statistics would go through "
+                               "ATen reductions, which must not be captured into a HIP graph (DESIGN.md §6)")
+        if os.environ.get("FLEX_GRAPH_AUDIT") == "1":
+            from .util import audit_graph_body
+            self.audit = audit_graph_body(self.body)
         side = th.cuda.Stream()
         side.wait_stream(th.cuda.current_stream())
         with th.cuda.stream(side):

@@ -8,6 +8,8 @@ import torch as th
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .util import note_fallback
+
 
 def _find_fused_gru():
     """ATen's pointwise GRU cell, what nn.GRUCell dispatches to on the GPU after its two gate GEMMs (ATen RNN.cpp)."""
@@ -80,6 +82,9 @@ class RNNAgent(nn.Module):
         W = self.fc1.weight
         if not (obs.is_cuda and obs.dtype == th.float32 and lnrelu_supported(self, n_agents) and _FUSED_GRU is not None
                 and W.shape[1] == o + (n_agents if agent_id else 0) and obs.shape[0] % n_agents == 0):
+            if obs.is_cuda:
+                note_fallback("actor_update_pass", f"hid {self.args.hid_size}, act {self.args.hid_activation}, agents "
+                                                   f"{n_agents}, dtype {obs.dtype}")
             return None
         z = wide_batch_linear(obs, W[:, :o]) if not obs.requires_grad else tall_linear(obs, W[:, :o])
         ln = self.layernorm if self.args.layernorm else None
@@ -165,6 +170,9 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
     a = agent.args
     if not (isinstance(agent, RNNAgent) and a.hid_size == 64 and a.hid_activation == "relu" and obs.is_cuda
             and obs.dtype == th.float32 and obs.shape[-1] <= 144 and n_agents <= 8 and a.action_dim <= 8):
+        if obs.is_cuda:
+            note_fallback("actor_forward", f"{type(agent).__name__}, hid {a.hid_size}, act {a.hid_activation}, obs "
+                                           f"{obs.shape[-1]}, agents {n_agents}, dtype {obs.dtype}")
         return None
     lib = _lib.load()
     rows = obs.shape[0] * obs.shape[1]
@@ -197,10 +205,12 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
                     ("means", means), ("hidden_out", hid_out), ("noise", noise), ("action", action),
                     ("env_action", env_action)):
         if t is not None and not t.is_contiguous():
+            note_fallback("actor_forward", f"non-contiguous {name}")
             return None
         setattr(args, name, None if t is None else t.data_ptr())
     rc = lib.flexnet_actor_forward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream))
     if rc == _lib.FLEXNET_EUNSUPPORTED:
+        note_fallback("actor_forward", "FLEXNET_EUNSUPPORTED from flexnet_actor_forward")
         return None
     _lib.check(rc, "flexnet_actor_forward")
     return (means, hid_out, action, env_action) if explore else (means, hid_out)
@@ -477,8 +487,11 @@ def wide_batch_linear(x, w):
 
 def critic_tail_supported(critic, x):
     a = critic.args
-    return (x.is_cuda and x.dtype == th.float32 and x.dim() == 2 and x.shape[1] == 64 and a.hid_size == 64
-            and a.hid_activation == "relu" and critic.fc3.out_features == 1 and getattr(critic, "fused_tail", True))
+    ok = (x.is_cuda and x.dtype == th.float32 and x.dim() == 2 and x.shape[1] == 64 and a.hid_size == 64
+          and a.hid_activation == "relu" and critic.fc3.out_features == 1 and getattr(critic, "fused_tail", True))
+    if x.is_cuda and not ok and getattr(critic, "fused_tail", True):
+        note_fallback("critic_tail", f"hid {a.hid_size}, act {a.hid_activation}, out {critic.fc3.out_features}, dtype {x.dtype}")
+    return ok
 
 
 CRITIC_VARIANT = 0              # 0: matrix-core forward / dz1-only backward (csrc/critic.hip); 1: the VALU kernels

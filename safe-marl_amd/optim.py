@@ -31,6 +31,10 @@ def clip_and_step(opt, params, max_norm):
     """Clip the gradients of ``params`` to ``max_norm`` (2-norm over all of them), take one RMSprop step, return the
     pre-clip norm (a 0-dim tensor) — ``clip_grad_norm_`` + ``opt.step()``."""
     if not (params and params[0].is_cuda and _supported(opt, params)):
+        if params and params[0].is_cuda:
+            from .util import note_fallback
+            note_fallback("clip_rmsprop", "optimiser configuration outside csrc/optim.hip (capturable RMSprop, no momentum / "
+                                          "centering / weight decay, contiguous fp32 tensors)")
         norm = th.nn.utils.clip_grad_norm_(params, max_norm)
         opt.step()
         return norm

@@ -90,7 +90,7 @@ class PGTrainer(object):
         step — losses, backward, gradient clip, RMSprop — is replayed as one HIP graph.  Returns False when this
         configuration does not qualify (the caller then runs the eager step)."""
         buf = self.replay_buffer
-        if not (self.graph_updates and self.device.type == "cuda" and self.world == 1 and hasattr(buf, "store2d")):
+        if not (self.graph_updates and self.device.type == "cuda" and hasattr(buf, "store2d")):
             return False
         if not getattr(self.behaviour_net, "graph_safe_updates", False):
             # Only models whose gradient path is free of PyTorch's multi-block reductions are replayed as graphs: with
@@ -119,6 +119,12 @@ class PGTrainer(object):
             if first < bs:
                 flat[first:].copy_(buf.store2d[:bs - first, c0:c1])
         g["graph"].replay()
+        if g["apply"] is not None:
+            # more than one rank: the captured region is split at the exchange step — graph A (losses, backward, gradients
+            # into ONE static flat bucket), the all-reduce of that bucket through RCCL (eager: one ncclAllReduce of
+            # <= 208 KB), graph B (scale by 1/world, gradient clip, RMSprop).  SURVEY.md §8(e): the clip comes AFTER.
+            fdist.allreduce_flat(g["flat"])
+            g["apply"].replay()
         stat.update(g["stat"])
         return True
 
@@ -149,16 +155,32 @@ class PGTrainer(object):
         net_snap = {k: v.clone() for k, v in self.behaviour_net.state_dict().items()}
         had_state = {p: {k: (v.clone() if th.is_tensor(v) else v) for k, v in opt.state[p].items()}
                      for p in opt.param_groups[0]["params"] if p in opt.state}
+        import os
+        if os.environ.get("FLEX_GRAPH_AUDIT") == "1":     # the body about to be captured launches no ATen multi-block reduction
+            from .util import audit_graph_body
+            self.graph_audit = getattr(self, "graph_audit", {})
+            self.graph_audit[which] = audit_graph_body(lambda: self._sub_update(which, {}, batch, fresh_leaves=True))
+        flat = None
+        if self.world > 1:
+            flat = th.zeros(sum(p.numel() for p in opt.param_groups[0]["params"]), dtype=th.float32, device=self.device)
         side = th.cuda.Stream()
         side.wait_stream(th.cuda.current_stream())
         with th.cuda.stream(side):
             for _ in range(2):                        # warm-up off the capturing stream (allocator, rocBLAS handles)
-                self._sub_update(which, out, batch, fresh_leaves=True)
+                self._sub_update(which, out, batch, fresh_leaves=True, flat=flat)
         th.cuda.current_stream().wait_stream(side)
         graph = th.cuda.CUDAGraph()
+        apply_graph = None
         out = {}
-        with th.cuda.graph(graph):
-            self._sub_update(which, out, batch, fresh_leaves=True)
+        if flat is None:
+            with th.cuda.graph(graph):
+                self._sub_update(which, out, batch, fresh_leaves=True)
+        else:
+            with th.cuda.graph(graph):
+                self._loss_and_grads(which, out, batch, fresh_leaves=True, flat=flat)
+            apply_graph = th.cuda.CUDAGraph()
+            with th.cuda.graph(apply_graph, pool=graph.pool()):
+                self._apply_grads(which, out, flat=flat)
         with th.no_grad():
             for k, v in self.behaviour_net.state_dict().items():
                 v.copy_(net_snap[k])
@@ -169,7 +191,7 @@ class PGTrainer(object):
                         v.copy_(old) if old is not None else v.zero_()
         # `batch` stays referenced: its constant fields (action_avail, ...) were allocated eagerly and are baked into the
         # graph by address; released, the allocator would hand their memory to the next eager tensor
-        return dict(graph=graph, static=static, stat=out, bs=bs, buf=buf, batch=batch)
+        return dict(graph=graph, apply=apply_graph, flat=flat, static=static, stat=out, bs=bs, buf=buf, batch=batch)
 
     # kept for callers that hand over a batch themselves (trainer.py:81,99)
     def policy_transition_process(self, stat, trans):
@@ -179,9 +201,22 @@ class PGTrainer(object):
         self._sub_update("value", stat, trans)
 
     # ---- one gradient step -----------------------------------------------------------------------
-    def _sub_update(self, which, stat, batch, fresh_leaves=False):
+    def _sub_update(self, which, stat, batch, fresh_leaves=False, flat=None):
         """zero_grad -> loss -> backward -> (all-reduce) -> clip_grad_norm_(1.0) -> RMSprop (trainer.py:81-108).
         The policy loss carries the entropy bonus of trainer.py:47-57, a constant under the fixed std.
+        ``flat``: a static bucket the gradients are gathered in (multi-rank graphed updates); None = per-call bucket."""
+        self._loss_and_grads(which, stat, batch, fresh_leaves=fresh_leaves, flat=flat)
+        if self.world > 1:
+            if flat is not None:
+                fdist.allreduce_flat(flat)
+            else:
+                opt = self.policy_optimizer if which == "policy" else self.value_optimizer
+                fdist.allreduce_grads(opt.param_groups[0]["params"])
+        self._apply_grads(which, stat, flat=flat)
+
+    def _loss_and_grads(self, which, stat, batch, fresh_leaves=False, flat=None):
+        """The loss this sub-update steps on and the gradients of ITS optimiser's parameters (left in ``p.grad``; with
+        ``flat`` they are views of that bucket, in parameter order).
 
         ``fresh_leaves`` (graph capture): the loss is formed on detached aliases of the parameters.  Autograd keeps one
         gradient accumulator per parameter, bound to the stream it was first used on; if the caller still holds a
@@ -215,14 +250,28 @@ class PGTrainer(object):
         # gradients of THIS optimiser's parameters only: a plain backward() would also fill the other network's
         # .grad (the critic's first-layer weight gradient is the largest GEMM of a policy step) just to have it
         # zeroed by that optimiser's next zero_grad (trainer.py:82,100)
-        for p, g in zip(params, th.autograd.grad(loss, leaves, allow_unused=True)):
-            p.grad = g
-        if self.world > 1:
-            fdist.allreduce_grads(params)
-        # clip_grad_norm_ + RMSprop step (trainer.py:86-90,103-107), after the all-reduce; one HIP launch on the GPU
+        grads = th.autograd.grad(loss, leaves, allow_unused=True)
+        if flat is None:
+            for p, g in zip(params, grads):
+                p.grad = g
+        else:
+            views, off = [], 0
+            for p in params:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            th._foreach_copy_(views, [g if g is not None else th.zeros_like(v) for g, v in zip(grads, views)])
+            for p, v in zip(params, views):
+                p.grad = v
+        stat[f"mean_train_{which}_loss"] = loss.detach()
+
+    def _apply_grads(self, which, stat, flat=None):
+        """clip_grad_norm_ + RMSprop step (trainer.py:86-90,103-107), after the all-reduce; one HIP launch on the GPU."""
+        opt = self.policy_optimizer if which == "policy" else self.value_optimizer
+        params = opt.param_groups[0]["params"]
+        if flat is not None and self.world > 1:
+            flat.mul_(1.0 / self.world)               # the bucket holds the SUM over ranks
         grad_norm = clip_and_step(opt, params, self.args.grad_clip_eps)
         stat[f"mean_train_{which}_grad_norm"] = grad_norm.detach()
-        stat[f"mean_train_{which}_loss"] = loss.detach()
 
     # ---- episode loop hooks (train_agent.py:125-146) --------------------------------------------
     def run(self, stat, episode):

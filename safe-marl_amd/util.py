@@ -11,20 +11,85 @@ import torch as th
 from torch.distributions.normal import Normal
 
 
+FALLBACKS = {}          # reason -> count: fused HIP paths that declined on GPU tensors (visible, never silent)
+
+
+def note_fallback(key, detail=""):
+    """A fused HIP path declined a GPU call (shape or configuration outside what the kernel covers) and the PyTorch
+    composition runs instead: 4-5x slower, same numbers.  Counted in ``FALLBACKS`` and reported ONCE per reason, so a
+    configuration drift (say hid_size != 64) cannot quietly lose the fast path under green tests."""
+    first = key not in FALLBACKS
+    FALLBACKS[key] = FALLBACKS.get(key, 0) + 1
+    if first:
+        import warnings
+        warnings.warn(f"safe_marl_amd: fused path '{key}' declined ({detail}); the PyTorch composition runs instead",
+                      RuntimeWarning, stacklevel=3)
+
+
+# kernels that must never be recorded into a HIP graph with this PyTorch-ROCm build: ATen's multi-block reductions
+# keep a global semaphore that a captured memset node resets, and replays came back stale or partial (DESIGN.md §6)
+GRAPH_DENYLIST = ("reduce_kernel", "batch_norm_collect_statistics", "batch_norm_backward_reduce", "MeanOps", "SumOps",
+                  "NormOps", "multi_tensor_apply_kernel<at::native::(anonymous namespace)::TensorListMetadata<1>, at::native::(anonymous namespace)::LpNorm")
+
+
+def audit_graph_body(fn, allow=()):
+    """Run ``fn`` (the body about to be captured) eagerly under torch.profiler and return the device kernel names it
+    launched; raises if one of them is on ``GRAPH_DENYLIST``.  Used by the tests and, with FLEX_GRAPH_AUDIT=1, by the
+    capture sites themselves (trainer._capture_sub_update, learner.RolloutGraph.capture)."""
+    from torch.profiler import ProfilerActivity, profile
+    th.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        fn()
+        th.cuda.synchronize()
+    names = sorted({ev.key for ev in prof.key_averages() if "cuda" in str(getattr(ev, "device_type", "")).lower()})
+    bad = [n for n in names if any(d in n for d in GRAPH_DENYLIST) and not any(a in n for a in allow)]
+    if bad:
+        raise RuntimeError("graph body launches multi-block ATen reductions (stale on HIP-graph replay): " + "; ".join(bad))
+    return names
+
+
 def convert(dictionary):
     """util.py:190-191"""
     return namedtuple("GenericDict", dictionary.keys())(**dictionary)
 
 
+_SUM_WS = {}
+
+
+class _MeanAllFn(th.autograd.Function):
+    """x.mean() over all elements through csrc/tdloss.hip's fixed-order sum (include/flexnet.h: flexnet_scaled_sum);
+    the gradient of a mean is a broadcast."""
+
+    @staticmethod
+    def forward(ctx, x):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        flat = x.contiguous().view(-1)
+        out = th.empty((), dtype=th.float32, device=x.device)
+        if x.device not in _SUM_WS:
+            _SUM_WS[x.device] = th.empty(_lib.FLEXNET_SUM_WS_FLOATS // 2, dtype=th.float64, device=x.device)
+        ws = _SUM_WS[x.device]
+        a = _lib.FlexSumArgs()
+        a.n, a.scale = flat.numel(), 1.0 / flat.numel()
+        a.x, a.out, a.workspace, a.workspace_floats = flat.data_ptr(), out.data_ptr(), ws.data_ptr(), 2 * ws.numel()
+        _lib.check(lib.flexnet_scaled_sum(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_scaled_sum")
+        ctx.shape, ctx.n = x.shape, flat.numel()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g / ctx.n).expand(ctx.shape)
+
+
 def mean_all(x):
-    """``x.mean()`` over all elements.  On the GPU, large inputs are summed in two steps (rows of 256, then the row
-    sums): with this PyTorch-ROCm build a full ``mean`` / ``sum``-to-scalar of ~10^5+ elements is a multi-block kernel
-    with a global semaphore, and such a scalar captured into a HIP graph came back stale or as a partial sum on replay
-    (seen on the reported losses; the gradient of a mean is a broadcast and was never affected).  Same value up to
-    fp32 summation order, same gradient."""
-    n = x.numel()
-    if x.is_cuda and n >= 16384 and n % 256 == 0:
-        return x.reshape(-1, 256).sum(1).sum() / n
+    """``x.mean()`` over all elements.  On the GPU it is this project's fixed-order sum kernel: with this PyTorch-ROCm
+    build a full ``mean`` / ``sum``-to-scalar of ~10^5+ elements is a multi-block kernel with a global semaphore, and such
+    a scalar captured into a HIP graph came back stale or as a partial sum on replay (seen on the reported losses; the
+    gradient of a mean is a broadcast and was never affected).  Same value up to fp32 summation order (the kernel
+    accumulates in fp64), same gradient."""
+    if x.is_cuda and x.dtype == th.float32 and x.numel() >= 1:
+        return _MeanAllFn.apply(x)
     return x.mean()
 
 

@@ -1,0 +1,168 @@
+"""GPU: the remaining BASELINE.json configurations at their stated inputs / sizes.
+
+  config 1  run_pf.py:37-54 inputs (every PQ bus P = 0.1, Q = 0.005 pu; buildings reduce by 50 %, PV 0.5 pv_scale,
+            ESS charging at p_ch_max from e_max / 2) through ``pf_solve_batch`` (power_flow_solver, utils/pf.py:10-113);
+  config 4  the safety projection (safemaddpg.py:176-299) at 8192 environments: a sampled subset against the separable
+            CPU oracle to 1e-12, the whole batch through size-independent properties (feasibility of the slab,
+            idempotence, non-negativity, untouched actions where the layer reports no intervention);
+  f2        CSV files in the reference's on-disk format (env:431-471: time column + 32 load / 5 PV / 1 price columns, 3-min
+            raw data resampled to 15 min) ingested by ``series.load_csv_dir`` and driven through the HIP env against the
+            scalar oracle on the same table."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_run_pf_inputs_through_the_hip_solver(net):
+    import torch
+    from oracle import pf_oracle
+    from safe_marl_amd.flex_env import pf_solve_batch
+    from safe_marl_amd.network import build_tables
+    buses = net["bus_numbers"]
+    blds = net["buildings"]
+    pd = {b: 0 if net["bus_types"][b] == 1 else 0.1 for b in buses}
+    qd = {b: 0 if net["bus_types"][b] == 1 else 0.005 for b in buses}
+    pred = {b: pd[b] * 0.5 for b in blds}
+    ppv = {b: 0.5 * 0.15 for b in blds}
+    qpv = {b: 0 for b in blds}
+    ch = {b: 0.005 for b in blds}
+    dis = {b: 0 for b in blds}
+    e0 = {b: 0.025 / 2 for b in blds}
+    ref = pf_oracle.power_flow_solver(net, pd, qd, pred, ppv, qpv, ch, dis, e0)
+    # net injections exactly as pf.py:69-73,81-82 forms them
+    pnet = np.array([pd[b] - (pred[b] + ppv[b] - ch[b] + dis[b] if b in blds else 0.0) for b in buses])
+    qnet = np.array([qd[b] - (qpv[b] if b in blds else 0.0) for b in buses])
+    t = build_tables(net)
+    for solver in (0, 2, 1):                       # tree Newton, sweeps (default), dense Newton (the north-star variant)
+        out = pf_solve_batch(net, torch.from_numpy(pnet[None]).cuda(), torch.from_numpy(qnet[None]).cuda(),
+                             want_branch=True, solver=solver)
+        torch.cuda.synchronize()
+        assert not bool(out["failed"][0])
+        v = out["v"][0].cpu().numpy()
+        assert np.abs(v - np.array([ref["Voltages"][b] for b in buses])).max() < 1e-10, solver
+        assert v[buses.index(1)] == 1.0
+        isqr, pl, ql = (out[k][0].cpu().numpy() for k in ("isqr", "pl", "ql"))
+        for b in range(t.n_bus):
+            key = t.line_of_bus[b]
+            if key is None:
+                continue
+            assert abs(np.sqrt(isqr[b]) - ref["Currents"][key]) < 1e-9
+            assert abs(pl[b] - ref["Power Flows"][key][0]) < 1e-9 and abs(ql[b] - ref["Power Flows"][key][1]) < 1e-9
+    # the ESS half of power_flow_solver (pf.py:96-98) is the env kernel's business; its closed form is checked here
+    for b in blds:
+        assert ref["Next ESS Energy"][b] == pytest.approx(0.0125 + 0.25 * 0.9 * 0.005, abs=1e-15)
+
+
+def test_safety_projection_at_8192_envs(net, series_small):
+    import torch
+    from oracle import safety_oracle
+    from oracle.env_oracle import FlexEnvOracle
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd import safety_signal as ss
+    n = 8192
+    rng = np.random.default_rng(5)
+    vp = ss.fit_voltage_predictor(net, num_scenarios=300)
+    sp, sq, beta = vp.building_terms(net)
+    vec = VecFlexProvisionEnv({"alg": "safemaddpg"}, n, series=series_small, net=net, seed=17)
+    vec.reset()
+    for t in range(2):
+        vec.step(torch.from_numpy(rng.uniform(0, 1, (n, 5, 4)) * [0.5, 0.005, 0.005, 0.02]).cuda())
+    proposed = rng.uniform(-0.2, 1.2, (n, 5, 4)).astype(np.float32)
+    row, E = vec.peek("ROW").cpu().numpy(), vec.peek("E").cpu().numpy()
+    helper = FlexEnvOracle(net, {}, series_small.active, series_small.reactive, series_small.pv, series_small.price)
+    buses = list(net["bus_numbers"])
+    idx = [buses.index(b) for b in net["buildings"]]
+    # the parsed proposal of every environment (safemaddpg.py:142-174 = the env's own a5-a7 helpers), type-major
+    x0 = np.zeros((n, 4, 5))
+    pd_b, qd_b = np.zeros((n, 5)), np.zeros((n, 5))
+    for i in range(n):
+        helper.start = 0
+        helper._load_row(int(row[i]))
+        pct, _, ch, dis, q = helper._parse(proposed[i].astype(np.float64).reshape(-1), E[i], scaled=True)
+        x0[i] = [pct, ch, dis, q]
+        pd_b[i], qd_b[i] = helper.cur_pd[idx], helper.cur_qd[idx]
+
+    def g_of(x):            # the regressor's own-bus voltage prediction, safemaddpg.py:266,272
+        return sp * (pd_b * (1 - x[:, 0]) + x[:, 1] - x[:, 2]) + sq * (qd_b + x[:, 3]) + beta
+
+    regimes = []
+    # raw predictions sit near 2.0-2.1 on per-unit inputs: three limit sets = never / partly / always binding
+    for limits in ((0.0, 5.0), (2.0, 2.05), (2.08, 2.3), (0.9, 1.1)):
+        adj_t, hit_t = vec.safety_project(torch.from_numpy(proposed).cuda(), sp, sq, beta, *limits)
+        adj = adj_t.cpu().numpy().reshape(n, 4, 5).astype(np.float64)
+        hit = hit_t.cpu().numpy().astype(bool)
+        # (1) sampled subset against the separable closed-form oracle, 1e-12
+        worst = 0.0
+        for i in rng.choice(n, 64, replace=False):
+            for k in range(5):
+                x = safety_oracle.solve_separable(x0[i, :, k], pd_b[i, k], qd_b[i, k], sp[k], sq[k], beta[k], *limits)
+                worst = max(worst, np.abs(adj[i, :, k] - x).max())
+        assert worst < 1e-12, (limits, worst)
+        # (2) the whole batch, size-independent properties
+        assert np.isfinite(adj).all() and (adj[:, :3] >= 0).all()                        # pr, ch, dis >= 0 (safemaddpg.py:196-198)
+        g0, g1 = g_of(x0), g_of(adj)
+        out0 = np.maximum(limits[0] - g0, 0) + np.maximum(g0 - limits[1], 0)             # distance of the proposal to the slab
+        out1 = np.maximum(limits[0] - g1, 0) + np.maximum(g1 - limits[1], 0)
+        moved = np.abs(adj - x0).max(axis=1) > 0                                          # [n, 5] per building
+        assert np.array_equal(moved.any(axis=1), hit)                                     # `hit` = some building was adjusted
+        assert not moved[out0 == 0].any()                                                 # feasible proposals are returned unchanged
+        assert moved[out0 > 1e-12].all()                                                  # infeasible ones are projected ...
+        assert (out1[moved] < out0[moved]).all()                                          # ... towards the slab ...
+        # idempotence: a point the layer put ON the slab needs no further adjustment (a penalty-capped move, where paying
+        # slack is cheaper than moving on, is not a projection and is pinned by the sampled oracle comparison instead)
+        on_slab = np.argwhere(moved & (out1 < 1e-12))
+        for i, k in on_slab[rng.choice(len(on_slab), min(40, len(on_slab)), replace=False)] if len(on_slab) else []:
+            x = safety_oracle.solve_separable(adj[i, :, k], pd_b[i, k], qd_b[i, k], sp[k], sq[k], beta[k], *limits)
+            assert np.abs(np.asarray(x) - adj[i, :, k]).max() < 1e-9
+        regimes.append(float(hit.mean()))
+    assert regimes[0] == 0.0 and 0.0 < regimes[1] <= 1.0 and regimes[3] == 1.0, regimes
+
+
+def test_csv_ingested_series_through_the_hip_env(tmp_path, net):
+    pd = pytest.importorskip("pandas")
+    import torch
+    from oracle.env_oracle import FlexEnvOracle
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.series import load_csv_dir
+    rng = np.random.default_rng(3)
+    days = 6
+    idx = pd.date_range("2021-03-01", periods=days * 24 * 20, freq="3min")         # 3-min raw data, like the reference's
+    hours = (idx.hour + idx.minute / 60.0).to_numpy()
+    base_p = np.array([net["active_power_demand"][b] for b in net["bus_numbers"]][1:])
+    base_q = np.array([net["reactive_power_demand"][b] for b in net["bus_numbers"]][1:])
+    shape = (0.6 + 0.4 * np.sin(np.pi * hours / 24) ** 2)[:, None]
+    frames = {"load_active.csv": base_p[None] * shape * rng.uniform(0.8, 1.2, (len(idx), 32)),
+              "load_reactive.csv": base_q[None] * shape * rng.uniform(0.8, 1.2, (len(idx), 32)),
+              "pv_active.csv": np.maximum(0, np.sin(np.pi * (hours - 6) / 12))[:, None] * rng.uniform(0.7, 1.0, (len(idx), 5)),
+              "prices.csv": rng.uniform(0.05, 0.30, (len(idx), 1))}
+    for name, arr in frames.items():
+        df = pd.DataFrame(arr, columns=[f"c{i}" for i in range(arr.shape[1])])
+        df.insert(0, "time", idx)
+        if name == "prices.csv":
+            df.iloc[40:43, 1] = np.nan                                              # gaps: interpolate('linear'), env:470
+        df.to_csv(tmp_path / name, index=False)
+    st = load_csv_dir(net, str(tmp_path), {"pv_scale": 0.15})
+    assert st.rows == days * 96 and st.time_delta == 15
+    n = 24
+    vec = VecFlexProvisionEnv({}, n, net=net, series=st, seed=2)
+    spec = dict(day=rng.integers(0, st.n_start_days(96), n).astype(np.int32), hour=rng.integers(0, 24, n).astype(np.int32),
+                interval=rng.integers(0, 4, n).astype(np.int32), e0=rng.uniform(0.01125, 0.01375, (n, 5)),
+                a0=rng.uniform(0, 1, (n, 20)))
+    vec.reset(spec=spec)
+    oracles = [FlexEnvOracle(net, {}, st.active, st.reactive, st.pv, st.price) for _ in range(n)]
+    for i, o in enumerate(oracles):
+        o.reset(spec=(spec["day"][i], spec["hour"][i], spec["interval"][i], spec["e0"][i], spec["a0"][i]))
+    worst_r = worst_v = 0.0
+    for t in range(95):
+        acts = rng.uniform(0.5, 1.0, (n, 5, 4))
+        reward, done, info = vec.step(torch.from_numpy(acts).cuda(), fuse_obs=True)
+        reward, obs = reward.cpu().numpy(), vec.obs.cpu().numpy()
+        v = vec.peek("V").cpu().numpy()
+        for i, o in enumerate(oracles):
+            r, d, _ = o.step(acts[i])
+            ob = np.stack(o.get_obs()).astype(np.float32)
+            worst_r = max(worst_r, abs(r - reward[i]))
+            worst_v = max(worst_v, float(np.abs(v[i] - o.current_voltage).max()))
+            assert np.allclose(obs[i], ob, rtol=2e-7, atol=0) and bool(done[i]) == d
+    assert worst_r < 1e-10 and worst_v < 1e-10

@@ -87,3 +87,84 @@ def test_two_ranks_stay_identical_and_average_gradients():
     w = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.parameters()]).numpy()
     assert np.allclose(w, a["w1"], atol=2e-6)
     assert abs(float(stat["mean_train_value_grad_norm"]) - a["vnorm"]) < 1e-4 * max(1.0, a["vnorm"])
+
+
+class _StubVecEnv:
+    """The slice of VecFlexProvisionEnv that Model._train_process_vec touches, on CPU tensors: independent synthetic
+    environments (per-rank seed), so that the two ranks see DIFFERENT data and only the gradient all-reduce can keep the
+    replicas identical.  The physics is irrelevant here (the HIP env has no CPU path); the control flow is the product's."""
+    handle = True
+
+    def __init__(self, n_envs, seed, n_agents=5, obs_size=144, episode_limit=25):
+        self.n_envs, self.n_agents, self.obs_size, self.episode_limit = n_envs, n_agents, obs_size, episode_limit
+        self.gen = th.Generator().manual_seed(seed)
+        self.t = 0
+        self.obs = th.zeros(n_envs, n_agents, obs_size)
+        self.reward = th.zeros(n_envs, dtype=th.float64)
+        self.done = th.zeros(n_envs, dtype=th.uint8)
+        self.failed = th.zeros(n_envs, dtype=th.uint8)
+        self.info = th.zeros(n_envs, 8, dtype=th.float64)
+
+    def _draw_obs(self):
+        self.obs = 0.3 * th.randn(self.n_envs, self.n_agents, self.obs_size, generator=self.gen)
+
+    def reset(self):
+        self.t = 0
+        self._draw_obs()
+        return self.obs
+
+    def step(self, actions, fuse_obs=True, auto_reset=True):
+        self.t += 1
+        self.reward = (0.03 + 0.1 * actions.double().mean((1, 2)) + 0.02 * th.randn(self.n_envs, generator=self.gen).double())
+        self.done = th.full((self.n_envs,), int(self.t >= self.episode_limit - 1), dtype=th.uint8)
+        self.info = self.reward.unsqueeze(1).expand(-1, 8).contiguous()
+        self._draw_obs()
+        return self.reward, self.done, self.info
+
+
+def _train_worker(rank, world, port, out):
+    import safe_marl_amd  # noqa: F401
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.trainer import PGTrainer
+    from safe_marl_amd.util import convert
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = json.load(open(os.path.join(G, "learner_args.json")))
+    d.update(behaviour_update_freq=10, target_update_freq=20)
+    args = convert(d)
+    th.manual_seed(100 + rank)                    # different initial weights per rank: the constructor broadcast fixes that
+    np.random.seed(7 + rank)                      # ... and a different replay window per rank (per-rank shard, SURVEY §8e)
+    env = _StubVecEnv(8, seed=1000 + rank)
+    trainer = PGTrainer(args, MADDPG, env, None, batch_scale=2)
+    w0 = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.parameters()]).clone()
+    stat = {}
+    trainer.behaviour_net.train_process(stat, trainer)        # 24 vector steps: update events at steps 10 and 20
+    w1 = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.parameters()])
+    tgt = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.target_net.parameters()])
+    out[rank] = dict(w0=w0.numpy(), w1=w1.numpy(), tgt=tgt.numpy(), steps=trainer.steps, buf=len(trainer.replay_buffer.buffer),
+                     vloss=float(stat["mean_train_value_loss"]), reward=float(stat["mean_train_reward"]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_train_process_on_two_ranks_keeps_replicas_identical():
+    """model.py:198-267 + model.py:40-71 under data parallelism (BASELINE config 5's control flow on gloo): every rank
+    rolls out its own env shard into its own replay shard, the 22 sub-updates of two update events all-reduce their
+    gradient bucket before the clip, and behaviour AND target replicas end bit-identical although the data differ."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_train_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    assert a["steps"] == b["steps"] == 24 and a["buf"] == b["buf"] == 24 * 8
+    assert np.array_equal(a["w0"], b["w0"])
+    assert not np.array_equal(a["w0"], a["w1"])                    # updates happened
+    assert np.array_equal(a["w1"], b["w1"]) and np.array_equal(a["tgt"], b["tgt"])
+    assert a["vloss"] != b["vloss"] and a["reward"] != b["reward"]          # the ranks really saw different data
+    # a lone rank 0 from the same start, without the exchange, ends somewhere else: the all-reduce mattered
+    solo = mgr.dict()
+    mp.spawn(_train_worker, args=(1, _free_port(), solo), nprocs=1, join=True)
+    assert np.array_equal(solo[0]["w0"], a["w0"]) and not np.array_equal(solo[0]["w1"], a["w1"])

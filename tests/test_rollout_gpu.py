@@ -44,11 +44,18 @@ def test_fast_step_equals_general_step(n_envs):
     slow.model.fused_inference = False             # general path end to end: the module, torch glue
     for rg in (fast, slow):
         rg.start_episode(rg.env.reset())
+    want_info = torch.zeros_like(slow.info_sum)
+    want_rew = torch.zeros_like(slow.rew_sum)
     for step in range(4):
         for rg in (fast, slow):
             torch.manual_seed(100 + step)          # the same exploration draws
             rg.body()
         torch.cuda.synchronize()
+        # the pack kernel's statistics blocks (fixed-order fp64 block sums) against plain tensor sums of the env outputs
+        want_info += slow.env.info.sum(0)
+        want_rew += slow.env.reward.sum()
+        assert torch.allclose(slow.info_sum, want_info, rtol=1e-12, atol=1e-12)
+        assert torch.allclose(slow.rew_sum, want_rew, rtol=1e-12, atol=1e-12)
         for name in ("rec", "obs", "hid"):
             a, b = getattr(fast, name), getattr(slow, name)
             # two fp32 summation orders through a recurrent net, four steps: relative 5e-4
@@ -157,8 +164,8 @@ def test_safemaddpg_fused_step_applies_the_safety_layer():
     assert hits > 0                                                           # the layer really acted in this test
 
 
-@pytest.mark.parametrize("alg", ["matd3", "iddpg"])
-def test_general_graph_body_follows_get_actions(alg):
+@pytest.mark.parametrize("alg,N", [("matd3", 40), ("iddpg", 40), ("matd3", 4096)])
+def test_general_graph_body_follows_get_actions(alg, N):
     """MATD3 / IDDPG in the graph rollout: the body calls their own get_actions (agent-summed action selection,
     matd3.py:88-111, iddpg.py:66-71) exactly as the eager vector loop does; record, hand-over and statistics against
     that loop spelled out here, then a captured replay."""
@@ -175,7 +182,6 @@ def test_general_graph_body_follows_get_actions(alg):
     a = dict(DEFAULT_ALG_ARGS)
     a.update(alg=alg, agent_num=5, obs_size=144, state_size=110, action_dim=4)
     cls = {"matd3": learner.MATD3, "iddpg": learner.IDDPG}[alg]
-    N = 40
     envs = [VecFlexProvisionEnv({}, N, net=net, series=series, seed=4, warm_start=True) for _ in range(2)]
     torch.manual_seed(8)
     m = cls(convert(a)).cuda()
@@ -205,12 +211,25 @@ def test_general_graph_body_follows_get_actions(alg):
         obs = envs[1].obs.clone()
         hid = new_hid * (1.0 - envs[1].done.float()).view(N, 1, 1)
         assert torch.equal(rg.obs, obs) and torch.equal(rg.hid, hid)
-    rg.capture()
+    os.environ["FLEX_GRAPH_AUDIT"] = "1"          # capture() first checks its body for ATen multi-block reductions
+    try:
+        rg.capture()
+    finally:
+        del os.environ["FLEX_GRAPH_AUDIT"]
+    assert any("rollout_pack_kernel" in k for k in rg.audit) and any("flex_step_kernel" in k for k in rg.audit)
     rg.start_episode(envs[0].reset())
     before = rg.obs.clone()
-    for _ in range(3):
+    want_info = torch.zeros_like(rg.info_sum)
+    want_rew = torch.zeros_like(rg.rew_sum)
+    for _ in range(6):
         rg.graph.replay()
-    torch.cuda.synchronize()
+        # REPLAYED statistics (the headline batch size included) against eager sums of what the replay left in the env
+        want_info += envs[0].info.sum(0)
+        want_rew += envs[0].reward.sum()
+        torch.cuda.synchronize()
+        assert torch.allclose(rg.info_sum, want_info, rtol=1e-12, atol=1e-12), (rg.info_sum, want_info)
+        assert torch.allclose(rg.rew_sum, want_rew, rtol=1e-12, atol=1e-12)
+        assert rg.fail_sum.item() == 0.0
     assert not torch.equal(before, rg.obs) and torch.isfinite(rg.rec).all()
 
 

@@ -72,3 +72,52 @@ def test_graph_and_eager_stay_bit_identical_over_a_long_schedule():
         assert stats[0] == stats[1], (i, which, stats)
         for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
             assert torch.equal(va, vb), (i, which, ka)
+
+
+def test_graphed_regions_contain_no_aten_multiblock_reduction(monkeypatch):
+    """Guard rail for DESIGN.md §6: with FLEX_GRAPH_AUDIT=1 every capture site first runs its body under torch.profiler
+    and refuses kernels of util.GRAPH_DENYLIST (ATen reduce_kernel / batch_norm statistics).  Both sub-update graphs
+    and the fused rollout graph of MADDPG pass, and the audit really saw this project's kernels."""
+    monkeypatch.setenv("FLEX_GRAPH_AUDIT", "1")
+    tr = _trainer(True, 256)
+    rg = tr.behaviour_net._rollout_graph
+    for which in ("value", "policy"):
+        np.random.seed(3)
+        (tr.value_replay_process if which == "value" else tr.policy_replay_process)({})
+    torch.cuda.synchronize()
+    assert tr.graph_updates and set(tr._update_graphs) == {"value", "policy"}
+    for which, must in (("value", ("td_", "critic_tail", "clip_rmsprop", "actor_forward")),
+                        ("policy", ("lnrelu", "wgrad", "clip_rmsprop", "sum_partial"))):
+        names = tr.graph_audit[which]
+        for m in must:
+            assert any(m in k for k in names), (which, m, names)
+        assert not any("reduce_kernel" in k or "batch_norm" in k for k in names), names
+    assert any("rollout_pack_kernel" in k for k in rg.audit) and any("actor_forward" in k for k in rg.audit)
+    # and the guard itself fires on an ATen full reduction
+    from safe_marl_amd.util import audit_graph_body
+    x = torch.randn(1 << 20, device="cuda")
+    with pytest.raises(RuntimeError, match="multi-block"):
+        audit_graph_body(lambda: x.sum())
+
+
+def test_fused_paths_do_not_fall_back_at_the_default_configuration():
+    """Guard rail (c): a training episode + both sub-updates at the default configuration take no PyTorch fallback of a
+    fused path (util.FALLBACKS stays empty); a drifted configuration is reported once."""
+    import warnings
+    from safe_marl_amd import util
+    util.FALLBACKS.clear()
+    tr = _trainer(True, 256)
+    for which in ("value", "policy"):
+        np.random.seed(3)
+        (tr.value_replay_process if which == "value" else tr.policy_replay_process)({})
+    torch.cuda.synchronize()
+    assert util.FALLBACKS == {}, util.FALLBACKS
+    from safe_marl_amd.nets import fused_actor_forward
+    agent = tr.behaviour_net.policy_dicts[0]
+    wide = torch.zeros(4, 5, 200, device="cuda")            # 200 observation columns: outside csrc/actor.hip
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert fused_actor_forward(agent, wide, torch.zeros(20, 64, device="cuda"), 5, True) is None
+        assert fused_actor_forward(agent, wide, torch.zeros(20, 64, device="cuda"), 5, True) is None
+    assert util.FALLBACKS.get("actor_forward") == 2 and sum("actor_forward" in str(x.message) for x in w) == 1
+    util.FALLBACKS.clear()
