@@ -655,6 +655,16 @@ class MADDPG(Model):
         return policy_loss, value_loss, action_out
 
 
+def _sum_agents(x):
+    """x.sum(dim=1, keepdim=True) over the (small) agent axis as n - 1 pointwise adds: the same numbers up to fp32
+    summation order, and no ATen reduce_kernel in a captured rollout graph (util.GRAPH_DENYLIST is strict about those)."""
+    parts = x.unbind(1)
+    out = parts[0]
+    for p in parts[1:]:
+        out = out + p
+    return out.unsqueeze(1)
+
+
 class MATD3(MADDPG):
     """madrl/models/matd3.py:8-149: twin centralised critics realised as ONE shared network with
     a trailing 0/1 input flag (matd3.py:64-67), clipped-double-Q target min(Q1', Q2') (matd3.py:139-140) and a
@@ -702,7 +712,7 @@ class MATD3(MADDPG):
         means = means.masked_fill(avail == 0, 0.0)
         log_stds = log_stds.masked_fill(avail == 0, 0.0)
         if means.size(-1) > 1:                                              # matd3.py:94-96: sum over dim=1 (agents)
-            means_, log_stds_ = means.sum(dim=1, keepdim=True), log_stds.sum(dim=1, keepdim=True)
+            means_, log_stds_ = _sum_agents(means), _sum_agents(log_stds)
         else:
             means_, log_stds_ = means, log_stds
         actions, log_prob_a = select_action(self.args, means_, status=status, exploration=exploration,
@@ -768,7 +778,7 @@ class IDDPG(MADDPG):
         pol = self.target_net.policy if (target and self.args.target) else self.policy
         means, log_stds, hiddens = pol(state, last_hid=last_hid)
         if means.size(-1) > 1:
-            means_, log_stds_ = means.sum(dim=1, keepdim=True), log_stds.sum(dim=1, keepdim=True)
+            means_, log_stds_ = _sum_agents(means), _sum_agents(log_stds)
         else:
             means_, log_stds_ = means, log_stds
         actions, log_prob_a = select_action(self.args, means_, status=status, exploration=exploration,

@@ -28,8 +28,8 @@ def note_fallback(key, detail=""):
 
 # kernels that must never be recorded into a HIP graph with this PyTorch-ROCm build: ATen's multi-block reductions
 # keep a global semaphore that a captured memset node resets, and replays came back stale or partial
-GRAPH_DENYLIST = ("reduce_kernel", "batch_norm_collect_statistics", "batch_norm_backward_reduce", "MeanOps", "SumOps",
-                  "NormOps", "multi_tensor_apply_kernel<at::native::(anonymous namespace)::TensorListMetadata<1>, at::native::(anonymous namespace)::LpNorm")
+GRAPH_DENYLIST = ("at::native::reduce_kernel", "batch_norm_collect_statistics", "batch_norm_backward_reduce",
+                  "at::native::(anonymous namespace)::LpNormFunctor")
 
 
 def audit_graph_body(fn, allow=()):

@@ -91,7 +91,7 @@ def test_graphed_regions_contain_no_aten_multiblock_reduction(monkeypatch):
         names = tr.graph_audit[which]
         for m in must:
             assert any(m in k for k in names), (which, m, names)
-        assert not any("reduce_kernel" in k or "batch_norm" in k for k in names), names
+        assert not any("at::native::reduce_kernel" in k or "batch_norm" in k for k in names), names
     assert any("rollout_pack_kernel" in k for k in rg.audit) and any("actor_forward" in k for k in rg.audit)
     # and the guard itself fires on an ATen full reduction
     from safe_marl_amd.util import audit_graph_body
