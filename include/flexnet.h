@@ -230,35 +230,62 @@ typedef struct {
 int flexnet_scaled_sum(const FlexSumArgs* args, void* stream);
 
 /* One vector step's bookkeeping of the rollout (madrl/models/model.py:230-262 per environment, utils/replay_buffer.py:
- * 23-27): the transition record [state | action | reward | next_state | done | last_step | last_hid | hid] lands in a
- * packed staging row per environment (the replay ring takes it with one copy), the observation and the hidden state are
- * handed over to the next step (hidden state zeroed where the episode ended, model.py:255-258), and the episode
- * statistics are accumulated — one launch instead of some twenty pointwise kernels. */
+ * 23-27) in ONE launch.  The replay ring is slab-structured — slab k holds, for every environment of vector step k,
+ * the observation the policy acted on, the hidden state it started from, and (once the step has run) its action,
+ * reward, done and last_step flags:
+ *     obs_ring   [slabs, N, n * obs_dim]      obs(k)
+ *     hid_ring   [slabs, N, n * 64]           hidden state going INTO step k (model.py:211,259; zero after a terminal step)
+ *     small_ring [slabs, N, small_w]          [action n*act | reward n | done | last_step | pad]
+ * Every observation is stored ONCE: the next_state of a transition in slab k is obs(k + 1), the `hid` of model.py:241 is
+ * the hidden state of slab k + 1 (zeroed where done = 1 — where the TD target multiplies the bootstrap value by zero
+ * anyway, maddpg.py:117) and `last_hid` is the slab's own.  This launch, after step k ran:
+ *     slab k     <- action, reward, done (last_step = done; the caller flags the final step of a horizon, model.py:229)
+ *     slab k + 1 <- obs_next (what the environment kernel just produced), hid_new * (1 - done)
+ *     hid_state  <- hid_new * (1 - done)      (hand-over to the next policy evaluation)
+ *     statistics += this step's info / reward / failure sums (fixed-order block sums)
+ *     cursor[0]  <- k + 1                     (by the last block to finish: a self-resetting ticket, no memset)
+ * k = cursor[0] is read on the device, so the launch can be replayed from a HIP graph. */
 typedef struct {
     int32_t n_envs, n_agents, obs_dim, act_dim;
-    int32_t rec_stride;        /* floats per record row */
-    int32_t col_state, col_action, col_reward, col_next_state, col_done, col_last_step, col_last_hid, col_hid;
+    int32_t slabs;             /* ring capacity in slabs, >= 2 */
+    int32_t small_w;           /* floats per small record: >= n_agents * act_dim + n_agents + 2 */
     int32_t info_w;            /* columns of `info` (7) */
-    int32_t pad0, pad1;
-    const float* obs_prev;     /* [N, n, obs_dim] */
-    const float* action;       /* [N, n, act_dim] */
+    int32_t pad0;
+    const float* action;       /* [N, n, act_dim]  what the replay keeps (model.py:232) */
     const double* reward;      /* [N]   one reward per environment, stored once per agent */
     const float* obs_next;     /* [N, n, obs_dim] */
     const uint8_t* done;       /* [N] */
-    const float* hid_prev;     /* [N, n, 64] */
     const float* hid_new;      /* [N, n, 64] */
     const double* info;        /* [N, info_w] or NULL */
     const uint8_t* failed;     /* [N] or NULL */
-    float* rec;                /* out [N, rec_stride] */
-    float* obs_state;          /* out [N, n, obs_dim] <- obs_next            (may be obs_prev) */
-    float* hid_state;          /* out [N, n, 64]      <- hid_new * (1 - done) (may be hid_prev) */
-    double* info_sum;          /* += [info_w] or NULL */
-    double* rew_sum;           /* += [1] */
-    double* fail_sum;          /* += [1] or NULL */
-    uint64_t* rng_state;       /* device [2] or NULL: [1] += 1 (the step counter of flexnet_actor_forward's noise stream) */
+    float* obs_ring;
+    float* hid_ring;
+    float* small_ring;
+    float* hid_state;          /* out [N, n, 64]; may alias hid_new */
+    int64_t* cursor;           /* [2]: {slab counter k, ticket} */
+    double* info_sum;          /* [info_w] or NULL */
+    double* rew_sum;           /* [1] */
+    double* fail_sum;          /* [1] or NULL */
+    int64_t* rng_state;        /* [2] or NULL: {seed, step}; step += 1 (the actor kernel's noise stream, flexnet_actor_forward) */
 } FlexRolloutPackArgs;
 
 int flexnet_rollout_pack(const FlexRolloutPackArgs* args, void* stream);
+
+/* Replay-window refresh: up to FLEXNET_GATHER_MAX_JOBS strided row copies in one launch.  A sampled window of the slab
+ * ring (utils/replay_buffer.py:17-21: consecutive transitions) becomes the contiguous static batch a captured sub-update
+ * reads; each field is one job (two where the window crosses the ring's seam). */
+#define FLEXNET_GATHER_MAX_JOBS 12
+typedef struct {
+    int32_t n_jobs, pad0;
+    const float* src[FLEXNET_GATHER_MAX_JOBS];
+    float* dst[FLEXNET_GATHER_MAX_JOBS];
+    int64_t rows[FLEXNET_GATHER_MAX_JOBS];
+    int32_t width[FLEXNET_GATHER_MAX_JOBS];        /* floats per row */
+    int32_t src_stride[FLEXNET_GATHER_MAX_JOBS];   /* floats between rows */
+    int32_t dst_stride[FLEXNET_GATHER_MAX_JOBS];
+} FlexGatherArgs;
+
+int flexnet_gather_rows(const FlexGatherArgs* args, void* stream);
 
 #ifdef __cplusplus
 }

@@ -60,7 +60,7 @@ SYMBOLS = (
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss",
-    "flexnet_scaled_sum",
+    "flexnet_scaled_sum", "flexnet_gather_rows",
 )
 
 class FlexActorArgs(C.Structure):
@@ -139,12 +139,21 @@ FLEXNET_SUM_WS_FLOATS = 2 * 64
 
 class FlexRolloutPackArgs(C.Structure):
     """include/flexnet.h"""
-    _fields_ = [(k, C.c_int32) for k in ("n_envs", "n_agents", "obs_dim", "act_dim", "rec_stride", "col_state", "col_action",
-                                         "col_reward", "col_next_state", "col_done", "col_last_step", "col_last_hid",
-                                         "col_hid", "info_w", "pad0", "pad1")] + \
-               [(k, C.c_void_p) for k in ("obs_prev", "action", "reward", "obs_next", "done", "hid_prev", "hid_new", "info",
-                                          "failed", "rec", "obs_state", "hid_state", "info_sum", "rew_sum", "fail_sum",
+    _fields_ = [(k, C.c_int32) for k in ("n_envs", "n_agents", "obs_dim", "act_dim", "slabs", "small_w", "info_w", "pad0")] + \
+               [(k, C.c_void_p) for k in ("action", "reward", "obs_next", "done", "hid_new", "info", "failed", "obs_ring",
+                                          "hid_ring", "small_ring", "hid_state", "cursor", "info_sum", "rew_sum", "fail_sum",
                                           "rng_state")]
+
+
+FLEXNET_GATHER_MAX_JOBS = 12
+
+
+class FlexGatherArgs(C.Structure):
+    """include/flexnet.h"""
+    _fields_ = [("n_jobs", C.c_int32), ("pad0", C.c_int32),
+                ("src", C.c_void_p * FLEXNET_GATHER_MAX_JOBS), ("dst", C.c_void_p * FLEXNET_GATHER_MAX_JOBS),
+                ("rows", C.c_int64 * FLEXNET_GATHER_MAX_JOBS), ("width", C.c_int32 * FLEXNET_GATHER_MAX_JOBS),
+                ("src_stride", C.c_int32 * FLEXNET_GATHER_MAX_JOBS), ("dst_stride", C.c_int32 * FLEXNET_GATHER_MAX_JOBS)]
 
 
 FLEXNET_EUNSUPPORTED = -3
@@ -184,6 +193,8 @@ def load():
     lib.flexnet_actor_forward.restype = C.c_int
     lib.flexnet_rollout_pack.argtypes = [C.POINTER(FlexRolloutPackArgs), vp]
     lib.flexnet_rollout_pack.restype = C.c_int
+    lib.flexnet_gather_rows.argtypes = [C.POINTER(FlexGatherArgs), vp]
+    lib.flexnet_gather_rows.restype = C.c_int
     lib.flexnet_wgrad.argtypes = [C.POINTER(FlexWgradArgs), vp]
     lib.flexnet_wgrad.restype = C.c_int
     lib.flexnet_clip_rmsprop.argtypes = [C.POINTER(FlexClipRmspropArgs), vp]

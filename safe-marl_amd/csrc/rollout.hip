@@ -1,7 +1,11 @@
-// rollout.hip — one vector step's transition packing, hand-over and statistics in one launch (gfx950).
-// Boundary: include/flexnet.h (FlexRolloutPackArgs).  Reference: madrl/models/model.py:230-262, utils/replay_buffer.py:23-27.
-// Pure data movement: ~8.4 KB per environment (two observations, two hidden states, action, reward) -> 35 MB per step at
-// 4096 envs, which the PyTorch path moved with some twenty pointwise launches.
+// rollout.hip — replay bookkeeping of the vectorised rollout (gfx950): one vector step's transition into the slab ring at
+// a device-side cursor, hidden-state hand-over and statistics in one launch (rollout_pack_kernel), and the replay-window
+// refresh as one multi-job row copy (gather_rows_kernel).
+// Boundary: include/flexnet.h (FlexRolloutPackArgs, FlexGatherArgs).  Reference: madrl/models/model.py:230-262,
+// utils/replay_buffer.py:14-27.
+// Pure data movement, HBM-bound.  Every observation is stored once (next_state of slab k = obs of slab k + 1), so a step
+// moves obs_next + hid_new in and ring + hand-over out: 4 096 envs x (2 880 + 1 280 read, 2 880 + 2 x 1 280 + 112 written) =
+// 39 MB, against 154 MB for the round-1 layout (packed record with state AND next_state, then a ring copy).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "flexnet.h"
@@ -10,86 +14,157 @@
 #define PACK_ENVS 2                // environments per copy block
 #define PACK_STATS 10               // statistics blocks at the head of the grid
 
+typedef float pack_f4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(PACK_THREADS) void rollout_pack_kernel(FlexRolloutPackArgs a) {
+    const int tid = threadIdx.x;
+    // every block reads the cursor before it takes its ticket; the last ticket holder advances it (below)
+    const int64_t k = a.cursor[0];
     if (blockIdx.x < PACK_STATS) {
         // the first ten blocks own one statistic each (info columns, reward, failures): a block reduction over all
-        // environments and one plain += — ten atomics per copy block (20 k on ten addresses) cost more than the copies
+        // environments in a fixed order and one plain += — no atomics on the sums, bit-reproducible
         __shared__ double red[PACK_THREADS];
-        const int q = blockIdx.x, t = threadIdx.x;
+        const int q = blockIdx.x;
         const bool is_info = q < 8;
-        if (is_info && (q >= a.info_w || !a.info || !a.info_sum)) return;
-        if (q == 9 && (!a.failed || !a.fail_sum)) return;
-        double v = 0.0;
-        for (int e = t; e < a.n_envs; e += PACK_THREADS)
-            v += is_info ? a.info[(int64_t)e * a.info_w + q] : (q == 8 ? a.reward[e] : (a.failed[e] ? 1.0 : 0.0));
-        red[t] = v;
-        __syncthreads();
-        for (int sft = PACK_THREADS / 2; sft > 0; sft >>= 1) {
-            if (t < sft) red[t] += red[t + sft];
+        const bool live = is_info ? (q < a.info_w && a.info && a.info_sum) : (q == 8 ? true : (a.failed && a.fail_sum));
+        if (live) {
+            double v = 0.0;
+            for (int e = tid; e < a.n_envs; e += PACK_THREADS)
+                v += is_info ? a.info[(int64_t)e * a.info_w + q] : (q == 8 ? a.reward[e] : (a.failed[e] ? 1.0 : 0.0));
+            red[tid] = v;
             __syncthreads();
+            for (int sft = PACK_THREADS / 2; sft > 0; sft >>= 1) {
+                if (tid < sft) red[tid] += red[tid + sft];
+                __syncthreads();
+            }
+            if (tid == 0) {
+                if (is_info) a.info_sum[q] += red[0];
+                else if (q == 8) { *a.rew_sum += red[0]; if (a.rng_state) a.rng_state[1] += 1; }
+                else *a.fail_sum += red[0];
+            }
         }
-        if (t == 0) {
-            if (is_info) a.info_sum[q] += red[0];
-            else if (q == 8) { *a.rew_sum += red[0]; if (a.rng_state) a.rng_state[1] += 1; }     // this block always runs
-            else *a.fail_sum += red[0];
+    } else {
+        const int no = a.n_agents * a.obs_dim, na = a.n_agents * a.act_dim, nh = a.n_agents * FLEXNET_HID;
+        const int64_t cur = k % a.slabs, nxt = (k + 1) % a.slabs;
+        const int e0 = (blockIdx.x - PACK_STATS) * PACK_ENVS;
+        for (int j = 0; j < PACK_ENVS; ++j) {
+            const int e = e0 + j;
+            if (e >= a.n_envs) break;
+            const float keep = a.done[e] ? 0.0f : 1.0f;
+            // loads first, then stores (hid_state may alias hid_new): 16-byte units, no * obs_dim and 64 are multiples of 4
+            const pack_f4* on = reinterpret_cast<const pack_f4*>(a.obs_next + (int64_t)e * no);
+            const pack_f4* hn = reinterpret_cast<const pack_f4*>(a.hid_new + (int64_t)e * nh);
+            pack_f4* o_ring = reinterpret_cast<pack_f4*>(a.obs_ring + (nxt * a.n_envs + e) * (int64_t)no);
+            pack_f4* h_ring = reinterpret_cast<pack_f4*>(a.hid_ring + (nxt * a.n_envs + e) * (int64_t)nh);
+            pack_f4* h_state = reinterpret_cast<pack_f4*>(a.hid_state + (int64_t)e * nh);
+            const int no4 = no >> 2, nh4 = nh >> 2;
+            constexpr int MO = (FLEXNET_MAX_AGENTS * FLEXNET_MAX_OBS / 4 + PACK_THREADS - 1) / PACK_THREADS;      // 2
+            constexpr int MH = (FLEXNET_MAX_AGENTS * FLEXNET_HID / 4 + PACK_THREADS - 1) / PACK_THREADS;          // 1
+            pack_f4 ob[MO], hb[MH];
+#pragma unroll
+            for (int t = 0; t < MO; ++t) { const int i = tid + PACK_THREADS * t; if (i < no4) ob[t] = on[i]; }
+#pragma unroll
+            for (int t = 0; t < MH; ++t) { const int i = tid + PACK_THREADS * t; if (i < nh4) hb[t] = hn[i] * keep; }
+#pragma unroll
+            for (int t = 0; t < MO; ++t) {
+                const int i = tid + PACK_THREADS * t;
+                if (i < no4) __builtin_nontemporal_store(ob[t], &o_ring[i]);           // model.py:236,262: next_state = the next state
+            }
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                const int i = tid + PACK_THREADS * t;
+                if (i < nh4) { __builtin_nontemporal_store(hb[t], &h_ring[i]); h_state[i] = hb[t]; }      // fresh hidden state after a terminal step
+            }
+            float* sm = a.small_ring + (cur * a.n_envs + e) * (int64_t)a.small_w;
+            for (int i = tid; i < na; i += PACK_THREADS) sm[i] = a.action[(int64_t)e * na + i];     // model.py:232
+            if (tid < a.n_agents) sm[na + tid] = (float)a.reward[e];                                // model.py:235: one reward, n copies
+            if (tid == 0) { sm[na + a.n_agents] = 1.0f - keep; sm[na + a.n_agents + 1] = 1.0f - keep; }
         }
-        return;
     }
-    const int tid = threadIdx.x;
-    const int no = a.n_agents * a.obs_dim, na = a.n_agents * a.act_dim, nh = a.n_agents * FLEXNET_HID;
-    const int e0 = (blockIdx.x - PACK_STATS) * PACK_ENVS;
-    for (int k = 0; k < PACK_ENVS; ++k) {
-        const int e = e0 + k;
-        if (e >= a.n_envs) break;
-        float* rec = a.rec + (int64_t)e * a.rec_stride;
-        const float done = a.done[e] ? 1.0f : 0.0f;
-        // all loads first, then the stores: obs_state / hid_state may BE obs_prev / hid_prev, so the compiler has to keep
-        // every load-store pair in order and would otherwise expose one memory round trip per loop iteration
-        constexpr int MO = (FLEXNET_MAX_AGENTS * FLEXNET_MAX_OBS + PACK_THREADS - 1) / PACK_THREADS;     // 5
-        constexpr int MH = (FLEXNET_MAX_AGENTS * FLEXNET_HID + PACK_THREADS - 1) / PACK_THREADS;         // 2
-        float prev[MO], next[MO], hp[MH], hn[MH];
-#pragma unroll
-        for (int j = 0; j < MO; ++j) {
-            const int i = tid + PACK_THREADS * j;
-            if (i < no) { prev[j] = a.obs_prev[(int64_t)e * no + i]; next[j] = a.obs_next[(int64_t)e * no + i]; }
+    // self-resetting ticket: the block that takes the last one knows every block has read cursor[0]
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long* ticket = reinterpret_cast<unsigned long long*>(a.cursor + 1);
+        const unsigned long long t = atomicAdd(ticket, 1ULL);
+        if (t == (unsigned long long)gridDim.x - 1ULL) {
+            *ticket = 0ULL;
+            a.cursor[0] = k + 1;
         }
-#pragma unroll
-        for (int j = 0; j < MH; ++j) {
-            const int i = tid + PACK_THREADS * j;
-            if (i < nh) { hp[j] = a.hid_prev[(int64_t)e * nh + i]; hn[j] = a.hid_new[(int64_t)e * nh + i]; }
-        }
-#pragma unroll
-        for (int j = 0; j < MO; ++j) {
-            const int i = tid + PACK_THREADS * j;
-            if (i < no) {
-                rec[a.col_state + i] = prev[j];                        // model.py:230
-                rec[a.col_next_state + i] = next[j];                   // model.py:236
-                a.obs_state[(int64_t)e * no + i] = next[j];            // model.py:262: state = next_state
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < MH; ++j) {
-            const int i = tid + PACK_THREADS * j;
-            if (i < nh) {
-                rec[a.col_last_hid + i] = hp[j];
-                rec[a.col_hid + i] = hn[j];
-                a.hid_state[(int64_t)e * nh + i] = hn[j] * (1.0f - done);   // fresh hidden state for a new episode
-            }
-        }
-        for (int i = tid; i < na; i += PACK_THREADS) rec[a.col_action + i] = a.action[(int64_t)e * na + i];
-        if (tid < a.n_agents) rec[a.col_reward + tid] = (float)a.reward[e];
-        if (tid == 0) { rec[a.col_done] = done; rec[a.col_last_step] = done; }
     }
 }
 
 extern "C" int flexnet_rollout_pack(const FlexRolloutPackArgs* a, void* stream) {
     if (!a || a->n_envs < 0) return FLEXNET_EINVAL;
     if (a->n_envs == 0) return FLEXNET_OK;
-    if (!a->obs_prev || !a->action || !a->reward || !a->obs_next || !a->done || !a->hid_prev || !a->hid_new || !a->rec ||
-        !a->obs_state || !a->hid_state || !a->rew_sum || a->info_w < 0 || a->info_w > 8 || a->n_agents < 1 ||
-        a->n_agents > FLEXNET_MAX_AGENTS || a->obs_dim > FLEXNET_MAX_OBS)
+    if (!a->action || !a->reward || !a->obs_next || !a->done || !a->hid_new || !a->obs_ring || !a->hid_ring ||
+        !a->small_ring || !a->hid_state || !a->cursor || !a->rew_sum || a->info_w < 0 || a->info_w > 8 || a->n_agents < 1 ||
+        a->n_agents > FLEXNET_MAX_AGENTS || a->obs_dim < 1 || a->obs_dim > FLEXNET_MAX_OBS || a->act_dim < 1 ||
+        a->act_dim > FLEXNET_MAX_ACT || a->slabs < 2 || a->small_w < a->n_agents * a->act_dim + a->n_agents + 2)
         return FLEXNET_EINVAL;
+    if (((a->n_agents * a->obs_dim) & 3) != 0) return FLEXNET_EUNSUPPORTED;       // 16-byte units (obs_dim = 6 * history)
+    const uintptr_t align = reinterpret_cast<uintptr_t>(a->obs_next) | reinterpret_cast<uintptr_t>(a->hid_new) |
+                            reinterpret_cast<uintptr_t>(a->obs_ring) | reinterpret_cast<uintptr_t>(a->hid_ring) |
+                            reinterpret_cast<uintptr_t>(a->hid_state);
+    if (align & 15) return FLEXNET_EINVAL;
     const int blocks = (a->n_envs + PACK_ENVS - 1) / PACK_ENVS + PACK_STATS;
     hipLaunchKernelGGL(rollout_pack_kernel, dim3(blocks), dim3(PACK_THREADS), 0, (hipStream_t)stream, *a);
+    return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}
+
+// ---- replay-window refresh ------------------------------------------------------------------------------------------------
+// Job j copies rows[j] rows of width[j] floats from src (row pitch src_stride) to dst (row pitch dst_stride).  The grid is
+// cut over the jobs in proportion to their size (host side); inside a job a block walks 16-byte units when pitch, width and
+// base allow, single floats otherwise (the small record's reward / done columns).
+#define GATHER_THREADS 256
+struct GatherPlan { int first_block[FLEXNET_GATHER_MAX_JOBS + 1]; };
+
+__global__ __launch_bounds__(GATHER_THREADS) void gather_rows_kernel(FlexGatherArgs a, GatherPlan p) {
+    int j = 0;
+    while (j + 1 < a.n_jobs && (int)blockIdx.x >= p.first_block[j + 1]) ++j;
+    const int nb = p.first_block[j + 1] - p.first_block[j], b = blockIdx.x - p.first_block[j];
+    const float* __restrict__ src = a.src[j];
+    float* __restrict__ dst = a.dst[j];
+    const int w = a.width[j], ss = a.src_stride[j], ds = a.dst_stride[j];
+    const int64_t rows = a.rows[j];
+    const bool vec = ((w | ss | ds) & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    if (vec) {
+        const int w4 = w >> 2;
+        const int64_t total = rows * w4;
+        const bool dense = ss == w && ds == w;
+        for (int64_t i = (int64_t)b * GATHER_THREADS + threadIdx.x; i < total; i += (int64_t)nb * GATHER_THREADS) {
+            int64_t so = i, dof = i;
+            if (!dense) { const int64_t r = i / w4; const int c = (int)(i - r * w4); so = r * (ss >> 2) + c; dof = r * (ds >> 2) + c; }
+            const pack_f4 v = __builtin_nontemporal_load(reinterpret_cast<const pack_f4*>(src) + so);
+            reinterpret_cast<pack_f4*>(dst)[dof] = v;
+        }
+    } else {
+        const int64_t total = rows * w;
+        for (int64_t i = (int64_t)b * GATHER_THREADS + threadIdx.x; i < total; i += (int64_t)nb * GATHER_THREADS) {
+            const int64_t r = i / w;
+            const int c = (int)(i - r * w);
+            dst[r * ds + c] = src[r * ss + c];
+        }
+    }
+}
+
+extern "C" int flexnet_gather_rows(const FlexGatherArgs* a, void* stream) {
+    if (!a || a->n_jobs < 0 || a->n_jobs > FLEXNET_GATHER_MAX_JOBS) return FLEXNET_EINVAL;
+    if (a->n_jobs == 0) return FLEXNET_OK;
+    GatherPlan p;
+    int blocks = 0;
+    for (int j = 0; j < a->n_jobs; ++j) {
+        if (!a->src[j] || !a->dst[j] || a->rows[j] < 0 || a->width[j] < 1 || a->src_stride[j] < a->width[j] ||
+            a->dst_stride[j] < a->width[j])
+            return FLEXNET_EINVAL;
+        p.first_block[j] = blocks;
+        // ~16 KB per block, at least one block per job, at most 4096 per job (the loop strides)
+        const int64_t bytes = a->rows[j] * (int64_t)a->width[j] * 4;
+        int64_t nb = (bytes + 16383) / 16384;
+        nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
+        blocks += (int)nb;
+    }
+    p.first_block[a->n_jobs] = blocks;
+    for (int j = a->n_jobs + 1; j <= FLEXNET_GATHER_MAX_JOBS; ++j) p.first_block[j] = blocks;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(GATHER_THREADS), 0, (hipStream_t)stream, *a, p);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }

@@ -132,6 +132,7 @@ class VecFlexProvisionEnv:
         self.info = torch.zeros(N, _lib.FLEX_INFO_W, dtype=torch.float64, device=dev)
         self.failed = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.obs = torch.zeros(N, na, self.obs_size, dtype=torch.float32, device=dev)
+        self.calls = 0          # reset() / step() calls made through this object (a captured graph replays none)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -155,6 +156,7 @@ class VecFlexProvisionEnv:
     def reset(self, mask=None, spec=None, obs_out=None, want_obs=True):
         """spec: dict with any of day/hour/interval (int32 [N]) and e0 [N,na], a0 [N,4na] (f64) device
         tensors; missing items come from the Philox reset stream."""
+        self.calls += 1
         rs = None
         keep = []
         if spec:
@@ -179,6 +181,7 @@ class VecFlexProvisionEnv:
     def step(self, actions, obs_out=None, fuse_obs=False, auto_reset=False):
         """auto_reset: environments that terminate in this step restart inside the same launch (their row of the
         fused observation is then the first observation of the new episode)."""
+        self.calls += 1
         if actions.device != self.device:
             actions = actions.to(self.device)
         actions = actions.contiguous()

@@ -28,27 +28,24 @@ from .util import prep_obs, scale_action, select_action, translate_action, mean_
 
 class RolloutGraph:
     """One vector step of the rollout — policy forward, exploration noise, action scaling, the fused env kernel,
-    packing of the transition record, statistics, hand-over of (obs, hidden) to the next step — captured ONCE as a
-    HIP graph and replayed per step.  Eagerly this is ~25 tiny kernels whose launch cost (0.36 ms) dwarfs the 17 us
-    env kernel; as a graph it is one launch.  Everything the graph touches is a static tensor owned here."""
+    the transition into the slab replay ring, statistics, hand-over of the hidden state — captured ONCE as a HIP graph
+    and replayed per step.  Eagerly this is ~25 tiny kernels whose launch cost (0.36 ms) dwarfs the 14 us env kernel; as
+    a graph it is one launch.  Everything the graph touches is a static tensor owned here, by the env or by the ring.
 
-    STORED = ("state", "action", "reward", "next_state", "done", "last_step", "last_hid", "hid")
+    The observation the policy reads IS the env's own output buffer (``env.obs``): the ring already holds it (the pack
+    kernel of the step that produced it wrote it into the next slab), so nothing is handed over or copied twice."""
 
     def __init__(self, model, env, buf):
         self.model, self.env, self.buf = model, env, buf
         N, n, o, a, h = env.n_envs, model.n_, model.obs_dim, model.act_dim, model.hid_dim
         dev = model.device
-        shapes = {"state": (n, o), "action": (n, a), "reward": (n,), "next_state": (n, o), "done": (), "last_step": (),
-                  "last_hid": (n, h), "hid": (n, h)}
-        if buf.store is None:
-            buf.alloc_packed(shapes)
-            buf.consts = {"log_prob_a": 0.0, "value": 0.0, "next_value": 0.0, "action_avail": 1.0}
-            buf.const_shapes = {"log_prob_a": (n, a), "value": (n, 1), "next_value": (n, 1), "action_avail": (n, a)}
-        if not hasattr(buf, "store2d"):
-            raise RuntimeError("replay buffer was not allocated in packed mode")
-        self.rec = th.zeros(N, buf.store2d.shape[1], device=dev)
-        self.f = buf.record_views(self.rec)
-        self.obs = th.zeros(N, n, o, device=dev)
+        if not buf.slab_mode:
+            if buf.store is not None:
+                raise RuntimeError("replay buffer already holds field-by-field transitions; the graph rollout needs slab mode")
+            buf.alloc_slabs(N, n, o, a, h)
+        if (buf.n_envs, buf.n_agents, buf.obs_dim, buf.act_dim, buf.hid_dim) != (N, n, o, a, h):
+            raise RuntimeError("replay buffer was allocated for another environment batch")
+        self.obs = env.obs                          # [N, n, o]: written by the env kernel, read by the policy
         self.hid = th.zeros(N, n, h, device=dev)
         self.info_sum = th.zeros(env.info.shape[1], dtype=th.float64, device=dev)
         self.rew_sum = th.zeros((), dtype=th.float64, device=dev)
@@ -60,34 +57,33 @@ class RolloutGraph:
         self.rng_state[0] = int(th.randint(0, 2 ** 62, (1,)).item())
         self.plain = type(model).get_actions is MADDPG.get_actions and bool(model.args.action_enforcebound)
         self.avail = th.ones(N, n, a, device=dev)             # every action is available (env:721-730)
-        # plain MADDPG on the GPU: policy + exploration in one HIP launch, packing + hand-over + statistics in another
+        # plain MADDPG on the GPU: policy + exploration in one HIP launch, ring write + hand-over + statistics in another
         self.safe = type(model).__name__ == "SAFEMADDPG"       # + the safety projection between policy and env
         # (the actor kernel's exploration epilogue IS tanh(mean + std * noise), util.py:57-64: without action_enforcebound
         # the reference adds unbounded noise, util.py:66-74, and the general body below runs select_action itself)
         self.fast = (type(model).__name__ in ("MADDPG", "SAFEMADDPG") and model.fused_inference
                      and model.args.shared_params and self.obs.is_cuda and model.args.agent_type == "rnn" and h == 64
                      and o <= 144 and bool(model.args.action_enforcebound))
-        # record packing / hand-over / statistics in ONE launch of this project's kernel (fixed-order block sums): no ATen
+        # ring write / hand-over / statistics in ONE launch of this project's kernel (fixed-order block sums): no ATen
         # reduction is ever captured into the rollout graph, whatever the algorithm
-        self.packable = self.obs.is_cuda and h == 64 and o <= 144 and n <= 8 and a <= 8
+        self.packable = self.obs.is_cuda and h == 64 and o <= 144 and n <= 8 and a <= 8 and (n * o) % 4 == 0
         if self.safe:
             self.predictor = tuple(th.as_tensor(x, dtype=th.float64, device=dev).contiguous() for x in model.predictor)
-        self.cols = {k: buf.packed_cols[k][0] for k in self.STORED}
+        self.env_calls = None                                  # env.calls after this object's last step (continuity check)
 
     def _pack(self, action, hid):
         """model.py:230-262 for every environment in one launch (include/flexnet.h: flexnet_rollout_pack)."""
         import ctypes as C
         from . import _lib
-        m, env = self.model, self.env
+        m, env, buf = self.model, self.env, self.buf
         a = _lib.FlexRolloutPackArgs()
         a.n_envs, a.n_agents, a.obs_dim, a.act_dim = env.n_envs, m.n_, m.obs_dim, m.act_dim
-        a.rec_stride, a.info_w = self.rec.shape[1], env.info.shape[1]
-        for k in self.STORED:
-            setattr(a, "col_" + k, self.cols[k])
-        for name, t in (("obs_prev", self.obs), ("action", action), ("reward", env.reward), ("obs_next", env.obs),
-                        ("done", env.done), ("hid_prev", self.hid), ("hid_new", hid), ("info", env.info),
-                        ("failed", env.failed), ("rec", self.rec), ("obs_state", self.obs), ("hid_state", self.hid),
-                        ("info_sum", self.info_sum), ("rew_sum", self.rew_sum), ("fail_sum", self.fail_sum)):
+        a.slabs, a.small_w, a.info_w = buf.slabs, buf.small_w, env.info.shape[1]
+        for name, t in (("action", action), ("reward", env.reward), ("obs_next", env.obs), ("done", env.done),
+                        ("hid_new", hid), ("info", env.info), ("failed", env.failed), ("obs_ring", buf.obs_ring),
+                        ("hid_ring", buf.hid_ring), ("small_ring", buf.small_ring), ("hid_state", self.hid),
+                        ("cursor", buf.cursor), ("info_sum", self.info_sum), ("rew_sum", self.rew_sum),
+                        ("fail_sum", self.fail_sum)):
             assert t.is_contiguous()
             setattr(a, name, t.data_ptr())
         if not self.torch_noise:
@@ -95,8 +91,14 @@ class RolloutGraph:
         _lib.check(_lib.load().flexnet_rollout_pack(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)),
                    "flexnet_rollout_pack")
 
+    def last_transition(self):
+        """Views of the transition the last step wrote (tests, debugging): the slab before the cursor."""
+        buf = self.buf
+        N = self.env.n_envs
+        return buf.slab_window((buf.k - 1) * N, N)
+
     def body(self):
-        m, env, f = self.model, self.env, self.f
+        m, env = self.model, self.env
         N = env.n_envs
         if self.fast:
             with th.no_grad():
@@ -130,26 +132,25 @@ class RolloutGraph:
                                                               actions_avail=self.avail, target=False, last_hid=self.hid)
                 action_pol = action_pol.expand(N, m.n_, m.act_dim)
             env.step(m.env_action(action), fuse_obs=True, auto_reset=True)
-            if self.packable:
-                self._pack(action_pol.to(th.float32).contiguous(), hid.reshape(N, m.n_, -1).to(th.float32).contiguous())
-                return
-            # shapes outside the pack kernel (never captured as a graph: capture() refuses): plain tensor ops
-            donef = env.done.float()
-            f["state"].copy_(self.obs); f["action"].copy_(action_pol); f["next_state"].copy_(env.obs)
-            f["reward"].copy_(env.reward.float().unsqueeze(1).expand(N, m.n_))
-            f["done"].copy_(donef); f["last_step"].copy_(donef)
-            f["last_hid"].copy_(self.hid); f["hid"].copy_(hid)
-            self.info_sum += env.info.sum(0)
-            self.rew_sum += env.reward.sum()
-            self.fail_sum += env.failed.sum()
-            self.obs.copy_(env.obs)
-            self.hid.copy_(hid * (1.0 - donef).view(N, 1, 1))
+            self._pack(action_pol.to(th.float32).contiguous(), hid.reshape(N, m.n_, -1).to(th.float32).contiguous())
+
+    def step(self):
+        """One vector step: a graph replay (or the eager body before capture) plus the host mirror of the ring cursor.
+        Returns the physical slab the step completed."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.body()
+        return self.buf.stepped()
 
     def capture(self):
+        """Warm-up + capture.  The warm-up steps are real steps of the environment; the ring cursor and the statistics
+        they moved are put back afterwards (the slabs they wrote are overwritten by the steps that follow)."""
         import os
         if not self.packable:
             raise RuntimeError("observation / hidden sizes outside flexnet_rollout_pack: the statistics would go through "
                                "ATen reductions, which must not be captured into a HIP graph (DESIGN.md §6)")
+        cursor0 = self.buf.cursor.clone()
         if os.environ.get("FLEX_GRAPH_AUDIT") == "1":
             from .util import audit_graph_body
             self.audit = audit_graph_body(self.body)
@@ -163,10 +164,17 @@ class RolloutGraph:
         with th.cuda.graph(g):
             self.body()
         self.graph = g
+        self.buf.cursor.copy_(cursor0)
 
-    def start_episode(self, first_obs):
-        self.obs.copy_(first_obs)
-        self.hid.zero_()
+    def start_episode(self, first_obs=None):
+        """``first_obs`` given: a hard reset happened (env.reset()); the stream restarts in the ring and the hidden state
+        is zero.  None: the environments continue where the last step left them (those that terminated restarted
+        inside that launch, their hidden state was zeroed by the pack kernel)."""
+        if first_obs is not None:
+            if first_obs.data_ptr() != self.obs.data_ptr():
+                self.obs.copy_(first_obs)
+            self.hid.zero_()
+            self.buf.begin_stream(self.obs)
         self.info_sum.zero_(); self.rew_sum.zero_(); self.fail_sum.zero_()
 
 
@@ -423,6 +431,7 @@ class Model(nn.Module):
         rg = getattr(self, "_rollout_graph", None)
         if rg is None or rg.env is not env or rg.buf is not buf:
             rg = RolloutGraph(self, env, buf)
+            rg.start_episode(env.reset())                 # the warm-up steps of capture() need a live episode
             try:
                 rg.capture()
             except Exception as exc:                      # capture unsupported here: fall back to the eager loop
@@ -431,20 +440,29 @@ class Model(nn.Module):
                 trainer.graph_rollout = False
                 return self._train_process_vec(stat, trainer)
             object.__setattr__(self, "_rollout_graph", rg)
-        rg.start_episode(env.reset())
+        # model.py:208 resets the environment at the start of every episode.  Here an episode of `horizon` vector steps
+        # ends with every environment terminated and restarted IN the last launch (fresh draws from the same reset
+        # stream), so the next episode continues from that state: same distribution, and the replay ring stays one
+        # unbroken stream (next_state of slab k is slab k + 1).  A hard reset happens when that is not the case: the
+        # first episode, environments out of phase (a solver failure restarted some mid-episode), or anybody else having
+        # stepped / reset the env since (evaluation).
+        if rg.env_calls == getattr(env, "calls", None) and getattr(rg, "in_phase", False):
+            rg.start_episode(None)
+        else:
+            rg.start_episode(env.reset())
+        small = buf.small_ring
+        last_col = self.n_ * self.act_dim + self.n_ + 1
         for t in range(horizon):
-            rg.graph.replay()
-            start = buf.add_packed(rg.rec)
+            slab = rg.step()
             if t == horizon - 1:                                              # model.py:229: last_step on the final step
-                c0 = buf.packed_cols["last_step"][0]
-                first = min(N, buf.size - start)
-                buf.store2d[start:start + first, c0] = 1.0
-                if first < N:
-                    buf.store2d[:N - first, c0] = 1.0
+                small[slab, :, last_col] = 1.0
             self.transition_update(trainer, None, stat)
             trainer.steps += 1
         trainer.episodes += 1
-        vals = th.cat([rg.info_sum, rg.rew_sum.view(1), rg.fail_sum.view(1)]).cpu().numpy() / float(N * horizon)
+        vals = th.cat([rg.info_sum, rg.rew_sum.view(1), rg.fail_sum.view(1), env.done.double().sum().view(1)]).cpu().numpy()
+        rg.in_phase = bool(vals[-1] == N)                 # everybody terminated (and restarted) in the last launch
+        rg.env_calls = getattr(env, "calls", None)
+        vals = vals[:-1] / float(N * horizon)
         from ._lib import INFO_KEYS
         for i, k in enumerate(INFO_KEYS):
             stat["mean_train_" + k] = float(vals[i])

@@ -54,30 +54,175 @@ class DeviceReplayBuffer:
         self.store = {k: th.zeros((self.size,) + tuple(s), dtype=th.float32, device=self.device)
                       for k, s in shapes.items()}
 
-    def alloc_packed(self, shapes):
-        """One [size, D] tensor holding every stored field side by side; ``store[field]`` are strided views into it.
-        A whole transition batch then lands with ONE copy (``add_packed``) — what a graph-captured rollout needs —
-        while ``add_batch`` / ``window`` keep working field by field."""
-        widths = {k: int(np.prod(sh)) if len(sh) else 1 for k, sh in shapes.items()}
-        self.packed_cols, off = {}, 0
-        for k, w in widths.items():
-            self.packed_cols[k] = (off, off + w, tuple(shapes[k]))
-            off += w
-        self.store2d = th.zeros(self.size, off, dtype=th.float32, device=self.device)
-        self.store = {k: self.store2d[:, c0:c1].view((self.size,) + sh) for k, (c0, c1, sh) in self.packed_cols.items()}
+    # -- slab mode: the vectorised, graph-captured rollout ------------------------------------------------------------
+    def alloc_slabs(self, n_envs, n_agents, obs_dim, act_dim, hid_dim):
+        """Slab-structured ring for N environments stepping in lockstep (include/flexnet.h: flexnet_rollout_pack writes it
+        at a device-side cursor).  Slab k = vector step k: ``obs_ring[k]`` the observation acted on, ``hid_ring[k]`` the
+        hidden state going in, ``small_ring[k]`` = [action | reward | done | last_step].  Every observation is stored
+        once: next_state of slab k is ``obs_ring[k + 1]``, model.py:241's ``hid`` is ``hid_ring[k + 1]``.
 
-    def record_views(self, rec):
-        """Field views of a packed [B, D] staging record with the same column layout."""
-        return {k: rec[:, c0:c1].view((rec.shape[0],) + sh) for k, (c0, c1, sh) in self.packed_cols.items()}
+        Host-side bookkeeping mirrors the device cursor: slab counter ``k`` (monotone), the slab being filled is
+        ``k % slabs``; transitions are the COMPLETE slabs still in the ring.  A slab left without an action (the rollout
+        was restarted from a hard reset instead of continuing) is a *gap*; sampled windows never span one."""
+        self.n_envs, self.n_agents, self.obs_dim, self.act_dim, self.hid_dim = n_envs, n_agents, obs_dim, act_dim, hid_dim
+        self.slabs = self.size // n_envs
+        if self.slabs < 4:
+            raise ValueError("slab replay needs room for at least 4 vector steps")
+        no, nh = n_agents * obs_dim, n_agents * hid_dim
+        self.small_w = ((n_agents * act_dim + n_agents + 2 + 3) // 4) * 4       # 16-byte rows
+        dev = self.device
+        self.obs_ring = th.zeros(self.slabs, n_envs, no, dtype=th.float32, device=dev)
+        self.hid_ring = th.zeros(self.slabs, n_envs, nh, dtype=th.float32, device=dev)
+        self.small_ring = th.zeros(self.slabs, n_envs, self.small_w, dtype=th.float32, device=dev)
+        self.cursor = th.zeros(2, dtype=th.int64, device=dev)                     # {slab counter, ticket}
+        self.k = 0                   # host mirror of cursor[0]
+        self.first = 0               # oldest slab counter whose transition may still be in the ring
+        self.gaps = []               # slab counters without a transition (half-written by the step before a hard reset)
+        self.consts = {"log_prob_a": 0.0, "value": 0.0, "next_value": 0.0, "action_avail": 1.0}
+        self.const_shapes = {"log_prob_a": (n_agents, act_dim), "value": (n_agents, 1), "next_value": (n_agents, 1),
+                             "action_avail": (n_agents, act_dim)}
+        self.store = None
+        self.head = 0
+        self.length = 0
 
-    def add_packed(self, rec):
-        b = rec.shape[0]
-        start = self._slots(b)
-        first = min(b, self.size - start)
-        self.store2d[start:start + first].copy_(rec[:first])
-        if first < b:
-            self.store2d[:b - first].copy_(rec[first:])
-        return start
+    @property
+    def slab_mode(self):
+        return getattr(self, "obs_ring", None) is not None
+
+    def begin_stream(self, first_obs):
+        """A rollout starts from a hard reset: ``first_obs`` [N, n, obs] becomes the observation of the slab at the
+        cursor, its hidden state is zero.  If a previous stream left the slab at the cursor half-written (observation
+        without an action), that slab becomes a gap and the stream starts one slab later."""
+        if self.k > 0:
+            self.gaps.append(self.k)
+            self.k += 1
+        p = self.k % self.slabs
+        self.obs_ring[p].copy_(first_obs.reshape(self.n_envs, -1))
+        self.hid_ring[p].zero_()
+        self.cursor[0] = self.k
+        self._retire()
+
+    def stepped(self):
+        """Host mirror of one flexnet_rollout_pack launch (or graph replay): slab k is complete, the cursor moved on.
+        Returns the physical index of the slab just completed."""
+        done_slab = self.k % self.slabs
+        self.k += 1
+        self._retire()
+        return done_slab
+
+    def _retire(self):
+        # the slab at the cursor (and its half-written successor after the next step) overwrite the oldest ones
+        self.first = max(self.first, self.k + 2 - self.slabs)
+        self.gaps = [g for g in self.gaps if g >= self.first]
+        self.length = self.n_envs * (self.k - self.first - len(self.gaps))
+
+    def _runs(self):
+        """Maximal runs [a, b) of slab counters holding consecutive complete transitions."""
+        runs, a = [], self.first
+        for g in self.gaps:
+            if g > a:
+                runs.append((a, g))
+            a = g + 1
+        if self.k > a:
+            runs.append((a, self.k))
+        return runs
+
+    def sample_slot(self, batch_size):
+        """utils/replay_buffer.py:17-21 on the slab ring: a uniformly random start among the windows of ``batch_size``
+        consecutive transitions (slots; time-major, so consecutive slots are the N environments of one vector step, then
+        the next step).  Returns the start as a global slot number (slab counter * N + env)."""
+        N = self.n_envs
+        spans = [(a * N, (b - a) * N - batch_size + 1) for a, b in self._runs() if (b - a) * N >= batch_size]
+        total = sum(c for _, c in spans)
+        if total < 1:
+            raise ValueError("not enough transitions for a batch")
+        r = int(np.random.randint(total))
+        for base, c in spans:
+            if r < c:
+                return base + r
+            r -= c
+        raise AssertionError
+
+    def segments(self, slot, rows):
+        """Physical pieces of the global slot range [slot, slot + rows): [(physical_slot, count)] (two at the ring's seam)."""
+        cap = self.slabs * self.n_envs
+        p = slot % cap
+        first = min(rows, cap - p)
+        return [(p, first)] + ([(0, rows - first)] if first < rows else [])
+
+    def slab_window(self, slot, batch_size):
+        """Transition of device tensors for the window starting at global slot ``slot`` (eager consumers)."""
+        N, n = self.n_envs, self.n_agents
+
+        def take(ring, start, rows):
+            flat = ring.view(self.slabs * N, -1)
+            parts = [flat[p:p + c] for p, c in self.segments(start, rows)]
+            return parts[0] if len(parts) == 1 else th.cat(parts)
+
+        na = n * self.act_dim
+        small = take(self.small_ring, slot, batch_size)
+        out = {"state": take(self.obs_ring, slot, batch_size).view(batch_size, n, self.obs_dim),
+               "next_state": take(self.obs_ring, slot + N, batch_size).view(batch_size, n, self.obs_dim),
+               "last_hid": take(self.hid_ring, slot, batch_size).view(batch_size, n, self.hid_dim),
+               "hid": take(self.hid_ring, slot + N, batch_size).view(batch_size, n, self.hid_dim),
+               "action": small[:, :na].reshape(batch_size, n, self.act_dim),
+               "reward": small[:, na:na + n], "done": small[:, na + n], "last_step": small[:, na + n + 1]}
+        for k, c in self.consts.items():
+            shape = self.const_shapes.get(k, ())
+            out[k] = th.full((1,) + tuple(1 for _ in shape), float(c), device=self.device).expand((batch_size,) + tuple(shape))
+            out[k]._flex_const = float(c)
+        return Transition(**out)
+
+    # what a field of the Transition is in the ring: (ring name, first column, width or None = whole row, slab offset)
+    def field_source(self, name):
+        n, na = self.n_agents, self.n_agents * self.act_dim
+        return {"state": ("obs_ring", 0, None, 0), "next_state": ("obs_ring", 0, None, 1),
+                "last_hid": ("hid_ring", 0, None, 0), "hid": ("hid_ring", 0, None, 1),
+                "action": ("small_ring", 0, na, 0), "reward": ("small_ring", na, n, 0),
+                "done": ("small_ring", na + n, 1, 0), "last_step": ("small_ring", na + n + 1, 1, 0)}[name]
+
+    def field_shape(self, name):
+        n = self.n_agents
+        return {"state": (n, self.obs_dim), "next_state": (n, self.obs_dim), "last_hid": (n, self.hid_dim),
+                "hid": (n, self.hid_dim), "action": (n, self.act_dim), "reward": (n,), "done": (), "last_step": ()}[name]
+
+    STORED = ("state", "action", "reward", "next_state", "done", "last_step", "last_hid", "hid")
+
+    def gather(self, plan, slot):
+        """Refresh static batch tensors from the window starting at global slot ``slot``: ONE launch of
+        flexnet_gather_rows (include/flexnet.h).  ``plan`` = [(ring name, first column, width, row offset, rows, dst)],
+        dst a contiguous [rows, width] fp32 tensor."""
+        import ctypes as C
+        from . import _lib
+        a = _lib.FlexGatherArgs()
+        j = 0
+        cap = self.slabs * self.n_envs
+        for ring_name, col0, width, row_off, rows, dst in plan:
+            ring = getattr(self, ring_name)
+            stride = ring.shape[2]
+            width = stride if width is None else width
+            base, out, done_rows = ring.data_ptr(), dst.data_ptr(), 0
+            for p, c in self.segments(slot + row_off, rows):
+                if j >= _lib.FLEXNET_GATHER_MAX_JOBS:
+                    raise RuntimeError("replay refresh needs more copy jobs than flexnet_gather_rows takes")
+                a.src[j], a.dst[j] = base + 4 * (p * stride + col0), out + 4 * done_rows * width
+                a.rows[j], a.width[j], a.src_stride[j], a.dst_stride[j] = c, width, stride, width
+                done_rows += c
+                j += 1
+        a.n_jobs = j
+        assert cap > 0
+        _lib.check(_lib.load().flexnet_gather_rows(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_gather_rows")
+
+    def _logical_to_slot(self, index):
+        """Global slot of logical transition ``index`` (0 = oldest), skipping gaps."""
+        N = self.n_envs
+        for a, b in self._runs():
+            cnt = (b - a) * N
+            if index < cnt:
+                return a * N + index
+            index -= cnt
+        raise IndexError("transition index out of range")
 
     def _slots(self, count):
         """Physical slots for ``count`` new transitions, dropping the oldest when full."""
@@ -96,6 +241,9 @@ class DeviceReplayBuffer:
         consts = {k: v for k, v in fields.items() if not isinstance(v, th.Tensor)}
         fields = {k: v for k, v in fields.items() if isinstance(v, th.Tensor)}
         b = next(iter(fields.values())).shape[0]
+        if self.slab_mode:
+            raise RuntimeError("this replay buffer is in slab mode (written by flexnet_rollout_pack); add_batch is the "
+                               "field-by-field mode of the eager rollout")
         if self.store is None:
             self._alloc({k: v.shape[1:] for k, v in fields.items()})
             self.consts = dict(consts)
@@ -129,6 +277,8 @@ class DeviceReplayBuffer:
     def clear(self):
         self.head = 0
         self.length = 0
+        if self.slab_mode:
+            self.first, self.gaps = self.k, []
 
     # -- sampling ------------------------------------------------------------------------------
     def sample_start(self, batch_size):
@@ -144,6 +294,11 @@ class DeviceReplayBuffer:
 
     def window(self, start, batch_size):
         """Device tensors of logical transitions [start, start+batch_size)."""
+        if self.slab_mode:
+            slot = self._logical_to_slot(start)
+            if self._logical_to_slot(start + batch_size - 1) != slot + batch_size - 1:
+                raise ValueError("window spans a gap of the slab ring")
+            return self.slab_window(slot, batch_size)
         p0 = (self.head + start) % self.size
         out = {}
         for k, c in self.consts.items():
@@ -158,6 +313,8 @@ class DeviceReplayBuffer:
         return Transition(**out)
 
     def get_batch_tensors(self, batch_size):
+        if self.slab_mode:
+            return self.slab_window(self.sample_slot(batch_size), batch_size)
         return self.window(self.sample_start(batch_size), batch_size)
 
     def get_single(self, index):

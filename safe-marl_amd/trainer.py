@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import logging
 
+import numpy as np
 import torch as th
 from torch.optim import RMSprop
 
@@ -86,11 +87,11 @@ class PGTrainer(object):
     # ---- a sub-update as one HIP graph -----------------------------------------------------------------------
     def _graphed_sub_update(self, which, stat):
         """A sub-update is ~120 kernel launches that take the host longer to issue (1.6 ms) than the GPU to run; with
-        the replay ring in its packed layout the sampled window is copied into a static batch (one copy per field read) and the whole
-        step — losses, backward, gradient clip, RMSprop — is replayed as one HIP graph.  Returns False when this
-        configuration does not qualify (the caller then runs the eager step)."""
+        the replay in slab mode the sampled window is gathered into a static batch (ONE launch, include/flexnet.h:
+        flexnet_gather_rows) and the whole step — losses, backward, gradient clip, RMSprop — is replayed as one HIP graph.
+        Returns False when this configuration does not qualify (the caller then runs the eager step)."""
         buf = self.replay_buffer
-        if not (self.graph_updates and self.device.type == "cuda" and hasattr(buf, "store2d")):
+        if not (self.graph_updates and self.device.type == "cuda" and getattr(buf, "slab_mode", False)):
             return False
         if not getattr(self.behaviour_net, "graph_safe_updates", False):
             # Only models whose gradient path is free of PyTorch's multi-block reductions are replayed as graphs: with
@@ -109,15 +110,7 @@ class PGTrainer(object):
                 self.graph_updates = False
                 return False
             self._update_graphs[which] = g
-        start = buf.sample_start(bs)
-        p0 = (buf.head + start) % buf.size
-        first = min(bs, buf.size - p0)
-        for k, dst in g["static"].items():         # only the record columns this sub-update reads
-            c0, c1 = buf.packed_cols[k][:2]
-            flat = dst.view(bs, c1 - c0)
-            flat[:first].copy_(buf.store2d[p0:p0 + first, c0:c1])
-            if first < bs:
-                flat[first:].copy_(buf.store2d[:bs - first, c0:c1])
+        buf.gather(g["plan"], buf.sample_slot(bs))       # only the ring columns this sub-update reads
         g["graph"].replay()
         if g["apply"] is not None:
             # more than one rank: the captured region is split at the exchange step — graph A (losses, backward, gradients
@@ -128,25 +121,49 @@ class PGTrainer(object):
         stat.update(g["stat"])
         return True
 
+    def _static_batch(self, which, bs):
+        """Static tensors a captured sub-update reads, and the gather plan that refreshes them.  Every observation sits
+        in the ring once, so when a loss reads both ``state`` and ``next_state`` they are two views — N rows apart — of
+        ONE gathered block of bs + N observation rows (9/16 of the bytes of two separate copies at the default batch)."""
+        buf = self.replay_buffer
+        N = buf.n_envs
+        names = (getattr(self.behaviour_net, "update_fields", None) or {}).get(which) or buf.STORED
+        fields, plan = {}, []
+        dev = self.device
+
+        def block(rows, width):
+            return th.zeros(rows, width, dtype=th.float32, device=dev)
+
+        if "state" in names and "next_state" in names:
+            w = buf.n_agents * buf.obs_dim
+            win = block(bs + N, w)
+            plan.append(("obs_ring", 0, None, 0, bs + N, win))
+            fields["state"] = win[:bs].view((bs,) + buf.field_shape("state"))
+            fields["next_state"] = win[N:N + bs].view((bs,) + buf.field_shape("next_state"))
+        for k in names:
+            if k in fields:
+                continue
+            ring, col0, width, slab_off = buf.field_source(k)
+            shape = buf.field_shape(k)
+            w = int(np.prod(shape)) if len(shape) else 1
+            t = block(bs, w)
+            plan.append((ring, col0, width, slab_off * N, bs, t))
+            fields[k] = t.view((bs,) + shape)
+        for k in buf.STORED:                          # never read by this loss: a broadcast zero of the right shape
+            if k not in fields:
+                shape = buf.field_shape(k)
+                fields[k] = th.zeros((1,) + tuple(1 for _ in shape), device=dev).expand((bs,) + shape)
+        for k, c in buf.consts.items():
+            shape = buf.const_shapes.get(k, ())
+            fields[k] = th.full((1,) + tuple(1 for _ in shape), float(c), device=dev).expand((bs,) + tuple(shape))
+            fields[k]._flex_const = float(c)
+        return fields, plan
+
     def _capture_sub_update(self, which, bs):
         from .replay_buffer import Transition
         buf = self.replay_buffer
-        # static batch: the fields this loss reads as CONTIGUOUS tensors of their own (the per-replay refresh
-        # de-interleaves the packed rows, so no reshape of a field costs a copy inside the graph); the others, never
-        # read, as views of one spare packed row block
-        names = (getattr(self.behaviour_net, "update_fields", None) or {}).get(which) or tuple(buf.packed_cols)
-        batch2d = th.zeros(bs, buf.store2d.shape[1], dtype=th.float32, device=self.device)
-        fields = buf.record_views(batch2d)
-        static = {}
-        for k in names:
-            c0, c1, shape = buf.packed_cols[k]
-            static[k] = th.zeros((bs,) + tuple(shape), dtype=th.float32, device=self.device)
-            static[k].view(bs, c1 - c0).copy_(buf.store2d[:bs, c0:c1])
-            fields[k] = static[k]
-        for k, c in buf.consts.items():
-            shape = buf.const_shapes.get(k, ())
-            fields[k] = th.full((1,) + tuple(1 for _ in shape), float(c), device=self.device).expand((bs,) + tuple(shape))
-            fields[k]._flex_const = float(c)
+        fields, plan = self._static_batch(which, bs)
+        buf.gather(plan, buf._logical_to_slot(0))          # real transitions for the warm-up steps
         batch = Transition(**fields)
         out = {}
         # the warm-up steps are real optimiser steps: everything they touch is put back afterwards, IN PLACE (the graph
@@ -191,7 +208,7 @@ class PGTrainer(object):
                         v.copy_(old) if old is not None else v.zero_()
         # `batch` stays referenced: its constant fields (action_avail, ...) were allocated eagerly and are baked into the
         # graph by address; released, the allocator would hand their memory to the next eager tensor
-        return dict(graph=graph, apply=apply_graph, flat=flat, static=static, stat=out, bs=bs, buf=buf, batch=batch)
+        return dict(graph=graph, apply=apply_graph, flat=flat, plan=plan, stat=out, bs=bs, buf=buf, batch=batch)
 
     # kept for callers that hand over a batch themselves (trainer.py:81,99)
     def policy_transition_process(self, stat, trans):

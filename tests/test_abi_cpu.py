@@ -43,7 +43,9 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.SeriesTab) == 24 and C.sizeof(_lib.ResetSpec) == 40
     assert C.sizeof(_lib.FlexActorArgs) == 8 * 4 + 17 * 8 + 4 * 4 + 8     # include/flexnet.h
     assert C.sizeof(_lib.FlexCriticTailArgs) == 4 * 4 + 18 * 8 + 2 * 4 + 2 * 8 + 8 + 8
-    assert C.sizeof(_lib.FlexRolloutPackArgs) == 16 * 4 + 16 * 8
+    assert C.sizeof(_lib.FlexRolloutPackArgs) == 8 * 4 + 16 * 8
+    assert C.sizeof(_lib.FlexGatherArgs) == 8 + 12 * (8 + 8 + 8 + 4 + 4 + 4)
+    assert C.sizeof(_lib.FlexSumArgs) == 8 + 4 + 4 + 3 * 8 + 8
     assert C.sizeof(_lib.FlexWgradArgs) == 4 * 8 + 4 * 4 + 5 * 8
     assert C.sizeof(_lib.FlexLnReluArgs) == 4 * 4 + 13 * 8 + 8
     assert C.sizeof(_lib.FlexTdLossArgs) == 6 * 4 + 12 * 8 + 8
@@ -65,6 +67,14 @@ def test_bad_arguments_are_rejected_before_any_device_work(lib, net):
     a = _lib.FlexActorArgs()
     a.rows = 8
     assert lib.flexnet_actor_forward(C.byref(a), None) == -1                            # null tensors
+    p = _lib.FlexRolloutPackArgs()
+    p.n_envs, p.n_agents, p.obs_dim, p.act_dim, p.slabs, p.small_w = 4, 5, 144, 4, 8, 28
+    assert lib.flexnet_rollout_pack(C.byref(p), None) == -1                             # null rings / cursor
+    g = _lib.FlexGatherArgs()
+    g.n_jobs = 13
+    assert lib.flexnet_gather_rows(C.byref(g), None) == -1                              # more jobs than the struct holds
+    g.n_jobs = 1
+    assert lib.flexnet_gather_rows(C.byref(g), None) == -1                              # null job
 
 
 def test_product_path_fails_loudly_without_the_library(monkeypatch, tmp_path):

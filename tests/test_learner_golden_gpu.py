@@ -197,28 +197,36 @@ def test_maddpg_one_optimizer_step_and_target_update_match_the_reference(gold, t
 
 
 def test_maddpg_graphed_sub_updates_match_the_reference(gold):
-    """The same two sub-updates as HIP-graph replays out of the packed replay ring (trainer._graphed_sub_update):
-    the ring holds exactly one batch — the golden batch tiled 64 times — so the sampled window is that batch."""
+    """The same two sub-updates as HIP-graph replays out of the slab replay ring (trainer._graphed_sub_update): the ring
+    holds exactly one complete vector step of bs "environments" — slab 0 = (state, last_hid, action, reward, done) of the
+    golden batch tiled 64 times, slab 1 = (next_state, hid) — so the only window there is to sample is that batch."""
     from safe_marl_amd.learner import MADDPG
     from safe_marl_amd.trainer import PGTrainer
     _loaded_lib()
     tile = 64
     bs = 32 * tile
     args = _args()
-    trainer = PGTrainer(args, MADDPG, StubEnv(), None, batch_scale=tile, replay_capacity=bs, graph_updates=True)
+    trainer = PGTrainer(args, MADDPG, StubEnv(), None, batch_scale=tile, replay_capacity=4 * bs, graph_updates=True)
     trainer.behaviour_net.load_state_dict(_load_sd("learner_state_dict.npz"))
     buf = trainer.replay_buffer
     n, o, a, h = 5, 144, 4, 64
-    buf.alloc_packed({"state": (n, o), "action": (n, a), "reward": (n,), "next_state": (n, o), "done": (), "last_step": (),
-                      "last_hid": (n, h), "hid": (n, h)})
-    buf.consts = {"log_prob_a": 0.0, "value": 0.0, "next_value": 0.0, "action_avail": 1.0}
-    buf.const_shapes = {"log_prob_a": (n, a), "value": (n, 1), "next_value": (n, 1), "action_avail": (n, a)}
     b = _batch(tile)
-    rec = th.zeros(bs, buf.store2d.shape[1], device="cuda")
-    for k, view in buf.record_views(rec).items():
-        view.copy_(getattr(b, k))
-    buf.add_packed(rec)
+    buf.alloc_slabs(bs, n, o, a, h)
+    buf.begin_stream(b.state)
+    buf.hid_ring[0].copy_(b.last_hid.reshape(bs, -1))
+    small = buf.small_ring[0]
+    small[:, :n * a].copy_(b.action.reshape(bs, -1))
+    small[:, n * a:n * a + n].copy_(b.reward)
+    small[:, n * a + n].copy_(b.done)
+    small[:, n * a + n + 1].copy_(b.last_step)
+    buf.obs_ring[1].copy_(b.next_state.reshape(bs, -1))
+    buf.hid_ring[1].copy_(b.hid.reshape(bs, -1))
+    buf.cursor[0] = 1
+    assert buf.stepped() == 0
     assert len(buf.buffer) == bs == trainer.effective_batch_size()
+    w = buf.get_batch_tensors(bs)
+    for k in ("state", "action", "reward", "next_state", "done", "last_hid", "hid"):
+        assert th.equal(getattr(w, k).reshape(getattr(b, k).shape), getattr(b, k)), k
     stat = {}
     trainer.value_replay_process(stat)
     trainer.policy_replay_process(stat)

@@ -1,5 +1,5 @@
-"""The two-launch rollout step (fused actor + exploration epilogue, flexnet_rollout_pack) against the PyTorch glue it
-replaces (learner.RolloutGraph.body's general path, which follows model.py:198-267 on the batched env)."""
+"""The rollout step (fused actor + exploration epilogue, env kernel, flexnet_rollout_pack into the slab replay ring)
+against the PyTorch glue it replaces (model.py:198-267 on the batched env, spelled out here with plain tensor ops)."""
 import os
 import sys
 
@@ -35,6 +35,11 @@ def _setup(n_envs):
     return out
 
 
+def _fields(rg):
+    t = rg.last_transition()
+    return {k: getattr(t, k) for k in ("state", "action", "reward", "next_state", "done", "last_step", "last_hid", "hid")}
+
+
 @pytest.mark.parametrize("n_envs", [64, 33])
 def test_fast_step_equals_general_step(n_envs):
     fast, slow = _setup(n_envs)
@@ -47,47 +52,53 @@ def test_fast_step_equals_general_step(n_envs):
     want_info = torch.zeros_like(slow.info_sum)
     want_rew = torch.zeros_like(slow.rew_sum)
     for step in range(4):
+        prev_obs, prev_hid = slow.obs.clone(), slow.hid.clone()
         for rg in (fast, slow):
             torch.manual_seed(100 + step)          # the same exploration draws
-            rg.body()
+            rg.step()
         torch.cuda.synchronize()
         # the pack kernel's statistics blocks (fixed-order fp64 block sums) against plain tensor sums of the env outputs
         want_info += slow.env.info.sum(0)
         want_rew += slow.env.reward.sum()
         assert torch.allclose(slow.info_sum, want_info, rtol=1e-12, atol=1e-12)
         assert torch.allclose(slow.rew_sum, want_rew, rtol=1e-12, atol=1e-12)
-        for name in ("rec", "obs", "hid"):
-            a, b = getattr(fast, name), getattr(slow, name)
+        ff, fs = _fields(fast), _fields(slow)
+        for name in ff:
+            a, b = ff[name], fs[name]
             # two fp32 summation orders through a recurrent net, four steps: relative 5e-4
             assert (a - b).abs().max().item() < 5e-4 * max(1.0, b.abs().max().item()), (step, name, (a - b).abs().max().item())
+        assert (fast.hid - slow.hid).abs().max().item() < 5e-4
         assert abs(fast.rew_sum.item() - slow.rew_sum.item()) < 1e-4 * max(1.0, abs(slow.rew_sum.item()))
         assert torch.allclose(fast.info_sum, slow.info_sum, rtol=1e-5, atol=1e-5)
         assert fast.fail_sum.item() == slow.fail_sum.item()
-    # the record really is the transition: columns against their sources
-    f = fast.f
-    assert torch.equal(f["next_state"], fast.env.obs)
-    assert torch.equal(f["done"], fast.env.done.float())
-    assert torch.allclose(f["reward"], fast.env.reward.float().unsqueeze(1).expand(-1, 5))
+        # the ring really holds the transition of model.py:230-242: every field against its source
+        assert torch.equal(fs["state"], prev_obs) and torch.equal(fs["last_hid"], prev_hid)
+        assert torch.equal(fs["next_state"], slow.env.obs) and torch.equal(fs["hid"], slow.hid)
+        assert torch.equal(fs["done"], slow.env.done.float()) and torch.equal(fs["last_step"], slow.env.done.float())
+        assert torch.equal(fs["reward"], slow.env.reward.float().unsqueeze(1).expand(-1, 5))
+    assert fast.buf.k == 4 and int(fast.buf.cursor[0]) == 4 and int(fast.buf.cursor[1]) == 0      # cursor moved, ticket reset
+    assert len(fast.buf.buffer) == 4 * n_envs
 
 
 def test_graph_capture_with_the_fused_step():
     fast, _ = _setup(128)
+    fast.start_episode(fast.env.reset())
     fast.capture()
     fast.start_episode(fast.env.reset())
     before = fast.obs.clone()
     for _ in range(3):
-        fast.graph.replay()
+        fast.step()
     torch.cuda.synchronize()
-    assert not torch.equal(before, fast.obs) and torch.isfinite(fast.rec).all()
-    assert torch.equal(fast.obs, fast.env.obs)
+    assert not torch.equal(before, fast.obs) and all(torch.isfinite(v).all() for v in _fields(fast).values())
+    assert fast.buf.k == int(fast.buf.cursor[0]) == 3
     # the exploration noise is drawn anew on every replay (graph-safe Philox offsets), not frozen at capture
     o0, h0 = fast.obs.clone(), fast.hid.clone()
     acts = []
     for _ in range(2):
         fast.obs.copy_(o0); fast.hid.copy_(h0)
-        fast.graph.replay()
+        fast.step()
         torch.cuda.synchronize()
-        acts.append(fast.f["action"].clone())
+        acts.append(_fields(fast)["action"].clone())
     assert (acts[0] - acts[1]).abs().mean().item() > 1e-3
     assert not fast.torch_noise and int(fast.rng_state[1].item()) >= 5        # the in-kernel stream: one step per replay
 
@@ -95,15 +106,16 @@ def test_graph_capture_with_the_fused_step():
 def test_graph_replays_with_torch_noise_too():
     fast, _ = _setup(64)
     fast.torch_noise = True
+    fast.start_episode(fast.env.reset())
     fast.capture()
     fast.start_episode(fast.env.reset())
     o0, h0 = fast.obs.clone(), fast.hid.clone()
     acts = []
     for _ in range(2):
         fast.obs.copy_(o0); fast.hid.copy_(h0)
-        fast.graph.replay()
+        fast.step()
         torch.cuda.synchronize()
-        acts.append(fast.f["action"].clone())
+        acts.append(_fields(fast)["action"].clone())
     assert (acts[0] - acts[1]).abs().mean().item() > 1e-3 and int(fast.rng_state[1].item()) == 0
 
 
@@ -146,7 +158,7 @@ def test_safemaddpg_fused_step_applies_the_safety_layer():
     hits = 0
     for step in range(3):
         torch.manual_seed(300 + step)
-        rg.body()
+        rg.step()
         torch.manual_seed(300 + step)
         with torch.no_grad():
             noise = torch.randn(N, 5, 4, device="cuda")
@@ -156,7 +168,7 @@ def test_safemaddpg_fused_step_applies_the_safety_layer():
             hits += int(m._last_intervened.sum())
             envs[1].step(m.env_action(adjusted), fuse_obs=True, auto_reset=True)
         torch.cuda.synchronize()
-        assert (rg.f["action"] - action).abs().max().item() < 2e-4            # the replay keeps the policy's own action
+        assert (_fields(rg)["action"] - action).abs().max().item() < 2e-4     # the replay keeps the policy's own action
         assert (envs[0].reward - envs[1].reward).abs().max().item() < 1e-4 * max(1.0, envs[1].reward.abs().max().item())
         assert (rg.obs - envs[1].obs).abs().max().item() < 5e-4
         obs = envs[1].obs.clone()
@@ -196,20 +208,22 @@ def test_general_graph_body_follows_get_actions(alg, N):
     avail = torch.ones(N, 5, 4, device="cuda")
     for step in range(3):
         torch.manual_seed(500 + step)
-        rg.body()
+        rg.step()
         torch.manual_seed(500 + step)
         with torch.no_grad():
             action, action_pol, _, _, new_hid = m.get_actions(obs, status="train", exploration=True, actions_avail=avail,
                                                               target=False, last_hid=hid)
             envs[1].step(m.env_action(action), fuse_obs=True, auto_reset=True)
         torch.cuda.synchronize()
-        assert torch.equal(rg.f["state"], obs)
-        assert torch.equal(rg.f["action"], action_pol.expand(N, 5, 4))
-        assert torch.equal(rg.f["hid"], new_hid) and torch.equal(rg.f["last_hid"], hid)
+        f = _fields(rg)
+        assert torch.equal(f["state"], obs)
+        assert torch.equal(f["action"], action_pol.expand(N, 5, 4))
+        assert torch.equal(f["last_hid"], hid)
         assert torch.equal(envs[0].reward, envs[1].reward)
-        assert torch.equal(rg.f["next_state"], envs[1].obs)
+        assert torch.equal(f["next_state"], envs[1].obs)
         obs = envs[1].obs.clone()
         hid = new_hid * (1.0 - envs[1].done.float()).view(N, 1, 1)
+        assert torch.equal(f["hid"], hid)                  # model.py:241's hid, zeroed where the episode ended (model.py:255-258)
         assert torch.equal(rg.obs, obs) and torch.equal(rg.hid, hid)
     os.environ["FLEX_GRAPH_AUDIT"] = "1"          # capture() first checks its body for ATen multi-block reductions
     try:
@@ -222,7 +236,7 @@ def test_general_graph_body_follows_get_actions(alg, N):
     want_info = torch.zeros_like(rg.info_sum)
     want_rew = torch.zeros_like(rg.rew_sum)
     for _ in range(6):
-        rg.graph.replay()
+        rg.step()
         # REPLAYED statistics (the headline batch size included) against eager sums of what the replay left in the env
         want_info += envs[0].info.sum(0)
         want_rew += envs[0].reward.sum()
@@ -230,15 +244,16 @@ def test_general_graph_body_follows_get_actions(alg, N):
         assert torch.allclose(rg.info_sum, want_info, rtol=1e-12, atol=1e-12), (rg.info_sum, want_info)
         assert torch.allclose(rg.rew_sum, want_rew, rtol=1e-12, atol=1e-12)
         assert rg.fail_sum.item() == 0.0
-    assert not torch.equal(before, rg.obs) and torch.isfinite(rg.rec).all()
+    assert not torch.equal(before, rg.obs) and all(torch.isfinite(v).all() for v in _fields(rg).values())
 
 
 def test_graph_replays_equal_eager_steps_bit_for_bit():
     """The captured rollout step against the same body run eagerly, from the same environment state, policy, hidden
-    state and noise-stream position: records, hand-over tensors and statistics identical over ten steps (in-launch
+    state and noise-stream position: ring contents, hand-over tensors and statistics identical over ten steps (in-launch
     auto-resets excluded by the short horizon; both use the actor kernel's own noise stream)."""
     import numpy as np
     graph, eager = _setup(96)
+    graph.start_episode(graph.env.reset())
     graph.capture()                                   # warm-up + capture advance env, hidden state and the noise step
     rng = np.random.default_rng(0)
     n, na = 96, 5
@@ -248,10 +263,69 @@ def test_graph_replays_equal_eager_steps_bit_for_bit():
     for rg in (graph, eager):
         rg.start_episode(rg.env.reset(spec=spec))
         rg.rng_state.copy_(torch.tensor([1234567, 42], dtype=torch.int64))
+    assert graph.graph is not None and eager.graph is None
     for step in range(10):
-        graph.graph.replay()
-        eager.body()
+        graph.step()
+        eager.step()
         torch.cuda.synchronize()
-        for name in ("rec", "obs", "hid", "info_sum", "rew_sum", "fail_sum", "rng_state"):
+        for name in ("obs", "hid", "info_sum", "rew_sum", "fail_sum", "rng_state"):
             assert torch.equal(getattr(graph, name), getattr(eager, name)), (step, name)
-    assert int(graph.rng_state[1]) == 52
+        fg, fe = _fields(graph), _fields(eager)
+        for name in fg:
+            assert torch.equal(fg[name], fe[name]), (step, name)
+        assert torch.equal(graph.buf.cursor, eager.buf.cursor)
+    assert int(graph.rng_state[1]) == 52 and int(graph.buf.cursor[0]) == graph.buf.k == 10
+
+
+def test_ring_wraps_and_windows_stay_consecutive():
+    """Slab ring bookkeeping on the device and its host mirror: 30 steps through a ring of 12 slabs, a hard restart in
+    the middle (gap), sampled windows are consecutive transitions of one stream (utils/replay_buffer.py:17-21) whose
+    next_state is the following slab's state, and the gathered static batch equals the window read eagerly."""
+    import numpy as np
+    from safe_marl_amd.replay_buffer import TransReplayBuffer
+    from safe_marl_amd.learner import RolloutGraph
+    (rg, _), N = _setup(16), 16
+    rg = RolloutGraph(rg.model, rg.env, TransReplayBuffer(N * 12, device="cuda"))
+    buf = rg.buf
+    assert buf.slabs == 12
+    rg.start_episode(rg.env.reset())
+    states = {}
+    for t in range(30):
+        if t == 17:
+            rg.start_episode(rg.env.reset())          # hard restart: slab 17 stays half-written -> gap
+        k = buf.k
+        states[k] = rg.obs.clone()
+        rg.step()
+    torch.cuda.synchronize()
+    assert buf.gaps == [] or all(g >= buf.first for g in buf.gaps)
+    assert buf.k == 31 and int(buf.cursor[0]) == 31 and buf.first == 31 + 2 - 12
+    assert len(buf.buffer) == N * (31 - buf.first - len(buf.gaps))
+    np.random.seed(0)
+    for _ in range(50):
+        bs = 3 * N + 5
+        slot = buf.sample_slot(bs)
+        j0, j1 = slot // N, (slot + bs - 1) // N
+        assert buf.first <= j0 and j1 < buf.k and not any(j0 <= g <= j1 for g in buf.gaps)
+        w = buf.slab_window(slot, bs)
+        # slot -> (slab counter, env): state is what the policy saw at that step, next_state the next slab's state
+        for r in (0, bs // 2, bs - 1):
+            j, e = (slot + r) // N, (slot + r) % N
+            assert torch.equal(w.state[r], states[j][e])
+            if j + 1 in states:
+                assert torch.equal(w.next_state[r], states[j + 1][e])
+    # one gather launch fills a static batch with exactly that window (seam of the ring included)
+    bs = 2 * N
+    plan_out = {k: torch.zeros((bs,) + buf.field_shape(k), device="cuda") for k in buf.STORED}
+    for slot in (buf.first * N + 3, (buf.k - 3) * N + 1, 23 * N + 9):          # 24 % 12 == 0: the third one crosses the seam
+        if any(slot // N <= g <= (slot + bs - 1) // N for g in buf.gaps):
+            continue
+        plan = []
+        for k, dst in plan_out.items():
+            ring, col0, width, off = buf.field_source(k)
+            plan.append((ring, col0, width, off * N, bs, dst.view(bs, -1)))
+        buf.gather(plan[:6], slot)
+        buf.gather(plan[6:], slot)
+        w = buf.slab_window(slot, bs)
+        torch.cuda.synchronize()
+        for k, dst in plan_out.items():
+            assert torch.equal(dst, getattr(w, k).reshape(dst.shape)), (slot, k)

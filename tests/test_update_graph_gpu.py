@@ -37,7 +37,8 @@ def test_graphed_sub_updates_equal_eager_ones(n_envs):
     a, b = _trainer(True, n_envs), _trainer(False, n_envs)
     for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
         assert torch.equal(va, vb), ka                           # same start
-    assert torch.equal(a.replay_buffer.store2d, b.replay_buffer.store2d)
+    for ring in ("obs_ring", "hid_ring", "small_ring"):
+        assert torch.equal(getattr(a.replay_buffer, ring), getattr(b.replay_buffer, ring)), ring
     for which in ("value", "value", "policy", "policy", "value", "policy"):
         stats = []
         for k, tr in enumerate((a, b)):
