@@ -166,6 +166,10 @@ int flexenv_peek(FlexEnv* env, int32_t field, void* dev_out, void* stream);
 int flexenv_poke(FlexEnv* env, int32_t field, const void* dev_in, void* stream);
 
 int32_t flexenv_num_envs(const FlexEnv* env);
+/* Optional launch counter: every later flexenv_step adds 1 to *counter (device int64, caller-owned, NULL switches it
+ * off) from one lane of the launch.  Lets a consumer that indexes by vector step — the replay ring cursor of
+ * flexnet_rollout_pack (include/flexnet.h) — follow the steps of a replayed HIP graph without a launch of its own. */
+int flexenv_set_step_counter(FlexEnv* env, int64_t* counter);
 int32_t flexenv_obs_size(const FlexEnv* env);    /* 6*history, env:71 */
 int32_t flexenv_state_size(const FlexEnv* env);  /* env:72 */
 

@@ -243,14 +243,16 @@ int flexnet_scaled_sum(const FlexSumArgs* args, void* stream);
  *     slab k + 1 <- obs_next (what the environment kernel just produced), hid_new * (1 - done)
  *     hid_state  <- hid_new * (1 - done)      (hand-over to the next policy evaluation)
  *     statistics += this step's info / reward / failure sums (fixed-order block sums)
- *     cursor[0]  <- k + 1                     (by the last block to finish: a self-resetting ticket, no memset)
- * k = cursor[0] is read on the device, so the launch can be replayed from a HIP graph. */
+ *     cursor[0]  <- k + 1                     (a one-thread launch of its own behind the copy kernel — or, with
+ *                                              cursor_stepped, by the environment's step kernel itself)
+ * k is read from cursor[0] on the device, so the launches can be replayed from a HIP graph. */
 typedef struct {
     int32_t n_envs, n_agents, obs_dim, act_dim;
     int32_t slabs;             /* ring capacity in slabs, >= 2 */
     int32_t small_w;           /* floats per small record: >= n_agents * act_dim + n_agents + 2 */
     int32_t info_w;            /* columns of `info` (7) */
-    int32_t pad0;
+    int32_t cursor_stepped;    /* 1: cursor[0] was already advanced for this step (by flexenv_step, flexenv_set_step_counter):
+                                  k = cursor[0] - 1 and nothing is written to it; 0: k = cursor[0], advanced by a launch here */
     const float* action;       /* [N, n, act_dim]  what the replay keeps (model.py:232) */
     const double* reward;      /* [N]   one reward per environment, stored once per agent */
     const float* obs_next;     /* [N, n, obs_dim] */
@@ -262,7 +264,7 @@ typedef struct {
     float* hid_ring;
     float* small_ring;
     float* hid_state;          /* out [N, n, 64]; may alias hid_new */
-    int64_t* cursor;           /* [2]: {slab counter k, ticket} */
+    int64_t* cursor;           /* [2]: {slab counter k, reserved} */
     double* info_sum;          /* [info_w] or NULL */
     double* rew_sum;           /* [1] */
     double* fail_sum;          /* [1] or NULL */

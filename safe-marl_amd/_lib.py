@@ -57,7 +57,7 @@ class ResetSpec(C.Structure):
 # every symbol include/flexenv.h declares
 SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
-    "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_obs_size", "flexenv_state_size",
+    "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss",
     "flexnet_scaled_sum", "flexnet_gather_rows",
@@ -139,7 +139,8 @@ FLEXNET_SUM_WS_FLOATS = 2 * 64
 
 class FlexRolloutPackArgs(C.Structure):
     """include/flexnet.h"""
-    _fields_ = [(k, C.c_int32) for k in ("n_envs", "n_agents", "obs_dim", "act_dim", "slabs", "small_w", "info_w", "pad0")] + \
+    _fields_ = [(k, C.c_int32) for k in ("n_envs", "n_agents", "obs_dim", "act_dim", "slabs", "small_w", "info_w",
+                                         "cursor_stepped")] + \
                [(k, C.c_void_p) for k in ("action", "reward", "obs_next", "done", "hid_new", "info", "failed", "obs_ring",
                                           "hid_ring", "small_ring", "hid_state", "cursor", "info_sum", "rew_sum", "fail_sum",
                                           "rng_state")]
@@ -195,6 +196,8 @@ def load():
     lib.flexnet_rollout_pack.restype = C.c_int
     lib.flexnet_gather_rows.argtypes = [C.POINTER(FlexGatherArgs), vp]
     lib.flexnet_gather_rows.restype = C.c_int
+    lib.flexenv_set_step_counter.argtypes = [vp, vp]
+    lib.flexenv_set_step_counter.restype = C.c_int
     lib.flexnet_wgrad.argtypes = [C.POINTER(FlexWgradArgs), vp]
     lib.flexnet_wgrad.restype = C.c_int
     lib.flexnet_clip_rmsprop.argtypes = [C.POINTER(FlexClipRmspropArgs), vp]

@@ -37,6 +37,7 @@ struct FlexEnv {
     DevNet* net;       // device
     DevNet hnet;       // host copy
     DevState st;
+    int64_t* step_counter;   // device cell flexenv_step bumps once per launch (flexenv_set_step_counter), or NULL
 };
 
 // Diagnostic build only (-DFLEX_STAMPS): per-phase s_memtime stamps, lane 0 of each wave, written to a
@@ -65,6 +66,7 @@ struct KArgs {
     int32_t row_bytes;         // cols * 8; the series table is addressed with 32-bit byte offsets (checked at create)
     float inv_h, inv_h3;       // 1/history, 1/(3*history) for the observation plan's small_mod
     double inv_eta_ch, inv_eta_dis;
+    int64_t* step_counter;     // += 1 per flex_step_kernel launch (one lane), or NULL
 };
 
 __device__ __forceinline__ double load_action(const void* p, int dtype, int64_t i) {
@@ -615,6 +617,12 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
         const KArgs& ar = *relaunder_kernarg<KArgs>();
         flex_reset_body<EPW, ObsT>(ar, env, restart, ln0, none, obs, want_obs, failed, true);
     }
+    // launch counter for consumers that index by vector step (flexnet_rollout_pack's ring cursor): one lane of the whole
+    // grid, pointer re-read from the kernarg segment so that it is not carried across the solve
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int64_t* const sc = relaunder_kernarg<KArgs>()->step_counter;
+        if (sc) *sc += 1;
+    }
 #ifdef FLEX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -947,6 +955,7 @@ static KArgs make_args(const FlexEnv* e) {
     k.row_bytes = e->series.cols * 8;
     k.inv_h = 1.0f / (float)e->cfg.history; k.inv_h3 = 1.0f / (float)(3 * e->cfg.history);
     k.inv_eta_ch = 1.0 / e->cfg.eta_ch; k.inv_eta_dis = 1.0 / e->cfg.eta_dis;
+    k.step_counter = nullptr;                      // only flexenv_step hands it on
     return k;
 }
 
@@ -1021,6 +1030,11 @@ void flexenv_destroy(FlexEnv* e) {
 }
 
 int32_t flexenv_num_envs(const FlexEnv* e) { return e ? e->n_envs : 0; }
+int flexenv_set_step_counter(FlexEnv* e, int64_t* counter) {
+    if (!e) return FLEX_EINVAL;
+    e->step_counter = counter;
+    return FLEX_OK;
+}
 int32_t flexenv_obs_size(const FlexEnv* e) { return e ? 6 * e->cfg.history : 0; }
 int32_t flexenv_state_size(const FlexEnv* e) { return e ? 3 * e->n_bus + 2 * e->cfg.n_agents + 1 : 0; }
 
@@ -1054,6 +1068,7 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     if (act_dtype != FLEX_F32 && act_dtype != FLEX_F64) return FLEX_EINVAL;
     if (obs && obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64) return FLEX_EINVAL;
     KArgs k = make_args(e);
+    k.step_counter = e->step_counter;
     hipStream_t s = (hipStream_t)stream;
     const int epw = e->hnet.epw;
     const dim3 grid = env_grid(e->n_envs, epw);

@@ -11,15 +11,16 @@
 #include "flexnet.h"
 
 #define PACK_THREADS 256
-#define PACK_ENVS 2                // environments per copy block
+#define PACK_ENVS 4                // environments per copy block: all their loads are in flight before the first store
 #define PACK_STATS 10               // statistics blocks at the head of the grid
 
 typedef float pack_f4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(PACK_THREADS) void rollout_pack_kernel(FlexRolloutPackArgs a) {
     const int tid = threadIdx.x;
-    // every block reads the cursor before it takes its ticket; the last ticket holder advances it (below)
-    const int64_t k = a.cursor[0];
+    // nobody in this launch writes the cursor: it is advanced by rollout_cursor_kernel AFTER it, or (cursor_stepped) it
+    // was advanced by the environment's step kernel BEFORE it
+    const int64_t k = a.cursor[0] - a.cursor_stepped;
     if (blockIdx.x < PACK_STATS) {
         // the first ten blocks own one statistic each (info columns, reward, failures): a block reduction over all
         // environments in a fixed order and one plain += — no atomics on the sums, bit-reproducible
@@ -47,50 +48,57 @@ __global__ __launch_bounds__(PACK_THREADS) void rollout_pack_kernel(FlexRolloutP
         const int no = a.n_agents * a.obs_dim, na = a.n_agents * a.act_dim, nh = a.n_agents * FLEXNET_HID;
         const int64_t cur = k % a.slabs, nxt = (k + 1) % a.slabs;
         const int e0 = (blockIdx.x - PACK_STATS) * PACK_ENVS;
+        const int no4 = no >> 2, nh4 = nh >> 2;
+        constexpr int MO = (FLEXNET_MAX_AGENTS * FLEXNET_MAX_OBS / 4 + PACK_THREADS - 1) / PACK_THREADS;      // 2
+        constexpr int MH = (FLEXNET_MAX_AGENTS * FLEXNET_HID / 4 + PACK_THREADS - 1) / PACK_THREADS;          // 1
+        pack_f4 ob[PACK_ENVS][MO], hb[PACK_ENVS][MH];
+        float keep[PACK_ENVS];
+        // loads first, then stores (hid_state may alias hid_new): 16-byte units, n * obs_dim and 64 are multiples of 4
+#pragma unroll
+        for (int j = 0; j < PACK_ENVS; ++j) {
+            const int e = e0 + j < a.n_envs ? e0 + j : a.n_envs - 1;          // clamped: loads stay in bounds, stores are skipped
+            keep[j] = a.done[e] ? 0.0f : 1.0f;
+            const pack_f4* on = reinterpret_cast<const pack_f4*>(a.obs_next + (int64_t)e * no);
+            const pack_f4* hn = reinterpret_cast<const pack_f4*>(a.hid_new + (int64_t)e * nh);
+#pragma unroll
+            for (int t = 0; t < MO; ++t) { const int i = tid + PACK_THREADS * t; if (i < no4) ob[j][t] = on[i]; }
+#pragma unroll
+            for (int t = 0; t < MH; ++t) { const int i = tid + PACK_THREADS * t; if (i < nh4) hb[j][t] = hn[i]; }
+        }
+#pragma unroll
         for (int j = 0; j < PACK_ENVS; ++j) {
             const int e = e0 + j;
             if (e >= a.n_envs) break;
-            const float keep = a.done[e] ? 0.0f : 1.0f;
-            // loads first, then stores (hid_state may alias hid_new): 16-byte units, no * obs_dim and 64 are multiples of 4
-            const pack_f4* on = reinterpret_cast<const pack_f4*>(a.obs_next + (int64_t)e * no);
-            const pack_f4* hn = reinterpret_cast<const pack_f4*>(a.hid_new + (int64_t)e * nh);
             pack_f4* o_ring = reinterpret_cast<pack_f4*>(a.obs_ring + (nxt * a.n_envs + e) * (int64_t)no);
             pack_f4* h_ring = reinterpret_cast<pack_f4*>(a.hid_ring + (nxt * a.n_envs + e) * (int64_t)nh);
             pack_f4* h_state = reinterpret_cast<pack_f4*>(a.hid_state + (int64_t)e * nh);
-            const int no4 = no >> 2, nh4 = nh >> 2;
-            constexpr int MO = (FLEXNET_MAX_AGENTS * FLEXNET_MAX_OBS / 4 + PACK_THREADS - 1) / PACK_THREADS;      // 2
-            constexpr int MH = (FLEXNET_MAX_AGENTS * FLEXNET_HID / 4 + PACK_THREADS - 1) / PACK_THREADS;          // 1
-            pack_f4 ob[MO], hb[MH];
-#pragma unroll
-            for (int t = 0; t < MO; ++t) { const int i = tid + PACK_THREADS * t; if (i < no4) ob[t] = on[i]; }
-#pragma unroll
-            for (int t = 0; t < MH; ++t) { const int i = tid + PACK_THREADS * t; if (i < nh4) hb[t] = hn[i] * keep; }
 #pragma unroll
             for (int t = 0; t < MO; ++t) {
                 const int i = tid + PACK_THREADS * t;
-                if (i < no4) __builtin_nontemporal_store(ob[t], &o_ring[i]);           // model.py:236,262: next_state = the next state
+                if (i < no4) __builtin_nontemporal_store(ob[j][t], &o_ring[i]);        // model.py:236,262: next_state = the next state
             }
 #pragma unroll
             for (int t = 0; t < MH; ++t) {
                 const int i = tid + PACK_THREADS * t;
-                if (i < nh4) { __builtin_nontemporal_store(hb[t], &h_ring[i]); h_state[i] = hb[t]; }      // fresh hidden state after a terminal step
+                if (i < nh4) {                                                          // fresh hidden state after a terminal step
+                    const pack_f4 h = hb[j][t] * keep[j];
+                    __builtin_nontemporal_store(h, &h_ring[i]);
+                    h_state[i] = h;
+                }
             }
             float* sm = a.small_ring + (cur * a.n_envs + e) * (int64_t)a.small_w;
             for (int i = tid; i < na; i += PACK_THREADS) sm[i] = a.action[(int64_t)e * na + i];     // model.py:232
             if (tid < a.n_agents) sm[na + tid] = (float)a.reward[e];                                // model.py:235: one reward, n copies
-            if (tid == 0) { sm[na + a.n_agents] = 1.0f - keep; sm[na + a.n_agents + 1] = 1.0f - keep; }
+            if (tid == 0) { sm[na + a.n_agents] = 1.0f - keep[j]; sm[na + a.n_agents + 1] = 1.0f - keep[j]; }
         }
     }
-    // self-resetting ticket: the block that takes the last one knows every block has read cursor[0]
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long* ticket = reinterpret_cast<unsigned long long*>(a.cursor + 1);
-        const unsigned long long t = atomicAdd(ticket, 1ULL);
-        if (t == (unsigned long long)gridDim.x - 1ULL) {
-            *ticket = 0ULL;
-            a.cursor[0] = k + 1;
-        }
-    }
+}
+
+// cursor[0] += 1 as a launch of its own: every block of rollout_pack_kernel reads the cursor, so the increment has to wait
+// for all of them.  (A last-block ticket inside the pack kernel was tried first: 2 058 device-scope atomics on one address
+// — executed memory-side, past the per-XCD L2s — took longer than the 39 MB of copies: 34.8 us per launch.)
+__global__ void rollout_cursor_kernel(int64_t* cursor) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) cursor[0] += 1;
 }
 
 extern "C" int flexnet_rollout_pack(const FlexRolloutPackArgs* a, void* stream) {
@@ -108,6 +116,7 @@ extern "C" int flexnet_rollout_pack(const FlexRolloutPackArgs* a, void* stream) 
     if (align & 15) return FLEXNET_EINVAL;
     const int blocks = (a->n_envs + PACK_ENVS - 1) / PACK_ENVS + PACK_STATS;
     hipLaunchKernelGGL(rollout_pack_kernel, dim3(blocks), dim3(PACK_THREADS), 0, (hipStream_t)stream, *a);
+    if (!a->cursor_stepped) hipLaunchKernelGGL(rollout_cursor_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->cursor);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 

@@ -196,6 +196,15 @@ class VecFlexProvisionEnv:
                                          _lib.FLEX_STEP_AUTORESET if auto_reset else 0, _stream()), "flexenv_step")
         return self.reward, self.done, self.info
 
+    def set_step_counter(self, counter):
+        """Every later step() adds 1 to ``counter[0]`` (int64 device tensor, or None to switch it off) from inside the
+        step kernel — how a replayed HIP graph keeps the replay ring's cursor moving without a launch of its own
+        (include/flexenv.h: flexenv_set_step_counter).  The tensor is kept alive for as long as the env points at it."""
+        if counter is not None and not (counter.is_cuda and counter.dtype == torch.int64 and counter.is_contiguous()):
+            raise ValueError("step counter must be a contiguous int64 device tensor")
+        _lib.check(self.lib.flexenv_set_step_counter(self.handle, _ptr(counter)), "flexenv_set_step_counter")
+        self._step_counter = counter
+
     def get_obs(self, obs_out=None):
         out = self.obs if obs_out is None else obs_out
         _lib.check(self.lib.flexenv_obs(self.handle, _ptr(out), self._dtype_tag(out), _stream()), "flexenv_obs")

@@ -70,6 +70,11 @@ class RolloutGraph:
         if self.safe:
             self.predictor = tuple(th.as_tensor(x, dtype=th.float64, device=dev).contiguous() for x in model.predictor)
         self.env_calls = None                                  # env.calls after this object's last step (continuity check)
+        # the ring cursor is advanced by the env's step kernel itself (one lane): no launch of its own per vector step
+        self.cursor_stepped = 0
+        if hasattr(env, "set_step_counter") and self.obs.is_cuda:
+            env.set_step_counter(buf.cursor)
+            self.cursor_stepped = 1
 
     def _pack(self, action, hid):
         """model.py:230-262 for every environment in one launch (include/flexnet.h: flexnet_rollout_pack)."""
@@ -78,7 +83,7 @@ class RolloutGraph:
         m, env, buf = self.model, self.env, self.buf
         a = _lib.FlexRolloutPackArgs()
         a.n_envs, a.n_agents, a.obs_dim, a.act_dim = env.n_envs, m.n_, m.obs_dim, m.act_dim
-        a.slabs, a.small_w, a.info_w = buf.slabs, buf.small_w, env.info.shape[1]
+        a.slabs, a.small_w, a.info_w, a.cursor_stepped = buf.slabs, buf.small_w, env.info.shape[1], self.cursor_stepped
         for name, t in (("action", action), ("reward", env.reward), ("obs_next", env.obs), ("done", env.done),
                         ("hid_new", hid), ("info", env.info), ("failed", env.failed), ("obs_ring", buf.obs_ring),
                         ("hid_ring", buf.hid_ring), ("small_ring", buf.small_ring), ("hid_state", self.hid),
@@ -277,10 +282,13 @@ class Model(nn.Module):
                 and len(trainer.replay_buffer.buffer) >= trainer.effective_batch_size() \
                 and trainer.steps % self.args.behaviour_update_freq == 0
             if replay_cond:
-                for _ in range(self.args.value_update_epochs):
-                    trainer.value_replay_process(stat)
-                for _ in range(self.args.policy_update_epochs):
-                    trainer.policy_replay_process(stat)
+                if hasattr(trainer, "replay_event"):      # same sub-updates in the same order, software-pipelined
+                    trainer.replay_event(stat, self.args.value_update_epochs, self.args.policy_update_epochs)
+                else:
+                    for _ in range(self.args.value_update_epochs):
+                        trainer.value_replay_process(stat)
+                    for _ in range(self.args.policy_update_epochs):
+                        trainer.policy_replay_process(stat)
         else:
             raise NotImplementedError("the MADDPG path always replays (default.yaml:22)")
         if self.args.target and trainer.steps % self.args.target_update_freq == 0:
@@ -574,7 +582,7 @@ class MADDPG(Model):
         carries agent i's own-action gradient.  Returns [b, n, 1]."""
         b, n, o, a = obs.size(0), self.n_, self.obs_dim, self.act_dim
         act_det = act.detach()
-        own = act - act_det                                               # zeros that carry d/d act_i
+        own = act - act_det if act.requires_grad else None                # zeros that carry d/d act_i
         values = []
         nets = self.value_dicts if not self.args.shared_params else [self.value_dicts[0]] * 1
         if self.args.shared_params:
@@ -592,7 +600,12 @@ class MADDPG(Model):
                     and critic_replayed_supported(net, obs_cols, act_cols, n)):
                 # value loss on replayed actions: the whole critic as one autograd node (nets._CriticReplayedFn)
                 return CriticTail.apply_replayed(obs_cols, act_cols, n, net).view(b, n, 1)
-            shared = wide_batch_linear(obs.reshape(b, n * o), W_obs) + wide_batch_linear(act_cols, W_act) + bias   # [b, hid]
+            if not th.is_grad_enabled() or not (W.requires_grad or act.requires_grad or obs.requires_grad):
+                # bootstrap targets: no graph — two GEMMs, the bias rides the first, the second accumulates
+                shared = th.addmm(bias, obs_cols, W_obs.t())
+                shared.addmm_(act_cols, W_act.t())
+            else:
+                shared = wide_batch_linear(obs_cols, W_obs) + wide_batch_linear(act_cols, W_act) + bias      # [b, hid]
             if not act.requires_grad and self.args.agent_id and critic_tail_supported(net, shared):
                 # replayed actions (value loss, bootstrap target): every row is shared[b] + the agent's id column; the
                 # fused tail composes it on the fly instead of reading a materialised [b * n, hid] tensor

@@ -42,6 +42,9 @@ class PGTrainer(object):
         self.graph_rollout = graph_rollout      # vectorised envs: replay each rollout step as one HIP graph
         self.graph_updates = graph_updates      # ... and each sub-update (packed replay on the GPU, one rank)
         self._update_graphs = {}
+        self._update_graphs_alt = {}            # second static batch per kind for the pipelined update event
+        self._side_stream = None
+        self.pipeline_updates = True            # replay_event: gather window j + 1 while sub-update j runs
         self.entr = args.entr
         self.world = fdist.world_size()
 
@@ -85,22 +88,21 @@ class PGTrainer(object):
             self._sub_update("value", stat, self.replay_buffer.get_batch_tensors(self.effective_batch_size()))
 
     # ---- a sub-update as one HIP graph -----------------------------------------------------------------------
-    def _graphed_sub_update(self, which, stat):
-        """A sub-update is ~120 kernel launches that take the host longer to issue (1.6 ms) than the GPU to run; with
-        the replay in slab mode the sampled window is gathered into a static batch (ONE launch, include/flexnet.h:
-        flexnet_gather_rows) and the whole step — losses, backward, gradient clip, RMSprop — is replayed as one HIP graph.
-        Returns False when this configuration does not qualify (the caller then runs the eager step)."""
+    def _ensure_graph(self, which, slot=0):
+        """The captured sub-update of kind ``which`` on static batch ``slot`` (0, or 1 for the double-buffered pipeline of
+        replay_event), capturing it on first use; None when this configuration does not qualify for graphed updates."""
         buf = self.replay_buffer
         if not (self.graph_updates and self.device.type == "cuda" and getattr(buf, "slab_mode", False)):
-            return False
+            return None
         if not getattr(self.behaviour_net, "graph_safe_updates", False):
             # Only models whose gradient path is free of PyTorch's multi-block reductions are replayed as graphs: with
             # this PyTorch-ROCm build such a reduction (global semaphore + memset) captured into a HIP graph can come back
             # stale or partial on replay (DESIGN.md §6).  MADDPG / SAFEMADDPG reduce with this project's fixed-order
             # kernels and are checked against eager updates at full size; MATD3 / IDDPG keep eager sub-updates.
-            return False
+            return None
         bs = self.effective_batch_size()
-        g = self._update_graphs.get(which)
+        store = self._update_graphs if slot == 0 else self._update_graphs_alt
+        g = store.get(which)
         if g is None or g["bs"] != bs or g["buf"] is not buf:
             try:
                 g = self._capture_sub_update(which, bs)
@@ -108,9 +110,11 @@ class PGTrainer(object):
                 import warnings
                 warnings.warn(f"sub-update graph capture failed ({exc}); using eager sub-updates")
                 self.graph_updates = False
-                return False
-            self._update_graphs[which] = g
-        buf.gather(g["plan"], buf.sample_slot(bs))       # only the ring columns this sub-update reads
+                return None
+            store[which] = g
+        return g
+
+    def _replay(self, g, stat):
         g["graph"].replay()
         if g["apply"] is not None:
             # more than one rank: the captured region is split at the exchange step — graph A (losses, backward, gradients
@@ -119,7 +123,68 @@ class PGTrainer(object):
             fdist.allreduce_flat(g["flat"])
             g["apply"].replay()
         stat.update(g["stat"])
+
+    def _graphed_sub_update(self, which, stat):
+        """A sub-update is ~120 kernel launches that take the host longer to issue (1.6 ms) than the GPU to run; with
+        the replay in slab mode the sampled window is gathered into a static batch (ONE launch, include/flexnet.h:
+        flexnet_gather_rows) and the whole step — losses, backward, gradient clip, RMSprop — is replayed as one HIP graph.
+        Returns False when this configuration does not qualify (the caller then runs the eager step)."""
+        g = self._ensure_graph(which)
+        if g is None:
+            return False
+        buf = self.replay_buffer
+        buf.gather(g["plan"], buf.sample_slot(g["bs"]))       # only the ring columns this sub-update reads
+        self._replay(g, stat)
         return True
+
+    def replay_event(self, stat, n_value, n_policy):
+        """One update event of model.py:47-50 — ``n_value`` value sub-updates, then ``n_policy`` policy sub-updates.
+        With graphed updates the event is software-pipelined: the window of sub-update j + 1 is sampled and gathered into
+        the OTHER static batch of its kind on a side stream while the graph of sub-update j runs, so the HBM-bound gather
+        (50 us of a 570 us value step at 4096 envs) hides in the bubbles of the replay instead of preceding it.  Windows
+        are drawn in the same order from the same NumPy stream as by the one-at-a-time calls, the gathered data and the
+        replayed graphs are the same: the result is bit-identical (tests/test_update_graph_gpu.py)."""
+        kinds = ["value"] * int(n_value) + ["policy"] * int(n_policy)
+        if not self.pipeline_updates or len(kinds) < 2 or self._ensure_graph(kinds[0]) is None:
+            for which in kinds:
+                (self.value_replay_process if which == "value" else self.policy_replay_process)(stat)
+            return
+        buf = self.replay_buffer
+        seen, graphs = {}, []
+        for which in kinds:                             # every (kind, slot) graph exists before the pipeline starts
+            slot = seen.get(which, 0) % 2
+            seen[which] = seen.get(which, 0) + 1
+            g = self._ensure_graph(which, slot)
+            if g is None:                               # capture failed half-way: plain calls for the whole event
+                for w in kinds:
+                    (self.value_replay_process if w == "value" else self.policy_replay_process)(stat)
+                return
+            graphs.append(g)
+        main = th.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = th.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(main)                          # the ring writes of the rollout so far
+
+        def launch_gather(j):
+            g = graphs[j]
+            slot_start = buf.sample_slot(g["bs"])       # drawn in sub-update order, like the one-at-a-time calls
+            with th.cuda.stream(side):
+                if g.get("free") is not None:
+                    side.wait_event(g["free"])          # the last replay that read this static batch has finished
+                buf.gather(g["plan"], slot_start)
+                ev = th.cuda.Event()
+                ev.record(side)
+            return ev
+
+        ready = launch_gather(0)
+        for j, g in enumerate(graphs):
+            nxt = launch_gather(j + 1) if j + 1 < len(graphs) else None
+            main.wait_event(ready)
+            self._replay(g, stat)
+            g["free"] = th.cuda.Event()
+            g["free"].record(main)
+            ready = nxt
 
     def _static_batch(self, which, bs):
         """Static tensors a captured sub-update reads, and the gather plan that refreshes them.  Every observation sits

@@ -122,3 +122,24 @@ def test_fused_paths_do_not_fall_back_at_the_default_configuration():
         assert fused_actor_forward(agent, wide, torch.zeros(20, 64, device="cuda"), 5, True) is None
     assert util.FALLBACKS.get("actor_forward") == 2 and sum("actor_forward" in str(x.message) for x in w) == 1
     util.FALLBACKS.clear()
+
+
+def test_pipelined_update_event_equals_one_at_a_time_sub_updates():
+    """trainer.replay_event (model.py:47-50: ten value sub-updates, then a policy one) with the next window gathered on a
+    side stream into the second static batch while the current graph runs, against the same event done one call at a
+    time: same windows (same NumPy stream), same graphs — weights, optimiser-visible buffers and statistics bit-identical
+    over three events at the headline batch."""
+    a, b = _trainer(True, 4096), _trainer(True, 4096)
+    b.pipeline_updates = False
+    for ev in range(3):
+        stats = []
+        for tr in (a, b):
+            np.random.seed(40 + ev)
+            st = {}
+            tr.replay_event(st, 10, 1)
+            torch.cuda.synchronize()
+            stats.append({k: float(v) for k, v in st.items()})
+        assert stats[0] == stats[1], (ev, stats)
+        for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
+            assert torch.equal(va, vb), (ev, ka)
+    assert set(a._update_graphs_alt) == {"value"} and not b._update_graphs_alt      # the double buffer really was used
