@@ -186,7 +186,8 @@ def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, m
            "batch_per_gpu": trainer.effective_batch_size(),
            "rollout_graph": bool(rg is not None and rg.graph is not None), "rollout_fused": bool(rg is not None and rg.fast),
            "graphed_updates": sorted(trainer._update_graphs), "split_update_graphs": bool(world > 1 and trainer._update_graphs),
-           "grad_allreduce": "rccl flat bucket (sum, 1/world inside graph B), before the clip" if world > 1 else None,
+           "grad_allreduce": (f"{torch.distributed.get_backend()} all-reduce of one flat bucket (sum, 1/world inside graph B), "
+                              "before the clip") if world > 1 else None,
            "mean_train_reward": float(stat.get("mean_train_reward", float("nan"))),
            "mean_train_value_loss": float(stat.get("mean_train_value_loss", float("nan")))}
     del trainer, env
@@ -313,8 +314,8 @@ def main():
         env.step(pool[k % ACTION_POOL], fuse_obs=True, auto_reset=True)
 
     # The loop is launch-issue sensitive (9 us of Python + ctypes per launch against a 14 us kernel), so consecutive steps
-    # are captured as HIP graphs and replayed: blocks of ACTION_POOL steps plus ONE graph for the remainder (K mod 16), so
-    # that short runs (the driver's --steps 20) are replays too.  Work per step is identical either way (one flexenv_step
+    # are captured as HIP graphs and replayed: blocks of ACTION_POOL steps plus ONE graph for the remainder (K mod 16); a
+    # short run (the driver's --steps 20) is one graph of exactly K step launches.  Work per step is identical either way (one flexenv_step
     # launch per step); `--no-graph` keeps everything eager.
     graphs = {}
 
@@ -332,7 +333,10 @@ def main():
             with torch.cuda.stream(side):
                 one_step(0)
             torch.cuda.current_stream().wait_stream(side)
-            for n_steps in sorted({ACTION_POOL, a.steps % ACTION_POOL, a.warmup % ACTION_POOL} - {0}):
+            sizes = {ACTION_POOL, a.steps % ACTION_POOL, a.warmup % ACTION_POOL}
+            if a.steps <= 128:
+                sizes.add(a.steps)                    # a short timed region (the driver's --steps 20) is ONE graph launch
+            for n_steps in sorted(sizes - {0}):
                 graphs[n_steps] = capture(n_steps)
         except Exception as exc:                      # capture not available: eager launches
             print(f"[bench] HIP graph capture failed ({exc}); eager launches", file=sys.stderr)
@@ -340,6 +344,9 @@ def main():
 
     def run_steps(count):
         done_steps = 0
+        if count in graphs and count != ACTION_POOL:
+            graphs[count].replay()
+            return
         if ACTION_POOL in graphs:
             while count - done_steps >= ACTION_POOL:
                 graphs[ACTION_POOL].replay()
@@ -350,8 +357,6 @@ def main():
             done_steps += rest
         for k in range(done_steps, count):
             one_step(k)
-
-    run_steps(a.warmup)
 
     def barrier():
         if distributed:
@@ -364,6 +369,23 @@ def main():
         t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    # training legs first (every rank takes part: with N > 1 the gradient bucket goes through RCCL); the env-only legs
+    # below then run on a GPU that is already at its working clocks
+    train = None
+    if not a.no_train:
+        legs = [("maddpg", 5, N_ENVS)] if distributed else [("maddpg", 5, N_ENVS), ("maddpg", 3, N_ENVS), ("safemaddpg", 5, 2 * N_ENVS)]
+        train = []
+        for alg, n_ag, n_env in legs:
+            try:
+                train.append(train_leg(alg, n_ag, n_env, max(2, a.train_episodes), rank, local_rank, world, barrier,
+                                       max_over_ranks))
+            except Exception as exc:                  # a failed leg must not cost the headline line
+                if distributed:
+                    raise
+                train.append({"alg": alg, "n_agents": n_ag, "envs_per_gpu": n_env, "error": repr(exc)[:300]})
+
+    run_steps(a.warmup)
 
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -411,22 +433,6 @@ def main():
     iters_mean = float(env.peek("PF_ITERS").float().mean().item())
     sweeps_mean = float(env.peek("PF_SWEEPS").float().mean().item())
     n_agents_env, n_bus_env, used_graph = env.n_agents, env.n_bus, bool(graphs)
-
-    # training legs (every rank takes part: with N > 1 the gradient bucket goes through RCCL)
-    train = None
-    if not a.no_train:
-        del env, pool, graphs
-        torch.cuda.empty_cache()
-        legs = [("maddpg", 5, N_ENVS)] if distributed else [("maddpg", 5, N_ENVS), ("maddpg", 3, N_ENVS), ("safemaddpg", 5, 2 * N_ENVS)]
-        train = []
-        for alg, n_ag, n_env in legs:
-            try:
-                train.append(train_leg(alg, n_ag, n_env, max(2, a.train_episodes), rank, local_rank, world, barrier,
-                                       max_over_ranks))
-            except Exception as exc:                  # a failed leg must not cost the headline line
-                if distributed:
-                    raise
-                train.append({"alg": alg, "n_agents": n_ag, "envs_per_gpu": n_env, "error": repr(exc)[:300]})
 
     if rank == 0:
         total_env_steps = a.envs * world * a.steps

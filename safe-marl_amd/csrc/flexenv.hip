@@ -22,8 +22,8 @@ enum { IF_STEPS = 0, IF_START, IF_ROW, IF_OBSCNT, IF_EPISODE, IF_ITERS, IF_SWEEP
 
 struct DevState {
     double* vm;        // [N, n_bus]   |V| in BUS order           (current_voltage, env:146,310)
-    double* ve;        // [N, 64]      Re V in group-LANE order    (warm start)
-    double* vf;        // [N, 64]      Im V in LANE order
+    float2* vw;        // [N, 64]      (Re V, Im V) in group-LANE order, fp32: the warm start of the next solve — an initial
+                       //              guess only (the solve ends on an fp64 mismatch test), so 8 bytes per bus instead of 16
     double* agent;     // [N, AF_COUNT, FLEX_MAX_AGENTS]
     double* cumrew;    // [N]
     int32_t* ienv;     // [N, IF_COUNT]
@@ -384,8 +384,7 @@ __device__ __forceinline__ void flex_reset_body(const KArgs& a, int env, bool va
     const double v = sqrt(e * e + f * f);
     if (ln.pq) {
         a.st.vm[(int64_t)env * nb + ln.bus] = v;
-        a.st.ve[(int64_t)env * 64 + ln.l] = ok ? e : 1.0;
-        a.st.vf[(int64_t)env * 64 + ln.l] = ok ? f : 0.0;
+        a.st.vw[(int64_t)env * 64 + ln.l] = ok ? make_float2((float)e, (float)f) : make_float2(1.0f, 0.0f);
     }
     if (is_bld && valid) {
         agst[AF_E * FLEX_MAX_AGENTS + ag] = e_new;          // env:147
@@ -462,8 +461,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
 
     // wavefront-uniform bases and per-lane byte offsets
     double* const b_agent = a.st.agent + (int64_t)env0 * (AF_COUNT * FLEX_MAX_AGENTS);
-    double* const b_ve = a.st.ve + (int64_t)env0 * 64;
-    double* const b_vf = a.st.vf + (int64_t)env0 * 64;
+    float2* const b_vw = a.st.vw + (int64_t)env0 * 64;
     double* const b_vm = a.st.vm + (int64_t)env0 * nb;
     const ActT* const b_act = actions + (int64_t)env0 * (na * 4);
     const uint32_t o_agent = (g * (AF_COUNT * FLEX_MAX_AGENTS) + ag) * 8;          // + field * FLEX_MAX_AGENTS * 8
@@ -492,7 +490,8 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
         const double2 t0 = ld_at<double2>(b_act, o_act), t1 = ld_at<double2>(b_act, o_act + 16);
         av[0] = t0.x; av[1] = t0.y; av[2] = t1.x; av[3] = t1.y;
     }
-    const double we = ld_at<double>(b_ve, o_volt), wf = ld_at<double>(b_vf, o_volt);
+    const float2 wv = ld_at<float2>(b_vw, o_volt);
+    const double we = (double)wv.x, wf = (double)wv.y;
     // 2) what only get_obs() needs: the row env:340 will load (start + steps, A2) and the history part of the
     //    stacked observation, which is copied right away and drains underneath the solve; an environment that
     //    turns out to restart below rewrites its whole observation afterwards (same wavefront, program order)
@@ -536,8 +535,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     const KArgs& z = *relaunder_kernarg<KArgs>();
     const FlexCfg& cz = z.cfg;
     double* const e_agent = z.st.agent + (int64_t)env0 * (AF_COUNT * FLEX_MAX_AGENTS);
-    double* const e_ve = z.st.ve + (int64_t)env0 * 64;
-    double* const e_vf = z.st.vf + (int64_t)env0 * 64;
+    float2* const e_vw = z.st.vw + (int64_t)env0 * 64;
     double* const e_vm = z.st.vm + (int64_t)env0 * z.n_bus;
     int32_t* const e_ienv = z.st.ienv + (int64_t)env0 * IF_COUNT;
     const uint32_t o_vm = (g * z.n_bus + busi) * 8;
@@ -548,8 +546,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
         e_new = e_init + cz.dt * (cz.eta_ch * ch - z.inv_eta_dis * dis);                 // pf.py:96-98
         if (ln.pq) {
             st_at<double>(e_vm, o_vm, v);
-            st_at<double>(e_ve, o_volt, e);
-            st_at<double>(e_vf, o_volt, f);
+            st_at2(e_vw, o_volt, make_float2((float)e, (float)f));
         }
         if (is_bld && valid) {
             st_at<double>(e_agent, o_agent + AF_PRED * AFB, pred);
@@ -992,22 +989,20 @@ int flexenv_create(const FlexCfg* cfg, const NetFix* net, const SeriesTab* serie
     if (rc != FLEX_OK) { delete e; return rc; }
     // allocate everything or nothing
     const int64_t N = n_envs;
-    const size_t sz_vm = N * net->n_bus * sizeof(double), sz_v = N * 64 * sizeof(double);
+    const size_t sz_vm = N * net->n_bus * sizeof(double), sz_v = N * 64 * sizeof(float2);
     const size_t sz_ag = N * AF_COUNT * FLEX_MAX_AGENTS * sizeof(double), sz_cr = N * sizeof(double);
     const size_t sz_ie = N * IF_COUNT * sizeof(int32_t), sz_ring = N * cfg->n_agents * cfg->history * 6 * sizeof(float);
     hipError_t err = hipSetDevice(device);
     if (err == hipSuccess) err = hipMalloc(&e->net, sizeof(DevNet));
     if (err == hipSuccess) err = hipMemcpy(e->net, &e->hnet, sizeof(DevNet), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMalloc(&e->st.vm, sz_vm);
-    if (err == hipSuccess) err = hipMalloc(&e->st.ve, sz_v);
-    if (err == hipSuccess) err = hipMalloc(&e->st.vf, sz_v);
+    if (err == hipSuccess) err = hipMalloc(&e->st.vw, sz_v);
     if (err == hipSuccess) err = hipMalloc(&e->st.agent, sz_ag);
     if (err == hipSuccess) err = hipMalloc(&e->st.cumrew, sz_cr);
     if (err == hipSuccess) err = hipMalloc(&e->st.ienv, sz_ie);
     if (err == hipSuccess) err = hipMalloc(&e->st.ring, sz_ring);
     if (err == hipSuccess) err = hipMemset(e->st.vm, 0, sz_vm);
-    if (err == hipSuccess) err = hipMemset(e->st.ve, 0, sz_v);
-    if (err == hipSuccess) err = hipMemset(e->st.vf, 0, sz_v);
+    if (err == hipSuccess) err = hipMemset(e->st.vw, 0, sz_v);
     if (err == hipSuccess) err = hipMemset(e->st.agent, 0, sz_ag);
     if (err == hipSuccess) err = hipMemset(e->st.cumrew, 0, sz_cr);
     if (err == hipSuccess) err = hipMemset(e->st.ienv, 0, sz_ie);
@@ -1024,7 +1019,7 @@ int flexenv_create(const FlexCfg* cfg, const NetFix* net, const SeriesTab* serie
 void flexenv_destroy(FlexEnv* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    void* ptrs[] = {e->net, e->st.vm, e->st.ve, e->st.vf, e->st.agent, e->st.cumrew, e->st.ienv, e->st.ring};
+    void* ptrs[] = {e->net, e->st.vm, e->st.vw, e->st.agent, e->st.cumrew, e->st.ienv, e->st.ring};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
 }

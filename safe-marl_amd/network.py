@@ -100,15 +100,87 @@ def create_network(env_args: Optional[dict] = None, nodes=None, lines=None) -> d
     }
 
 
-def load_network_xlsx(data_path: str, env_args: Optional[dict] = None) -> dict:
-    """``create_network()`` from the reference's own files (create_net.py:11-12)
-    when the user has the LFS data and openpyxl; same columns, same scaling."""
-    import pandas as pd  # needs openpyxl for .xlsx
+def read_xlsx_table(path: str):
+    """First worksheet of an .xlsx workbook as (header, rows) — what ``pd.read_excel(path)`` hands the reference
+    (utils/create_net.py:11-12), without openpyxl: an .xlsx file is a zip of XML parts (ECMA-376), and the two tables
+    this path reads are plain header + numeric rows.  Shared strings, inline strings and numeric cells are understood;
+    empty trailing rows are dropped; a cell missing from a row is None."""
+    import re
+    import zipfile
+    import xml.etree.ElementTree as ET
 
-    nd = pd.read_excel(f"{data_path}/Nodes_33.xlsx")
-    ld = pd.read_excel(f"{data_path}/Lines_33.xlsx")
-    nodes = [(nd.loc[i, "NODES"], nd.loc[i, "Tb"], nd.loc[i, "PDn"], nd.loc[i, "QDn"]) for i in nd.index]
-    lines = [(ld.loc[i, "FROM"], ld.loc[i, "TO"], ld.loc[i, "R"], ld.loc[i, "X"], ld.loc[i, "Imax"]) for i in ld.index]
+    ns = {"m": "http://schemas.openxmlformats.org/spreadsheetml/2006/main",
+          "r": "http://schemas.openxmlformats.org/officeDocument/2006/relationships",
+          "p": "http://schemas.openxmlformats.org/package/2006/relationships"}
+    with zipfile.ZipFile(path) as z:
+        names = set(z.namelist())
+        shared = []
+        if "xl/sharedStrings.xml" in names:
+            for si in ET.fromstring(z.read("xl/sharedStrings.xml")).findall("m:si", ns):
+                shared.append("".join(t.text or "" for t in si.iter("{%s}t" % ns["m"])))
+        # first sheet of the workbook, through its relationship (falls back to the conventional part name)
+        sheet = "xl/worksheets/sheet1.xml"
+        try:
+            wb = ET.fromstring(z.read("xl/workbook.xml"))
+            first = wb.find("m:sheets", ns).find("m:sheet", ns)
+            rid = first.get("{%s}id" % ns["r"])
+            rels = ET.fromstring(z.read("xl/_rels/workbook.xml.rels"))
+            for rel in rels.findall("p:Relationship", ns):
+                if rel.get("Id") == rid:
+                    target = rel.get("Target").lstrip("/")
+                    sheet = target if target.startswith("xl/") else "xl/" + target
+        except (KeyError, AttributeError):
+            pass
+        root = ET.fromstring(z.read(sheet))
+
+    def col_index(ref):
+        letters = re.match(r"[A-Z]+", ref).group(0)
+        k = 0
+        for ch in letters:
+            k = k * 26 + (ord(ch) - 64)
+        return k - 1
+
+    table = []
+    for row in root.find("m:sheetData", ns).findall("m:row", ns):
+        cells = {}
+        for pos, c in enumerate(row.findall("m:c", ns)):
+            j = col_index(c.get("r")) if c.get("r") else pos
+            t = c.get("t")
+            v = c.find("m:v", ns)
+            if t == "s":
+                val = shared[int(v.text)]
+            elif t == "inlineStr":
+                val = "".join(x.text or "" for x in c.iter("{%s}t" % ns["m"]))
+            elif t == "str":
+                val = v.text if v is not None else ""
+            elif v is None or v.text is None:
+                val = None
+            else:
+                val = float(v.text)
+            cells[j] = val
+        if cells and any(x is not None for x in cells.values()):
+            table.append([cells.get(j) for j in range(max(cells) + 1)])
+    if not table:
+        raise ValueError(f"{path}: empty worksheet")
+    header = [str(h).strip() if h is not None else "" for h in table[0]]
+    rows = [r + [None] * (len(header) - len(r)) for r in table[1:]]
+    return header, rows
+
+
+def load_network_xlsx(data_path: str, env_args: Optional[dict] = None) -> dict:
+    """``create_network()`` from the reference's own files (utils/create_net.py:11-24): ``Nodes_33.xlsx`` with columns
+    NODES, Tb, PDn, QDn and ``Lines_33.xlsx`` with FROM, TO, R, X, Imax — same columns, same per-unit scaling.  The
+    workbooks are read with ``read_xlsx_table`` (no openpyxl needed)."""
+    def table(name, cols):
+        header, rows = read_xlsx_table(f"{data_path}/{name}")
+        missing = [c for c in cols if c not in header]
+        if missing:
+            raise KeyError(f"{name}: missing column(s) {missing} (have {header})")
+        idx = [header.index(c) for c in cols]
+        return [tuple(r[i] for i in idx) for r in rows if r[idx[0]] is not None]
+
+    nodes = table("Nodes_33.xlsx", ("NODES", "Tb", "PDn", "QDn"))
+    lines = table("Lines_33.xlsx", ("FROM", "TO", "R", "X", "Imax"))
     return create_network(env_args, nodes, lines)
 
 
