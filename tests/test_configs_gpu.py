@@ -6,8 +6,9 @@
             CPU oracle to 1e-12, the whole batch through size-independent properties (feasibility of the slab,
             idempotence, non-negativity, untouched actions where the layer reports no intervention);
   f2        CSV files in the reference's on-disk format (env:431-471: time column + 32 load / 5 PV / 1 price columns, 3-min
-            raw data resampled to 15 min) ingested by ``series.load_csv_dir`` and driven through the HIP env against the
-            scalar oracle on the same table."""
+            raw data resampled to 15 min) ingested by ``series.load_csv_dir``, on the network ingested from
+            Nodes_33.xlsx / Lines_33.xlsx (create_net.py:11-24) by ``network.load_network_xlsx``, driven through the HIP env
+            against the scalar oracle on the same tables."""
 import numpy as np
 import pytest
 
@@ -121,12 +122,17 @@ def test_safety_projection_at_8192_envs(net, series_small):
     assert regimes[0] == 0.0 and 0.0 < regimes[1] <= 1.0 and regimes[3] == 1.0, regimes
 
 
-def test_csv_ingested_series_through_the_hip_env(tmp_path, net):
+def test_csv_ingested_series_through_the_hip_env(tmp_path, write_xlsx):
     pd = pytest.importorskip("pandas")
     import torch
     from oracle.env_oracle import FlexEnvOracle
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.network import ieee33_tables, load_network_xlsx
     from safe_marl_amd.series import load_csv_dir
+    nodes, lines = ieee33_tables()
+    write_xlsx(tmp_path / "Nodes_33.xlsx", ["NODES", "Tb", "PDn", "QDn"], [tuple(float(x) for x in n[:4]) for n in nodes])
+    write_xlsx(tmp_path / "Lines_33.xlsx", ["FROM", "TO", "R", "X", "Imax"], [tuple(float(x) for x in l[:5]) for l in lines])
+    net = load_network_xlsx(str(tmp_path))             # the network itself comes from the reference's workbook format
     rng = np.random.default_rng(3)
     days = 6
     idx = pd.date_range("2021-03-01", periods=days * 24 * 20, freq="3min")         # 3-min raw data, like the reference's

@@ -56,55 +56,17 @@ def test_synthetic_series_layout(net):
     assert st.price.min() >= 0.05 and st.price.max() <= 0.30
 
 
-def _write_xlsx(path, header, rows, shared_strings=True):
-    """A minimal ECMA-376 workbook (what Excel / openpyxl / pandas.to_excel produce, minus styles): header cells as
-    shared strings or inline strings, numeric cells as <v>."""
-    import zipfile
-
-    def ref(j, i):
-        s, j = "", j + 1
-        while j:
-            j, rem = divmod(j - 1, 26)
-            s = chr(65 + rem) + s
-        return f"{s}{i + 1}"
-
-    strings = list(header)
-    sheet = ['<?xml version="1.0" encoding="UTF-8" standalone="yes"?>',
-             '<worksheet xmlns="http://schemas.openxmlformats.org/spreadsheetml/2006/main"><sheetData>', '<row r="1">']
-    for j, h in enumerate(header):
-        if shared_strings:
-            sheet.append(f'<c r="{ref(j, 0)}" t="s"><v>{strings.index(h)}</v></c>')
-        else:
-            sheet.append(f'<c r="{ref(j, 0)}" t="inlineStr"><is><t>{h}</t></is></c>')
-    sheet.append("</row>")
-    for i, row in enumerate(rows, start=1):
-        sheet.append(f'<row r="{i + 1}">' + "".join(f'<c r="{ref(j, i)}"><v>{v!r}</v></c>' for j, v in enumerate(row)) + "</row>")
-    sheet.append("</sheetData></worksheet>")
-    with zipfile.ZipFile(path, "w") as z:
-        z.writestr("[Content_Types].xml", '<?xml version="1.0"?><Types xmlns="http://schemas.openxmlformats.org/package/2006/content-types"/>')
-        z.writestr("xl/workbook.xml", '<?xml version="1.0"?><workbook xmlns="http://schemas.openxmlformats.org/spreadsheetml/2006/main" '
-                   'xmlns:r="http://schemas.openxmlformats.org/officeDocument/2006/relationships"><sheets>'
-                   '<sheet name="Sheet1" sheetId="1" r:id="rId1"/></sheets></workbook>')
-        z.writestr("xl/_rels/workbook.xml.rels", '<?xml version="1.0"?><Relationships xmlns="http://schemas.openxmlformats.org/package/2006/relationships">'
-                   '<Relationship Id="rId1" Type="http://schemas.openxmlformats.org/officeDocument/2006/relationships/worksheet" '
-                   'Target="worksheets/sheet1.xml"/></Relationships>')
-        z.writestr("xl/worksheets/sheet1.xml", "".join(sheet))
-        if shared_strings:
-            z.writestr("xl/sharedStrings.xml", '<?xml version="1.0"?><sst xmlns="http://schemas.openxmlformats.org/spreadsheetml/2006/main">'
-                       + "".join(f"<si><t>{h}</t></si>" for h in strings) + "</sst>")
-
-
 @pytest.mark.parametrize("shared_strings", [True, False])
-def test_network_xlsx_ingestion(tmp_path, shared_strings):
+def test_network_xlsx_ingestion(tmp_path, shared_strings, write_xlsx):
     """utils/create_net.py:11-24 on the reference's on-disk format: Nodes_33.xlsx (NODES, Tb, PDn, QDn) and
     Lines_33.xlsx (FROM, TO, R, X, Imax) -> the same dict as create_network() on the same tables, and from there the
     same kernel tables.  (The reference's own files are Git-LFS pointers; the workbooks are written here.)"""
     from safe_marl_amd.network import load_network_xlsx, read_xlsx_table
     nodes, lines = ieee33_tables()
     # extra / reordered columns, as real workbooks have them
-    _write_xlsx(tmp_path / "Nodes_33.xlsx", ["NODES", "Tb", "PDn", "QDn", "comment"],
+    write_xlsx(tmp_path / "Nodes_33.xlsx", ["NODES", "Tb", "PDn", "QDn", "comment"],
                 [(float(n[0]), float(n[1]), float(n[2]), float(n[3]), 0.0) for n in nodes], shared_strings)
-    _write_xlsx(tmp_path / "Lines_33.xlsx", ["FROM", "TO", "X", "R", "Imax"],
+    write_xlsx(tmp_path / "Lines_33.xlsx", ["FROM", "TO", "X", "R", "Imax"],
                 [(float(l[0]), float(l[1]), float(l[3]), float(l[2]), float(l[4])) for l in lines], shared_strings)
     header, rows = read_xlsx_table(str(tmp_path / "Lines_33.xlsx"))
     assert header == ["FROM", "TO", "X", "R", "Imax"] and len(rows) == 32 and rows[0][:2] == [1.0, 2.0]
@@ -119,7 +81,7 @@ def test_network_xlsx_ingestion(tmp_path, shared_strings):
     a, b = build_tables(got), build_tables(want)
     assert np.array_equal(a.parent, b.parent) and np.array_equal(a.r, b.r) and np.array_equal(a.x, b.x)
     with pytest.raises(KeyError):
-        _write_xlsx(tmp_path / "Nodes_33.xlsx", ["NODES", "Tb", "PDn"], [(1.0, 1.0, 0.0)], shared_strings)
+        write_xlsx(tmp_path / "Nodes_33.xlsx", ["NODES", "Tb", "PDn"], [(1.0, 1.0, 0.0)], shared_strings)
         load_network_xlsx(str(tmp_path))
 
 
