@@ -148,6 +148,8 @@ int flexenv_reset(FlexEnv* env, const uint8_t* mask /*dev [N] or NULL*/, const R
  * into the same launch. */
 #define FLEX_STEP_AUTORESET 1   /* an env that terminates in this step restarts (Philox stream) inside the same
                                   launch; its `obs` row then holds the FIRST observation of the new episode */
+#define FLEX_STEP_OBS_RING 2    /* `obs` is the BASE of the slab ring registered with flexenv_set_obs_ring: this launch writes its
+                                  observations into slab (cursor[0] + 1) mod slabs, read on the device (replayable HIP graph) */
 int flexenv_step(FlexEnv* env, const void* actions, int32_t act_dtype,
                  double* reward /*dev [N]*/, uint8_t* done /*dev [N]*/,
                  double* info /*dev [N, FLEX_INFO_W] or NULL*/, uint8_t* failed /*dev [N] or NULL*/,
@@ -167,9 +169,15 @@ int flexenv_poke(FlexEnv* env, int32_t field, const void* dev_in, void* stream);
 
 int32_t flexenv_num_envs(const FlexEnv* env);
 /* Optional launch counter: every later flexenv_step adds 1 to *counter (device int64, caller-owned, NULL switches it
- * off) from one lane of the launch.  Lets a consumer that indexes by vector step — the replay ring cursor of
- * flexnet_rollout_pack (include/flexnet.h) — follow the steps of a replayed HIP graph without a launch of its own. */
-int flexenv_set_step_counter(FlexEnv* env, int64_t* counter);
+ * off) from one lane of the launch, wrapping to 0 at `modulo` (0 = never).  Lets a consumer that indexes by vector step
+ * — the replay ring cursor of flexnet_rollout_pack (include/flexnet.h) — follow the steps of a replayed HIP graph
+ * without a launch of its own. */
+int flexenv_set_step_counter(FlexEnv* env, int64_t* counter, int64_t modulo);
+/* Observation ring for FLEX_STEP_OBS_RING: `cursor` (device int64, caller-owned, never written by this library) holds the
+ * slab the consumer is reading; a step writes slab (cursor[0] + 1) mod slabs of a ring whose slabs are
+ * `slab_stride` elements apart — the observation lands where the replay keeps it, once, and nothing copies it again.
+ * slabs = 0 switches it off. */
+int flexenv_set_obs_ring(FlexEnv* env, const int64_t* cursor, int64_t slab_stride, int32_t slabs);
 int32_t flexenv_obs_size(const FlexEnv* env);    /* 6*history, env:71 */
 int32_t flexenv_state_size(const FlexEnv* env);  /* env:72 */
 

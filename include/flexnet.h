@@ -62,6 +62,12 @@ typedef struct {
      * by rng_state[0] (seed) with counter (row, action group, rng_state[1] = step), Box-Muller on 24-bit uniforms.  The
      * caller (or flexnet_rollout_pack, given the same pointer) advances rng_state[1] between launches.  variant 0 only. */
     const uint64_t* rng_state; /* device [2] or NULL */
+    /* Inputs in a slab ring (the replay ring of flexnet_rollout_pack, written in place by the environment kernel):
+     * with `cursor` non-NULL the launch reads obs + cursor[0] * obs_slab_stride and hidden_in + cursor[0] *
+     * hid_slab_stride (strides in floats; cursor[0] is read on the device, so the launch replays from a HIP graph). */
+    const int64_t* cursor;     /* device [1] or NULL */
+    int64_t obs_slab_stride;
+    int64_t hid_slab_stride;
 } FlexActorArgs;
 
 /* rnn_agent.py:25-33 + model.py:102-116 for all rows. */
@@ -240,22 +246,24 @@ int flexnet_scaled_sum(const FlexSumArgs* args, void* stream);
  * the hidden state of slab k + 1 (zeroed where done = 1 — where the TD target multiplies the bootstrap value by zero
  * anyway, maddpg.py:117) and `last_hid` is the slab's own.  This launch, after step k ran:
  *     slab k     <- action, reward, done (last_step = done; the caller flags the final step of a horizon, model.py:229)
- *     slab k + 1 <- obs_next (what the environment kernel just produced), hid_new * (1 - done)
- *     hid_state  <- hid_new * (1 - done)      (hand-over to the next policy evaluation)
+ *     slab k + 1 <- obs_next (skipped when NULL: the environment kernel wrote it there itself, FLEX_STEP_OBS_RING of
+ *                   include/flexenv.h), hid_new * (1 - done)
+ *     hid_state  <- hid_new * (1 - done)      (hand-over to a policy that does not read the ring; skipped when NULL)
  *     statistics += this step's info / reward / failure sums (fixed-order block sums)
- *     cursor[0]  <- k + 1                     (a one-thread launch of its own behind the copy kernel — or, with
- *                                              cursor_stepped, by the environment's step kernel itself)
- * k is read from cursor[0] on the device, so the launches can be replayed from a HIP graph. */
+ * Slab indices live on the device (the launch replays from a HIP graph) in two cells, each written by exactly one kernel
+ * of the step so that no launch reads a cell it also writes: cursor[0] = the slab the policy reads (advanced HERE, by one
+ * lane, when cursor_stepped), cursor[1] = the slab being filled next (advanced by the environment's step kernel,
+ * flexenv_set_step_counter, before this launch).  Without an environment counter (cursor_stepped = 0) this launch reads
+ * cursor[0] and a one-thread launch behind it advances both cells. */
 typedef struct {
     int32_t n_envs, n_agents, obs_dim, act_dim;
     int32_t slabs;             /* ring capacity in slabs, >= 2 */
     int32_t small_w;           /* floats per small record: >= n_agents * act_dim + n_agents + 2 */
     int32_t info_w;            /* columns of `info` (7) */
-    int32_t cursor_stepped;    /* 1: cursor[0] was already advanced for this step (by flexenv_step, flexenv_set_step_counter):
-                                  k = cursor[0] - 1 and nothing is written to it; 0: k = cursor[0], advanced by a launch here */
+    int32_t cursor_stepped;    /* 1: cursor[1] was already advanced for this step by flexenv_step; 0: see above */
     const float* action;       /* [N, n, act_dim]  what the replay keeps (model.py:232) */
     const double* reward;      /* [N]   one reward per environment, stored once per agent */
-    const float* obs_next;     /* [N, n, obs_dim] */
+    const float* obs_next;     /* [N, n, obs_dim], or NULL (already in the ring) */
     const uint8_t* done;       /* [N] */
     const float* hid_new;      /* [N, n, 64] */
     const double* info;        /* [N, info_w] or NULL */
@@ -263,8 +271,8 @@ typedef struct {
     float* obs_ring;
     float* hid_ring;
     float* small_ring;
-    float* hid_state;          /* out [N, n, 64]; may alias hid_new */
-    int64_t* cursor;           /* [2]: {slab counter k, reserved} */
+    float* hid_state;          /* out [N, n, 64] or NULL; may alias hid_new */
+    int64_t* cursor;           /* [2]: physical slab indices, see above */
     double* info_sum;          /* [info_w] or NULL */
     double* rew_sum;           /* [1] */
     double* fail_sum;          /* [1] or NULL */

@@ -77,6 +77,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 __global__ __launch_bounds__(64 * AW, 1) void actor_forward_kernel(FlexActorArgs a) {
     __shared__ ActorLds s;
+    if (a.cursor) { const int64_t p = *a.cursor; a.obs += p * a.obs_slab_stride; a.hidden_in += p * a.hid_slab_stride; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int od = a.obs_dim, na = a.n_agents, ad = a.act_dim;
     const int ld1 = od + (a.agent_id ? na : 0);
@@ -266,6 +267,7 @@ __device__ __forceinline__ void actor_noise4(uint64_t seed, uint64_t step, uint3
 __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActorArgs a) {
     __shared__ ActorLdsM s;
     ASTAMP(0);
+    if (a.cursor) { const int64_t p = *a.cursor; a.obs += p * a.obs_slab_stride; a.hidden_in += p * a.hid_slab_stride; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rb = lane & 31, hf = lane >> 5;
     const int od = a.obs_dim, na = a.n_agents, ad = a.act_dim;
@@ -555,6 +557,7 @@ extern "C" int flexnet_actor_forward(const FlexActorArgs* a, void* stream) {
         a->act_dim < 1 || a->act_dim > FLEXNET_MAX_ACT)
         return FLEXNET_EUNSUPPORTED;
     if ((int64_t)a->rows * a->obs_dim * 4 >= 0x7ffffff0ll) return FLEXNET_EUNSUPPORTED;   // observations are addressed with 32-bit byte offsets
+    if (a->cursor && (a->obs_slab_stride < (int64_t)a->rows * a->obs_dim || a->hid_slab_stride < 0)) return FLEXNET_EINVAL;
     const int cus = flex_cu_count();                      // one block per CU owns that CU's LDS
     if (cus < 1) return FLEXNET_EHIP;
     if (a->variant == 0) {

@@ -38,6 +38,10 @@ struct FlexEnv {
     DevNet hnet;       // host copy
     DevState st;
     int64_t* step_counter;   // device cell flexenv_step bumps once per launch (flexenv_set_step_counter), or NULL
+    int64_t step_modulo;     // ... wrapping to 0 here (0 = never)
+    const int64_t* obs_cursor;   // FLEX_STEP_OBS_RING (flexenv_set_obs_ring)
+    int64_t obs_slab_stride;
+    int32_t obs_slabs;
 };
 
 // Diagnostic build only (-DFLEX_STAMPS): per-phase s_memtime stamps, lane 0 of each wave, written to a
@@ -67,6 +71,10 @@ struct KArgs {
     float inv_h, inv_h3;       // 1/history, 1/(3*history) for the observation plan's small_mod
     double inv_eta_ch, inv_eta_dis;
     int64_t* step_counter;     // += 1 per flex_step_kernel launch (one lane), or NULL
+    int64_t step_modulo;       // the counter wraps to 0 here (0 = never)
+    const int64_t* obs_cursor; // FLEX_STEP_OBS_RING: the observation goes to slab (obs_cursor[0] + 1) mod obs_slabs ...
+    int64_t obs_slab_stride;   // ... of a ring whose slabs are this many elements apart
+    int32_t obs_slabs;         // 0: `obs` is the output buffer itself
 };
 
 __device__ __forceinline__ double load_action(const void* p, int dtype, int64_t i) {
@@ -441,6 +449,12 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     const int env0 = wave * EPW;                               // first environment of this wavefront
     if (env0 >= a.n_envs) return;
+    if (a.obs_slabs > 0) {
+        // FLEX_STEP_OBS_RING (launch-uniform): the observations go straight into the consumer's slab ring, one slab past
+        // the one it is reading; nobody in this launch writes the cursor
+        const int64_t p = *a.obs_cursor + 1;
+        obs += (p >= a.obs_slabs ? 0 : p) * a.obs_slab_stride;
+    }
     // the spare group of an odd batch computes on env0's inputs (no out-of-bounds reads) and stores nothing
     const bool valid = env0 + lane / LW < a.n_envs;
     const int g = valid ? lane / LW : 0;
@@ -617,8 +631,12 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     // launch counter for consumers that index by vector step (flexnet_rollout_pack's ring cursor): one lane of the whole
     // grid, pointer re-read from the kernarg segment so that it is not carried across the solve
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int64_t* const sc = relaunder_kernarg<KArgs>()->step_counter;
-        if (sc) *sc += 1;
+        const KArgs* const ac = relaunder_kernarg<KArgs>();
+        int64_t* const sc = ac->step_counter;
+        if (sc) {
+            const int64_t nx = *sc + 1;
+            *sc = (ac->step_modulo > 0 && nx >= ac->step_modulo) ? 0 : nx;
+        }
     }
 #ifdef FLEX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -952,7 +970,8 @@ static KArgs make_args(const FlexEnv* e) {
     k.row_bytes = e->series.cols * 8;
     k.inv_h = 1.0f / (float)e->cfg.history; k.inv_h3 = 1.0f / (float)(3 * e->cfg.history);
     k.inv_eta_ch = 1.0 / e->cfg.eta_ch; k.inv_eta_dis = 1.0 / e->cfg.eta_dis;
-    k.step_counter = nullptr;                      // only flexenv_step hands it on
+    k.step_counter = nullptr;                      // only flexenv_step hands these on
+    k.step_modulo = 0; k.obs_cursor = nullptr; k.obs_slab_stride = 0; k.obs_slabs = 0;
     return k;
 }
 
@@ -1025,9 +1044,18 @@ void flexenv_destroy(FlexEnv* e) {
 }
 
 int32_t flexenv_num_envs(const FlexEnv* e) { return e ? e->n_envs : 0; }
-int flexenv_set_step_counter(FlexEnv* e, int64_t* counter) {
-    if (!e) return FLEX_EINVAL;
+int flexenv_set_step_counter(FlexEnv* e, int64_t* counter, int64_t modulo) {
+    if (!e || modulo < 0) return FLEX_EINVAL;
     e->step_counter = counter;
+    e->step_modulo = modulo;
+    return FLEX_OK;
+}
+int flexenv_set_obs_ring(FlexEnv* e, const int64_t* cursor, int64_t slab_stride, int32_t slabs) {
+    if (!e || slabs < 0 || (slabs > 0 && (!cursor || slabs < 2 || slab_stride < (int64_t)e->n_envs * e->cfg.n_agents * e->cfg.history * 6)))
+        return FLEX_EINVAL;
+    e->obs_cursor = slabs > 0 ? cursor : nullptr;
+    e->obs_slab_stride = slab_stride;
+    e->obs_slabs = slabs;
     return FLEX_OK;
 }
 int32_t flexenv_obs_size(const FlexEnv* e) { return e ? 6 * e->cfg.history : 0; }
@@ -1063,7 +1091,11 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     if (act_dtype != FLEX_F32 && act_dtype != FLEX_F64) return FLEX_EINVAL;
     if (obs && obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64) return FLEX_EINVAL;
     KArgs k = make_args(e);
-    k.step_counter = e->step_counter;
+    k.step_counter = e->step_counter; k.step_modulo = e->step_modulo;
+    if (flags & FLEX_STEP_OBS_RING) {
+        if (!obs || e->obs_slabs < 2 || obs_dtype != FLEX_F32) return FLEX_EINVAL;      // ring registered, fp32 slabs
+        k.obs_cursor = e->obs_cursor; k.obs_slab_stride = e->obs_slab_stride; k.obs_slabs = e->obs_slabs;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int epw = e->hnet.epw;
     const dim3 grid = env_grid(e->n_envs, epw);

@@ -18,9 +18,13 @@ typedef float pack_f4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(PACK_THREADS) void rollout_pack_kernel(FlexRolloutPackArgs a) {
     const int tid = threadIdx.x;
-    // nobody in this launch writes the cursor: it is advanced by rollout_cursor_kernel AFTER it, or (cursor_stepped) it
-    // was advanced by the environment's step kernel BEFORE it
-    const int64_t k = a.cursor[0] - a.cursor_stepped;
+    // Two cursor cells, each written by ONE kernel of the step and read only by others: cursor[0] = slab the policy reads
+    // (written here, at the end, by one lane; read by the policy and the environment kernel), cursor[1] = slab the step
+    // fills next (advanced by the environment's step kernel BEFORE this launch when cursor_stepped, read here).  Without
+    // an environment counter this launch reads cursor[0] and rollout_cursor_kernel advances both cells AFTER it.
+    int64_t cur, nxt;
+    if (a.cursor_stepped) { nxt = a.cursor[1]; cur = nxt == 0 ? a.slabs - 1 : nxt - 1; }
+    else { cur = a.cursor[0]; nxt = cur + 1 >= a.slabs ? 0 : cur + 1; }
     if (blockIdx.x < PACK_STATS) {
         // the first ten blocks own one statistic each (info columns, reward, failures): a block reduction over all
         // environments in a fixed order and one plain += — no atomics on the sums, bit-reproducible
@@ -40,13 +44,16 @@ __global__ __launch_bounds__(PACK_THREADS) void rollout_pack_kernel(FlexRolloutP
             }
             if (tid == 0) {
                 if (is_info) a.info_sum[q] += red[0];
-                else if (q == 8) { *a.rew_sum += red[0]; if (a.rng_state) a.rng_state[1] += 1; }
+                else if (q == 8) {                                    // this block always runs
+                    *a.rew_sum += red[0];
+                    if (a.rng_state) a.rng_state[1] += 1;
+                    if (a.cursor_stepped) a.cursor[0] = nxt;          // no block of this launch reads cursor[0] in this mode
+                }
                 else *a.fail_sum += red[0];
             }
         }
     } else {
         const int no = a.n_agents * a.obs_dim, na = a.n_agents * a.act_dim, nh = a.n_agents * FLEXNET_HID;
-        const int64_t cur = k % a.slabs, nxt = (k + 1) % a.slabs;
         const int e0 = (blockIdx.x - PACK_STATS) * PACK_ENVS;
         const int no4 = no >> 2, nh4 = nh >> 2;
         constexpr int MO = (FLEXNET_MAX_AGENTS * FLEXNET_MAX_OBS / 4 + PACK_THREADS - 1) / PACK_THREADS;      // 2
@@ -60,8 +67,10 @@ __global__ __launch_bounds__(PACK_THREADS) void rollout_pack_kernel(FlexRolloutP
             keep[j] = a.done[e] ? 0.0f : 1.0f;
             const pack_f4* on = reinterpret_cast<const pack_f4*>(a.obs_next + (int64_t)e * no);
             const pack_f4* hn = reinterpret_cast<const pack_f4*>(a.hid_new + (int64_t)e * nh);
+            if (a.obs_next) {                                             // NULL: the environment kernel wrote the slab itself
 #pragma unroll
-            for (int t = 0; t < MO; ++t) { const int i = tid + PACK_THREADS * t; if (i < no4) ob[j][t] = on[i]; }
+                for (int t = 0; t < MO; ++t) { const int i = tid + PACK_THREADS * t; if (i < no4) ob[j][t] = on[i]; }
+            }
 #pragma unroll
             for (int t = 0; t < MH; ++t) { const int i = tid + PACK_THREADS * t; if (i < nh4) hb[j][t] = hn[i]; }
         }
@@ -72,18 +81,20 @@ __global__ __launch_bounds__(PACK_THREADS) void rollout_pack_kernel(FlexRolloutP
             pack_f4* o_ring = reinterpret_cast<pack_f4*>(a.obs_ring + (nxt * a.n_envs + e) * (int64_t)no);
             pack_f4* h_ring = reinterpret_cast<pack_f4*>(a.hid_ring + (nxt * a.n_envs + e) * (int64_t)nh);
             pack_f4* h_state = reinterpret_cast<pack_f4*>(a.hid_state + (int64_t)e * nh);
+            if (a.obs_next) {
 #pragma unroll
-            for (int t = 0; t < MO; ++t) {
-                const int i = tid + PACK_THREADS * t;
-                if (i < no4) __builtin_nontemporal_store(ob[j][t], &o_ring[i]);        // model.py:236,262: next_state = the next state
+                for (int t = 0; t < MO; ++t) {
+                    const int i = tid + PACK_THREADS * t;
+                    if (i < no4) __builtin_nontemporal_store(ob[j][t], &o_ring[i]);    // model.py:236,262: next_state = the next state
+                }
             }
 #pragma unroll
             for (int t = 0; t < MH; ++t) {
                 const int i = tid + PACK_THREADS * t;
                 if (i < nh4) {                                                          // fresh hidden state after a terminal step
                     const pack_f4 h = hb[j][t] * keep[j];
-                    __builtin_nontemporal_store(h, &h_ring[i]);
-                    h_state[i] = h;
+                    h_ring[i] = h;                     // read back by the next policy launch when it takes its input from the ring
+                    if (a.hid_state) h_state[i] = h;
                 }
             }
             float* sm = a.small_ring + (cur * a.n_envs + e) * (int64_t)a.small_w;
@@ -97,15 +108,19 @@ __global__ __launch_bounds__(PACK_THREADS) void rollout_pack_kernel(FlexRolloutP
 // cursor[0] += 1 as a launch of its own: every block of rollout_pack_kernel reads the cursor, so the increment has to wait
 // for all of them.  (A last-block ticket inside the pack kernel was tried first: 2 058 device-scope atomics on one address
 // — executed memory-side, past the per-XCD L2s — took longer than the 39 MB of copies: 34.8 us per launch.)
-__global__ void rollout_cursor_kernel(int64_t* cursor) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) cursor[0] += 1;
+__global__ void rollout_cursor_kernel(int64_t* cursor, int slabs) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int64_t nxt = cursor[0] + 1 >= slabs ? 0 : cursor[0] + 1;
+        cursor[0] = nxt;
+        cursor[1] = nxt;
+    }
 }
 
 extern "C" int flexnet_rollout_pack(const FlexRolloutPackArgs* a, void* stream) {
     if (!a || a->n_envs < 0) return FLEXNET_EINVAL;
     if (a->n_envs == 0) return FLEXNET_OK;
-    if (!a->action || !a->reward || !a->obs_next || !a->done || !a->hid_new || !a->obs_ring || !a->hid_ring ||
-        !a->small_ring || !a->hid_state || !a->cursor || !a->rew_sum || a->info_w < 0 || a->info_w > 8 || a->n_agents < 1 ||
+    if (!a->action || !a->reward || !a->done || !a->hid_new || !a->obs_ring || !a->hid_ring ||
+        !a->small_ring || !a->cursor || !a->rew_sum || a->info_w < 0 || a->info_w > 8 || a->n_agents < 1 ||
         a->n_agents > FLEXNET_MAX_AGENTS || a->obs_dim < 1 || a->obs_dim > FLEXNET_MAX_OBS || a->act_dim < 1 ||
         a->act_dim > FLEXNET_MAX_ACT || a->slabs < 2 || a->small_w < a->n_agents * a->act_dim + a->n_agents + 2)
         return FLEXNET_EINVAL;
@@ -116,7 +131,7 @@ extern "C" int flexnet_rollout_pack(const FlexRolloutPackArgs* a, void* stream) 
     if (align & 15) return FLEXNET_EINVAL;
     const int blocks = (a->n_envs + PACK_ENVS - 1) / PACK_ENVS + PACK_STATS;
     hipLaunchKernelGGL(rollout_pack_kernel, dim3(blocks), dim3(PACK_THREADS), 0, (hipStream_t)stream, *a);
-    if (!a->cursor_stepped) hipLaunchKernelGGL(rollout_cursor_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->cursor);
+    if (!a->cursor_stepped) hipLaunchKernelGGL(rollout_cursor_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->cursor, a->slabs);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 

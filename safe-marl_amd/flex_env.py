@@ -178,9 +178,10 @@ class VecFlexProvisionEnv:
                                           _ptr(self.failed), _stream()), "flexenv_reset")
         return out
 
-    def step(self, actions, obs_out=None, fuse_obs=False, auto_reset=False):
+    def step(self, actions, obs_out=None, fuse_obs=False, auto_reset=False, obs_ring=None):
         """auto_reset: environments that terminate in this step restart inside the same launch (their row of the
-        fused observation is then the first observation of the new episode)."""
+        fused observation is then the first observation of the new episode).  obs_ring: base tensor of the slab ring
+        registered with set_obs_ring — the fused observation goes into the slab after the cursor instead of ``self.obs``."""
         self.calls += 1
         if actions.device != self.device:
             actions = actions.to(self.device)
@@ -188,22 +189,35 @@ class VecFlexProvisionEnv:
         if actions.numel() != self.n_envs * self.n_agents * 4:
             raise ValueError(f"actions must have {self.n_envs}x{self.n_agents}x4 elements, got {tuple(actions.shape)}")
         out = None
-        if fuse_obs:
+        flags = _lib.FLEX_STEP_AUTORESET if auto_reset else 0
+        if obs_ring is not None:
+            out, flags = obs_ring, flags | _lib.FLEX_STEP_OBS_RING
+        elif fuse_obs:
             out = self.obs if obs_out is None else obs_out
         _lib.check(self.lib.flexenv_step(self.handle, _ptr(actions), self._dtype_tag(actions), _ptr(self.reward),
                                          _ptr(self.done), _ptr(self.info), _ptr(self.failed), _ptr(out),
-                                         self._dtype_tag(out) if out is not None else 0,
-                                         _lib.FLEX_STEP_AUTORESET if auto_reset else 0, _stream()), "flexenv_step")
+                                         self._dtype_tag(out) if out is not None else 0, flags, _stream()), "flexenv_step")
         return self.reward, self.done, self.info
 
-    def set_step_counter(self, counter):
+    def set_step_counter(self, counter, modulo=0):
         """Every later step() adds 1 to ``counter[0]`` (int64 device tensor, or None to switch it off) from inside the
-        step kernel — how a replayed HIP graph keeps the replay ring's cursor moving without a launch of its own
-        (include/flexenv.h: flexenv_set_step_counter).  The tensor is kept alive for as long as the env points at it."""
+        step kernel, wrapping to 0 at ``modulo`` (0 = never) — how a replayed HIP graph keeps the replay ring's cursor
+        moving without a launch of its own (include/flexenv.h: flexenv_set_step_counter).  The tensor is kept alive for as
+        long as the env points at it."""
         if counter is not None and not (counter.is_cuda and counter.dtype == torch.int64 and counter.is_contiguous()):
             raise ValueError("step counter must be a contiguous int64 device tensor")
-        _lib.check(self.lib.flexenv_set_step_counter(self.handle, _ptr(counter)), "flexenv_set_step_counter")
+        _lib.check(self.lib.flexenv_set_step_counter(self.handle, _ptr(counter), int(modulo)), "flexenv_set_step_counter")
         self._step_counter = counter
+
+    def set_obs_ring(self, cursor, slab_stride, slabs):
+        """Register a slab ring for ``step(..., obs_ring=base)``: that launch writes its observations into slab
+        ``(cursor[0] + 1) % slabs`` of the ring starting at ``base`` (slabs ``slab_stride`` floats apart), read on the
+        device (include/flexenv.h: flexenv_set_obs_ring).  ``slabs = 0`` switches it off."""
+        if slabs and not (cursor.is_cuda and cursor.dtype == torch.int64 and cursor.is_contiguous()):
+            raise ValueError("ring cursor must be a contiguous int64 device tensor")
+        _lib.check(self.lib.flexenv_set_obs_ring(self.handle, _ptr(cursor) if slabs else None, int(slab_stride), int(slabs)),
+                   "flexenv_set_obs_ring")
+        self._obs_cursor = cursor if slabs else None
 
     def get_obs(self, obs_out=None):
         out = self.obs if obs_out is None else obs_out

@@ -45,8 +45,8 @@ class RolloutGraph:
             buf.alloc_slabs(N, n, o, a, h)
         if (buf.n_envs, buf.n_agents, buf.obs_dim, buf.act_dim, buf.hid_dim) != (N, n, o, a, h):
             raise RuntimeError("replay buffer was allocated for another environment batch")
-        self.obs = env.obs                          # [N, n, o]: written by the env kernel, read by the policy
-        self.hid = th.zeros(N, n, h, device=dev)
+        self._obs = env.obs                         # [N, n, o]: written by the env kernel, read by the policy (tensor mode)
+        self._hid = th.zeros(N, n, h, device=dev)
         self.info_sum = th.zeros(env.info.shape[1], dtype=th.float64, device=dev)
         self.rew_sum = th.zeros((), dtype=th.float64, device=dev)
         self.fail_sum = th.zeros((), dtype=th.float64, device=dev)
@@ -62,19 +62,43 @@ class RolloutGraph:
         # (the actor kernel's exploration epilogue IS tanh(mean + std * noise), util.py:57-64: without action_enforcebound
         # the reference adds unbounded noise, util.py:66-74, and the general body below runs select_action itself)
         self.fast = (type(model).__name__ in ("MADDPG", "SAFEMADDPG") and model.fused_inference
-                     and model.args.shared_params and self.obs.is_cuda and model.args.agent_type == "rnn" and h == 64
+                     and model.args.shared_params and env.obs.is_cuda and model.args.agent_type == "rnn" and h == 64
                      and o <= 144 and bool(model.args.action_enforcebound))
         # ring write / hand-over / statistics in ONE launch of this project's kernel (fixed-order block sums): no ATen
         # reduction is ever captured into the rollout graph, whatever the algorithm
-        self.packable = self.obs.is_cuda and h == 64 and o <= 144 and n <= 8 and a <= 8 and (n * o) % 4 == 0
+        self.packable = env.obs.is_cuda and h == 64 and o <= 144 and n <= 8 and a <= 8 and (n * o) % 4 == 0
         if self.safe:
             self.predictor = tuple(th.as_tensor(x, dtype=th.float64, device=dev).contiguous() for x in model.predictor)
         self.env_calls = None                                  # env.calls after this object's last step (continuity check)
-        # the ring cursor is advanced by the env's step kernel itself (one lane): no launch of its own per vector step
+        # the slab the step fills (cursor[1]) is advanced by the env's step kernel itself (one lane): no launch of its own
         self.cursor_stepped = 0
-        if hasattr(env, "set_step_counter") and self.obs.is_cuda:
-            env.set_step_counter(buf.cursor)
+        if hasattr(env, "set_step_counter") and env.obs.is_cuda:
+            env.set_step_counter(buf.cursor[1:], buf.slabs)
             self.cursor_stepped = 1
+        # Ring I/O (the fused path): the env kernel writes its observation straight into the slab after the cursor, the
+        # actor kernel reads observation and hidden state from the slab at the cursor — the observation is written once,
+        # where the replay keeps it, and never copied; the pack kernel only moves the hidden state and the small record.
+        self.ring_io = bool(self.fast and self.cursor_stepped and hasattr(env, "set_obs_ring"))
+        if self.ring_io:
+            env.set_obs_ring(buf.cursor, N * n * o, buf.slabs)
+
+    @property
+    def ring_active(self):
+        return self.ring_io and self.fast          # (tests switch `fast` off to run the general body on the same object)
+
+    @property
+    def obs(self):
+        """The observation the next policy evaluation reads: [N, n, o]."""
+        if self.ring_active:
+            return self.buf.obs_ring[self.buf.k % self.buf.slabs].view(self.env.n_envs, self.model.n_, self.model.obs_dim)
+        return self._obs
+
+    @property
+    def hid(self):
+        """The hidden state the next policy evaluation starts from: [N, n, h]."""
+        if self.ring_active:
+            return self.buf.hid_ring[self.buf.k % self.buf.slabs].view(self.env.n_envs, self.model.n_, self.model.hid_dim)
+        return self._hid
 
     def _pack(self, action, hid):
         """model.py:230-262 for every environment in one launch (include/flexnet.h: flexnet_rollout_pack)."""
@@ -84,13 +108,14 @@ class RolloutGraph:
         a = _lib.FlexRolloutPackArgs()
         a.n_envs, a.n_agents, a.obs_dim, a.act_dim = env.n_envs, m.n_, m.obs_dim, m.act_dim
         a.slabs, a.small_w, a.info_w, a.cursor_stepped = buf.slabs, buf.small_w, env.info.shape[1], self.cursor_stepped
-        for name, t in (("action", action), ("reward", env.reward), ("obs_next", env.obs), ("done", env.done),
-                        ("hid_new", hid), ("info", env.info), ("failed", env.failed), ("obs_ring", buf.obs_ring),
-                        ("hid_ring", buf.hid_ring), ("small_ring", buf.small_ring), ("hid_state", self.hid),
-                        ("cursor", buf.cursor), ("info_sum", self.info_sum), ("rew_sum", self.rew_sum),
-                        ("fail_sum", self.fail_sum)):
-            assert t.is_contiguous()
-            setattr(a, name, t.data_ptr())
+        for name, t in (("action", action), ("reward", env.reward), ("obs_next", None if self.ring_active else env.obs),
+                        ("done", env.done), ("hid_new", hid), ("info", env.info), ("failed", env.failed),
+                        ("obs_ring", buf.obs_ring), ("hid_ring", buf.hid_ring), ("small_ring", buf.small_ring),
+                        ("hid_state", None if self.ring_active else self._hid), ("cursor", buf.cursor),
+                        ("info_sum", self.info_sum), ("rew_sum", self.rew_sum), ("fail_sum", self.fail_sum)):
+            if t is not None:
+                assert t.is_contiguous()
+                setattr(a, name, t.data_ptr())
         if not self.torch_noise:
             a.rng_state = self.rng_state.data_ptr()       # next step of the actor kernel's noise stream
         _lib.check(_lib.load().flexnet_rollout_pack(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)),
@@ -111,21 +136,28 @@ class RolloutGraph:
                 # when this object was built; the pack kernel advances the step counter), or — torch_noise, used by the
                 # tests that compare with the PyTorch glue draw for draw — by torch.randn.  Inside a HIP graph torch.randn
                 # costs a launch plus two seed/offset fill kernels per replay.
-                noise = th.randn(N, m.n_, m.act_dim, device=self.obs.device) if self.torch_noise else None
-                out = fused_actor_forward(m.policy_dicts[0], self.obs, self.hid, m.n_, m.args.agent_id, noise=noise,
+                buf = self.buf
+                noise = th.randn(N, m.n_, m.act_dim, device=env.obs.device) if self.torch_noise else None
+                ring = dict(ring_cursor=buf.cursor, obs_slab_stride=buf.obs_ring.stride(0),
+                            hid_slab_stride=buf.hid_ring.stride(0)) if self.ring_active else {}
+                obs_in = buf.obs_ring[0].view(N, m.n_, m.obs_dim) if self.ring_active else self._obs
+                hid_in = buf.hid_ring[0].view(N, m.n_, m.hid_dim) if self.ring_active else self._hid
+                out = fused_actor_forward(m.policy_dicts[0], obs_in, hid_in, m.n_, m.args.agent_id, noise=noise,
                                           std=self.std, low=m.args.action_low, high=m.args.action_high,
-                                          rng_state=None if self.torch_noise else self.rng_state)
-                if out is not None:
-                    _, hid, action, env_action = out
-                    if self.safe:
-                        # safemaddpg.py:90-111: the proposed action goes through the safety layer (HIP closed form,
-                        # flexenv_safety_project); the replay keeps the policy's own action (model.py:232)
-                        vec = env.vec if hasattr(env, "vec") else env
-                        adjusted, _ = vec.safety_project(action.view(N, m.n_, m.act_dim), *self.predictor, m.V_min, m.V_max)
-                        env_action = m.env_action(adjusted.to(th.float32))
-                    env.step(env_action.view(N, m.n_, m.act_dim), fuse_obs=True, auto_reset=True)
-                    self._pack(action, hid)
-                    return
+                                          rng_state=None if self.torch_noise else self.rng_state, **ring)
+                if out is None:
+                    raise RuntimeError("the fused actor kernel declined a configuration RolloutGraph.fast admitted")
+                _, hid, action, env_action = out
+                if self.safe:
+                    # safemaddpg.py:90-111: the proposed action goes through the safety layer (HIP closed form,
+                    # flexenv_safety_project); the replay keeps the policy's own action (model.py:232)
+                    vec = env.vec if hasattr(env, "vec") else env
+                    adjusted, _ = vec.safety_project(action.view(N, m.n_, m.act_dim), *self.predictor, m.V_min, m.V_max)
+                    env_action = m.env_action(adjusted.to(th.float32))
+                env.step(env_action.view(N, m.n_, m.act_dim), fuse_obs=True, auto_reset=True,
+                         obs_ring=buf.obs_ring if self.ring_active else None)
+                self._pack(action, hid)
+                return
         with th.no_grad():
             if self.plain:
                 means, _, hid = m.policy(self.obs, last_hid=self.hid)
@@ -176,10 +208,10 @@ class RolloutGraph:
         is zero.  None: the environments continue where the last step left them (those that terminated restarted
         inside that launch, their hidden state was zeroed by the pack kernel)."""
         if first_obs is not None:
-            if first_obs.data_ptr() != self.obs.data_ptr():
-                self.obs.copy_(first_obs)
-            self.hid.zero_()
-            self.buf.begin_stream(self.obs)
+            if not self.ring_active and first_obs.data_ptr() != self._obs.data_ptr():
+                self._obs.copy_(first_obs)
+            self._hid.zero_()
+            self.buf.begin_stream(first_obs)
         self.info_sum.zero_(); self.rew_sum.zero_(); self.fail_sum.zero_()
 
 

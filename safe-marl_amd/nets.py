@@ -154,7 +154,7 @@ class MLPCritic(nn.Module):
 
 
 def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=1.0, low=0.0, high=1.0, variant=0,
-                        rng_state=None):
+                        rng_state=None, ring_cursor=None, obs_slab_stride=0, hid_slab_stride=0):
     """rnn_agent.py:25-33 + model.py:102-116 without an autograd graph, in one HIP launch.
 
     ``obs`` [b, n, obs_dim] fp32 on the GPU WITHOUT the one-hot id columns (the kernel adds fc1's id column of
@@ -164,7 +164,9 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
     back: action = tanh(mean + std * noise) (util.py:57-64) and the environment's action (util.py:125-128).  With
     ``rng_state`` (int64 device tensor [seed, step]) instead of ``noise`` the kernel draws the normal numbers itself
     (Philox4x32-10 + Box-Muller, csrc/actor.hip actor_noise4); the caller advances ``rng_state[1]`` per call —
-    flexnet_rollout_pack does when handed the same tensor."""
+    flexnet_rollout_pack does when handed the same tensor.  With ``ring_cursor`` (int64 device tensor) ``obs`` and ``hidden``
+    are slab 0 of two slab rings and the launch reads slab ``ring_cursor[0]`` of each (strides in floats), resolved on the
+    device — the rollout graph's way of reading the observation where the environment kernel wrote it."""
     import ctypes as C
     from . import _lib
     a = agent.args
@@ -192,6 +194,8 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
         if not (rng_state.is_cuda and rng_state.dtype == th.int64 and rng_state.numel() == 2 and rng_state.is_contiguous()):
             raise ValueError("rng_state must be a contiguous int64 device tensor [seed, step]")
         args.rng_state = rng_state.data_ptr()
+    if ring_cursor is not None:
+        args.cursor, args.obs_slab_stride, args.hid_slab_stride = ring_cursor.data_ptr(), int(obs_slab_stride), int(hid_slab_stride)
     if explore:
         action, env_action = th.empty_like(means), th.empty_like(means)
         args.std, args.action_low, args.action_high = float(std), float(low), float(high)

@@ -74,7 +74,8 @@ class DeviceReplayBuffer:
         self.obs_ring = th.zeros(self.slabs, n_envs, no, dtype=th.float32, device=dev)
         self.hid_ring = th.zeros(self.slabs, n_envs, nh, dtype=th.float32, device=dev)
         self.small_ring = th.zeros(self.slabs, n_envs, self.small_w, dtype=th.float32, device=dev)
-        self.cursor = th.zeros(2, dtype=th.int64, device=dev)                     # {slab counter, ticket}
+        # physical slab indices on the device (include/flexnet.h): [0] the slab the policy reads, [1] the slab being filled
+        self.cursor = th.zeros(2, dtype=th.int64, device=dev)
         self.k = 0                   # host mirror of cursor[0]
         self.first = 0               # oldest slab counter whose transition may still be in the ring
         self.gaps = []               # slab counters without a transition (half-written by the step before a hard reset)
@@ -99,7 +100,7 @@ class DeviceReplayBuffer:
         p = self.k % self.slabs
         self.obs_ring[p].copy_(first_obs.reshape(self.n_envs, -1))
         self.hid_ring[p].zero_()
-        self.cursor[0] = self.k
+        self.cursor.fill_(p)
         self._retire()
 
     def stepped(self):
