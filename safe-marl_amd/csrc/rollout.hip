@@ -33,9 +33,21 @@ __global__ __launch_bounds__(PACK_THREADS) void rollout_pack_kernel(FlexRolloutP
         const bool is_info = q < 8;
         const bool live = is_info ? (q < a.info_w && a.info && a.info_sum) : (q == 8 ? true : (a.failed && a.fail_sum));
         if (live) {
+            // eight loads in flight per thread (the statistics blocks are the launch's long pole otherwise: sixteen
+            // dependent round trips at 4096 environments), summed in a fixed order
             double v = 0.0;
-            for (int e = tid; e < a.n_envs; e += PACK_THREADS)
-                v += is_info ? a.info[(int64_t)e * a.info_w + q] : (q == 8 ? a.reward[e] : (a.failed[e] ? 1.0 : 0.0));
+            for (int e0 = tid; e0 < a.n_envs; e0 += 8 * PACK_THREADS) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * PACK_THREADS;
+                    const int ec = e < a.n_envs ? e : a.n_envs - 1;
+                    const double t = is_info ? a.info[(int64_t)ec * a.info_w + q] : (q == 8 ? a.reward[ec] : (a.failed[ec] ? 1.0 : 0.0));
+                    x[u] = e < a.n_envs ? t : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += x[u];
+            }
             red[tid] = v;
             __syncthreads();
             for (int sft = PACK_THREADS / 2; sft > 0; sft >>= 1) {

@@ -19,7 +19,7 @@ import numpy as np
 import torch as th
 import torch.nn as nn
 
-from .nets import (WGRAD_MIN_ROWS, CriticTail, MLPAgent, MLPCritic, RNNAgent, critic_replayed_supported,
+from .nets import (WGRAD_MIN_ROWS, CriticTail, MLPAgent, MLPCritic, RNNAgent, critic_policy_supported, critic_replayed_supported,
                    critic_tail_supported, fused_actor_forward, td_loss, td_loss_supported, wide_batch_linear,
                    batchnorm_stats_supported, batchnorm_update_running_stats)
 from .replay_buffer import Transition
@@ -301,9 +301,14 @@ class Model(nn.Module):
         policy call otherwise; nothing downstream writes into it."""
         cache = self.__dict__.setdefault("_log_std_cache", {})
         if means.device not in cache:
-            cache[means.device] = th.full((1,), float(np.log(self.args.fixed_policy_std)), dtype=means.dtype,
-                                          device=means.device)
-        return cache[means.device].expand_as(means)
+            log_std = float(np.log(self.args.fixed_policy_std))
+            # the entropy of N(mean, std) does not depend on the mean: with the fixed std it is ONE number (SURVEY A17)
+            cache[means.device] = (th.full((1,), log_std, dtype=means.dtype, device=means.device),
+                                   th.full((), 0.5 + 0.5 * float(np.log(2.0 * np.pi)) + log_std, dtype=means.dtype,
+                                           device=means.device))
+        out = cache[means.device][0].expand_as(means)
+        out._flex_entropy = cache[means.device][1]        # mean entropy of Normal(means, exp(out)) (util.py:35-36)
+        return out
 
     # -- update cadence (model.py:40-71) -----------------------------------------------------------
     def transition_update(self, trainer, trans, stat):
@@ -606,13 +611,17 @@ class MADDPG(Model):
         self.construct_value_net()
         self.construct_policy_net()
 
-    def value(self, obs, act):
+    def value(self, obs, act, critic_frozen=False):
         """maddpg.py:33-76.  Row i of the reference's critic input is
         [obs_0..obs_{n-1} | onehot(i) | act_0..act_{n-1}] with act_j detached for j != i.  fc1 of that row is
         W_obs @ obs_all + W_id[:, i] + W_act @ act_all(detached) + W_act[:, block i] @ (act_i - act_i.detach()) + b:
         the first and third terms are shared by the n rows of a sample, the last one is zero-valued and only
-        carries agent i's own-action gradient.  Returns [b, n, 1]."""
+        carries agent i's own-action gradient.  Returns [b, n, 1].  ``critic_frozen``: the caller differentiates w.r.t. the
+        actions only (the policy loss of a policy sub-update) — one autograd node, no critic-parameter gradients."""
         b, n, o, a = obs.size(0), self.n_, self.obs_dim, self.act_dim
+        if (critic_frozen and self.args.shared_params and self.args.agent_id and act.requires_grad and th.is_grad_enabled()
+                and critic_policy_supported(self.value_dicts[0], obs.reshape(b, n * o), act, n)):
+            return CriticTail.apply_policy(obs.reshape(b, n * o), act, self.value_dicts[0]).view(b, n, 1)
         act_det = act.detach()
         own = act - act_det if act.requires_grad else None                # zeros that carry d/d act_i
         values = []
@@ -694,7 +703,9 @@ class MADDPG(Model):
             _, actions_pol, _, action_out, _ = self.get_actions(state, status="train", exploration=False,
                                                                 actions_avail=actions_avail, target=False,
                                                                 last_hid=last_hids)
-            advantages = self.value(state, actions_pol).view(-1, self.n_)
+            # need == "policy": a policy sub-update — only the policy optimiser's parameters take this loss's gradient
+            # (utils/trainer.py:99-108), so the critic is differentiated w.r.t. the actions alone
+            advantages = self.value(state, actions_pol, critic_frozen=(need == "policy")).view(-1, self.n_)
             if self.args.normalize_advantages:
                 advantages = self.batchnorm(advantages)
             policy_loss = mean_all(-advantages)
@@ -742,7 +753,7 @@ class MATD3(MADDPG):
         count = 1 if self.args.shared_params else self.n_
         self.value_dicts = nn.ModuleList([MLPCritic(input_shape, 1, self.args) for _ in range(count)])
 
-    def value(self, obs, act):
+    def value(self, obs, act, critic_frozen=False):
         """matd3.py:33-86: returns cat([Q1, Q2], dim=0) of shape [2b, n, 1].  Same column-block evaluation as
         MADDPG.value; the twin flag only adds fc1.weight's last column to the second head's pre-activation."""
         if not self.args.shared_params:
@@ -824,7 +835,7 @@ class IDDPG(MADDPG):
         count = 1 if self.args.shared_params else self.n_
         self.value_dicts = nn.ModuleList([MLPCritic(input_shape, 1, self.args) for _ in range(count)])
 
-    def value(self, obs, act):
+    def value(self, obs, act, critic_frozen=False):
         """iddpg.py:32-59: rows [o_i | onehot(i) | a_i] -> [b, n, 1]."""
         b = obs.size(0)
         if self.args.agent_id:

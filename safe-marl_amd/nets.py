@@ -690,6 +690,65 @@ class _CriticReplayedFn(th.autograd.Function):
                 None)
 
 
+class _CriticPolicyFn(th.autograd.Function):
+    """The shared-parameter critic inside the POLICY loss, maddpg.py:33-76 + maddpg.py:104-107: q[b, i] on the policy's own
+    actions, differentiated w.r.t. those actions only (row i of a sample carries agent i's own action block; the other
+    agents' blocks are detached, maddpg.py:47-54).  Value-wise every row is still shared[b] + W_id[:, i] — the own-action
+    term is zero-valued — so the forward is two GEMMs and the composed tail kernel; the backward is the tail's dz1-only
+    kernel and d act[b, i] = dz1[b, i] @ W_act[:, block i].  The critic's parameters get no gradient from this node: it
+    is used where only the policy optimiser steps (utils/trainer.py:99-108 steps the policy on the policy loss)."""
+
+    @staticmethod
+    def forward(ctx, obs2d, act, W, bias, ln_w, ln_b, w2, b2, w3, b3, eps):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        b, n, na_ = act.shape
+        no = obs2d.shape[1]
+        act2d = act.reshape(b, n * na_)
+        shared = th.addmm(bias, obs2d, W[:, :no].t())
+        shared.addmm_(act2d, W[:, no + n:no + n + n * na_].t())
+        id_cols = W[:, no:no + n].t().contiguous()
+        rows = b * n
+        q = th.empty(rows, 1, dtype=th.float32, device=shared.device)
+        args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, eps)
+        args.rows, args.z1, args.z_shared, args.z_id, args.n_agents = rows, None, shared.data_ptr(), id_cols.data_ptr(), n
+        args.q = q.data_ptr()
+        _lib.check(lib.flexnet_critic_tail_forward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_critic_tail_forward")
+        ctx.eps, ctx.dims = eps, (b, n, na_, no)
+        ctx.save_for_backward(shared, id_cols, W, ln_w, ln_b, w2, b2, w3, b3)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        shared, id_cols, W, ln_w, ln_b, w2, b2, w3, b3 = ctx.saved_tensors
+        b, n, na_, no = ctx.dims
+        rows = b * n
+        dq = dq.contiguous()
+        dz1 = th.empty(rows, 64, dtype=th.float32, device=shared.device)
+        args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, ctx.eps)
+        args.rows, args.z1, args.z_shared, args.z_id, args.n_agents = rows, None, shared.data_ptr(), id_cols.data_ptr(), n
+        args.dq, args.dz1 = dq.data_ptr(), dz1.data_ptr()
+        _lib.check(lib.flexnet_critic_tail_backward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_critic_tail_backward")
+        W_act = W[:, no + n:no + n + n * na_].reshape(64, n, na_)
+        d_act = th.einsum("bih,hia->bia", dz1.view(b, n, 64), W_act)
+        return (None, d_act) + (None,) * 9
+
+
+def critic_policy_supported(critic, obs2d, act, n_agents):
+    a = critic.args
+    W = critic.fc1.weight
+    return (obs2d.is_cuda and obs2d.dtype == th.float32 and act.dtype == th.float32 and act.dim() == 3 and a.hid_size == 64
+            and a.hid_activation == "relu" and critic.fc3.out_features == 1 and getattr(critic, "fused_tail", True)
+            and 1 <= n_agents <= 8 and not obs2d.requires_grad and act.shape[1] == n_agents
+            and W.shape[1] == obs2d.shape[1] + n_agents + n_agents * act.shape[2])
+
+
 def critic_replayed_supported(critic, obs2d, act2d, n_agents):
     a = critic.args
     W = critic.fc1.weight
@@ -701,6 +760,14 @@ def critic_replayed_supported(critic, obs2d, act2d, n_agents):
 
 
 class CriticTail:
+    @staticmethod
+    def apply_policy(obs2d, act, critic):
+        ln = critic.layernorm if critic.args.layernorm else None
+        return _CriticPolicyFn.apply(obs2d, act, critic.fc1.weight, critic.fc1.bias,
+                                     None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                     critic.fc2.weight, critic.fc2.bias, critic.fc3.weight, critic.fc3.bias,
+                                     1e-5 if ln is None else ln.eps)
+
     @staticmethod
     def apply_replayed(obs2d, act2d, n_agents, critic):
         ln = critic.layernorm if critic.args.layernorm else None

@@ -324,7 +324,11 @@ class PGTrainer(object):
             loss = policy_loss
             if self.entr > 0:
                 means, log_stds = dist_params
-                entropy = normal_entropy(means, log_stds.exp())
+                # fixed policy std (model.py:121-123): the entropy bonus of trainer.py:47-57 is a constant that
+                # Model.policy hands over with its log-std view — no elementwise kernels over [batch, n, act] per sub-update
+                entropy = getattr(log_stds, "_flex_entropy", None)
+                if entropy is None:
+                    entropy = normal_entropy(means, log_stds.exp())
                 loss = loss - self.entr * entropy
                 stat["mean_train_entropy"] = entropy.detach()
         else:
