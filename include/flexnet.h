@@ -68,10 +68,44 @@ typedef struct {
     const int64_t* cursor;     /* device [1] or NULL */
     int64_t obs_slab_stride;
     int64_t hid_slab_stride;
+    /* Training forward (variant 0): what the backward pass of rnn_agent.py:25-33 needs, stored on the way ([rows, 64]
+     * each, all six or none): fc1's raw output (before bias / id column / LayerNorm), the GRU input x = ReLU(LayerNorm(.)),
+     * the gates r, z, n and the hidden part of the candidate, W_hn h + b_hn.  flexnet_gru_backward consumes them. */
+    float* save_z1;
+    float* save_x;
+    float* save_r;
+    float* save_z;
+    float* save_n;
+    float* save_hn;
 } FlexActorArgs;
 
 /* rnn_agent.py:25-33 + model.py:102-116 for all rows. */
 int flexnet_actor_forward(const FlexActorArgs* args, void* stream);
+
+/* Pointwise backward of the GRUCell and of fc2's input (rnn_agent.py:30-32) for a training batch, from the tensors
+ * flexnet_actor_forward saved: with h' = (1 - z) n + z h,
+ *     dh'  = d_means @ fc2_w (+ d_hidden_out)
+ *     dn~  = dh' (1 - z) (1 - n^2)      dz~ = dh' (h - n) z (1 - z)      dr~ = dn~ (W_hn h + b_hn) r (1 - r)
+ *     d_gi = [dr~ | dz~ | dn~]  [rows, 192]   (gradient of W_ih x + b_ih; W_hh's first 128 rows see the same dr~, dz~)
+ *     d_gh = [dr~ | dz~ | dn~ r] [rows, 192]  (gradient of W_hh h + b_hh)
+ * Weight and bias gradients are then flexnet_wgrad products of d_gi / d_gh with x and h; dx = d_gi @ W_ih.  The previous
+ * hidden state takes no gradient (a replayed tensor). */
+typedef struct {
+    int32_t rows;
+    int32_t act_dim;           /* <= FLEXNET_MAX_ACT */
+    const float* d_means;      /* [rows, act_dim] */
+    const float* d_hidden;     /* [rows, 64] or NULL: gradient arriving at the new hidden state directly */
+    const float* fc2_w;        /* [act_dim, 64] */
+    const float* r;            /* saved by flexnet_actor_forward */
+    const float* z;
+    const float* n;
+    const float* hn;
+    const float* h_prev;       /* [rows, 64] */
+    float* d_gi;               /* out [rows, 192] */
+    float* d_gh;               /* out [rows, 192] */
+} FlexGruBwdArgs;
+
+int flexnet_gru_backward(const FlexGruBwdArgs* args, void* stream);
 
 /* The centralised critic (madrl/critics/mlp_critic.py:5-34: fc1 -> LayerNorm -> ReLU -> fc2 -> ReLU -> fc3) AFTER its
  * first layer: the caller forms fc1's output z1 from column blocks (maddpg.py:38-54 repeats every agent's observation

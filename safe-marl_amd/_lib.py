@@ -61,7 +61,7 @@ SYMBOLS = (
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss",
-    "flexnet_scaled_sum", "flexnet_gather_rows",
+    "flexnet_scaled_sum", "flexnet_gather_rows", "flexnet_gru_backward",
 )
 
 class FlexActorArgs(C.Structure):
@@ -72,7 +72,14 @@ class FlexActorArgs(C.Structure):
                                           "b_hh", "fc2_w", "fc2_b", "means", "hidden_out", "noise", "action", "env_action")] + \
                [("std", C.c_float), ("action_low", C.c_float), ("action_high", C.c_float), ("pad1", C.c_float),
                 ("rng_state", C.c_void_p), ("cursor", C.c_void_p), ("obs_slab_stride", C.c_int64),
-                ("hid_slab_stride", C.c_int64)]
+                ("hid_slab_stride", C.c_int64)] + \
+               [(k, C.c_void_p) for k in ("save_z1", "save_x", "save_r", "save_z", "save_n", "save_hn")]
+
+
+class FlexGruBwdArgs(C.Structure):
+    """include/flexnet.h"""
+    _fields_ = [("rows", C.c_int32), ("act_dim", C.c_int32)] + \
+               [(k, C.c_void_p) for k in ("d_means", "d_hidden", "fc2_w", "r", "z", "n", "hn", "h_prev", "d_gi", "d_gh")]
 
 
 class FlexCriticTailArgs(C.Structure):
@@ -198,6 +205,8 @@ def load():
     lib.flexnet_rollout_pack.restype = C.c_int
     lib.flexnet_gather_rows.argtypes = [C.POINTER(FlexGatherArgs), vp]
     lib.flexnet_gather_rows.restype = C.c_int
+    lib.flexnet_gru_backward.argtypes = [C.POINTER(FlexGruBwdArgs), vp]
+    lib.flexnet_gru_backward.restype = C.c_int
     lib.flexenv_set_step_counter.argtypes = [vp, vp, C.c_int64]
     lib.flexenv_set_step_counter.restype = C.c_int
     lib.flexenv_set_obs_ring.argtypes = [vp, vp, C.c_int64, i32]

@@ -415,6 +415,16 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
                     robs, nt < n_tiles && e < nq ? nxoff + 32 * e : -1, 0, 0));
         }
         ASTAMP(2);
+        const bool save = a.save_z1 != nullptr && r0 + rb < a.rows;       // training forward: keep what the backward needs
+        const int64_t so = (int64_t)(r0 + rb) * HID + 4 * hf;              // + 32 u + 8 q: this lane's float4 groups
+        if (save) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(a.save_z1 + so + 32 * u + 8 * q) =
+                        make_float4(z1[u][4 * q], z1[u][4 * q + 1], z1[u][4 * q + 2], z1[u][4 * q + 3]);
+        }
         // ---- + bias (+ id column), LayerNorm over the row's 64 units (32 here, 32 in the other half), ReLU ----
         const int ag = row % na;
         const float* w1id_l = s.w1id + ag * HID + 4 * hf;
@@ -460,6 +470,14 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int i = 0; i < 16; ++i) z1[u][i] = fmaxf(z1[u][i], 0.0f);     // x = ReLU(LayerNorm(z1))
+        if (save) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(a.save_x + so + 32 * u + 8 * q) =
+                        make_float4(z1[u][4 * q], z1[u][4 * q + 1], z1[u][4 * q + 2], z1[u][4 * q + 3]);
+        }
         f32x16 hnew[2];
         ASTAMP(3);
 #pragma unroll
@@ -504,6 +522,17 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
                 const float zg = fast_sigmoid(az[i]);
                 const float ng = fast_tanh(gin[i] + rg * ghn[i]);
                 hnew[t][i] = ng + zg * (hv[t][i] - ng);                  // (1 - z) n + z h
+                ar[i] = rg; az[i] = zg; gin[i] = ng;                     // the gates themselves, for the stores below
+            }
+            if (save) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t at = so + 32 * t + 8 * q;
+                    *reinterpret_cast<float4*>(a.save_r + at) = make_float4(ar[4 * q], ar[4 * q + 1], ar[4 * q + 2], ar[4 * q + 3]);
+                    *reinterpret_cast<float4*>(a.save_z + at) = make_float4(az[4 * q], az[4 * q + 1], az[4 * q + 2], az[4 * q + 3]);
+                    *reinterpret_cast<float4*>(a.save_n + at) = make_float4(gin[4 * q], gin[4 * q + 1], gin[4 * q + 2], gin[4 * q + 3]);
+                    *reinterpret_cast<float4*>(a.save_hn + at) = make_float4(ghn[4 * q], ghn[4 * q + 1], ghn[4 * q + 2], ghn[4 * q + 3]);
+                }
             }
             if (r0 + rb < a.rows) {
 #pragma unroll
@@ -558,6 +587,12 @@ extern "C" int flexnet_actor_forward(const FlexActorArgs* a, void* stream) {
         return FLEXNET_EUNSUPPORTED;
     if ((int64_t)a->rows * a->obs_dim * 4 >= 0x7ffffff0ll) return FLEXNET_EUNSUPPORTED;   // observations are addressed with 32-bit byte offsets
     if (a->cursor && (a->obs_slab_stride < (int64_t)a->rows * a->obs_dim || a->hid_slab_stride < 0)) return FLEXNET_EINVAL;
+    {
+        const int saves = (a->save_z1 != nullptr) + (a->save_x != nullptr) + (a->save_r != nullptr) + (a->save_z != nullptr) +
+                          (a->save_n != nullptr) + (a->save_hn != nullptr);
+        if (saves != 0 && saves != 6) return FLEXNET_EINVAL;                  // all six or none
+        if (saves && a->variant != 0) return FLEXNET_EUNSUPPORTED;
+    }
     const int cus = flex_cu_count();                      // one block per CU owns that CU's LDS
     if (cus < 1) return FLEXNET_EHIP;
     if (a->variant == 0) {

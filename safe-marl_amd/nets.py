@@ -80,6 +80,16 @@ class RNNAgent(nn.Module):
         configuration is outside what csrc/lnrelu.hip covers (the caller concatenates the ids and calls forward)."""
         o = obs.shape[1]
         W = self.fc1.weight
+        hx0 = hidden_state.reshape(-1, self.args.hid_size)
+        if actor_train_supported(self, obs, n_agents, agent_id) and not hx0.requires_grad and hx0.dtype == th.float32:
+            # one autograd node: fused matrix-core forward, hand-written backward (csrc/actor.hip, gru.hip, wgrad.hip, lnrelu.hip)
+            ln = self.layernorm if self.args.layernorm else None
+            r = self.rnn
+            means, h = _ActorTrainFn.apply(obs, hx0, n_agents, bool(agent_id), W, self.fc1.bias,
+                                           None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                           1e-5 if ln is None else ln.eps, r.weight_ih, r.weight_hh, r.bias_ih, r.bias_hh,
+                                           self.fc2.weight, self.fc2.bias)
+            return means, None, h
         if not (obs.is_cuda and obs.dtype == th.float32 and lnrelu_supported(self, n_agents) and _FUSED_GRU is not None
                 and W.shape[1] == o + (n_agents if agent_id else 0) and obs.shape[0] % n_agents == 0):
             if obs.is_cuda:
@@ -445,6 +455,106 @@ class _LnReluFn(th.autograd.Function):
                    "flexnet_lnrelu_backward")
         return (dz, None if bias is None else small[2], None if id_cols is None else small[3:],
                 None if ln_w is None else small[0], None if ln_w is None else small[1], None, None)
+
+
+class _ActorTrainFn(th.autograd.Function):
+    """The whole actor of rnn_agent.py:25-33 for an update batch as ONE autograd node: the forward is the fused
+    matrix-core kernel of csrc/actor.hip (fc1 -> LayerNorm -> ReLU -> GRUCell -> fc2 chained through registers) with its
+    `save_*` outputs, the backward is csrc/gru.hip (gate gradients, fc2's input gradient folded in), csrc/wgrad.hip for
+    every weight / bias gradient, one library GEMM for dx and csrc/lnrelu.hip for the first layer's epilogue.  Replaces
+    the composition fc1 GEMM + lnrelu + two gate GEMMs + ATen's pointwise GRU cell + fc2 GEMM (309 us forward at 163 840
+    rows) and their autograd backward.  Observations and the previous hidden state are replayed tensors: no gradient."""
+
+    @staticmethod
+    def forward(ctx, obs, hidden, n_agents, agent_id, fc1_w, fc1_b, ln_w, ln_b, ln_eps, w_ih, w_hh, b_ih, b_hh, fc2_w, fc2_b):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        rows, o = obs.shape
+        act_dim = fc2_w.shape[0]
+        obs, hidden = obs.contiguous(), hidden.contiguous()
+        means = th.empty(rows, act_dim, dtype=th.float32, device=obs.device)
+        hid_out = th.empty(rows, 64, dtype=th.float32, device=obs.device)
+        saved = th.empty(6, rows, 64, dtype=th.float32, device=obs.device)          # z1 | x | r | z | n | hn
+        a = _lib.FlexActorArgs()
+        a.rows, a.n_agents, a.obs_dim, a.act_dim = rows, n_agents, o, act_dim
+        a.agent_id, a.layernorm, a.ln_eps, a.variant = int(bool(agent_id)), int(ln_w is not None), float(ln_eps), 0
+        for name, t in (("obs", obs), ("hidden_in", hidden), ("fc1_w", fc1_w), ("fc1_b", fc1_b), ("ln_w", ln_w), ("ln_b", ln_b),
+                        ("w_ih", w_ih), ("w_hh", w_hh), ("b_ih", b_ih), ("b_hh", b_hh), ("fc2_w", fc2_w), ("fc2_b", fc2_b),
+                        ("means", means), ("hidden_out", hid_out), ("save_z1", saved[0]), ("save_x", saved[1]),
+                        ("save_r", saved[2]), ("save_z", saved[3]), ("save_n", saved[4]), ("save_hn", saved[5])):
+            if t is not None:
+                if not t.is_contiguous():
+                    raise ValueError(f"actor training forward: {name} must be contiguous")
+                setattr(a, name, t.data_ptr())
+        _lib.check(lib.flexnet_actor_forward(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_actor_forward")
+        ctx.n_agents, ctx.agent_id, ctx.ln_eps = n_agents, bool(agent_id), float(ln_eps)
+        ctx.save_for_backward(obs, hidden, hid_out, saved, fc1_w, fc1_b, ln_w, ln_b, w_ih, fc2_w)
+        ctx.mark_non_differentiable(hid_out)          # the new hidden state is returned for the caller's bookkeeping only
+        return means, hid_out
+
+    @staticmethod
+    def backward(ctx, d_means, _d_hid):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        obs, hidden, hid_out, saved, fc1_w, fc1_b, ln_w, ln_b, w_ih, fc2_w = ctx.saved_tensors
+        rows, o = obs.shape
+        n, dev = ctx.n_agents, obs.device
+        stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
+        d_means = d_means.contiguous()
+        d_gi = th.empty(rows, 192, dtype=th.float32, device=dev)
+        d_gh = th.empty(rows, 192, dtype=th.float32, device=dev)
+        g = _lib.FlexGruBwdArgs()
+        g.rows, g.act_dim = rows, fc2_w.shape[0]
+        g.d_means, g.fc2_w = d_means.data_ptr(), fc2_w.data_ptr()
+        g.r, g.z, g.n, g.hn = saved[2].data_ptr(), saved[3].data_ptr(), saved[4].data_ptr(), saved[5].data_ptr()
+        g.h_prev, g.d_gi, g.d_gh = hidden.data_ptr(), d_gi.data_ptr(), d_gh.data_ptr()
+        _lib.check(lib.flexnet_gru_backward(C.byref(g), stream), "flexnet_gru_backward")
+        # fc2: weight and bias gradients from one pass over d_means
+        d_fc2_b = th.empty(fc2_w.shape[0], dtype=th.float32, device=dev)
+        d_fc2_w = tall_wgrad(d_means, hid_out, colsum=d_fc2_b)
+        # GRUCell: W_ih sees [dr | dz | dn], W_hh sees [dr | dz | dn r]; the biases are the column sums of the same passes
+        d_b_ih = th.empty(192, dtype=th.float32, device=dev)
+        d_w_ih = tall_wgrad(d_gi, saved[1], colsum=d_b_ih)
+        d_b_hh = th.empty(192, dtype=th.float32, device=dev)
+        d_w_hh = tall_wgrad(d_gh, hidden, colsum=d_b_hh)
+        # first layer: dx = d_gi @ W_ih, then the LayerNorm / ReLU / bias / id-column epilogue backward and fc1's weight
+        dx = d_gi @ w_ih
+        dz = th.empty(rows, 64, dtype=th.float32, device=dev)
+        small = th.empty(3 + n, 64, dtype=th.float32, device=dev)
+        id_cols = fc1_w[:, o:].t().contiguous() if ctx.agent_id else None
+        la = _lnrelu_args(saved[0], fc1_b, id_cols, ln_w, ln_b, ctx.ln_eps, n)
+        la.dout, la.dz = dx.data_ptr(), dz.data_ptr()
+        if ln_w is not None:
+            la.d_ln_w, la.d_ln_b = small[0].data_ptr(), small[1].data_ptr()
+        la.d_bias = small[2].data_ptr()
+        if id_cols is not None:
+            la.d_id = small[3:].data_ptr()
+        if dev not in _LNRELU_WS:
+            _LNRELU_WS[dev] = th.empty(_lib.FLEXNET_LNRELU_WS_FLOATS, dtype=th.float32, device=dev)
+        ws = _LNRELU_WS[dev]
+        la.workspace, la.workspace_floats = ws.data_ptr(), ws.numel()
+        _lib.check(lib.flexnet_lnrelu_backward(C.byref(la), stream), "flexnet_lnrelu_backward")
+        d_fc1_w = th.empty_like(fc1_w)
+        tall_wgrad(dz, obs, out=d_fc1_w[:, :o])
+        if ctx.agent_id:
+            d_fc1_w[:, o:] = small[3:].t()
+        has_ln = ln_w is not None
+        return (None, None, None, None, d_fc1_w, small[2], small[0] if has_ln else None, small[1] if has_ln else None, None,
+                d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_fc2_w, d_fc2_b)
+
+
+def actor_train_supported(agent, obs, n_agents, agent_id):
+    """What the fused training pass covers: the RNN agent at 64 hidden units with ReLU, fp32 GPU rows >= WGRAD_MIN_ROWS."""
+    a = agent.args
+    W = agent.fc1.weight
+    return (isinstance(agent, RNNAgent) and obs.is_cuda and obs.dtype == th.float32 and obs.dim() == 2
+            and a.hid_size == 64 and a.hid_activation == "relu" and obs.shape[1] <= 144 and 1 <= n_agents <= 8
+            and a.action_dim <= 8 and obs.shape[0] >= WGRAD_MIN_ROWS and obs.shape[0] % n_agents == 0
+            and W.shape[1] == obs.shape[1] + (n_agents if agent_id else 0) and not obs.requires_grad
+            and getattr(agent, "fused_training", True) and getattr(agent, "fused_epilogue", True))
 
 
 def lnrelu_supported(agent, n_agents):
