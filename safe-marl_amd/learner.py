@@ -708,7 +708,7 @@ class MADDPG(Model):
             advantages = self.value(state, actions_pol, critic_frozen=(need == "policy")).view(-1, self.n_)
             if self.args.normalize_advantages:
                 advantages = self.batchnorm(advantages)
-            policy_loss = mean_all(-advantages)
+            policy_loss = mean_all(advantages, sign=-1.0)
         if need in ("both", "value"):
             with th.no_grad():          # the bootstrap target carries no gradient (maddpg.py:110,115: .detach())
                 _, next_actions, _, _, _ = self.get_actions(next_state, status="train", exploration=False,
@@ -806,7 +806,7 @@ class MATD3(MADDPG):
             advantages = self.value(state, actions_pol)[:b].reshape(-1, self.n_)          # first head only
             if self.args.normalize_advantages:
                 advantages = self.batchnorm(advantages)
-            policy_loss = mean_all(-advantages)
+            policy_loss = mean_all(advantages, sign=-1.0)
         if need in ("both", "value"):
             with th.no_grad():
                 _, next_actions, _, _, _ = self.get_actions(next_state, status="train", exploration=True,

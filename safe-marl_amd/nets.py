@@ -492,6 +492,7 @@ class _ActorTrainFn(th.autograd.Function):
         ctx.n_agents, ctx.agent_id, ctx.ln_eps = n_agents, bool(agent_id), float(ln_eps)
         ctx.save_for_backward(obs, hidden, hid_out, saved, fc1_w, fc1_b, ln_w, ln_b, w_ih, fc2_w)
         ctx.mark_non_differentiable(hid_out)          # the new hidden state is returned for the caller's bookkeeping only
+        ctx.set_materialize_grads(False)              # ... and must not cost a [rows, 64] zero fill per backward
         return means, hid_out
 
     @staticmethod

@@ -44,6 +44,7 @@ class PGTrainer(object):
         self._update_graphs = {}
         self._update_graphs_alt = {}            # second static batch per kind for the pipelined update event
         self._side_stream = None
+        self._entr_terms = {}
         self.pipeline_updates = True            # replay_event: gather window j + 1 while sub-update j runs
         self.entr = args.entr
         self.world = fdist.world_size()
@@ -329,7 +330,12 @@ class PGTrainer(object):
                 entropy = getattr(log_stds, "_flex_entropy", None)
                 if entropy is None:
                     entropy = normal_entropy(means, log_stds.exp())
-                loss = loss - self.entr * entropy
+                    loss = loss - self.entr * entropy
+                else:                                      # the constant's product with entr, formed once per device
+                    key = (entropy.device, float(self.entr))
+                    if key not in self._entr_terms:
+                        self._entr_terms[key] = (self.entr * entropy).detach()
+                    loss = loss - self._entr_terms[key]
                 stat["mean_train_entropy"] = entropy.detach()
         else:
             loss = value_loss

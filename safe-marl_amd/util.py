@@ -61,7 +61,7 @@ class _MeanAllFn(th.autograd.Function):
     the gradient of a mean is a broadcast."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, sign):
         import ctypes as C
         from . import _lib
         lib = _lib.load()
@@ -71,26 +71,26 @@ class _MeanAllFn(th.autograd.Function):
             _SUM_WS[x.device] = th.empty(_lib.FLEXNET_SUM_WS_FLOATS // 2, dtype=th.float64, device=x.device)
         ws = _SUM_WS[x.device]
         a = _lib.FlexSumArgs()
-        a.n, a.scale = flat.numel(), 1.0 / flat.numel()
+        a.n, a.scale = flat.numel(), sign / flat.numel()
         a.x, a.out, a.workspace, a.workspace_floats = flat.data_ptr(), out.data_ptr(), ws.data_ptr(), 2 * ws.numel()
         _lib.check(lib.flexnet_scaled_sum(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_scaled_sum")
-        ctx.shape, ctx.n = x.shape, flat.numel()
+        ctx.shape, ctx.scale = x.shape, sign / flat.numel()
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return (g / ctx.n).expand(ctx.shape)
+        return (g * ctx.scale).expand(ctx.shape), None
 
 
-def mean_all(x):
+def mean_all(x, sign=1.0):
     """``x.mean()`` over all elements.  On the GPU it is this project's fixed-order sum kernel: with this PyTorch-ROCm
     build a full ``mean`` / ``sum``-to-scalar of ~10^5+ elements is a multi-block kernel with a global semaphore, and such
     a scalar captured into a HIP graph came back stale or as a partial sum on replay (seen on the reported losses; the
     gradient of a mean is a broadcast and was never affected).  Same value up to fp32 summation order (the kernel
     accumulates in fp64), same gradient."""
     if x.is_cuda and x.dtype == th.float32 and x.numel() >= 1:
-        return _MeanAllFn.apply(x)
-    return x.mean()
+        return _MeanAllFn.apply(x, float(sign))      # ``sign`` = -1: mean(-x) without a negation pass over x
+    return x.mean() if sign == 1.0 else (sign * x).mean()
 
 
 def normal_entropy(mean, std):
