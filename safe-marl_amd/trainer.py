@@ -15,6 +15,7 @@ Built for device-resident data instead of per-step Python objects:
 from __future__ import annotations
 
 import logging
+import os
 
 import numpy as np
 import torch as th
@@ -45,7 +46,9 @@ class PGTrainer(object):
         self._update_graphs_alt = {}            # second static batch per kind for the pipelined update event
         self._side_stream = None
         self._entr_terms = {}
-        self.pipeline_updates = True            # replay_event: gather window j + 1 while sub-update j runs
+        # replay_event: gather window j + 1 while sub-update j runs (FLEX_NO_PIPELINE=1: one after the other, for profiles
+        # in which every kernel's duration is its own)
+        self.pipeline_updates = os.environ.get("FLEX_NO_PIPELINE") != "1"
         self.entr = args.entr
         self.world = fdist.world_size()
 
