@@ -46,9 +46,11 @@ class PGTrainer(object):
         self._update_graphs_alt = {}            # second static batch per kind for the pipelined update event
         self._side_stream = None
         self._entr_terms = {}
-        # replay_event: gather window j + 1 while sub-update j runs (FLEX_NO_PIPELINE=1: one after the other, for profiles
-        # in which every kernel's duration is its own)
-        self.pipeline_updates = os.environ.get("FLEX_NO_PIPELINE") != "1"
+        # replay_event can gather window j + 1 on a side stream while sub-update j runs.  Measured (bench.py training legs,
+        # A/B on one box): the overlapped gather fights the replay for HBM — its own duration stretches from 49 to ~140 us,
+        # the replay's first GEMM from 31 to ~48 us — and the loop is 4-8 % SLOWER than gather-then-replay, so it is off
+        # unless asked for (FLEX_PIPELINE_UPDATES=1); bit-identical either way (tests/test_update_graph_gpu.py)
+        self.pipeline_updates = os.environ.get("FLEX_PIPELINE_UPDATES") == "1"
         self.entr = args.entr
         self.world = fdist.world_size()
 

@@ -130,7 +130,7 @@ def test_pipelined_update_event_equals_one_at_a_time_sub_updates():
     time: same windows (same NumPy stream), same graphs — weights, optimiser-visible buffers and statistics bit-identical
     over three events at the headline batch."""
     a, b = _trainer(True, 4096), _trainer(True, 4096)
-    b.pipeline_updates = False
+    a.pipeline_updates, b.pipeline_updates = True, False
     for ev in range(3):
         stats = []
         for tr in (a, b):

@@ -13,10 +13,3 @@ for k in train upd; do
 done
 tail -2 gpurun_out/prof_train_$tag.log
 tail -4 gpurun_out/prof_upd_$tag.log
-# the same training run with the update pipeline off: every kernel's duration is its own (no overlap with the gather)
-cd /tmp
-FLEX_NO_PIPELINE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trainnp_$tag -- python3 $R/examples/train_maddpg.py --alg maddpg --envs 4096 --episodes 8 > $R/gpurun_out/prof_trainnp_$tag.log 2>&1
-cd $R
-f=$(find gpurun_out/prof_trainnp_$tag -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cp "$f" gpurun_out/${tag}_trainnp_kernel_stats.csv
-tail -1 gpurun_out/prof_trainnp_$tag.log | cut -c1-300
