@@ -200,3 +200,45 @@ def test_graph_rollout_equals_eager_rollout_in_what_it_stores(net, series_small)
         assert np.isfinite(stats[True][k]) and np.isfinite(stats[False][k])
         assert abs(stats[True][k] - stats[False][k]) < 0.25 * abs(stats[False][k]) + 1e-3   # same policy, different noise draws
     assert stats[True]["mean_train_solver_failed"] == 0.0
+
+
+def test_trainer_run_with_evaluation_keeps_the_ring_consistent(net, series_small):
+    """train_agent.py:125-128 for 22 episodes on the vectorised env: trainer.run = train_process (+ evaluation at episodes 0
+    and 19, trainer.py:122-124).  Evaluation steps the env behind the rollout graph's back, so the next episode starts from
+    a hard reset and leaves a gap slab in the replay ring; every other episode continues the stream.  The ring's host mirror
+    must agree with the device cursor throughout, windows must stay sampleable, statistics finite."""
+    import torch as th
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.trainer import PGTrainer
+    th.manual_seed(0)
+    np.random.seed(0)
+    n = 512
+    env = VecFlexProvisionEnv({}, n, net=net, series=series_small, seed=11, warm_start=True)
+    args = _args(behaviour_update_freq=60, target_update_freq=120, eval_freq=20)
+    trainer = PGTrainer(args, MADDPG, env, None, replay_capacity=n * 96 * 3)
+    buf = trainer.replay_buffer
+    hard_resets = []
+    for ep in range(22):
+        stat = {}
+        k0 = buf.k if buf.slab_mode else 0
+        trainer.run(stat, ep)
+        assert np.isfinite(stat["mean_train_reward"]) and stat["mean_train_solver_failed"] == 0.0
+        if ep in (0, 19):
+            assert np.isfinite(stat["mean_test_reward"])
+        # device cells == host mirror; after an evaluation the env's own cell (cursor[1]) has run ahead — evaluation stepped
+        # the env without the rollout graph — and is re-seated by the hard reset that starts the next episode
+        cells = buf.cursor.tolist()
+        assert cells[0] == buf.k % buf.slabs and (cells[1] == cells[0] or ep in (0, 19)), (ep, cells, buf.k)
+        hard_resets.append(buf.k - k0 - 95)                                    # 1: a gap slab was spent, 0: the stream continued
+    # episode 0 starts the stream (no gap), episodes 1 and 20 follow an evaluation (gap), all others continue
+    assert hard_resets[1] == 1 and hard_resets[20] == 1 and sum(hard_resets[2:20]) == 0 and hard_resets[21] == 0, hard_resets
+    assert trainer.steps == 22 * 95 and trainer.graph_updates and set(trainer._update_graphs) == {"value", "policy"}
+    live_gaps = [g for g in buf.gaps if g >= buf.first]
+    assert len(buf.buffer) == n * (buf.k - buf.first - len(live_gaps))
+    for _ in range(200):                                                        # windows never span a gap
+        bs = trainer.effective_batch_size()
+        slot = buf.sample_slot(bs)
+        j0, j1 = slot // n, (slot + bs - 1) // n
+        assert buf.first <= j0 and j1 < buf.k and not any(j0 <= g <= j1 for g in live_gaps)
+    assert np.isfinite(float(stat["mean_train_value_loss"])) and np.isfinite(float(stat["mean_train_policy_loss"]))
