@@ -188,6 +188,14 @@ def load():
         raise FlexLibraryError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    # the binary must be THIS tree's: its build stamp is the content hash of sources, headers and flags (build.py)
+    if os.environ.get("FLEX_SKIP_DIGEST_CHECK") != "1":
+        from . import build as _build
+        built, want = _build.built_digest(), _build.source_digest()
+        if built != want:
+            raise FlexLibraryError(
+                f"{LIB_PATH} was built from other sources (stamp {str(built)[:16]}, tree {want[:16]}): run "
+                "`python -c 'import __graft_entry__ as g; g.build()'`")
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as exc:  # pragma: no cover - depends on the box

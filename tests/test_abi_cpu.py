@@ -95,3 +95,14 @@ def test_no_product_module_touches_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "flexenv_oracle" not in text, f
+
+
+def test_a_stale_library_is_refused(monkeypatch):
+    """The .so travels to the GPU box as a built artefact: loading one whose build stamp (content hash of sources, headers
+    and flags) does not match the tree raises instead of running old kernels under new host code."""
+    from safe_marl_amd import _lib, build
+    build.build()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "source_digest", lambda: "0" * 64)
+    with pytest.raises(_lib.FlexLibraryError, match="other sources"):
+        _lib.load()

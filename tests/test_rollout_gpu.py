@@ -330,3 +330,36 @@ def test_ring_wraps_and_windows_stay_consecutive():
         torch.cuda.synchronize()
         for k, dst in plan_out.items():
             assert torch.equal(dst, getattr(w, k).reshape(dst.shape)), (slot, k)
+
+
+def test_unbounded_actions_take_the_general_body():
+    """util.py:66-74: without action_enforcebound the exploration is mean + noise (no tanh); the actor kernel's epilogue is
+    tanh(mean + std * noise), so RolloutGraph.fast must be off and the general body (select_action itself) runs."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.learner import MADDPG, RolloutGraph
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.replay_buffer import TransReplayBuffer
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.util import convert
+    net = create_network()
+    series = make_synthetic_series(net, n_days=30)
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="maddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4, action_enforcebound=False)
+    torch.manual_seed(1)
+    m = MADDPG(convert(alg)).cuda()
+    env = VecFlexProvisionEnv({}, 32, net=net, series=series, seed=5, warm_start=True)
+    rg = RolloutGraph(m, env, TransReplayBuffer(32 * 8, device="cuda"))
+    assert not rg.fast and not rg.ring_active and not rg.plain
+    rg.start_episode(env.reset())
+    obs = rg.obs.clone()
+    torch.manual_seed(9)
+    rg.step()
+    torch.manual_seed(9)
+    with torch.no_grad():
+        means, _, _ = m.policy(obs, last_hid=torch.zeros(32, 5, 64, device="cuda"))
+        from torch.distributions.normal import Normal
+        want = means + Normal(torch.zeros_like(means), torch.ones_like(means)).rsample()     # util.py:66-74, fixed std of 1
+    got = rg.last_transition().action
+    assert (got - want).abs().max().item() < 1e-5 and got.abs().max().item() > 1.0          # really unbounded
