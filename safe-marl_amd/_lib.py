@@ -188,14 +188,20 @@ def load():
         raise FlexLibraryError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
-    # the binary must be THIS tree's: its build stamp is the content hash of sources, headers and flags (build.py)
+    # the binary must be THIS tree's: its build stamp is the content hash of sources, headers and flags (build.py).  A
+    # binary from other sources is rebuilt in place when the compiler is here (it is on the GPU box), refused otherwise.
     if os.environ.get("FLEX_SKIP_DIGEST_CHECK") != "1":
         from . import build as _build
         built, want = _build.built_digest(), _build.source_digest()
         if built != want:
-            raise FlexLibraryError(
-                f"{LIB_PATH} was built from other sources (stamp {str(built)[:16]}, tree {want[:16]}): run "
-                "`python -c 'import __graft_entry__ as g; g.build()'`")
+            if os.path.exists(_build.HIPCC):
+                import warnings
+                warnings.warn(f"{LIB_NAME} was built from other sources (stamp {str(built)[:16]}, tree {want[:16]}): rebuilding")
+                _build.build(force=True)
+            else:
+                raise FlexLibraryError(
+                    f"{LIB_PATH} was built from other sources (stamp {str(built)[:16]}, tree {want[:16]}) and there is no "
+                    f"{_build.HIPCC} to rebuild it: run `python -c 'import __graft_entry__ as g; g.build()'`")
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as exc:  # pragma: no cover - depends on the box

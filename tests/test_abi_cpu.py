@@ -97,12 +97,20 @@ def test_no_product_module_touches_the_oracle():
                 assert "flexenv_oracle" not in text, f
 
 
-def test_a_stale_library_is_refused(monkeypatch):
+def test_a_stale_library_is_rebuilt_or_refused(monkeypatch):
     """The .so travels to the GPU box as a built artefact: loading one whose build stamp (content hash of sources, headers
-    and flags) does not match the tree raises instead of running old kernels under new host code."""
+    and flags) does not match the tree rebuilds it when hipcc is there and raises otherwise — never old kernels under new
+    host code."""
     from safe_marl_amd import _lib, build
     build.build()
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(build, "source_digest", lambda: "0" * 64)
+    monkeypatch.setattr(build, "HIPCC", "/nonexistent/hipcc")
     with pytest.raises(_lib.FlexLibraryError, match="other sources"):
         _lib.load()
+    calls = []
+    monkeypatch.setattr(build, "HIPCC", "/bin/true")
+    monkeypatch.setattr(build, "build", lambda force=False, verbose=False: calls.append(force))
+    with pytest.warns(UserWarning, match="rebuilding"):
+        _lib.load()
+    assert calls == [True]
