@@ -19,8 +19,8 @@ import numpy as np
 import torch as th
 import torch.nn as nn
 
-from .nets import (WGRAD_MIN_ROWS, CriticTail, MLPAgent, MLPCritic, RNNAgent, critic_policy_supported, critic_replayed_supported,
-                   critic_tail_supported, fused_actor_forward, td_loss, td_loss_supported, wide_batch_linear,
+from .nets import (WGRAD_MIN_ROWS, CriticTail, expand_agents, MLPAgent, MLPCritic, RNNAgent, critic_policy_supported, critic_replayed_supported,
+                   critic_tail_supported, fused_actor_forward, tall_linear, td_loss, td_loss_supported, wide_batch_linear,
                    batchnorm_stats_supported, batchnorm_update_running_stats)
 from .replay_buffer import Transition
 from .util import prep_obs, scale_action, select_action, translate_action, mean_all
@@ -745,7 +745,9 @@ class MATD3(MADDPG):
     value loss averaged over the twins (matd3.py:148).  Bug-compatible with the reference's action selection, which
     sums the policy means over the AGENT axis before sampling (matd3.py:92-97)."""
 
-    graph_safe_updates = False      # value / policy losses go through PyTorch reductions: eager sub-updates
+    # since round 2 the GPU path of both losses reduces only through this project's fixed-order kernels (twin critic
+    # nodes, flexnet_td_loss, flexnet_scaled_sum, pointwise agent sums): sub-updates replay as HIP graphs like MADDPG's
+    graph_safe_updates = True
 
     def construct_value_net(self):
         """matd3.py:18-27: the MADDPG critic input plus the twin flag."""
@@ -753,18 +755,39 @@ class MATD3(MADDPG):
         count = 1 if self.args.shared_params else self.n_
         self.value_dicts = nn.ModuleList([MLPCritic(input_shape, 1, self.args) for _ in range(count)])
 
-    def value(self, obs, act, critic_frozen=False):
-        """matd3.py:33-86: returns cat([Q1, Q2], dim=0) of shape [2b, n, 1].  Same column-block evaluation as
-        MADDPG.value; the twin flag only adds fc1.weight's last column to the second head's pre-activation."""
+    def value(self, obs, act, critic_frozen=False, first_head_only=False):
+        """matd3.py:33-86: returns cat([Q1, Q2], dim=0) of shape [2b, n, 1] (``first_head_only``: Q1 alone, [b, n, 1] — all
+        the policy loss reads, matd3.py:121).  Same column-block evaluation as MADDPG.value; the twin flag only adds
+        fc1.weight's last column to the second head's pre-activation."""
         if not self.args.shared_params:
             raise NotImplementedError("MATD3 is built for shared_params (default.yaml:26)")
         b, n, o, a = obs.size(0), self.n_, self.obs_dim, self.act_dim
         net = self.value_dicts[0]
         W, bias = net.fc1.weight, net.fc1.bias
+        obs_cols = obs.reshape(b, n * o)
+        if self.args.agent_id and obs.is_cuda:
+            # GPU paths as single autograd nodes / fused tails (nets.py), every reduction in this project's kernels
+            if (critic_frozen and first_head_only and act.requires_grad and th.is_grad_enabled()
+                    and critic_policy_supported(net, obs_cols, act, n)):
+                return CriticTail.apply_policy(obs_cols, act, net).view(b, n, 1)
+            act_cols = act.detach().reshape(b, n * a)
+            if (not act.requires_grad and th.is_grad_enabled() and W.requires_grad
+                    and critic_replayed_supported(net, obs_cols, act_cols, n)):
+                q1 = CriticTail.apply_replayed(obs_cols, act_cols, n, net)
+                q2 = CriticTail.apply_replayed(obs_cols, act_cols, n, net, twin=True)
+                return th.cat([q1.view(b, n, 1), q2.view(b, n, 1)], dim=0)
+            if not th.is_grad_enabled() and critic_tail_supported(net, obs_cols.new_empty(1, self.hid_dim)):
+                off = n * o
+                shared = th.addmm(bias, obs_cols, W[:, :off].t())
+                shared.addmm_(act_cols, W[:, off + n:off + n + n * a].t())
+                ids = W[:, off:off + n].t()
+                q1 = CriticTail.apply_composed(shared, ids, net)
+                q2 = CriticTail.apply_composed(shared, ids + W[:, -1], net)
+                return th.cat([q1.view(b, n, 1), q2.view(b, n, 1)], dim=0)
         act_det = act.detach()
         own = act - act_det
         off = n * o
-        h = wide_batch_linear(obs.reshape(b, n * o), W[:, :off]) + bias
+        h = wide_batch_linear(obs_cols, W[:, :off]) + bias
         h = h.unsqueeze(1).expand(b, n, -1)
         if self.args.agent_id:
             h = h + W[:, off:off + n].t().unsqueeze(0)
@@ -775,6 +798,8 @@ class MATD3(MADDPG):
             h = h + th.einsum("bia,hia->bih", own, W_act.view(-1, n, a))
         flag = W[:, off + n * a]                                            # column of the 0/1 twin flag
         v1, _ = net.forward_from_hidden(h.reshape(b * n, -1), need_hidden=False)
+        if first_head_only:
+            return v1.view(b, n, 1)
         v2, _ = net.forward_from_hidden((h + flag).reshape(b * n, -1), need_hidden=False)
         return th.cat([v1.view(b, n, 1), v2.view(b, n, 1)], dim=0)
 
@@ -791,19 +816,34 @@ class MATD3(MADDPG):
             means_, log_stds_ = means, log_stds
         actions, log_prob_a = select_action(self.args, means_, status=status, exploration=exploration,
                                             info={"clip": clip, "log_std": log_stds_})
-        restore_actions = (1.0 - (avail == 0).float()) * actions
+        if getattr(actions_avail, "_flex_const", None) == 1.0 and actions.size(1) == 1:
+            # every action available (env:721-730): the mask is 1; the agent-summed action goes to every agent
+            restore_actions = expand_agents(actions, self.n_)
+        else:
+            restore_actions = (1.0 - (avail == 0).float()) * actions
         return actions, restore_actions, log_prob_a, (means, log_stds), hiddens
 
     def get_loss(self, batch, need="both"):
-        """matd3.py:113-149."""
-        state, actions, _, _, _, rewards, next_state, done, _, actions_avail, last_hids, hids = self.unpack_data(batch)
+        """matd3.py:113-149.  ``need`` = "value" / "policy" (what a sub-update asks for) on the GPU: the reward BatchNorm
+        and both TD terms through flexnet_td_loss (batch statistics once, running statistics moved once), the policy loss
+        through the first head's action-gradient node; "both" is the reference's call."""
+        on_gpu = (isinstance(batch.reward, th.Tensor) and batch.reward.is_cuda and self.fused_inference
+                  and th.is_grad_enabled() and need in ("value", "policy") and self.args.reward_normalisation
+                  and batchnorm_stats_supported(self.batchnorm, batch.reward))
+        state, actions, _, _, _, rewards, next_state, done, _, actions_avail, last_hids, hids = \
+            self.unpack_data(batch, normalise_reward=not on_gpu)
         b = state.size(0)
         policy_loss = value_loss = action_out = None
         if need in ("both", "policy"):
+            if on_gpu:                      # the policy loss never reads the reward: the module's bookkeeping only
+                batchnorm_update_running_stats(self.batchnorm, rewards)
             _, actions_pol, _, action_out, _ = self.get_actions(state, status="train", exploration=False,
                                                                 actions_avail=actions_avail, target=False,
                                                                 last_hid=last_hids)
-            advantages = self.value(state, actions_pol)[:b].reshape(-1, self.n_)          # first head only
+            if on_gpu:
+                advantages = self.value(state, actions_pol, critic_frozen=True, first_head_only=True).reshape(-1, self.n_)
+            else:
+                advantages = self.value(state, actions_pol)[:b].reshape(-1, self.n_)      # first head only
             if self.args.normalize_advantages:
                 advantages = self.batchnorm(advantages)
             policy_loss = mean_all(advantages, sign=-1.0)
@@ -816,9 +856,19 @@ class MATD3(MADDPG):
                 next_min = th.min(nxt[:b].reshape(-1, self.n_), nxt[b:].reshape(-1, self.n_))
             cur = self.value(state, actions)
             values1, values2 = cur[:b].reshape(-1, self.n_), cur[b:].reshape(-1, self.n_)
-            returns = rewards + self.args.gamma * (1 - done) * next_min
-            assert returns.size() == values1.size() == values2.size()
-            value_loss = 0.5 * (mean_all((returns - values1).pow(2)) + mean_all((returns - values2).pow(2)))
+            if on_gpu and td_loss_supported(values1, next_min, rewards, done, self.batchnorm):
+                # matd3.py:141-148: both twins against the same normalised return; the second term must not move the
+                # BatchNorm's running statistics again
+                value_loss = 0.5 * (td_loss(values1, next_min, rewards, done, self.args.gamma, self.batchnorm)
+                                    + td_loss(values2, next_min, rewards, done, self.args.gamma, self.batchnorm,
+                                              update_stats=False))
+            else:
+                if on_gpu:                  # the raw reward was handed on: normalise it here
+                    with th.no_grad():
+                        rewards = self.batchnorm(rewards.contiguous())
+                returns = rewards + self.args.gamma * (1 - done) * next_min
+                assert returns.size() == values1.size() == values2.size()
+                value_loss = 0.5 * (mean_all((returns - values1).pow(2)) + mean_all((returns - values2).pow(2)))
         return policy_loss, value_loss, action_out
 
 
@@ -827,7 +877,7 @@ class IDDPG(MADDPG):
     independent critics Q_i(o_i, a_i) on the agent's own observation and action (plus its one-hot id), the same
     DDPG losses as MADDPG, and the agent-summed action selection it shares with MATD3 (iddpg.py:66-71)."""
 
-    graph_safe_updates = False      # value / policy losses go through PyTorch reductions: eager sub-updates
+    graph_safe_updates = True       # as MATD3: no PyTorch reduction is left on the GPU path of either loss
 
     def construct_value_net(self):
         """iddpg.py:17-26"""
@@ -843,7 +893,14 @@ class IDDPG(MADDPG):
             obs = th.cat((obs, ids), dim=-1)
         inputs = th.cat((obs, act), dim=-1)
         if self.args.shared_params:
-            v, _ = self.value_dicts[0](inputs.reshape(b * self.n_, -1), None)
+            net = self.value_dicts[0]
+            rows = inputs.reshape(b * self.n_, -1)
+            if rows.is_cuda and rows.shape[0] >= WGRAD_MIN_ROWS:
+                # update batches: first layer with the batch-reduced weight gradient of csrc/wgrad.hip (the library's
+                # dW = dY^T X over 163 840 rows took 0.8 ms), the rest of the critic in the fused tail kernels
+                v, _ = net.forward_from_hidden(tall_linear(rows, net.fc1.weight, net.fc1.bias), need_hidden=False)
+            else:
+                v, _ = net(rows, None)
             return v.view(b, self.n_, -1)
         return th.stack([net(inputs[:, i, :], None)[0] for i, net in enumerate(self.value_dicts)], dim=1)
 
@@ -857,7 +914,10 @@ class IDDPG(MADDPG):
             means_, log_stds_ = means, log_stds
         actions, log_prob_a = select_action(self.args, means_, status=status, exploration=exploration,
                                             info={"log_std": log_stds_})
-        restore_actions = (1.0 - (actions_avail.to(means.device) == 0).float()) * actions
+        if getattr(actions_avail, "_flex_const", None) == 1.0 and actions.size(1) == 1:
+            restore_actions = expand_agents(actions, self.n_)       # every action available: the mask is 1
+        else:
+            restore_actions = (1.0 - (actions_avail.to(means.device) == 0).float()) * actions
         return actions, restore_actions, log_prob_a, (means, log_stds), hiddens
 
 

@@ -315,7 +315,7 @@ class _TdLossFn(th.autograd.Function):
     updated in place as its own forward would."""
 
     @staticmethod
-    def forward(ctx, q, next_q, reward, done, gamma, bn):
+    def forward(ctx, q, next_q, reward, done, gamma, bn, update_stats=True):
         import ctypes as C
         from . import _lib
         lib = _lib.load()
@@ -334,7 +334,7 @@ class _TdLossFn(th.autograd.Function):
             a.bn_eps, a.bn_momentum = float(bn.eps), float(bn.momentum)
             if bn.affine:
                 a.bn_weight, a.bn_bias = bn.weight.data_ptr(), bn.bias.data_ptr()
-            if bn.track_running_stats:
+            if bn.track_running_stats and update_stats:
                 a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
                 a.num_batches_tracked = bn.num_batches_tracked.data_ptr()
         a.dq, a.loss = dq.data_ptr(), loss.data_ptr()
@@ -347,7 +347,7 @@ class _TdLossFn(th.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss):
         (dq,) = ctx.saved_tensors
-        return (dq * grad_loss).view(ctx.q_shape), None, None, None, None, None
+        return (dq * grad_loss).view(ctx.q_shape), None, None, None, None, None, None
 
 
 def td_loss_supported(q, next_q, reward, done, bn):
@@ -391,8 +391,10 @@ def batchnorm_stats_supported(bn, x):
                 and bn.num_features == x.shape[1] and bn.running_mean.dtype == th.float32)
 
 
-def td_loss(q, next_q, reward, done, gamma, bn=None):
-    return _TdLossFn.apply(q, next_q, reward, done, gamma, bn)
+def td_loss(q, next_q, reward, done, gamma, bn=None, update_stats=True):
+    """``update_stats=False``: the same batch-statistics normalisation without moving the module's running statistics
+    (a second loss term on the same normalised reward, matd3.py:141-148)."""
+    return _TdLossFn.apply(q, next_q, reward, done, gamma, bn, update_stats)
 
 
 _LNRELU_WS = {}
@@ -743,14 +745,17 @@ class _CriticReplayedFn(th.autograd.Function):
     adds, plus a separate bias reduction."""
 
     @staticmethod
-    def forward(ctx, obs2d, act2d, n_agents, W, bias, ln_w, ln_b, w2, b2, w3, b3, eps):
+    def forward(ctx, obs2d, act2d, n_agents, W, bias, ln_w, ln_b, w2, b2, w3, b3, eps, twin=False):
         import ctypes as C
         from . import _lib
         lib = _lib.load()
         no, na_ = obs2d.shape[1], act2d.shape[1]
         shared = th.addmm(bias, obs2d, W[:, :no].t())
         shared.addmm_(act2d, W[:, no + n_agents:no + n_agents + na_].t())
-        id_cols = W[:, no:no + n_agents].t().contiguous()
+        # twin (matd3.py:64-67): the second head is the same network with the trailing 0/1 input flag set — fc1's last
+        # column joins every agent's id column
+        id_cols = (W[:, no:no + n_agents] + W[:, -1:]).t().contiguous() if twin else W[:, no:no + n_agents].t().contiguous()
+        ctx.twin = bool(twin)
         rows = shared.shape[0] * n_agents
         q = th.empty(rows, 1, dtype=th.float32, device=shared.device)
         args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, eps)
@@ -796,9 +801,37 @@ class _CriticReplayedFn(th.autograd.Function):
         tall_wgrad(d_shared, act2d, out=dW[:, no + n:no + n + na_])
         if W.shape[1] > no + n + na_:
             dW[:, no + n + na_:] = 0.0
+            if ctx.twin:                 # the flag column sees every agent's row: the sum of the id-column gradients
+                tot = d_id[0]
+                for i in range(1, n):
+                    tot = tot + d_id[i]      # (n - 1 pointwise adds: no ATen reduction in a captured graph)
+                dW[:, -1] = tot
         has_ln = ln_w is not None
         return (None, None, None, dW, d_bias, (d_g if has_ln else None), (d_b if has_ln else None), d_w2, d_b2, d_w3, d_b3,
-                None)
+                None, None)
+
+
+class _ExpandAgentsFn(th.autograd.Function):
+    """x [b, 1, a] -> [b, n, a] (the agent-summed action of matd3.py:92-97 / iddpg.py:66-71 handed to every agent); the
+    backward sums over the agent axis with n - 1 pointwise adds instead of ATen's reduce_kernel (a captured HIP graph
+    must not hold one)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return x.expand(-1, n, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        parts = g.unbind(1)
+        tot = parts[0]
+        for p in parts[1:]:
+            tot = tot + p
+        return tot.unsqueeze(1), None
+
+
+def expand_agents(x, n):
+    return _ExpandAgentsFn.apply(x, n) if x.requires_grad else x.expand(-1, n, -1)
 
 
 class _CriticPolicyFn(th.autograd.Function):
@@ -857,7 +890,8 @@ def critic_policy_supported(critic, obs2d, act, n_agents):
     return (obs2d.is_cuda and obs2d.dtype == th.float32 and act.dtype == th.float32 and act.dim() == 3 and a.hid_size == 64
             and a.hid_activation == "relu" and critic.fc3.out_features == 1 and getattr(critic, "fused_tail", True)
             and 1 <= n_agents <= 8 and not obs2d.requires_grad and act.shape[1] == n_agents
-            and W.shape[1] == obs2d.shape[1] + n_agents + n_agents * act.shape[2])
+            and W.shape[1] in (obs2d.shape[1] + n_agents + n_agents * act.shape[2],
+                               obs2d.shape[1] + n_agents + n_agents * act.shape[2] + 1))      # + MATD3's twin flag column
 
 
 def critic_replayed_supported(critic, obs2d, act2d, n_agents):
@@ -866,7 +900,8 @@ def critic_replayed_supported(critic, obs2d, act2d, n_agents):
     return (obs2d.is_cuda and obs2d.dtype == th.float32 and act2d.dtype == th.float32 and a.hid_size == 64
             and a.hid_activation == "relu" and critic.fc3.out_features == 1 and getattr(critic, "fused_tail", True)
             and 1 <= n_agents <= 8 and not obs2d.requires_grad and not act2d.requires_grad
-            and obs2d.shape[0] >= WGRAD_MIN_ROWS and W.shape[1] == obs2d.shape[1] + n_agents + act2d.shape[1]
+            and obs2d.shape[0] >= WGRAD_MIN_ROWS and W.shape[1] in (obs2d.shape[1] + n_agents + act2d.shape[1],
+                                                                    obs2d.shape[1] + n_agents + act2d.shape[1] + 1)
             and all(x.dim() == 2 and x.stride(1) == 1 and x.shape[1] <= x.stride(0) < (1 << 24) for x in (obs2d, act2d)))
 
 
@@ -880,12 +915,12 @@ class CriticTail:
                                      1e-5 if ln is None else ln.eps)
 
     @staticmethod
-    def apply_replayed(obs2d, act2d, n_agents, critic):
+    def apply_replayed(obs2d, act2d, n_agents, critic, twin=False):
         ln = critic.layernorm if critic.args.layernorm else None
         return _CriticReplayedFn.apply(obs2d, act2d, n_agents, critic.fc1.weight, critic.fc1.bias,
                                        None if ln is None else ln.weight, None if ln is None else ln.bias,
                                        critic.fc2.weight, critic.fc2.bias, critic.fc3.weight, critic.fc3.bias,
-                                       1e-5 if ln is None else ln.eps)
+                                       1e-5 if ln is None else ln.eps, twin)
 
     @staticmethod
     def apply_composed(shared, id_cols, critic):

@@ -10,24 +10,25 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _trainer(graph_updates, n_envs=256):
+def _trainer(graph_updates, n_envs=256, alg="maddpg"):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
     from train_maddpg import DEFAULT_ALG_ARGS
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
-    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd import learner
     from safe_marl_amd.network import create_network
     from safe_marl_amd.series import make_synthetic_series
     from safe_marl_amd.trainer import PGTrainer
     from safe_marl_amd.util import convert
     net = create_network()
     series = make_synthetic_series(net, n_days=30)
-    alg = dict(DEFAULT_ALG_ARGS)
-    alg.update(alg="maddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4, behaviour_update_freq=10 ** 9,
+    cls = {"maddpg": learner.MADDPG, "matd3": learner.MATD3, "iddpg": learner.IDDPG}[alg]
+    name, alg = alg, dict(DEFAULT_ALG_ARGS)
+    alg.update(alg=name, agent_num=5, obs_size=144, state_size=110, action_dim=4, behaviour_update_freq=10 ** 9,
                target_update_freq=10 ** 9)
     torch.manual_seed(7)
     np.random.seed(7)
     env = VecFlexProvisionEnv({}, n_envs, net=net, series=series, seed=3, warm_start=True)
-    tr = PGTrainer(convert(alg), MADDPG, env, None, replay_capacity=n_envs * 96 * 2, graph_updates=graph_updates)
+    tr = PGTrainer(convert(alg), cls, env, None, replay_capacity=n_envs * 96 * 2, graph_updates=graph_updates)
     tr.behaviour_net.train_process({}, tr)                       # fill the replay (no updates: huge update period)
     return tr
 
@@ -143,3 +144,40 @@ def test_pipelined_update_event_equals_one_at_a_time_sub_updates():
         for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
             assert torch.equal(va, vb), (ev, ka)
     assert set(a._update_graphs_alt) == {"value"} and not b._update_graphs_alt      # the double buffer really was used
+
+
+@pytest.mark.parametrize("alg", ["matd3", "iddpg"])
+def test_matd3_and_iddpg_sub_updates_replay_as_graphs(alg, monkeypatch):
+    """Round 2: the GPU path of MATD3's and IDDPG's losses reduces only through this project's kernels (twin critic nodes,
+    flexnet_td_loss, pointwise agent sums), so their sub-updates are captured like MADDPG's.  The capture-time audit
+    accepts both bodies; the policy sub-update (no random draw inside) replays bit-identically to the eager step; the value
+    sub-update (MATD3 draws its target-smoothing noise inside, matd3.py:136-138) moves the critic and stays finite."""
+    monkeypatch.setenv("FLEX_GRAPH_AUDIT", "1")
+    a, b = _trainer(True, 256, alg), _trainer(False, 256, alg)
+    for ka, kb in zip(a.behaviour_net.state_dict().values(), b.behaviour_net.state_dict().values()):
+        assert torch.equal(ka, kb)
+    for which in ("policy", "policy"):
+        stats = []
+        for tr in (a, b):
+            np.random.seed(5)
+            st = {}
+            tr.policy_replay_process(st)
+            torch.cuda.synchronize()
+            stats.append({k: float(v) for k, v in st.items()})
+        assert stats[0] == stats[1], stats
+        for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
+            assert torch.equal(va, vb), (alg, ka)
+    before = {k: v.clone() for k, v in a.behaviour_net.value_dicts.state_dict().items()}
+    for _ in range(3):
+        st = {}
+        np.random.seed(6)
+        a.value_replay_process(st)
+    torch.cuda.synchronize()
+    assert a.graph_updates and set(a._update_graphs) == {"value", "policy"} and not b._update_graphs
+    assert np.isfinite(float(st["mean_train_value_loss"])) and np.isfinite(float(st["mean_train_value_grad_norm"]))
+    after = a.behaviour_net.value_dicts.state_dict()
+    assert all(torch.isfinite(v).all() for v in after.values()) and any(not torch.equal(before[k], after[k]) for k in before)
+    for which in ("value", "policy"):
+        names = a.graph_audit[which]
+        assert not any("at::native::reduce_kernel" in k or "batch_norm" in k for k in names), (alg, which, names)
+        assert any("clip_rmsprop" in k for k in names)
