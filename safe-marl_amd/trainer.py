@@ -104,7 +104,8 @@ class PGTrainer(object):
             # Only models whose gradient path is free of PyTorch's multi-block reductions are replayed as graphs: with
             # this PyTorch-ROCm build such a reduction (global semaphore + memset) captured into a HIP graph can come back
             # stale or partial on replay.  MADDPG / SAFEMADDPG reduce with this project's fixed-order
-            # kernels and are checked against eager updates at full size; MATD3 / IDDPG keep eager sub-updates.
+            # kernels and are checked against eager updates at full size; so do MATD3 / IDDPG since round 2 (a model outside
+            # this package declares graph_safe_updates only if FLEX_GRAPH_AUDIT=1 accepts both of its sub-update bodies).
             return None
         bs = self.effective_batch_size()
         store = self._update_graphs if slot == 0 else self._update_graphs_alt
