@@ -319,9 +319,11 @@ def main():
     # launch per step); `--no-graph` keeps everything eager.
     graphs = {}
 
+    from safe_marl_amd.util import CAPTURE_MODE
+
     def capture(n_steps):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
             for j in range(n_steps):
                 one_step(j)
         return g

@@ -23,7 +23,7 @@ from .nets import (WGRAD_MIN_ROWS, CriticTail, expand_agents, MLPAgent, MLPCriti
                    critic_tail_supported, fused_actor_forward, tall_linear, td_loss, td_loss_supported, wide_batch_linear,
                    batchnorm_stats_supported, batchnorm_update_running_stats)
 from .replay_buffer import Transition
-from .util import prep_obs, scale_action, select_action, translate_action, mean_all
+from .util import CAPTURE_MODE, prep_obs, scale_action, select_action, translate_action, mean_all
 
 
 class RolloutGraph:
@@ -198,7 +198,7 @@ class RolloutGraph:
                 self.body()                      # warm-up on a side stream, as graph capture requires
         th.cuda.current_stream().wait_stream(side)
         g = th.cuda.CUDAGraph()
-        with th.cuda.graph(g):
+        with th.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
             self.body()
         self.graph = g
         self.buf.cursor.copy_(cursor0)

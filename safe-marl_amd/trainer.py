@@ -24,7 +24,7 @@ from torch.optim import RMSprop
 from . import dist as fdist
 from .optim import clip_and_step
 from .replay_buffer import TransReplayBuffer
-from .util import normal_entropy
+from .util import CAPTURE_MODE, normal_entropy
 
 train_logger = logging.getLogger("TrainLogger")
 
@@ -258,17 +258,19 @@ class PGTrainer(object):
             for _ in range(2):                        # warm-up off the capturing stream (allocator, rocBLAS handles)
                 self._sub_update(which, out, batch, fresh_leaves=True, flat=flat)
         th.cuda.current_stream().wait_stream(side)
+        if self.world > 1:
+            th.cuda.synchronize()                     # no collective of the warm-up is outstanding when capture begins
         graph = th.cuda.CUDAGraph()
         apply_graph = None
         out = {}
         if flat is None:
-            with th.cuda.graph(graph):
+            with th.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
                 self._sub_update(which, out, batch, fresh_leaves=True)
         else:
-            with th.cuda.graph(graph):
+            with th.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
                 self._loss_and_grads(which, out, batch, fresh_leaves=True, flat=flat)
             apply_graph = th.cuda.CUDAGraph()
-            with th.cuda.graph(apply_graph, pool=graph.pool()):
+            with th.cuda.graph(apply_graph, pool=graph.pool(), capture_error_mode=CAPTURE_MODE):
                 self._apply_grads(which, out, flat=flat)
         with th.no_grad():
             for k, v in self.behaviour_net.state_dict().items():

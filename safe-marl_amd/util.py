@@ -11,6 +11,11 @@ import torch as th
 from torch.distributions.normal import Normal
 
 
+# HIP-graph captures are thread-local: with more than one rank ProcessGroupNCCL's watchdog thread polls events of
+# outstanding collectives (hipEventQuery) from ITS thread, which the default "global" capture mode treats as an illegal
+# call during capture and fails the capture with.  Only this thread's calls are checked.
+CAPTURE_MODE = "thread_local"
+
 FALLBACKS = {}          # reason -> count: fused HIP paths that declined on GPU tensors (visible, never silent)
 
 
