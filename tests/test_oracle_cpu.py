@@ -142,3 +142,31 @@ def test_c_restatement_matches_python(net, series_small, base_loads):
             assert np.allclose(np.stack(e.get_obs()).astype(np.float32), cenv.obs[i], rtol=2e-7, atol=0)
         assert np.abs(cenv.V - np.stack([e.current_voltage for e in envs])).max() < 1e-11
         assert np.abs(cenv.E - np.stack([e.current_ess_energy for e in envs])).max() < 1e-13
+
+
+def test_reference_nlp_from_ipopts_default_start_lands_on_the_oracle_voltages(net, base_loads):
+    """oracle/pf_nlp_oracle.py: the reference's NLP (pf.py:39-94, verbatim) solved by SciPy's SLSQP from the start point
+    Pyomo + IPOPT would use (variables without initial values: 0, pushed 1e-2 inside the bounds) — base case, the
+    run_pf.py:37-54 injections, heavy load, reverse flow — reaches the oracle's voltages (the fixed point the HIP kernels
+    converge to), not a low-voltage root; trust-constr (a trust-region interior point, IPOPT's family) agrees on the base
+    case."""
+    from oracle.pf_nlp_oracle import ReferenceNLP
+    p, q = base_loads
+    rng = np.random.default_rng(4)
+    buses = net["bus_numbers"]
+    blds = [buses.index(b) for b in net["buildings"]]
+    run_pf_p = np.array([0.0 if net["bus_types"][b] == 1 else 0.1 for b in buses])
+    run_pf_p[blds] -= 0.05 + 0.075 - 0.005                                   # Pred, Ppv, -Pesc of run_pf.py:37-54
+    run_pf_q = np.array([0.0 if net["bus_types"][b] == 1 else 0.005 for b in buses])
+    cases = [("base", p, q), ("run_pf", run_pf_p, run_pf_q), ("heavy", 1.5 * p, 1.5 * q),
+             ("reverse", p - 0.25 * (np.arange(len(p)) > 0) * rng.uniform(0.5, 1.0, len(p)), 0.3 * q)]
+    for _ in range(6):
+        cases.append(("random", p * rng.uniform(0.0, 1.6, len(p)), q * rng.uniform(-0.5, 1.6, len(p))))
+    for name, P, Q in cases:
+        ref = pf_oracle.solve_pf(net, P, Q)
+        got = ReferenceNLP(net, P, Q).solve("SLSQP")
+        assert got["residual"] < 1e-10, (name, got["residual"])          # (SLSQP's own stop flag is not the criterion: feasibility is)
+        assert np.abs(got["vm"] - ref["vm"]).max() < 1e-9, (name, np.abs(got["vm"] - ref["vm"]).max())
+        assert got["vm"].min() > 0.8                                         # the high-voltage root
+    tc = ReferenceNLP(net, p, q).solve("trust-constr")
+    assert np.abs(tc["vm"] - pf_oracle.solve_pf(net, p, q)["vm"]).max() < 1e-8
