@@ -7,7 +7,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libflexenv_hip.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+# FLEX_LIB_OVERRIDE: a diagnostic build of the same ABI (kernel variants for A/B timing, tools/*_variants.sh); never set in
+# tests or in the product path — the digest check below is skipped for it
+LIB_PATH = os.environ.get("FLEX_LIB_OVERRIDE") or os.path.join(_HERE, LIB_NAME)
 
 FLEX_MAX_BUS = 64
 FLEX_MAX_AGENTS = 8
@@ -190,7 +192,7 @@ def load():
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
     # the binary must be THIS tree's: its build stamp is the content hash of sources, headers and flags (build.py).  A
     # binary from other sources is rebuilt in place when the compiler is here (it is on the GPU box), refused otherwise.
-    if os.environ.get("FLEX_SKIP_DIGEST_CHECK") != "1":
+    if os.environ.get("FLEX_SKIP_DIGEST_CHECK") != "1" and not os.environ.get("FLEX_LIB_OVERRIDE"):
         from . import build as _build
         built, want = _build.built_digest(), _build.source_digest()
         if built != want:
