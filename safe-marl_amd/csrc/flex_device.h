@@ -19,7 +19,9 @@
 #include "flexenv.h"
 
 #define FLEX_WAVE 64
+#ifndef FLEX_WAVES_PER_BLOCK
 #define FLEX_WAVES_PER_BLOCK 4
+#endif
 #define FLEX_JUMP_ROUNDS 6           // 2^6 >= FLEX_MAX_BUS
 
 // Network tables in group-local LANE order (device memory, one copy per handle).

@@ -440,7 +440,7 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
 // <= 128 VGPRs); in both cases the whole batch must be co-resident, otherwise the last blocks start only when the
 // first ones retire and the launch takes twice as long (measured: profiles/).
 template <int EPW, typename ObsT, typename ActT, int NA_CAP>
-__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, (EPW == 1 ? 4 : 2))
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, (EPW == 1 ? 16 : 8) / FLEX_WAVES_PER_BLOCK)
 void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restrict__ reward,
                       uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
                       ObsT* __restrict__ obs, int want_obs, int auto_reset) {
