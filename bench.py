@@ -292,10 +292,12 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        # a collective that cannot complete (a rank died) errors out after three minutes instead of hanging the job
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group(a.backend)
+            dist.init_process_group(a.backend, timeout=datetime.timedelta(seconds=180))
     coll_dev = dev if a.backend == "nccl" else torch.device("cpu")
 
     net = create_network()
@@ -372,21 +374,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # training legs first (every rank takes part: with N > 1 the gradient bucket goes through RCCL); the env-only legs
-    # below then run on a GPU that is already at its working clocks
-    train = None
-    if not a.no_train:
-        legs = [("maddpg", 5, N_ENVS)] if distributed else [("maddpg", 5, N_ENVS), ("maddpg", 3, N_ENVS), ("safemaddpg", 5, 2 * N_ENVS)]
-        train = []
-        for alg, n_ag, n_env in legs:
-            try:
-                train.append(train_leg(alg, n_ag, n_env, max(2, a.train_episodes), rank, local_rank, world, barrier,
-                                       max_over_ranks))
-            except Exception as exc:                  # a failed leg must not cost the headline line
-                if distributed:
-                    raise
-                train.append({"alg": alg, "n_agents": n_ag, "envs_per_gpu": n_env, "error": repr(exc)[:300]})
-
     run_steps(a.warmup)
 
     barrier()
@@ -435,6 +422,21 @@ def main():
     iters_mean = float(env.peek("PF_ITERS").float().mean().item())
     sweeps_mean = float(env.peek("PF_SWEEPS").float().mean().item())
     n_agents_env, n_bus_env, used_graph = env.n_agents, env.n_bus, bool(graphs)
+
+    # training legs LAST: the headline (which the scaling curve is computed from) is already measured if a leg fails; every
+    # rank takes part — with N > 1 the gradient bucket goes through RCCL — and a failure is recorded, not fatal
+    train = None
+    if not a.no_train:
+        legs = [("maddpg", 5, N_ENVS)] if distributed else [("maddpg", 5, N_ENVS), ("maddpg", 3, N_ENVS), ("safemaddpg", 5, 2 * N_ENVS)]
+        train = []
+        for alg, n_ag, n_env in legs:
+            try:
+                train.append(train_leg(alg, n_ag, n_env, max(2, a.train_episodes), rank, local_rank, world, barrier,
+                                       max_over_ranks))
+            except Exception as exc:                  # a failed leg must not cost the headline line
+                print(f"[bench] rank {rank}: training leg {alg}/{n_ag}/{n_env} failed: {exc!r}", file=sys.stderr)
+                train.append({"alg": alg, "n_agents": n_ag, "envs_per_gpu": n_env, "n_gpus": world, "error": repr(exc)[:300]})
+                break
 
     if rank == 0:
         total_env_steps = a.envs * world * a.steps
@@ -487,8 +489,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(net, series, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as exc:                       # a rank that failed its training leg is not waited for twice
+            print(f"[bench] rank {rank}: shutdown: {exc!r}", file=sys.stderr)
 
 
 if __name__ == "__main__":
