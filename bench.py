@@ -195,6 +195,63 @@ def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, m
     return out
 
 
+def learner_rooflines():
+    """The learner-side kernels against THEIR rooflines, timed live with HIP events on torch's current stream (the stream
+    these kernels are launched on): the fused actor forward on the matrix cores (exact fp32 MFMA, 157.3 TFLOP/s dense
+    peak, MI355X_MICROARCH.md) at the update batch and at the rollout batch, the batch-reduced weight gradient and the
+    replay-window gather against HBM (8 TB/s).  Algorithmic flops / bytes are stated per entry."""
+    import torch
+    from safe_marl_amd.nets import RNNAgent, fused_actor_forward, tall_wgrad
+    from safe_marl_amd.replay_buffer import TransReplayBuffer
+    from safe_marl_amd.util import convert
+    d = dict(TRAIN_ALG_ARGS)
+    d.update(agent_num=5, obs_size=144, action_dim=4)
+    agent = RNNAgent(149, convert(d)).cuda()
+
+    def timed(fn, n=100):
+        for _ in range(10):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3                       # seconds per launch
+
+    out = []
+    for b, what in ((32768, "update batch: bootstrap actions of a value sub-update"), (4096, "rollout batch: one vector step")):
+        obs = torch.randn(b, 5, 144, device="cuda")
+        hid = torch.randn(b, 5, 64, device="cuda")
+        with torch.no_grad():
+            t = timed(lambda: fused_actor_forward(agent, obs, hid, 5, True))
+        flops = 2.0 * b * 5 * (149 * 64 + 2 * 192 * 64 + 64 * 4)
+        out.append({"kernel": "actor_forward_mfma_kernel", "rows": b * 5, "what": what, "bound": "mfma", "dtype": "f32",
+                    "achieved": flops / t / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t / 1e12 / 157.3,
+                    "launch_us": t * 1e6})
+    k, m, n = 32768, 64, 720
+    dy, x = torch.randn(k, m, device="cuda"), torch.randn(k, n, device="cuda")
+    t = timed(lambda: tall_wgrad(dy, x))
+    out.append({"kernel": "wgrad_kernel<2,5> + reduce", "shape": [k, m, n], "what": "critic fc1 weight gradient dY^T X", "bound": "hbm",
+                "achieved": 4.0 * k * (m + n) / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": 4.0 * k * (m + n) / t / 1e9 / HBM_PEAK_GBS, "launch_us": t * 1e6,
+                "note": "algorithmic bytes = both operands once; the kernel sits at the HBM / fp32-MFMA balance point"})
+    N, bs = 4096, 32768
+    buf = TransReplayBuffer(N * 24, device="cuda")
+    buf.alloc_slabs(N, 5, 144, 4, 64)
+    buf.k, buf.first = 20, 0
+    win = torch.zeros(bs + N, 720, device="cuda")
+    hidw = torch.zeros(bs, 320, device="cuda")
+    plan = [("obs_ring", 0, None, 0, bs + N, win), ("hid_ring", 0, None, N, bs, hidw)]
+    t = timed(lambda: buf.gather(plan, 2 * N + 17))
+    moved = 4.0 * ((bs + N) * 720 + bs * 320)
+    out.append({"kernel": "gather_rows_kernel", "what": "replay window -> static batch of a value sub-update", "bound": "hbm",
+                "achieved": 2.0 * moved / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 2.0 * moved / t / 1e9 / HBM_PEAK_GBS,
+                "launch_us": t * 1e6, "note": "bytes read + written"})
+    return out
+
+
 def kernel_shares_child():
     """Child process (started before the parent touches the GPU): per-kernel GPU time of one MADDPG training episode
     (5 agents, 4096 envs) through torch.profiler; prints one JSON line."""
@@ -438,6 +495,13 @@ def main():
                 train.append({"alg": alg, "n_agents": n_ag, "envs_per_gpu": n_env, "n_gpus": world, "error": repr(exc)[:300]})
                 break
 
+    learner = None
+    if rank == 0 and not distributed and not a.no_train:
+        try:
+            learner = learner_rooflines()
+        except Exception as exc:
+            print(f"[bench] learner rooflines failed: {exc!r}", file=sys.stderr)
+
     if rank == 0:
         total_env_steps = a.envs * world * a.steps
         achieved = B_ALG_WITH_OBS * a.envs / (kern_ms * 1e-3) / 1e9
@@ -484,6 +548,7 @@ def main():
             "sustained": sustained,
             "train": train,
             "train_kernel_shares": shares,
+            "learner_rooflines": learner,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(net, series, a.cpu_seconds)
