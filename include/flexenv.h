@@ -150,6 +150,8 @@ int flexenv_reset(FlexEnv* env, const uint8_t* mask /*dev [N] or NULL*/, const R
                                   launch; its `obs` row then holds the FIRST observation of the new episode */
 #define FLEX_STEP_OBS_RING 2    /* `obs` is the BASE of the slab ring registered with flexenv_set_obs_ring: this launch writes its
                                   observations into slab (cursor[0] + 1) mod slabs, read on the device (replayable HIP graph) */
+#define FLEX_STEP_REPLAY_SINK 4 /* with FLEX_STEP_OBS_RING: the launch also files this step's transition in the consumer's slab ring
+                                  (flexenv_set_replay_sink) — no bookkeeping launch follows the step */
 int flexenv_step(FlexEnv* env, const void* actions, int32_t act_dtype,
                  double* reward /*dev [N]*/, uint8_t* done /*dev [N]*/,
                  double* info /*dev [N, FLEX_INFO_W] or NULL*/, uint8_t* failed /*dev [N] or NULL*/,
@@ -178,6 +180,25 @@ int flexenv_set_step_counter(FlexEnv* env, int64_t* counter, int64_t modulo);
  * `slab_stride` elements apart — the observation lands where the replay keeps it, once, and nothing copies it again.
  * slabs = 0 switches it off. */
 int flexenv_set_obs_ring(FlexEnv* env, const int64_t* cursor, int64_t slab_stride, int32_t slabs);
+/* Replay sink for FLEX_STEP_REPLAY_SINK (madrl/models/model.py:230-262 + utils/replay_buffer.py:23-27 inside the step
+ * launch): with p = the obs-ring cursor and p' = (p + 1) mod slabs, every environment e of the launch writes
+ *     small_ring[p][e]  = [policy_action[e] (act_w floats) | reward x n_agents | done | last_step = done]
+ *     hid_ring[p'][e]   = hid_new[e] * (1 - done)          (hid_w floats; the recurrent state the next step starts from)
+ *     acc[e][0..8]     += info[0..6], reward, solver_failed  (per-environment running sums, fp64: episode statistics)
+ * and one lane of the launch sets *cursor_out = p' and adds 1 to *aux_counter (either may be NULL).  The launch never
+ * reads cursor_out / aux_counter and never writes the obs-ring cursor, so it replays from a HIP graph next to a policy
+ * kernel that reads cursor_out and writes the obs-ring cursor.  All pointers are device memory owned by the caller. */
+typedef struct {
+    const float* policy_action; /* [N, act_w] */
+    const float* hid_new;       /* [N, hid_w], hid_w a multiple of 4, 16-byte aligned */
+    float* small_ring;          /* [slabs, N, small_w], small_w >= act_w + n_agents + 2 */
+    float* hid_ring;            /* [slabs, N, hid_w] */
+    double* acc;                /* [N, 10] */
+    int64_t* cursor_out;
+    int64_t* aux_counter;
+    int32_t act_w, hid_w, small_w, pad0;
+} FlexReplaySink;
+int flexenv_set_replay_sink(FlexEnv* env, const FlexReplaySink* sink /* NULL: off */);
 int32_t flexenv_obs_size(const FlexEnv* env);    /* 6*history, env:71 */
 int32_t flexenv_state_size(const FlexEnv* env);  /* env:72 */
 

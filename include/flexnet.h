@@ -68,6 +68,9 @@ typedef struct {
     const int64_t* cursor;     /* device [1] or NULL */
     int64_t obs_slab_stride;
     int64_t hid_slab_stride;
+    int64_t* cursor_out;       /* device [1] or NULL: one lane writes the slab index this launch read there (never read by
+                                  this launch) — the cell the environment's step launch takes its slab from when it files
+                                  the transition itself (FLEX_STEP_REPLAY_SINK, include/flexenv.h) */
     /* Training forward (variant 0): what the backward pass of rnn_agent.py:25-33 needs, stored on the way ([rows, 64]
      * each, all six or none): fc1's raw output (before bias / id column / LayerNorm), the GRU input x = ReLU(LayerNorm(.)),
      * the gates r, z, n and the hidden part of the candidate, W_hn h + b_hn.  flexnet_gru_backward consumes them. */

@@ -18,6 +18,7 @@ FLEX_INFO_W = 7
 FLEX_F64, FLEX_F32 = 0, 1
 FLEX_STEP_AUTORESET = 1
 FLEX_STEP_OBS_RING = 2
+FLEX_STEP_REPLAY_SINK = 4
 FLEX_SOLVER_TREE, FLEX_SOLVER_DENSE, FLEX_SOLVER_SWEEP = 0, 1, 2
 
 PEEK = dict(V=0, E=1, E_INIT=2, PRED=3, CH=4, DIS=5, QPV=6, PCT=7, CUMREW=8, STEPS=9, ROW=10, START=11,
@@ -48,6 +49,13 @@ class NetFix(C.Structure):
     ]
 
 
+class FlexReplaySink(C.Structure):
+    """include/flexenv.h"""
+    _fields_ = [(k, C.c_void_p) for k in ("policy_action", "hid_new", "small_ring", "hid_ring", "acc", "cursor_out",
+                                          "aux_counter")] + \
+               [(k, C.c_int32) for k in ("act_w", "hid_w", "small_w", "pad0")]
+
+
 class SeriesTab(C.Structure):
     _fields_ = [("table", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int32)]
 
@@ -60,7 +68,7 @@ class ResetSpec(C.Structure):
 # every symbol include/flexenv.h declares
 SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
-    "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_obs_size", "flexenv_state_size",
+    "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss",
     "flexnet_scaled_sum", "flexnet_gather_rows", "flexnet_gru_backward",
@@ -74,7 +82,7 @@ class FlexActorArgs(C.Structure):
                                           "b_hh", "fc2_w", "fc2_b", "means", "hidden_out", "noise", "action", "env_action")] + \
                [("std", C.c_float), ("action_low", C.c_float), ("action_high", C.c_float), ("pad1", C.c_float),
                 ("rng_state", C.c_void_p), ("cursor", C.c_void_p), ("obs_slab_stride", C.c_int64),
-                ("hid_slab_stride", C.c_int64)] + \
+                ("hid_slab_stride", C.c_int64), ("cursor_out", C.c_void_p)] + \
                [(k, C.c_void_p) for k in ("save_z1", "save_x", "save_r", "save_z", "save_n", "save_hn")]
 
 
@@ -227,6 +235,8 @@ def load():
     lib.flexenv_set_step_counter.restype = C.c_int
     lib.flexenv_set_obs_ring.argtypes = [vp, vp, C.c_int64, i32]
     lib.flexenv_set_obs_ring.restype = C.c_int
+    lib.flexenv_set_replay_sink.argtypes = [vp, C.POINTER(FlexReplaySink)]
+    lib.flexenv_set_replay_sink.restype = C.c_int
     lib.flexnet_wgrad.argtypes = [C.POINTER(FlexWgradArgs), vp]
     lib.flexnet_wgrad.restype = C.c_int
     lib.flexnet_clip_rmsprop.argtypes = [C.POINTER(FlexClipRmspropArgs), vp]

@@ -267,7 +267,11 @@ __device__ __forceinline__ void actor_noise4(uint64_t seed, uint64_t step, uint3
 __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActorArgs a) {
     __shared__ ActorLdsM s;
     ASTAMP(0);
-    if (a.cursor) { const int64_t p = *a.cursor; a.obs += p * a.obs_slab_stride; a.hidden_in += p * a.hid_slab_stride; }
+    if (a.cursor) {
+        const int64_t p = *a.cursor;
+        a.obs += p * a.obs_slab_stride; a.hidden_in += p * a.hid_slab_stride;
+        if (a.cursor_out && blockIdx.x == 0 && threadIdx.x == 0) *a.cursor_out = p;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rb = lane & 31, hf = lane >> 5;
     const int od = a.obs_dim, na = a.n_agents, ad = a.act_dim;
@@ -587,6 +591,7 @@ extern "C" int flexnet_actor_forward(const FlexActorArgs* a, void* stream) {
         return FLEXNET_EUNSUPPORTED;
     if ((int64_t)a->rows * a->obs_dim * 4 >= 0x7ffffff0ll) return FLEXNET_EUNSUPPORTED;   // observations are addressed with 32-bit byte offsets
     if (a->cursor && (a->obs_slab_stride < (int64_t)a->rows * a->obs_dim || a->hid_slab_stride < 0)) return FLEXNET_EINVAL;
+    if (a->cursor_out && (!a->cursor || a->variant != 0 || a->cursor_out == a->cursor)) return FLEXNET_EINVAL;
     {
         const int saves = (a->save_z1 != nullptr) + (a->save_x != nullptr) + (a->save_r != nullptr) + (a->save_z != nullptr) +
                           (a->save_n != nullptr) + (a->save_hn != nullptr);

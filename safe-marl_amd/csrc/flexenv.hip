@@ -42,6 +42,8 @@ struct FlexEnv {
     const int64_t* obs_cursor;   // FLEX_STEP_OBS_RING (flexenv_set_obs_ring)
     int64_t obs_slab_stride;
     int32_t obs_slabs;
+    FlexReplaySink sink;         // FLEX_STEP_REPLAY_SINK (flexenv_set_replay_sink)
+    int32_t has_sink;
 };
 
 // Diagnostic build only (-DFLEX_STAMPS): per-phase s_memtime stamps, lane 0 of each wave, written to a
@@ -75,6 +77,7 @@ struct KArgs {
     const int64_t* obs_cursor; // FLEX_STEP_OBS_RING: the observation goes to slab (obs_cursor[0] + 1) mod obs_slabs ...
     int64_t obs_slab_stride;   // ... of a ring whose slabs are this many elements apart
     int32_t obs_slabs;         // 0: `obs` is the output buffer itself
+    FlexReplaySink sink;       // FLEX_STEP_REPLAY_SINK: read only by the SINK instantiation's epilogue
 };
 
 __device__ __forceinline__ double load_action(const void* p, int dtype, int64_t i) {
@@ -439,7 +442,7 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
 // Residency: 4096 envs are 2048 wavefronts at EPW = 2 (2 per SIMD, <= 256 VGPRs) or 4096 at EPW = 1 (4 per SIMD,
 // <= 128 VGPRs); in both cases the whole batch must be co-resident, otherwise the last blocks start only when the
 // first ones retire and the launch takes twice as long (measured: profiles/).
-template <int EPW, typename ObsT, typename ActT, int NA_CAP>
+template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK = false>
 __global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, (EPW == 1 ? 16 : 8) / FLEX_WAVES_PER_BLOCK)
 void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restrict__ reward,
                       uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
@@ -605,6 +608,45 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
         st_at<int>(e_ienv, o_ienv + IF_ROW * 4, new_row);                              // env:340 reads row `steps` (A2)
         st_at<int>(e_ienv, o_ienv + IF_ITERS * 4, iters);
         st_at<int>(e_ienv, o_ienv + IF_SWEEPS * 4, sweeps);
+    }
+    if constexpr (SINK) {
+        // FLEX_STEP_REPLAY_SINK: this step's transition goes into the consumer's slab ring from here (include/flexenv.h) —
+        // the small record into the slab the policy read, the masked recurrent state into the next one, the episode
+        // statistics into per-environment running sums.  Everything is re-read from the kernarg segment: nothing of it
+        // is live across the solve.
+        const KArgs& zs = *relaunder_kernarg<KArgs>();
+        const FlexReplaySink& sk = zs.sink;
+        const int64_t p = *zs.obs_cursor;
+        const int64_t pn = p + 1 >= zs.obs_slabs ? 0 : p + 1;
+        const float keep = term ? 0.0f : 1.0f;
+        if (valid) {
+            typedef float sk_f4 __attribute__((ext_vector_type(4)));
+            const sk_f4* hs = reinterpret_cast<const sk_f4*>(sk.hid_new + (int64_t)env * sk.hid_w);
+            sk_f4* hd = reinterpret_cast<sk_f4*>(sk.hid_ring + (pn * zs.n_envs + env) * (int64_t)sk.hid_w);
+            const int h4 = sk.hid_w >> 2;
+            sk_f4 hv[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { const int i = ln.l + LW * r; if (i < h4) hv[r] = hs[i]; }
+            float* const sm = sk.small_ring + (p * zs.n_envs + env) * (int64_t)sk.small_w;
+            float av_ = 0.0f;
+            if (ln.l < sk.act_w) av_ = sk.policy_action[(int64_t)env * sk.act_w + ln.l];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { const int i = ln.l + LW * r; if (i < h4) hd[i] = hv[r] * keep; }
+            if (ln.l < sk.act_w) sm[ln.l] = av_;                                        // model.py:232
+            if (ln.l == 0) {
+                const int na_ = cz.n_agents;
+                for (int j = 0; j < na_; ++j) sm[sk.act_w + j] = (float)rwd;            // model.py:235: one reward, n copies
+                sm[sk.act_w + na_] = 1.0f - keep;
+                sm[sk.act_w + na_ + 1] = 1.0f - keep;
+                double* const ac = sk.acc + (int64_t)env * 10;
+                ac[0] += rw.reward; ac[1] += rw.revenue; ac[2] += rw.der; ac[3] += rw.ess; ac[4] += rw.disc; ac[5] += rw.vpen;
+                ac[6] += cum_before; ac[7] += rwd; ac[8] += ok ? 0.0 : 1.0;
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (sk.cursor_out) *sk.cursor_out = pn;
+            if (sk.aux_counter) *sk.aux_counter += 1;
+        }
     }
 #ifdef FLEX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -972,6 +1014,7 @@ static KArgs make_args(const FlexEnv* e) {
     k.inv_eta_ch = 1.0 / e->cfg.eta_ch; k.inv_eta_dis = 1.0 / e->cfg.eta_dis;
     k.step_counter = nullptr;                      // only flexenv_step hands these on
     k.step_modulo = 0; k.obs_cursor = nullptr; k.obs_slab_stride = 0; k.obs_slabs = 0;
+    memset(&k.sink, 0, sizeof(k.sink));
     return k;
 }
 
@@ -1050,6 +1093,18 @@ int flexenv_set_step_counter(FlexEnv* e, int64_t* counter, int64_t modulo) {
     e->step_modulo = modulo;
     return FLEX_OK;
 }
+int flexenv_set_replay_sink(FlexEnv* e, const FlexReplaySink* sink) {
+    if (!e) return FLEX_EINVAL;
+    if (!sink) { e->has_sink = 0; return FLEX_OK; }
+    if (!sink->policy_action || !sink->hid_new || !sink->small_ring || !sink->hid_ring || !sink->acc || sink->act_w < 1 ||
+        sink->act_w > FLEX_WAVE / 2 || sink->hid_w < 4 || (sink->hid_w & 3) || sink->hid_w > 3 * 4 * (FLEX_WAVE / 2) ||
+        sink->small_w < sink->act_w + e->cfg.n_agents + 2 ||
+        ((reinterpret_cast<uintptr_t>(sink->hid_new) | reinterpret_cast<uintptr_t>(sink->hid_ring)) & 15))
+        return FLEX_EINVAL;
+    e->sink = *sink;
+    e->has_sink = 1;
+    return FLEX_OK;
+}
 int flexenv_set_obs_ring(FlexEnv* e, const int64_t* cursor, int64_t slab_stride, int32_t slabs) {
     if (!e || slabs < 0 || (slabs > 0 && (!cursor || slabs < 2 || slab_stride < (int64_t)e->n_envs * e->cfg.n_agents * e->cfg.history * 6)))
         return FLEX_EINVAL;
@@ -1096,6 +1151,12 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
         if (!obs || e->obs_slabs < 2 || obs_dtype != FLEX_F32) return FLEX_EINVAL;      // ring registered, fp32 slabs
         k.obs_cursor = e->obs_cursor; k.obs_slab_stride = e->obs_slab_stride; k.obs_slabs = e->obs_slabs;
     }
+    const bool sink = (flags & FLEX_STEP_REPLAY_SINK) != 0;
+    if (sink) {
+        // the sink instantiation exists for the vectorised fp32 path: two environments per wavefront, fp32 actions
+        if (!(flags & FLEX_STEP_OBS_RING) || !e->has_sink || e->hnet.epw != 2 || act_dtype != FLEX_F32) return FLEX_EINVAL;
+        k.sink = e->sink;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int epw = e->hnet.epw;
     const dim3 grid = env_grid(e->n_envs, epw);
@@ -1113,7 +1174,14 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
         case 1: FLEX_LAUNCH_STEP(1, float, double); break;
         case 2: FLEX_LAUNCH_STEP(1, double, float); break;
         case 3: FLEX_LAUNCH_STEP(1, double, double); break;
-        case 4: FLEX_LAUNCH_STEP(2, float, float); break;
+        case 4:
+            if (sink) {
+                if (small_obs) hipLaunchKernelGGL((flex_step_kernel<2, float, float, FLEX_OBS_AGENTS_SMALL, true>), grid, env_block(), 0, s, k,
+                    (const float*)actions, reward, done, info, failed, (float*)obs, want, auto_reset);
+                else hipLaunchKernelGGL((flex_step_kernel<2, float, float, FLEX_OBS_AGENTS_LARGE, true>), grid, env_block(), 0, s, k,
+                    (const float*)actions, reward, done, info, failed, (float*)obs, want, auto_reset);
+            } else FLEX_LAUNCH_STEP(2, float, float);
+            break;
         case 5: FLEX_LAUNCH_STEP(2, float, double); break;
         case 6: FLEX_LAUNCH_STEP(2, double, float); break;
         default: FLEX_LAUNCH_STEP(2, double, double); break;

@@ -178,7 +178,7 @@ class VecFlexProvisionEnv:
                                           _ptr(self.failed), _stream()), "flexenv_reset")
         return out
 
-    def step(self, actions, obs_out=None, fuse_obs=False, auto_reset=False, obs_ring=None):
+    def step(self, actions, obs_out=None, fuse_obs=False, auto_reset=False, obs_ring=None, replay_sink=False):
         """auto_reset: environments that terminate in this step restart inside the same launch (their row of the
         fused observation is then the first observation of the new episode).  obs_ring: base tensor of the slab ring
         registered with set_obs_ring — the fused observation goes into the slab after the cursor instead of ``self.obs``."""
@@ -192,6 +192,8 @@ class VecFlexProvisionEnv:
         flags = _lib.FLEX_STEP_AUTORESET if auto_reset else 0
         if obs_ring is not None:
             out, flags = obs_ring, flags | _lib.FLEX_STEP_OBS_RING
+            if replay_sink:                  # the step files its own transition (set_replay_sink)
+                flags |= _lib.FLEX_STEP_REPLAY_SINK
         elif fuse_obs:
             out = self.obs if obs_out is None else obs_out
         _lib.check(self.lib.flexenv_step(self.handle, _ptr(actions), self._dtype_tag(actions), _ptr(self.reward),
@@ -218,6 +220,32 @@ class VecFlexProvisionEnv:
         _lib.check(self.lib.flexenv_set_obs_ring(self.handle, _ptr(cursor) if slabs else None, int(slab_stride), int(slabs)),
                    "flexenv_set_obs_ring")
         self._obs_cursor = cursor if slabs else None
+
+    def set_replay_sink(self, policy_action, hid_new, small_ring, hid_ring, acc, cursor_out=None, aux_counter=None):
+        """Register where ``step(..., obs_ring=..., replay_sink=True)`` files a step's transition (include/flexenv.h:
+        FlexReplaySink): the policy's action and new recurrent state are read from ``policy_action`` [N, act_w] /
+        ``hid_new`` [N, hid_w]; the small record goes to slab cursor of ``small_ring``, the masked recurrent state to slab
+        cursor + 1 of ``hid_ring``, the episode statistics to the per-environment running sums ``acc`` [N, 10] (fp64).
+        ``None`` for the first argument switches the sink off.  The tensors are kept alive with the env."""
+        if policy_action is None:
+            _lib.check(self.lib.flexenv_set_replay_sink(self.handle, None), "flexenv_set_replay_sink")
+            self._sink_keep = None
+            return
+        sk = _lib.FlexReplaySink()
+        N = self.n_envs
+        pa, hn = policy_action.view(N, -1), hid_new.view(N, -1)
+        for t in (pa, hn, small_ring, hid_ring, acc):
+            if not (t.is_cuda and t.is_contiguous()):
+                raise ValueError("replay sink tensors must be contiguous device tensors")
+        if acc.dtype != torch.float64 or acc.shape != (N, 10):
+            raise ValueError("acc must be a float64 [n_envs, 10] tensor")
+        sk.policy_action, sk.hid_new, sk.small_ring, sk.hid_ring, sk.acc = (pa.data_ptr(), hn.data_ptr(), small_ring.data_ptr(),
+                                                                             hid_ring.data_ptr(), acc.data_ptr())
+        sk.cursor_out = _ptr(cursor_out)
+        sk.aux_counter = _ptr(aux_counter)
+        sk.act_w, sk.hid_w, sk.small_w = pa.shape[1], hn.shape[1], small_ring.shape[-1]
+        _lib.check(self.lib.flexenv_set_replay_sink(self.handle, C.byref(sk)), "flexenv_set_replay_sink")
+        self._sink_keep = (policy_action, hid_new, small_ring, hid_ring, acc, cursor_out, aux_counter)
 
     def get_obs(self, obs_out=None):
         out = self.obs if obs_out is None else obs_out

@@ -47,12 +47,12 @@ class RolloutGraph:
             raise RuntimeError("replay buffer was allocated for another environment batch")
         self._obs = env.obs                         # [N, n, o]: written by the env kernel, read by the policy (tensor mode)
         self._hid = th.zeros(N, n, h, device=dev)
-        self.info_sum = th.zeros(env.info.shape[1], dtype=th.float64, device=dev)
-        self.rew_sum = th.zeros((), dtype=th.float64, device=dev)
-        self.fail_sum = th.zeros((), dtype=th.float64, device=dev)
+        self._info_sum = th.zeros(env.info.shape[1], dtype=th.float64, device=dev)
+        self._rew_sum = th.zeros((), dtype=th.float64, device=dev)
+        self._fail_sum = th.zeros((), dtype=th.float64, device=dev)
         self.std = float(model.args.fixed_policy_std)
         self.graph = None
-        self.torch_noise = False
+        self._torch_noise = False
         self.rng_state = th.zeros(2, dtype=th.int64, device=dev)           # [seed, step] of the actor kernel's noise stream
         self.rng_state[0] = int(th.randint(0, 2 ** 62, (1,)).item())
         self.plain = type(model).get_actions is MADDPG.get_actions and bool(model.args.action_enforcebound)
@@ -61,7 +61,7 @@ class RolloutGraph:
         self.safe = type(model).__name__ == "SAFEMADDPG"       # + the safety projection between policy and env
         # (the actor kernel's exploration epilogue IS tanh(mean + std * noise), util.py:57-64: without action_enforcebound
         # the reference adds unbounded noise, util.py:66-74, and the general body below runs select_action itself)
-        self.fast = (type(model).__name__ in ("MADDPG", "SAFEMADDPG") and model.fused_inference
+        self._fast = (type(model).__name__ in ("MADDPG", "SAFEMADDPG") and model.fused_inference
                      and model.args.shared_params and env.obs.is_cuda and model.args.agent_type == "rnn" and h == 64
                      and o <= 144 and bool(model.args.action_enforcebound))
         # ring write / hand-over / statistics in ONE launch of this project's kernel (fixed-order block sums): no ATen
@@ -70,17 +70,78 @@ class RolloutGraph:
         if self.safe:
             self.predictor = tuple(th.as_tensor(x, dtype=th.float64, device=dev).contiguous() for x in model.predictor)
         self.env_calls = None                                  # env.calls after this object's last step (continuity check)
-        # the slab the step fills (cursor[1]) is advanced by the env's step kernel itself (one lane): no launch of its own
-        self.cursor_stepped = 0
-        if hasattr(env, "set_step_counter") and env.obs.is_cuda:
-            env.set_step_counter(buf.cursor[1:], buf.slabs)
-            self.cursor_stepped = 1
+        # The env's step kernel advances the slab the step fills (cursor[1]) itself (one lane): no launch of its own.
+        self.cursor_stepped = 1 if (hasattr(env, "set_step_counter") and env.obs.is_cuda) else 0
         # Ring I/O (the fused path): the env kernel writes its observation straight into the slab after the cursor, the
         # actor kernel reads observation and hidden state from the slab at the cursor — the observation is written once,
-        # where the replay keeps it, and never copied; the pack kernel only moves the hidden state and the small record.
-        self.ring_io = bool(self.fast and self.cursor_stepped and hasattr(env, "set_obs_ring"))
-        if self.ring_io:
-            env.set_obs_ring(buf.cursor, N * n * o, buf.slabs)
+        # where the replay keeps it, and never copied.
+        self.ring_io = bool(self._fast and self.cursor_stepped and hasattr(env, "set_obs_ring"))
+        # Sink (ring I/O + an env that files transitions): the env step kernel also writes the small record, the masked
+        # hidden state and the per-environment statistics — a vector step is TWO launches, policy and environment, and no
+        # bookkeeping kernel.  Cursor cells then follow the two-kernel protocol of include/flexenv.h: cursor[0] is read by
+        # the policy and written by the env step (slab to read next), cursor[1] is read by the env step and written by the
+        # policy (slab it just read).
+        self.sink = bool(self.ring_io and hasattr(env, "set_replay_sink"))
+        if self.sink:
+            self.act_buf = th.zeros(N * n, a, device=dev)
+            self.hid_buf = th.zeros(N * n, h, device=dev)
+            self.acc = th.zeros(N, 10, dtype=th.float64, device=dev)
+        self._configure_env()
+
+    def _configure_env(self):
+        """Point the env's device-side hooks at this object's ring for the mode in force (fast / general body, in-kernel
+        or torch noise): called at construction and whenever a test flips ``fast`` or ``torch_noise``."""
+        env, buf = self.env, self.buf
+        if not self.cursor_stepped:
+            return
+        N, n, o = env.n_envs, self.model.n_, self.model.obs_dim
+        if self.sink_active:
+            env.set_step_counter(None)                      # the env step sets cursor[0] itself in this mode
+            env.set_obs_ring(buf.cursor[1:], N * n * o, buf.slabs)
+            env.set_replay_sink(self.act_buf, self.hid_buf, buf.small_ring, buf.hid_ring, self.acc, cursor_out=buf.cursor[0:1],
+                                aux_counter=None if self._torch_noise else self.rng_state[1:2])
+        else:
+            env.set_step_counter(buf.cursor[1:], buf.slabs)
+            if self.ring_io:
+                env.set_obs_ring(buf.cursor, N * n * o, buf.slabs)
+            if hasattr(env, "set_replay_sink"):
+                env.set_replay_sink(None, None, None, None, None)
+
+    @property
+    def fast(self):
+        return self._fast
+
+    @fast.setter
+    def fast(self, value):
+        self._fast = bool(value)
+        self._configure_env()
+
+    @property
+    def torch_noise(self):
+        return self._torch_noise
+
+    @torch_noise.setter
+    def torch_noise(self, value):
+        self._torch_noise = bool(value)
+        self._configure_env()
+
+    @property
+    def sink_active(self):
+        return self.sink and self.fast
+
+    # episode statistics: block sums of the pack kernel, or (sink) the env step's per-environment running sums, added up
+    # when asked for (outside any graph)
+    @property
+    def info_sum(self):
+        return self.acc[:, :self._info_sum.numel()].sum(0) if self.sink_active else self._info_sum
+
+    @property
+    def rew_sum(self):
+        return self.acc[:, 7].sum() if self.sink_active else self._rew_sum
+
+    @property
+    def fail_sum(self):
+        return self.acc[:, 8].sum() if self.sink_active else self._fail_sum
 
     @property
     def ring_active(self):
@@ -112,7 +173,7 @@ class RolloutGraph:
                         ("done", env.done), ("hid_new", hid), ("info", env.info), ("failed", env.failed),
                         ("obs_ring", buf.obs_ring), ("hid_ring", buf.hid_ring), ("small_ring", buf.small_ring),
                         ("hid_state", None if self.ring_active else self._hid), ("cursor", buf.cursor),
-                        ("info_sum", self.info_sum), ("rew_sum", self.rew_sum), ("fail_sum", self.fail_sum)):
+                        ("info_sum", self._info_sum), ("rew_sum", self._rew_sum), ("fail_sum", self._fail_sum)):
             if t is not None:
                 assert t.is_contiguous()
                 setattr(a, name, t.data_ptr())
@@ -142,6 +203,8 @@ class RolloutGraph:
                             hid_slab_stride=buf.hid_ring.stride(0)) if self.ring_active else {}
                 obs_in = buf.obs_ring[0].view(N, m.n_, m.obs_dim) if self.ring_active else self._obs
                 hid_in = buf.hid_ring[0].view(N, m.n_, m.hid_dim) if self.ring_active else self._hid
+                if self.sink_active:           # static outputs the env step reads back (registered with its replay sink)
+                    ring.update(cursor_out=buf.cursor[1:], out=dict(hidden_out=self.hid_buf, action=self.act_buf))
                 out = fused_actor_forward(m.policy_dicts[0], obs_in, hid_in, m.n_, m.args.agent_id, noise=noise,
                                           std=self.std, low=m.args.action_low, high=m.args.action_high,
                                           rng_state=None if self.torch_noise else self.rng_state, **ring)
@@ -155,8 +218,9 @@ class RolloutGraph:
                     adjusted, _ = vec.safety_project(action.view(N, m.n_, m.act_dim), *self.predictor, m.V_min, m.V_max)
                     env_action = m.env_action(adjusted.to(th.float32))
                 env.step(env_action.view(N, m.n_, m.act_dim), fuse_obs=True, auto_reset=True,
-                         obs_ring=buf.obs_ring if self.ring_active else None)
-                self._pack(action, hid)
+                         obs_ring=buf.obs_ring if self.ring_active else None, replay_sink=self.sink_active)
+                if not self.sink_active:
+                    self._pack(action, hid)
                 return
         with th.no_grad():
             if self.plain:
@@ -212,7 +276,9 @@ class RolloutGraph:
                 self._obs.copy_(first_obs)
             self._hid.zero_()
             self.buf.begin_stream(first_obs)
-        self.info_sum.zero_(); self.rew_sum.zero_(); self.fail_sum.zero_()
+        self._info_sum.zero_(); self._rew_sum.zero_(); self._fail_sum.zero_()
+        if self.sink:
+            self.acc.zero_()
 
 
 class Model(nn.Module):

@@ -164,7 +164,8 @@ class MLPCritic(nn.Module):
 
 
 def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=1.0, low=0.0, high=1.0, variant=0,
-                        rng_state=None, ring_cursor=None, obs_slab_stride=0, hid_slab_stride=0):
+                        rng_state=None, ring_cursor=None, obs_slab_stride=0, hid_slab_stride=0, cursor_out=None,
+                        out=None):
     """rnn_agent.py:25-33 + model.py:102-116 without an autograd graph, in one HIP launch.
 
     ``obs`` [b, n, obs_dim] fp32 on the GPU WITHOUT the one-hot id columns (the kernel adds fc1's id column of
@@ -191,7 +192,9 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
     obs = obs.contiguous()
     hidden = hidden.reshape(rows, 64).to(th.float32).contiguous()
     means = th.empty(rows, a.action_dim, dtype=th.float32, device=obs.device)
-    hid_out = th.empty(rows, 64, dtype=th.float32, device=obs.device)
+    hid_out = (out or {}).get("hidden_out")
+    if hid_out is None:
+        hid_out = th.empty(rows, 64, dtype=th.float32, device=obs.device)
     args = _lib.FlexActorArgs()
     args.rows, args.n_agents, args.obs_dim, args.act_dim = rows, n_agents, obs.shape[-1], a.action_dim
     args.agent_id, args.layernorm, args.ln_eps = int(bool(agent_id)), int(bool(a.layernorm)), 1e-5
@@ -206,8 +209,12 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
         args.rng_state = rng_state.data_ptr()
     if ring_cursor is not None:
         args.cursor, args.obs_slab_stride, args.hid_slab_stride = ring_cursor.data_ptr(), int(obs_slab_stride), int(hid_slab_stride)
+        if cursor_out is not None:
+            args.cursor_out = cursor_out.data_ptr()
     if explore:
-        action, env_action = th.empty_like(means), th.empty_like(means)
+        action, env_action = (out or {}).get("action"), th.empty_like(means)
+        if action is None:
+            action = th.empty_like(means)
         args.std, args.action_low, args.action_high = float(std), float(low), float(high)
     ln = agent.layernorm if a.layernorm else None
     if ln is not None:

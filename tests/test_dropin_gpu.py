@@ -226,10 +226,9 @@ def test_trainer_run_with_evaluation_keeps_the_ring_consistent(net, series_small
         assert np.isfinite(stat["mean_train_reward"]) and stat["mean_train_solver_failed"] == 0.0
         if ep in (0, 19):
             assert np.isfinite(stat["mean_test_reward"])
-        # device cells == host mirror; after an evaluation the env's own cell (cursor[1]) has run ahead — evaluation stepped
-        # the env without the rollout graph — and is re-seated by the hard reset that starts the next episode
+        # device cursor == host mirror: cell 0 is the slab the policy reads next, cell 1 the slab the env step filed last
         cells = buf.cursor.tolist()
-        assert cells[0] == buf.k % buf.slabs and (cells[1] == cells[0] or ep in (0, 19)), (ep, cells, buf.k)
+        assert cells == [buf.k % buf.slabs, (buf.k - 1) % buf.slabs], (ep, cells, buf.k)
         hard_resets.append(buf.k - k0 - 95)                                    # 1: a gap slab was spent, 0: the stream continued
     # episode 0 starts the stream (no gap), episodes 1 and 20 follow an evaluation (gap), all others continue
     assert hard_resets[1] == 1 and hard_resets[20] == 1 and sum(hard_resets[2:20]) == 0 and hard_resets[21] == 0, hard_resets

@@ -76,8 +76,10 @@ def test_fast_step_equals_general_step(n_envs):
         assert torch.equal(fs["next_state"], slow.env.obs) and torch.equal(fs["hid"], slow.hid)
         assert torch.equal(fs["done"], slow.env.done.float()) and torch.equal(fs["last_step"], slow.env.done.float())
         assert torch.equal(fs["reward"], slow.env.reward.float().unsqueeze(1).expand(-1, 5))
-    assert fast.buf.k == 4 and fast.buf.cursor.tolist() == [4, 4]            # both cursor cells followed the steps
-    assert fast.ring_active and not slow.ring_active                          # ring I/O against tensor hand-over
+    # the cursor cells followed the steps: the sink protocol's policy-read cell leads its env-read cell by one slab, the
+    # pack protocol's cells agree (include/flexenv.h, include/flexnet.h)
+    assert fast.buf.k == 4 and fast.buf.cursor.tolist() == [4, 3] and slow.buf.cursor.tolist() == [4, 4]
+    assert fast.sink_active and fast.ring_active and not slow.ring_active     # env-filed transitions against pack + tensors
     assert len(fast.buf.buffer) == 4 * n_envs
 
 
@@ -91,7 +93,7 @@ def test_graph_capture_with_the_fused_step():
         fast.step()
     torch.cuda.synchronize()
     assert not torch.equal(before, fast.obs) and all(torch.isfinite(v).all() for v in _fields(fast).values())
-    assert fast.buf.k == 3 and fast.buf.cursor.tolist() == [3, 3]
+    assert fast.buf.k == 3 and fast.buf.cursor.tolist() == [3, 2]
     # the exploration noise is drawn anew on every replay (graph-safe Philox offsets), not frozen at capture
     o0, h0 = fast.obs.clone(), fast.hid.clone()
     acts = []
@@ -275,7 +277,7 @@ def test_graph_replays_equal_eager_steps_bit_for_bit():
         for name in fg:
             assert torch.equal(fg[name], fe[name]), (step, name)
         assert torch.equal(graph.buf.cursor, eager.buf.cursor)
-    assert int(graph.rng_state[1]) == 52 and graph.buf.k == 10 and graph.buf.cursor.tolist() == [10 % graph.buf.slabs] * 2
+    assert int(graph.rng_state[1]) == 52 and graph.buf.k == 10 and graph.buf.cursor.tolist() == [10 % graph.buf.slabs, 9 % graph.buf.slabs]
 
 
 def test_ring_wraps_and_windows_stay_consecutive():
@@ -299,7 +301,7 @@ def test_ring_wraps_and_windows_stay_consecutive():
         rg.step()
     torch.cuda.synchronize()
     assert buf.gaps == [] or all(g >= buf.first for g in buf.gaps)
-    assert buf.k == 31 and buf.cursor.tolist() == [31 % 12, 31 % 12] and buf.first == 31 + 2 - 12
+    assert buf.k == 31 and buf.cursor.tolist() == [31 % 12, 30 % 12] and buf.first == 31 + 2 - 12
     assert len(buf.buffer) == N * (31 - buf.first - len(buf.gaps))
     np.random.seed(0)
     for _ in range(50):
