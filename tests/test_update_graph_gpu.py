@@ -94,7 +94,9 @@ def test_graphed_regions_contain_no_aten_multiblock_reduction(monkeypatch):
         for m in must:
             assert any(m in k for k in names), (which, m, names)
         assert not any("at::native::reduce_kernel" in k or "batch_norm" in k for k in names), names
-    assert any("rollout_pack_kernel" in k for k in rg.audit) and any("actor_forward" in k for k in rg.audit)
+    # the fused rollout step is TWO kernels: the policy and the env step that files the transition itself
+    assert rg.sink_active and any("actor_forward" in k for k in rg.audit) and any("flex_step_kernel" in k for k in rg.audit)
+    assert not any("rollout_pack_kernel" in k for k in rg.audit)
     # and the guard itself fires on an ATen full reduction
     from safe_marl_amd.util import audit_graph_body
     x = torch.randn(1 << 20, device="cuda")
