@@ -291,8 +291,11 @@ def kernel_shares_child():
 def spawn_kernel_shares():
     """Run kernel_shares_child() in a child started BEFORE this process initialises the GPU; None on any failure."""
     import subprocess
-    if "rocprof" in (os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "")).lower():
-        return None                                             # a profiler is already attached to this process tree
+    if any("rocprof" in (k + "=" + v).lower() for k, v in os.environ.items()):
+        # a profiler is attached to this process tree (rocprofv3 exports ROCPROF_* and preloads its tool library): its
+        # preloaded library may already have initialised the GPU in THIS process, and a child started from such a process
+        # is exactly the exec the GPU boxes forbid — no child, no kernel shares
+        return None
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--kernel-shares-child"], capture_output=True,
                            text=True, timeout=240)
