@@ -312,6 +312,9 @@ def launch_ranks(a):
     process that has touched the GPU — this one has not) and relay rank 0's JSON line."""
     import socket
     import subprocess
+    if any("rocprof" in (k + "=" + v).lower() for k, v in os.environ.items()):
+        raise SystemExit("bench.py --gpus N under a profiler: start the ranks with torch.distributed.run yourself (a process the "
+                         "profiler has attached to must not start children that use the GPU)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
