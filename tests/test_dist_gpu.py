@@ -46,3 +46,16 @@ def test_two_ranks_train_with_split_update_graphs(tmp_path):
     # and the exchange mattered: a lone rank from rank 0's start ends elsewhere
     solo = _run(str(tmp_path / "solo"), True, nproc=1)
     assert not np.array_equal(solo[0]["w"], g[0]["w"])
+
+
+def test_split_update_graphs_next_to_a_live_rccl_communicator():
+    """RCCL itself (world size 1 — all this box allows): HIP-graph capture beside a live NCCL communicator and its watchdog
+    thread, ncclAllReduce of the flat bucket issued between graph A and graph B for three training episodes."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_world1_probe.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "nccl world-1 probe ok" in r.stdout
