@@ -140,13 +140,17 @@ typedef struct {
     const float* z_shared;     /* [rows / n_agents, 64]  the part of fc1's output all agents of a sample share (maddpg.py:38-54) */
     const float* z_id;         /* [n_agents, 64]         fc1's one-hot id columns, transposed */
     int32_t n_agents;          /* used with z_shared */
-    int32_t pad1;
+    int32_t overwrite_grads;   /* backward, fixed-order path only: the six parameter gradients are STORED, not added to
+                                * (no zero fill by the caller); with the atomic path set: FLEXNET_EINVAL */
     float* d_z_shared;         /* backward, composed input: out [rows / n_agents, 64] = sum over a sample's agents of dz1, or NULL */
     float* d_z_id;             /* backward, composed input: out [n_agents, 64] = sum over samples of dz1, or NULL (both or none;
                                 * needs the workspace) */
     float* workspace;          /* backward: scratch for the per-block partial sums, or NULL */
     int64_t workspace_floats;  /* >= FLEXNET_CRITIC_WS_FLOATS: the parameter gradients are then reduced in a fixed order
                                 * (bit-reproducible) by a second small launch; otherwise with atomics */
+    int32_t d_z_id_agent_stride;   /* d_z_id element (agent i, unit u) is stored at i * agent_stride + u * unit_stride floats; */
+    int32_t d_z_id_unit_stride;    /* 0, 0 = the dense [n_agents, 64] layout (64, 1).  (1, fc1 row length) writes the id */
+                                   /* columns of fc1.weight's gradient in place */
 } FlexCriticTailArgs;
 
 #define FLEXNET_CRITIC_WS_FLOATS (1024 * 4416)
@@ -170,6 +174,15 @@ typedef struct {
     float* c;                  /* out [m, n] */
     float* workspace;
     float* colsum;             /* out [m] = sum_k A[k, m] (the layer's bias gradient), or NULL */
+    /* optional second input block (NULL / 0: none): B is then the column concatenation [b | b2] read in place from its two
+     * homes — the critic's observation block and action block, mlp_critic.py:25 after maddpg.py:47-54 — and the result
+     * columns n .. n + n2 - 1 go to c2.  One launch instead of two.  n must be a multiple of the kernel's lane width
+     * for this shape (5 for 32 < m <= 64 and n > 64; anything else: FLEXNET_EUNSUPPORTED, make two calls). */
+    const float* b2;           /* [k, n2] */
+    float* c2;                 /* out [m, n2] */
+    int64_t ldb2;              /* row pitch of b2 */
+    int32_t n2;
+    int32_t ldc2;              /* row pitch of c2; 0 = n2 */
 } FlexWgradArgs;
 
 #define FLEXNET_WGRAD_WS_FLOATS (520 * 12288 + 520 * 192)

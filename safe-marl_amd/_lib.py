@@ -97,8 +97,9 @@ class FlexCriticTailArgs(C.Structure):
     _fields_ = [("rows", C.c_int32), ("layernorm", C.c_int32), ("ln_eps", C.c_float), ("variant", C.c_int32)] + \
                [(k, C.c_void_p) for k in ("z1", "ln_w", "ln_b", "fc2_w", "fc2_b", "fc3_w", "fc3_b", "q", "dq", "dz1",
                                           "d_ln_w", "d_ln_b", "d_fc2_w", "d_fc2_b", "d_fc3_w", "d_fc3_b", "z_shared", "z_id")] + \
-               [("n_agents", C.c_int32), ("pad1", C.c_int32), ("d_z_shared", C.c_void_p), ("d_z_id", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
+               [("n_agents", C.c_int32), ("overwrite_grads", C.c_int32), ("d_z_shared", C.c_void_p), ("d_z_id", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
+                ("d_z_id_agent_stride", C.c_int32), ("d_z_id_unit_stride", C.c_int32)]
 
 
 FLEXNET_CRITIC_WS_FLOATS = 1024 * 4416
@@ -108,7 +109,8 @@ class FlexWgradArgs(C.Structure):
     _fields_ = [("k", C.c_int64), ("lda", C.c_int64), ("ldb", C.c_int64), ("workspace_floats", C.c_int64),
                 ("m", C.c_int32), ("n", C.c_int32), ("accumulate", C.c_int32), ("ldc", C.c_int32),
                 ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("workspace", C.c_void_p),
-                ("colsum", C.c_void_p)]
+                ("colsum", C.c_void_p), ("b2", C.c_void_p), ("c2", C.c_void_p), ("ldb2", C.c_int64), ("n2", C.c_int32),
+                ("ldc2", C.c_int32)]
 
 
 FLEXNET_WGRAD_WS_FLOATS = 520 * 12288 + 520 * 192

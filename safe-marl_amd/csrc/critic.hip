@@ -231,19 +231,21 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticT
 }
 
 // second stage of the deterministic path: element e of every block's partial row, summed in a fixed order, ADDED to
-// the caller's gradient tensor.  64 elements x 16 block groups per thread block: each thread walks its group's rows
+// the caller's gradient tensor (or stored there: overwrite_grads).  64 elements x 16 block groups per thread block: each thread walks its group's rows
 // with eight loads in flight, the 16 group sums are folded through LDS in index order.
 #define RED_G FLEX_RED_G
 __global__ __launch_bounds__(64 * RED_G) void critic_reduce_kernel(FlexCriticTailArgs a, int blocks) {
     const int e = blockIdx.x * 64 + (threadIdx.x & 63);
     float sum;
     if (!flex_reduce_rows(a.workspace + e, CRITIC_WS_PITCH, blocks, e < HID * HID + 4 * HID + 1, sum)) return;
-    if (e < HID * HID) a.d_fc2_w[e] += sum;
-    else if (e < HID * HID + HID) a.d_fc2_b[e - HID * HID] += sum;
-    else if (e < HID * HID + 2 * HID) a.d_fc3_w[e - HID * HID - HID] += sum;
-    else if (e < HID * HID + 3 * HID) { if (a.layernorm) a.d_ln_w[e - HID * HID - 2 * HID] += sum; }
-    else if (e < HID * HID + 4 * HID) { if (a.layernorm) a.d_ln_b[e - HID * HID - 3 * HID] += sum; }
-    else a.d_fc3_b[0] += sum;
+    float* dst;
+    if (e < HID * HID) dst = a.d_fc2_w + e;
+    else if (e < HID * HID + HID) dst = a.d_fc2_b + (e - HID * HID);
+    else if (e < HID * HID + 2 * HID) dst = a.d_fc3_w + (e - HID * HID - HID);
+    else if (e < HID * HID + 3 * HID) { if (!a.layernorm) return; dst = a.d_ln_w + (e - HID * HID - 2 * HID); }
+    else if (e < HID * HID + 4 * HID) { if (!a.layernorm) return; dst = a.d_ln_b + (e - HID * HID - 3 * HID); }
+    else dst = a.d_fc3_b;
+    *dst = a.overwrite_grads ? sum : *dst + sum;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -680,7 +682,9 @@ __global__ __launch_bounds__(64 * RED_G) void critic_dz_reduce_kernel(FlexCritic
     const int e = blockIdx.x * 64 + (threadIdx.x & 63);                   // agent blockIdx.x, unit ex
     float sum;
     if (!flex_reduce_rows(a.workspace + e, DZF_PITCH, blocks, true, sum)) return;
-    a.d_z_id[e] = sum;
+    const int sa = a.d_z_id_agent_stride, su = a.d_z_id_unit_stride;
+    if (sa == 0 && su == 0) a.d_z_id[e] = sum;
+    else a.d_z_id[(int64_t)blockIdx.x * sa + (int64_t)(threadIdx.x & 63) * su] = sum;
 }
 
 static int critic_dz_fold(const FlexCriticTailArgs& k, hipStream_t stream) {
@@ -702,6 +706,8 @@ static int critic_check(const FlexCriticTailArgs* a, bool backward) {
     if (backward && (!a->dq || !a->dz1)) return FLEXNET_EINVAL;
     if (backward && ((a->d_z_shared != nullptr) != (a->d_z_id != nullptr))) return FLEXNET_EINVAL;
     if (backward && a->d_z_shared && (a->z1 || !a->workspace || a->n_agents > FLEXNET_MAX_AGENTS)) return FLEXNET_EINVAL;
+    if (a->d_z_id_agent_stride < 0 || a->d_z_id_unit_stride < 0 || ((a->d_z_id_agent_stride == 0) != (a->d_z_id_unit_stride == 0)))
+        return FLEXNET_EINVAL;
     // parameter gradients: all of them, or none (d_fc2_w == NULL: dz1 only)
     if (backward && a->d_fc2_w && (!a->d_fc2_b || !a->d_fc3_w || !a->d_fc3_b || (a->layernorm && (!a->d_ln_w || !a->d_ln_b))))
         return FLEXNET_EINVAL;
@@ -757,6 +763,7 @@ static int critic_tail_backward_main(const FlexCriticTailArgs* a, void* stream) 
         return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
     }
     const bool two_stage = k.workspace && k.workspace_floats >= FLEXNET_CRITIC_WS_FLOATS;
+    if (k.overwrite_grads && !two_stage) return FLEXNET_EINVAL;
     if (two_stage && k.variant == 0 && k.rows >= CRITIC_MFMA_MIN_ROWS) {
         const int nb = critic_mfma_grid(k.rows);
         if (nb < 1 || nb > 1024) return FLEXNET_EHIP;

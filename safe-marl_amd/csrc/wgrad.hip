@@ -23,7 +23,12 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 #define WG_WAVES 4
+#ifndef WG_UNROLL
 #define WG_UNROLL(MT, NT) ((MT) * (NT) >= 10 ? 2 : 4)   // k steps (2 rows each) whose loads are issued together
+#endif
+#ifndef WG_DEPTH
+#define WG_DEPTH(MT, NT) 2                              // register buffers in rotation
+#endif
 #define WG_IMG(MT, NT) ((MT) * (NT) * 1024)
 
 #define WG_CS_FLOATS (520 * 192)      // head of the workspace: per-block column sums of A
@@ -37,10 +42,15 @@ struct WgradK {
     float* colsum;
     int64_t k, lda, ldb, a_floats, b_floats;
     int32_t m, n, rows_per_block, slabs, accumulate, ldc;
+    // second input block (TWO instantiations): B = [b | b2], columns n .. n + n2 - 1 of the result go to c2
+    const float* b2;
+    float* c2;
+    int64_t ldb2, b2_floats;
+    int32_t n2, ldc2;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const float* base, int64_t floats) {
-    const int64_t bytes = floats * 4;
+    const int64_t bytes = floats > 0 ? floats * 4 : 0;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)bytes, 0x00027000);
 }
 
@@ -62,7 +72,7 @@ __device__ __forceinline__ void wg_load(__amdgpu_buffer_rsrc_t r, int off, float
     }
 }
 
-template <int MT, int NT, bool CS>
+template <int MT, int NT, bool CS, bool TWO = false>
 __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
     __shared__ float fold[WG_IMG(MT, NT)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -77,6 +87,15 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
     if (eb < fb) fb = eb;
     const __amdgpu_buffer_rsrc_t ra = wg_rsrc(p.a + k0 * p.lda, fa);
     const __amdgpu_buffer_rsrc_t rb = wg_rsrc(p.b + k0 * p.ldb + n0, fb);
+    // TWO: a lane's NT columns lie in b (virtual column < n) or in b2 (n is a multiple of NT: never astride); it loads
+    // from both views every step with the offset of the other one out of range (-> zeros) and keeps its own
+    int64_t fb2 = 0;
+    if (TWO) {
+        fb2 = (int64_t)rows * p.ldb2;
+        const int64_t eb2 = p.b2_floats - k0 * p.ldb2;
+        if (eb2 < fb2) fb2 = eb2;
+    }
+    const __amdgpu_buffer_rsrc_t rb2 = wg_rsrc(TWO ? p.b2 + k0 * p.ldb2 : p.b, TWO ? fb2 : 0);
 
     v16f acc[MT][NT];
 #pragma unroll
@@ -93,10 +112,25 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
     int offa = (2 * wave + half) * lda4 + col * (MT * 4);
     int offb = (2 * wave + half) * ldb4 + col * (NT * 4);
     const int stepa = 2 * WG_WAVES * lda4, stepb = 2 * WG_WAVES * ldb4;
+    // (offsets are advanced as unsigned numbers: an out-of-range lane starts at 2^31 and stays past every view, whose
+    // size is below 2^31 bytes by the dispatcher's check on rows_per_block)
+    unsigned offb2 = 0x80000000u, stepb2 = 0;
+    bool in_b2 = false;
+    if (TWO) {
+        const int vcol = n0 + NT * col - p.n;            // this lane's first column, counted from the start of b2
+        in_b2 = vcol >= 0;
+        stepb2 = 2 * WG_WAVES * (unsigned)p.ldb2 * 4u;
+        if (in_b2) {
+            offb2 = (unsigned)((2 * wave + half) * (int)p.ldb2 * 4 + vcol * 4);
+            offb = (int)0x80000000u;
+        }
+    }
     const int mine = steps > wave ? (steps - wave + WG_WAVES - 1) / WG_WAVES : 0;
 
     constexpr int U = WG_UNROLL(MT, NT);
-    float av[2][U][MT], bv[2][U][NT];
+    constexpr int D = WG_DEPTH(MT, NT);
+    float av[D][U][MT], bv[D][U][NT];
+    float bw[TWO ? D : 1][TWO ? U : 1][NT];
     float csum[MT];                  // this lane's share of sum_k A[k, MT * col + i] (the bias gradient)
 #pragma unroll
     for (int i = 0; i < MT; ++i) csum[i] = 0.0f;
@@ -106,7 +140,11 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
         for (int u = 0; u < U; ++u) {
             wg_load<MT>(ra, offa, av[buf][u]);
             wg_load<NT>(rb, offb, bv[buf][u]);
-            offa += stepa; offb += stepb;
+            offa += stepa; offb = (int)((unsigned)offb + (unsigned)stepb);
+            if constexpr (TWO) {
+                wg_load<NT>(rb2, (int)offb2, bw[buf][u]);
+                offb2 += stepb2;
+            }
         }
     };
     auto multiply = [&](int buf) {
@@ -115,8 +153,15 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][i], bv[buf][u][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) {
+                    float bj = bv[buf][u][j];
+                    if constexpr (TWO) bj = in_b2 ? bw[buf][u][j] : bj;
+#ifdef WG_PROBE_NOMUL
+                    acc[i][j][0] += av[buf][u][i] * bj;
+#else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][i], bj, acc[i][j], 0, 0, 0);
+#endif
+                }
         if (CS) {                    // (every column chunk adds; only chunk 0 stores)
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -124,17 +169,17 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
                 for (int i = 0; i < MT; ++i) csum[i] += av[buf][u][i];
         }
     };
-    // rows past the block's end lie outside the buffer views and contribute 0 * 0, so the trip count is rounded up
+    // D register buffers in rotation, D - 1 groups of loads in flight behind the one being multiplied.  Rows past the
+    // block's end lie outside the buffer views and load 0 (0 * 0 adds nothing), so the trip count is rounded up to a
+    // whole rotation and the loads issued past the last group are harmless.
     const int groups = (mine + U - 1) / U;
     if (groups > 0) {
-        issue(0);
-        int g = 0;
-        for (; g + 2 < groups; g += 2) {
-            issue(1); multiply(0);
-            issue(0); multiply(1);
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) issue(d);
+        for (int g = 0; g < groups; g += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) { issue((d + D - 1) % D); multiply(d); }
         }
-        if (g + 1 < groups) { issue(1); multiply(0); multiply(1); }
-        else multiply(0);
     }
 
     if (want_cs) {                   // lanes l and l + 32 hold the same columns; then the four wavefronts in order
@@ -181,39 +226,47 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
             for (int r = 0; r < 16; ++r) out[((i * NT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
 }
 
-// element e of the slabs' register images, summed in a fixed order, stored at its place in C
+// element e of the slabs' register images, summed in a fixed order, stored at its place in C; the thread blocks past
+// the image (column chunk 0 only, when column sums were asked for) sum the blocks' column-sum partials the same way
 #define WG_RED FLEX_RED_G
 template <int MT, int NT>
 __global__ __launch_bounds__(64 * WG_RED) void wgrad_reduce_kernel(WgradK p) {
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63);        // < WG_IMG: the grid covers it exactly
+    constexpr int IMG_BLOCKS = WG_IMG(MT, NT) / 64;
     float sum;
+    if (blockIdx.x >= IMG_BLOCKS) {
+        if (blockIdx.y != 0) return;
+        const int m = (blockIdx.x - IMG_BLOCKS) * 64 + (threadIdx.x & 63);
+        if (!flex_reduce_rows(p.cs + m, 32 * MT, p.slabs, m < 32 * MT, sum) || m >= p.m) return;
+        p.colsum[m] = p.accumulate ? p.colsum[m] + sum : sum;
+        return;
+    }
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);        // < WG_IMG: the grid covers it exactly
     if (!flex_reduce_rows(p.ws + (int64_t)blockIdx.y * p.slabs * WG_IMG(MT, NT) + e, WG_IMG(MT, NT), p.slabs, true, sum)) return;
     // register image -> matrix position (v_mfma_f32_32x32x2_f32 result layout, tile rows / columns interleaved)
     const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
     const int ti = t / NT, tj = t - ti * NT;
     const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
     const int m = MT * i + ti, n = blockIdx.y * (32 * NT) + NT * j + tj;
-    if (m < p.m && n < p.n) {
-        float* dst = p.c + (int64_t)m * p.ldc + n;
-        *dst = p.accumulate ? *dst + sum : sum;
-    }
-}
-
-// column sums: element m of every block's partial row, in the same fixed order
-__global__ __launch_bounds__(64 * WG_RED) void wgrad_colsum_kernel(WgradK p, int pitch) {
-    const int m = blockIdx.x * 64 + (threadIdx.x & 63);
-    float sum;
-    if (!flex_reduce_rows(p.cs + m, pitch, p.slabs, m < pitch, sum) || m >= p.m) return;
-    p.colsum[m] = p.accumulate ? p.colsum[m] + sum : sum;
+    if (m >= p.m) return;
+    float* dst;
+    if (n < p.n) dst = p.c + (int64_t)m * p.ldc + n;
+    else if (n - p.n < p.n2) dst = p.c2 + (int64_t)m * p.ldc2 + (n - p.n);       // (n2 = 0 without a second block)
+    else return;
+    *dst = p.accumulate ? *dst + sum : sum;
 }
 
 template <int MT, int NT>
 static int wgrad_launch(WgradK p, int chunks, hipStream_t s) {
-    if (p.cs) hipLaunchKernelGGL((wgrad_kernel<MT, NT, true>), dim3(p.slabs, chunks), dim3(64 * WG_WAVES), 0, s, p);
+    if (p.b2) {
+        if constexpr (MT == 2 && NT == 5) {
+            if (p.cs) hipLaunchKernelGGL((wgrad_kernel<MT, NT, true, true>), dim3(p.slabs, chunks), dim3(64 * WG_WAVES), 0, s, p);
+            else hipLaunchKernelGGL((wgrad_kernel<MT, NT, false, true>), dim3(p.slabs, chunks), dim3(64 * WG_WAVES), 0, s, p);
+        } else return FLEXNET_EUNSUPPORTED;
+    } else if (p.cs) hipLaunchKernelGGL((wgrad_kernel<MT, NT, true>), dim3(p.slabs, chunks), dim3(64 * WG_WAVES), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<MT, NT, false>), dim3(p.slabs, chunks), dim3(64 * WG_WAVES), 0, s, p);
-    hipLaunchKernelGGL((wgrad_reduce_kernel<MT, NT>), dim3(WG_IMG(MT, NT) / 64, chunks), dim3(64 * WG_RED), 0, s, p);
-    if (p.cs)
-        hipLaunchKernelGGL(wgrad_colsum_kernel, dim3((32 * MT + 63) / 64), dim3(64 * WG_RED), 0, s, p, 32 * MT);
+    // the column-sum blocks ride at the end of every grid row; those of column chunks > 0 return at once
+    const int cs_blocks = p.cs ? (32 * MT + 63) / 64 : 0;
+    hipLaunchKernelGGL((wgrad_reduce_kernel<MT, NT>), dim3(WG_IMG(MT, NT) / 64 + cs_blocks, chunks), dim3(64 * WG_RED), 0, s, p);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 
@@ -221,9 +274,13 @@ extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) {
     if (!a || !a->a || !a->b || !a->c || !a->workspace || a->k < 0 || a->m < 1 || a->n < 1) return FLEXNET_EINVAL;
     if (a->lda < a->m || a->ldb < a->n || (a->ldc != 0 && a->ldc < a->n)) return FLEXNET_EINVAL;
     if (a->m > 192 || a->lda >= (1 << 24) || a->ldb >= (1 << 24)) return FLEXNET_EUNSUPPORTED;
+    const bool two = a->b2 != nullptr || a->n2 != 0;
+    if (two && (!a->b2 || !a->c2 || a->n2 < 1 || a->ldb2 < a->n2 || (a->ldc2 != 0 && a->ldc2 < a->n2))) return FLEXNET_EINVAL;
     const int mt = a->m <= 32 ? 1 : a->m <= 64 ? 2 : 6;
     const int nt = a->n <= 32 ? 1 : a->n <= 64 ? 2 : (mt == 6 ? 2 : 5);
-    const int chunks = (a->n + 32 * nt - 1) / (32 * nt);
+    if (two && (mt != 2 || nt != 5 || a->n % nt != 0 || a->ldb2 >= (1 << 24))) return FLEXNET_EUNSUPPORTED;
+    const int n_all = a->n + (two ? a->n2 : 0);
+    const int chunks = (n_all + 32 * nt - 1) / (32 * nt);
     const int64_t img = (int64_t)mt * nt * 1024;
     // thread blocks: about two per CU over all column chunks, at least 64 rows each, within the workspace
     const int64_t ws_floats = a->workspace_floats - WG_CS_FLOATS;
@@ -239,7 +296,9 @@ extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) {
     int64_t rpb = (a->k + slabs - 1) / slabs;
     rpb = (rpb + 7) & ~(int64_t)7;
     if (rpb < 8) rpb = 8;
-    if (rpb * (a->lda > a->ldb ? a->lda : a->ldb) * 4 >= 0x7fffffffll) return FLEXNET_EUNSUPPORTED;
+    int64_t ldmax = a->lda > a->ldb ? a->lda : a->ldb;
+    if (two && a->ldb2 > ldmax) ldmax = a->ldb2;
+    if (rpb * ldmax * 4 >= 0x7fffffffll) return FLEXNET_EUNSUPPORTED;
     slabs = a->k > 0 ? (a->k + rpb - 1) / rpb : 1;
     WgradK p;
     p.a = a->a; p.b = a->b; p.c = a->c; p.ws = a->workspace + WG_CS_FLOATS;
@@ -249,6 +308,9 @@ extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) {
     p.b_floats = a->k > 0 ? (a->k - 1) * a->ldb + a->n : 0;
     p.m = a->m; p.n = a->n; p.rows_per_block = (int)rpb; p.slabs = (int)slabs; p.accumulate = a->accumulate;
     p.ldc = a->ldc > 0 ? a->ldc : a->n;
+    p.b2 = two ? a->b2 : nullptr; p.c2 = two ? a->c2 : nullptr; p.ldb2 = two ? a->ldb2 : 0;
+    p.b2_floats = two && a->k > 0 ? (a->k - 1) * a->ldb2 + a->n2 : 0;
+    p.n2 = two ? a->n2 : 0; p.ldc2 = two ? (a->ldc2 > 0 ? a->ldc2 : a->n2) : 0;
     hipStream_t s = (hipStream_t)stream;
     switch (mt * 10 + nt) {
         case 11: return wgrad_launch<1, 1>(p, chunks, s);

@@ -248,15 +248,21 @@ def tall_wgrad_supported(dy, x):
                                       and x.stride(0) >= x.shape[1] and max(dy.stride(0), x.stride(0)) < (1 << 24))))
 
 
-def tall_wgrad(dy, x, out=None, accumulate=False, colsum=None):
+def tall_wgrad(dy, x, out=None, accumulate=False, colsum=None, x2=None, out2=None):
     """dW[m, n] = sum_k dy[k, m] * x[k, n] (csrc/wgrad.hip: include/flexnet.h flexnet_wgrad) — the weight gradient of
     y = x @ W.T over a tall batch.  Row-strided views (column slices of the packed replay rows) are read in place.
-    The workspace is per device: calls are expected on one stream at a time (the update's)."""
+    The workspace is per device: calls are expected on one stream at a time (the update's).
+    ``x2`` / ``out2``: a second input block of the same layer (out2 = dy.T @ x2) — in the same launch where the kernel
+    takes [x | x2] as one operand (64 output rows, x wider than 64 columns and a multiple of 5), else a second call."""
     import ctypes as C
     from . import _lib
     lib = _lib.load()
     k, m = dy.shape
     n = x.shape[1]
+    if x2 is not None and not (32 < m <= 64 and n > 64 and n % 5 == 0 and k > 1 and tall_wgrad_supported(dy, x2)
+                               and out2.stride(1) == 1):
+        tall_wgrad(dy, x2, out=out2, accumulate=accumulate)
+        x2 = None
     if k <= 1:
         dy, x = dy.contiguous(), x.contiguous()
     if out is None:
@@ -274,6 +280,8 @@ def tall_wgrad(dy, x, out=None, accumulate=False, colsum=None):
     a.ldc = out.stride(0) if m > 1 else n
     if colsum is not None:          # [m] <- sum_k dy[k, :], the bias gradient, from the same pass over dy
         a.colsum = colsum.data_ptr()
+    if x2 is not None:
+        a.b2, a.c2, a.ldb2, a.n2, a.ldc2 = x2.data_ptr(), out2.data_ptr(), x2.stride(0), x2.shape[1], out2.stride(0)
     _lib.check(lib.flexnet_wgrad(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_wgrad")
     return out
 
@@ -354,6 +362,9 @@ class _TdLossFn(th.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss):
         (dq,) = ctx.saved_tensors
+        from .util import is_unit_seed
+        if is_unit_seed(grad_loss):                   # the trainer's root gradient: dq is the answer as it stands
+            return dq.view(ctx.q_shape), None, None, None, None, None, None
         return (dq * grad_loss).view(ctx.q_shape), None, None, None, None, None, None
 
 
@@ -785,7 +796,8 @@ class _CriticReplayedFn(th.autograd.Function):
         rows = shared.shape[0] * n
         dq = dq.contiguous()
         dz1 = th.empty(rows, 64, dtype=th.float32, device=shared.device)
-        grads = th.zeros(64 * 64 + 64 * 4 + 1, dtype=th.float32, device=shared.device)
+        # the six tail gradients are STORED by the fixed-order second stage (overwrite_grads): no zero fill
+        grads = th.empty(64 * 64 + 64 * 4 + 1, dtype=th.float32, device=shared.device)
         d_w2, d_b2, d_w3 = grads[:4096].view(64, 64), grads[4096:4160], grads[4160:4224].view(1, 64)
         d_g, d_b, d_b3 = grads[4224:4288], grads[4288:4352], grads[4352:4353]
         args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, ctx.eps)
@@ -795,17 +807,22 @@ class _CriticReplayedFn(th.autograd.Function):
         if ln_w is not None:
             args.d_ln_w, args.d_ln_b = d_g.data_ptr(), d_b.data_ptr()
         ws = _critic_workspace(shared.device)
-        args.workspace, args.workspace_floats = ws.data_ptr(), ws.numel()
+        args.workspace, args.workspace_floats, args.overwrite_grads = ws.data_ptr(), ws.numel(), 1
         d_shared = th.empty_like(shared)                    # dz1 folded onto its two sources by the same call
-        d_id = th.empty(n, 64, dtype=th.float32, device=shared.device)
+        dW = th.empty_like(W)
+        if ctx.twin:
+            d_id = th.empty(n, 64, dtype=th.float32, device=shared.device)
+        else:                                               # ... the id-column sums straight into dW[:, no:no + n]
+            d_id = dW[:, no:no + n]
+            args.d_z_id_agent_stride, args.d_z_id_unit_stride = 1, W.shape[1]
         args.d_z_shared, args.d_z_id = d_shared.data_ptr(), d_id.data_ptr()
         _lib.check(lib.flexnet_critic_tail_backward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
                    "flexnet_critic_tail_backward")
-        dW = th.empty_like(W)
         d_bias = th.empty(64, dtype=th.float32, device=W.device)
-        tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias)
-        dW[:, no:no + n] = d_id.t()
-        tall_wgrad(d_shared, act2d, out=dW[:, no + n:no + n + na_])
+        # fc1: the observation block and the action block of dW from one launch (the action block rides in the last column chunk)
+        tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias, x2=act2d, out2=dW[:, no + n:no + n + na_])
+        if ctx.twin:
+            dW[:, no:no + n] = d_id.t()
         if W.shape[1] > no + n + na_:
             dW[:, no + n + na_:] = 0.0
             if ctx.twin:                 # the flag column sees every agent's row: the sum of the id-column gradients

@@ -350,7 +350,11 @@ class PGTrainer(object):
         # gradients of THIS optimiser's parameters only: a plain backward() would also fill the other network's
         # .grad (the critic's first-layer weight gradient is the largest GEMM of a policy step) just to have it
         # zeroed by that optimiser's next zero_grad (trainer.py:82,100)
-        grads = th.autograd.grad(loss, leaves, allow_unused=True)
+        seed = None
+        if loss.is_cuda and loss.dim() == 0 and loss.dtype == th.float32:
+            from .util import unit_seed
+            seed = unit_seed(loss.device)             # recognised by the loss nodes: no ones-fill, no multiply by one
+        grads = th.autograd.grad(loss, leaves, grad_outputs=seed, allow_unused=True)
         if flat is None:
             for p, g in zip(params, grads):
                 p.grad = g

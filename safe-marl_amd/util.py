@@ -59,6 +59,40 @@ def convert(dictionary):
 
 
 _SUM_WS = {}
+_UNIT = {}
+_CONST_GRADS = {}
+
+
+def unit_seed(device):
+    """The scalar 1.0 a backward pass starts from, one per device and never written again.  Handed to autograd as the root
+    gradient (``grad_outputs``) it saves the engine's own ones-fill; the loss nodes below recognise it BY ADDRESS
+    (``is_unit_seed``) and return their stored / constant gradient as it is instead of multiplying it by one — two to
+    three ~5 us launches per sub-update that carried no information."""
+    device = th.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = th.device("cuda", th.cuda.current_device())
+    if device not in _UNIT:
+        _UNIT[device] = th.ones((), dtype=th.float32, device=device)
+    return _UNIT[device]
+
+
+def is_unit_seed(g):
+    u = _UNIT.get(g.device)
+    return u is not None and g.dim() == 0 and g.data_ptr() == u.data_ptr()
+
+
+def const_grad(shape, value, device):
+    """A read-only tensor of ``shape`` filled with ``value``, cached (the gradient of a mean under the unit seed).  Made
+    while a HIP graph is being captured it is not cached: its memory and its fill would belong to that graph."""
+    key = (th.device(device), tuple(shape), float(value))
+    t = _CONST_GRADS.get(key)
+    if t is None:
+        t = th.full(tuple(shape), float(value), dtype=th.float32, device=device)
+        if not (t.is_cuda and th.cuda.is_current_stream_capturing()):
+            if len(_CONST_GRADS) >= 64:
+                _CONST_GRADS.clear()
+            _CONST_GRADS[key] = t
+    return t
 
 
 class _MeanAllFn(th.autograd.Function):
@@ -84,6 +118,8 @@ class _MeanAllFn(th.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if is_unit_seed(g):
+            return const_grad(ctx.shape, ctx.scale, g.device), None
         return (g * ctx.scale).expand(ctx.shape), None
 
 

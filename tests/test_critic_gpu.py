@@ -188,3 +188,53 @@ def test_whole_critic_on_replayed_actions_matches_the_layerwise_path():
     for a, e in zip(*res):
         assert a.shape == e.shape
         assert _rel(a, e) < 2e-5
+
+
+@pytest.mark.parametrize("samples,n", [(4096, 5), (777, 3)])
+def test_stored_gradients_and_strided_id_sums(samples, n):
+    """include/flexnet.h: overwrite_grads stores the six tail gradients over whatever the buffers held (NaN here) — the
+    same numbers the adding form leaves in zeroed buffers — and d_z_id written through (agent, unit) strides lands in
+    the id columns of a wider fc1 gradient, equal to the dense [n, 64] form."""
+    import ctypes as C
+    from safe_marl_amd import _lib
+    from safe_marl_amd.nets import _critic_args, _critic_workspace
+    lib = _lib.load()
+    c = _critic()
+    g = torch.Generator(device="cuda").manual_seed(samples)
+    shared = torch.randn(samples, 64, device="cuda", generator=g)
+    ids = torch.randn(n, 64, device="cuda", generator=g)
+    dq = torch.randn(samples * n, device="cuda", generator=g)
+    ws = _critic_workspace(shared.device)
+
+    def run(overwrite, strided):
+        fill = float("nan") if overwrite else 0.0
+        grads = torch.full((64 * 64 + 64 * 4 + 1,), fill, device="cuda")
+        dz1 = torch.empty(samples * n, 64, device="cuda")
+        d_shared = torch.empty_like(shared)
+        wide = torch.full((64, 11 + n), float("nan"), device="cuda")
+        d_id = torch.empty(n, 64, device="cuda")
+        a = _critic_args(shared, c.layernorm.weight, c.layernorm.bias, c.fc2.weight, c.fc2.bias, c.fc3.weight, c.fc3.bias,
+                         c.layernorm.eps)
+        a.rows, a.z1, a.z_shared, a.z_id, a.n_agents = samples * n, None, shared.data_ptr(), ids.data_ptr(), n
+        a.dq, a.dz1 = dq.data_ptr(), dz1.data_ptr()
+        a.d_fc2_w, a.d_fc2_b, a.d_fc3_w = grads.data_ptr(), grads[4096:].data_ptr(), grads[4160:].data_ptr()
+        a.d_ln_w, a.d_ln_b, a.d_fc3_b = grads[4224:].data_ptr(), grads[4288:].data_ptr(), grads[4352:].data_ptr()
+        a.workspace, a.workspace_floats, a.overwrite_grads = ws.data_ptr(), ws.numel(), int(overwrite)
+        a.d_z_shared = d_shared.data_ptr()
+        if strided:
+            a.d_z_id, a.d_z_id_agent_stride, a.d_z_id_unit_stride = wide[:, 7:].data_ptr(), 1, wide.stride(0)
+        else:
+            a.d_z_id = d_id.data_ptr()
+        rc = lib.flexnet_critic_tail_backward(C.byref(a), None)
+        torch.cuda.synchronize()
+        return rc, grads, (wide if strided else d_id), a
+
+    rc0, g0, id0, _ = run(False, False)
+    rc1, g1, wide, a = run(True, True)
+    assert rc0 == 0 and rc1 == 0
+    assert torch.isfinite(g1).all() and torch.equal(g0, g1)
+    assert torch.equal(wide[:, 7:7 + n], id0.t()) and torch.isnan(wide[:, :7]).all() and torch.isnan(wide[:, 7 + n:]).all()
+    a.d_z_id_unit_stride = 0                                   # one stride without the other
+    assert lib.flexnet_critic_tail_backward(C.byref(a), None) == -1
+    a.d_z_id_unit_stride, a.workspace_floats = wide.stride(0), 16
+    assert lib.flexnet_critic_tail_backward(C.byref(a), None) == -1      # stored gradients need the fixed-order path

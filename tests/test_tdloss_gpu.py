@@ -104,3 +104,37 @@ def test_statistics_only_pass_moves_the_running_statistics_like_a_forward():
         assert a.num_batches_tracked.item() == b.num_batches_tracked.item() == step + 1
     a.eval()
     assert not batchnorm_stats_supported(a, x)
+
+
+def test_unit_seed_is_the_gradient_of_one_without_the_launches():
+    """util.unit_seed: the trainer's root gradient.  The loss nodes recognise it by address and hand back their stored /
+    constant gradient (no ones-fill, no multiply by one); any other root gradient takes the general path.  Same numbers
+    either way, and the seed itself is never written."""
+    import torch.nn as nn
+    from safe_marl_amd.nets import td_loss
+    from safe_marl_amd.util import mean_all, unit_seed, is_unit_seed, audit_graph_body
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rows, n = 4096, 5
+    q = torch.randn(rows, n, device="cuda", generator=g, requires_grad=True)
+    nq, r = torch.randn(rows, n, device="cuda", generator=g), torch.randn(rows, n, device="cuda", generator=g)
+    d = (torch.rand(rows, 1, device="cuda", generator=g) < 0.1).float()
+    seed = unit_seed("cuda")
+    assert is_unit_seed(seed) and not is_unit_seed(torch.ones((), device="cuda")) and seed is unit_seed(q.device)
+
+    def grads(root):
+        bn = nn.BatchNorm1d(n).cuda().train()
+        loss = td_loss(q, nq, r, d, 0.99, bn)
+        pol = mean_all(q * 1.0, sign=-1.0) - 0.25
+        return torch.autograd.grad(loss, q, grad_outputs=root)[0], torch.autograd.grad(pol, q, grad_outputs=root)[0]
+
+    a_v, a_p = grads(seed)
+    b_v, b_p = grads(None)
+    c_v, c_p = grads(torch.full((), 2.0, device="cuda"))
+    assert torch.equal(a_v, b_v) and torch.equal(a_p, b_p)
+    assert torch.equal(c_v, 2.0 * b_v) and torch.allclose(c_p, 2.0 * b_p, rtol=1e-7, atol=0)
+    assert float(seed) == 1.0
+    # and the launches are really gone: the value-loss backward under the seed is free of pointwise kernels
+    bn = nn.BatchNorm1d(n).cuda().train()
+    loss = td_loss(q, nq, r, d, 0.99, bn)
+    names = audit_graph_body(lambda: torch.autograd.grad(loss, q, grad_outputs=seed))
+    assert not [k for k in names if "elementwise" in k], names

@@ -138,3 +138,46 @@ def test_actor_update_pass_matches_the_module_path():
         nets._FUSED_GRU, nets.WGRAD_MIN_ROWS = saved
     for a, e in zip(fast, plain):     # outputs differ by the order in which the cell adds its biases (1 ulp)
         assert (a - e).abs().max().item() <= 1e-4 * max(1.0, e.abs().max().item())
+
+
+@pytest.mark.parametrize("k,n,n2", [(32768, 720, 20), (4099, 720, 20), (2051, 150, 7), (1000, 160, 160), (515, 75, 161)])
+def test_second_input_block_in_the_same_launch(k, n, n2):
+    """[x | x2] read from their two homes as ONE operand (the critic's observation and action blocks, maddpg.py:47-54):
+    the same numbers, bit for bit, as two separate calls; both blocks are column slices of wider records with NaN
+    neighbours, and the outputs are column blocks of one wider gradient."""
+    import ctypes as C
+    from safe_marl_amd import _lib
+    from safe_marl_amd.nets import tall_wgrad
+    g = torch.Generator(device="cuda").manual_seed(k + n + n2)
+    dy = torch.randn(k, 64, device="cuda", generator=g)
+    rec1 = torch.full((k, n + 9), float("nan"), device="cuda")
+    rec2 = torch.full((k, n2 + 6), float("nan"), device="cuda")
+    x, x2 = rec1[:, 4:4 + n], rec2[:, 3:3 + n2]
+    x.copy_(torch.randn(k, n, device="cuda", generator=g))
+    x2.copy_(torch.randn(k, n2, device="cuda", generator=g))
+    dW = torch.full((64, n + 5 + n2), float("nan"), device="cuda")
+    cs = torch.empty(64, device="cuda")
+    tall_wgrad(dy, x, out=dW[:, :n], colsum=cs, x2=x2, out2=dW[:, n + 5:])
+    assert torch.isnan(dW[:, n:n + 5]).all()                       # nothing written between the two blocks
+    want1, want2 = tall_wgrad(dy, x), tall_wgrad(dy, x2)
+    assert torch.equal(dW[:, :n], want1)
+    assert _close(dW[:, n + 5:], _ref(dy, x2), k)
+    if n2 <= 64 and n % 5 == 0:
+        # the separate call sums the same products over the same row blocks only when both calls split the rows alike;
+        # what must hold always is agreement within fp32 summation error and run-to-run reproducibility
+        again = torch.empty_like(dW)
+        tall_wgrad(dy, x, out=again[:, :n], x2=x2, out2=again[:, n + 5:])
+        assert torch.equal(again[:, n + 5:], dW[:, n + 5:]) and torch.equal(again[:, :n], dW[:, :n])
+    assert (want2 - dW[:, n + 5:]).abs().max().item() <= 3e-7 * k ** 0.5 * max(1.0, want2.abs().max().item())
+    assert (cs.double() - dy.double().sum(0)).abs().max().item() <= 1e-3
+    # the entry point itself refuses what the kernel does not cover (the wrapper then makes two calls)
+    lib = _lib.load()
+    a = _lib.FlexWgradArgs()
+    ws = torch.empty(_lib.FLEXNET_WGRAD_WS_FLOATS, device="cuda")
+    out = torch.empty(64, 64, device="cuda")
+    a.k, a.m, a.n, a.lda, a.ldb = 100, 64, 64, 64, 64
+    a.a, a.b, a.c, a.workspace, a.workspace_floats = dy.data_ptr(), dy.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel()
+    a.b2, a.c2, a.ldb2, a.n2 = dy.data_ptr(), out.data_ptr(), 64, 8
+    assert lib.flexnet_wgrad(C.byref(a), None) == _lib.FLEXNET_EUNSUPPORTED     # n <= 64: not the five-column lane shape
+    a.n2 = 0
+    assert lib.flexnet_wgrad(C.byref(a), None) == -1                            # b2 without columns

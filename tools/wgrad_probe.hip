@@ -1,0 +1,30 @@
+// Stand-alone timing of csrc/wgrad.hip on the update's shapes, for trying main-loop variants:
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Isafe-marl_amd/csrc [-DWG_...] tools/wgrad_probe.hip -o tools/wgrad_probe_X
+#include "../safe-marl_amd/csrc/wgrad.hip"
+#include <cstdio>
+#include <vector>
+
+int main() {
+    struct Shape { int64_t k; int m, n; } shapes[] = {{163840, 192, 64}, {163840, 64, 144}, {163840, 4, 64}, {32768, 64, 720}, {32768, 64, 20}};
+    float *a, *b, *c, *ws, *cs;
+    const int64_t maxk = 163840;
+    hipMalloc(&a, maxk * 192 * 4); hipMalloc(&b, maxk * 720 * 4); hipMalloc(&c, 192 * 745 * 4); hipMalloc(&cs, 192 * 4);
+    hipMalloc(&ws, (int64_t)FLEXNET_WGRAD_WS_FLOATS * 4);
+    hipMemset(a, 0, maxk * 192 * 4); hipMemset(b, 0, maxk * 720 * 4);
+    hipStream_t s; hipStreamCreate(&s);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (auto sh : shapes) {
+        FlexWgradArgs w{};
+        w.a = a; w.b = b; w.c = c; w.k = sh.k; w.m = sh.m; w.n = sh.n; w.lda = sh.m; w.ldb = sh.n; w.ldc = sh.n;
+        w.workspace = ws; w.workspace_floats = FLEXNET_WGRAD_WS_FLOATS; w.accumulate = 0; w.colsum = cs;
+        for (int i = 0; i < 5; ++i) if (flexnet_wgrad(&w, s) != 0) { printf("launch failed\n"); return 1; }
+        const int reps = 50;
+        hipEventRecord(e0, s);
+        for (int i = 0; i < reps; ++i) flexnet_wgrad(&w, s);
+        hipEventRecord(e1, s); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double us = ms * 1e3 / reps, gb = sh.k * (double)(sh.m + sh.n) * 4 / 1e9, tf = 2.0 * sh.k * sh.m * sh.n / 1e12;
+        printf("k=%6ld m=%3d n=%3d  %7.1f us  %5.2f TB/s  %5.1f TFLOP/s\n", (long)sh.k, sh.m, sh.n, us, gb / us * 1e3, tf / us * 1e6);
+    }
+    return 0;
+}
