@@ -151,6 +151,8 @@ typedef struct {
     int32_t d_z_id_agent_stride;   /* d_z_id element (agent i, unit u) is stored at i * agent_stride + u * unit_stride floats; */
     int32_t d_z_id_unit_stride;    /* 0, 0 = the dense [n_agents, 64] layout (64, 1).  (1, fc1 row length) writes the id */
                                    /* columns of fc1.weight's gradient in place */
+    int32_t z_id_agent_stride;     /* the same for the INPUT z_id: (1, fc1 row length) reads the id columns of fc1.weight where */
+    int32_t z_id_unit_stride;      /* they are (every kernel stages the [n_agents, 64] table in LDS once per block) */
 } FlexCriticTailArgs;
 
 #define FLEXNET_CRITIC_WS_FLOATS (1024 * 4416)

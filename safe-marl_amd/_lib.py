@@ -99,7 +99,8 @@ class FlexCriticTailArgs(C.Structure):
                                           "d_ln_w", "d_ln_b", "d_fc2_w", "d_fc2_b", "d_fc3_w", "d_fc3_b", "z_shared", "z_id")] + \
                [("n_agents", C.c_int32), ("overwrite_grads", C.c_int32), ("d_z_shared", C.c_void_p), ("d_z_id", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
-                ("d_z_id_agent_stride", C.c_int32), ("d_z_id_unit_stride", C.c_int32)]
+                ("d_z_id_agent_stride", C.c_int32), ("d_z_id_unit_stride", C.c_int32),
+                ("z_id_agent_stride", C.c_int32), ("z_id_unit_stride", C.c_int32)]
 
 
 FLEXNET_CRITIC_WS_FLOATS = 1024 * 4416

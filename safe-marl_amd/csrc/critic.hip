@@ -23,10 +23,22 @@
 struct CriticRow { float xhat, rstd, y, a1; };
 
 // fc1's output of row r for this lane's unit: stored, or composed from the per-sample part and the agent's id column
-__device__ __forceinline__ float critic_z1(const FlexCriticTailArgs& a, int r, int lane) {
+__device__ __forceinline__ float critic_z1(const FlexCriticTailArgs& a, const float* idt, int r, int lane) {
     if (a.z1) return a.z1[(int64_t)r * HID + lane];
     const int b = r / a.n_agents, i = r - b * a.n_agents;
-    return a.z_shared[(int64_t)b * HID + lane] + a.z_id[i * HID + lane];
+    return a.z_shared[(int64_t)b * HID + lane] + idt[i * HID + lane];
+}
+
+// the id-column table [n_agents, 64] of the composed input, staged in LDS once per block from wherever it lives (dense, or
+// the id columns of fc1.weight through the two strides); the caller's next __syncthreads() publishes it
+#define CRITIC_IDT_FLOATS (FLEXNET_MAX_AGENTS * HID)
+__device__ __forceinline__ void critic_stage_ids(const FlexCriticTailArgs& a, float* idt, int tid, int threads) {
+    if (a.z1) return;
+    const int sa = a.z_id_agent_stride ? a.z_id_agent_stride : HID, su = a.z_id_agent_stride ? a.z_id_unit_stride : 1;
+    for (int e = tid; e < a.n_agents * HID; e += threads) {
+        const int i = e / HID, u = e - i * HID;
+        idt[e] = a.z_id[(int64_t)i * sa + (int64_t)u * su];
+    }
 }
 
 // LayerNorm + ReLU of one row held one unit per lane (mlp_critic.py:27-29)
@@ -50,11 +62,13 @@ __device__ __forceinline__ CriticRow critic_ln_relu(float z1, bool layernorm, fl
 __global__ __launch_bounds__(64 * CW, 2) void critic_tail_fwd_kernel(FlexCriticTailArgs a) {
     __shared__ float stage[CW][HID * CRT];               // per wavefront: a1 as [i][row]
     __shared__ float w2t[HID * (HID + 1)];               // w2t[i][j] = W2[j][i]: lane j reads its row of W2 along i
+    __shared__ float idt[CRITIC_IDT_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int idx = tid; idx < HID * HID; idx += 64 * CW) {
         const int j = idx / HID, i = idx - j * HID;
         w2t[i * (HID + 1) + j] = a.fc2_w[idx];
     }
+    critic_stage_ids(a, idt, tid, 64 * CW);
     __syncthreads();
     float* sa = stage[wave];
     const float g = a.layernorm ? a.ln_w[lane] : 1.0f, be = a.layernorm ? a.ln_b[lane] : 0.0f;
@@ -66,7 +80,7 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_fwd_kernel(FlexCriticT
 #pragma unroll
         for (int r = 0; r < CRT; ++r) {
             const int rr = min(r0 + r, a.rows - 1);
-            a1v[r] = critic_ln_relu(critic_z1(a, rr, lane), a.layernorm != 0, a.ln_eps, g, be).a1;
+            a1v[r] = critic_ln_relu(critic_z1(a, idt, rr, lane), a.layernorm != 0, a.ln_eps, g, be).a1;
         }
         *reinterpret_cast<float4*>(sa + lane * CRT) = make_float4(a1v[0], a1v[1], a1v[2], a1v[3]);
         __builtin_amdgcn_wave_barrier();
@@ -101,6 +115,7 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticT
     __shared__ float sd[HID * BT];                       // dz2 as [j][row]
     __shared__ float w2t[HID * (HID + 1)];               // w2t[i][j] = W2[j][i]
     __shared__ float w2n[HID * (HID + 1)];               // w2n[j][i] = W2[j][i]: lane i reads its column along j
+    __shared__ float idt[CRITIC_IDT_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int idx = tid; idx < HID * HID; idx += 64 * CW) {
         const int j = idx / HID, i = idx - j * HID;
@@ -108,6 +123,7 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticT
         w2t[i * (HID + 1) + j] = w;
         w2n[j * (HID + 1) + i] = w;
     }
+    critic_stage_ids(a, idt, tid, 64 * CW);
     __syncthreads();
     const float g = a.layernorm ? a.ln_w[lane] : 1.0f, be = a.layernorm ? a.ln_b[lane] : 0.0f;
     const float b2 = a.fc2_b[lane], w3 = a.fc3_w[lane];
@@ -123,7 +139,7 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticT
 #pragma unroll
         for (int r = 0; r < CRT; ++r) {
             const int rr = min(r0 + r, a.rows - 1);
-            row[r] = critic_ln_relu(critic_z1(a, rr, lane), a.layernorm != 0, a.ln_eps, g, be);
+            row[r] = critic_ln_relu(critic_z1(a, idt, rr, lane), a.layernorm != 0, a.ln_eps, g, be);
             a1v[r] = row[r].a1;
         }
         float* my_a = sa + wave * CRT;                   // this wavefront's four columns of the [i][16] staging
@@ -265,7 +281,7 @@ typedef float cf32x16 __attribute__((ext_vector_type(16)));
 #define CMFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32((a_), (b_), (c_), 0, 0, 0)
 
 // z1 of this lane's row in the accumulator layout: v[u][4q + j] = z1[row][32u + 8q + 4hf + j]
-__device__ __forceinline__ void critic_load_z1(const FlexCriticTailArgs& a, int row, int hf, cf32x16* v) {
+__device__ __forceinline__ void critic_load_z1(const FlexCriticTailArgs& a, const float* idt, int row, int hf, cf32x16* v) {
     const float* p0;
     const float* p1 = nullptr;
     if (a.z1) {
@@ -273,7 +289,7 @@ __device__ __forceinline__ void critic_load_z1(const FlexCriticTailArgs& a, int 
     } else {
         const int b = row / a.n_agents, i = row - b * a.n_agents;
         p0 = a.z_shared + (int64_t)b * HID + 4 * hf;
-        p1 = a.z_id + i * HID + 4 * hf;
+        p1 = idt + i * HID + 4 * hf;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -334,6 +350,7 @@ __global__ __launch_bounds__(64 * CMW, 2) void critic_tail_mfma_kernel(FlexCriti
     __shared__ float w2t[HID * HID];                     // w2t[k][j] = W2[j][k]: A operand of z2 = W2 a1
     __shared__ float w2n[BACKWARD ? HID * HID : 1];      // W2 as stored [j][i]:  A operand of da1 = W2^T dz2
     __shared__ float vec[5][HID];                        // ln_w, ln_b, b2, w3, (unused)
+    __shared__ __attribute__((aligned(16))) float idt[CRITIC_IDT_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rb = lane & 31, hf = lane >> 5;
     for (int idx = tid; idx < HID * HID; idx += 64 * CMW) {
@@ -342,6 +359,7 @@ __global__ __launch_bounds__(64 * CMW, 2) void critic_tail_mfma_kernel(FlexCriti
         w2t[k * HID + j] = w;
         if (BACKWARD) w2n[idx] = w;
     }
+    critic_stage_ids(a, idt, tid, 64 * CMW);
     if (tid < HID) {
         vec[0][tid] = a.layernorm ? a.ln_w[tid] : 1.0f;
         vec[1][tid] = a.layernorm ? a.ln_b[tid] : 0.0f;
@@ -363,7 +381,7 @@ __global__ __launch_bounds__(64 * CMW, 2) void critic_tail_mfma_kernel(FlexCriti
         const int row = min(r0 + rb, a.rows - 1);
         const bool live = r0 + rb < a.rows;
         cf32x16 xh[2], a1[2];
-        critic_load_z1(a, row, hf, xh);
+        critic_load_z1(a, idt, row, hf, xh);
         const float rstd = critic_ln_inplace(xh, ln, a.ln_eps);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -447,6 +465,7 @@ __global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(Fle
     __shared__ float w2n[HID * HID];
     __shared__ float vec[4][HID];
     __shared__ float tr[CPW][2][32 * CTP];               // per wavefront: a1 tile, dz2 tile as [row][unit]
+    __shared__ __attribute__((aligned(16))) float idt[CRITIC_IDT_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rb = lane & 31, hf = lane >> 5;
     for (int idx = tid; idx < HID * HID; idx += 64 * CPW) {
@@ -455,6 +474,7 @@ __global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(Fle
         w2t[k * HID + j] = w;
         w2n[idx] = w;
     }
+    critic_stage_ids(a, idt, tid, 64 * CPW);
     if (tid < HID) {
         vec[0][tid] = a.layernorm ? a.ln_w[tid] : 1.0f;
         vec[1][tid] = a.layernorm ? a.ln_b[tid] : 0.0f;
@@ -493,7 +513,7 @@ __global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(Fle
         const bool live = r0 + rb < a.rows;
         // ---- phase A ------------------------------------------------------------------------------------------
         cf32x16 xh[2], a1[2];
-        critic_load_z1(a, row, hf, xh);
+        critic_load_z1(a, idt, row, hf, xh);
         const float rstd = critic_ln_inplace(xh, ln, a.ln_eps);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -708,6 +728,9 @@ static int critic_check(const FlexCriticTailArgs* a, bool backward) {
     if (backward && a->d_z_shared && (a->z1 || !a->workspace || a->n_agents > FLEXNET_MAX_AGENTS)) return FLEXNET_EINVAL;
     if (a->d_z_id_agent_stride < 0 || a->d_z_id_unit_stride < 0 || ((a->d_z_id_agent_stride == 0) != (a->d_z_id_unit_stride == 0)))
         return FLEXNET_EINVAL;
+    if (a->z_id_agent_stride < 0 || a->z_id_unit_stride < 0 || ((a->z_id_agent_stride == 0) != (a->z_id_unit_stride == 0)))
+        return FLEXNET_EINVAL;
+    if (!a->z1 && a->n_agents > FLEXNET_MAX_AGENTS) return FLEXNET_EINVAL;
     // parameter gradients: all of them, or none (d_fc2_w == NULL: dz1 only)
     if (backward && a->d_fc2_w && (!a->d_fc2_b || !a->d_fc3_w || !a->d_fc3_b || (a->layernorm && (!a->d_ln_w || !a->d_ln_b))))
         return FLEXNET_EINVAL;

@@ -135,33 +135,49 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) csum[i] = 0.0f;
     const bool want_cs = CS && blockIdx.y == 0;
+    // TWO: only the column chunk astride the seam loads from both views; the others load from the one they lie in
+    const bool has1 = !TWO || n0 < p.n, has2 = TWO && n0 + 32 * NT > p.n;
+    if (TWO) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { bv[d][u][j] = 0.0f; bw[d][u][j] = 0.0f; }
+    }
     auto issue = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             wg_load<MT>(ra, offa, av[buf][u]);
-            wg_load<NT>(rb, offb, bv[buf][u]);
-            offa += stepa; offb = (int)((unsigned)offb + (unsigned)stepb);
+            offa += stepa;
             if constexpr (TWO) {
-                wg_load<NT>(rb2, (int)offb2, bw[buf][u]);
+                if (has1) wg_load<NT>(rb, offb, bv[buf][u]);
+                if (has2) wg_load<NT>(rb2, (int)offb2, bw[buf][u]);
+                offb = (int)((unsigned)offb + (unsigned)stepb);
                 offb2 += stepb2;
+            } else {
+                wg_load<NT>(rb, offb, bv[buf][u]);
+                offb += stepb;
             }
         }
     };
     auto multiply = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+            float bsel[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bsel[j] = (TWO && in_b2) ? bw[TWO ? buf : 0][TWO ? u : 0][j] : bv[buf][u][j];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    float bj = bv[buf][u][j];
-                    if constexpr (TWO) bj = in_b2 ? bw[buf][u][j] : bj;
 #ifdef WG_PROBE_NOMUL
-                    acc[i][j][0] += av[buf][u][i] * bj;
+                    acc[i][j][0] += av[buf][u][i] * bsel[j];
 #else
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][i], bj, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][i], bsel[j], acc[i][j], 0, 0, 0);
 #endif
                 }
+        }
         if (CS) {                    // (every column chunk adds; only chunk 0 stores)
 #pragma unroll
             for (int u = 0; u < U; ++u)

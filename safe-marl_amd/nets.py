@@ -646,6 +646,16 @@ def _critic_args(z1, ln_w, ln_b, w2, b2, w3, b3, eps):
 _CRITIC_WS = {}
 
 
+def _set_critic_ids(args, W, col0, n, dense=None):
+    """The composed input's id-column table: ``dense`` [n, 64] if given, else columns col0 .. col0 + n - 1 of fc1.weight
+    read where they are (the kernels stage the table in LDS through the two strides: no transposed copy per call)."""
+    if dense is not None:
+        args.z_id = dense.data_ptr()
+    else:
+        args.z_id = W[:, col0:col0 + n].data_ptr()
+        args.z_id_agent_stride, args.z_id_unit_stride = 1, W.stride(0)
+
+
 def _critic_workspace(device):
     """Per-device scratch for the backward kernel's per-block partial sums (18 MB, allocated once)."""
     from . import _lib
@@ -772,12 +782,13 @@ class _CriticReplayedFn(th.autograd.Function):
         shared.addmm_(act2d, W[:, no + n_agents:no + n_agents + na_].t())
         # twin (matd3.py:64-67): the second head is the same network with the trailing 0/1 input flag set — fc1's last
         # column joins every agent's id column
-        id_cols = (W[:, no:no + n_agents] + W[:, -1:]).t().contiguous() if twin else W[:, no:no + n_agents].t().contiguous()
+        id_cols = (W[:, no:no + n_agents] + W[:, -1:]).t().contiguous() if twin else None
         ctx.twin = bool(twin)
         rows = shared.shape[0] * n_agents
         q = th.empty(rows, 1, dtype=th.float32, device=shared.device)
         args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, eps)
-        args.rows, args.z1, args.z_shared, args.z_id, args.n_agents = rows, None, shared.data_ptr(), id_cols.data_ptr(), n_agents
+        args.rows, args.z1, args.z_shared, args.n_agents = rows, None, shared.data_ptr(), n_agents
+        _set_critic_ids(args, W, no, n_agents, dense=id_cols)
         args.q = q.data_ptr()
         _lib.check(lib.flexnet_critic_tail_forward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
                    "flexnet_critic_tail_forward")
@@ -790,7 +801,7 @@ class _CriticReplayedFn(th.autograd.Function):
         import ctypes as C
         from . import _lib
         lib = _lib.load()
-        obs2d, act2d, shared, id_cols, W, ln_w, ln_b, w2, b2, w3, b3 = ctx.saved_tensors
+        obs2d, act2d, shared, id_cols, W, ln_w, ln_b, w2, b2, w3, b3 = ctx.saved_tensors      # (id_cols: twin only)
         n = ctx.n_agents
         no, na_ = obs2d.shape[1], act2d.shape[1]
         rows = shared.shape[0] * n
@@ -801,7 +812,8 @@ class _CriticReplayedFn(th.autograd.Function):
         d_w2, d_b2, d_w3 = grads[:4096].view(64, 64), grads[4096:4160], grads[4160:4224].view(1, 64)
         d_g, d_b, d_b3 = grads[4224:4288], grads[4288:4352], grads[4352:4353]
         args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, ctx.eps)
-        args.rows, args.z1, args.z_shared, args.z_id, args.n_agents = rows, None, shared.data_ptr(), id_cols.data_ptr(), n
+        args.rows, args.z1, args.z_shared, args.n_agents = rows, None, shared.data_ptr(), n
+        _set_critic_ids(args, W, no, n, dense=id_cols)
         args.dq, args.dz1 = dq.data_ptr(), dz1.data_ptr()
         args.d_fc2_w, args.d_fc2_b, args.d_fc3_w, args.d_fc3_b = d_w2.data_ptr(), d_b2.data_ptr(), d_w3.data_ptr(), d_b3.data_ptr()
         if ln_w is not None:
@@ -876,16 +888,16 @@ class _CriticPolicyFn(th.autograd.Function):
         act2d = act.reshape(b, n * na_)
         shared = th.addmm(bias, obs2d, W[:, :no].t())
         shared.addmm_(act2d, W[:, no + n:no + n + n * na_].t())
-        id_cols = W[:, no:no + n].t().contiguous()
         rows = b * n
         q = th.empty(rows, 1, dtype=th.float32, device=shared.device)
         args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, eps)
-        args.rows, args.z1, args.z_shared, args.z_id, args.n_agents = rows, None, shared.data_ptr(), id_cols.data_ptr(), n
+        args.rows, args.z1, args.z_shared, args.n_agents = rows, None, shared.data_ptr(), n
+        _set_critic_ids(args, W, no, n)
         args.q = q.data_ptr()
         _lib.check(lib.flexnet_critic_tail_forward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
                    "flexnet_critic_tail_forward")
         ctx.eps, ctx.dims = eps, (b, n, na_, no)
-        ctx.save_for_backward(shared, id_cols, W, ln_w, ln_b, w2, b2, w3, b3)
+        ctx.save_for_backward(shared, W, ln_w, ln_b, w2, b2, w3, b3)
         return q
 
     @staticmethod
@@ -893,13 +905,14 @@ class _CriticPolicyFn(th.autograd.Function):
         import ctypes as C
         from . import _lib
         lib = _lib.load()
-        shared, id_cols, W, ln_w, ln_b, w2, b2, w3, b3 = ctx.saved_tensors
+        shared, W, ln_w, ln_b, w2, b2, w3, b3 = ctx.saved_tensors
         b, n, na_, no = ctx.dims
         rows = b * n
         dq = dq.contiguous()
         dz1 = th.empty(rows, 64, dtype=th.float32, device=shared.device)
         args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, ctx.eps)
-        args.rows, args.z1, args.z_shared, args.z_id, args.n_agents = rows, None, shared.data_ptr(), id_cols.data_ptr(), n
+        args.rows, args.z1, args.z_shared, args.n_agents = rows, None, shared.data_ptr(), n
+        _set_critic_ids(args, W, no, n)
         args.dq, args.dz1 = dq.data_ptr(), dz1.data_ptr()
         _lib.check(lib.flexnet_critic_tail_backward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
                    "flexnet_critic_tail_backward")

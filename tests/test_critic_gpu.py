@@ -194,7 +194,8 @@ def test_whole_critic_on_replayed_actions_matches_the_layerwise_path():
 def test_stored_gradients_and_strided_id_sums(samples, n):
     """include/flexnet.h: overwrite_grads stores the six tail gradients over whatever the buffers held (NaN here) — the
     same numbers the adding form leaves in zeroed buffers — and d_z_id written through (agent, unit) strides lands in
-    the id columns of a wider fc1 gradient, equal to the dense [n, 64] form."""
+    the id columns of a wider fc1 gradient, equal to the dense [n, 64] form; the input table read through strides from
+    the columns of a wider matrix (fc1.weight's id columns in place) gives the same bits as the dense table."""
     import ctypes as C
     from safe_marl_amd import _lib
     from safe_marl_amd.nets import _critic_args, _critic_workspace
@@ -205,6 +206,8 @@ def test_stored_gradients_and_strided_id_sums(samples, n):
     ids = torch.randn(n, 64, device="cuda", generator=g)
     dq = torch.randn(samples * n, device="cuda", generator=g)
     ws = _critic_workspace(shared.device)
+    wide_in = torch.full((64, 3 + n + 2), float("nan"), device="cuda")
+    wide_in[:, 3:3 + n] = ids.t()
 
     def run(overwrite, strided):
         fill = float("nan") if overwrite else 0.0
@@ -221,17 +224,19 @@ def test_stored_gradients_and_strided_id_sums(samples, n):
         a.d_ln_w, a.d_ln_b, a.d_fc3_b = grads[4224:].data_ptr(), grads[4288:].data_ptr(), grads[4352:].data_ptr()
         a.workspace, a.workspace_floats, a.overwrite_grads = ws.data_ptr(), ws.numel(), int(overwrite)
         a.d_z_shared = d_shared.data_ptr()
-        if strided:
+        if strided:                                            # input table too: read from the columns of a wider matrix
+            a.z_id, a.z_id_agent_stride, a.z_id_unit_stride = wide_in[:, 3:].data_ptr(), 1, wide_in.stride(0)
             a.d_z_id, a.d_z_id_agent_stride, a.d_z_id_unit_stride = wide[:, 7:].data_ptr(), 1, wide.stride(0)
         else:
             a.d_z_id = d_id.data_ptr()
         rc = lib.flexnet_critic_tail_backward(C.byref(a), None)
         torch.cuda.synchronize()
-        return rc, grads, (wide if strided else d_id), a
+        return rc, grads, (wide if strided else d_id), a, dz1, d_shared
 
-    rc0, g0, id0, _ = run(False, False)
-    rc1, g1, wide, a = run(True, True)
+    rc0, g0, id0, _, dz0, ds0 = run(False, False)
+    rc1, g1, wide, a, dz1_, ds1 = run(True, True)
     assert rc0 == 0 and rc1 == 0
+    assert torch.equal(dz0, dz1_) and torch.equal(ds0, ds1)
     assert torch.isfinite(g1).all() and torch.equal(g0, g1)
     assert torch.equal(wide[:, 7:7 + n], id0.t()) and torch.isnan(wide[:, :7]).all() and torch.isnan(wide[:, 7 + n:]).all()
     a.d_z_id_unit_stride = 0                                   # one stride without the other
