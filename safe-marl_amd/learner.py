@@ -52,6 +52,7 @@ class RolloutGraph:
         self._fail_sum = th.zeros((), dtype=th.float64, device=dev)
         self.std = float(model.args.fixed_policy_std)
         self.graph = None
+        self.bursts = {}                                       # k -> graph of k bodies (run())
         self._torch_noise = False
         self.rng_state = th.zeros(2, dtype=th.int64, device=dev)           # [seed, step] of the actor kernel's noise stream
         self.rng_state[0] = int(th.randint(0, 2 ** 62, (1,)).item())
@@ -244,6 +245,37 @@ class RolloutGraph:
             self.body()
         return self.buf.stepped()
 
+    BURSTS = (16, 8, 4, 2)
+
+    def run(self, m):
+        """``m`` consecutive vector steps with nothing for the host to do in between: graphs of 16 / 8 / 4 / 2 bodies
+        (captured on first use, sharing the one-step graph's memory pool) and single steps for the rest.  Every body
+        finds its slabs through the device-side cursors, so k bodies in one graph are k replays of the one-step graph
+        minus k - 1 graph launches (~8 us of idle GPU each at 4096 envs).  Returns the slabs completed, in order."""
+        done = []
+        while m > 0:
+            k = next((b for b in self.BURSTS if b <= m), 1) if self.graph is not None else 1
+            if k == 1:
+                done.append(self.step())
+                m -= 1
+                continue
+            g = self.bursts.get(k)
+            if g is None:
+                # recording launches nothing: the environment, the ring and the cursors are untouched (the bodies were
+                # warmed up when the one-step graph was captured); only the env's host-side call counter would move
+                calls = getattr(self.env, "calls", None)
+                g = th.cuda.CUDAGraph()
+                with th.cuda.graph(g, pool=self.graph.pool(), capture_error_mode=CAPTURE_MODE):
+                    for _ in range(k):
+                        self.body()
+                if calls is not None:
+                    self.env.calls = calls
+                self.bursts[k] = g
+            g.replay()
+            done.extend(self.buf.stepped() for _ in range(k))
+            m -= k
+        return done
+
     def capture(self):
         """Warm-up + capture.  The warm-up steps are real steps of the environment; the ring cursor and the statistics
         they moved are put back afterwards (the slabs they wrote are overwritten by the steps that follow)."""
@@ -265,6 +297,7 @@ class RolloutGraph:
         with th.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
             self.body()
         self.graph = g
+        self.bursts = {}
         self.buf.cursor.copy_(cursor0)
 
     def start_episode(self, first_obs=None):
@@ -563,10 +596,19 @@ class Model(nn.Module):
             rg.start_episode(env.reset())
         small = buf.small_ring
         last_col = self.n_ * self.act_dim + self.n_ + 1
-        for t in range(horizon):
-            slab = rg.step()
-            if t == horizon - 1:                                              # model.py:229: last_step on the final step
-                small[slab, :, last_col] = 1.0
+        # model.py:215-262 steps, then asks transition_update whether an update is due — which it is only when the step
+        # counter reaches a multiple of behaviour_update_freq / target_update_freq (model.py:43-50).  The steps up to the
+        # next such multiple (or the end of the episode) need nothing from the host and go out as bursts.
+        freqs = [int(self.args.behaviour_update_freq)] + ([int(self.args.target_update_freq)] if self.args.target else [])
+        t = 0
+        while t < horizon:
+            s0 = trainer.steps
+            m = min([horizon - t] + [(-s0) % f + 1 for f in freqs if f > 0])
+            slabs = rg.run(m)
+            t += m
+            if t == horizon:                                                  # model.py:229: last_step on the final step
+                small[slabs[-1], :, last_col] = 1.0
+            trainer.steps = s0 + m - 1
             self.transition_update(trainer, None, stat)
             trainer.steps += 1
         trainer.episodes += 1

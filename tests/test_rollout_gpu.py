@@ -365,3 +365,83 @@ def test_unbounded_actions_take_the_general_body():
         want = means + Normal(torch.zeros_like(means), torch.ones_like(means)).rsample()     # util.py:66-74, fixed std of 1
     got = rg.last_transition().action
     assert (got - want).abs().max().item() < 1e-5 and got.abs().max().item() > 1.0          # really unbounded
+
+
+@pytest.mark.parametrize("fast", [True, False])
+def test_bursts_of_steps_equal_single_steps_bit_for_bit(fast):
+    """RolloutGraph.run(m): graphs of 16 / 8 / 4 / 2 bodies and single replays against m single-step replays from the
+    same state — 31 + 7 + 16 steps through the wrap of an 8-slab ring: every slab of the ring, the hand-over tensors,
+    the statistics, the cursors and the noise position identical; recording a burst moves nothing."""
+    import numpy as np
+    a, b = _setup(64)
+    rng = np.random.default_rng(3)
+    n, na = 64, 5
+    spec = dict(day=rng.integers(0, 20, n).astype(np.int32), hour=rng.integers(0, 20, n).astype(np.int32),
+                interval=rng.integers(0, 4, n).astype(np.int32), e0=0.0125 + 0.001 * rng.random((n, na)),
+                a0=0.5 + 0.5 * rng.random((n, 4 * na)))
+    for rg in (a, b):
+        rg.fast = fast
+        rg.start_episode(rg.env.reset())
+        rg.capture()
+        rg.start_episode(rg.env.reset(spec=spec))
+        rg.rng_state.copy_(torch.tensor([99, 7], dtype=torch.int64))
+        torch.manual_seed(5)                                   # (the general body draws its noise with torch.randn)
+    calls = a.env.calls
+    for m in (31, 7, 16):
+        if not fast:
+            torch.manual_seed(m)
+        slabs_a = a.run(m)
+        if not fast:
+            torch.manual_seed(m)
+        slabs_b = [b.step() for _ in range(m)]
+        torch.cuda.synchronize()
+        assert slabs_a == slabs_b and a.buf.k == b.buf.k
+        for name in ("obs", "hid", "info_sum", "rew_sum", "fail_sum", "rng_state"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (m, name)
+        assert torch.equal(a.buf.cursor, b.buf.cursor)
+        for ring in ("obs_ring", "hid_ring", "small_ring"):
+            assert torch.equal(getattr(a.buf, ring), getattr(b.buf, ring)), (m, ring)
+    assert sorted(a.bursts) == [2, 4, 8, 16] and not b.bursts
+    assert a.env.calls == calls                                # replays never go through env.step; recording is undone
+
+
+def test_training_loop_schedule_is_unchanged_by_bursts():
+    """train_process with bursts against the step-by-step loop (BURSTS emptied): the same update events at the same
+    steps — identical parameters, optimiser state and replay ring after two episodes with updates every 7 steps and
+    target updates every 11."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.learner import MADDPG, RolloutGraph
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.trainer import PGTrainer
+    from safe_marl_amd.util import convert
+    net = create_network()
+    series = make_synthetic_series(net, n_days=30)
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="maddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4, behaviour_update_freq=7,
+               target_update_freq=11, replay_warmup=0, batch_size=4, value_update_epochs=2, policy_update_epochs=1)
+    res = []
+    saved = RolloutGraph.BURSTS
+    try:
+        for bursts in (saved, ()):
+            RolloutGraph.BURSTS = bursts
+            torch.manual_seed(3)
+            np.random.seed(3)                                  # replay windows are drawn with numpy (utils/replay_buffer.py:17-21)
+            env = VecFlexProvisionEnv({}, 256, net=net, series=series, seed=9, warm_start=True)
+            tr = PGTrainer(convert(alg), MADDPG, env, None, replay_capacity=256 * 96 * 2)
+            for _ in range(2):
+                tr.behaviour_net.train_process({}, tr)
+            torch.cuda.synchronize()
+            rg = tr.behaviour_net._rollout_graph
+            assert bool(rg.bursts) == bool(bursts)
+            res.append((tr.steps, [p.detach().clone() for p in tr.behaviour_net.parameters()],
+                        [p.detach().clone() for p in tr.behaviour_net.target_net.parameters()],
+                        tr.replay_buffer.small_ring.clone(), tr.replay_buffer.obs_ring.clone()))
+    finally:
+        RolloutGraph.BURSTS = saved
+    assert res[0][0] == res[1][0] == 190
+    for x, y in zip(res[0][1] + res[0][2] + list(res[0][3:]), res[1][1] + res[1][2] + list(res[1][3:])):
+        assert torch.equal(x, y)
