@@ -282,7 +282,9 @@ def kernel_shares_child():
     if total <= 0:
         raise SystemExit("no device activity recorded")
     top = sorted(agg.items(), key=lambda kv: -kv[1][0])[:16]
-    print(json.dumps({"episode": "MADDPG 5 agents x 4096 envs, 95 vector steps incl. one update event (11 sub-updates)",
+    subs = sum(v[1] for k, v in agg.items() if k.startswith("gather_rows_kernel"))
+    print(json.dumps({"episode": f"MADDPG 5 agents x 4096 envs, one episode of 95 vector steps incl. {subs} sub-updates "
+                                 f"(an update event every 60 steps: 10 value + 1 policy)",
                       "gpu_ms_total": total / 1e3,
                       "top": [{"kernel": k[:96], "calls": v[1], "ms": v[0] / 1e3, "share": v[0] / total} for k, v in top]}),
           flush=True)
