@@ -265,9 +265,18 @@ typedef struct {
     int64_t workspace_floats;  /* >= FLEXNET_TD_WS_FLOATS */
 } FlexTdLossArgs;
 
-#define FLEXNET_TD_WS_FLOATS (2 * (64 * 2 * 8 + 64))
+#define FLEXNET_TD_WS_FLOATS (2 * (64 * 2 * 8 + 1024))
 
 int flexnet_td_loss(const FlexTdLossArgs* args, void* stream);
+
+/* The value loss AND the critic's backward in one pass (maddpg.py:100-123 over mlp_critic.py:25-33): the matrix-core
+ * backward kernel recomputes the tail's forward anyway, so it forms q, the TD error, dLoss/dq and the loss partial sums
+ * itself — no forward launch of the tail, no q / dq round trip.  `critic`: as for flexnet_critic_tail_backward, `dq`
+ * unused; `td`: as for flexnet_td_loss with rows * n_agents == critic->rows; td->q and td->dq are optional OUTPUTS here
+ * ([rows * n_agents] each, NULL = not stored).  Covers what the matrix-core backward covers (variant 0, parameter
+ * gradients through the fixed-order workspace path, critic->rows >= 65 536); otherwise FLEXNET_EUNSUPPORTED and the caller
+ * makes the two separate calls around a forward. */
+int flexnet_critic_td_backward(const FlexCriticTailArgs* critic, const FlexTdLossArgs* td, void* stream);
 
 /* out[0] = scale * sum(x[0 .. n)) in a FIXED order (fp64 partial sums of 64 blocks, one-wavefront finish): the scalar
  * means the losses report — policy_loss = -Q(s, pi(s)).mean() (madrl/models/maddpg.py:107), the entropy of

@@ -70,7 +70,7 @@ SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
-    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss",
+    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_critic_td_backward",
     "flexnet_scaled_sum", "flexnet_gather_rows", "flexnet_gru_backward",
 )
 
@@ -147,7 +147,7 @@ class FlexTdLossArgs(C.Structure):
                [("workspace_floats", C.c_int64)]
 
 
-FLEXNET_TD_WS_FLOATS = 2 * (64 * 2 * 8 + 64)
+FLEXNET_TD_WS_FLOATS = 2 * (64 * 2 * 8 + 1024)
 
 
 class FlexSumArgs(C.Structure):
@@ -240,6 +240,8 @@ def load():
     lib.flexenv_set_obs_ring.restype = C.c_int
     lib.flexenv_set_replay_sink.argtypes = [vp, C.POINTER(FlexReplaySink)]
     lib.flexenv_set_replay_sink.restype = C.c_int
+    lib.flexnet_critic_td_backward.argtypes = [C.POINTER(FlexCriticTailArgs), C.POINTER(FlexTdLossArgs), vp]
+    lib.flexnet_critic_td_backward.restype = C.c_int
     lib.flexnet_wgrad.argtypes = [C.POINTER(FlexWgradArgs), vp]
     lib.flexnet_wgrad.restype = C.c_int
     lib.flexnet_clip_rmsprop.argtypes = [C.POINTER(FlexClipRmspropArgs), vp]

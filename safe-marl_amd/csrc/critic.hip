@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include "flexnet.h"
 #include "flex_reduce.h"
+#include "flex_td.h"
 #include "flex_launch.h"
 
 #define HID FLEXNET_HID
@@ -460,10 +461,17 @@ __global__ __launch_bounds__(64 * CMW, 2) void critic_tail_mfma_kernel(FlexCriti
 // ---------------------------------------------------------------------------------------------------------------
 #define CPW 4                                            // wavefronts per block
 #define CTP 68                                           // transpose pitch (floats): float4-aligned rows
-__global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(FlexCriticTailArgs a) {
+// TD: the kernel forms dLoss/dq itself (flexnet_critic_td_backward) — the forward recompute already holds fc2's output, so
+// q = fc3(h2) is one more in-lane dot product; with the reward column's batch statistics (csrc/tdloss.hip's statistics pass),
+// the bootstrap value and the done flag of the row: dq = -2 (BatchNorm(r) + gamma (1 - done) q' - q) / rows, maddpg.py:110-123.
+// No forward launch of the tail, no q / dq round trip, no td_apply launch.
+template <bool TD>
+__global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(FlexCriticTailArgs a, FlexTdLossArgs td) {
     __shared__ float w2t[HID * HID];
     __shared__ float w2n[HID * HID];
     __shared__ float vec[4][HID];
+    __shared__ float td_m[TD_NA], td_sc[TD_NA], td_sh[TD_NA];
+    __shared__ double td_sqw[CPW];
     __shared__ float tr[CPW][2][32 * CTP];               // per wavefront: a1 tile, dz2 tile as [row][unit]
     __shared__ __attribute__((aligned(16))) float idt[CRITIC_IDT_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -475,6 +483,7 @@ __global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(Fle
         w2n[idx] = w;
     }
     critic_stage_ids(a, idt, tid, 64 * CPW);
+    if (TD && tid < TD_NA) td_column_affine(td, tid, td_m[tid], td_sc[tid], td_sh[tid]);
     if (tid < HID) {
         vec[0][tid] = a.layernorm ? a.ln_w[tid] : 1.0f;
         vec[1][tid] = a.layernorm ? a.ln_b[tid] : 0.0f;
@@ -505,6 +514,8 @@ __global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(Fle
             dW[u][0][i] = 0.0f; dW[u][1][i] = 0.0f; sg[u][i] = 0.0f; sb[u][i] = 0.0f; sw3[u][i] = 0.0f;
         }
     float cs2[2] = {0.0f, 0.0f}, sb3 = 0.0f;
+    double td_sq = 0.0;                                  // TD: this lane's sum of squared TD errors
+    const float td_b3 = TD ? a.fc3_b[0] : 0.0f, td_inv = TD ? 1.0f / (float)a.rows : 0.0f;
 
     const int n_tiles = (a.rows + 31) / 32;
     for (int tile = wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * CPW) {
@@ -528,9 +539,17 @@ __global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(Fle
             for (int q = 0; q < 4; ++q)
                 *reinterpret_cast<float4*>(t1_w + 32 * u + 8 * q) =
                     make_float4(a1[u][4 * q], a1[u][4 * q + 1], a1[u][4 * q + 2], a1[u][4 * q + 3]);
-        const float dq = live ? a.dq[r0 + rb] : 0.0f;       // spare rows of the last tile contribute nothing
-        if (hf == 0) sb3 += dq;
+        float dq = 0.0f, td_r = 0.0f, td_nq = 0.0f, td_dn = 0.0f;
+        int td_j = 0;
+        if constexpr (TD) {                                  // the row's TD inputs, in flight under fc2
+            const int tb = row / td.n_agents;
+            td_j = row - tb * td.n_agents;
+            td_r = td.reward[row]; td_nq = td.next_q[row]; td_dn = td.done[tb];
+        } else {
+            dq = live ? a.dq[r0 + rb] : 0.0f;                // spare rows of the last tile contribute nothing
+        }
         cf32x16 z2[2];
+        float qp = 0.0f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             z2[t] = critic_mfma_tile(w2t_l, t, a1);
@@ -538,10 +557,31 @@ __global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(Fle
             for (int i = 0; i < 16; ++i) {
                 const int cu = 32 * t + CDU0(i);
                 const float zz = z2[t][i] + b2_l[cu];
-                sw3[t][i] = fmaf(dq, fmaxf(zz, 0.0f), sw3[t][i]);
-                z2[t][i] = zz > 0.0f ? dq * w3_l[cu] : 0.0f;                                           // dz2
+                z2[t][i] = zz;
+                if constexpr (TD) qp = fmaf(w3_l[cu], fmaxf(zz, 0.0f), qp);
             }
         }
+        if constexpr (TD) {
+            const float q = qp + __shfl_xor(qp, 32, 64) + td_b3;
+            const float rn = (td_r - td_m[td_j]) * td_sc[td_j] + td_sh[td_j];
+            const float delta = rn + td.gamma * (1.0f - td_dn) * td_nq - q;
+            dq = live ? -2.0f * delta * td_inv : 0.0f;
+            if (live && hf == 0) {
+                td_sq += (double)delta * (double)delta;
+                if (td.q) const_cast<float*>(td.q)[r0 + rb] = q;          // (outputs here: the caller asked to see them)
+                if (td.dq) td.dq[r0 + rb] = dq;
+            }
+        }
+        if (hf == 0) sb3 += dq;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int cu = 32 * t + CDU0(i);
+                const float zz = z2[t][i];
+                sw3[t][i] = fmaf(dq, fmaxf(zz, 0.0f), sw3[t][i]);
+                z2[t][i] = zz > 0.0f ? dq * w3_l[cu] : 0.0f;                                               // dz2
+            }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -601,7 +641,21 @@ __global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(Fle
     }
 
     // ---- the wavefront's sums -> the block's partial row [dW2 | db2 | dw3 | dg | db | db3] ---------------------------
+    if constexpr (TD) {                                                        // squared TD errors: lanes, then wavefronts in order
+        double v = td_sq;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) td_sqw[wave] = v;
+    }
     __syncthreads();
+    if constexpr (TD) {
+        if (tid == 0) {
+            double v = td_sqw[0];
+#pragma unroll
+            for (int w = 1; w < CPW; ++w) v += td_sqw[w];
+            reinterpret_cast<double*>(td.workspace)[TD_WS_SQ + blockIdx.x] = v;
+        }
+    }
     float* fold = &tr[0][0][0];                                                // CRITIC_WS_PITCH floats, all tiles are done
     for (int w = 0; w < CPW; ++w) {
         if (wave == w) {
@@ -717,13 +771,13 @@ static int critic_dz_fold(const FlexCriticTailArgs& k, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 
-static int critic_check(const FlexCriticTailArgs* a, bool backward) {
+static int critic_check(const FlexCriticTailArgs* a, bool backward, bool need_dq = true) {
     if (!a || a->rows < 0) return FLEXNET_EINVAL;
     if (!a->fc2_w || !a->fc2_b || !a->fc3_w || !a->fc3_b || (a->layernorm && (!a->ln_w || !a->ln_b)))
         return FLEXNET_EINVAL;
     if (!a->z1 && (!a->z_shared || !a->z_id || a->n_agents < 1 || a->rows % a->n_agents != 0)) return FLEXNET_EINVAL;
     if (!backward && !a->q) return FLEXNET_EINVAL;
-    if (backward && (!a->dq || !a->dz1)) return FLEXNET_EINVAL;
+    if (backward && ((need_dq && !a->dq) || !a->dz1)) return FLEXNET_EINVAL;
     if (backward && ((a->d_z_shared != nullptr) != (a->d_z_id != nullptr))) return FLEXNET_EINVAL;
     if (backward && a->d_z_shared && (a->z1 || !a->workspace || a->n_agents > FLEXNET_MAX_AGENTS)) return FLEXNET_EINVAL;
     if (a->d_z_id_agent_stride < 0 || a->d_z_id_unit_stride < 0 || ((a->d_z_id_agent_stride == 0) != (a->d_z_id_unit_stride == 0)))
@@ -771,6 +825,30 @@ extern "C" int flexnet_critic_tail_backward(const FlexCriticTailArgs* a, void* s
     return critic_dz_fold(*a, (hipStream_t)stream);        // after the main launches: it reuses their workspace
 }
 
+// The value loss and the critic's backward in one pass (maddpg.py:100-123 + mlp_critic.py:25-33): reward statistics, then
+// the matrix-core backward forming q, the TD error, dLoss/dq and the loss partial sums itself, the fixed-order second
+// stage, the loss / running-statistics finish, and (composed input) dz1 folded onto its sources.
+extern "C" int flexnet_critic_td_backward(const FlexCriticTailArgs* a, const FlexTdLossArgs* t, void* stream) {
+    const int rc = critic_check(a, true, false);
+    if (rc != FLEXNET_OK) return rc;
+    if (!t || t->rows < 1 || t->n_agents < 1 || !t->reward || !t->done || !t->next_q || !t->loss || !t->workspace ||
+        t->workspace_floats < FLEXNET_TD_WS_FLOATS || (reinterpret_cast<uintptr_t>(t->workspace) & 7) != 0)
+        return FLEXNET_EINVAL;
+    if ((int64_t)t->rows * t->n_agents != a->rows) return FLEXNET_EINVAL;
+    if (t->n_agents > TD_NA) return FLEXNET_EUNSUPPORTED;
+    const bool two_stage = a->workspace && a->workspace_floats >= FLEXNET_CRITIC_WS_FLOATS;
+    if (!a->d_fc2_w || !two_stage || a->variant != 0 || a->rows < CRITIC_MFMA_MIN_ROWS) return FLEXNET_EUNSUPPORTED;
+    const int nb = critic_mfma_grid(a->rows);
+    if (nb < 1 || nb > 1024 || nb > TD_SQ_MAX) return FLEXNET_EHIP;
+    hipStream_t s = (hipStream_t)stream;
+    if (t->normalise) flex_td_launch_stats(*t, s);
+    hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<true>, dim3(nb), dim3(64 * CPW), 0, s, *a, *t);
+    hipLaunchKernelGGL(critic_reduce_kernel, dim3((HID * HID + 4 * HID + 1 + 63) / 64), dim3(64 * RED_G), 0, s, *a, nb);
+    flex_td_launch_finish(*t, nb, s);
+    if (hipGetLastError() != hipSuccess) return FLEXNET_EHIP;
+    return a->d_z_shared ? critic_dz_fold(*a, s) : FLEXNET_OK;
+}
+
 static int critic_tail_backward_main(const FlexCriticTailArgs* a, void* stream) {
     FlexCriticTailArgs k = *a;
     if (!k.d_fc2_w && k.variant == 0 && k.rows >= CRITIC_MFMA_MIN_ROWS) {
@@ -790,7 +868,7 @@ static int critic_tail_backward_main(const FlexCriticTailArgs* a, void* stream) 
     if (two_stage && k.variant == 0 && k.rows >= CRITIC_MFMA_MIN_ROWS) {
         const int nb = critic_mfma_grid(k.rows);
         if (nb < 1 || nb > 1024) return FLEXNET_EHIP;
-        hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel, dim3(nb), dim3(64 * CPW), 0, (hipStream_t)stream, k);
+        hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<false>, dim3(nb), dim3(64 * CPW), 0, (hipStream_t)stream, k, FlexTdLossArgs{});
         hipLaunchKernelGGL(critic_reduce_kernel, dim3((HID * HID + 4 * HID + 1 + 63) / 64), dim3(64 * RED_G), 0, (hipStream_t)stream, k, nb);
         return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
     }

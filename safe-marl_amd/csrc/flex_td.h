@@ -1,0 +1,45 @@
+// flex_td.h — what csrc/tdloss.hip (flexnet_td_loss) and the critic backward that forms the TD error itself
+// (csrc/critic.hip, flexnet_critic_td_backward) share: the workspace layout of the value loss and its launch helpers.
+#ifndef FLEX_TD_H
+#define FLEX_TD_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "flexnet.h"
+
+#define TD_THREADS 256
+#define TD_BLOCKS 64
+#define TD_NA FLEXNET_MAX_AGENTS
+#define TD_SQ_MAX 1024                // per-block sums of squared TD errors the finish kernel may be asked to add up
+
+// workspace (doubles): [TD_BLOCKS][2 TD_NA] column sums and sums of squares of the reward | [<= TD_SQ_MAX] sums of squared TD errors
+#define TD_WS_SQ (TD_BLOCKS * 2 * TD_NA)
+
+// batch mean and biased variance of reward column j from the statistics pass's per-block partial sums (fixed order)
+__device__ __forceinline__ void td_column_stats(const FlexTdLossArgs& a, int j, double& mean, double& var) {
+    const double* ws = reinterpret_cast<const double*>(a.workspace);
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < TD_BLOCKS; ++b) { s += ws[b * 2 * TD_NA + j]; ss += ws[b * 2 * TD_NA + TD_NA + j]; }
+    mean = s / (double)a.rows;
+    var = ss / (double)a.rows - mean * mean;                     // biased (what the normalisation uses)
+    if (var < 0.0) var = 0.0;
+}
+
+// reward normalisation of column j as (r - mean) * scale + shift (nn.BatchNorm1d in training mode), or the identity
+__device__ __forceinline__ void td_column_affine(const FlexTdLossArgs& a, int j, float& m, float& sc, float& sh) {
+    m = 0.0f; sc = 1.0f; sh = 0.0f;
+    if (a.normalise && j < a.n_agents) {
+        double mean, var;
+        td_column_stats(a, j, mean, var);
+        const float w = a.bn_weight ? a.bn_weight[j] : 1.0f;
+        m = (float)mean;
+        sc = (float)(1.0 / sqrt(var + (double)a.bn_eps)) * w;
+        sh = a.bn_bias ? a.bn_bias[j] : 0.0f;
+    }
+}
+
+// csrc/tdloss.hip: the statistics pass (per-block column sums of the reward) and the one-wavefront finish (loss from
+// `sq_blocks` partial sums of squared errors; running statistics moved as nn.BatchNorm1d moves them)
+void flex_td_launch_stats(const FlexTdLossArgs& a, hipStream_t s);
+void flex_td_launch_finish(const FlexTdLossArgs& a, int sq_blocks, hipStream_t s);
+
+#endif

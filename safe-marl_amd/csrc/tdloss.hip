@@ -13,13 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "flexnet.h"
-
-#define TD_THREADS 256
-#define TD_BLOCKS 64
-#define TD_NA FLEXNET_MAX_AGENTS
-
-// workspace (doubles): [TD_BLOCKS][2 TD_NA] column sums and sums of squares | [TD_BLOCKS] sums of squared TD errors
-#define TD_WS_SQ (TD_BLOCKS * 2 * TD_NA)
+#include "flex_td.h"
 
 __global__ __launch_bounds__(TD_THREADS) void td_stats_kernel(FlexTdLossArgs a) {
     const int tid = threadIdx.x, n = a.n_agents;
@@ -51,29 +45,13 @@ __global__ __launch_bounds__(TD_THREADS) void td_stats_kernel(FlexTdLossArgs a) 
     }
 }
 
-__device__ __forceinline__ void td_column_stats(const FlexTdLossArgs& a, int j, double& mean, double& var) {
-    const double* ws = reinterpret_cast<const double*>(a.workspace);
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < TD_BLOCKS; ++b) { s += ws[b * 2 * TD_NA + j]; ss += ws[b * 2 * TD_NA + TD_NA + j]; }
-    mean = s / (double)a.rows;
-    var = ss / (double)a.rows - mean * mean;                     // biased (what the normalisation uses)
-    if (var < 0.0) var = 0.0;
-}
-
 __global__ __launch_bounds__(TD_THREADS) void td_apply_kernel(FlexTdLossArgs a) {
     __shared__ float mean_s[TD_NA], scale_s[TD_NA], shift_s[TD_NA];
     __shared__ double red[TD_THREADS];
     const int tid = threadIdx.x, n = a.n_agents;
     if (tid < TD_NA) {
-        float m = 0.0f, sc = 1.0f, sh = 0.0f;
-        if (a.normalise && tid < n) {
-            double mean, var;
-            td_column_stats(a, tid, mean, var);
-            const float w = a.bn_weight ? a.bn_weight[tid] : 1.0f;
-            m = (float)mean;
-            sc = (float)(1.0 / sqrt(var + (double)a.bn_eps)) * w;
-            sh = a.bn_bias ? a.bn_bias[tid] : 0.0f;
-        }
+        float m, sc, sh;
+        td_column_affine(a, tid, m, sc, sh);
         mean_s[tid] = m; scale_s[tid] = sc; shift_s[tid] = sh;
     }
     __syncthreads();
@@ -97,12 +75,12 @@ __global__ __launch_bounds__(TD_THREADS) void td_apply_kernel(FlexTdLossArgs a) 
     if (tid == 0) reinterpret_cast<double*>(a.workspace)[TD_WS_SQ + blockIdx.x] = red[0];
 }
 
-__global__ __launch_bounds__(64) void td_finish_kernel(FlexTdLossArgs a) {
+__global__ __launch_bounds__(64) void td_finish_kernel(FlexTdLossArgs a, int sq_blocks) {
     const int lane = threadIdx.x;
     const double* ws = reinterpret_cast<const double*>(a.workspace);
     if (lane == 0) {
         double t = 0.0;
-        for (int b = 0; b < TD_BLOCKS; ++b) t += ws[TD_WS_SQ + b];
+        for (int b = 0; b < sq_blocks; ++b) t += ws[TD_WS_SQ + b];
         if (a.loss) *a.loss = (float)(t / ((double)a.rows * a.n_agents));
         if (a.normalise && a.num_batches_tracked) *a.num_batches_tracked += 1;
     }
@@ -116,6 +94,14 @@ __global__ __launch_bounds__(64) void td_finish_kernel(FlexTdLossArgs a) {
     }
 }
 
+void flex_td_launch_stats(const FlexTdLossArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(td_stats_kernel, dim3(TD_BLOCKS), dim3(TD_THREADS), 0, s, a);
+}
+
+void flex_td_launch_finish(const FlexTdLossArgs& a, int sq_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(td_finish_kernel, dim3(1), dim3(64), 0, s, a, sq_blocks);
+}
+
 extern "C" int flexnet_td_loss(const FlexTdLossArgs* a, void* stream) {
     if (!a || a->rows < 1 || a->n_agents < 1 || !a->reward || !a->workspace || a->workspace_floats < FLEXNET_TD_WS_FLOATS)
         return FLEXNET_EINVAL;
@@ -127,9 +113,9 @@ extern "C" int flexnet_td_loss(const FlexTdLossArgs* a, void* stream) {
     if (a->n_agents > TD_NA) return FLEXNET_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a->workspace) & 7) != 0) return FLEXNET_EINVAL;         // holds doubles
     hipStream_t s = (hipStream_t)stream;
-    if (a->normalise) hipLaunchKernelGGL(td_stats_kernel, dim3(TD_BLOCKS), dim3(TD_THREADS), 0, s, *a);
+    if (a->normalise) flex_td_launch_stats(*a, s);
     if (!stats_only) hipLaunchKernelGGL(td_apply_kernel, dim3(TD_BLOCKS), dim3(TD_THREADS), 0, s, *a);
-    hipLaunchKernelGGL(td_finish_kernel, dim3(1), dim3(64), 0, s, *a);
+    flex_td_launch_finish(*a, stats_only ? 0 : TD_BLOCKS, s);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 

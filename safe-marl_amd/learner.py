@@ -19,7 +19,7 @@ import numpy as np
 import torch as th
 import torch.nn as nn
 
-from .nets import (WGRAD_MIN_ROWS, CriticTail, expand_agents, MLPAgent, MLPCritic, RNNAgent, critic_policy_supported, critic_replayed_supported,
+from .nets import (WGRAD_MIN_ROWS, CriticTail, critic_td_loss, critic_td_loss_supported, expand_agents, MLPAgent, MLPCritic, RNNAgent, critic_policy_supported, critic_replayed_supported,
                    critic_tail_supported, fused_actor_forward, tall_linear, td_loss, td_loss_supported, wide_batch_linear,
                    batchnorm_stats_supported, batchnorm_update_running_stats)
 from .replay_buffer import Transition
@@ -823,8 +823,13 @@ class MADDPG(Model):
                                                             actions_avail=actions_avail, target=not self.args.double_q,
                                                             last_hid=hids)
                 next_values = self.target_net.value(next_state, next_actions).view(-1, self.n_)
-            values = self.value(state, actions).view(-1, self.n_)
             bn = self.batchnorm if self.args.reward_normalisation else None
+            if fused_td:
+                # update batches: Q(s, a), the TD error and the critic's whole backward in one pass (nets._CriticTdLossFn)
+                value_loss = self._critic_td_loss(state, actions, next_values, rewards, done, bn)
+                if value_loss is not None:
+                    return policy_loss, value_loss, action_out
+            values = self.value(state, actions).view(-1, self.n_)
             if fused_td and td_loss_supported(values, next_values, rewards, done, bn):
                 value_loss = td_loss(values, next_values, rewards, done, self.args.gamma, bn)
             else:
@@ -835,6 +840,23 @@ class MADDPG(Model):
                 assert returns.size() == values.size()
                 value_loss = mean_all((returns - values).pow(2))
         return policy_loss, value_loss, action_out
+
+
+def _maddpg_critic_td_loss(self, state, actions, next_values, rewards, done, bn):
+    """MADDPG.value + the value loss + the critic's backward as one node, or None where that node does not apply."""
+    if not (self.args.shared_params and self.args.agent_id and not actions.requires_grad and self.fused_td_backward
+            and type(self).value is MADDPG.value):          # (IDDPG / MATD3 bring their own critic input layout)
+        return None
+    b, n = state.size(0), self.n_
+    net = self.value_dicts[0]
+    obs_cols, act_cols = state.reshape(b, n * self.obs_dim), actions.reshape(b, n * self.act_dim)
+    if not critic_td_loss_supported(net, obs_cols, act_cols, n, next_values, rewards, done, bn):
+        return None
+    return critic_td_loss(obs_cols, act_cols, n, net, next_values, rewards, done, self.args.gamma, bn)
+
+
+MADDPG._critic_td_loss = _maddpg_critic_td_loss
+MADDPG.fused_td_backward = True          # (tests switch it off to compare with the forward / td_loss / backward sequence)
 
 
 def _sum_agents(x):

@@ -847,6 +847,113 @@ class _CriticReplayedFn(th.autograd.Function):
                 None, None)
 
 
+class _CriticTdLossFn(th.autograd.Function):
+    """mean((BatchNorm(reward) + gamma (1 - done) Q'(s', pi'(s')) - Q(s, a))^2) for the shared-parameter critic on replayed
+    inputs — maddpg.py:100-123 over maddpg.py:33-76 + mlp_critic.py:25-33 — with the critic's backward run IN the forward
+    (include/flexnet.h: flexnet_critic_td_backward): the matrix-core backward kernel recomputes the tail's forward anyway,
+    so it forms q, the TD error, dLoss/dq and the loss itself.  No forward launch of the tail, no q / dq tensors, no
+    td_apply launch; every parameter gradient of the critic is ready when the loss is, and ``backward`` hands them over
+    (times the incoming gradient unless that is util.unit_seed).  The BatchNorm module's running statistics move as its
+    own training-mode forward would move them."""
+
+    @staticmethod
+    def forward(ctx, obs2d, act2d, n_agents, W, bias, ln_w, ln_b, w2, b2, w3, b3, eps, next_q, reward, done, gamma, bn):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
+        n = n_agents
+        no, na_ = obs2d.shape[1], act2d.shape[1]
+        dev = obs2d.device
+        shared = th.addmm(bias, obs2d, W[:, :no].t())
+        shared.addmm_(act2d, W[:, no + n:no + n + na_].t())
+        rows = shared.shape[0] * n
+        dz1 = th.empty(rows, 64, dtype=th.float32, device=dev)
+        grads = th.empty(64 * 64 + 64 * 4 + 1, dtype=th.float32, device=dev)
+        d_w2, d_b2, d_w3 = grads[:4096].view(64, 64), grads[4096:4160], grads[4160:4224].view(1, 64)
+        d_g, d_b, d_b3 = grads[4224:4288], grads[4288:4352], grads[4352:4353]
+        args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, eps)
+        args.rows, args.z1, args.z_shared, args.n_agents = rows, None, shared.data_ptr(), n
+        _set_critic_ids(args, W, no, n)
+        args.dz1 = dz1.data_ptr()
+        args.d_fc2_w, args.d_fc2_b, args.d_fc3_w, args.d_fc3_b = d_w2.data_ptr(), d_b2.data_ptr(), d_w3.data_ptr(), d_b3.data_ptr()
+        if ln_w is not None:
+            args.d_ln_w, args.d_ln_b = d_g.data_ptr(), d_b.data_ptr()
+        ws = _critic_workspace(dev)
+        args.workspace, args.workspace_floats, args.overwrite_grads = ws.data_ptr(), ws.numel(), 1
+        d_shared = th.empty_like(shared)
+        dW = th.empty_like(W)
+        args.d_z_shared, args.d_z_id = d_shared.data_ptr(), dW[:, no:no + n].data_ptr()
+        args.d_z_id_agent_stride, args.d_z_id_unit_stride = 1, W.shape[1]
+        nq, r, d = next_q.reshape(-1, n).contiguous(), reward.contiguous(), done.reshape(-1).contiguous()
+        loss = th.empty((), dtype=th.float32, device=dev)
+        t = _td_args(r, d, nq, gamma, bn, update_stats=True)
+        t.loss = loss.data_ptr()
+        _lib.check(lib.flexnet_critic_td_backward(C.byref(args), C.byref(t), stream), "flexnet_critic_td_backward")
+        d_bias = th.empty(64, dtype=th.float32, device=dev)
+        tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias, x2=act2d, out2=dW[:, no + n:no + n + na_])
+        if W.shape[1] > no + n + na_:
+            dW[:, no + n + na_:] = 0.0
+        has_ln = ln_w is not None
+        ctx.has_ln = has_ln
+        ctx.save_for_backward(dW, d_bias, grads)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        from .util import is_unit_seed
+        dW, d_bias, grads = ctx.saved_tensors
+        if not is_unit_seed(g):
+            dW, d_bias, grads = dW * g, d_bias * g, grads * g
+        d_w2, d_b2, d_w3 = grads[:4096].view(64, 64), grads[4096:4160], grads[4160:4224].view(1, 64)
+        d_g, d_b, d_b3 = grads[4224:4288], grads[4288:4352], grads[4352:4353]
+        return (None, None, None, dW, d_bias, (d_g if ctx.has_ln else None), (d_b if ctx.has_ln else None), d_w2, d_b2, d_w3,
+                d_b3) + (None,) * 6
+
+
+def _td_args(reward, done, next_q, gamma, bn, update_stats=True):
+    """FlexTdLossArgs for [rows, n] tensors (q / dq / loss left to the caller); the workspace is per device."""
+    from . import _lib
+    rows, n = reward.shape
+    if reward.device not in _TD_WS:
+        _TD_WS[reward.device] = th.empty(_lib.FLEXNET_TD_WS_FLOATS // 2, dtype=th.float64, device=reward.device)
+    ws = _TD_WS[reward.device]
+    a = _lib.FlexTdLossArgs()
+    a.rows, a.n_agents, a.normalise, a.gamma = rows, n, int(bn is not None), float(gamma)
+    a.reward, a.done, a.next_q = reward.data_ptr(), done.data_ptr(), next_q.data_ptr()
+    if bn is not None:
+        a.bn_eps, a.bn_momentum = float(bn.eps), float(bn.momentum)
+        if bn.affine:
+            a.bn_weight, a.bn_bias = bn.weight.data_ptr(), bn.bias.data_ptr()
+        if bn.track_running_stats and update_stats:
+            a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            a.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+    a.workspace, a.workspace_floats = ws.data_ptr(), 2 * ws.numel()
+    return a
+
+
+CRITIC_TD_MIN_ROWS = 65536          # csrc/critic.hip CRITIC_MFMA_MIN_ROWS: below it the matrix-core backward is not used
+
+
+def critic_td_loss_supported(critic, obs2d, act2d, n_agents, next_q, reward, done, bn):
+    """What flexnet_critic_td_backward covers: the replayed-input critic node's configuration at matrix-core batch sizes,
+    an fc1 without trailing extra columns, the fused value loss's tensors, gradients wanted."""
+    W = critic.fc1.weight
+    return (critic_replayed_supported(critic, obs2d, act2d, n_agents) and th.is_grad_enabled() and W.requires_grad
+            and obs2d.shape[0] * n_agents >= CRITIC_TD_MIN_ROWS and CRITIC_VARIANT == 0
+            and W.shape[1] == obs2d.shape[1] + n_agents + act2d.shape[1]
+            and reward.dim() == 2 and reward.shape == (obs2d.shape[0], n_agents)
+            and td_loss_supported(reward, next_q, reward, done, bn))
+
+
+def critic_td_loss(obs2d, act2d, n_agents, critic, next_q, reward, done, gamma, bn):
+    ln = critic.layernorm if critic.args.layernorm else None
+    return _CriticTdLossFn.apply(obs2d, act2d, n_agents, critic.fc1.weight, critic.fc1.bias,
+                                 None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                 critic.fc2.weight, critic.fc2.bias, critic.fc3.weight, critic.fc3.bias,
+                                 1e-5 if ln is None else ln.eps, next_q, reward, done, gamma, bn)
+
+
 class _ExpandAgentsFn(th.autograd.Function):
     """x [b, 1, a] -> [b, n, a] (the agent-summed action of matd3.py:92-97 / iddpg.py:66-71 handed to every agent); the
     backward sums over the agent axis with n - 1 pointwise adds instead of ATen's reduce_kernel (a captured HIP graph

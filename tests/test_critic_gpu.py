@@ -243,3 +243,109 @@ def test_stored_gradients_and_strided_id_sums(samples, n):
     assert lib.flexnet_critic_tail_backward(C.byref(a), None) == -1
     a.d_z_id_unit_stride, a.workspace_floats = wide.stride(0), 16
     assert lib.flexnet_critic_tail_backward(C.byref(a), None) == -1      # stored gradients need the fixed-order path
+
+
+@pytest.mark.parametrize("b,norm", [(32768, True), (16384, True), (13108, False)])
+def test_value_loss_and_critic_backward_in_one_pass(b, norm):
+    """include/flexnet.h: flexnet_critic_td_backward (nets._CriticTdLossFn) against the sequence it replaces — critic
+    forward, flexnet_td_loss, critic backward (nets._CriticReplayedFn + nets._TdLossFn): loss, every critic parameter
+    gradient, q / dq as the kernel formed them, and the BatchNorm's running statistics."""
+    import os, sys
+    import torch.nn as nn
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd import learner, nets
+    from safe_marl_amd.util import convert, unit_seed
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="maddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4)
+    torch.manual_seed(4)
+    m = learner.MADDPG(convert(alg)).cuda()
+    with torch.no_grad():
+        for p in m.value_dicts.parameters():
+            p.copy_(torch.randn_like(p) * 0.1)
+    g = torch.Generator(device="cuda").manual_seed(b)
+    n = 5
+    obs = torch.randn(b, n, 144, device="cuda", generator=g)
+    act = torch.randn(b, n, 4, device="cuda", generator=g)
+    nq = torch.randn(b, n, device="cuda", generator=g)
+    rew = torch.randn(b, n, device="cuda", generator=g) * 3.0 + 1.0
+    done = (torch.rand(b, 1, device="cuda", generator=g) < 0.05).float()
+    params = list(m.value_dicts.parameters())
+    net = m.value_dicts[0]
+    res = []
+    for fused in (True, False):
+        bn = nn.BatchNorm1d(n).cuda().train() if norm else None
+        if fused:
+            assert nets.critic_td_loss_supported(net, obs.reshape(b, -1), act.reshape(b, -1), n, nq, rew, done, bn)
+            loss = m._critic_td_loss(obs, act, nq, rew, done, bn)
+            assert type(loss.grad_fn).__name__ == "_CriticTdLossFnBackward"
+        else:
+            m.fused_td_backward = False
+            try:
+                assert m._critic_td_loss(obs, act, nq, rew, done, bn) is None
+            finally:
+                m.fused_td_backward = True
+            loss = nets.td_loss(m.value(obs, act).view(-1, n), nq, rew, done, 0.99, bn)
+        grads = torch.autograd.grad(loss, params, grad_outputs=unit_seed("cuda"))
+        stats = (bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()) if norm else ()
+        res.append((loss, grads, stats))
+    (l1, g1, s1), (l2, g2, s2) = res
+    assert abs(l1.item() - l2.item()) <= 2e-6 * abs(l2.item())
+    for a, e in zip(g1, g2):
+        assert a.shape == e.shape and _rel(a, e) < 2e-5
+    for a, e in zip(s1, s2):
+        assert torch.equal(a, e)
+    # a root gradient other than the unit seed scales every gradient
+    bn = nn.BatchNorm1d(n).cuda().train() if norm else None
+    loss = m._critic_td_loss(obs, act, nq, rew, done, bn)
+    for a, e in zip(torch.autograd.grad(loss, params, grad_outputs=torch.full((), 0.5, device="cuda")), g1):
+        assert torch.allclose(a, 0.5 * e, rtol=1e-6, atol=0)
+    # below the matrix-core batch size the node declines and the sequence runs
+    assert m._critic_td_loss(obs[:1000], act[:1000], nq[:1000], rew[:1000], done[:1000], bn) is None
+
+
+def test_td_backward_outputs_q_and_dq_when_asked():
+    """The optional q / dq outputs of flexnet_critic_td_backward equal the forward kernel's q and flexnet_td_loss's dq."""
+    import ctypes as C
+    import torch.nn as nn
+    from safe_marl_amd import _lib
+    from safe_marl_amd.nets import _critic_args, _critic_workspace, _td_args, CriticTail, td_loss
+    lib = _lib.load()
+    c = _critic()
+    g = torch.Generator(device="cuda").manual_seed(12)
+    samples, n = 16384, 5
+    shared = torch.randn(samples, 64, device="cuda", generator=g)
+    ids = torch.randn(n, 64, device="cuda", generator=g)
+    nq = torch.randn(samples, n, device="cuda", generator=g)
+    rew = torch.randn(samples, n, device="cuda", generator=g)
+    done = (torch.rand(samples, device="cuda", generator=g) < 0.1).float()
+    bn = nn.BatchNorm1d(n).cuda().train()
+    q_ref = CriticTail.apply_composed(shared, ids, c).detach().view(samples, n)
+    qr = q_ref.clone().requires_grad_(True)
+    bn2 = nn.BatchNorm1d(n).cuda().train()
+    loss_ref = td_loss(qr, nq, rew, done, 0.99, bn2)
+    dq_ref = torch.autograd.grad(loss_ref, qr)[0]
+    ws = _critic_workspace(shared.device)
+    grads = torch.empty(64 * 64 + 64 * 4 + 1, device="cuda")
+    dz1 = torch.empty(samples * n, 64, device="cuda")
+    d_shared, d_id = torch.empty_like(shared), torch.empty(n, 64, device="cuda")
+    q_out, dq_out, loss = torch.empty(samples, n, device="cuda"), torch.empty(samples, n, device="cuda"), torch.empty((), device="cuda")
+    a = _critic_args(shared, c.layernorm.weight, c.layernorm.bias, c.fc2.weight, c.fc2.bias, c.fc3.weight, c.fc3.bias,
+                     c.layernorm.eps)
+    a.rows, a.z1, a.z_shared, a.z_id, a.n_agents = samples * n, None, shared.data_ptr(), ids.data_ptr(), n
+    a.dz1 = dz1.data_ptr()
+    a.d_fc2_w, a.d_fc2_b, a.d_fc3_w = grads.data_ptr(), grads[4096:].data_ptr(), grads[4160:].data_ptr()
+    a.d_ln_w, a.d_ln_b, a.d_fc3_b = grads[4224:].data_ptr(), grads[4288:].data_ptr(), grads[4352:].data_ptr()
+    a.workspace, a.workspace_floats, a.overwrite_grads = ws.data_ptr(), ws.numel(), 1
+    a.d_z_shared, a.d_z_id = d_shared.data_ptr(), d_id.data_ptr()
+    t = _td_args(rew, done, nq, 0.99, bn)
+    t.q, t.dq, t.loss = q_out.data_ptr(), dq_out.data_ptr(), loss.data_ptr()
+    assert lib.flexnet_critic_td_backward(C.byref(a), C.byref(t), None) == 0
+    torch.cuda.synchronize()
+    assert (q_out - q_ref).abs().max().item() <= 2e-5 * max(1.0, q_ref.abs().max().item())
+    assert (dq_out - dq_ref).abs().max().item() <= 2e-5 * dq_ref.abs().max().item()
+    assert abs(loss.item() - loss_ref.item()) <= 2e-6 * loss_ref.item()
+    t.rows = samples - 1                                          # rows x agents must be the critic's rows
+    assert lib.flexnet_critic_td_backward(C.byref(a), C.byref(t), None) == -1
+    t.rows, a.variant = samples, 1                                # the VALU variant has no TD form
+    assert lib.flexnet_critic_td_backward(C.byref(a), C.byref(t), None) == _lib.FLEXNET_EUNSUPPORTED
