@@ -251,8 +251,14 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticT
 // the caller's gradient tensor (or stored there: overwrite_grads).  64 elements x 16 block groups per thread block: each thread walks its group's rows
 // with eight loads in flight, the 16 group sums are folded through LDS in index order.
 #define RED_G FLEX_RED_G
+__device__ __forceinline__ void critic_reduce(const FlexCriticTailArgs& a, int blocks, int chunk);
+
 __global__ __launch_bounds__(64 * RED_G) void critic_reduce_kernel(FlexCriticTailArgs a, int blocks) {
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    critic_reduce(a, blocks, blockIdx.x);
+}
+
+__device__ __forceinline__ void critic_reduce(const FlexCriticTailArgs& a, int blocks, int chunk) {
+    const int e = chunk * 64 + (threadIdx.x & 63);
     float sum;
     if (!flex_reduce_rows(a.workspace + e, CRITIC_WS_PITCH, blocks, e < HID * HID + 4 * HID + 1, sum)) return;
     float* dst;
@@ -723,7 +729,7 @@ static int critic_mfma_grid(int rows) {
 // then summed over blocks in a fixed order) — instead of two library reductions that each read dz1 again.
 #define DZF_W 4
 #define DZF_PITCH (FLEXNET_MAX_AGENTS * HID)
-__global__ __launch_bounds__(64 * DZF_W) void critic_dz_fold_kernel(FlexCriticTailArgs a) {
+__global__ __launch_bounds__(64 * DZF_W) void critic_dz_fold_kernel(FlexCriticTailArgs a, int64_t ws_off) {
     __shared__ float fold[DZF_W][DZF_PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = a.n_agents, samples = a.rows / n;
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(64 * DZF_W) void critic_dz_fold_kernel(FlexCriticTa
 #pragma unroll
     for (int i = 0; i < FLEXNET_MAX_AGENTS; ++i) fold[wave][i * HID + lane] = acc[i];
     __syncthreads();
-    float* out = a.workspace + (int64_t)blockIdx.x * DZF_PITCH;
+    float* out = a.workspace + ws_off + (int64_t)blockIdx.x * DZF_PITCH;
     for (int e = threadIdx.x; e < DZF_PITCH; e += 64 * DZF_W) {
         float t = fold[0][e];
 #pragma unroll
@@ -752,13 +758,18 @@ __global__ __launch_bounds__(64 * DZF_W) void critic_dz_fold_kernel(FlexCriticTa
     }
 }
 
-__global__ __launch_bounds__(64 * RED_G) void critic_dz_reduce_kernel(FlexCriticTailArgs a, int blocks) {
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63);                   // agent blockIdx.x, unit ex
+// agent `agent`'s id-column sums from the fold kernel's per-block partial rows (fixed order)
+__device__ __forceinline__ void critic_dz_reduce(const FlexCriticTailArgs& a, const float* partials, int blocks, int agent) {
+    const int e = agent * 64 + (threadIdx.x & 63);                        // unit ex
     float sum;
-    if (!flex_reduce_rows(a.workspace + e, DZF_PITCH, blocks, true, sum)) return;
+    if (!flex_reduce_rows(partials + e, DZF_PITCH, blocks, true, sum)) return;
     const int sa = a.d_z_id_agent_stride, su = a.d_z_id_unit_stride;
     if (sa == 0 && su == 0) a.d_z_id[e] = sum;
-    else a.d_z_id[(int64_t)blockIdx.x * sa + (int64_t)(threadIdx.x & 63) * su] = sum;
+    else a.d_z_id[(int64_t)agent * sa + (int64_t)(threadIdx.x & 63) * su] = sum;
+}
+
+__global__ __launch_bounds__(64 * RED_G) void critic_dz_reduce_kernel(FlexCriticTailArgs a, int blocks) {
+    critic_dz_reduce(a, a.workspace, blocks, blockIdx.x);
 }
 
 static int critic_dz_fold(const FlexCriticTailArgs& k, hipStream_t stream) {
@@ -766,9 +777,24 @@ static int critic_dz_fold(const FlexCriticTailArgs& k, hipStream_t stream) {
     int blocks = (samples + DZF_W - 1) / DZF_W;
     if (blocks > 256) blocks = 256;                      // one per CU: the second stage walks one partial row per block
     if ((int64_t)blocks * DZF_PITCH > k.workspace_floats) return FLEXNET_EINVAL;
-    hipLaunchKernelGGL(critic_dz_fold_kernel, dim3(blocks), dim3(64 * DZF_W), 0, stream, k);
+    hipLaunchKernelGGL(critic_dz_fold_kernel, dim3(blocks), dim3(64 * DZF_W), 0, stream, k, (int64_t)0);
     hipLaunchKernelGGL(critic_dz_reduce_kernel, dim3(k.n_agents), dim3(64 * RED_G), 0, stream, k, blocks);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}
+
+// Everything that follows the two first-stage kernels of flexnet_critic_td_backward in ONE launch: the parameter gradients'
+// fixed-order sums (blocks 0 .. CRITIC_RED_BLOCKS - 1), the id-column sums (one block per agent) and the loss / running
+// statistics finish (last block, one wavefront).
+#define CRITIC_RED_BLOCKS ((HID * HID + 4 * HID + 1 + 63) / 64)
+__global__ __launch_bounds__(64 * RED_G) void critic_td_finish_kernel(FlexCriticTailArgs a, FlexTdLossArgs td, int nb, int dz_blocks,
+                                                                      int64_t dz_off) {
+    const int bx = blockIdx.x;
+    if (bx < CRITIC_RED_BLOCKS) { critic_reduce(a, nb, bx); return; }
+    if (bx < CRITIC_RED_BLOCKS + (dz_blocks > 0 ? a.n_agents : 0)) {
+        critic_dz_reduce(a, a.workspace + dz_off, dz_blocks, bx - CRITIC_RED_BLOCKS);
+        return;
+    }
+    if (threadIdx.x < 64) td_finish(td, nb, threadIdx.x);
 }
 
 static int critic_check(const FlexCriticTailArgs* a, bool backward, bool need_dq = true) {
@@ -843,10 +869,19 @@ extern "C" int flexnet_critic_td_backward(const FlexCriticTailArgs* a, const Fle
     hipStream_t s = (hipStream_t)stream;
     if (t->normalise) flex_td_launch_stats(*t, s);
     hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<true>, dim3(nb), dim3(64 * CPW), 0, s, *a, *t);
-    hipLaunchKernelGGL(critic_reduce_kernel, dim3((HID * HID + 4 * HID + 1 + 63) / 64), dim3(64 * RED_G), 0, s, *a, nb);
-    flex_td_launch_finish(*t, nb, s);
-    if (hipGetLastError() != hipSuccess) return FLEXNET_EHIP;
-    return a->d_z_shared ? critic_dz_fold(*a, s) : FLEXNET_OK;
+    // dz1 folded onto its sources: the fold's partial rows go behind the backward kernel's, so ONE launch finishes both
+    int dz_blocks = 0;
+    const int64_t dz_off = (int64_t)nb * CRITIC_WS_PITCH;
+    if (a->d_z_shared) {
+        const int samples = a->rows / a->n_agents;
+        dz_blocks = (samples + DZF_W - 1) / DZF_W;
+        if (dz_blocks > 256) dz_blocks = 256;
+        if (dz_off + (int64_t)dz_blocks * DZF_PITCH > a->workspace_floats) return FLEXNET_EINVAL;
+        hipLaunchKernelGGL(critic_dz_fold_kernel, dim3(dz_blocks), dim3(64 * DZF_W), 0, s, *a, dz_off);
+    }
+    hipLaunchKernelGGL(critic_td_finish_kernel, dim3(CRITIC_RED_BLOCKS + (dz_blocks > 0 ? a->n_agents : 0) + 1), dim3(64 * RED_G),
+                       0, s, *a, *t, nb, dz_blocks, dz_off);
+    return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 
 static int critic_tail_backward_main(const FlexCriticTailArgs* a, void* stream) {

@@ -37,6 +37,29 @@ __device__ __forceinline__ void td_column_affine(const FlexTdLossArgs& a, int j,
     }
 }
 
+// One wavefront (lane = 0..63): the loss from `sq_blocks` per-block sums of squared TD errors — lane l adds those of blocks
+// l, l + 64, ..., then a fixed shuffle tree — and the BatchNorm's running statistics moved as nn.BatchNorm1d (training
+// mode) moves them: momentum weighting, unbiased variance, num_batches_tracked += 1.
+__device__ __forceinline__ void td_finish(const FlexTdLossArgs& a, int sq_blocks, int lane) {
+    const double* ws = reinterpret_cast<const double*>(a.workspace);
+    double t = 0.0;
+    for (int b = lane; b < sq_blocks; b += 64) t += ws[TD_WS_SQ + b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (lane == 0) {
+        if (a.loss) *a.loss = (float)(t / ((double)a.rows * a.n_agents));
+        if (a.normalise && a.num_batches_tracked) *a.num_batches_tracked += 1;
+    }
+    if (a.normalise && lane < a.n_agents && a.running_mean && a.running_var) {
+        double mean, var;
+        td_column_stats(a, lane, mean, var);
+        const double m = (double)a.bn_momentum;
+        const double unbiased = a.rows > 1 ? var * (double)a.rows / (double)(a.rows - 1) : var;
+        a.running_mean[lane] = (float)((1.0 - m) * (double)a.running_mean[lane] + m * mean);
+        a.running_var[lane] = (float)((1.0 - m) * (double)a.running_var[lane] + m * unbiased);
+    }
+}
+
 // csrc/tdloss.hip: the statistics pass (per-block column sums of the reward) and the one-wavefront finish (loss from
 // `sq_blocks` partial sums of squared errors; running statistics moved as nn.BatchNorm1d moves them)
 void flex_td_launch_stats(const FlexTdLossArgs& a, hipStream_t s);

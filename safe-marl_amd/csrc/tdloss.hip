@@ -76,22 +76,7 @@ __global__ __launch_bounds__(TD_THREADS) void td_apply_kernel(FlexTdLossArgs a) 
 }
 
 __global__ __launch_bounds__(64) void td_finish_kernel(FlexTdLossArgs a, int sq_blocks) {
-    const int lane = threadIdx.x;
-    const double* ws = reinterpret_cast<const double*>(a.workspace);
-    if (lane == 0) {
-        double t = 0.0;
-        for (int b = 0; b < sq_blocks; ++b) t += ws[TD_WS_SQ + b];
-        if (a.loss) *a.loss = (float)(t / ((double)a.rows * a.n_agents));
-        if (a.normalise && a.num_batches_tracked) *a.num_batches_tracked += 1;
-    }
-    if (a.normalise && lane < a.n_agents && a.running_mean && a.running_var) {      // nn.BatchNorm1d, train mode
-        double mean, var;
-        td_column_stats(a, lane, mean, var);
-        const double m = (double)a.bn_momentum;
-        const double unbiased = a.rows > 1 ? var * (double)a.rows / (double)(a.rows - 1) : var;
-        a.running_mean[lane] = (float)((1.0 - m) * (double)a.running_mean[lane] + m * mean);
-        a.running_var[lane] = (float)((1.0 - m) * (double)a.running_var[lane] + m * unbiased);
-    }
+    td_finish(a, sq_blocks, threadIdx.x);
 }
 
 void flex_td_launch_stats(const FlexTdLossArgs& a, hipStream_t s) {

@@ -721,12 +721,14 @@ class _CriticTailComposedFn(th.autograd.Function):
         import ctypes as C
         from . import _lib
         lib = _lib.load()
-        shared, id_cols = shared.contiguous(), id_cols.contiguous()
+        shared = shared.contiguous()
         n = id_cols.shape[0]
         rows = shared.shape[0] * n
         q = th.empty(rows, 1, dtype=th.float32, device=shared.device)
         args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, eps)
         args.rows, args.z1, args.z_shared, args.z_id, args.n_agents = rows, None, shared.data_ptr(), id_cols.data_ptr(), n
+        if not id_cols.is_contiguous():          # fc1.weight's id columns, transposed view: read in place through strides
+            args.z_id_agent_stride, args.z_id_unit_stride = id_cols.stride(0), id_cols.stride(1)
         args.q = q.data_ptr()
         _lib.check(lib.flexnet_critic_tail_forward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
                    "flexnet_critic_tail_forward")
@@ -740,6 +742,7 @@ class _CriticTailComposedFn(th.autograd.Function):
         from . import _lib
         lib = _lib.load()
         shared, id_cols, ln_w, ln_b, w2, b2, w3, b3 = ctx.saved_tensors
+        id_cols = id_cols.contiguous()
         n = id_cols.shape[0]
         rows = shared.shape[0] * n
         dq = dq.contiguous()
