@@ -183,3 +183,30 @@ def test_matd3_and_iddpg_sub_updates_replay_as_graphs(alg, monkeypatch):
         names = a.graph_audit[which]
         assert not any("at::native::reduce_kernel" in k or "batch_norm" in k for k in names), (alg, which, names)
         assert any("clip_rmsprop" in k for k in names)
+
+
+def test_value_steps_with_the_td_error_formed_in_the_backward_track_the_sequence():
+    """Twelve value sub-updates at the headline batch (32 768 samples x 5 agents): nets._CriticTdLossFn (the TD error
+    formed inside the critic's backward kernel) against the forward -> flexnet_td_loss -> backward sequence from the same
+    start on the same replay windows.  Different summation orders, same mathematics: the reported losses agree to 1e-5
+    relative, parameters and RMSprop state stay within fp32 round-off of each other, BatchNorm statistics likewise."""
+    from safe_marl_amd import learner
+    a, b = _trainer(True, 4096), _trainer(True, 4096)
+    b.behaviour_net.fused_td_backward = False                  # instance attribute: this trainer's learner only
+    for i in range(12):
+        stats = []
+        for tr in (a, b):
+            np.random.seed(300 + i)
+            st = {}
+            tr.value_replay_process(st)
+            torch.cuda.synchronize()
+            stats.append(float(st["mean_train_value_loss"]))
+        assert abs(stats[0] - stats[1]) <= 1e-5 * abs(stats[1]), (i, stats)
+    na = [k for k in a.graph_audit["value"]] if getattr(a, "graph_audit", None) else None
+    for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
+        if va.dtype.is_floating_point:
+            assert (va - vb).abs().max().item() <= 1e-6 + 1e-4 * vb.abs().max().item(), ka
+    oa, ob = a.value_optimizer.state_dict()["state"], b.value_optimizer.state_dict()["state"]
+    for k in oa:
+        assert torch.allclose(oa[k]["square_avg"], ob[k]["square_avg"], rtol=1e-3, atol=1e-12), k
+    assert type(a.behaviour_net)._critic_td_loss is learner._maddpg_critic_td_loss

@@ -20,6 +20,10 @@ net = create_network(env_args); series = make_synthetic_series(net, n_days=365)
 env = VecFlexProvisionEnv(env_args, envs, net=net, series=series, seed=1, warm_start=True)
 a = dict(DEFAULT_ALG_ARGS); a.update(alg=alg_name, agent_num=5, obs_size=144, state_size=110, action_dim=4, v_min=0.9, v_max=1.1)
 cls = {"maddpg": learner.MADDPG, "safemaddpg": learner.SAFEMADDPG, "matd3": learner.MATD3, "iddpg": learner.IDDPG}[alg_name]
+if os.environ.get("SOAK_UNFUSED_TD") == "1":          # A/B: the forward -> flexnet_td_loss -> backward sequence
+    learner.MADDPG.fused_td_backward = False
+if os.environ.get("SOAK_NO_BURSTS") == "1":
+    learner.RolloutGraph.BURSTS = ()
 torch.manual_seed(0); np.random.seed(0)
 tr = PGTrainer(convert(a), cls, env, None, replay_capacity=envs * 96 * 2)
 t0 = time.perf_counter()
