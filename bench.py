@@ -237,6 +237,7 @@ def learner_rooflines():
                 "achieved": 4.0 * k * (m + n) / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": 4.0 * k * (m + n) / t / 1e9 / HBM_PEAK_GBS, "launch_us": t * 1e6,
                 "note": "algorithmic bytes = both operands once; the kernel sits at the HBM / fp32-MFMA balance point"})
+    out.append(critic_backward_roofline(timed))
     N, bs = 4096, 32768
     buf = TransReplayBuffer(N * 24, device="cuda")
     buf.alloc_slabs(N, 5, 144, 4, 64)
@@ -250,6 +251,53 @@ def learner_rooflines():
                 "achieved": 2.0 * moved / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 2.0 * moved / t / 1e9 / HBM_PEAK_GBS,
                 "launch_us": t * 1e6, "note": "bytes read + written"})
     return out
+
+
+def critic_backward_roofline(timed):
+    """flexnet_critic_td_backward at the update batch (32 768 samples x 5 agents): reward statistics, the matrix-core backward
+    that forms q / the TD error / dLoss/dq itself, the dz1 fold and the one-launch finish.  fp32 MFMA work per row: forward
+    recompute 2 * 64 * 64, dz2 -> da1 2 * 64 * 64, dW2 2 * 64 * 64 flops (+ the 64-wide fc3 / LayerNorm vector work, not
+    counted)."""
+    import ctypes as C
+    import torch
+    import torch.nn as nn
+    from safe_marl_amd import _lib
+    from safe_marl_amd.nets import MLPCritic, _critic_args, _critic_workspace, _td_args
+    from safe_marl_amd.util import convert
+    d = dict(TRAIN_ALG_ARGS)
+    d.update(agent_num=5, obs_size=144, action_dim=4)
+    c = MLPCritic(745, 1, convert(d)).cuda()
+    lib = _lib.load()
+    samples, n = 32768, 5
+    shared, ids = torch.randn(samples, 64, device="cuda"), torch.randn(n, 64, device="cuda")
+    nq, rew = torch.randn(samples, n, device="cuda"), torch.randn(samples, n, device="cuda")
+    done = (torch.rand(samples, device="cuda") < 0.05).float()
+    bn = nn.BatchNorm1d(n).cuda().train()
+    ws = _critic_workspace(shared.device)
+    grads = torch.empty(64 * 64 + 64 * 4 + 1, device="cuda")
+    dz1 = torch.empty(samples * n, 64, device="cuda")
+    d_shared, d_id, loss = torch.empty_like(shared), torch.empty(n, 64, device="cuda"), torch.empty((), device="cuda")
+    a = _critic_args(shared, c.layernorm.weight, c.layernorm.bias, c.fc2.weight, c.fc2.bias, c.fc3.weight, c.fc3.bias,
+                     c.layernorm.eps)
+    a.rows, a.z1, a.z_shared, a.z_id, a.n_agents = samples * n, None, shared.data_ptr(), ids.data_ptr(), n
+    a.dz1 = dz1.data_ptr()
+    a.d_fc2_w, a.d_fc2_b, a.d_fc3_w = grads.data_ptr(), grads[4096:].data_ptr(), grads[4160:].data_ptr()
+    a.d_ln_w, a.d_ln_b, a.d_fc3_b = grads[4224:].data_ptr(), grads[4288:].data_ptr(), grads[4352:].data_ptr()
+    a.workspace, a.workspace_floats, a.overwrite_grads = ws.data_ptr(), ws.numel(), 1
+    a.d_z_shared, a.d_z_id = d_shared.data_ptr(), d_id.data_ptr()
+    t_args = _td_args(rew, done, nq, 0.99, bn)
+    t_args.loss = loss.data_ptr()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def call():
+        _lib.check(lib.flexnet_critic_td_backward(C.byref(a), C.byref(t_args), stream), "flexnet_critic_td_backward")
+
+    t = timed(call)
+    flops = 3.0 * 2 * 64 * 64 * samples * n
+    return {"kernel": "critic_tail_pgrad_mfma_kernel<TD> + statistics, fold, finish", "rows": samples * n,
+            "what": "value loss + critic backward of a value sub-update (4 launches)", "bound": "mfma", "dtype": "f32",
+            "achieved": flops / t / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t / 1e12 / 157.3, "launch_us": t * 1e6,
+            "note": "one wavefront per SIMD (371 registers); more than half of a tile's time is VALU / LDS work between the MFMAs"}
 
 
 def kernel_shares_child():
