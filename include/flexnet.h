@@ -153,6 +153,15 @@ typedef struct {
                                    /* columns of fc1.weight's gradient in place */
     int32_t z_id_agent_stride;     /* the same for the INPUT z_id: (1, fc1 row length) reads the id columns of fc1.weight where */
     int32_t z_id_unit_stride;      /* they are (every kernel stages the [n_agents, 64] table in LDS once per block) */
+    /* dz1-only matrix-core backward (d_fc2_w == NULL, variant 0, rows >= 65 536) of a loss that is a scaled mean of q
+     * (the policy loss -mean Q(s, pi(s)), maddpg.py:104-107): every row's dLoss/dq is `dq_value` (`dq` is not read), and
+     * the kernel — which recomputes the forward anyway — also returns q_mean_scale * sum(q) in *q_mean_out (fixed-order
+     * sums, fp64 partials in the workspace).  The two come together; set elsewhere: FLEXNET_EUNSUPPORTED. */
+    int32_t dq_uniform;
+    float dq_value;
+    float q_mean_scale;
+    int32_t pad2;
+    float* q_mean_out;             /* NULL: no sum of q */
 } FlexCriticTailArgs;
 
 #define FLEXNET_CRITIC_WS_FLOATS (1024 * 4416)

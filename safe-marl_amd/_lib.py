@@ -100,7 +100,9 @@ class FlexCriticTailArgs(C.Structure):
                [("n_agents", C.c_int32), ("overwrite_grads", C.c_int32), ("d_z_shared", C.c_void_p), ("d_z_id", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
                 ("d_z_id_agent_stride", C.c_int32), ("d_z_id_unit_stride", C.c_int32),
-                ("z_id_agent_stride", C.c_int32), ("z_id_unit_stride", C.c_int32)]
+                ("z_id_agent_stride", C.c_int32), ("z_id_unit_stride", C.c_int32),
+                ("dq_uniform", C.c_int32), ("dq_value", C.c_float), ("q_mean_scale", C.c_float), ("pad2", C.c_int32),
+                ("q_mean_out", C.c_void_p)]
 
 
 FLEXNET_CRITIC_WS_FLOATS = 1024 * 4416

@@ -352,12 +352,14 @@ __device__ __forceinline__ cf32x16 critic_mfma_tile(const float* wl, int t, cons
     return acc;
 }
 
-template <bool BACKWARD>
+template <bool BACKWARD, bool QMEAN = false>         // QMEAN (with BACKWARD): uniform dLoss/dq and the sum of q (the policy loss)
 __global__ __launch_bounds__(64 * CMW, 2) void critic_tail_mfma_kernel(FlexCriticTailArgs a) {
     __shared__ float w2t[HID * HID];                     // w2t[k][j] = W2[j][k]: A operand of z2 = W2 a1
     __shared__ float w2n[BACKWARD ? HID * HID : 1];      // W2 as stored [j][i]:  A operand of da1 = W2^T dz2
     __shared__ float vec[5][HID];                        // ln_w, ln_b, b2, w3, (unused)
     __shared__ __attribute__((aligned(16))) float idt[CRITIC_IDT_FLOATS];
+    __shared__ double qsw[QMEAN ? CMW : 1];
+    float qsum = 0.0f;                                   // BACKWARD with q_mean_out: this lane's sum of q over its (two or three) rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rb = lane & 31, hf = lane >> 5;
     for (int idx = tid; idx < HID * HID; idx += 64 * CMW) {
@@ -414,7 +416,14 @@ __global__ __launch_bounds__(64 * CMW, 2) void critic_tail_mfma_kernel(FlexCriti
             if (hf == 0 && live) a.q[r0 + rb] = qv;
             continue;
         }
-        const float dq = live ? a.dq[r0 + rb] : 0.0f;
+        float dq;
+        if constexpr (QMEAN) {
+            dq = live ? a.dq_value : 0.0f;
+            const float qv = part + __shfl_xor(part, 32, 64) + b3;
+            if (hf == 0 && live) qsum += qv;
+        } else {
+            dq = live ? a.dq[r0 + rb] : 0.0f;
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -452,6 +461,30 @@ __global__ __launch_bounds__(64 * CMW, 2) void critic_tail_mfma_kernel(FlexCriti
                         make_float4(d[u][4 * q], d[u][4 * q + 1], d[u][4 * q + 2], d[u][4 * q + 3]);
         }
     }
+    if constexpr (QMEAN) {                               // lanes, then wavefronts in order -> the block's partial
+        double v = (double)qsum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) qsw[wave] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double t = qsw[0];
+#pragma unroll
+            for (int w = 1; w < CMW; ++w) t += qsw[w];
+            reinterpret_cast<double*>(a.workspace)[blockIdx.x] = t;
+        }
+    }
+}
+
+// sum of q over the blocks' partials (lane-strided, then a fixed shuffle tree), scaled: the loss value of a mean-of-q loss
+__global__ __launch_bounds__(64) void critic_qmean_finish_kernel(FlexCriticTailArgs a, int blocks) {
+    const int lane = threadIdx.x;
+    const double* ws = reinterpret_cast<const double*>(a.workspace);
+    double t = 0.0;
+    for (int b = lane; b < blocks; b += 64) t += ws[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (lane == 0) *a.q_mean_out = (float)(t * (double)a.q_mean_scale);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -803,7 +836,7 @@ static int critic_check(const FlexCriticTailArgs* a, bool backward, bool need_dq
         return FLEXNET_EINVAL;
     if (!a->z1 && (!a->z_shared || !a->z_id || a->n_agents < 1 || a->rows % a->n_agents != 0)) return FLEXNET_EINVAL;
     if (!backward && !a->q) return FLEXNET_EINVAL;
-    if (backward && ((need_dq && !a->dq) || !a->dz1)) return FLEXNET_EINVAL;
+    if (backward && ((need_dq && !a->dq && !a->dq_uniform) || !a->dz1)) return FLEXNET_EINVAL;
     if (backward && ((a->d_z_shared != nullptr) != (a->d_z_id != nullptr))) return FLEXNET_EINVAL;
     if (backward && a->d_z_shared && (a->z1 || !a->workspace || a->n_agents > FLEXNET_MAX_AGENTS)) return FLEXNET_EINVAL;
     if (a->d_z_id_agent_stride < 0 || a->d_z_id_unit_stride < 0 || ((a->d_z_id_agent_stride == 0) != (a->d_z_id_unit_stride == 0)))
@@ -889,9 +922,18 @@ static int critic_tail_backward_main(const FlexCriticTailArgs* a, void* stream) 
     if (!k.d_fc2_w && k.variant == 0 && k.rows >= CRITIC_MFMA_MIN_ROWS) {
         const int nb = critic_mfma_grid(k.rows);
         if (nb < 1) return FLEXNET_EHIP;
-        hipLaunchKernelGGL(critic_tail_mfma_kernel<true>, dim3(nb), dim3(64 * CMW), 0, (hipStream_t)stream, k);
+        if (k.q_mean_out && (!k.workspace || k.workspace_floats < 2 * (int64_t)nb ||
+                             (reinterpret_cast<uintptr_t>(k.workspace) & 7) != 0)) return FLEXNET_EINVAL;
+        if (k.dq_uniform != (k.q_mean_out != nullptr)) return FLEXNET_EUNSUPPORTED;      // (the two come together)
+        if (k.q_mean_out) {
+            hipLaunchKernelGGL((critic_tail_mfma_kernel<true, true>), dim3(nb), dim3(64 * CMW), 0, (hipStream_t)stream, k);
+            hipLaunchKernelGGL(critic_qmean_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, nb);
+        } else {
+            hipLaunchKernelGGL(critic_tail_mfma_kernel<true>, dim3(nb), dim3(64 * CMW), 0, (hipStream_t)stream, k);
+        }
         return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
     }
+    if (k.dq_uniform || k.q_mean_out) return FLEXNET_EUNSUPPORTED;       // the matrix-core dz1-only backward's extras
     if (!k.d_fc2_w) {
         const int nb = critic_grid(k.rows, 4);
         if (nb < 1) return FLEXNET_EHIP;

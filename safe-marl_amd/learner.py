@@ -19,7 +19,8 @@ import numpy as np
 import torch as th
 import torch.nn as nn
 
-from .nets import (WGRAD_MIN_ROWS, CriticTail, critic_td_loss, critic_td_loss_supported, expand_agents, MLPAgent, MLPCritic, RNNAgent, critic_policy_supported, critic_replayed_supported,
+from .nets import (WGRAD_MIN_ROWS, CriticTail, critic_td_loss, critic_td_loss_supported, critic_policy_loss,
+                   critic_policy_loss_supported, expand_agents, MLPAgent, MLPCritic, RNNAgent, critic_policy_supported, critic_replayed_supported,
                    critic_tail_supported, fused_actor_forward, tall_linear, td_loss, td_loss_supported, wide_batch_linear,
                    batchnorm_stats_supported, batchnorm_update_running_stats)
 from .replay_buffer import Transition
@@ -813,10 +814,12 @@ class MADDPG(Model):
                                                                 last_hid=last_hids)
             # need == "policy": a policy sub-update — only the policy optimiser's parameters take this loss's gradient
             # (utils/trainer.py:99-108), so the critic is differentiated w.r.t. the actions alone
-            advantages = self.value(state, actions_pol, critic_frozen=(need == "policy")).view(-1, self.n_)
-            if self.args.normalize_advantages:
-                advantages = self.batchnorm(advantages)
-            policy_loss = mean_all(advantages, sign=-1.0)
+            policy_loss = self._critic_policy_loss(state, actions_pol) if need == "policy" else None
+            if policy_loss is None:
+                advantages = self.value(state, actions_pol, critic_frozen=(need == "policy")).view(-1, self.n_)
+                if self.args.normalize_advantages:
+                    advantages = self.batchnorm(advantages)
+                policy_loss = mean_all(advantages, sign=-1.0)
         if need in ("both", "value"):
             with th.no_grad():          # the bootstrap target carries no gradient (maddpg.py:110,115: .detach())
                 _, next_actions, _, _, _ = self.get_actions(next_state, status="train", exploration=False,
@@ -855,7 +858,22 @@ def _maddpg_critic_td_loss(self, state, actions, next_values, rewards, done, bn)
     return critic_td_loss(obs_cols, act_cols, n, net, next_values, rewards, done, self.args.gamma, bn)
 
 
+def _maddpg_critic_policy_loss(self, state, actions_pol):
+    """-mean Q(s, pi(s)) with the critic frozen (a policy sub-update) as one node, or None where that node does not apply."""
+    if not (self.args.shared_params and self.args.agent_id and self.fused_td_backward and not self.args.normalize_advantages
+            and type(self).value is MADDPG.value and isinstance(actions_pol, th.Tensor) and actions_pol.is_cuda
+            and self.fused_inference):
+        return None
+    b, n = state.size(0), self.n_
+    net = self.value_dicts[0]
+    obs_cols = state.reshape(b, n * self.obs_dim)
+    if not critic_policy_loss_supported(net, obs_cols, actions_pol, n):
+        return None
+    return critic_policy_loss(obs_cols, actions_pol, net, sign=-1.0)
+
+
 MADDPG._critic_td_loss = _maddpg_critic_td_loss
+MADDPG._critic_policy_loss = _maddpg_critic_policy_loss
 MADDPG.fused_td_backward = True          # (tests switch it off to compare with the forward / td_loss / backward sequence)
 
 

@@ -1031,6 +1031,60 @@ class _CriticPolicyFn(th.autograd.Function):
         return (None, d_act) + (None,) * 9
 
 
+class _CriticPolicyLossFn(th.autograd.Function):
+    """sign * mean(Q(s, pi(s))) over all [b, n] entries for the shared-parameter critic, differentiated w.r.t. the policy's
+    actions only — the policy loss of maddpg.py:104-107 as ONE node.  The gradient of a mean is a constant, so the critic
+    needs no forward pass of its own: the dz1-only backward kernel (which recomputes the forward) runs in this node's
+    ``forward`` with a uniform dLoss/dq and also returns the sum of q, i.e. the loss.  No tail forward launch, no loss
+    reduction launches; ``backward`` hands the stored action gradient over."""
+
+    @staticmethod
+    def forward(ctx, obs2d, act, W, bias, ln_w, ln_b, w2, b2, w3, b3, eps, sign):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        b, n, na_ = act.shape
+        no = obs2d.shape[1]
+        act2d = act.reshape(b, n * na_)
+        shared = th.addmm(bias, obs2d, W[:, :no].t())
+        shared.addmm_(act2d, W[:, no + n:no + n + n * na_].t())
+        rows = b * n
+        dz1 = th.empty(rows, 64, dtype=th.float32, device=shared.device)
+        loss = th.empty((), dtype=th.float32, device=shared.device)
+        args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, eps)
+        args.rows, args.z1, args.z_shared, args.n_agents = rows, None, shared.data_ptr(), n
+        _set_critic_ids(args, W, no, n)
+        args.dz1 = dz1.data_ptr()
+        args.dq_uniform, args.dq_value, args.q_mean_scale, args.q_mean_out = 1, sign / rows, sign / rows, loss.data_ptr()
+        ws = _critic_workspace(shared.device)
+        args.workspace, args.workspace_floats = ws.data_ptr(), ws.numel()
+        _lib.check(lib.flexnet_critic_tail_backward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_critic_tail_backward")
+        W_act = W[:, no + n:no + n + n * na_].reshape(64, n, na_)
+        d_act = th.einsum("bih,hia->bia", dz1.view(b, n, 64), W_act)
+        ctx.save_for_backward(d_act)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        from .util import is_unit_seed
+        (d_act,) = ctx.saved_tensors
+        return (None, d_act if is_unit_seed(g) else d_act * g) + (None,) * 10
+
+
+def critic_policy_loss_supported(critic, obs2d, act, n_agents):
+    return (critic_policy_supported(critic, obs2d, act, n_agents) and CRITIC_VARIANT == 0
+            and act.shape[0] * n_agents >= CRITIC_TD_MIN_ROWS and act.requires_grad and th.is_grad_enabled())
+
+
+def critic_policy_loss(obs2d, act, critic, sign=-1.0):
+    ln = critic.layernorm if critic.args.layernorm else None
+    return _CriticPolicyLossFn.apply(obs2d, act, critic.fc1.weight, critic.fc1.bias,
+                                     None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                     critic.fc2.weight, critic.fc2.bias, critic.fc3.weight, critic.fc3.bias,
+                                     1e-5 if ln is None else ln.eps, float(sign))
+
+
 def critic_policy_supported(critic, obs2d, act, n_agents):
     a = critic.args
     W = critic.fc1.weight

@@ -349,3 +349,42 @@ def test_td_backward_outputs_q_and_dq_when_asked():
     assert lib.flexnet_critic_td_backward(C.byref(a), C.byref(t), None) == -1
     t.rows, a.variant = samples, 1                                # the VALU variant has no TD form
     assert lib.flexnet_critic_td_backward(C.byref(a), C.byref(t), None) == _lib.FLEXNET_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("b", [32768, 13108])
+def test_policy_loss_from_the_backward_kernel_alone(b):
+    """nets._CriticPolicyLossFn (-mean Q(s, pi(s)) with the critic frozen: uniform dLoss/dq, the sum of q returned by the
+    dz1-only backward kernel) against critic forward -> fixed-order mean -> backward: the loss and the gradient w.r.t. the
+    policy's actions; scaled root gradients; the critic's parameters receive nothing."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd import learner
+    from safe_marl_amd.util import convert, mean_all, unit_seed
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="maddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4)
+    torch.manual_seed(8)
+    m = learner.MADDPG(convert(alg)).cuda()
+    with torch.no_grad():
+        for p in m.value_dicts.parameters():
+            p.copy_(torch.randn_like(p) * 0.1)
+    g = torch.Generator(device="cuda").manual_seed(b + 1)
+    obs = torch.randn(b, 5, 144, device="cuda", generator=g)
+    act0 = torch.randn(b, 5, 4, device="cuda", generator=g)
+    a1 = act0.clone().requires_grad_(True)
+    loss1 = m._critic_policy_loss(obs, a1)
+    assert loss1 is not None and type(loss1.grad_fn).__name__ == "_CriticPolicyLossFnBackward"
+    g1 = torch.autograd.grad(loss1, a1, grad_outputs=unit_seed("cuda"))[0]
+    a2 = act0.clone().requires_grad_(True)
+    loss2 = mean_all(m.value(obs, a2, critic_frozen=True).view(-1, 5), sign=-1.0)
+    g2 = torch.autograd.grad(loss2, a2)[0]
+    assert abs(loss1.item() - loss2.item()) <= 2e-6 * max(1.0, abs(loss2.item()))
+    assert _rel(g1, g2) < 2e-5
+    a3 = act0.clone().requires_grad_(True)
+    g3 = torch.autograd.grad(m._critic_policy_loss(obs, a3), a3, grad_outputs=torch.full((), -3.0, device="cuda"))[0]
+    assert torch.allclose(g3, -3.0 * g1, rtol=1e-6, atol=0)
+    a4 = act0.clone().requires_grad_(True)
+    loss4 = m._critic_policy_loss(obs, a4)
+    assert all(x is None for x in torch.autograd.grad(loss4, list(m.value_dicts.parameters()), allow_unused=True))
+    # declines: small batches, advantage normalisation
+    assert m._critic_policy_loss(obs[:512], act0[:512].clone().requires_grad_(True)) is None
