@@ -54,19 +54,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const float* base, int
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)bytes, 0x00027000);
 }
 
-#ifndef WG_AUX
-#define WG_AUX 0                    // cache policy bits of the operand loads (probe builds try 2 = nt)
-#endif
 // W consecutive floats at byte offset `off` (out of range: zeros)
 template <int W>
 __device__ __forceinline__ void wg_load(__amdgpu_buffer_rsrc_t r, int off, float* out) {
     if constexpr (W == 1) {
-        out[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, WG_AUX));
+        out[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
     } else if constexpr (W == 2) {
-        const v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, WG_AUX));
+        const v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
         out[0] = v.x; out[1] = v.y;
     } else if constexpr (W >= 4) {
-        const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, WG_AUX));
+        const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
         out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
         if constexpr (W > 4) wg_load<W - 4>(r, off + 16, out + 4);
     } else {
@@ -79,17 +76,9 @@ template <int MT, int NT, bool CS, bool TWO = false>
 __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
     __shared__ float fold[WG_IMG(MT, NT)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#ifdef WG_PROBE_CYCLIC
-    // probe: row groups of 8 dealt round-robin over the blocks (all blocks read one moving window of the operands)
-    const int64_t k0 = (int64_t)blockIdx.x * 8;
-    const int64_t groups_all = (p.k + 7) / 8;
-    const int my_groups = groups_all > blockIdx.x ? (int)((groups_all - blockIdx.x + p.slabs - 1) / p.slabs) : 0;
-    const int rows = (int)(p.k - k0 > 0 ? p.k - k0 : 0);        // the view runs to the end of the tensor
-#else
     const int64_t k0 = (int64_t)blockIdx.x * p.rows_per_block;
     const int64_t left = p.k - k0;
     const int rows = left < p.rows_per_block ? (int)left : p.rows_per_block;
-#endif
     const int n0 = blockIdx.y * (32 * NT);
     // buffer views of this block's rows: anything past them (other blocks' rows, the end of the allocation) reads 0
     int64_t fa = (int64_t)rows * p.lda, fb = (int64_t)rows * p.ldb - n0;
@@ -122,11 +111,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
     const int lda4 = (int)p.lda * 4, ldb4 = (int)p.ldb * 4;
     int offa = (2 * wave + half) * lda4 + col * (MT * 4);
     int offb = (2 * wave + half) * ldb4 + col * (NT * 4);
-#ifdef WG_PROBE_CYCLIC
-    const int stepa = 2 * WG_WAVES * lda4 * p.slabs, stepb = 2 * WG_WAVES * ldb4 * p.slabs;
-#else
     const int stepa = 2 * WG_WAVES * lda4, stepb = 2 * WG_WAVES * ldb4;
-#endif
     // (offsets are advanced as unsigned numbers: an out-of-range lane starts at 2^31 and stays past every view, whose
     // size is below 2^31 bytes by the dispatcher's check on rows_per_block)
     unsigned offb2 = 0x80000000u, stepb2 = 0;
@@ -140,11 +125,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
             offb = (int)0x80000000u;
         }
     }
-#ifdef WG_PROBE_CYCLIC
-    const int mine = my_groups;      // one step (2 rows) per wavefront and group
-#else
     const int mine = steps > wave ? (steps - wave + WG_WAVES - 1) / WG_WAVES : 0;
-#endif
 
     constexpr int U = WG_UNROLL(MT, NT);
     constexpr int D = WG_DEPTH(MT, NT);
@@ -190,11 +171,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-#ifdef WG_PROBE_NOMUL
-                    acc[i][j][0] += av[buf][u][i] * bsel[j];
-#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][i], bsel[j], acc[i][j], 0, 0, 0);
-#endif
                 }
         }
         if (CS) {                    // (every column chunk adds; only chunk 0 stores)

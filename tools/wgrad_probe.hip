@@ -1,5 +1,6 @@
 // Stand-alone timing of csrc/wgrad.hip on the update's shapes, for trying main-loop variants:
-//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Isafe-marl_amd/csrc [-DWG_...] tools/wgrad_probe.hip -o tools/wgrad_probe_X
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Isafe-marl_amd/csrc ['-DWG_DEPTH(MT,NT)=3'] ['-DWG_UNROLL(MT,NT)=1'] \
+//         tools/wgrad_probe.hip -o tools/wp/<name>      (tools/wp/ is git-ignored; the binaries travel to the GPU box)
 #include "../safe-marl_amd/csrc/wgrad.hip"
 #include <cstdio>
 #include <vector>
