@@ -3,6 +3,7 @@
 //         tools/wgrad_probe.hip -o tools/wp/<name>      (tools/wp/ is git-ignored; the binaries travel to the GPU box)
 #include "../safe-marl_amd/csrc/wgrad.hip"
 #include <cstdio>
+#include <cmath>
 #include <vector>
 
 int main() {
@@ -11,7 +12,12 @@ int main() {
     const int64_t maxk = 163840;
     hipMalloc(&a, maxk * 192 * 4); hipMalloc(&b, maxk * 720 * 4); hipMalloc(&c, 192 * 745 * 4); hipMalloc(&cs, 192 * 4);
     hipMalloc(&ws, (int64_t)FLEXNET_WGRAD_WS_FLOATS * 4);
-    hipMemset(a, 0, maxk * 192 * 4); hipMemset(b, 0, maxk * 720 * 4);
+    {   // small integers: every product and partial sum is exact in fp32, so any two summation orders agree bit for bit
+        std::vector<float> ha(maxk * 192), hb(maxk * 720);
+        for (size_t i = 0; i < ha.size(); ++i) ha[i] = (float)((int)((i * 2654435761u) >> 29) - 3);
+        for (size_t i = 0; i < hb.size(); ++i) hb[i] = (float)((int)((i * 40503u + 7u) >> 5 & 7) - 3);
+        hipMemcpy(a, ha.data(), ha.size() * 4, hipMemcpyHostToDevice); hipMemcpy(b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+    }
     hipStream_t s; hipStreamCreate(&s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (auto sh : shapes) {
@@ -25,7 +31,13 @@ int main() {
         hipEventRecord(e1, s); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double us = ms * 1e3 / reps, gb = sh.k * (double)(sh.m + sh.n) * 4 / 1e9, tf = 2.0 * sh.k * sh.m * sh.n / 1e12;
-        printf("k=%6ld m=%3d n=%3d  %7.1f us  %5.2f TB/s  %5.1f TFLOP/s\n", (long)sh.k, sh.m, sh.n, us, gb / us * 1e3, tf / us * 1e6);
+        printf("k=%6ld m=%3d n=%3d  %7.1f us  %5.2f TB/s  %5.1f TFLOP/s", (long)sh.k, sh.m, sh.n, us, gb / us * 1e3, tf / us * 1e6);
+        {   // checksum of C (compare between variants / WG_RING=0|1)
+            std::vector<float> hc((size_t)sh.m * sh.n);
+            hipMemcpy(hc.data(), c, hc.size() * 4, hipMemcpyDeviceToHost);
+            double cs = 0, ca = 0; for (size_t i = 0; i < hc.size(); ++i) { cs += hc[i] * (double)((i % 97) + 1); ca += fabs(hc[i]); }
+            printf("  checksum %.6e abs %.6e\n", cs, ca);
+        }
     }
     return 0;
 }
