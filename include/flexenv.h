@@ -223,6 +223,15 @@ int flexenv_safety_project(FlexEnv* env, const void* proposed, int32_t dtype,
                            double* adjusted /*dev [N, 4*n_agents]*/,
                            uint8_t* intervened /*dev [N] or NULL*/, void* stream);
 
+/* The same, also handing over what env.step() is fed next (safemaddpg.py:106-111 -> model.py:217-218): env_action
+ * [N, 4*n_agents] f32 = translate_action (utils/util.py:125-128: 0.5 (clamp(a, low, high) + 1) (high - low) + low) of the
+ * fp32 cast of `adjusted`, in the same flat order (which env.step re-reads agent-major) — bit for bit what
+ * the cast and the five tensor operations produce, without their six launches.  env_action NULL = the call above. */
+int flexenv_safety_project_env(FlexEnv* env, const void* proposed, int32_t dtype, const double* s_p, const double* s_q,
+                               const double* beta, double v_min, double v_max, double penalty, double* adjusted,
+                               uint8_t* intervened /*dev [N] or NULL*/, float act_low, float act_high,
+                               float* env_action /*dev [N, 4*n_agents] or NULL*/, void* stream);
+
 const char* flexenv_version(void);
 
 #ifdef __cplusplus

@@ -69,7 +69,7 @@ class ResetSpec(C.Structure):
 SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_obs_size", "flexenv_state_size",
-    "pf_solve_batch", "flexenv_safety_project", "flexenv_version",
+    "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_critic_td_backward",
     "flexnet_scaled_sum", "flexnet_gather_rows", "flexnet_gru_backward",
 )
@@ -279,6 +279,9 @@ def load():
     lib.pf_solve_batch.restype = C.c_int
     lib.flexenv_safety_project.argtypes = [vp, vp, i32, vp, vp, vp, C.c_double, C.c_double, C.c_double, vp, vp, vp]
     lib.flexenv_safety_project.restype = C.c_int
+    lib.flexenv_safety_project_env.argtypes = [vp, vp, i32, vp, vp, vp, C.c_double, C.c_double, C.c_double, vp, vp,
+                                               C.c_float, C.c_float, vp, vp]
+    lib.flexenv_safety_project_env.restype = C.c_int
     lib.flexenv_version.argtypes = []
     lib.flexenv_version.restype = C.c_char_p
     _lib = lib

@@ -856,7 +856,8 @@ __device__ __forceinline__ void qp_side(const double x0[4], const double cvec[4]
 __global__ void flex_safety_kernel(KArgs a, const void* __restrict__ proposed, int dtype,
                                    const double* __restrict__ s_p, const double* __restrict__ s_q,
                                    const double* __restrict__ beta, double v_min, double v_max, double rho,
-                                   double* __restrict__ adjusted, uint8_t* __restrict__ intervened) {
+                                   double* __restrict__ adjusted, uint8_t* __restrict__ intervened,
+                                   float* __restrict__ env_action, float act_low, float act_span) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int na = a.cfg.n_agents;
     if (tid >= a.n_envs * na) return;
@@ -884,6 +885,17 @@ __global__ void flex_safety_kernel(KArgs a, const void* __restrict__ proposed, i
     if (!ch_up) qp_side(x0, cvec, d, v_min, -1.0, rho, x, ch_lo);
     double* o = adjusted + (int64_t)env * 4 * na;          // type-major, safemaddpg.py:297 (A13)
     o[0 * na + ag] = x[0]; o[1 * na + ag] = x[1]; o[2 * na + ag] = x[2]; o[3 * na + ag] = x[3];
+    if (env_action) {
+        // what the caller would feed env.step: translate_action (util.py:125-128) of the fp32 cast of the same flat vector,
+        // 0.5 (clamp(a, low, high) + 1) (high - low) + low, every step rounded to fp32 as the tensor ops round it
+        float* eo = env_action + (int64_t)env * 4 * na;
+        const float act_high = act_low + act_span;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float c = fminf(fmaxf((float)x[t], act_low), act_high);
+            eo[t * na + ag] = __fadd_rn(__fmul_rn(__fmul_rn(0.5f, __fadd_rn(c, 1.0f)), act_span), act_low);
+        }
+    }
     if (intervened && (ch_up || ch_lo)) intervened[env] = 1;
 }
 
@@ -1325,19 +1337,27 @@ int pf_solve_batch(const NetFix* net, int32_t n, const double* pnet, const doubl
     return FLEX_OK;
 }
 
-int flexenv_safety_project(FlexEnv* e, const void* proposed, int32_t dtype, const double* s_p, const double* s_q,
-                           const double* beta, double v_min, double v_max, double penalty, double* adjusted,
-                           uint8_t* intervened, void* stream) {
+int flexenv_safety_project_env(FlexEnv* e, const void* proposed, int32_t dtype, const double* s_p, const double* s_q,
+                               const double* beta, double v_min, double v_max, double penalty, double* adjusted,
+                               uint8_t* intervened, float act_low, float act_high, float* env_action, void* stream) {
     if (!e || !proposed || !s_p || !s_q || !beta || !adjusted) return FLEX_EINVAL;
     if (dtype != FLEX_F32 && dtype != FLEX_F64) return FLEX_EINVAL;
+    if (env_action && !(act_high >= act_low)) return FLEX_EINVAL;
     KArgs k = make_args(e);
     hipStream_t s = (hipStream_t)stream;
     if (intervened) HIP_TRY(hipMemsetAsync(intervened, 0, e->n_envs, s));
     const int tot = e->n_envs * e->cfg.n_agents;
     hipLaunchKernelGGL(flex_safety_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, k, proposed, dtype, s_p, s_q, beta,
-                       v_min, v_max, penalty, adjusted, intervened);
+                       v_min, v_max, penalty, adjusted, intervened, env_action, act_low, act_high - act_low);
     HIP_TRY(hipGetLastError());
     return FLEX_OK;
+}
+
+int flexenv_safety_project(FlexEnv* e, const void* proposed, int32_t dtype, const double* s_p, const double* s_q,
+                           const double* beta, double v_min, double v_max, double penalty, double* adjusted,
+                           uint8_t* intervened, void* stream) {
+    return flexenv_safety_project_env(e, proposed, dtype, s_p, s_q, beta, v_min, v_max, penalty, adjusted, intervened, 0.0f, 0.0f,
+                                      nullptr, stream);
 }
 
 }  // extern "C"

@@ -275,17 +275,28 @@ class VecFlexProvisionEnv:
         v = torch.as_tensor(value, dtype=torch.float64, device=self.device).contiguous()
         _lib.check(self.lib.flexenv_poke(self.handle, _lib.PEEK[name], _ptr(v), _stream()), "flexenv_poke")
 
-    def safety_project(self, proposed, s_p, s_q, beta, v_min, v_max, penalty=1000.0):
+    def safety_project(self, proposed, s_p, s_q, beta, v_min, v_max, penalty=1000.0, env_action_range=None, want_hit=True):
         """SAFEMADDPG.safety_layer_optimization on every env (safemaddpg.py:176-299).  Returns
-        (adjusted [N, 4*n_agents] f64 type-major, intervened [N] uint8)."""
+        (adjusted [N, 4*n_agents] f64 type-major, intervened [N] uint8).
+        ``env_action_range`` = (low, high): a third result, [N, 4*n_agents] f32 — translate_action (util.py:125-128) of the
+        fp32 cast of ``adjusted``, what env.step is fed next, from the same launch (include/flexenv.h:
+        flexenv_safety_project_env).  ``want_hit=False``: no intervention flags (their memset is a launch of its own)."""
         proposed = proposed.contiguous()
         adj = torch.empty(self.n_envs, 4 * self.n_agents, dtype=torch.float64, device=self.device)
-        hit = torch.empty(self.n_envs, dtype=torch.uint8, device=self.device)
+        hit = torch.empty(self.n_envs, dtype=torch.uint8, device=self.device) if want_hit else None
         sp, sq, bt = (torch.as_tensor(x, dtype=torch.float64, device=self.device).contiguous() for x in (s_p, s_q, beta))
-        _lib.check(self.lib.flexenv_safety_project(self.handle, _ptr(proposed), self._dtype_tag(proposed), _ptr(sp),
-                                                   _ptr(sq), _ptr(bt), float(v_min), float(v_max), float(penalty),
-                                                   _ptr(adj), _ptr(hit), _stream()), "flexenv_safety_project")
-        return adj, hit
+        if env_action_range is None:
+            _lib.check(self.lib.flexenv_safety_project(self.handle, _ptr(proposed), self._dtype_tag(proposed), _ptr(sp),
+                                                       _ptr(sq), _ptr(bt), float(v_min), float(v_max), float(penalty),
+                                                       _ptr(adj), _ptr(hit), _stream()), "flexenv_safety_project")
+            return adj, hit
+        low, high = env_action_range
+        env_action = torch.empty(self.n_envs, 4 * self.n_agents, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.flexenv_safety_project_env(self.handle, _ptr(proposed), self._dtype_tag(proposed), _ptr(sp),
+                                                       _ptr(sq), _ptr(bt), float(v_min), float(v_max), float(penalty),
+                                                       _ptr(adj), _ptr(hit), float(low), float(high), _ptr(env_action),
+                                                       _stream()), "flexenv_safety_project_env")
+        return adj, hit, env_action
 
     # size getters, env:708-738
     def get_obs_size(self):

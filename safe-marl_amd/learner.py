@@ -217,8 +217,10 @@ class RolloutGraph:
                     # safemaddpg.py:90-111: the proposed action goes through the safety layer (HIP closed form,
                     # flexenv_safety_project); the replay keeps the policy's own action (model.py:232)
                     vec = env.vec if hasattr(env, "vec") else env
-                    adjusted, _ = vec.safety_project(action.view(N, m.n_, m.act_dim), *self.predictor, m.V_min, m.V_max)
-                    env_action = m.env_action(adjusted.to(th.float32))
+                    # ... and the env's action (translate_action of the adjusted vector) comes out of the same launch
+                    _, _, env_action = vec.safety_project(action.view(N, m.n_, m.act_dim), *self.predictor, m.V_min, m.V_max,
+                                                          env_action_range=(m.args.action_low, m.args.action_high),
+                                                          want_hit=False)
                 env.step(env_action.view(N, m.n_, m.act_dim), fuse_obs=True, auto_reset=True,
                          obs_ring=buf.obs_ring if self.ring_active else None, replay_sink=self.sink_active)
                 if not self.sink_active:

@@ -53,3 +53,29 @@ def test_fit_voltage_predictor_on_gpu_equals_cpu_fit(net):
     V = np.stack([pf_oracle.nr_polar(net, P[i], Q[i])[0] for i in range(120)])
     ref = ss.fit_from_data(ss.interleave(P, Q), V)
     assert np.abs(vp.coef_ - ref.coef_).max() < 1e-6 and np.abs(vp.intercept_ - ref.intercept_).max() < 1e-6
+
+
+@pytest.mark.parametrize("low,high", [(0.0, 1.0), (-1.0, 1.0)])
+def test_env_action_from_the_same_launch_is_translate_action_bit_for_bit(net, series_small, low, high):
+    """include/flexenv.h: flexenv_safety_project_env — the adjusted vector and what env.step is fed next (the fp32 cast and
+    utils/util.py:125-128's clamp / shift / scale) from one launch: equal, bit for bit, to the cast and the five tensor
+    operations on the adjusted vector; the adjusted vector itself is the plain call's; no flags when none are asked for."""
+    import types
+    import torch
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd import safety_signal as ss
+    from safe_marl_amd.util import scale_action
+    vp = ss.fit_voltage_predictor(net, num_scenarios=300)
+    sp, sq, beta = vp.building_terms(net)
+    n = 1000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    vec = VecFlexProvisionEnv({"alg": "safemaddpg"}, n, series=series_small, net=net, seed=5)
+    vec.reset()
+    proposed = torch.rand(n, 5, 4, device="cuda", generator=g) * 2.4 - 1.2
+    adj0, hit0 = vec.safety_project(proposed, sp, sq, beta, 0.97, 1.03)
+    adj1, hit1, env1 = vec.safety_project(proposed, sp, sq, beta, 0.97, 1.03, env_action_range=(low, high))
+    adj2, hit2, env2 = vec.safety_project(proposed, sp, sq, beta, 0.97, 1.03, env_action_range=(low, high), want_hit=False)
+    want = scale_action(types.SimpleNamespace(action_low=low, action_high=high), adj0.to(torch.float32))
+    assert torch.equal(adj0, adj1) and torch.equal(adj0, adj2) and torch.equal(hit0, hit1) and hit2 is None
+    assert env1.dtype == torch.float32 and torch.equal(env1, want) and torch.equal(env2, want)
+    assert bool(hit0.any())                                  # the limits bite somewhere: the projection is exercised
