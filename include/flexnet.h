@@ -351,6 +351,25 @@ typedef struct {
 
 int flexnet_rollout_pack(const FlexRolloutPackArgs* args, void* stream);
 
+/* Agent-summed exploration of MATD3 / IDDPG (matd3.py:92-97 + utils/util.py:57-64, iddpg.py:66-71): the policy means of a
+ * sample are summed over the AGENT axis, ONE action tanh(sum + std * eps) is drawn and every agent receives it; the env is
+ * fed translate_action of it (util.py:125-128).  One launch for what the tensor composition spreads over ~40:
+ *     y[e, k]          = tanh(((m[e,0,k] + m[e,1,k]) + ...) + eps[e, k] * std[k])
+ *     action[e, i, k]  = y[e, k]
+ *     env_action[e, i, k] = 0.5 (clamp(y, low, high) + 1) (high - low) + low
+ * every step rounded to fp32 in the order the tensor operations round it (bit-identical to them). */
+typedef struct {
+    int32_t n_envs, n_agents, act_dim, pad0;
+    float act_low, act_high;
+    const float* means;        /* [N, n, a] */
+    const float* eps;          /* [N, a] standard normal draws */
+    const float* std;          /* [a] exp of the agent-summed log-std */
+    float* action;             /* out [N, n, a] */
+    float* env_action;         /* out [N, n, a] */
+} FlexAgentSumArgs;
+
+int flexnet_agent_sum_explore(const FlexAgentSumArgs* args, void* stream);
+
 /* Replay-window refresh: up to FLEXNET_GATHER_MAX_JOBS strided row copies in one launch.  A sampled window of the slab
  * ring (utils/replay_buffer.py:17-21: consecutive transitions) becomes the contiguous static batch a captured sub-update
  * reads; each field is one job (two where the window crosses the ring's seam). */

@@ -71,7 +71,7 @@ SYMBOLS = (
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_critic_td_backward",
-    "flexnet_scaled_sum", "flexnet_gather_rows", "flexnet_gru_backward",
+    "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gru_backward",
 )
 
 class FlexActorArgs(C.Structure):
@@ -150,6 +150,13 @@ class FlexTdLossArgs(C.Structure):
 
 
 FLEXNET_TD_WS_FLOATS = 2 * (64 * 2 * 8 + 1024)
+
+
+class FlexAgentSumArgs(C.Structure):
+    """include/flexnet.h"""
+    _fields_ = [("n_envs", C.c_int32), ("n_agents", C.c_int32), ("act_dim", C.c_int32), ("pad0", C.c_int32),
+                ("act_low", C.c_float), ("act_high", C.c_float)] + \
+               [(k, C.c_void_p) for k in ("means", "eps", "std", "action", "env_action")]
 
 
 class FlexSumArgs(C.Structure):
@@ -250,6 +257,8 @@ def load():
     lib.flexnet_clip_rmsprop.restype = C.c_int
     lib.flexnet_td_loss.argtypes = [C.POINTER(FlexTdLossArgs), vp]
     lib.flexnet_td_loss.restype = C.c_int
+    lib.flexnet_agent_sum_explore.argtypes = [C.POINTER(FlexAgentSumArgs), vp]
+    lib.flexnet_agent_sum_explore.restype = C.c_int
     lib.flexnet_scaled_sum.argtypes = [C.POINTER(FlexSumArgs), vp]
     lib.flexnet_scaled_sum.restype = C.c_int
     for fn in (lib.flexnet_lnrelu_forward, lib.flexnet_lnrelu_backward):

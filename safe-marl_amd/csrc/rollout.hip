@@ -151,6 +151,36 @@ extern "C" int flexnet_rollout_pack(const FlexRolloutPackArgs* a, void* stream) 
 // Job j copies rows[j] rows of width[j] floats from src (row pitch src_stride) to dst (row pitch dst_stride).  The grid is
 // cut over the jobs in proportion to their size (host side); inside a job a block walks 16-byte units when pitch, width and
 // base allow, single floats otherwise (the small record's reward / done columns).
+// ---- agent-summed exploration (flexnet_agent_sum_explore): one thread per (environment, action component) ---------------
+__global__ __launch_bounds__(256) void agent_sum_explore_kernel(FlexAgentSumArgs a) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= a.n_envs * a.act_dim) return;
+    const int e = tid / a.act_dim, k = tid - e * a.act_dim;
+    const int n = a.n_agents, ad = a.act_dim;
+    const float* m = a.means + (int64_t)e * n * ad + k;
+    float s = m[0];
+    for (int i = 1; i < n; ++i) s = __fadd_rn(s, m[i * ad]);                            // ((m0 + m1) + m2) + ...
+    const float x = __fadd_rn(s, __fmul_rn(a.eps[tid], a.std[k]));                    // loc + eps * scale
+    const float y = tanhf(x);
+    const float span = a.act_high - a.act_low;
+    const float c = fminf(fmaxf(y, a.act_low), a.act_high);
+    const float ev = __fadd_rn(__fmul_rn(__fmul_rn(0.5f, __fadd_rn(c, 1.0f)), span), a.act_low);
+    float* ao = a.action + (int64_t)e * n * ad + k;
+    float* eo = a.env_action + (int64_t)e * n * ad + k;
+    for (int i = 0; i < n; ++i) { ao[i * ad] = y; eo[i * ad] = ev; }
+}
+
+extern "C" int flexnet_agent_sum_explore(const FlexAgentSumArgs* a, void* stream) {
+    if (!a || a->n_envs < 0 || a->n_agents < 1 || a->act_dim < 1 || !a->means || !a->eps || !a->std || !a->action ||
+        !a->env_action || !(a->act_high >= a->act_low))
+        return FLEXNET_EINVAL;
+    if (a->n_envs == 0) return FLEXNET_OK;
+    const int64_t tot = (int64_t)a->n_envs * a->act_dim;
+    if (tot > 0x7fffffff) return FLEXNET_EUNSUPPORTED;
+    hipLaunchKernelGGL(agent_sum_explore_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}
+
 #define GATHER_THREADS 256
 struct GatherPlan { int first_block[FLEXNET_GATHER_MAX_JOBS + 1]; };
 
