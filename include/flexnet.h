@@ -362,10 +362,10 @@ typedef struct {
     int32_t n_envs, n_agents, act_dim, pad0;
     float act_low, act_high;
     const float* means;        /* [N, n, a] */
-    const float* eps;          /* [N, a] standard normal draws */
+    const float* eps;          /* [N, a] standard normal draws; NULL: no exploration, action = the summed mean (no tanh) */
     const float* std;          /* [a] exp of the agent-summed log-std */
     float* action;             /* out [N, n, a] */
-    float* env_action;         /* out [N, n, a] */
+    float* env_action;         /* out [N, n, a], or NULL (bootstrap actions of a value loss: no environment behind them) */
 } FlexAgentSumArgs;
 
 int flexnet_agent_sum_explore(const FlexAgentSumArgs* args, void* stream);

@@ -160,19 +160,22 @@ __global__ __launch_bounds__(256) void agent_sum_explore_kernel(FlexAgentSumArgs
     const float* m = a.means + (int64_t)e * n * ad + k;
     float s = m[0];
     for (int i = 1; i < n; ++i) s = __fadd_rn(s, m[i * ad]);                            // ((m0 + m1) + m2) + ...
-    const float x = __fadd_rn(s, __fmul_rn(a.eps[tid], a.std[k]));                    // loc + eps * scale
-    const float y = tanhf(x);
+    // eps == NULL: no exploration — the agent-summed mean itself goes to every agent (util.py:75-77 behind matd3.py:94-96)
+    const float y = a.eps ? tanhf(__fadd_rn(s, __fmul_rn(a.eps[tid], a.std[k]))) : s;  // tanh(loc + eps * scale)
     const float span = a.act_high - a.act_low;
     const float c = fminf(fmaxf(y, a.act_low), a.act_high);
     const float ev = __fadd_rn(__fmul_rn(__fmul_rn(0.5f, __fadd_rn(c, 1.0f)), span), a.act_low);
     float* ao = a.action + (int64_t)e * n * ad + k;
-    float* eo = a.env_action + (int64_t)e * n * ad + k;
-    for (int i = 0; i < n; ++i) { ao[i * ad] = y; eo[i * ad] = ev; }
+    for (int i = 0; i < n; ++i) ao[i * ad] = y;
+    if (a.env_action) {
+        float* eo = a.env_action + (int64_t)e * n * ad + k;
+        for (int i = 0; i < n; ++i) eo[i * ad] = ev;
+    }
 }
 
 extern "C" int flexnet_agent_sum_explore(const FlexAgentSumArgs* a, void* stream) {
-    if (!a || a->n_envs < 0 || a->n_agents < 1 || a->act_dim < 1 || !a->means || !a->eps || !a->std || !a->action ||
-        !a->env_action || !(a->act_high >= a->act_low))
+    if (!a || a->n_envs < 0 || a->n_agents < 1 || a->act_dim < 1 || !a->means || (a->eps && !a->std) || !a->action ||
+        !(a->act_high >= a->act_low))
         return FLEXNET_EINVAL;
     if (a->n_envs == 0) return FLEXNET_OK;
     const int64_t tot = (int64_t)a->n_envs * a->act_dim;

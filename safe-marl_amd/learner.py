@@ -240,20 +240,9 @@ class RolloutGraph:
                     self._pack(action, hid)
                 return
         if self.summed:
-            import ctypes as C
-            from torch.distributions.utils import _standard_normal
-            from . import _lib
             with th.no_grad():
                 means, _, hid = m.policy(self.obs, last_hid=self.hid)
-                means = means.to(th.float32).contiguous()
-                eps = _standard_normal((N, 1, m.act_dim), means.dtype, means.device)        # Normal.rsample's own draw
-                k = _lib.FlexAgentSumArgs()
-                k.n_envs, k.n_agents, k.act_dim = N, m.n_, m.act_dim
-                k.act_low, k.act_high = float(m.args.action_low), float(m.args.action_high)
-                k.means, k.eps, k.std = means.data_ptr(), eps.data_ptr(), self.std_sum.data_ptr()
-                k.action, k.env_action = self.act_pol_buf.data_ptr(), self.env_act_buf.data_ptr()
-                _lib.check(_lib.load().flexnet_agent_sum_explore(C.byref(k), C.c_void_p(th.cuda.current_stream().cuda_stream)),
-                           "flexnet_agent_sum_explore")
+                summed_exploration(m, means.to(th.float32), env_action=self.env_act_buf, action_out=self.act_pol_buf)
                 env.step(self.env_act_buf, fuse_obs=True, auto_reset=True)
                 self._pack(self.act_pol_buf, hid.reshape(N, m.n_, -1).to(th.float32).contiguous())
             return
@@ -910,6 +899,78 @@ MADDPG._critic_policy_loss = _maddpg_critic_policy_loss
 MADDPG.fused_td_backward = True          # (tests switch it off to compare with the forward / td_loss / backward sequence)
 
 
+def summed_exploration(model, means, env_action=None, action_out=None):
+    """tanh(sum over agents of the means + exp(sum of log-stds) * eps), the ONE action of matd3.py:92-97 / iddpg.py:66-71
+    under util.py:57-64, handed to every agent: [b, n, a] (and, with ``env_action``, translate_action of it) from one launch
+    of flexnet_agent_sum_explore.  eps is Normal.rsample's own draw; every fp32 rounding sits where the tensor ops have it."""
+    import ctypes as C
+    import torch.distributions.normal as tdn      # (looked up at call time: the very function Normal.rsample calls)
+    from . import _lib
+    b, n, a = means.shape
+    cache = model.__dict__.setdefault("_std_sum_cache", {})
+    if means.device not in cache:
+        with th.no_grad():
+            ls = model._log_stds_like(th.zeros(1, n, a, device=means.device))
+            cache[means.device] = _sum_agents(ls.expand(1, n, a)).exp().reshape(a).to(th.float32).contiguous()
+    means = means.contiguous()
+    eps = tdn._standard_normal((b, 1, a), means.dtype, means.device)
+    out = action_out if action_out is not None else th.empty(b, n, a, dtype=th.float32, device=means.device)
+    k = _lib.FlexAgentSumArgs()
+    k.n_envs, k.n_agents, k.act_dim = b, n, a
+    k.act_low, k.act_high = float(model.args.action_low), float(model.args.action_high)
+    k.means, k.eps, k.std, k.action = means.data_ptr(), eps.data_ptr(), cache[means.device].data_ptr(), out.data_ptr()
+    if env_action is not None:
+        k.env_action = env_action.data_ptr()
+    _lib.check(_lib.load().flexnet_agent_sum_explore(C.byref(k), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+               "flexnet_agent_sum_explore")
+    return out
+
+
+class _SumBroadcastAgentsFn(th.autograd.Function):
+    """y[b, i, :] = ((x[b, 0] + x[b, 1]) + ...) for every agent i — matd3.py:94-97's agent-summed mean handed back to every
+    agent (nets.expand_agents of _sum_agents) — and its gradient, which is the same operation on the incoming gradient; one
+    launch each way instead of 2 (n - 1) pointwise adds."""
+
+    @staticmethod
+    def forward(ctx, x, model):
+        ctx.model = model
+        return _sum_broadcast(model, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _sum_broadcast(ctx.model, g.contiguous()), None
+
+
+def _sum_broadcast(model, x):
+    import ctypes as C
+    from . import _lib
+    b, n, a = x.shape
+    x = x.contiguous()
+    out = th.empty(b, n, a, dtype=th.float32, device=x.device)
+    k = _lib.FlexAgentSumArgs()
+    k.n_envs, k.n_agents, k.act_dim = b, n, a
+    k.means, k.action = x.data_ptr(), out.data_ptr()
+    _lib.check(_lib.load().flexnet_agent_sum_explore(C.byref(k), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+               "flexnet_agent_sum_explore")
+    return out
+
+
+def _summed_mean_applies(model, means, status, exploration, actions_avail):
+    """Training mode without exploration (the losses' policy evaluations): the summed mean to every agent, one launch."""
+    return (status == "train" and not exploration and means.is_cuda and means.dtype == th.float32 and means.dim() == 3
+            and means.size(-1) > 1 and getattr(actions_avail, "_flex_const", None) == 1.0
+            and getattr(model, "fused_inference", False))
+
+
+def _summed_exploration_applies(model, means, status, exploration, actions_avail, need_log_prob):
+    """The one-launch form covers exactly: training-mode exploration with the bound enforced, every action available (the
+    constant mask of the vectorised paths), no gradient through the means, nobody asking for the log-probability."""
+    return (not need_log_prob and status == "train" and exploration and bool(model.args.action_enforcebound)
+            and means.is_cuda and means.dtype == th.float32 and means.dim() == 3 and means.size(-1) > 1
+            and not means.requires_grad and getattr(actions_avail, "_flex_const", None) == 1.0
+            and getattr(model, "fused_inference", False))
+
+
 def _sum_agents(x):
     """x.sum(dim=1, keepdim=True) over the (small) agent axis as n - 1 pointwise adds: the same numbers up to fp32
     summation order, and no ATen reduce_kernel in a captured rollout graph (util.GRAPH_DENYLIST is strict about those)."""
@@ -984,10 +1045,17 @@ class MATD3(MADDPG):
         v2, _ = net.forward_from_hidden((h + flag).reshape(b * n, -1), need_hidden=False)
         return th.cat([v1.view(b, n, 1), v2.view(b, n, 1)], dim=0)
 
-    def get_actions(self, obs, status, exploration, actions_avail, target=False, last_hid=None, clip=False):
-        """matd3.py:88-111 (continuous branch)."""
+    def get_actions(self, obs, status, exploration, actions_avail, target=False, last_hid=None, clip=False, need_log_prob=True):
+        """matd3.py:88-111 (continuous branch).  ``need_log_prob=False`` (the losses and the vectorised rollout never read
+        it): exploration in one launch where ``_summed_exploration_applies``."""
         pol = self.target_net.policy if (target and self.args.target) else self.policy
         means, log_stds, hiddens = pol(obs, last_hid=last_hid)
+        if _summed_exploration_applies(self, means, status, exploration, actions_avail, need_log_prob):
+            restore_actions = summed_exploration(self, means)
+            return restore_actions[:, :1], restore_actions, None, (means, log_stds), hiddens
+        if _summed_mean_applies(self, means, status, exploration, actions_avail):
+            restore_actions = _SumBroadcastAgentsFn.apply(means, self)
+            return restore_actions[:, :1], restore_actions, None, (means, log_stds), hiddens
         avail = actions_avail.to(means.device)
         means = means.masked_fill(avail == 0, 0.0)
         log_stds = log_stds.masked_fill(avail == 0, 0.0)
@@ -1032,7 +1100,7 @@ class MATD3(MADDPG):
             with th.no_grad():
                 _, next_actions, _, _, _ = self.get_actions(next_state, status="train", exploration=True,
                                                             actions_avail=actions_avail, target=not self.args.double_q,
-                                                            last_hid=hids, clip=True)
+                                                            last_hid=hids, clip=True, need_log_prob=False)
                 nxt = self.target_net.value(next_state, next_actions)
                 next_min = th.min(nxt[:b].reshape(-1, self.n_), nxt[b:].reshape(-1, self.n_))
             cur = self.value(state, actions)
@@ -1085,10 +1153,16 @@ class IDDPG(MADDPG):
             return v.view(b, self.n_, -1)
         return th.stack([net(inputs[:, i, :], None)[0] for i, net in enumerate(self.value_dicts)], dim=1)
 
-    def get_actions(self, state, status, exploration, actions_avail, target=False, last_hid=None):
+    def get_actions(self, state, status, exploration, actions_avail, target=False, last_hid=None, need_log_prob=True):
         """iddpg.py:61-83 (continuous branch): the means are summed over the agent axis before sampling."""
         pol = self.target_net.policy if (target and self.args.target) else self.policy
         means, log_stds, hiddens = pol(state, last_hid=last_hid)
+        if _summed_exploration_applies(self, means, status, exploration, actions_avail, need_log_prob):
+            restore_actions = summed_exploration(self, means)
+            return restore_actions[:, :1], restore_actions, None, (means, log_stds), hiddens
+        if _summed_mean_applies(self, means, status, exploration, actions_avail):
+            restore_actions = _SumBroadcastAgentsFn.apply(means, self)
+            return restore_actions[:, :1], restore_actions, None, (means, log_stds), hiddens
         if means.size(-1) > 1:
             means_, log_stds_ = _sum_agents(means), _sum_agents(log_stds)
         else:

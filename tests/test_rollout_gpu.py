@@ -445,3 +445,47 @@ def test_training_loop_schedule_is_unchanged_by_bursts():
     assert res[0][0] == res[1][0] == 190
     for x, y in zip(res[0][1] + res[0][2] + list(res[0][3:]), res[1][1] + res[1][2] + list(res[1][3:])):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("alg", ["matd3", "iddpg"])
+def test_one_launch_action_selection_equals_get_actions(alg):
+    """MATD3 / IDDPG.get_actions(need_log_prob=False) on the constant availability mask: exploration (tanh of the
+    agent-summed mean plus noise) and the no-exploration summed mean, each from one launch of flexnet_agent_sum_explore,
+    against the reference-shaped tensor composition — actions bit for bit (same draws), and the gradient w.r.t. the
+    policy's parameters through the summed mean."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd import learner
+    from safe_marl_amd.util import convert
+    a = dict(DEFAULT_ALG_ARGS)
+    a.update(alg=alg, agent_num=5, obs_size=144, state_size=110, action_dim=4)
+    cls = {"matd3": learner.MATD3, "iddpg": learner.IDDPG}[alg]
+    torch.manual_seed(3)
+    m = cls(convert(a)).cuda()
+    with torch.no_grad():
+        for p in m.policy_dicts.parameters():
+            p.mul_(10.0)
+    b = 4096
+    g = torch.Generator(device="cuda").manual_seed(1)
+    obs = torch.randn(b, 5, 144, device="cuda", generator=g)
+    hid = torch.randn(b, 5, 64, device="cuda", generator=g)
+    const = torch.ones(1, 1, 1, device="cuda").expand(b, 5, 4)
+    const._flex_const = 1.0
+    real = torch.ones(b, 5, 4, device="cuda")                     # a materialised mask takes the tensor composition
+    with torch.no_grad():
+        torch.manual_seed(77)
+        fa, fr, flp, _, fh = m.get_actions(obs, "train", True, const, last_hid=hid, need_log_prob=False)
+        torch.manual_seed(77)
+        sa, sr, slp, _, sh = m.get_actions(obs, "train", True, real, last_hid=hid)
+    assert flp is None and slp is not None
+    assert torch.equal(fa, sa) and torch.equal(fr, sr.expand(b, 5, 4)) and torch.equal(fh, sh)
+    # no exploration, with gradients (the policy loss's evaluation)
+    outs = []
+    for mask in (const, real):
+        act, rest, _, _, _ = m.get_actions(obs, "train", False, mask, last_hid=hid, need_log_prob=False)
+        w = torch.linspace(-1, 1, b * 20, device="cuda").view(b, 5, 4)
+        grads = torch.autograd.grad((rest * w).sum(), list(m.policy_dicts.parameters()))
+        outs.append((act.detach(), rest.detach().expand(b, 5, 4).clone(), grads))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for x, y in zip(outs[0][2], outs[1][2]):
+        assert (x - y).abs().max().item() <= 2e-4 * max(1e-6, y.abs().max().item())

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "examples"))
 import safe_marl_amd  # noqa: E402,F401
 from train_maddpg import DEFAULT_ALG_ARGS  # noqa: E402
 from safe_marl_amd.flex_env import VecFlexProvisionEnv  # noqa: E402
-from safe_marl_amd.learner import MADDPG  # noqa: E402
+from safe_marl_amd import learner  # noqa: E402
 from safe_marl_amd.network import create_network  # noqa: E402
 from safe_marl_amd.series import make_synthetic_series  # noqa: E402
 from safe_marl_amd.trainer import PGTrainer  # noqa: E402
@@ -23,7 +23,9 @@ series = make_synthetic_series(net, n_days=100)
 N = int(os.environ.get("ENVS", "4096"))
 env = VecFlexProvisionEnv({}, N, net=net, series=series, warm_start=True)
 alg = dict(DEFAULT_ALG_ARGS)
-alg.update(alg="maddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4, behaviour_update_freq=10 ** 9,
+ALG = os.environ.get("ALG", "maddpg")
+MADDPG = {"maddpg": learner.MADDPG, "matd3": learner.MATD3, "iddpg": learner.IDDPG}[ALG]
+alg.update(alg=ALG, agent_num=5, obs_size=144, state_size=110, action_dim=4, behaviour_update_freq=10 ** 9,
            target_update_freq=10 ** 9)
 tr = PGTrainer(convert(alg), MADDPG, env, None, replay_capacity=N * 96 * 2)
 st = {}
