@@ -695,11 +695,22 @@ class Model(nn.Module):
         avail = th.ones(N, self.n_, self.act_dim, device=self.device)
         info_sum = th.zeros(env.info.shape[1], dtype=th.float64, device=self.device)
         rew_sum = th.zeros((), dtype=th.float64, device=self.device)
+        # plain MADDPG in test mode is tanh(mean) (util.py:79-82) -> translate_action: the actor kernel's epilogue with a zero
+        # standard deviation, one launch instead of the policy plus a dozen pointwise ones
+        fused = (type(self).get_actions is MADDPG.get_actions and self.fused_eval and self.fused_inference
+                 and self.args.shared_params and env.obs.is_cuda and self.args.agent_type == "rnn" and self.hid_dim == 64
+                 and self.obs_dim <= 144 and bool(self.args.action_enforcebound))
+        zero_noise = th.zeros(N, self.n_, self.act_dim, device=self.device) if fused else None
         for t in range(horizon):
             with th.no_grad():
-                action, _, _, _, hid = self.get_actions(obs, status="test", exploration=False, actions_avail=avail,
-                                                        target=False, last_hid=last_hid)
-                actual = self.env_action(action)
+                out = fused_actor_forward(self.policy_dicts[0], obs, last_hid, self.n_, self.args.agent_id, noise=zero_noise,
+                                          std=0.0, low=self.args.action_low, high=self.args.action_high) if fused else None
+                if out is not None:
+                    hid, actual = out[1].view(N, self.n_, -1), out[3].view(N, self.n_, self.act_dim)
+                else:
+                    action, _, _, _, hid = self.get_actions(obs, status="test", exploration=False, actions_avail=avail,
+                                                            target=False, last_hid=last_hid)
+                    actual = self.env_action(action)
             reward, done, info = env.step(actual, fuse_obs=True, auto_reset=True)
             info_sum += info.sum(0)
             rew_sum += reward.sum()
@@ -896,6 +907,7 @@ def _maddpg_critic_policy_loss(self, state, actions_pol):
 
 MADDPG._critic_td_loss = _maddpg_critic_td_loss
 MADDPG._critic_policy_loss = _maddpg_critic_policy_loss
+MADDPG.fused_eval = True                  # (tests switch it off to compare the evaluation with the tensor composition)
 MADDPG.fused_td_backward = True          # (tests switch it off to compare with the forward / td_loss / backward sequence)
 
 

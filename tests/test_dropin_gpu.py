@@ -241,3 +241,39 @@ def test_trainer_run_with_evaluation_keeps_the_ring_consistent(net, series_small
         j0, j1 = slot // n, (slot + bs - 1) // n
         assert buf.first <= j0 and j1 < buf.k and not any(j0 <= g <= j1 for g in live_gaps)
     assert np.isfinite(float(stat["mean_train_value_loss"])) and np.isfinite(float(stat["mean_train_policy_loss"]))
+
+
+def test_evaluation_through_the_actor_epilogue_equals_the_tensor_composition():
+    """Model.evaluation on the vectorised env (model.py:269-306): test-mode MADDPG actions tanh(mean) -> translate_action from
+    the actor kernel's epilogue (zero standard deviation) against get_actions + env_action — the same episode (same reset
+    stream), statistics equal to fp32 round-off of the tanh (the kernel's exp2-based form against the library's)."""
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.trainer import PGTrainer
+    from safe_marl_amd.util import convert
+    net = create_network()
+    series = make_synthetic_series(net, n_days=30)
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="maddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4)
+    stats = []
+    for fused in (True, False):
+        torch.manual_seed(4)
+        env = VecFlexProvisionEnv({}, 512, net=net, series=series, seed=21, warm_start=True)
+        tr = PGTrainer(convert(alg), MADDPG, env, None, replay_capacity=512 * 96 * 2)
+        with torch.no_grad():
+            for p in tr.behaviour_net.policy_dicts.parameters():
+                p.mul_(10.0)
+        tr.behaviour_net.fused_eval = fused
+        st = {}
+        tr.behaviour_net.evaluation(st, tr)
+        stats.append(st)
+    assert stats[0].keys() == stats[1].keys() and "mean_test_reward" in stats[0]
+    for k in stats[0]:
+        assert abs(stats[0][k] - stats[1][k]) <= 1e-5 * max(1e-3, abs(stats[1][k])), (k, stats[0][k], stats[1][k])
