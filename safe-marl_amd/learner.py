@@ -1027,6 +1027,9 @@ class MATD3(MADDPG):
             act_cols = act.detach().reshape(b, n * a)
             if (not act.requires_grad and th.is_grad_enabled() and W.requires_grad
                     and critic_replayed_supported(net, obs_cols, act_cols, n)):
+                if W.shape[1] == n * o + n + n * a + 1 and self.fused_twin:
+                    # both heads as one node: fc1's output formed once, its weight gradient taken once (nets._CriticReplayedTwinFn)
+                    return CriticTail.apply_replayed_twin(obs_cols, act_cols, n, net).view(2 * b, n, 1)
                 q1 = CriticTail.apply_replayed(obs_cols, act_cols, n, net)
                 q2 = CriticTail.apply_replayed(obs_cols, act_cols, n, net, twin=True)
                 return th.cat([q1.view(b, n, 1), q2.view(b, n, 1)], dim=0)
@@ -1131,6 +1134,9 @@ class MATD3(MADDPG):
                 assert returns.size() == values1.size() == values2.size()
                 value_loss = 0.5 * (mean_all((returns - values1).pow(2)) + mean_all((returns - values2).pow(2)))
         return policy_loss, value_loss, action_out
+
+
+MATD3.fused_twin = True             # (tests switch it off to compare with the two single-head nodes)
 
 
 class IDDPG(MADDPG):

@@ -850,6 +850,84 @@ class _CriticReplayedFn(th.autograd.Function):
                 None, None)
 
 
+class _CriticReplayedTwinFn(th.autograd.Function):
+    """Both heads of MATD3's twin critic (matd3.py:33-86: ONE network, the second head with the trailing 0/1 input flag set)
+    on replayed inputs as one node: fc1's output on [obs | act] is the same for both heads — only the id-column table
+    differs (the flag column joins it) — so it is formed once, the tail runs forward and backward per head, and fc1's weight
+    gradient is taken ONCE on the sum of the two heads' input gradients.  Returns cat([Q1, Q2]) as [2 rows, 1]."""
+
+    @staticmethod
+    def forward(ctx, obs2d, act2d, n_agents, W, bias, ln_w, ln_b, w2, b2, w3, b3, eps):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
+        n = n_agents
+        no, na_ = obs2d.shape[1], act2d.shape[1]
+        shared = th.addmm(bias, obs2d, W[:, :no].t())
+        shared.addmm_(act2d, W[:, no + n:no + n + na_].t())
+        id2 = (W[:, no:no + n] + W[:, -1:]).t().contiguous()
+        rows = shared.shape[0] * n
+        q = th.empty(2 * rows, 1, dtype=th.float32, device=shared.device)
+        for h in range(2):
+            args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, eps)
+            args.rows, args.z1, args.z_shared, args.n_agents = rows, None, shared.data_ptr(), n
+            _set_critic_ids(args, W, no, n, dense=id2 if h else None)
+            args.q = q[h * rows:].data_ptr()
+            _lib.check(lib.flexnet_critic_tail_forward(C.byref(args), stream), "flexnet_critic_tail_forward")
+        ctx.eps, ctx.n_agents = eps, n
+        ctx.save_for_backward(obs2d, act2d, shared, id2, W, ln_w, ln_b, w2, b2, w3, b3)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
+        obs2d, act2d, shared, id2, W, ln_w, ln_b, w2, b2, w3, b3 = ctx.saved_tensors
+        n = ctx.n_agents
+        no, na_ = obs2d.shape[1], act2d.shape[1]
+        rows = shared.shape[0] * n
+        dev = shared.device
+        dq = dq.contiguous()
+        dz1 = th.empty(rows, 64, dtype=th.float32, device=dev)                 # (per head, consumed inside its call)
+        grads = th.empty(2, 64 * 64 + 64 * 4 + 1, dtype=th.float32, device=dev)
+        d_shared = th.empty((2,) + tuple(shared.shape), dtype=th.float32, device=dev)
+        d_id = th.empty(2, n, 64, dtype=th.float32, device=dev)
+        ws = _critic_workspace(dev)
+        for h in range(2):
+            g = grads[h]
+            args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, ctx.eps)
+            args.rows, args.z1, args.z_shared, args.n_agents = rows, None, shared.data_ptr(), n
+            _set_critic_ids(args, W, no, n, dense=id2 if h else None)
+            args.dq, args.dz1 = dq[h * rows:].data_ptr(), dz1.data_ptr()
+            args.d_fc2_w, args.d_fc2_b, args.d_fc3_w = g.data_ptr(), g[4096:].data_ptr(), g[4160:].data_ptr()
+            args.d_fc3_b = g[4352:].data_ptr()
+            if ln_w is not None:
+                args.d_ln_w, args.d_ln_b = g[4224:].data_ptr(), g[4288:].data_ptr()
+            args.workspace, args.workspace_floats, args.overwrite_grads = ws.data_ptr(), ws.numel(), 1
+            args.d_z_shared, args.d_z_id = d_shared[h].data_ptr(), d_id[h].data_ptr()
+            _lib.check(lib.flexnet_critic_tail_backward(C.byref(args), stream), "flexnet_critic_tail_backward")
+        gsum = grads[0] + grads[1]
+        dsum = d_shared[0] + d_shared[1]
+        isum = d_id[0] + d_id[1]
+        dW = th.empty_like(W)
+        d_bias = th.empty(64, dtype=th.float32, device=dev)
+        tall_wgrad(dsum, obs2d, out=dW[:, :no], colsum=d_bias, x2=act2d, out2=dW[:, no + n:no + n + na_])
+        dW[:, no:no + n] = isum.t()
+        tot = d_id[1, 0]                       # the flag column sees every agent's row of the second head
+        for i in range(1, n):
+            tot = tot + d_id[1, i]             # (n - 1 pointwise adds: no ATen reduction in a captured graph)
+        dW[:, -1] = tot
+        if W.shape[1] > no + n + na_ + 1:
+            dW[:, no + n + na_:-1] = 0.0
+        d_w2, d_b2, d_w3 = gsum[:4096].view(64, 64), gsum[4096:4160], gsum[4160:4224].view(1, 64)
+        d_g, d_b, d_b3 = gsum[4224:4288], gsum[4288:4352], gsum[4352:4353]
+        has_ln = ln_w is not None
+        return (None, None, None, dW, d_bias, (d_g if has_ln else None), (d_b if has_ln else None), d_w2, d_b2, d_w3, d_b3, None)
+
+
 class _CriticTdLossFn(th.autograd.Function):
     """mean((BatchNorm(reward) + gamma (1 - done) Q'(s', pi'(s')) - Q(s, a))^2) for the shared-parameter critic on replayed
     inputs — maddpg.py:100-123 over maddpg.py:33-76 + mlp_critic.py:25-33 — with the critic's backward run IN the forward
@@ -1114,6 +1192,14 @@ class CriticTail:
                                      None if ln is None else ln.weight, None if ln is None else ln.bias,
                                      critic.fc2.weight, critic.fc2.bias, critic.fc3.weight, critic.fc3.bias,
                                      1e-5 if ln is None else ln.eps)
+
+    @staticmethod
+    def apply_replayed_twin(obs2d, act2d, n_agents, critic):
+        ln = critic.layernorm if critic.args.layernorm else None
+        return _CriticReplayedTwinFn.apply(obs2d, act2d, n_agents, critic.fc1.weight, critic.fc1.bias,
+                                           None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                           critic.fc2.weight, critic.fc2.bias, critic.fc3.weight, critic.fc3.bias,
+                                           1e-5 if ln is None else ln.eps)
 
     @staticmethod
     def apply_replayed(obs2d, act2d, n_agents, critic, twin=False):

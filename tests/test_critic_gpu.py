@@ -388,3 +388,38 @@ def test_policy_loss_from_the_backward_kernel_alone(b):
     assert all(x is None for x in torch.autograd.grad(loss4, list(m.value_dicts.parameters()), allow_unused=True))
     # declines: small batches, advantage normalisation
     assert m._critic_policy_loss(obs[:512], act0[:512].clone().requires_grad_(True)) is None
+
+
+def test_twin_critic_as_one_node_matches_the_two_single_head_nodes():
+    """MATD3.value on replayed actions (matd3.py:33-86): nets._CriticReplayedTwinFn — fc1's output formed once for both
+    heads, its weight gradient taken once on the summed input gradient — against two nets._CriticReplayedFn nodes whose
+    parameter gradients autograd adds up: the values bit for bit, every gradient within fp32 summation error."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd import learner
+    from safe_marl_amd.util import convert
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="matd3", agent_num=5, obs_size=144, state_size=110, action_dim=4)
+    torch.manual_seed(5)
+    m = learner.MATD3(convert(alg)).cuda()
+    with torch.no_grad():
+        for p in m.value_dicts.parameters():
+            p.copy_(torch.randn_like(p) * 0.1)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    b = 16384
+    obs = torch.randn(b, 5, 144, device="cuda", generator=g)
+    act = torch.randn(b, 5, 4, device="cuda", generator=g)
+    up = torch.randn(2 * b, 5, 1, device="cuda", generator=g)
+    params = list(m.value_dicts.parameters())
+    res = []
+    for fused in (True, False):
+        m.fused_twin = fused
+        v = m.value(obs, act)
+        assert v.shape == (2 * b, 5, 1)
+        assert (type(v.grad_fn).__name__ == "_CriticReplayedTwinFnBackward") == fused or type(v.grad_fn).__name__ == "ViewBackward0"
+        res.append((v.detach().clone(),) + torch.autograd.grad((v * up).sum(), params))
+    m.fused_twin = True
+    assert torch.equal(res[0][0], res[1][0])
+    for a, e in zip(res[0][1:], res[1][1:]):
+        assert a.shape == e.shape and _rel(a, e) < 2e-5
