@@ -60,7 +60,11 @@ def parse_args():
     ap.add_argument("--no-train", action="store_true", help="skip the training legs (`train`)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2048-step env-only leg (`sustained`)")
     ap.add_argument("--no-kernel-shares", action="store_true", help="skip the torch.profiler child (`train_kernel_shares`)")
-    ap.add_argument("--train-episodes", type=int, default=3, help="timed 95-step episodes per training leg (>= 2)")
+    ap.add_argument("--train-episodes", type=int, default=12,
+                    help="timed 95-step episodes per training leg (>= 2).  12 episodes = 1140 vector steps = lcm(95, 60): exactly "
+                         "19 update events, the cadence's long-run average (3 episodes hold 4 or 5 events depending on phase)")
+    ap.add_argument("--strict", action="store_true",
+                    help="exit non-zero when a training leg fails or runs without its rollout graph / both update graphs")
     ap.add_argument("--kernel-shares-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=1.5, help="stepping time of the CPU baseline sample (x cores = CPU work)")
     ap.add_argument("--warm-start", type=int, default=1)
@@ -133,8 +137,11 @@ TRAIN_ALG_ARGS = dict(  # madrl/args/default.yaml merged with alg_args/maddpg.ya
 )
 
 
-def make_trainer(alg, n_agents, envs, rank, local_rank):
-    """PGTrainer(args, model, env, logger) as train_agent.py:67-107 builds it, on the vectorised HIP env."""
+def make_trainer(alg, n_agents, envs, rank, local_rank, batch_div=4):
+    """PGTrainer(args, model, env, logger) as train_agent.py:67-107 builds it, on the vectorised HIP env.  A sub-update's batch
+    is batch_size x (envs / batch_div) consecutive replay slots: batch_div = 4 is the trainer's default (1.47 samples consumed
+    per transition collected), batch_div = 1 the reference's own sample reuse (5.87 = 11 x 32 / 60, model.py:43-50 x
+    replay_buffer.py:17-21)."""
     import torch
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
     from safe_marl_amd.learner import MADDPG, SAFEMADDPG
@@ -155,22 +162,29 @@ def make_trainer(alg, n_agents, envs, rank, local_rank):
              v_min=0.9, v_max=1.1)
     torch.manual_seed(0)
     trainer = PGTrainer(convert(d), {"maddpg": MADDPG, "safemaddpg": SAFEMADDPG}[alg], env, None,
-                        replay_capacity=envs * 96 * 2)
+                        batch_scale=max(1, envs // batch_div), replay_capacity=envs * 96 * 2)
     return trainer, env
 
 
-def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, max_over_ranks):
-    """One training configuration: a warm-up episode (allocations, HIP-graph captures, rocBLAS plans), then `episodes`
-    timed episodes of 95 vector steps each between barriers; whole-job env-steps/s = envs x world x steps / max-rank time."""
+def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, max_over_ranks, batch_div=4):
+    """One training configuration: TWO warm-up episodes (allocations, HIP-graph captures of the rollout, its bursts and both
+    sub-updates — the first update event falls into the first episode, the first policy/value replays and the 8/4/2-step
+    bursts of the second window into the second —, rocBLAS plans), then `episodes` timed episodes of 95 vector steps each
+    between barriers; whole-job env-steps/s = envs x world x steps / max-rank time.  `episode_ms` lists the timed episodes
+    one by one (an episode holds one or two update events, so they alternate)."""
     import torch
-    trainer, env = make_trainer(alg, n_agents, envs, rank, local_rank)
+    trainer, env = make_trainer(alg, n_agents, envs, rank, local_rank, batch_div)
     stat = {}
-    trainer.behaviour_net.train_process(stat, trainer)
+    for _ in range(2):
+        trainer.behaviour_net.train_process(stat, trainer)
     barrier()
     steps0 = trainer.steps
+    episode_ms = []
     t0 = time.perf_counter()
     for _ in range(episodes):
-        trainer.behaviour_net.train_process(stat, trainer)
+        t1 = time.perf_counter()
+        trainer.behaviour_net.train_process(stat, trainer)      # (ends on a device -> host read of the episode statistics)
+        episode_ms.append((time.perf_counter() - t1) * 1e3)
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0
     barrier()
@@ -184,13 +198,18 @@ def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, m
            "vector_steps": steps, "ms_per_vector_step": dt / steps * 1e3,
            "env_steps_per_s": envs * world * steps / dt, "grad_steps": events * per_event,
            "batch_per_gpu": trainer.effective_batch_size(),
+           # samples a gradient step consumes per transition the rollout collects: (10 + 1) x batch per 60 x envs
+           "samples_per_transition": per_event * trainer.effective_batch_size() / float(freq * envs),
+           "episode_ms": [round(x, 3) for x in episode_ms],
            "rollout_graph": bool(rg is not None and rg.graph is not None), "rollout_fused": bool(rg is not None and rg.fast),
            "graphed_updates": sorted(trainer._update_graphs), "split_update_graphs": bool(world > 1 and trainer._update_graphs),
            "grad_allreduce": (f"{torch.distributed.get_backend()} all-reduce of one flat bucket (sum, 1/world inside graph B), "
                               "before the clip") if world > 1 else None,
            "mean_train_reward": float(stat.get("mean_train_reward", float("nan"))),
            "mean_train_value_loss": float(stat.get("mean_train_value_loss", float("nan")))}
-    del trainer, env
+    del trainer, env, rg
+    import gc
+    gc.collect()                  # the leg's HIP graphs die here, not inside the next leg's capture (util.graph_capture)
     torch.cuda.empty_cache()
     return out
 
@@ -434,11 +453,11 @@ def main():
     # launch per step); `--no-graph` keeps everything eager.
     graphs = {}
 
-    from safe_marl_amd.util import CAPTURE_MODE
+    from safe_marl_amd.util import graph_capture
 
     def capture(n_steps):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+        with graph_capture(g):
             for j in range(n_steps):
                 one_step(j)
         return g
@@ -536,19 +555,72 @@ def main():
     sweeps_mean = float(env.peek("PF_SWEEPS").float().mean().item())
     n_agents_env, n_bus_env, used_graph = env.n_agents, env.n_bus, bool(graphs)
 
+    # sibling figure with the OTHER solver (north_star names Newton-Raphson; the headline runs the sweep solver whose result
+    # Newton's fp64 mismatch test verifies): same step, same inputs, >= 512 launches as 16-step graphs, HIP events
+    sibling = None
+    if not a.no_sustained:
+        other = "newton" if a.solver == "sweep" else "sweep"
+        try:
+            env2 = VecFlexProvisionEnv({}, a.envs, device=f"cuda:{local_rank}", net=net, series=series,
+                                       seed=1234 + 1000 * rank, warm_start=bool(a.warm_start), pf_tol=a.pf_tol,
+                                       solver={"sweep": 2, "newton": 0}[other])
+            env2.reset()
+
+            def step2(k):
+                env2.step(pool[k % ACTION_POOL], fuse_obs=True, auto_reset=True)
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step2(0)
+            torch.cuda.current_stream().wait_stream(side)
+            g2 = torch.cuda.CUDAGraph()
+            with graph_capture(g2):
+                for j in range(ACTION_POOL):
+                    step2(j)
+            for _ in range(4):
+                g2.replay()
+            n2 = 512
+            barrier()
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t2 = time.perf_counter()
+            q0.record()
+            for _ in range(n2 // ACTION_POOL):
+                g2.replay()
+            q1.record()
+            barrier()
+            el2 = max_over_ranks(time.perf_counter() - t2)
+            sibling = {"solver": other, "steps": n2, "value": a.envs * world * n2 / el2, "unit": "env-steps/s",
+                       "device_ms_per_step": q0.elapsed_time(q1) / n2,
+                       "pf_newton_iters_mean": float(env2.peek("PF_ITERS").float().mean().item()),
+                       "pf_sweeps_mean": float(env2.peek("PF_SWEEPS").float().mean().item()),
+                       "solver_failed_frac": float(env2.failed.float().mean().item())}
+            del env2, g2
+        except Exception as exc:
+            print(f"[bench] rank {rank}: solver sibling leg failed: {exc!r}", file=sys.stderr)
+
     # training legs LAST: the headline (which the scaling curve is computed from) is already measured if a leg fails; every
     # rank takes part — with N > 1 the gradient bucket goes through RCCL — and a failure is recorded, not fatal
     train = None
+    train_failed = False
     if not a.no_train:
-        legs = [("maddpg", 5, N_ENVS)] if distributed else [("maddpg", 5, N_ENVS), ("maddpg", 3, N_ENVS), ("safemaddpg", 5, 2 * N_ENVS)]
+        # (alg, agents, envs per GPU, batch divisor): every configuration at the trainer's default batch (envs / 4 x 32:
+        # 1.47 samples per transition) AND at the reference's own sample reuse (envs x 32: 5.87)
+        if distributed:
+            legs = [("maddpg", 5, N_ENVS, 4), ("safemaddpg", 5, 2 * N_ENVS, 4)]
+        else:
+            legs = [("maddpg", 5, N_ENVS, 4), ("maddpg", 5, N_ENVS, 1), ("maddpg", 3, N_ENVS, 4), ("maddpg", 3, N_ENVS, 1),
+                    ("safemaddpg", 5, 2 * N_ENVS, 4), ("safemaddpg", 5, 2 * N_ENVS, 1)]
         train = []
-        for alg, n_ag, n_env in legs:
+        for alg, n_ag, n_env, div in legs:
             try:
                 train.append(train_leg(alg, n_ag, n_env, max(2, a.train_episodes), rank, local_rank, world, barrier,
-                                       max_over_ranks))
+                                       max_over_ranks, batch_div=div))
             except Exception as exc:                  # a failed leg must not cost the headline line
-                print(f"[bench] rank {rank}: training leg {alg}/{n_ag}/{n_env} failed: {exc!r}", file=sys.stderr)
-                train.append({"alg": alg, "n_agents": n_ag, "envs_per_gpu": n_env, "n_gpus": world, "error": repr(exc)[:300]})
+                print(f"[bench] rank {rank}: training leg {alg}/{n_ag}/{n_env}/{div} failed: {exc!r}", file=sys.stderr)
+                train.append({"alg": alg, "n_agents": n_ag, "envs_per_gpu": n_env, "n_gpus": world, "batch_div": div,
+                              "error": repr(exc)[:300]})
+                train_failed = True
                 break
 
     learner = None
@@ -585,11 +657,18 @@ def main():
             "dtype": "f64",
             "data": "synthetic (stand-in IEEE-33 Baran-Wu network, SURVEY.md App. C; generated series, SURVEY.md §8d)",
             "config": {
-                "workload": "flex_provision.step()+get_obs() batched, 4096 envs/GPU, 33-bus AC power flow (fp64 NR, tol %g), " % a.pf_tol +
-                            "5 agents, in-launch auto-reset",
+                "workload": ("flex_provision.step()+get_obs() batched, %d envs/GPU, 33-bus AC power flow, 5 agents, in-launch "
+                             "auto-reset; solver: %s, inf-norm power mismatch < %g pu") % (
+                                 a.envs,
+                                 "backward/forward sweeps (fp64 anchor sweeps, fp32 increment sweeps between them) + fp64 Newton "
+                                 "verification of the Ybus mismatch (%.3g Newton steps, %.2f sweeps per solve)" % (iters_mean, sweeps_mean)
+                                 if a.solver == "sweep" else
+                                 "fp64 Newton-Raphson on the Ybus, tree-structured elimination (%.2f Newton steps per solve)" % iters_mean,
+                                 a.pf_tol),
                 "envs_per_gpu": a.envs, "n_agents": n_agents_env, "n_bus": n_bus_env,
                 "warm_start": bool(a.warm_start), "launches_per_step": 1, "hip_graph": used_graph,
-                "device_ms_per_step": dev_ms / a.steps, "solver": a.solver, "pf_newton_iters_mean": iters_mean, "pf_sweeps_mean": sweeps_mean,
+                "device_ms_per_step": dev_ms / a.steps, "solver": ("sweep (mixed fp64/fp32 increments) + fp64 Newton verification" if a.solver == "sweep" else "newton (fp64, tree elimination)"),
+                "pf_newton_iters_mean": iters_mean, "pf_sweeps_mean": sweeps_mean,
                 "solver_failed_frac": failed_frac,
             },
             "roofline": {
@@ -602,6 +681,7 @@ def main():
                 "note": "latency/issue-bound fp64 kernel: ~4 KB per env-step cannot approach HBM peak (SURVEY.md §8d)",
             },
             "sustained": sustained,
+            "solver_sibling": sibling,
             "train": train,
             "train_kernel_shares": shares,
             "learner_rooflines": learner,
@@ -615,6 +695,11 @@ def main():
             dist.destroy_process_group()
         except Exception as exc:                       # a rank that failed its training leg is not waited for twice
             print(f"[bench] rank {rank}: shutdown: {exc!r}", file=sys.stderr)
+    if a.strict and train is not None:
+        bad = [t for t in train if "error" in t or not t.get("rollout_graph") or t.get("graphed_updates") != ["policy", "value"]]
+        if train_failed or bad:
+            print(f"[bench] --strict: {len(bad)} training leg(s) failed or ran without their graphs", file=sys.stderr)
+            sys.exit(3)
 
 
 if __name__ == "__main__":

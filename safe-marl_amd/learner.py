@@ -24,7 +24,7 @@ from .nets import (WGRAD_MIN_ROWS, CriticTail, critic_td_loss, critic_td_loss_su
                    critic_tail_supported, fused_actor_forward, tall_linear, td_loss, td_loss_supported, wide_batch_linear,
                    batchnorm_stats_supported, batchnorm_update_running_stats)
 from .replay_buffer import Transition
-from .util import CAPTURE_MODE, prep_obs, scale_action, select_action, translate_action, mean_all
+from .util import graph_capture, prep_obs, scale_action, select_action, translate_action, mean_all
 
 
 class RolloutGraph:
@@ -96,7 +96,11 @@ class RolloutGraph:
         # bookkeeping kernel.  Cursor cells then follow the two-kernel protocol of include/flexenv.h: cursor[0] is read by
         # the policy and written by the env step (slab to read next), cursor[1] is read by the env step and written by the
         # policy (slab it just read).
-        self.sink = bool(self.ring_io and hasattr(env, "set_replay_sink"))
+        # ... within the sink's own limits (flexenv_set_replay_sink: action row <= 32 floats, recurrent row <= 384 floats —
+        # seven agents x 64 units is 448 — and the two-environments-per-wavefront instantiation, i.e. <= 32 PQ buses);
+        # outside them the pack kernel files the transition (three launches per step)
+        self.sink = bool(self.ring_io and hasattr(env, "set_replay_sink") and n * a <= 32 and n * h <= 384
+                         and getattr(env, "n_bus", 33) - 1 <= 32)
         if self.sink:
             self.act_buf = th.zeros(N * n, a, device=dev)
             self.hid_buf = th.zeros(N * n, h, device=dev)
@@ -231,9 +235,14 @@ class RolloutGraph:
                     # flexenv_safety_project); the replay keeps the policy's own action (model.py:232)
                     vec = env.vec if hasattr(env, "vec") else env
                     # ... and the env's action (translate_action of the adjusted vector) comes out of the same launch
-                    _, _, env_action = vec.safety_project(action.view(N, m.n_, m.act_dim), *self.predictor, m.V_min, m.V_max,
-                                                          env_action_range=(m.args.action_low, m.args.action_high),
-                                                          want_hit=False)
+                    if m.intended_actions:        # (not the reference's routing: SAFEMADDPG.intended_actions)
+                        adj, _ = vec.safety_project(action.view(N, m.n_, m.act_dim), *self.predictor, m.V_min, m.V_max,
+                                                    want_hit=False)
+                        env_action = m.env_action(adj)
+                    else:
+                        _, _, env_action = vec.safety_project(action.view(N, m.n_, m.act_dim), *self.predictor, m.V_min, m.V_max,
+                                                              env_action_range=(m.args.action_low, m.args.action_high),
+                                                              want_hit=False)
                 env.step(env_action.view(N, m.n_, m.act_dim), fuse_obs=True, auto_reset=True,
                          obs_ring=buf.obs_ring if self.ring_active else None, replay_sink=self.sink_active)
                 if not self.sink_active:
@@ -284,20 +293,25 @@ class RolloutGraph:
                 continue
             g = self.bursts.get(k)
             if g is None:
-                # recording launches nothing: the environment, the ring and the cursors are untouched (the bodies were
-                # warmed up when the one-step graph was captured); only the env's host-side call counter would move
-                calls = getattr(self.env, "calls", None)
-                g = th.cuda.CUDAGraph()
-                with th.cuda.graph(g, pool=self.graph.pool(), capture_error_mode=CAPTURE_MODE):
-                    for _ in range(k):
-                        self.body()
-                if calls is not None:
-                    self.env.calls = calls
-                self.bursts[k] = g
+                g = self._capture_burst(k)
             g.replay()
             done.extend(self.buf.stepped() for _ in range(k))
             m -= k
         return done
+
+    def _capture_burst(self, k):
+        """A graph of ``k`` bodies, sharing the one-step graph's memory pool.  Recording launches nothing: the environment,
+        the ring and the cursors are untouched (the bodies were warmed up when the one-step graph was captured); only the
+        env's host-side call counter would move."""
+        calls = getattr(self.env, "calls", None)
+        g = th.cuda.CUDAGraph()
+        with graph_capture(g, pool=self.graph.pool()):
+            for _ in range(k):
+                self.body()
+        if calls is not None:
+            self.env.calls = calls
+        self.bursts[k] = g
+        return g
 
     def capture(self):
         """Warm-up + capture.  The warm-up steps are real steps of the environment; the ring cursor and the statistics
@@ -317,11 +331,29 @@ class RolloutGraph:
                 self.body()                      # warm-up on a side stream, as graph capture requires
         th.cuda.current_stream().wait_stream(side)
         g = th.cuda.CUDAGraph()
-        with th.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+        with graph_capture(g):
             self.body()
         self.graph = g
         self.bursts = {}
+        # every burst size NOW, not at first use: a first use falls into somebody's timed region (a 16-body capture is
+        # milliseconds of host work — BENCH_r02's SAFEMADDPG leg, timed from the second episode on, carried the 8 / 4 / 2
+        # captures and read 0.366 ms per vector step on the driver's box against 0.25-0.32 on others)
+        for k in self.BURSTS:
+            self._capture_burst(k)
         self.buf.cursor.copy_(cursor0)
+
+    def release(self):
+        """Undo what construction set up on the env and the replay buffer (capture failed: the eager rollout takes over and
+        writes the buffer field by field, so the env's device-side hooks must not point at a ring any more)."""
+        env = self.env
+        if self.cursor_stepped:
+            env.set_step_counter(None)
+            if hasattr(env, "set_obs_ring"):
+                env.set_obs_ring(None, 0, 0)
+            if hasattr(env, "set_replay_sink"):
+                env.set_replay_sink(None, None, None, None, None)
+        self.graph, self.bursts = None, {}
+        self.buf.release_slabs()
 
     def start_episode(self, first_obs=None):
         """``first_obs`` given: a hard reset happened (env.reset()); the stream restarts in the ring and the hidden state
@@ -597,14 +629,19 @@ class Model(nn.Module):
         N = env.n_envs
         rg = getattr(self, "_rollout_graph", None)
         if rg is None or rg.env is not env or rg.buf is not buf:
-            rg = RolloutGraph(self, env, buf)
-            rg.start_episode(env.reset())                 # the warm-up steps of capture() need a live episode
+            rg = None
             try:
+                rg = RolloutGraph(self, env, buf)
+                rg.start_episode(env.reset())             # the warm-up steps of capture() need a live episode
                 rg.capture()
             except Exception as exc:                      # capture unsupported here: fall back to the eager loop
                 import warnings
                 warnings.warn(f"rollout graph capture failed ({exc}); using the eager rollout")
                 trainer.graph_rollout = False
+                if rg is not None:
+                    rg.release()                          # env hooks off, slab ring dropped: add_batch works again
+                elif getattr(buf, "slab_mode", False) and buf.length == 0:
+                    buf.release_slabs()
                 return self._train_process_vec(stat, trainer)
             object.__setattr__(self, "_rollout_graph", rg)
         # model.py:208 resets the environment at the start of every episode.  Here an episode of `horizon` vector steps
@@ -687,10 +724,31 @@ class Model(nn.Module):
             stat[k] = v / float(self.args.num_eval_episodes)
 
     def _evaluation_vec(self, stat, trainer):
-        env = trainer.env
+        stat.update(self.evaluate_on(trainer.env))
+
+    def evaluate_on(self, env, spec=None):
+        """model.py:269-306 on every environment of ``env`` (a VecFlexProvisionEnv, not necessarily the trainer's): one
+        test-mode episode each — tanh(mean), no exploration (util.py:79-82) — and the reference's ``mean_test_*`` keys,
+        averaged over environments and steps.  ``spec``: injected episode draws (VecFlexProvisionEnv.reset), so that
+        different policies are compared on the SAME episodes.  Besides the reference's keys: ``mean_test_violation_rate``
+        = share of env-steps with any bus voltage outside [v_min, v_max] (voltage_penalty > 0, env:685) and
+        ``mean_test_solver_failed``."""
+        bound = self.__dict__.get("env", None)
+        rebind = bound is not None and (bound.vec if hasattr(bound, "vec") else bound) is not env
+        if rebind:                    # SAFEMADDPG projects against the env it is bound to (safemaddpg.py:143-172)
+            self.__dict__["env"] = env
+        try:
+            return self._evaluate_on(env, spec)
+        finally:
+            if rebind:
+                self.__dict__["env"] = bound
+
+    def _evaluate_on(self, env, spec):
         N = env.n_envs
         horizon = min(self.args.max_steps, env.episode_limit - 1)
-        obs = env.reset().clone()
+        obs = env.reset(spec=spec).clone()
+        viol_sum = th.zeros((), dtype=th.float64, device=self.device)
+        fail_sum = th.zeros((), dtype=th.float64, device=self.device)
         last_hid = th.zeros(N, self.n_, self.hid_dim, device=self.device)
         avail = th.ones(N, self.n_, self.act_dim, device=self.device)
         info_sum = th.zeros(env.info.shape[1], dtype=th.float64, device=self.device)
@@ -714,14 +772,20 @@ class Model(nn.Module):
             reward, done, info = env.step(actual, fuse_obs=True, auto_reset=True)
             info_sum += info.sum(0)
             rew_sum += reward.sum()
+            viol_sum += (info[:, 5] > 0).sum()
+            fail_sum += env.failed.sum()
             donef = done.float()
             obs = env.obs.clone()
             last_hid = hid * (1.0 - donef).view(N, 1, 1)
-        vals = th.cat([info_sum, rew_sum.view(1)]).cpu().numpy() / float(N * horizon)
+        vals = th.cat([info_sum, rew_sum.view(1), viol_sum.view(1), fail_sum.view(1)]).cpu().numpy() / float(N * horizon)
         from ._lib import INFO_KEYS
+        stat = {}
         for i, k in enumerate(INFO_KEYS):
             stat["mean_test_" + k] = float(vals[i])
-        stat["mean_test_reward"] = float(vals[-1])
+        stat["mean_test_reward"] = float(vals[-3])
+        stat["mean_test_violation_rate"] = float(vals[-2])
+        stat["mean_test_solver_failed"] = float(vals[-1])
+        return stat
 
 
 class MADDPG(Model):
@@ -1236,6 +1300,18 @@ class SAFEMADDPG(MADDPG):
         adjusted = self.safety_layer_optimization(restore_actions).to(th.float32)   # safemaddpg.py:106-109
         return adjusted, restore_actions, log_prob_a, action_out, hiddens
 
+    # NOT the reference's behaviour (off by default; no parity claim is made with it on).  The reference hands the safety
+    # layer's type-major physical-unit vector (safemaddpg.py:297) through translate_action (util.py:125-128: clamp to [0, 1],
+    # then 0.5 (a + 1)) to an env that re-reads it agent-major as raw values (env:268-274) — SURVEY A13.  Every entry then
+    # arrives >= 0.5: the load reduction is clipped to its maximum, charging and discharging cancel at their maxima, and q
+    # lands in [0.5, 0.5 + c] pu, so the policy cannot move the environment (tools/learning_curve.py: the test reward of
+    # SAFEMADDPG stays within 3e-4 of -0.097 from the untrained policy to episode 400, at either batch size).  With
+    # ``intended_actions`` the adjusted (percentage, charge, discharge, q) of building i reaches the env as is, agent-major:
+    # what safemaddpg.py:90-111 evidently means to do.
+    intended_actions = False
+
     def env_action(self, action):
+        if self.intended_actions:
+            return action.detach().reshape(-1, self.act_dim, self.n_).transpose(1, 2).to(th.float32).contiguous()
         # the type-major flat vector is re-read agent-major by env.step (safemaddpg.py:297 vs env:268-274, A13)
         return scale_action(self.args, action.detach()).reshape(-1, self.n_, self.act_dim)

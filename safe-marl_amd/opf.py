@@ -174,10 +174,10 @@ def _chol_retry(M, what):
 def _tri_solve(L, rhs):
     """(L L')^-1 rhs by two batched triangular solves (rocBLAS strided-batched trsm).  ``torch.cholesky_solve`` on the same
     operands — L [32, 1920, 1920] fp64 from ``cholesky_ex`` and rhs [32, 1920, 1], both contiguous with standard strides —
-    ended in a GPU memory fault in round 1: for batch > 1 and one right-hand side ATen routes it to hipSOLVER's
-    potrsBatched (array-of-pointers).  The operands are well-formed (this route and ``cholesky_ex`` consume the very same
-    tensors, and the steps pass the KKT / SLSQP checks); the call, shapes, strides and versions are written down in
-    tools/potrs_repro.py and DESIGN.md §9.  Nothing here depends on the faulting route."""
+    ended in a GPU memory fault in round 1 (for batch > 1 and one right-hand side ATen routes it to hipSOLVER's
+    potrsBatched, array-of-pointers).  The operands are well-formed (this route and ``cholesky_ex`` consume the very same
+    tensors, and the steps pass the KKT / SLSQP checks); the CAUSE is unconfirmed — no log or fault address of that run
+    was kept (tools/potrs_repro.py).  Nothing here depends on that call."""
     y = th.linalg.solve_triangular(L, rhs, upper=False)
     return th.linalg.solve_triangular(L.transpose(-1, -2), y, upper=True)
 

@@ -90,6 +90,16 @@ class DeviceReplayBuffer:
     def slab_mode(self):
         return getattr(self, "obs_ring", None) is not None
 
+    def release_slabs(self):
+        """Back to the field-by-field mode (the graph rollout could not be captured): the rings and their bookkeeping go,
+        ``add_batch`` allocates its own store on the next call.  Transitions the ring held are dropped."""
+        self.obs_ring = self.hid_ring = self.small_ring = self.cursor = None
+        self.k = self.first = 0
+        self.gaps = []
+        self.consts, self.const_shapes = {}, {}
+        self.store = None
+        self.head = self.length = 0
+
     def begin_stream(self, first_obs):
         """A rollout starts from a hard reset: ``first_obs`` [N, n, obs] becomes the observation of the slab at the
         cursor, its hidden state is zero.  If a previous stream left the slab at the cursor half-written (observation
@@ -144,6 +154,17 @@ class DeviceReplayBuffer:
             r -= c
         raise AssertionError
 
+    def warmup_slot(self, rows):
+        """Start of a window of ``rows`` consecutive complete slots for a capture's warm-up steps: the first run of the
+        ring that is long enough (the oldest run otherwise — its tail may then be slabs no transition was filed in, which
+        the warm-up, whose steps are undone, only needs to be finite).  Deterministic: sample_slot would move the global
+        NumPy stream that utils/replay_buffer.py:17-21 draws the real windows from."""
+        N = self.n_envs
+        for a, b in self._runs():
+            if (b - a) * N >= rows:
+                return a * N
+        return self._logical_to_slot(0)
+
     def segments(self, slot, rows):
         """Physical pieces of the global slot range [slot, slot + rows): [(physical_slot, count)] (two at the ring's seam)."""
         cap = self.slabs * self.n_envs
@@ -195,25 +216,26 @@ class DeviceReplayBuffer:
         dst a contiguous [rows, width] fp32 tensor."""
         import ctypes as C
         from . import _lib
-        a = _lib.FlexGatherArgs()
-        j = 0
-        cap = self.slabs * self.n_envs
+        jobs = []
         for ring_name, col0, width, row_off, rows, dst in plan:
             ring = getattr(self, ring_name)
             stride = ring.shape[2]
             width = stride if width is None else width
             base, out, done_rows = ring.data_ptr(), dst.data_ptr(), 0
             for p, c in self.segments(slot + row_off, rows):
-                if j >= _lib.FLEXNET_GATHER_MAX_JOBS:
-                    raise RuntimeError("replay refresh needs more copy jobs than flexnet_gather_rows takes")
-                a.src[j], a.dst[j] = base + 4 * (p * stride + col0), out + 4 * done_rows * width
-                a.rows[j], a.width[j], a.src_stride[j], a.dst_stride[j] = c, width, stride, width
+                jobs.append((base + 4 * (p * stride + col0), out + 4 * done_rows * width, c, width, stride))
                 done_rows += c
-                j += 1
-        a.n_jobs = j
-        assert cap > 0
-        _lib.check(_lib.load().flexnet_gather_rows(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)),
-                   "flexnet_gather_rows")
+        # a window that wraps the ring's seam splits every field in two: up to 2 x 8 stored fields = 16 jobs against the
+        # launch's FLEXNET_GATHER_MAX_JOBS (12) — the rest goes out as a second launch instead of an intermittent error
+        stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
+        for lo in range(0, len(jobs), _lib.FLEXNET_GATHER_MAX_JOBS):
+            a = _lib.FlexGatherArgs()
+            chunk = jobs[lo:lo + _lib.FLEXNET_GATHER_MAX_JOBS]
+            for j, (src, dst_p, c, width, stride) in enumerate(chunk):
+                a.src[j], a.dst[j] = src, dst_p
+                a.rows[j], a.width[j], a.src_stride[j], a.dst_stride[j] = c, width, stride, width
+            a.n_jobs = len(chunk)
+            _lib.check(_lib.load().flexnet_gather_rows(C.byref(a), stream), "flexnet_gather_rows")
 
     def _logical_to_slot(self, index):
         """Global slot of logical transition ``index`` (0 = oldest), skipping gaps."""

@@ -24,7 +24,7 @@ from torch.optim import RMSprop
 from . import dist as fdist
 from .optim import clip_and_step
 from .replay_buffer import TransReplayBuffer
-from .util import CAPTURE_MODE, normal_entropy
+from .util import graph_capture, normal_entropy
 
 train_logger = logging.getLogger("TrainLogger")
 
@@ -235,7 +235,8 @@ class PGTrainer(object):
         from .replay_buffer import Transition
         buf = self.replay_buffer
         fields, plan = self._static_batch(which, bs)
-        buf.gather(plan, buf._logical_to_slot(0))          # real transitions for the warm-up steps
+        buf.gather(plan, buf.warmup_slot(bs + buf.n_envs))  # real transitions for the warm-up steps: a window whose
+        #                          next_state rows (N slots further on) exist too; no draw from the NumPy stream
         batch = Transition(**fields)
         out = {}
         # the warm-up steps are real optimiser steps: everything they touch is put back afterwards, IN PLACE (the graph
@@ -264,13 +265,13 @@ class PGTrainer(object):
         apply_graph = None
         out = {}
         if flat is None:
-            with th.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
+            with graph_capture(graph):
                 self._sub_update(which, out, batch, fresh_leaves=True)
         else:
-            with th.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
+            with graph_capture(graph):
                 self._loss_and_grads(which, out, batch, fresh_leaves=True, flat=flat)
             apply_graph = th.cuda.CUDAGraph()
-            with th.cuda.graph(apply_graph, pool=graph.pool(), capture_error_mode=CAPTURE_MODE):
+            with graph_capture(apply_graph, pool=graph.pool()):
                 self._apply_grads(which, out, flat=flat)
         with th.no_grad():
             for k, v in self.behaviour_net.state_dict().items():

@@ -16,6 +16,40 @@ from torch.distributions.normal import Normal
 # call during capture and fails the capture with.  Only this thread's calls are checked.
 CAPTURE_MODE = "thread_local"
 
+
+
+class graph_capture:
+    """``torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE, **kw)`` with Python's cyclic garbage collector held off for
+    the duration of the capture (and run once before it).  A dead reference cycle that owns an OLD ``CUDAGraph`` (a trainer
+    that went out of scope: its nets, graphs and static batches point at each other) is freed whenever the collector
+    happens to run; if that is in the middle of another capture, ``~CUDAGraph`` calls ``hipGraphDestroy`` on the capturing
+    thread and the process dies with "operation not permitted when stream is capturing" (seen in bench.py's sixth training
+    leg: a trainer per leg).  This PyTorch build no longer collects at capture begin by itself."""
+
+    def __init__(self, graph, **kw):
+        self.ctx = th.cuda.graph(graph, capture_error_mode=CAPTURE_MODE, **kw)
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            return self.ctx.__enter__()
+        except BaseException:
+            if self.was_enabled:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.was_enabled:
+                gc.enable()
+
+
 FALLBACKS = {}          # reason -> count: fused HIP paths that declined on GPU tensors (visible, never silent)
 
 
@@ -83,14 +117,14 @@ def is_unit_seed(g):
 
 def const_grad(shape, value, device):
     """A read-only tensor of ``shape`` filled with ``value``, cached (the gradient of a mean under the unit seed).  Made
-    while a HIP graph is being captured it is not cached: its memory and its fill would belong to that graph."""
+    while a HIP graph is being captured it is not cached: its memory and its fill would belong to that graph.  Entries
+    are NEVER evicted: a sub-update graph captured after its eager warm-up has the cached tensor's address baked in, and
+    the cache is that tensor's only owner — one small tensor per (shape, value) a process ever asks for."""
     key = (th.device(device), tuple(shape), float(value))
     t = _CONST_GRADS.get(key)
     if t is None:
         t = th.full(tuple(shape), float(value), dtype=th.float32, device=device)
         if not (t.is_cuda and th.cuda.is_current_stream_capturing()):
-            if len(_CONST_GRADS) >= 64:
-                _CONST_GRADS.clear()
             _CONST_GRADS[key] = t
     return t
 

@@ -489,3 +489,67 @@ def test_one_launch_action_selection_equals_get_actions(alg):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for x, y in zip(outs[0][2], outs[1][2]):
         assert (x - y).abs().max().item() <= 2e-4 * max(1e-6, y.abs().max().item())
+
+
+def _trainer(n_envs, buildings=None, **over):
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.trainer import PGTrainer
+    from safe_marl_amd.util import convert
+    env_args = {} if buildings is None else {"buildings": buildings, "pv_nodes": buildings, "ess_nodes": buildings}
+    net = create_network(env_args)
+    series = make_synthetic_series(net, n_days=30)
+    env = VecFlexProvisionEnv(env_args, n_envs, net=net, series=series, seed=9, warm_start=True)
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="maddpg", agent_num=env.n_agents, obs_size=env.obs_size, state_size=env.state_size, action_dim=4,
+               behaviour_update_freq=30, batch_size=4)
+    alg.update(over)
+    torch.manual_seed(3)
+    np.random.seed(3)
+    return PGTrainer(convert(alg), MADDPG, env, None, replay_capacity=n_envs * 96 * 2)
+
+
+def test_capture_failure_falls_back_to_the_eager_rollout(monkeypatch):
+    """a failed rollout-graph capture used to leave the replay buffer in slab mode and the env's device-side
+    hooks pointed at the ring, so the promised eager rollout raised in add_batch.  Now the ring set-up is undone."""
+    import warnings
+    from safe_marl_amd.learner import RolloutGraph
+    tr = _trainer(256)
+
+    def boom(self):
+        raise RuntimeError("forced capture failure")
+
+    monkeypatch.setattr(RolloutGraph, "capture", boom)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for _ in range(2):
+            stat = {}
+            tr.behaviour_net.train_process(stat, tr)
+    assert any("rollout graph capture failed" in str(x.message) for x in w)
+    assert tr.graph_rollout is False and not tr.replay_buffer.slab_mode
+    assert tr.steps == 190 and len(tr.replay_buffer.buffer) == 190 * 256
+    assert all(torch.isfinite(torch.as_tensor(float(v))) for v in stat.values())
+    assert "mean_train_value_loss" in stat                       # update events ran on the field-by-field buffer
+
+
+def test_seven_agents_take_the_pack_path(monkeypatch):
+    """7 agents x 64 hidden units = 448 floats per env exceed the env-filed transition's 384-float recurrent
+    row (flexenv_set_replay_sink); the rollout must pick the three-launch body (pack kernel) instead of raising."""
+    blds = [5, 8, 10, 15, 20, 25, 30]
+    tr = _trainer(128, buildings=blds)
+    for _ in range(2):
+        stat = {}
+        tr.behaviour_net.train_process(stat, tr)
+    rg = tr.behaviour_net._rollout_graph
+    assert rg.graph is not None and rg.fast and rg.ring_active and not rg.sink and not rg.sink_active
+    assert tr.env.n_agents == 7 and tr.replay_buffer.slab_mode and tr.steps == 190
+    assert sorted(tr._update_graphs) == ["policy", "value"]
+    assert all(torch.isfinite(torch.as_tensor(float(v))) for v in stat.values())
+    # the ring holds what the policy did: actions of the last slab are tanh-bounded, rewards finite, 7 agents wide
+    t = rg.last_transition()
+    assert t.action.shape == (128, 7, 4) and t.action.abs().max().item() <= 1.0 and torch.isfinite(t.reward).all()

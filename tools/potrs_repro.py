@@ -12,12 +12,14 @@ interface) after cloning L into column-major batches (lda = n); both operands he
 standard strides — L.stride() = (1920*1920, 1920, 1), rhs.stride() = (1920, 1, 1), storage offsets 0, the last matrix
 starts 31 * 1920^2 = 114 278 400 elements (914 MB) into the allocation, below 2^31 in elements and in bytes.  The same
 L and rhs go through two rocBLAS strided-batched trsm calls (torch.linalg.solve_triangular) without trouble, and the
-resulting steps pass the KKT certificate of tests/test_opf_cpu.py and the SLSQP comparison of tests/test_opf_gpu.py: the
-operands are well-formed, the fault is specific to the potrsBatched route.  (The faulting line itself never reached the
-history — the first committed version of opf.py already used the trsm pair — and the run log of that session was not
-kept, so the fault address is not on record; the shapes, strides and versions above are.)
+resulting steps pass the KKT certificate of tests/test_opf_cpu.py and the SLSQP comparison of tests/test_opf_gpu.py, so
+the operands are well-formed.  THE CAUSE IS UNCONFIRMED: the faulting line itself never reached the history — the first
+committed version of opf.py already used the trsm pair — and neither the run log, a fault address nor a driver fault
+record of that session was kept.  "The potrsBatched route" is an inference from which call was replaced, not a finding.
+If the fault is ever pursued, start from a recorded run (dmesg / the driver's fault record), not from this file.
 
-Usage (at your own risk, on a box you may lose):  python tools/potrs_repro.py --run
+This script only PRINTS the operands' shapes, strides and versions and checks the trsm route; it does not make the
+cholesky_solve call (never re-trigger a GPU memory fault on a shared host).
 """
 import sys
 
@@ -34,8 +36,8 @@ def operands(batch=32, n=1920, device="cuda"):
 
 if __name__ == "__main__":
     print("torch", torch.__version__, "hip", torch.version.hip)
-    if "--run" not in sys.argv:
-        print(__doc__)
+    print(__doc__)
+    if not torch.cuda.is_available():
         sys.exit(0)
     N, rhs = operands()
     L, info = torch.linalg.cholesky_ex(N)
@@ -44,6 +46,4 @@ if __name__ == "__main__":
     x_trsm = torch.linalg.solve_triangular(L.transpose(-1, -2), y, upper=True)
     torch.cuda.synchronize()
     print("trsm route residual", float((N @ x_trsm - rhs).abs().max()))
-    x = torch.cholesky_solve(rhs, L)                 # the call on record
-    torch.cuda.synchronize()
-    print("potrs route residual", float((N @ x - rhs).abs().max()))
+    print("the call on record — NOT made here: torch.cholesky_solve(rhs, L)")
