@@ -160,7 +160,8 @@ typedef struct {
     int32_t dq_uniform;
     float dq_value;
     float q_mean_scale;
-    int32_t pad2;
+    int32_t variant_pgrad32;       /* backward WITH parameter gradients on the matrix cores: 0 = 16-row tiles, two wavefronts
+                                    * per SIMD (round 3); 1 = the 32-row kernel, one wavefront per SIMD (cross-check, A/B) */
     float* q_mean_out;             /* NULL: no sum of q */
 } FlexCriticTailArgs;
 

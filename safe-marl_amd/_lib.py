@@ -101,7 +101,7 @@ class FlexCriticTailArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
                 ("d_z_id_agent_stride", C.c_int32), ("d_z_id_unit_stride", C.c_int32),
                 ("z_id_agent_stride", C.c_int32), ("z_id_unit_stride", C.c_int32),
-                ("dq_uniform", C.c_int32), ("dq_value", C.c_float), ("q_mean_scale", C.c_float), ("pad2", C.c_int32),
+                ("dq_uniform", C.c_int32), ("dq_value", C.c_float), ("q_mean_scale", C.c_float), ("variant_pgrad32", C.c_int32),
                 ("q_mean_out", C.c_void_p)]
 
 

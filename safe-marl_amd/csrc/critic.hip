@@ -747,6 +747,334 @@ __global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(Fle
     for (int e = tid; e < HID * HID + 4 * HID + 1; e += 64 * CPW) out[e] = fold[e];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same backward (phase A + phase B, TD or handed-in dq) on 16-ROW tiles with v_mfma_f32_16x16x4_f32, TWO wavefronts
+// per SIMD (round 3).  The 32-row kernel above needs 371 registers — one wavefront per SIMD, so nobody issues VALU / LDS
+// work while its MFMA chains run and nobody issues MFMAs while it does its LayerNorm / ReLU arithmetic (0.21 of the fp32
+// matrix peak).  With 16x16 tiles a lane holds 16 units of ONE row (lane = row j + 16 g, register r of unit tile S =
+// unit 16 S + 4 g + r: the instruction's C/D map), so every per-row vector is 16 registers instead of 32 and the row-sum
+// accumulators (d ln_w, d ln_b, d fc3_w) 48 instead of 96; dW2 stays 64 (sixteen 16x16 accumulators).  Under 256
+// registers: a 512-thread block per CU, two wavefronts per SIMD that cover each other's chains.  The accumulator layout
+// chains into the next product exactly as with 32x32 tiles: MFMA step (S, r) contracts over units {16 S + 4 g + r}, the
+// matching weights come from LDS (pitch 68: the four lane groups of an A-operand read land 16 banks apart).  Same MFMA
+// time per row (192 x 32 cycles per 16 rows), same workspace row per block, same second-stage launches.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float cf32x4 __attribute__((ext_vector_type(4)));
+#define C16W 8                                           // wavefronts per block: two per SIMD
+#define C16P 68                                          // pitch (floats) of the two W2 images
+#define C16Q 80                                          // pitch of the per-wavefront [row][unit] transposes
+#define C16MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
+
+// sum over the 16 lanes of a DPP row (the 16 rows of a tile for one lane group); valid in lane 15 of the row
+__device__ __forceinline__ float critic16_row_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    return v;
+}
+
+// sum over the four lane groups holding one row (lanes j, j + 16, j + 32, j + 48)
+__device__ __forceinline__ float critic16_group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// out[T] (T = 0..3: output units 16 T .., accumulator layout) = M * in; M as wl[k * C16P + unit] with the lane part
+// (4 g rows down, j units across) already in the pointer.  Four independent accumulators per step (the instruction's
+// dependent latency is 40 cycles against a 32-cycle issue), the next step's weights requested before this step's MFMAs.
+__device__ __forceinline__ void critic16_layer(const float* wl, const cf32x4* in, cf32x4* out) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = cf32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float w[4], wn[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w[t] = wl[16 * t];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+        if (st + 1 < 16) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wn[t] = wl[(16 * ((st + 1) >> 2) + ((st + 1) & 3)) * C16P + 16 * t];
+        }
+        const float b = in[st >> 2][st & 3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) out[t] = C16MFMA(w[t], b, out[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w[t] = wn[t];
+    }
+}
+
+template <bool TD>
+__global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCriticTailArgs a, FlexTdLossArgs td) {
+    __shared__ float w2t[HID * C16P];                    // w2t[k][j] = W2[j][k]: A operand of z2 = W2 a1
+    __shared__ float w2n[HID * C16P];                    // W2 as stored [j][i]:  A operand of da1 = W2^T dz2
+    __shared__ __attribute__((aligned(16))) float vec[4][HID];
+    __shared__ float td_m[TD_NA], td_sc[TD_NA], td_sh[TD_NA];
+    __shared__ double td_sqw[C16W];
+    __shared__ __attribute__((aligned(16))) float tr[C16W][2][16 * C16Q];     // per wavefront: a1 tile, dz2 tile as [row][unit]
+    __shared__ __attribute__((aligned(16))) float idt[CRITIC_IDT_FLOATS];
+    static_assert(sizeof(tr) >= 4 * CRITIC_WS_PITCH * sizeof(float), "the end-of-kernel fold needs four partial rows");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    for (int idx = tid; idx < HID * HID; idx += 64 * C16W) {
+        const int r = idx / HID, c = idx - r * HID;
+        const float w = a.fc2_w[idx];
+        w2t[c * C16P + r] = w;
+        w2n[r * C16P + c] = w;
+    }
+    critic_stage_ids(a, idt, tid, 64 * C16W);
+    if (TD && tid < TD_NA) td_column_affine(td, tid, td_m[tid], td_sc[tid], td_sh[tid]);
+    if (tid < HID) {
+        vec[0][tid] = a.layernorm ? a.ln_w[tid] : 1.0f;
+        vec[1][tid] = a.layernorm ? a.ln_b[tid] : 0.0f;
+        vec[2][tid] = a.fc2_b[tid];
+        vec[3][tid] = a.fc3_w[tid];
+    }
+    __syncthreads();
+    const float* w2t_l = w2t + (4 * g) * C16P + j;
+    const float* w2n_l = w2n + (4 * g) * C16P + j;
+    const float* g_l = vec[0] + 4 * g;                   // unit 16 S + 4 g + r at [16 S + r]
+    const float* be_l = vec[1] + 4 * g;
+    const float* b2_l = vec[2] + 4 * g;
+    const float* w3_l = vec[3] + 4 * g;
+    float* t1 = tr[wave][0];
+    float* t2 = tr[wave][1];
+    float* t1_w = t1 + j * C16Q + 4 * g;                 // this lane's row, its unit pattern (write side)
+    float* t2_w = t2 + j * C16Q + 4 * g;
+    const float* t1_r = t1 + g * C16Q + j;               // row 4 s + g, unit 16 T + j: read side
+    const float* t2_r = t2 + g * C16Q + j;
+    const bool ln = a.layernorm != 0;
+
+    cf32x4 dW[4][4];                                     // [tj][ti]: dW2 rows 16 tj + 4 g + r, column 16 ti + j
+    cf32x4 sg[4], sb[4], sw3[4];                         // per-lane (row) partial sums of dy xhat, dy, dq h2
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dW[u][v] = cf32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        sg[u] = cf32x4{0.0f, 0.0f, 0.0f, 0.0f}; sb[u] = sg[u]; sw3[u] = sg[u];
+    }
+    float cs2[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sb3 = 0.0f;
+    double td_sq = 0.0;
+    const float td_b3 = a.fc3_b[0], td_inv = TD ? 1.0f / (float)a.rows : 0.0f;
+
+    const int n_tiles = (a.rows + 15) / 16;
+    for (int tile = wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * C16W) {
+        const int r0 = tile * 16;
+        const int row = min(r0 + j, a.rows - 1);
+        const bool live = r0 + j < a.rows;
+        // ---- phase A ------------------------------------------------------------------------------------------
+        cf32x4 xh[4], a1[4];
+        {
+            const float* p0;
+            const float* p1 = nullptr;
+            if (a.z1) {
+                p0 = a.z1 + (int64_t)row * HID + 4 * g;
+            } else {
+                const int b = row / a.n_agents, i = row - b * a.n_agents;
+                p0 = a.z_shared + (int64_t)b * HID + 4 * g;
+                p1 = idt + i * HID + 4 * g;
+            }
+#pragma unroll
+            for (int S = 0; S < 4; ++S) {
+                float4 t = *reinterpret_cast<const float4*>(p0 + 16 * S);
+                if (p1) {
+                    const float4 s = *reinterpret_cast<const float4*>(p1 + 16 * S);
+                    t.x += s.x; t.y += s.y; t.z += s.z; t.w += s.w;
+                }
+                xh[S] = cf32x4{t.x, t.y, t.z, t.w};
+            }
+        }
+        float rstd = 1.0f;
+        if (ln) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int S = 0; S < 4; ++S)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum += xh[S][r];
+            const float mean = critic16_group_sum(sum) * (1.0f / HID);
+            float var = 0.0f;
+#pragma unroll
+            for (int S = 0; S < 4; ++S)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = xh[S][r] - mean; var = fmaf(d, d, var); }
+            rstd = rsqrtf(critic16_group_sum(var) * (1.0f / HID) + a.ln_eps);
+#pragma unroll
+            for (int S = 0; S < 4; ++S)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xh[S][r] = (xh[S][r] - mean) * rstd;
+        }
+#pragma unroll
+        for (int S = 0; S < 4; ++S) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                a1[S][r] = fmaxf(ln ? fmaf(xh[S][r], g_l[16 * S + r], be_l[16 * S + r]) : xh[S][r], 0.0f);
+            *reinterpret_cast<float4*>(t1_w + 16 * S) = make_float4(a1[S][0], a1[S][1], a1[S][2], a1[S][3]);
+        }
+        float dq = 0.0f, td_r = 0.0f, td_nq = 0.0f, td_dn = 0.0f;
+        int td_j = 0;
+        if constexpr (TD) {                                  // the row's TD inputs, in flight under fc2
+            const int tb = row / td.n_agents;
+            td_j = row - tb * td.n_agents;
+            td_r = td.reward[row]; td_nq = td.next_q[row]; td_dn = td.done[tb];
+        } else {
+            dq = live ? a.dq[r0 + j] : 0.0f;                 // spare rows of the last tile contribute nothing
+        }
+        cf32x4 z2[4];
+        critic16_layer(w2t_l, a1, z2);
+        float qp = 0.0f;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float zz = z2[T][r] + b2_l[16 * T + r];
+                z2[T][r] = zz;
+                if constexpr (TD) qp = fmaf(w3_l[16 * T + r], fmaxf(zz, 0.0f), qp);
+            }
+        if constexpr (TD) {
+            const float q = critic16_group_sum(qp) + td_b3;
+            const float rn = (td_r - td_m[td_j]) * td_sc[td_j] + td_sh[td_j];
+            const float delta = rn + td.gamma * (1.0f - td_dn) * td_nq - q;
+            dq = live ? -2.0f * delta * td_inv : 0.0f;
+            if (live && g == 0) {
+                td_sq += (double)delta * (double)delta;
+                if (td.q) const_cast<float*>(td.q)[r0 + j] = q;          // (outputs here: the caller asked to see them)
+                if (td.dq) td.dq[r0 + j] = dq;
+            }
+        }
+        if (g == 0) sb3 += dq;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float zz = z2[T][r];
+                sw3[T][r] = fmaf(dq, fmaxf(zz, 0.0f), sw3[T][r]);
+                z2[T][r] = zz > 0.0f ? dq * w3_l[16 * T + r] : 0.0f;                                       // dz2
+            }
+            *reinterpret_cast<float4*>(t2_w + 16 * T) = make_float4(z2[T][0], z2[T][1], z2[T][2], z2[T][3]);
+        }
+        cf32x4 d[4];
+        critic16_layer(w2n_l, z2, d);                                                                     // da1
+        float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+        for (int U = 0; U < 4; ++U)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dy = a1[U][r] > 0.0f ? d[U][r] : 0.0f;          // a1 > 0 <=> y > 0
+                if (ln) {
+                    sg[U][r] = fmaf(dy, xh[U][r], sg[U][r]);
+                    sb[U][r] += dy;
+                }
+                const float dxh = ln ? dy * g_l[16 * U + r] : dy;
+                d[U][r] = dxh;
+                m1 += dxh;
+                m2 = fmaf(dxh, xh[U][r], m2);
+            }
+        if (ln) {
+            m1 = critic16_group_sum(m1) * (1.0f / HID);
+            m2 = critic16_group_sum(m2) * (1.0f / HID);
+#pragma unroll
+            for (int U = 0; U < 4; ++U)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[U][r] = rstd * (d[U][r] - m1 - xh[U][r] * m2);
+        }
+        if (live) {
+            float* out = a.dz1 + (int64_t)(r0 + j) * HID + 4 * g;
+#pragma unroll
+            for (int U = 0; U < 4; ++U)
+                *reinterpret_cast<float4*>(out + 16 * U) = make_float4(d[U][0], d[U][1], d[U][2], d[U][3]);
+        }
+        // ---- phase B: dW2 += dz2^T a1 over the tile's 16 rows (4 row groups), db2 from the A operands ----------------
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                    // lgkmcnt(0): the transposes have landed
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { av[T] = t2_r[4 * s * C16Q + 16 * T]; bv[T] = t1_r[4 * s * C16Q + 16 * T]; }
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) dW[tj][ti] = C16MFMA(av[tj], bv[ti], dW[tj][ti]);
+                cs2[tj] += av[tj];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                       // the next tile overwrites the transposes
+    }
+
+    // ---- the wavefronts' sums -> the block's partial row [dW2 | db2 | dw3 | dg | db | db3] ---------------------------
+    if constexpr (TD) {                                                        // squared TD errors: lanes, then wavefronts in order
+        double v = td_sq;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) td_sqw[wave] = v;
+    }
+    // row-lane vectors: over the 16 rows of the lane group (DPP), valid in lane j == 15
+#pragma unroll
+    for (int S = 0; S < 4; ++S)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sw3[S][r] = critic16_row_sum(sw3[S][r]);
+            sg[S][r] = critic16_row_sum(sg[S][r]);
+            sb[S][r] = critic16_row_sum(sb[S][r]);
+        }
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) cs2[tj] = critic16_group_sum(cs2[tj]);      // db2[16 tj + j], every group holds it
+    float b3t = g == 0 ? sb3 : 0.0f;                                           // rows live in the g == 0 lanes
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) b3t += __shfl_xor(b3t, off, 64);
+    __syncthreads();                                                           // all tiles done: tr becomes the fold area
+    if constexpr (TD) {
+        if (tid == 0) {
+            double v = td_sqw[0];
+#pragma unroll
+            for (int w = 1; w < C16W; ++w) v += td_sqw[w];
+            reinterpret_cast<double*>(td.workspace)[TD_WS_SQ + blockIdx.x] = v;
+        }
+    }
+    // wavefronts 0-3 store their partial row into area w, wavefronts 4-7 add theirs to area w - 4, then the four areas are
+    // summed in index order: a fixed order whatever the timing
+    float* area = &tr[0][0][0] + (wave & 3) * CRITIC_WS_PITCH;
+    for (int half = 0; half < 2; ++half) {
+        if ((wave >> 2) == half) {
+            const bool first = half == 0;
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = (16 * tj + 4 * g + r) * HID + 16 * ti + j;                     // dW2[j][i]
+                        area[e] = (first ? 0.0f : area[e]) + dW[tj][ti][r];
+                    }
+            if (g == 0) {
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) {
+                    const int e = HID * HID + 16 * tj + j;
+                    area[e] = (first ? 0.0f : area[e]) + cs2[tj];
+                }
+            }
+            if (j == 15) {
+#pragma unroll
+                for (int S = 0; S < 4; ++S)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int u = 16 * S + 4 * g + r;
+                        float* p = area + HID * HID + HID + u;
+                        p[0] = (first ? 0.0f : p[0]) + sw3[S][r];
+                        p[HID] = (first ? 0.0f : p[HID]) + sg[S][r];
+                        p[2 * HID] = (first ? 0.0f : p[2 * HID]) + sb[S][r];
+                    }
+            }
+            if (lane == 0) { const int e = HID * HID + 4 * HID; area[e] = (first ? 0.0f : area[e]) + b3t; }
+        }
+        __syncthreads();
+    }
+    const float* a0 = &tr[0][0][0];
+    float* out = a.workspace + (int64_t)blockIdx.x * CRITIC_WS_PITCH;
+    for (int e = tid; e < HID * HID + 4 * HID + 1; e += 64 * C16W)
+        out[e] = ((a0[e] + a0[CRITIC_WS_PITCH + e]) + a0[2 * CRITIC_WS_PITCH + e]) + a0[3 * CRITIC_WS_PITCH + e];
+}
+
 // below this the VALU kernels (4 rows per wavefront, 8 blocks per CU) spread a batch over the chip better than
 // 32-row MFMA tiles do: 8.5 vs 11.4 us forward at 20 480 rows, 43.5 vs 28.5 us at 163 840
 #define CRITIC_MFMA_MIN_ROWS 65536
@@ -901,7 +1229,10 @@ extern "C" int flexnet_critic_td_backward(const FlexCriticTailArgs* a, const Fle
     if (nb < 1 || nb > 1024 || nb > TD_SQ_MAX) return FLEXNET_EHIP;
     hipStream_t s = (hipStream_t)stream;
     if (t->normalise) flex_td_launch_stats(*t, s);
-    hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<true>, dim3(nb), dim3(64 * CPW), 0, s, *a, *t);
+    if (a->variant_pgrad32)      // the 32-row kernel (one wavefront per SIMD), kept as the cross-check and for A/B timing
+        hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<true>, dim3(nb), dim3(64 * CPW), 0, s, *a, *t);
+    else
+        hipLaunchKernelGGL(critic_tail_pgrad16_kernel<true>, dim3(nb), dim3(64 * C16W), 0, s, *a, *t);
     // dz1 folded onto its sources: the fold's partial rows go behind the backward kernel's, so ONE launch finishes both
     int dz_blocks = 0;
     const int64_t dz_off = (int64_t)nb * CRITIC_WS_PITCH;
@@ -945,7 +1276,10 @@ static int critic_tail_backward_main(const FlexCriticTailArgs* a, void* stream) 
     if (two_stage && k.variant == 0 && k.rows >= CRITIC_MFMA_MIN_ROWS) {
         const int nb = critic_mfma_grid(k.rows);
         if (nb < 1 || nb > 1024) return FLEXNET_EHIP;
-        hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<false>, dim3(nb), dim3(64 * CPW), 0, (hipStream_t)stream, k, FlexTdLossArgs{});
+        if (k.variant_pgrad32)
+            hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<false>, dim3(nb), dim3(64 * CPW), 0, (hipStream_t)stream, k, FlexTdLossArgs{});
+        else
+            hipLaunchKernelGGL(critic_tail_pgrad16_kernel<false>, dim3(nb), dim3(64 * C16W), 0, (hipStream_t)stream, k, FlexTdLossArgs{});
         hipLaunchKernelGGL(critic_reduce_kernel, dim3((HID * HID + 4 * HID + 1 + 63) / 64), dim3(64 * RED_G), 0, (hipStream_t)stream, k, nb);
         return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
     }

@@ -630,12 +630,15 @@ def critic_tail_supported(critic, x):
 
 
 CRITIC_VARIANT = 0              # 0: matrix-core forward / dz1-only backward (csrc/critic.hip); 1: the VALU kernels
+CRITIC_PGRAD32 = 0              # matrix-core backward WITH parameter gradients: 0 = 16-row tiles, two wavefronts per SIMD;
+#                                 1 = the 32-row kernel it replaced (tests and tools/critic_bench.py compare the two)
 
 
 def _critic_args(z1, ln_w, ln_b, w2, b2, w3, b3, eps):
     from . import _lib
     a = _lib.FlexCriticTailArgs()
     a.rows, a.layernorm, a.ln_eps, a.variant = z1.shape[0], int(ln_w is not None), float(eps), CRITIC_VARIANT
+    a.variant_pgrad32 = CRITIC_PGRAD32
     a.z1 = z1.data_ptr()
     if ln_w is not None:
         a.ln_w, a.ln_b = ln_w.data_ptr(), ln_b.data_ptr()

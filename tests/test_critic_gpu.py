@@ -423,3 +423,37 @@ def test_twin_critic_as_one_node_matches_the_two_single_head_nodes():
     assert torch.equal(res[0][0], res[1][0])
     for a, e in zip(res[0][1:], res[1][1:]):
         assert a.shape == e.shape and _rel(a, e) < 2e-5
+
+
+@pytest.mark.parametrize("b,n,ln", [(32768, 5, True), (13108, 5, True), (21846, 3, False)])
+def test_pgrad_kernels_on_16_and_32_row_tiles_agree(b, n, ln):
+    """The backward WITH parameter gradients on the matrix cores: 16-row tiles / v_mfma_f32_16x16x4_f32, two wavefronts
+    per SIMD (round 3, the default) against the 32-row kernel it replaced — the same exact-fp32 products in another
+    summation order — handed-in dq and the TD form, full and ragged last tiles (13108 x 5 = 65540 rows = 16 x 4096 + 4)."""
+    from safe_marl_amd import nets
+    from safe_marl_amd.nets import CriticTail
+    c = _critic(layernorm=ln)
+    g = torch.Generator(device="cuda").manual_seed(b + n)
+    shared = torch.randn(b, 64, device="cuda", generator=g)
+    ids = torch.randn(n, 64, device="cuda", generator=g)
+    w = torch.randn(b * n, 1, device="cuda", generator=g)
+    params = [p for name, p in c.named_parameters() if not name.startswith("fc1")]
+    res = []
+    for v32 in (0, 1):
+        nets.CRITIC_PGRAD32 = v32
+        try:
+            s1, i1 = shared.clone().requires_grad_(True), ids.clone().requires_grad_(True)
+            q = CriticTail.apply_composed(s1, i1, c)
+            res.append((q,) + torch.autograd.grad((q * w).sum(), [s1, i1] + params))
+            s2, i2 = shared.clone().requires_grad_(True), ids.clone().requires_grad_(True)
+            again = torch.autograd.grad((CriticTail.apply_composed(s2, i2, c) * w).sum(), [s2, i2] + params)
+            for x, y in zip(res[-1][1:], again):
+                assert torch.equal(x, y)                      # fixed-order sums: bit-reproducible run to run
+        finally:
+            nets.CRITIC_PGRAD32 = 0
+    assert torch.equal(res[0][0], res[1][0])
+    scale = max(1e-6, res[1][1].abs().max().item())
+    row_err = (res[0][1] - res[1][1]).abs().max(dim=1).values / scale     # d_z_shared, per sample (ReLU-mask flips: see above)
+    assert int((row_err > 2e-5).sum().item()) <= max(2, row_err.numel() // 4096) and row_err.max().item() < 0.05
+    for x, y in zip(res[0][2:], res[1][2:]):
+        assert _rel(x, y) < 1e-4, (x.shape, _rel(x, y))

@@ -401,7 +401,7 @@ def test_bursts_of_steps_equal_single_steps_bit_for_bit(fast):
         assert torch.equal(a.buf.cursor, b.buf.cursor)
         for ring in ("obs_ring", "hid_ring", "small_ring"):
             assert torch.equal(getattr(a.buf, ring), getattr(b.buf, ring)), (m, ring)
-    assert sorted(a.bursts) == [2, 4, 8, 16] and not b.bursts
+    assert sorted(a.bursts) == [2, 4, 8, 16] == sorted(b.bursts)   # all captured with the one-step graph; b never replayed one
     assert a.env.calls == calls                                # replays never go through env.step; recording is undone
 
 

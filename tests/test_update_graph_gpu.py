@@ -205,7 +205,9 @@ def test_value_steps_with_the_td_error_formed_in_the_backward_track_the_sequence
     na = [k for k in a.graph_audit["value"]] if getattr(a, "graph_audit", None) else None
     for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
         if va.dtype.is_floating_point:
-            assert (va - vb).abs().max().item() <= 1e-6 + 1e-4 * vb.abs().max().item(), ka
+            # (3e-6: the post-RMSprop tolerance of the golden tests — twelve steps of lr 1e-4 on gradients that are sums over
+            # 163 840 rows in two summation orders; LayerNorm's bias starts at zero, so the relative term is no help there)
+            assert (va - vb).abs().max().item() <= 3e-6 + 1e-4 * vb.abs().max().item(), ka
     oa, ob = a.value_optimizer.state_dict()["state"], b.value_optimizer.state_dict()["state"]
     for k in oa:
         assert torch.allclose(oa[k]["square_avg"], ob[k]["square_avg"], rtol=1e-3, atol=1e-12), k

@@ -81,3 +81,14 @@ for rows in (20480, 163840):
         tf, tb = graph_timed(fwd), graph_timed(both)
         print(f"{rows:7d} rows, variant {variant}: forward {tf:6.1f} us, forward + dz1-only backward {tb:6.1f} us")
     nets.CRITIC_VARIANT = 0
+
+# the value sub-update's critic backward (flexnet_critic_td_backward: statistics, matrix-core backward with parameter
+# gradients forming the TD error itself, dz fold, finish) on 16-row tiles / two wavefronts per SIMD vs the 32-row kernel
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+for v32 in (0, 1):
+    nets.CRITIC_PGRAD32 = v32
+    r = bench.critic_backward_roofline(lambda fn, n=200: timed(fn, n) * 1e-6)
+    print(f"td backward, {'32-row kernel, 1 wavefront/SIMD' if v32 else '16-row kernel, 2 wavefronts/SIMD'}: "
+          f"{r['launch_us']:6.1f} us for {r['rows']} rows = {r['achieved']:.1f} TFLOP/s fp32 = {r['frac']:.3f} of the matrix peak")
+nets.CRITIC_PGRAD32 = 0
