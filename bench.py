@@ -313,10 +313,11 @@ def critic_backward_roofline(timed):
 
     t = timed(call)
     flops = 3.0 * 2 * 64 * 64 * samples * n
-    return {"kernel": "critic_tail_pgrad_mfma_kernel<TD> + statistics, fold, finish", "rows": samples * n,
-            "what": "value loss + critic backward of a value sub-update (4 launches)", "bound": "mfma", "dtype": "f32",
+    return {"kernel": "critic_tail_pgrad16_kernel<TD, SM> + statistics, finish", "rows": samples * n,
+            "what": "value loss + critic backward of a value sub-update (3 launches)", "bound": "mfma", "dtype": "f32",
             "achieved": flops / t / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t / 1e12 / 157.3, "launch_us": t * 1e6,
-            "note": "one wavefront per SIMD (371 registers); more than half of a tile's time is VALU / LDS work between the MFMAs"}
+            "note": "16-row tiles on v_mfma_f32_16x16x4_f32, two wavefronts per SIMD; sample-major: d_z_shared / d_z_id formed in the "
+                    "backward kernel, no dz1 round trip, no fold launch (3 launches: statistics, backward, finish)"}
 
 
 def kernel_shares_child():

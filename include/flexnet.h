@@ -142,7 +142,8 @@ typedef struct {
     int32_t n_agents;          /* used with z_shared */
     int32_t overwrite_grads;   /* backward, fixed-order path only: the six parameter gradients are STORED, not added to
                                 * (no zero fill by the caller); with the atomic path set: FLEXNET_EINVAL */
-    float* d_z_shared;         /* backward, composed input: out [rows / n_agents, 64] = sum over a sample's agents of dz1, or NULL */
+    float* d_z_shared;         /* backward, composed input: out [rows / n_agents, 64] = sum over a sample's agents of dz1, or NULL
+                                * (set: the contents of dz1 after the call are unspecified, see variant_pgrad32) */
     float* d_z_id;             /* backward, composed input: out [n_agents, 64] = sum over samples of dz1, or NULL (both or none;
                                 * needs the workspace) */
     float* workspace;          /* backward: scratch for the per-block partial sums, or NULL */
@@ -160,8 +161,12 @@ typedef struct {
     int32_t dq_uniform;
     float dq_value;
     float q_mean_scale;
-    int32_t variant_pgrad32;       /* backward WITH parameter gradients on the matrix cores: 0 = 16-row tiles, two wavefronts
-                                    * per SIMD (round 3); 1 = the 32-row kernel, one wavefront per SIMD (cross-check, A/B) */
+    int32_t variant_pgrad32;       /* backward WITH parameter gradients on the matrix cores (rows >= 65 536, fixed-order workspace):
+                                    * 0 = 16-row tiles, two wavefronts per SIMD (round 3) — on a composed input with d_z_shared
+                                    *     set, in its sample-major form: d_z_shared and d_z_id come out of the backward kernel
+                                    *     itself and `dz1` is NOT written (scratch the caller still provides);
+                                    * 1 = the 32-row kernel, one wavefront per SIMD, dz1 stored and folded by a second kernel;
+                                    * 2 = 16-row tiles over consecutive rows, dz1 stored and folded (cross-checks, A/B) */
     float* q_mean_out;             /* NULL: no sum of q */
 } FlexCriticTailArgs;
 

@@ -758,11 +758,21 @@ __global__ __launch_bounds__(64 * CPW, 1) void critic_tail_pgrad_mfma_kernel(Fle
 // chains into the next product exactly as with 32x32 tiles: MFMA step (S, r) contracts over units {16 S + 4 g + r}, the
 // matching weights come from LDS (pitch 68: the four lane groups of an A-operand read land 16 banks apart).  Same MFMA
 // time per row (192 x 32 cycles per 16 rows), same workspace row per block, same second-stage launches.
+//
+// SM ("sample-major", composed input with d_z_shared wanted — both callers of the update path): a tile is 16 SAMPLES of
+// one agent, and a wavefront walks the n agents of its 16 samples before it moves on.  Then d_z_shared[b] = sum over the
+// agents of dz1[b n + i] is an in-lane sum (16 registers, stored once per sample tile) and d_z_id[i] = sum over samples of
+// dz1 is a DPP row sum per tile into a per-wavefront LDS row: dz1 itself — 42 MB at the update batch — is never written,
+// and the fold launch that read it back (critic_dz_fold_kernel, 17 us) is gone; the block's id partial rows go where the
+// fold kernel's went, for the same second stage.
 // ---------------------------------------------------------------------------------------------------------------
 typedef float cf32x4 __attribute__((ext_vector_type(4)));
 #define C16W 8                                           // wavefronts per block: two per SIMD
 #define C16P 68                                          // pitch (floats) of the two W2 images
-#define C16Q 80                                          // pitch of the per-wavefront [row][unit] transposes
+#define C16Q 68                                          // pitch of the per-wavefront [row][unit] transposes: the float4 stores of
+                                                         // eight consecutive rows cover all 32 banks (the reads of two row
+                                                         // groups overlap in 12 of 16 banks: 32 two-way reads per tile, cheaper
+                                                         // than four-way stores at pitch 80, and 12 KB less LDS)
 #define C16MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
 
 // sum over the 16 lanes of a DPP row (the 16 rows of a tile for one lane group); valid in lane 15 of the row
@@ -774,11 +784,16 @@ __device__ __forceinline__ float critic16_row_sum(float v) {
     return v;
 }
 
-// sum over the four lane groups holding one row (lanes j, j + 16, j + 32, j + 48)
+// sum over the four lane groups holding one row (lanes j, j + 16, j + 32, j + 48), the same bits in all four:
+// v_permlane16_swap / v_permlane32_swap (gfx950) exchange 16- and 32-lane halves in the VALU — no trip through the LDS
+// crossbar as with ds_bpermute (five of these sit on every tile's dependent chain)
 __device__ __forceinline__ float critic16_group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);       // r[0] = rows 0,0,2,2 of x; r[1] = rows 1,1,3,3
+    v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    const unsigned y = __builtin_bit_cast(unsigned, v);
+    auto q = __builtin_amdgcn_permlane32_swap(y, y, false, false);       // q[0] = lower half twice; q[1] = upper half twice
+    return __builtin_bit_cast(float, (unsigned)q[0]) + __builtin_bit_cast(float, (unsigned)q[1]);
 }
 
 // out[T] (T = 0..3: output units 16 T .., accumulator layout) = M * in; M as wl[k * C16P + unit] with the lane part
@@ -804,18 +819,42 @@ __device__ __forceinline__ void critic16_layer(const float* wl, const cf32x4* in
     }
 }
 
-template <bool TD>
-__global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCriticTailArgs a, FlexTdLossArgs td) {
+// diagnostic build (-DCRITIC_STAMPS, tools/critic_stamps.py): s_memtime between the phases of block 0's first wavefront,
+// summed over its tiles (never timed, never shipped; the stamps' own s_waitcnt drains the LDS queue at every boundary)
+#ifdef CRITIC_STAMPS
+__device__ unsigned long long critic_stamps[16];
+#define CSTAMP_DECL unsigned long long cs_last = __builtin_amdgcn_s_memtime(), cs_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define CSTAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cs_acc[k] += t_ - cs_last; cs_last = t_; } while (0)
+#define CSTAMP_OUT do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int k_ = 0; k_ < 10; ++k_) critic_stamps[k_] = cs_acc[k_]; } } while (0)
+extern "C" int flexnet_debug_critic_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(critic_stamps), sizeof(critic_stamps)) == hipSuccess ? 0 : -2;
+}
+#else
+#define CSTAMP_DECL do { } while (0)
+#define CSTAMP(k) do { } while (0)
+#define CSTAMP_OUT do { } while (0)
+#endif
+
+#define C16_IDW (FLEXNET_MAX_AGENTS * HID)               // a wavefront's id-column sums [agent][unit] (SM)
+
+template <bool TD, bool SM, bool LN>
+__global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCriticTailArgs a, FlexTdLossArgs td, int64_t dz_off) {
     __shared__ float w2t[HID * C16P];                    // w2t[k][j] = W2[j][k]: A operand of z2 = W2 a1
     __shared__ float w2n[HID * C16P];                    // W2 as stored [j][i]:  A operand of da1 = W2^T dz2
     __shared__ __attribute__((aligned(16))) float vec[4][HID];
     __shared__ float td_m[TD_NA], td_sc[TD_NA], td_sh[TD_NA];
+    __shared__ double td_part[8][2 * TD_NA];
     __shared__ double td_sqw[C16W];
-    __shared__ __attribute__((aligned(16))) float tr[C16W][2][16 * C16Q];     // per wavefront: a1 tile, dz2 tile as [row][unit]
+    // one pool: per wavefront the a1 tile and the dz2 tile as [row][unit] (pitch C16Q), then (SM) per wavefront the sample
+    // tile's shared rows as loaded [16][64]; at the end of the kernel the pool is the fold area (four partial rows)
+    constexpr int TR_FLOATS = C16W * 2 * 16 * C16Q, XS_FLOATS = SM ? C16W * 16 * HID : 0;
+    constexpr int POOL_FLOATS = TR_FLOATS + XS_FLOATS > 4 * CRITIC_WS_PITCH ? TR_FLOATS + XS_FLOATS : 4 * CRITIC_WS_PITCH;
+    __shared__ __attribute__((aligned(16))) float pool[POOL_FLOATS];
     __shared__ __attribute__((aligned(16))) float idt[CRITIC_IDT_FLOATS];
-    static_assert(sizeof(tr) >= 4 * CRITIC_WS_PITCH * sizeof(float), "the end-of-kernel fold needs four partial rows");
+    __shared__ float idacc[SM ? C16W : 1][C16_IDW];      // SM: per-wavefront sums over samples of dz1, per agent
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
+    CSTAMP_DECL;
     for (int idx = tid; idx < HID * HID; idx += 64 * C16W) {
         const int r = idx / HID, c = idx - r * HID;
         const float w = a.fc2_w[idx];
@@ -823,7 +862,22 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
         w2n[r * C16P + c] = w;
     }
     critic_stage_ids(a, idt, tid, 64 * C16W);
-    if (TD && tid < TD_NA) td_column_affine(td, tid, td_m[tid], td_sc[tid], td_sh[tid]);
+    if constexpr (SM) {
+        for (int e = tid; e < C16W * C16_IDW; e += 64 * C16W) (&idacc[0][0])[e] = 0.0f;
+    }
+    if constexpr (TD) {
+        // the reward columns' batch statistics from the statistics pass's 64 per-block partial sums: 128 threads take 8
+        // blocks each (loads in flight together), 16 threads finish — td_column_stats' loop, run by one thread per column,
+        // was 128 dependent-latency loads in the prologue of every block
+        if (td.normalise && tid < 128) {
+            const int c = tid & 15, part = tid >> 4;
+            const double* ws = reinterpret_cast<const double*>(td.workspace);
+            double v = 0.0;
+#pragma unroll
+            for (int b = 0; b < TD_BLOCKS / 8; ++b) v += ws[(part * (TD_BLOCKS / 8) + b) * 2 * TD_NA + c];
+            td_part[part][c] = v;
+        }
+    }
     if (tid < HID) {
         vec[0][tid] = a.layernorm ? a.ln_w[tid] : 1.0f;
         vec[1][tid] = a.layernorm ? a.ln_b[tid] : 0.0f;
@@ -831,19 +885,34 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
         vec[3][tid] = a.fc3_w[tid];
     }
     __syncthreads();
+    if constexpr (TD) {
+        if (tid < TD_NA) {
+            float m = 0.0f, sc = 1.0f, sh = 0.0f;
+            if (td.normalise && tid < td.n_agents) {
+                double su = 0.0, ss = 0.0;
+#pragma unroll
+                for (int p8 = 0; p8 < 8; ++p8) { su += td_part[p8][tid]; ss += td_part[p8][TD_NA + tid]; }
+                const double mean = su / (double)td.rows;
+                double var = ss / (double)td.rows - mean * mean;                     // biased (what the normalisation uses)
+                if (var < 0.0) var = 0.0;
+                m = (float)mean;
+                sc = (float)(1.0 / sqrt(var + (double)td.bn_eps)) * (td.bn_weight ? td.bn_weight[tid] : 1.0f);
+                sh = td.bn_bias ? td.bn_bias[tid] : 0.0f;
+            }
+            td_m[tid] = m; td_sc[tid] = sc; td_sh[tid] = sh;
+        }
+        __syncthreads();
+    }
     const float* w2t_l = w2t + (4 * g) * C16P + j;
     const float* w2n_l = w2n + (4 * g) * C16P + j;
-    const float* g_l = vec[0] + 4 * g;                   // unit 16 S + 4 g + r at [16 S + r]
-    const float* be_l = vec[1] + 4 * g;
-    const float* b2_l = vec[2] + 4 * g;
-    const float* w3_l = vec[3] + 4 * g;
-    float* t1 = tr[wave][0];
-    float* t2 = tr[wave][1];
+    float* t1 = pool + (2 * wave) * 16 * C16Q;
+    float* t2 = pool + (2 * wave + 1) * 16 * C16Q;
     float* t1_w = t1 + j * C16Q + 4 * g;                 // this lane's row, its unit pattern (write side)
     float* t2_w = t2 + j * C16Q + 4 * g;
     const float* t1_r = t1 + g * C16Q + j;               // row 4 s + g, unit 16 T + j: read side
     const float* t2_r = t2 + g * C16Q + j;
-    const bool ln = a.layernorm != 0;
+    constexpr bool ln = LN;
+    const bool composed = SM || !a.z1;
 
     cf32x4 dW[4][4];                                     // [tj][ti]: dW2 rows 16 tj + 4 g + r, column 16 ti + j
     cf32x4 sg[4], sb[4], sw3[4];                         // per-lane (row) partial sums of dy xhat, dy, dq h2
@@ -857,32 +926,83 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
     double td_sq = 0.0;
     const float td_b3 = a.fc3_b[0], td_inv = TD ? 1.0f / (float)a.rows : 0.0f;
 
-    const int n_tiles = (a.rows + 15) / 16;
-    for (int tile = wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * C16W) {
-        const int r0 = tile * 16;
-        const int row = min(r0 + j, a.rows - 1);
-        const bool live = r0 + j < a.rows;
+    // Work items.  Plain: 16 consecutive rows per tile.  SM: sample tile `ot` (16 samples) x agent `ia`, agents innermost.
+    const int n_ag = SM ? a.n_agents : 1;
+    const int units = SM ? a.rows / a.n_agents : a.rows;                       // samples (SM) or rows
+    const int n_ot = (units + 15) / 16;
+    const int ot_step = gridDim.x * C16W;
+    int ot = wave * gridDim.x + blockIdx.x, ia = 0;
+    // the raw first-layer row of a work item (z1 row, or the sample's shared part): requested one item ahead, into the
+    // registers the previous item's xhat has just vacated
+    cf32x4 xn[4];
+    auto request = [&](int o, cf32x4* dst) {
+        const int u = min(16 * o + j, units - 1);
+        const float* p0;
+        if (SM) p0 = a.z_shared + (int64_t)u * HID + 4 * g;
+        else if (a.z1) p0 = a.z1 + (int64_t)u * HID + 4 * g;
+        else p0 = a.z_shared + (int64_t)(u / a.n_agents) * HID + 4 * g;
+#pragma unroll
+        for (int S = 0; S < 4; ++S) {
+            const float4 t = *reinterpret_cast<const float4*>(p0 + 16 * S);
+            dst[S] = cf32x4{t.x, t.y, t.z, t.w};
+        }
+    };
+    if (!SM && ot < n_ot) request(ot, xn);
+    cf32x4 dzs[SM ? 4 : 1];                              // SM: sum over the agents of dz1, this lane's sample
+    float* xs_l = pool + TR_FLOATS + (SM ? wave * 16 * HID + j * HID + 4 * g : 0);   // this lane's 4 x 16 bytes of its sample's row
+    // static priority for the second-dispatched half: at equal priority the older wavefront of a SIMD wins every issue
+    // arbitration, finishes first and leaves the younger one to run its tail alone (67.7 -> 66.5 us for the TD backward's
+    // launches at the update batch; alternating the priority per tile measured the same)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    CSTAMP(0);                                                                 // staging, barriers
+    while (ot < n_ot) {
+        // the four parameter vectors are read from LDS where they are used: 64 loop-invariant reads hoisted out of this
+        // loop (which the compiler does when it can prove the offset invariant) are 64 registers this kernel does not have
+        int voff = 4 * g;
+        asm volatile("" : "+v"(voff));
+        const float* g_l = vec[0] + voff;                // unit 16 S + 4 g + r at [16 S + r]
+        const float* be_l = vec[1] + voff;
+        const float* b2_l = vec[2] + voff;
+        const float* w3_l = vec[3] + voff;
+        const int u0 = 16 * ot;
+        const int unit = min(u0 + j, units - 1);                               // sample (SM) or row
+        const bool live = u0 + j < units;
+        const int row = SM ? unit * n_ag + ia : unit;
         // ---- phase A ------------------------------------------------------------------------------------------
         cf32x4 xh[4], a1[4];
         {
-            const float* p0;
-            const float* p1 = nullptr;
-            if (a.z1) {
-                p0 = a.z1 + (int64_t)row * HID + 4 * g;
-            } else {
-                const int b = row / a.n_agents, i = row - b * a.n_agents;
-                p0 = a.z_shared + (int64_t)b * HID + 4 * g;
-                p1 = idt + i * HID + 4 * g;
+            const float* p1 = idt + 4 * g;
+            if (SM) p1 += ia * HID;
+            else if (composed) p1 += (row - (row / a.n_agents) * a.n_agents) * HID;
+            if constexpr (SM) {
+                // the sample's shared row: from HBM for the first agent (kept in LDS as loaded), from LDS for the others —
+                // no second trip to memory, and no registers holding it across the tile
+                if (ia == 0) {
+                    request(ot, xn);
+#pragma unroll
+                    for (int S = 0; S < 4; ++S)
+                        *reinterpret_cast<float4*>(xs_l + 16 * S) = make_float4(xn[S][0], xn[S][1], xn[S][2], xn[S][3]);
+                } else {
+#pragma unroll
+                    for (int S = 0; S < 4; ++S) {
+                        const float4 t = *reinterpret_cast<const float4*>(xs_l + 16 * S);
+                        xn[S] = cf32x4{t.x, t.y, t.z, t.w};
+                    }
+                }
             }
 #pragma unroll
-            for (int S = 0; S < 4; ++S) {
-                float4 t = *reinterpret_cast<const float4*>(p0 + 16 * S);
-                if (p1) {
-                    const float4 s = *reinterpret_cast<const float4*>(p1 + 16 * S);
-                    t.x += s.x; t.y += s.y; t.z += s.z; t.w += s.w;
+            for (int S = 0; S < 4; ++S) xh[S] = xn[S];
+            if (composed) {
+#pragma unroll
+                for (int S = 0; S < 4; ++S) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(p1 + 16 * S);
+                    xh[S][0] += s4.x; xh[S][1] += s4.y; xh[S][2] += s4.z; xh[S][3] += s4.w;
                 }
-                xh[S] = cf32x4{t.x, t.y, t.z, t.w};
             }
+        }
+        if (SM && ia == 0) {
+#pragma unroll
+            for (int S = 0; S < 4; ++S) dzs[S] = cf32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
         float rstd = 1.0f;
         if (ln) {
@@ -903,24 +1023,29 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xh[S][r] = (xh[S][r] - mean) * rstd;
         }
+        unsigned amask = 0;                                                    // bit 4 S + r: a1 > 0 (<=> y > 0)
 #pragma unroll
         for (int S = 0; S < 4; ++S) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) {
                 a1[S][r] = fmaxf(ln ? fmaf(xh[S][r], g_l[16 * S + r], be_l[16 * S + r]) : xh[S][r], 0.0f);
+                amask |= (a1[S][r] > 0.0f ? 1u : 0u) << (4 * S + r);
+            }
             *reinterpret_cast<float4*>(t1_w + 16 * S) = make_float4(a1[S][0], a1[S][1], a1[S][2], a1[S][3]);
         }
         float dq = 0.0f, td_r = 0.0f, td_nq = 0.0f, td_dn = 0.0f;
         int td_j = 0;
         if constexpr (TD) {                                  // the row's TD inputs, in flight under fc2
-            const int tb = row / td.n_agents;
-            td_j = row - tb * td.n_agents;
+            const int tb = SM ? unit : row / td.n_agents;
+            td_j = SM ? ia : row - tb * td.n_agents;
             td_r = td.reward[row]; td_nq = td.next_q[row]; td_dn = td.done[tb];
         } else {
-            dq = live ? a.dq[r0 + j] : 0.0f;                 // spare rows of the last tile contribute nothing
+            dq = live ? a.dq[row] : 0.0f;                    // spare rows of the last tile contribute nothing
         }
+        CSTAMP(1);                                                             // LayerNorm, a1, transposed store
         cf32x4 z2[4];
         critic16_layer(w2t_l, a1, z2);
+        CSTAMP(2);                                                             // fc2 forward chain
         float qp = 0.0f;
 #pragma unroll
         for (int T = 0; T < 4; ++T)
@@ -937,8 +1062,8 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
             dq = live ? -2.0f * delta * td_inv : 0.0f;
             if (live && g == 0) {
                 td_sq += (double)delta * (double)delta;
-                if (td.q) const_cast<float*>(td.q)[r0 + j] = q;          // (outputs here: the caller asked to see them)
-                if (td.dq) td.dq[r0 + j] = dq;
+                if (td.q) const_cast<float*>(td.q)[row] = q;             // (outputs here: the caller asked to see them)
+                if (td.dq) td.dq[row] = dq;
             }
         }
         if (g == 0) sb3 += dq;
@@ -952,14 +1077,16 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
             }
             *reinterpret_cast<float4*>(t2_w + 16 * T) = make_float4(z2[T][0], z2[T][1], z2[T][2], z2[T][3]);
         }
+        CSTAMP(3);                                                             // bias, q, TD error, dz2, transposed store
         cf32x4 d[4];
         critic16_layer(w2n_l, z2, d);                                                                     // da1
+        CSTAMP(4);                                                             // da1 chain
         float m1 = 0.0f, m2 = 0.0f;
 #pragma unroll
         for (int U = 0; U < 4; ++U)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float dy = a1[U][r] > 0.0f ? d[U][r] : 0.0f;          // a1 > 0 <=> y > 0
+                const float dy = (amask >> (4 * U + r)) & 1u ? d[U][r] : 0.0f;
                 if (ln) {
                     sg[U][r] = fmaf(dy, xh[U][r], sg[U][r]);
                     sb[U][r] += dy;
@@ -977,20 +1104,42 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
 #pragma unroll
                 for (int r = 0; r < 4; ++r) d[U][r] = rstd * (d[U][r] - m1 - xh[U][r] * m2);
         }
-        if (live) {
-            float* out = a.dz1 + (int64_t)(r0 + j) * HID + 4 * g;
+        // the next work item's raw row is requested here: xhat is dead, phase B covers the latency
+        int ot_n = ot, ia_n = ia + 1;
+        if (ia_n == n_ag) { ia_n = 0; ot_n = ot + ot_step; }
+        if (!SM && ot_n < n_ot) request(ot_n, xn);
+        if constexpr (SM) {
 #pragma unroll
             for (int U = 0; U < 4; ++U)
-                *reinterpret_cast<float4*>(out + 16 * U) = make_float4(d[U][0], d[U][1], d[U][2], d[U][3]);
-        }
-        // ---- phase B: dW2 += dz2^T a1 over the tile's 16 rows (4 row groups), db2 from the A operands ----------------
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);                                    // lgkmcnt(0): the transposes have landed
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+                for (int r = 0; r < 4; ++r) {
+                    const float v = live ? d[U][r] : 0.0f;                     // (spare samples of the last tile: nothing)
+                    dzs[U][r] += v;
+                    const float cs = critic16_row_sum(v);                      // over the tile's 16 samples
+                    if (j == 15) atomicAdd(&idacc[wave][ia * HID + 16 * U + 4 * g + r], cs);   // this wavefront's row only:
+                }                                                              // in-order ds_add_f32, nobody to race with
+            if (ia == n_ag - 1 && live) {
+                float* out = a.d_z_shared + (int64_t)unit * HID + 4 * g;
+#pragma unroll
+                for (int U = 0; U < 4; ++U)
+                    *reinterpret_cast<float4*>(out + 16 * U) = make_float4(dzs[U][0], dzs[U][1], dzs[U][2], dzs[U][3]);
+            }
+        } else {
+            if (live) {
+                float* out = a.dz1 + (int64_t)row * HID + 4 * g;
+#pragma unroll
+                for (int U = 0; U < 4; ++U)
+                    *reinterpret_cast<float4*>(out + 16 * U) = make_float4(d[U][0], d[U][1], d[U][2], d[U][3]);
+            }
+        }
+        CSTAMP(5);                                                             // ReLU / LayerNorm backward, dz1 / d_z_shared
+        // ---- phase B: dW2 += dz2^T a1 over the tile's 16 rows (4 row groups), db2 from the A operands ----------------
+        // (a wavefront's own LDS writes and reads execute in order: no wait between the transposed stores and these reads)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
             float av[4], bv[4];
 #pragma unroll
-            for (int T = 0; T < 4; ++T) { av[T] = t2_r[4 * s * C16Q + 16 * T]; bv[T] = t1_r[4 * s * C16Q + 16 * T]; }
+            for (int T = 0; T < 4; ++T) { av[T] = t2_r[4 * s4 * C16Q + 16 * T]; bv[T] = t1_r[4 * s4 * C16Q + 16 * T]; }
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj) {
 #pragma unroll
@@ -998,7 +1147,9 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
                 cs2[tj] += av[tj];
             }
         }
-        __builtin_amdgcn_wave_barrier();                                       // the next tile overwrites the transposes
+        __builtin_amdgcn_wave_barrier();                                       // (compiler: the next item's stores stay below)
+        CSTAMP(6);                                                             // phase B
+        ot = ot_n; ia = ia_n;
     }
 
     // ---- the wavefronts' sums -> the block's partial row [dW2 | db2 | dw3 | dg | db | db3] ---------------------------
@@ -1031,9 +1182,18 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
             reinterpret_cast<double*>(td.workspace)[TD_WS_SQ + blockIdx.x] = v;
         }
     }
+    if constexpr (SM) {                                                        // the block's id-column partial row, wavefronts in order
+        float* dzo = a.workspace + dz_off + (int64_t)blockIdx.x * C16_IDW;
+        for (int e = tid; e < C16_IDW; e += 64 * C16W) {
+            float t = idacc[0][e];
+#pragma unroll
+            for (int w = 1; w < C16W; ++w) t += idacc[w][e];
+            dzo[e] = t;
+        }
+    }
     // wavefronts 0-3 store their partial row into area w, wavefronts 4-7 add theirs to area w - 4, then the four areas are
     // summed in index order: a fixed order whatever the timing
-    float* area = &tr[0][0][0] + (wave & 3) * CRITIC_WS_PITCH;
+    float* area = pool + (wave & 3) * CRITIC_WS_PITCH;
     for (int half = 0; half < 2; ++half) {
         if ((wave >> 2) == half) {
             const bool first = half == 0;
@@ -1069,10 +1229,24 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
         }
         __syncthreads();
     }
-    const float* a0 = &tr[0][0][0];
+    const float* a0 = pool;
     float* out = a.workspace + (int64_t)blockIdx.x * CRITIC_WS_PITCH;
     for (int e = tid; e < HID * HID + 4 * HID + 1; e += 64 * C16W)
         out[e] = ((a0[e] + a0[CRITIC_WS_PITCH + e]) + a0[2 * CRITIC_WS_PITCH + e]) + a0[3 * CRITIC_WS_PITCH + e];
+    CSTAMP(7);                                                                 // end-of-kernel fold
+    CSTAMP_OUT;
+}
+
+template <bool TD>
+static void critic_launch_pgrad16(int nb, bool sm, const FlexCriticTailArgs& a, const FlexTdLossArgs& t, int64_t dz_off, hipStream_t s) {
+    const dim3 grid(nb), block(64 * C16W);
+    if (sm) {
+        if (a.layernorm) hipLaunchKernelGGL((critic_tail_pgrad16_kernel<TD, true, true>), grid, block, 0, s, a, t, dz_off);
+        else hipLaunchKernelGGL((critic_tail_pgrad16_kernel<TD, true, false>), grid, block, 0, s, a, t, dz_off);
+    } else {
+        if (a.layernorm) hipLaunchKernelGGL((critic_tail_pgrad16_kernel<TD, false, true>), grid, block, 0, s, a, t, dz_off);
+        else hipLaunchKernelGGL((critic_tail_pgrad16_kernel<TD, false, false>), grid, block, 0, s, a, t, dz_off);
+    }
 }
 
 // below this the VALU kernels (4 rows per wavefront, 8 blocks per CU) spread a batch over the chip better than
@@ -1090,6 +1264,7 @@ static int critic_mfma_grid(int rows) {
 // then summed over blocks in a fixed order) — instead of two library reductions that each read dz1 again.
 #define DZF_W 4
 #define DZF_PITCH (FLEXNET_MAX_AGENTS * HID)
+static_assert(DZF_PITCH == C16_IDW, "the 16-row kernel writes the fold kernel's partial rows itself (SM)");
 __global__ __launch_bounds__(64 * DZF_W) void critic_dz_fold_kernel(FlexCriticTailArgs a, int64_t ws_off) {
     __shared__ float fold[DZF_W][DZF_PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1203,12 +1378,27 @@ extern "C" int flexnet_critic_tail_forward(const FlexCriticTailArgs* a, void* st
 
 static int critic_tail_backward_main(const FlexCriticTailArgs* a, void* stream);
 
+// the matrix-core backward with parameter gradients runs on 16-row tiles in its sample-major form (it forms d_z_shared and
+// the id-column partial rows itself, dz1 is not written)
+static bool critic_pgrad16_sm(const FlexCriticTailArgs& k) {
+    const bool two_stage = k.workspace && k.workspace_floats >= FLEXNET_CRITIC_WS_FLOATS;
+    return k.d_fc2_w && two_stage && k.variant == 0 && k.rows >= CRITIC_MFMA_MIN_ROWS && k.variant_pgrad32 == 0 &&
+           k.d_z_shared && !k.z1;
+}
+
 extern "C" int flexnet_critic_tail_backward(const FlexCriticTailArgs* a, void* stream) {
     const int rc = critic_check(a, true);
     if (rc != FLEXNET_OK) return rc;
     if (a->rows == 0) return FLEXNET_OK;
     const int rm = critic_tail_backward_main(a, stream);
     if (rm != FLEXNET_OK || !a->d_z_shared) return rm;
+    if (critic_pgrad16_sm(*a)) {                           // the id-column partial rows are there already: second stage only
+        const int nb = critic_mfma_grid(a->rows);
+        FlexCriticTailArgs k = *a;
+        k.workspace = a->workspace + (int64_t)nb * CRITIC_WS_PITCH;
+        hipLaunchKernelGGL(critic_dz_reduce_kernel, dim3(k.n_agents), dim3(64 * RED_G), 0, (hipStream_t)stream, k, nb);
+        return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+    }
     return critic_dz_fold(*a, (hipStream_t)stream);        // after the main launches: it reuses their workspace
 }
 
@@ -1229,14 +1419,22 @@ extern "C" int flexnet_critic_td_backward(const FlexCriticTailArgs* a, const Fle
     if (nb < 1 || nb > 1024 || nb > TD_SQ_MAX) return FLEXNET_EHIP;
     hipStream_t s = (hipStream_t)stream;
     if (t->normalise) flex_td_launch_stats(*t, s);
-    if (a->variant_pgrad32)      // the 32-row kernel (one wavefront per SIMD), kept as the cross-check and for A/B timing
-        hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<true>, dim3(nb), dim3(64 * CPW), 0, s, *a, *t);
-    else
-        hipLaunchKernelGGL(critic_tail_pgrad16_kernel<true>, dim3(nb), dim3(64 * C16W), 0, s, *a, *t);
-    // dz1 folded onto its sources: the fold's partial rows go behind the backward kernel's, so ONE launch finishes both
-    int dz_blocks = 0;
+    // dz1 folded onto its sources: the partial rows of the id-column sums go behind the backward kernel's, so ONE launch
+    // finishes both.  16-row kernel on a composed input (SM): it forms d_z_shared and those partial rows itself; otherwise
+    // the fold kernel reads dz1 back.
     const int64_t dz_off = (int64_t)nb * CRITIC_WS_PITCH;
-    if (a->d_z_shared) {
+    const bool sm = a->variant_pgrad32 == 0 && a->d_z_shared && !a->z1;
+    if (sm && (t->n_agents != a->n_agents || dz_off + (int64_t)nb * DZF_PITCH > a->workspace_floats)) return FLEXNET_EINVAL;
+    if (a->variant_pgrad32 == 1)  // the 32-row kernel (one wavefront per SIMD), kept as the cross-check and for A/B timing
+        hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<true>, dim3(nb), dim3(64 * CPW), 0, s, *a, *t);
+    else if (sm)
+        critic_launch_pgrad16<true>(nb, true, *a, *t, dz_off, s);
+    else
+        critic_launch_pgrad16<true>(nb, false, *a, *t, dz_off, s);
+    int dz_blocks = 0;
+    if (sm) {
+        dz_blocks = nb;
+    } else if (a->d_z_shared) {
         const int samples = a->rows / a->n_agents;
         dz_blocks = (samples + DZF_W - 1) / DZF_W;
         if (dz_blocks > 256) dz_blocks = 256;
@@ -1276,10 +1474,13 @@ static int critic_tail_backward_main(const FlexCriticTailArgs* a, void* stream) 
     if (two_stage && k.variant == 0 && k.rows >= CRITIC_MFMA_MIN_ROWS) {
         const int nb = critic_mfma_grid(k.rows);
         if (nb < 1 || nb > 1024) return FLEXNET_EHIP;
-        if (k.variant_pgrad32)
+        const int64_t dz_off = (int64_t)nb * CRITIC_WS_PITCH;
+        const bool sm = critic_pgrad16_sm(k);
+        if (sm && dz_off + (int64_t)nb * DZF_PITCH > k.workspace_floats) return FLEXNET_EINVAL;
+        if (k.variant_pgrad32 == 1)
             hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<false>, dim3(nb), dim3(64 * CPW), 0, (hipStream_t)stream, k, FlexTdLossArgs{});
         else
-            hipLaunchKernelGGL(critic_tail_pgrad16_kernel<false>, dim3(nb), dim3(64 * C16W), 0, (hipStream_t)stream, k, FlexTdLossArgs{});
+            critic_launch_pgrad16<false>(nb, sm, k, FlexTdLossArgs{}, dz_off, (hipStream_t)stream);
         hipLaunchKernelGGL(critic_reduce_kernel, dim3((HID * HID + 4 * HID + 1 + 63) / 64), dim3(64 * RED_G), 0, (hipStream_t)stream, k, nb);
         return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
     }

@@ -99,7 +99,10 @@ def test_composed_first_layer_matches_the_materialised_one(b, n, ln):
     assert _rel(g1[0], g2[0]) < 1e-6
     assert _rel(g1[1], g2[1]) < 1e-4           # a sum over b rows in two different orders
     for a, e in zip(g1[2:], g2[2:]):
-        assert torch.equal(a, e)                # fixed-order reduction: bit-reproducible
+        # fixed-order reductions (bit-reproducible run to run: test_pgrad_kernels_on_16_and_32_row_tiles_agree); since round 3
+        # the composed form at update batches walks sample-major tiles, i.e. sums the rows in another order than the
+        # materialised form does
+        assert _rel(a, e) < 2e-5
 
 
 def test_backward_without_parameter_gradients():
@@ -439,7 +442,7 @@ def test_pgrad_kernels_on_16_and_32_row_tiles_agree(b, n, ln):
     w = torch.randn(b * n, 1, device="cuda", generator=g)
     params = [p for name, p in c.named_parameters() if not name.startswith("fc1")]
     res = []
-    for v32 in (0, 1):
+    for v32 in (0, 1, 2):       # 0: 16-row tiles, sample-major (the default); 1: the 32-row kernel; 2: 16-row tiles, consecutive rows
         nets.CRITIC_PGRAD32 = v32
         try:
             s1, i1 = shared.clone().requires_grad_(True), ids.clone().requires_grad_(True)
@@ -452,8 +455,13 @@ def test_pgrad_kernels_on_16_and_32_row_tiles_agree(b, n, ln):
         finally:
             nets.CRITIC_PGRAD32 = 0
     assert torch.equal(res[0][0], res[1][0])
-    scale = max(1e-6, res[1][1].abs().max().item())
-    row_err = (res[0][1] - res[1][1]).abs().max(dim=1).values / scale     # d_z_shared, per sample (ReLU-mask flips: see above)
-    assert int((row_err > 2e-5).sum().item()) <= max(2, row_err.numel() // 4096) and row_err.max().item() < 0.05
-    for x, y in zip(res[0][2:], res[1][2:]):
-        assert _rel(x, y) < 1e-4, (x.shape, _rel(x, y))
+    # d_z_shared, per sample: sample-major tiles sum dz1 over the agents in the lane, the other two store dz1 and fold it in
+    # a second kernel — the same mathematics on per-row arithmetic the compiler is free to contract differently in each
+    # instantiation; a handful of rows see a ReLU mask flip (see test_matrix_core_and_valu_kernels_agree)
+    for k in (1, 2):
+        scale = max(1e-6, res[k][1].abs().max().item())
+        row_err = (res[0][1] - res[k][1]).abs().max(dim=1).values / scale
+        assert int((row_err > 2e-5).sum().item()) <= max(2, row_err.numel() // 4096) and row_err.max().item() < 0.05, k
+    for k in (1, 2):
+        for x, y in zip(res[0][2:], res[k][2:]):
+            assert _rel(x, y) < 1e-4, (k, x.shape, _rel(x, y))

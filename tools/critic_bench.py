@@ -86,9 +86,10 @@ for rows in (20480, 163840):
 # gradients forming the TD error itself, dz fold, finish) on 16-row tiles / two wavefronts per SIMD vs the 32-row kernel
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-for v32 in (0, 1):
+for v32 in (0, 2, 1):
     nets.CRITIC_PGRAD32 = v32
     r = bench.critic_backward_roofline(lambda fn, n=200: timed(fn, n) * 1e-6)
-    print(f"td backward, {'32-row kernel, 1 wavefront/SIMD' if v32 else '16-row kernel, 2 wavefronts/SIMD'}: "
+    print(f"td backward, {['16-row tiles, sample-major, 2 wavefronts/SIMD', '32-row tiles + fold, 1 wavefront/SIMD', '16-row tiles + fold, 2 wavefronts/SIMD'][v32]}: "
           f"{r['launch_us']:6.1f} us for {r['rows']} rows = {r['achieved']:.1f} TFLOP/s fp32 = {r['frac']:.3f} of the matrix peak")
 nets.CRITIC_PGRAD32 = 0
+
