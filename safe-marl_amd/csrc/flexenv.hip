@@ -7,6 +7,7 @@
 #include <string.h>
 #include <vector>
 #include "flex_device.h"
+#include "flex_launch.h"
 
 #define FLEX_MAX_DEVICES 16
 #define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { \
@@ -442,8 +443,12 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
 // Residency: 4096 envs are 2048 wavefronts at EPW = 2 (2 per SIMD, <= 256 VGPRs) or 4096 at EPW = 1 (4 per SIMD,
 // <= 128 VGPRs); in both cases the whole batch must be co-resident, otherwise the last blocks start only when the
 // first ones retire and the launch takes twice as long (measured: profiles/).
-template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK = false>
-__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, (EPW == 1 ? 16 : 8) / FLEX_WAVES_PER_BLOCK)
+// WIDE (EPW = 1 only): built for two wavefronts per SIMD (256 registers) instead of four (128).  A feeder with more than
+// 32 PQ buses takes a whole wavefront per environment, and at the 128-register cap the step spills 136 registers (~310 B
+// of scratch per lane); batches of up to 8 environments per CU (2048 on an MI355X) are co-resident at two wavefronts
+// per SIMD anyway, so they run the 256-register build, which spills nothing (flexenv_step picks by batch size).
+template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK = false, bool WIDE = false>
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, ((EPW == 1 && !WIDE) ? 16 : 8) / FLEX_WAVES_PER_BLOCK)
 void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restrict__ reward,
                       uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
                       ObsT* __restrict__ obs, int want_obs, int auto_reset) {
@@ -535,6 +540,22 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     const double pnet = pd - act.pred - ppv + act.ch - act.dis;
     const double qnet = qd - act.q;
 
+    // FLEX_STEP_REPLAY_SINK: what the epilogue files into the replay ring but does not compute — the policy's action and
+    // its new recurrent state — is requested HERE, last in the prologue's load queue (loads return in order: nothing the
+    // solve waits for queues behind these), and lands underneath the solve; issued in the epilogue these loads were a full
+    // memory round trip between the solve and the stores (17.6 vs 13.9 us per launch against the kernel without the sink)
+    typedef float sk_f4 __attribute__((ext_vector_type(4)));
+    sk_f4 sk_hv[SINK ? 3 : 1];
+    float sk_av = 0.0f;
+    if constexpr (SINK) {
+        const FlexReplaySink& sk = a.sink;
+        const sk_f4* hs = reinterpret_cast<const sk_f4*>(sk.hid_new + (int64_t)env * sk.hid_w);
+        const int h4 = sk.hid_w >> 2;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { const int i = ln.l + LW * r; sk_hv[r] = hs[i < h4 ? i : 0]; }
+        sk_av = sk.policy_action[(int64_t)env * sk.act_w + (ln.l < sk.act_w ? ln.l : 0)];
+    }
+
     // power flow (pf.py:10-113)
     int iters = 0, sweeps = 0;
 #ifdef FLEX_STAMPS
@@ -620,19 +641,12 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
         const int64_t pn = p + 1 >= zs.obs_slabs ? 0 : p + 1;
         const float keep = term ? 0.0f : 1.0f;
         if (valid) {
-            typedef float sk_f4 __attribute__((ext_vector_type(4)));
-            const sk_f4* hs = reinterpret_cast<const sk_f4*>(sk.hid_new + (int64_t)env * sk.hid_w);
             sk_f4* hd = reinterpret_cast<sk_f4*>(sk.hid_ring + (pn * zs.n_envs + env) * (int64_t)sk.hid_w);
             const int h4 = sk.hid_w >> 2;
-            sk_f4 hv[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { const int i = ln.l + LW * r; if (i < h4) hv[r] = hs[i]; }
             float* const sm = sk.small_ring + (p * zs.n_envs + env) * (int64_t)sk.small_w;
-            float av_ = 0.0f;
-            if (ln.l < sk.act_w) av_ = sk.policy_action[(int64_t)env * sk.act_w + ln.l];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { const int i = ln.l + LW * r; if (i < h4) hd[i] = hv[r] * keep; }
-            if (ln.l < sk.act_w) sm[ln.l] = av_;                                        // model.py:232
+            for (int r = 0; r < 3; ++r) { const int i = ln.l + LW * r; if (i < h4) hd[i] = sk_hv[r] * keep; }
+            if (ln.l < sk.act_w) sm[ln.l] = sk_av;                                      // model.py:232
             if (ln.l == 0) {
                 const int na_ = cz.n_agents;
                 for (int j = 0; j < na_; ++j) sm[sk.act_w + j] = (float)rwd;            // model.py:235: one reward, n copies
@@ -1151,6 +1165,10 @@ int flexenv_reset(FlexEnv* e, const uint8_t* mask, const ResetSpec* inj, void* o
     return FLEX_OK;
 }
 
+// diagnostics (tools/epw1_bench.py): -1 = pick the one-environment-per-wavefront build by batch size, 0 / 1 = force
+static int g_epw1_wide = -1;
+int flexenv_debug_set_epw1_wide(int mode) { g_epw1_wide = mode; return FLEX_OK; }
+
 int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* reward, uint8_t* done, double* info,
                  uint8_t* failed, void* obs, int32_t obs_dtype, int32_t flags, void* stream) {
     const int auto_reset = (flags & FLEX_STEP_AUTORESET) ? 1 : 0;
@@ -1174,11 +1192,16 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     const dim3 grid = env_grid(e->n_envs, epw);
     const bool f64 = obs && obs_dtype == FLEX_F64;
     const int want = obs ? 1 : 0;
-#define FLEX_LAUNCH_STEP(EPW_, OBS_, ACT_) do { \
-        if (small_obs) hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_AGENTS_SMALL>), grid, env_block(), 0, s, k, \
+#define FLEX_LAUNCH_STEP_W(EPW_, OBS_, ACT_, WIDE_) do { \
+        if (small_obs) hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_AGENTS_SMALL, false, WIDE_>), grid, env_block(), 0, s, k, \
             (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset); \
-        else hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_AGENTS_LARGE>), grid, env_block(), 0, s, k, \
+        else hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_AGENTS_LARGE, false, WIDE_>), grid, env_block(), 0, s, k, \
             (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset); } while (0)
+    // one environment per wavefront: the 256-register build while the whole batch is co-resident at two wavefronts per SIMD
+    const int cus_ = flex_cu_count();
+    const bool wide = epw == 1 && (g_epw1_wide < 0 ? (cus_ > 0 && e->n_envs <= cus_ * 8) : g_epw1_wide != 0);
+#define FLEX_LAUNCH_STEP(EPW_, OBS_, ACT_) do { \
+        if (EPW_ == 1 && wide) FLEX_LAUNCH_STEP_W(1, OBS_, ACT_, true); else FLEX_LAUNCH_STEP_W(EPW_, OBS_, ACT_, false); } while (0)
     const bool small_obs = e->cfg.n_agents == FLEX_OBS_AGENTS_SMALL && 3 * e->cfg.history <= FLEX_OBS_CLASSES(epw) * (FLEX_WAVE / epw);
     const int variant = (epw == 2 ? 4 : 0) + (f64 ? 2 : 0) + (act_dtype == FLEX_F64 ? 1 : 0);
     switch (variant) {
@@ -1199,6 +1222,7 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
         default: FLEX_LAUNCH_STEP(2, double, double); break;
     }
 #undef FLEX_LAUNCH_STEP
+#undef FLEX_LAUNCH_STEP_W
     HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }

@@ -11,6 +11,7 @@ from safe_marl_amd.network import create_network
 from safe_marl_amd.series import make_synthetic_series
 from safe_marl_amd.flex_env import VecFlexProvisionEnv
 solver = int(sys.argv[1]) if len(sys.argv)>1 else 2
+sink = len(sys.argv) > 2 and sys.argv[2] == "sink"      # the SINK instantiation: the step files its own transition
 net=create_network(); s=make_synthetic_series(net,n_days=200)
 N=4096
 env=VecFlexProvisionEnv({}, N, net=net, series=s, seed=1, warm_start=True, solver=solver)
@@ -18,16 +19,29 @@ lib=_lib.load()
 stamps=torch.zeros(N,16,dtype=torch.int64,device='cuda')
 pool=(0.5+0.5*torch.rand(8,N,5,4,device='cuda')).float()
 env.reset()
-for k in range(30): env.step(pool[k%8], fuse_obs=True, auto_reset=True)
+kw = {}
+if sink:
+    from safe_marl_amd.replay_buffer import TransReplayBuffer
+    buf = TransReplayBuffer(N * 16, device='cuda'); buf.alloc_slabs(N, 5, 144, 4, 64)
+    act_buf = torch.rand(N * 5, 4, device='cuda'); hid_buf = torch.randn(N * 5, 64, device='cuda')
+    acc = torch.zeros(N, 10, dtype=torch.float64, device='cuda')
+    env.set_obs_ring(buf.cursor[1:], N * 5 * 144, buf.slabs)
+    env.set_replay_sink(act_buf, hid_buf, buf.small_ring, buf.hid_ring, acc, cursor_out=buf.cursor[0:1])
+    kw = dict(obs_ring=buf.obs_ring, replay_sink=True)
+    def adv():                      # the policy kernel's part of the cursor protocol: cell 1 = the slab it just read
+        buf.cursor[1] = buf.cursor[0]
+else:
+    def adv(): pass
+for k in range(30): adv(); env.step(pool[k%8], fuse_obs=True, auto_reset=True, **kw)
 lib.flexenv_debug_set_stamps.argtypes=[C.c_void_p]
 lib.flexenv_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
-env.step(pool[0], fuse_obs=True, auto_reset=True)
+adv(); env.step(pool[0], fuse_obs=True, auto_reset=True, **kw)
 torch.cuda.synchronize()
 st=stamps.cpu().numpy().astype(np.float64)
 t0=st[:,0].min()
 names=['start->loaded','solve','reward+stores','obs']
 d=np.diff(st[:,:5],axis=1)
-print('solver',solver,'phase cycles (memtime ticks @100MHz?) mean/median/max:')
+print('solver',solver,'SINK' if sink else 'no sink','phase cycles (memtime ticks @100MHz?) mean/median/max:')
 for i,nm in enumerate(names): print(f'  {nm:16s} {d[:,i].mean():9.1f} {np.median(d[:,i]):9.1f} {d[:,i].max():9.1f}')
 rt0, rt1 = st[:,5], st[:,6]
 print('  wave lifetime cycles', (st[:,4]-st[:,0]).mean(), ' realtime ticks(100MHz) per wave', (rt1-rt0).mean(), ' => clock GHz', ((st[:,4]-st[:,0])/(rt1-rt0)).mean()*0.1)
