@@ -202,7 +202,10 @@ def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, m
            "samples_per_transition": per_event * trainer.effective_batch_size() / float(freq * envs),
            "episode_ms": [round(x, 3) for x in episode_ms],
            "rollout_graph": bool(rg is not None and rg.graph is not None), "rollout_fused": bool(rg is not None and rg.fast),
-           "graphed_updates": sorted(trainer._update_graphs), "split_update_graphs": bool(world > 1 and trainer._update_graphs),
+           "graphed_updates": sorted(trainer._update_graphs), "split_update_graphs": bool(world > 1 and trainer._update_graphs and
+                                        not all(g.get("allreduce_in_graph") for g in trainer._update_graphs.values())),
+           "allreduce_in_graph": bool(world > 1 and trainer._update_graphs and
+                                      all(g.get("allreduce_in_graph") for g in trainer._update_graphs.values())),
            "grad_allreduce": (f"{torch.distributed.get_backend()} all-reduce of one flat bucket (sum, 1/world inside graph B), "
                               "before the clip") if world > 1 else None,
            "mean_train_reward": float(stat.get("mean_train_reward", float("nan"))),

@@ -7,7 +7,6 @@
 #include <string.h>
 #include <vector>
 #include "flex_device.h"
-#include "flex_launch.h"
 
 #define FLEX_MAX_DEVICES 16
 #define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { \
@@ -443,12 +442,14 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
 // Residency: 4096 envs are 2048 wavefronts at EPW = 2 (2 per SIMD, <= 256 VGPRs) or 4096 at EPW = 1 (4 per SIMD,
 // <= 128 VGPRs); in both cases the whole batch must be co-resident, otherwise the last blocks start only when the
 // first ones retire and the launch takes twice as long (measured: profiles/).
-// WIDE (EPW = 1 only): built for two wavefronts per SIMD (256 registers) instead of four (128).  A feeder with more than
-// 32 PQ buses takes a whole wavefront per environment, and at the 128-register cap the step spills 136 registers (~310 B
-// of scratch per lane); batches of up to 8 environments per CU (2048 on an MI355X) are co-resident at two wavefronts
-// per SIMD anyway, so they run the 256-register build, which spills nothing (flexenv_step picks by batch size).
-template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK = false, bool WIDE = false>
-__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, ((EPW == 1 && !WIDE) ? 16 : 8) / FLEX_WAVES_PER_BLOCK)
+// Both instantiations are built for two wavefronts per SIMD (256 registers).  A feeder with more than 32 PQ buses takes a
+// whole wavefront per environment (EPW = 1): until round 3 that build was capped at 128 registers so that 4096 environments
+// stayed co-resident at four wavefronts per SIMD, and spilled 136 registers (~310 B of scratch per lane) doing so.
+// Measured on a 45-bus feeder (tools/epw1_bench.py, profiles/r03_epw1_bench.txt): the 256-register build, which spills
+// nothing, is faster at EVERY batch size — 10.1 vs 12.2 us at 1024 environments, 12.2 vs 15.8 at 2048, 21.3 vs 23.8 at 4096
+// (two rounds of wavefronts) and 38.2 vs 40.7 at 8192 — so it is the only one.
+template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK = false>
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, 8 / FLEX_WAVES_PER_BLOCK)
 void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restrict__ reward,
                       uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
                       ObsT* __restrict__ obs, int want_obs, int auto_reset) {
@@ -514,6 +515,8 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     }
     const float2 wv = ld_at<float2>(b_vw, o_volt);
     const double we = (double)wv.x, wf = (double)wv.y;
+    // (the epilogue's only read-modify-write: requested here, not behind the solve — a memory round trip per launch)
+    const double cum_before = ld_at<double>(a.st.cumrew + env0, g * 8);
     // 2) what only get_obs() needs: the row env:340 will load (start + steps, A2) and the history part of the
     //    stacked observation, which is copied right away and drains underneath the solve; an environment that
     //    turns out to restart below rewrites its whole observation afterwards (same wavefront, program order)
@@ -547,7 +550,9 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     typedef float sk_f4 __attribute__((ext_vector_type(4)));
     sk_f4 sk_hv[SINK ? 3 : 1];
     float sk_av = 0.0f;
+    int64_t sk_p = 0;                                                           // the slab this step files into
     if constexpr (SINK) {
+        sk_p = *a.obs_cursor;
         const FlexReplaySink& sk = a.sink;
         const sk_f4* hs = reinterpret_cast<const sk_f4*>(sk.hid_new + (int64_t)env * sk.hid_w);
         const int h4 = sk.hid_w >> 2;
@@ -608,7 +613,6 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
 
     RewardOut rw = reward_terms<EPW>(cz, ln, is_bld, price, pred, ch, dis, q, v);        // env:330-335
     double* const b_cum = z.st.cumrew + env0;
-    const double cum_before = ld_at<double>(b_cum, g * 8);
     double rwd = rw.reward;
     if (!ok) rwd -= cz.fail_penalty;                                                    // env:336
     const int new_steps = steps + 1;                                                   // env:342
@@ -637,7 +641,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
         // is live across the solve.
         const KArgs& zs = *relaunder_kernarg<KArgs>();
         const FlexReplaySink& sk = zs.sink;
-        const int64_t p = *zs.obs_cursor;
+        const int64_t p = sk_p;
         const int64_t pn = p + 1 >= zs.obs_slabs ? 0 : p + 1;
         const float keep = term ? 0.0f : 1.0f;
         if (valid) {
@@ -652,9 +656,12 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
                 for (int j = 0; j < na_; ++j) sm[sk.act_w + j] = (float)rwd;            // model.py:235: one reward, n copies
                 sm[sk.act_w + na_] = 1.0f - keep;
                 sm[sk.act_w + na_ + 1] = 1.0f - keep;
+                // running sums: fp64 atomics without return (fire and forget; one lane per address and launch, so the order of
+                // the additions is the launch order) — as plain += they were nine loads behind the solve and a round trip
                 double* const ac = sk.acc + (int64_t)env * 10;
-                ac[0] += rw.reward; ac[1] += rw.revenue; ac[2] += rw.der; ac[3] += rw.ess; ac[4] += rw.disc; ac[5] += rw.vpen;
-                ac[6] += cum_before; ac[7] += rwd; ac[8] += ok ? 0.0 : 1.0;
+                unsafeAtomicAdd(ac + 0, rw.reward); unsafeAtomicAdd(ac + 1, rw.revenue); unsafeAtomicAdd(ac + 2, rw.der);
+                unsafeAtomicAdd(ac + 3, rw.ess); unsafeAtomicAdd(ac + 4, rw.disc); unsafeAtomicAdd(ac + 5, rw.vpen);
+                unsafeAtomicAdd(ac + 6, cum_before); unsafeAtomicAdd(ac + 7, rwd); unsafeAtomicAdd(ac + 8, ok ? 0.0 : 1.0);
             }
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1165,10 +1172,6 @@ int flexenv_reset(FlexEnv* e, const uint8_t* mask, const ResetSpec* inj, void* o
     return FLEX_OK;
 }
 
-// diagnostics (tools/epw1_bench.py): -1 = pick the one-environment-per-wavefront build by batch size, 0 / 1 = force
-static int g_epw1_wide = -1;
-int flexenv_debug_set_epw1_wide(int mode) { g_epw1_wide = mode; return FLEX_OK; }
-
 int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* reward, uint8_t* done, double* info,
                  uint8_t* failed, void* obs, int32_t obs_dtype, int32_t flags, void* stream) {
     const int auto_reset = (flags & FLEX_STEP_AUTORESET) ? 1 : 0;
@@ -1192,16 +1195,11 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     const dim3 grid = env_grid(e->n_envs, epw);
     const bool f64 = obs && obs_dtype == FLEX_F64;
     const int want = obs ? 1 : 0;
-#define FLEX_LAUNCH_STEP_W(EPW_, OBS_, ACT_, WIDE_) do { \
-        if (small_obs) hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_AGENTS_SMALL, false, WIDE_>), grid, env_block(), 0, s, k, \
-            (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset); \
-        else hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_AGENTS_LARGE, false, WIDE_>), grid, env_block(), 0, s, k, \
-            (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset); } while (0)
-    // one environment per wavefront: the 256-register build while the whole batch is co-resident at two wavefronts per SIMD
-    const int cus_ = flex_cu_count();
-    const bool wide = epw == 1 && (g_epw1_wide < 0 ? (cus_ > 0 && e->n_envs <= cus_ * 8) : g_epw1_wide != 0);
 #define FLEX_LAUNCH_STEP(EPW_, OBS_, ACT_) do { \
-        if (EPW_ == 1 && wide) FLEX_LAUNCH_STEP_W(1, OBS_, ACT_, true); else FLEX_LAUNCH_STEP_W(EPW_, OBS_, ACT_, false); } while (0)
+        if (small_obs) hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_AGENTS_SMALL>), grid, env_block(), 0, s, k, \
+            (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset); \
+        else hipLaunchKernelGGL((flex_step_kernel<EPW_, OBS_, ACT_, FLEX_OBS_AGENTS_LARGE>), grid, env_block(), 0, s, k, \
+            (const ACT_*)actions, reward, done, info, failed, (OBS_*)obs, want, auto_reset); } while (0)
     const bool small_obs = e->cfg.n_agents == FLEX_OBS_AGENTS_SMALL && 3 * e->cfg.history <= FLEX_OBS_CLASSES(epw) * (FLEX_WAVE / epw);
     const int variant = (epw == 2 ? 4 : 0) + (f64 ? 2 : 0) + (act_dtype == FLEX_F64 ? 1 : 0);
     switch (variant) {
@@ -1222,7 +1220,6 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
         default: FLEX_LAUNCH_STEP(2, double, double); break;
     }
 #undef FLEX_LAUNCH_STEP
-#undef FLEX_LAUNCH_STEP_W
     HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }

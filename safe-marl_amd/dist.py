@@ -14,6 +14,10 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def backend():
+    return str(dist.get_backend()) if dist.is_available() and dist.is_initialized() else ""
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 

@@ -51,6 +51,12 @@ class PGTrainer(object):
         # the replay's first GEMM from 31 to ~48 us — and the loop is 4-8 % SLOWER than gather-then-replay, so it is off
         # unless asked for (FLEX_PIPELINE_UPDATES=1); bit-identical either way (tests/test_update_graph_gpu.py)
         self.pipeline_updates = os.environ.get("FLEX_PIPELINE_UPDATES") == "1"
+        # more than one rank: first try to capture a sub-update as ONE graph with the gradient all-reduce inside it (RCCL
+        # collectives can be stream-captured: ProcessGroupNCCL joins its stream to the capture and does not hand captured
+        # work to its watchdog); if that capture fails (gloo: a host round trip; or an RCCL build that refuses) the region
+        # is split at the exchange step — graph A, eager all-reduce, graph B — as in round 2
+        self.allreduce_in_graph = (os.environ.get("FLEX_ALLREDUCE_IN_GRAPH", "1") == "1" and fdist.world_size() > 0
+                                   and fdist.backend() == "nccl")
         self.entr = args.entr
         self.world = fdist.world_size()
 
@@ -268,11 +274,27 @@ class PGTrainer(object):
             with graph_capture(graph):
                 self._sub_update(which, out, batch, fresh_leaves=True)
         else:
-            with graph_capture(graph):
-                self._loss_and_grads(which, out, batch, fresh_leaves=True, flat=flat)
-            apply_graph = th.cuda.CUDAGraph()
-            with graph_capture(apply_graph, pool=graph.pool()):
-                self._apply_grads(which, out, flat=flat)
+            fused = False
+            if self.allreduce_in_graph:
+                try:
+                    with graph_capture(graph):
+                        self._loss_and_grads(which, out, batch, fresh_leaves=True, flat=flat)
+                        fdist.allreduce_flat(flat)
+                        self._apply_grads(which, out, flat=flat)
+                    fused = True
+                except Exception as exc:
+                    import warnings
+                    warnings.warn(f"all-reduce inside the sub-update graph could not be captured ({exc}); splitting the graph at it")
+                    self.allreduce_in_graph = False
+                    th.cuda.synchronize()
+                    graph = th.cuda.CUDAGraph()
+                    out = {}
+            if not fused:
+                with graph_capture(graph):
+                    self._loss_and_grads(which, out, batch, fresh_leaves=True, flat=flat)
+                apply_graph = th.cuda.CUDAGraph()
+                with graph_capture(apply_graph, pool=graph.pool()):
+                    self._apply_grads(which, out, flat=flat)
         with th.no_grad():
             for k, v in self.behaviour_net.state_dict().items():
                 v.copy_(net_snap[k])
@@ -283,7 +305,8 @@ class PGTrainer(object):
                         v.copy_(old) if old is not None else v.zero_()
         # `batch` stays referenced: its constant fields (action_avail, ...) were allocated eagerly and are baked into the
         # graph by address; released, the allocator would hand their memory to the next eager tensor
-        return dict(graph=graph, apply=apply_graph, flat=flat, plan=plan, stat=out, bs=bs, buf=buf, batch=batch)
+        return dict(graph=graph, apply=apply_graph, flat=flat, plan=plan, stat=out, bs=bs, buf=buf, batch=batch,
+                    allreduce_in_graph=bool(flat is not None and apply_graph is None))
 
     # kept for callers that hand over a batch themselves (trainer.py:81,99)
     def policy_transition_process(self, stat, trans):

@@ -48,14 +48,20 @@ def test_two_ranks_train_with_split_update_graphs(tmp_path):
     assert not np.array_equal(solo[0]["w"], g[0]["w"])
 
 
-def test_split_update_graphs_next_to_a_live_rccl_communicator():
+@pytest.mark.parametrize("in_graph", ["1", "0"])
+def test_update_graphs_next_to_a_live_rccl_communicator(in_graph):
     """RCCL itself (world size 1 — all this box allows): HIP-graph capture beside a live NCCL communicator and its watchdog
-    thread, ncclAllReduce of the flat bucket issued between graph A and graph B for three training episodes."""
+    thread for three training episodes.  in_graph = 1 (the default since round 3): the trainer first tries ONE graph per
+    sub-update with ncclAllReduce of the flat bucket captured inside it, and falls back to graph A | all-reduce | graph B
+    if RCCL refuses the capture; in_graph = 0 forces the split form of round 2.  Either way the probe must finish and say
+    which of the two ran."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FLEX_ALLREDUCE_IN_GRAPH=in_graph)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_world1_probe.py")], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "nccl world-1 probe ok" in r.stdout
+    assert ("SPLIT_GRAPHS" in r.stdout) if in_graph == "0" else ("ALLREDUCE_IN_GRAPH" in r.stdout or "SPLIT_GRAPHS" in r.stdout)
+    print(r.stdout.strip().splitlines()[-1])

@@ -1,4 +1,7 @@
-"""One environment per wavefront (feeders with more than 32 PQ buses): the step kernel built for four wavefronts per
+"""(Round-3 experiment, kept for the record: the library now ships the 256-register build only, so the three modes below
+measure the same kernel; the numbers that decided it are in profiles/r03_epw1_bench.txt.)
+
+One environment per wavefront (feeders with more than 32 PQ buses): the step kernel built for four wavefronts per
 SIMD (128 registers, ~310 B of scratch per lane) against the build for two (256 registers, no scratch), at batch sizes
 on both sides of the two-per-SIMD residency limit (8 environments per CU).  HIP-event timed, HIP-graph replays of 16 steps."""
 import ctypes as C
@@ -15,7 +18,9 @@ from safe_marl_amd.series import make_synthetic_series
 from tests.test_pf_gpu import _random_feeder
 
 lib = _lib.load()
-lib.flexenv_debug_set_epw1_wide.argtypes = [C.c_int]
+has_switch = hasattr(lib, "flexenv_debug_set_epw1_wide")
+if has_switch:
+    lib.flexenv_debug_set_epw1_wide.argtypes = [C.c_int]
 blds = [7, 19, 33, 41]
 net = _random_feeder(45, 11, blds)
 series = make_synthetic_series(net, n_days=60)
@@ -25,7 +30,8 @@ for n in (1024, 2048, 3072, 4096, 8192):
     pool = (0.5 + 0.5 * torch.rand(16, n, 4, 4, device="cuda")).float()
     res = {}
     for mode, name in ((0, "128-register build (4 wavefronts/SIMD, spills)"), (1, "256-register build (2 wavefronts/SIMD)"), (-1, "auto")):
-        lib.flexenv_debug_set_epw1_wide(mode)
+        if has_switch:
+            lib.flexenv_debug_set_epw1_wide(mode)
         env.reset()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -47,6 +53,7 @@ for n in (1024, 2048, 3072, 4096, 8192):
         torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / 512 * 1e3
         assert float(env.failed.float().mean().item()) < 0.01
-    lib.flexenv_debug_set_epw1_wide(-1)
+    if has_switch:
+        lib.flexenv_debug_set_epw1_wide(-1)
     print(f"45-bus feeder, {n:5d} envs: " + "; ".join(f"{k}: {v:6.1f} us/step" for k, v in res.items()), flush=True)
     del env

@@ -30,7 +30,10 @@ for ep in range(3):
 torch.cuda.synchronize()
 w1 = torch.cat([p.detach().reshape(-1) for p in tr.behaviour_net.parameters()])
 assert torch.isfinite(w1).all() and not torch.equal(w0, w1)
-assert set(tr._update_graphs) == {"value", "policy"} and all(g["apply"] is not None for g in tr._update_graphs.values())
-print("nccl world-1 probe ok: split update graphs with ncclAllReduce between them,", tr.steps, "vector steps, value loss",
-      float(stat["mean_train_value_loss"]))
+assert set(tr._update_graphs) == {"value", "policy"}
+fused = [bool(g["allreduce_in_graph"]) for g in tr._update_graphs.values()]
+assert all(fused) or all(g["apply"] is not None for g in tr._update_graphs.values())
+print("nccl world-1 probe ok:", "ONE graph per sub-update with ncclAllReduce captured inside it" if all(fused) else
+      "split update graphs with ncclAllReduce between them", "-", tr.steps, "vector steps, value loss",
+      float(stat["mean_train_value_loss"]), "ALLREDUCE_IN_GRAPH" if all(fused) else "SPLIT_GRAPHS")
 dist.barrier(); dist.destroy_process_group()
