@@ -242,14 +242,41 @@ def learner_rooflines():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e-3                       # seconds per launch
 
+    def graph_timed(fn, reps=20, n=20):
+        """Per-call time inside a HIP graph of `reps` calls (how the rollout issues it): an eager call costs the host ~20 us
+        of Python + ctypes, more than a rollout-size kernel takes."""
+        from safe_marl_amd.util import graph_capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with graph_capture(g):
+            for _ in range(reps):
+                fn()
+        for _ in range(3):
+            g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (n * reps) * 1e-3
+
     out = []
-    for b, what in ((32768, "update batch: bootstrap actions of a value sub-update"), (4096, "rollout batch: one vector step")):
+    for b, what in ((32768, "update batch: bootstrap actions of a value sub-update (eager launches)"),
+                    (4096, "rollout batch: one vector step (HIP-graph replays of 20 calls)")):
         obs = torch.randn(b, 5, 144, device="cuda")
         hid = torch.randn(b, 5, 64, device="cuda")
         with torch.no_grad():
-            t = timed(lambda: fused_actor_forward(agent, obs, hid, 5, True))
+            t = (timed if b > 4096 else graph_timed)(lambda: fused_actor_forward(agent, obs, hid, 5, True))
         flops = 2.0 * b * 5 * (149 * 64 + 2 * 192 * 64 + 64 * 4)
-        out.append({"kernel": "actor_forward_mfma_kernel", "rows": b * 5, "what": what, "bound": "mfma", "dtype": "f32",
+        out.append({"kernel": "actor_forward_mfma_kernel (32-row tiles)" if b * 5 > 20480 else
+                    "actor_rollout16_kernel (five 16-row tiles per CU)", "rows": b * 5, "what": what, "bound": "mfma", "dtype": "f32",
                     "achieved": flops / t / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t / 1e12 / 157.3,
                     "launch_us": t * 1e6})
     k, m, n = 32768, 64, 720

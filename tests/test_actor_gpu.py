@@ -34,8 +34,11 @@ def _reference(agent, obs, hidden, n_agents, agent_id):
 
 @pytest.mark.parametrize("b,n,obs_dim,act,ln,aid", [(4096, 5, 144, 4, True, True), (3, 5, 144, 4, True, True),
                                                     (1, 1, 144, 4, True, False), (37, 3, 72, 2, False, True),
-                                                    (130, 8, 6, 8, True, True), (1001, 5, 144, 4, True, True)])
-@pytest.mark.parametrize("variant", [0, 1])          # 0: matrix-core kernel, 1: VALU kernel
+                                                    (130, 8, 6, 8, True, True), (1001, 5, 144, 4, True, True),
+                                                    (8192, 5, 144, 4, True, True), (4096, 3, 144, 4, True, True)])
+# 0: matrix-core kernels as the library picks them (five 16-row tiles per CU up to 80 rows per CU, 32-row tiles above),
+# 1: VALU kernel, 2: the five-tiles-per-CU kernel whatever the size (40 960 rows: two rounds per CU), 3: the 32-row kernel
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_matches_module(b, n, obs_dim, act, ln, aid, variant):
     from safe_marl_amd.nets import fused_actor_forward
     agent = _agent(obs_dim, n, act, layernorm=ln, agent_id=aid)
@@ -138,3 +141,27 @@ def test_in_kernel_noise_is_standard_normal_and_moves_with_the_step():
     assert abs(z.mean().item()) < 0.01 and abs(z.var().item() - 1.0) < 0.02
     assert abs((z[:, 0] * z[:, 1]).mean().item()) < 0.01 and abs((z[:-1, 0] * z[1:, 0]).mean().item()) < 0.01
     assert abs((outs[0] * outs[1]).mean().item()) < 0.01       # consecutive steps are independent draws
+
+
+@pytest.mark.parametrize("b", [4096, 1001, 7])
+def test_rollout_size_kernel_equals_the_32_row_kernel_per_row(b):
+    """The five-tiles-per-CU kernel (round 3: wavefronts 0-3 one 16-row tile each, wavefronts 4-7 a fifth tile shared by
+    output units through LDS) against the 32-row kernel: every output unit is one MFMA chain over the inputs in the same
+    order in both, whichever wavefront computes it — the same products, so the results agree to the last few ulps (the
+    two kernels differ in how fp32 LayerNorm sums are grouped), and the kernel's result does not depend on the tile a row
+    falls into: a batch permuted by whole rows gives the permuted result bit for bit."""
+    from safe_marl_amd.nets import fused_actor_forward
+    agent = _agent(144, 5, 4)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    obs = torch.randn(b, 5, 144, device="cuda", generator=g)
+    hid = torch.randn(b, 5, 64, device="cuda", generator=g)
+    noise = torch.randn(b, 5, 4, device="cuda", generator=g)
+    o16 = fused_actor_forward(agent, obs, hid, 5, True, noise=noise, variant=2)
+    o32 = fused_actor_forward(agent, obs, hid, 5, True, noise=noise, variant=3)
+    for x, y in zip(o16, o32):
+        assert x.shape == y.shape and (x - y).abs().max().item() < 2e-6 * max(1.0, y.abs().max().item())
+    # rows land in other tiles (full-tile wavefronts vs the cooperating four) after a rotation by 3 samples = 15 rows
+    rot = lambda t: torch.roll(t, 3, 0).contiguous()
+    r16 = fused_actor_forward(agent, rot(obs), rot(hid), 5, True, noise=rot(noise), variant=2)
+    for x, y in zip(o16, r16):
+        assert torch.equal(rot(x.view(b, 5, -1)), y.view(b, 5, -1))

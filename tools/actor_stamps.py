@@ -40,7 +40,21 @@ for b in (5, 4096):
         for _ in range(3):
             fused_actor_forward(agent, obs, hid, 5, True)
     torch.cuda.synchronize()
-    t = (C.c_ulonglong * 8)()
+    t = (C.c_ulonglong * 16)()
     stamped.flexnet_debug_actor_stamps(t)
-    print("%6d rows: weight staging %6d  fc1 %6d  LayerNorm %5d  GRU %6d  fc2 + stores %5d   cycles" %
+    print("%6d rows, wavefront 0 (one whole tile): weight staging %6d  fc1 %6d  LayerNorm %5d  GRU %6d  fc2 + stores %5d   cycles" %
           (b * 5, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]))
+    if t[13] > t[8]:
+        print("%6d rows, wavefront 4 (a quarter of the fifth tile): staging %6d  fc1 + rendezvous %6d  LayerNorm %5d  GRU + rendezvous %6d  "
+              "fc2 + stores %5d   cycles" % (b * 5, t[9] - t[8], t[10] - t[9], t[11] - t[10], t[12] - t[11], t[13] - t[12]))
+for b in (32768,):                                   # the 32-row kernel (update batches)
+    obs = torch.randn(b, 5, 144, device="cuda")
+    hid = torch.randn(b, 5, 64, device="cuda")
+    with torch.no_grad():
+        for _ in range(3):
+            fused_actor_forward(agent, obs, hid, 5, True)
+    torch.cuda.synchronize()
+    t = (C.c_ulonglong * 16)()
+    stamped.flexnet_debug_actor_stamps(t)
+    print("%6d rows (32-row kernel, last tile of block 0's first wavefront): weight staging %6d  fc1 %6d  LayerNorm %5d  GRU %6d  "
+          "fc2 + stores %5d   cycles" % (b * 5, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]))

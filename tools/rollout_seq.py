@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 nm = [r["Kernel_Name"].split("(")[0][-70:] for r in rows]
 S = [int(r["Start_Timestamp"]) for r in rows]; E = [int(r["End_Timestamp"]) for r in rows]
-act = [i for i, n in enumerate(nm) if "actor_forward" in n]
+act = [i for i, n in enumerate(nm) if "actor_forward" in n or "actor_rollout16" in n]
 # steps = consecutive actor launches with a flex_step in between and few kernels
 steps = [(a, b) for a, b in zip(act, act[1:]) if 1 < b - a <= 12 and any("flex_step" in nm[k] for k in range(a, b))]
 print(len(steps), "rollout steps found")

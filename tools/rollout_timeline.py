@@ -9,7 +9,7 @@ E = [int(r["End_Timestamp"]) for r in rows]
 runs, i = [], 0
 while i + 1 < len(rows):
     j = i
-    while j + 1 < len(rows) and "actor_forward" in nm[j] and "flex_step_kernel" in nm[j + 1]:
+    while j + 1 < len(rows) and ("actor_forward" in nm[j] or "actor_rollout16" in nm[j]) and "flex_step_kernel" in nm[j + 1]:
         j += 2
     if j - i >= 16:
         runs.append((i, j))
