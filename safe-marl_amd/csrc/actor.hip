@@ -733,6 +733,16 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
             xq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                 robs, (q < nq && tile < n_tiles) ? xoff + 64 * q : -1, 0, 0));
     };
+    // the previous hidden state of a tile's rows, requested with its observations (one round ahead)
+    f32x4 hv[4];
+    auto load_hid = [&](int tile) {
+        const int row = min(min(tile, n_tiles - 1) * 16 + j, a.rows - 1);
+#pragma unroll
+        for (int S = 0; S < 4; ++S) {
+            const float4 t = *reinterpret_cast<const float4*>(a.hidden_in + (int64_t)row * HID + 16 * S + 4 * g);
+            hv[S] = f32x4{t.x, t.y, t.z, t.w};
+        }
+    };
     load_obs(tile_of(rnd));                                                // in flight underneath the staging
     // ---- weights -> LDS (transposed); every global read of a thread is issued before its first LDS write.  A thread
     //      takes a 4 x 4 block (four output units x four inputs): four 16-byte reads, one per unit row, and four 16-byte
@@ -742,18 +752,14 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
     //      (the pitches are multiples of 4 for the A-operand reads: with consecutive lanes on consecutive inputs — how
     //      the 32-row kernel stages its odd-pitch images — a wavefront's scalar stores land on 8 banks, 14.1 k cycles of
     //      staging; with consecutive lanes on consecutive units the reads are 64 separate 16-byte requests, 17.9 k) -------
+    //      TWO STAGES: a CU receives ~12 B per cycle when every CU stages at once, so the 156 KB are ~13 k cycles however they
+    //      are requested.  fc1 needs only its own 39 KB: those (and the small vectors) are requested first — loads return in
+    //      order — and published with a first barrier; the gate weights, requested right behind, arrive while the first
+    //      tile's fc1 runs and are published by a second barrier after it.
+    constexpr int NGB = 2 * (3 * HID / 4) * (HID / 4) / (64 * R16_W);      // 3 blocks per thread over both gate matrices
+    static_assert(NGB * 64 * R16_W == 2 * (3 * HID / 4) * (HID / 4), "gate blocks split evenly");
+    float4 vg[NGB][4];
     {
-        constexpr int NGB = 2 * (3 * HID / 4) * (HID / 4) / (64 * R16_W);  // 3 blocks per thread over both gate matrices
-        static_assert(NGB * 64 * R16_W == 2 * (3 * HID / 4) * (HID / 4), "gate blocks split evenly");
-        float4 vg[NGB][4];
-#pragma unroll
-        for (int t = 0; t < NGB; ++t) {
-            const int e = tid + 64 * R16_W * t, rest = e >> 6;
-            const int ub = 8 * (rest % 6) + (e & 7), k4 = 8 * ((rest / 6) & 1) + ((e >> 3) & 7);
-            const float* src = (rest >= 12 ? a.w_hh : a.w_ih) + (int64_t)(4 * ub) * HID + 4 * k4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) vg[t][i] = *reinterpret_cast<const float4*>(src + i * HID);
-        }
         const int q4 = (od + 3) >> 2;
         const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.fc1_w), 0, HID * ld1 * 4, 0x00027000);
@@ -783,14 +789,12 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
         const float s_w2a = a.fc2_w[w2oc * HID + w2k0], s_w2b = a.fc2_w[w2oc * HID + w2k0 + 32];
         const float s_b2 = a.fc2_b[tid < ad ? tid : 0];
 #pragma unroll
-        for (int t = 0; t < NGB; ++t) {
+        for (int t = 0; t < NGB; ++t) {                                    // the gate weights: requested last, stored after fc1
             const int e = tid + 64 * R16_W * t, rest = e >> 6;
             const int ub = 8 * (rest % 6) + (e & 7), k4 = 8 * ((rest / 6) & 1) + ((e >> 3) & 7);
-            float* dst = s.wg + (4 * k4) * R16_PG + (rest >= 12 ? 3 * HID : 0) + 4 * ub;
-            *reinterpret_cast<float4*>(dst) = make_float4(vg[t][0].x, vg[t][1].x, vg[t][2].x, vg[t][3].x);
-            *reinterpret_cast<float4*>(dst + R16_PG) = make_float4(vg[t][0].y, vg[t][1].y, vg[t][2].y, vg[t][3].y);
-            *reinterpret_cast<float4*>(dst + 2 * R16_PG) = make_float4(vg[t][0].z, vg[t][1].z, vg[t][2].z, vg[t][3].z);
-            *reinterpret_cast<float4*>(dst + 3 * R16_PG) = make_float4(vg[t][0].w, vg[t][1].w, vg[t][2].w, vg[t][3].w);
+            const float* src = (rest >= 12 ? a.w_hh : a.w_ih) + (int64_t)(4 * ub) * HID + 4 * k4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vg[t][i] = *reinterpret_cast<const float4*>(src + i * HID);
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -831,15 +835,12 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
     const float* lnb_l = s.lnb + 4 * g;
     const uint64_t rng_seed = a.rng_state ? a.rng_state[0] : 0ull, rng_step = a.rng_state ? a.rng_state[1] : 0ull;
     int passes = 0;                                                        // rendezvous passed so far (cooperating wavefronts)
-    for (; 5 * rnd < n_tiles; rnd += gridDim.x) {
-        const int tile = tile_of(rnd);
-        if (tile >= n_tiles) break;                                        // (uniform per wavefront; for the cooperating four: all of them)
-        const int r0 = tile * 16;
-        const int row = min(r0 + j, a.rows - 1);
-        const bool live = r0 + j < a.rows;
-        const int ag = row % na;
+    f32x4 x[4];                                                            // fc1 output -> GRU input of the current tile
+    f32x4 zq = f32x4{0.0f, 0.0f, 0.0f, 0.0f};                              // cooperating wavefronts: fc1 output of their 16 units
+    // fc1 of this wavefront's tile of round `rnd` from the observation groups in xq (bias and id column added)
+    auto fc1 = [&](int tile) {
+        const int ag = min(tile * 16 + j, a.rows - 1) % na;
         const float* w1id_l = s.w1id + ag * HID + 4 * g;
-        f32x4 x[4], hv[4], hnew[4];
         if (!coop) {
             // ---- fc1, all 64 units: four independent chains ------------------------------------------------------------
 #pragma unroll
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
                 for (int r = 0; r < 4; ++r) x[T][r] += b1_l[16 * T + r] + w1id_l[16 * T + r];
         } else {
             // ---- fc1, this wavefront's 16 units (one chain: the order the full-tile wavefronts sum in) -------------------
-            f32x4 zq = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            zq = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int q = 0; q < FLEXNET_MAX_OBS / 16; ++q) {
                 if (q < nq) {
@@ -883,6 +884,34 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) zq[r] += b1_l[16 * cq + r] + w1id_l[16 * cq + r];
+        }
+    };
+    // the first tile's fc1 runs between the two staging stages, while the gate weights are still arriving
+    bool peeled = tile_of(rnd) < n_tiles;
+    if (peeled) fc1(tile_of(rnd));
+    load_hid(tile_of(rnd));                                                // (the observation registers are free now)
+    ASTAMP(2); ASTAMP_C(2);
+#pragma unroll
+    for (int t = 0; t < NGB; ++t) {
+        const int e = tid + 64 * R16_W * t, rest = e >> 6;
+        const int ub = 8 * (rest % 6) + (e & 7), k4 = 8 * ((rest / 6) & 1) + ((e >> 3) & 7);
+        float* dst = s.wg + (4 * k4) * R16_PG + (rest >= 12 ? 3 * HID : 0) + 4 * ub;
+        *reinterpret_cast<float4*>(dst) = make_float4(vg[t][0].x, vg[t][1].x, vg[t][2].x, vg[t][3].x);
+        *reinterpret_cast<float4*>(dst + R16_PG) = make_float4(vg[t][0].y, vg[t][1].y, vg[t][2].y, vg[t][3].y);
+        *reinterpret_cast<float4*>(dst + 2 * R16_PG) = make_float4(vg[t][0].z, vg[t][1].z, vg[t][2].z, vg[t][3].z);
+        *reinterpret_cast<float4*>(dst + 3 * R16_PG) = make_float4(vg[t][0].w, vg[t][1].w, vg[t][2].w, vg[t][3].w);
+    }
+    __syncthreads();
+    for (; 5 * rnd < n_tiles; rnd += gridDim.x) {
+        const int tile = tile_of(rnd);
+        if (tile >= n_tiles) break;                                        // (uniform per wavefront; for the cooperating four: all of them)
+        const int r0 = tile * 16;
+        const int row = min(r0 + j, a.rows - 1);
+        const bool live = r0 + j < a.rows;
+        f32x4 hnew[4];
+        if (!peeled) fc1(tile);
+        peeled = false;
+        if (coop) {
             *reinterpret_cast<float4*>(s.xz + j * R16_PX + 16 * cq + 4 * g) = make_float4(zq[0], zq[1], zq[2], zq[3]);
             ++passes;
             r16_rendezvous(&s.sync[0], 4 * passes, lane);
@@ -892,15 +921,9 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
                 x[S] = f32x4{t.x, t.y, t.z, t.w};
             }
         }
-        ASTAMP(2); ASTAMP_C(2);
         // the next round's observations go out now and land underneath LayerNorm and the GRU
         if (5 * (rnd + gridDim.x) < n_tiles) load_obs(tile_of(rnd + gridDim.x));
         r16_ln_relu(x, a.layernorm != 0, a.ln_eps, lnw_l, lnb_l);
-#pragma unroll
-        for (int S = 0; S < 4; ++S) {
-            const float4 t = *reinterpret_cast<const float4*>(a.hidden_in + (int64_t)row * HID + 16 * S + 4 * g);
-            hv[S] = f32x4{t.x, t.y, t.z, t.w};
-        }
         ASTAMP(3); ASTAMP_C(3);
         if (!coop) {
 #pragma unroll
@@ -910,6 +933,7 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
                     *reinterpret_cast<float4*>(a.hidden_out + (int64_t)(r0 + j) * HID + 16 * T + 4 * g) =
                         make_float4(hnew[T][0], hnew[T][1], hnew[T][2], hnew[T][3]);
             }
+            if (5 * (rnd + gridDim.x) < n_tiles) load_hid(tile_of(rnd + gridDim.x));     // (hv is dead: the next round's)
         } else {
             f32x4 hq;
             // (the tile index must be a compile-time constant of the inlined GRU body: one copy per unit tile)
@@ -919,6 +943,7 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
                 case 2: hq = r16_gru_tile(wg_l, gb_l, 2, x, hv); break;
                 default: hq = r16_gru_tile(wg_l, gb_l, 3, x, hv); break;
             }
+            if (5 * (rnd + gridDim.x) < n_tiles) load_hid(tile_of(rnd + gridDim.x));
             if (live)
                 *reinterpret_cast<float4*>(a.hidden_out + (int64_t)(r0 + j) * HID + 16 * cq + 4 * g) = make_float4(hq[0], hq[1], hq[2], hq[3]);
             *reinterpret_cast<float4*>(s.xh + j * R16_PX + 16 * cq + 4 * g) = make_float4(hq[0], hq[1], hq[2], hq[3]);
