@@ -32,11 +32,19 @@ bash tools/prof_bench.sh $tag > $O/${tag}_prof_bench.txt 2>&1 || exit 1
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train_$tag -- python3 $R/examples/train_maddpg.py --alg maddpg --envs 4096 --episodes 12 > $O/prof_train_$tag.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_safe_$tag -- python3 $R/examples/train_maddpg.py --alg safemaddpg --envs 8192 --episodes 12 > $O/prof_safe_$tag.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_upd_$tag -- python3 $R/tools/update_prof_plain.py > $O/prof_upd_$tag.log 2>&1 || exit 1
 cd $R
-for k in train safe; do
+for k in train safe upd; do
   f=$(find gpurun_out/prof_${k}_$tag -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/${tag}_${k}_kernel_stats.csv
 done
+# kernel sequences: one fused rollout step inside a burst, one value and one policy sub-update
+f=$(find gpurun_out/prof_train_$tag -name "*kernel_trace.csv" | head -1)
+[ -n "$f" ] && python3 tools/rollout_timeline.py "$f" > $O/${tag}_rollout_timeline.txt 2>&1
+f=$(find gpurun_out/prof_safe_$tag -name "*kernel_trace.csv" | head -1)
+[ -n "$f" ] && python3 tools/rollout_seq.py "$f" > $O/${tag}_rollout_seq_safemaddpg.txt 2>&1
+f=$(find gpurun_out/prof_upd_$tag -name "*kernel_trace.csv" | head -1)
+[ -n "$f" ] && python3 tools/update_timeline.py "$f" > $O/${tag}_update_timeline.txt 2>&1
 tail -1 $O/prof_train_$tag.log | cut -c1-400
 tail -1 $O/prof_safe_$tag.log | cut -c1-400
 echo "traces done"
