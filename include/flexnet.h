@@ -278,11 +278,20 @@ typedef struct {
     float* loss;               /* out [1] */
     float* workspace;          /* 8-byte aligned */
     int64_t workspace_floats;  /* >= FLEXNET_TD_WS_FLOATS */
+    /* Reward statistics over MORE than this call's rows (data-parallel ranks): run flexnet_td_stats, sum the
+     * first FLEXNET_TD_STAT_DOUBLES doubles of the workspace over the ranks (one all-reduce of 8 KB), then make the call
+     * with stats_ready = 1 and stat_rows = the rows those sums cover.  0 / 0: the call computes its own statistics. */
+    int32_t stats_ready;
+    int32_t pad0;
+    int64_t stat_rows;
 } FlexTdLossArgs;
 
 #define FLEXNET_TD_WS_FLOATS (2 * (64 * 2 * 8 + 1024))
+#define FLEXNET_TD_STAT_DOUBLES (64 * 2 * 8)   /* per-block partial sums and sums of squares of the reward columns */
 
 int flexnet_td_loss(const FlexTdLossArgs* args, void* stream);
+/* The statistics pass alone (args->reward, rows, n_agents, workspace): per-block partial column sums into the workspace. */
+int flexnet_td_stats(const FlexTdLossArgs* args, void* stream);
 
 /* The value loss AND the critic's backward in one pass (maddpg.py:100-123 over mlp_critic.py:25-33): the matrix-core
  * backward kernel recomputes the tail's forward anyway, so it forms q, the TD error, dLoss/dq and the loss partial sums

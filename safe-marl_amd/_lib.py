@@ -70,7 +70,7 @@ SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version",
-    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_critic_td_backward",
+    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_td_stats", "flexnet_critic_td_backward",
     "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gru_backward",
 )
 
@@ -146,10 +146,11 @@ class FlexTdLossArgs(C.Structure):
                 ("bn_eps", C.c_float), ("bn_momentum", C.c_float)] + \
                [(k, C.c_void_p) for k in ("reward", "done", "next_q", "q", "bn_weight", "bn_bias", "running_mean",
                                           "running_var", "num_batches_tracked", "dq", "loss", "workspace")] + \
-               [("workspace_floats", C.c_int64)]
+               [("workspace_floats", C.c_int64), ("stats_ready", C.c_int32), ("pad0", C.c_int32), ("stat_rows", C.c_int64)]
 
 
 FLEXNET_TD_WS_FLOATS = 2 * (64 * 2 * 8 + 1024)
+FLEXNET_TD_STAT_DOUBLES = 64 * 2 * 8
 
 
 class FlexAgentSumArgs(C.Structure):
@@ -257,6 +258,8 @@ def load():
     lib.flexnet_clip_rmsprop.restype = C.c_int
     lib.flexnet_td_loss.argtypes = [C.POINTER(FlexTdLossArgs), vp]
     lib.flexnet_td_loss.restype = C.c_int
+    lib.flexnet_td_stats.argtypes = [C.POINTER(FlexTdLossArgs), vp]
+    lib.flexnet_td_stats.restype = C.c_int
     lib.flexnet_agent_sum_explore.argtypes = [C.POINTER(FlexAgentSumArgs), vp]
     lib.flexnet_agent_sum_explore.restype = C.c_int
     lib.flexnet_scaled_sum.argtypes = [C.POINTER(FlexSumArgs), vp]

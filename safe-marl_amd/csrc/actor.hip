@@ -705,19 +705,15 @@ __device__ __forceinline__ f32x4 r16_gru_tile(const float* wg_l, const float* gb
 __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorArgs a) {
     __shared__ ActorLds16 s;
     ASTAMP(0); ASTAMP_C(0);
-    if (a.cursor) {
-        const int64_t p = *a.cursor;
-        a.obs += p * a.obs_slab_stride; a.hidden_in += p * a.hid_slab_stride;
-        if (a.cursor_out && blockIdx.x == 0 && threadIdx.x == 0) *a.cursor_out = p;
-    }
+    // the slab cursor (inputs in a slab ring): requested here, USED only after the weight loads below are in flight — they
+    // do not depend on it, and the cell was written by the launch before this one (a cold scalar load, ~1 us, that used to
+    // sit in front of everything)
+    const int64_t cur_p = a.cursor ? *a.cursor : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int od = a.obs_dim, na = a.n_agents, ad = a.act_dim;
     const int ld1 = od + (a.agent_id ? na : 0);
     const int nq = (od + 15) >> 4;                                         // 16-column groups of an observation row
-    const int64_t obs_bytes = (int64_t)a.rows * od * 4;
-    const __amdgpu_buffer_rsrc_t robs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.obs), 0, obs_bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)obs_bytes, 0x00027000);
     const int n_tiles = (a.rows + 15) / 16;
     const bool coop = wave >= 4;
     const int cq = wave & 3;                                               // cooperative wavefronts: their unit tile
@@ -725,6 +721,7 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
     int rnd = blockIdx.x;
     auto tile_of = [&](int r_) { return 5 * r_ + (coop ? 4 : wave); };
     f32x4 xq[FLEXNET_MAX_OBS / 16];
+    __amdgpu_buffer_rsrc_t robs;
     auto load_obs = [&](int tile) {
         const int row = min(tile * 16 + j, a.rows - 1);
         const int xoff = (row * od + 4 * g) * 4;
@@ -743,7 +740,6 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
             hv[S] = f32x4{t.x, t.y, t.z, t.w};
         }
     };
-    load_obs(tile_of(rnd));                                                // in flight underneath the staging
     // ---- weights -> LDS (transposed); every global read of a thread is issued before its first LDS write.  A thread
     //      takes a 4 x 4 block (four output units x four inputs): four 16-byte reads, one per unit row, and four 16-byte
     //      LDS writes, one per input row of the transposed image — a quarter of the LDS write instructions of a scalar
@@ -788,6 +784,18 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
         const int w2k0 = tid >> 4, w2o = tid & 15, w2oc = w2o < ad ? w2o : ad - 1;
         const float s_w2a = a.fc2_w[w2oc * HID + w2k0], s_w2b = a.fc2_w[w2oc * HID + w2k0 + 32];
         const float s_b2 = a.fc2_b[tid < ad ? tid : 0];
+        // the first tile's observations, behind fc1's weights in the queue (what fc1 needs first) and in front of the gate
+        // weights; this is where the slab cursor is first needed
+        if (a.cursor) {
+            a.obs += cur_p * a.obs_slab_stride; a.hidden_in += cur_p * a.hid_slab_stride;
+            if (a.cursor_out && blockIdx.x == 0 && threadIdx.x == 0) *a.cursor_out = cur_p;
+        }
+        {
+            const int64_t obs_bytes = (int64_t)a.rows * od * 4;
+            robs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.obs), 0,
+                                                     obs_bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)obs_bytes, 0x00027000);
+        }
+        load_obs(tile_of(rnd));
 #pragma unroll
         for (int t = 0; t < NGB; ++t) {                                    // the gate weights: requested last, stored after fc1
             const int e = tid + 64 * R16_W * t, rest = e >> 6;
@@ -823,6 +831,12 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
     for (int idx = tid; idx < (16 * nq - od) * HID; idx += 64 * R16_W)     // fc1 runs over 16-column groups: zero rows behind obs_dim
         s.w1t[(od + idx / HID) * R16_P1 + (idx % HID)] = 0.0f;
     if (tid < 2) s.sync[tid] = 0;
+    // the exploration noise of this wavefront's first tile depends on nothing but (seed, step, row): drawn here, underneath
+    // the wait for the weights — Philox + Box-Muller behind fc2 was 2.8 us of a 22.8 us call (tools/actor_bench.py)
+    const uint64_t rng_seed = a.rng_state ? a.rng_state[0] : 0ull, rng_step = a.rng_state ? a.rng_state[1] : 0ull;
+    const bool draws = !a.noise && a.rng_state && 4 * g < ad && (!coop || cq == 0);
+    float zr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (draws && tile_of(rnd) < n_tiles) actor_noise4(rng_seed, rng_step, (uint32_t)(tile_of(rnd) * 16 + j), (uint32_t)g, zr);
     __syncthreads();
     ASTAMP(1); ASTAMP_C(1);
 
@@ -833,7 +847,6 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
     const float* b1_l = s.b1 + 4 * g;
     const float* lnw_l = s.lnw + 4 * g;
     const float* lnb_l = s.lnb + 4 * g;
-    const uint64_t rng_seed = a.rng_state ? a.rng_state[0] : 0ull, rng_step = a.rng_state ? a.rng_state[1] : 0ull;
     int passes = 0;                                                        // rendezvous passed so far (cooperating wavefronts)
     f32x4 x[4];                                                            // fc1 output -> GRU input of the current tile
     f32x4 zq = f32x4{0.0f, 0.0f, 0.0f, 0.0f};                              // cooperating wavefronts: fc1 output of their 16 units
@@ -962,8 +975,6 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
         for (int st = 0; st < 16; ++st)
             mo = MFMA16(w2_l[(16 * (st >> 2) + (st & 3)) * R16_P2], hnew[st >> 2][st & 3], mo);
         if (live) {
-            float zr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (!a.noise && a.rng_state && 4 * g < ad) actor_noise4(rng_seed, rng_step, (uint32_t)(r0 + j), (uint32_t)g, zr);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = 4 * g + r;
@@ -980,6 +991,9 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
             }
         }
         ASTAMP(5); ASTAMP_C(5);
+        // (a block with more than one round: the next tile's draws, now)
+        if (draws && tile_of(rnd + gridDim.x) < n_tiles && 5 * (rnd + gridDim.x) < n_tiles)
+            actor_noise4(rng_seed, rng_step, (uint32_t)(tile_of(rnd + gridDim.x) * 16 + j), (uint32_t)g, zr);
     }
 }
 
@@ -1007,9 +1021,13 @@ extern "C" int flexnet_actor_forward(const FlexActorArgs* a, void* stream) {
     const int cus = flex_cu_count();                      // one block per CU owns that CU's LDS
     if (cus < 1) return FLEXNET_EHIP;
     const bool saves = a->save_z1 != nullptr;
-    // rollout-size batches (up to five 16-row tiles per CU: 20 480 rows on 256 CUs) take the five-tiles-per-CU kernel;
-    // variant 2 asks for it whatever the size, variant 3 for the 32-row kernel whatever the size (tests, tools/actor_bench.py)
-    const bool rollout16 = !saves && (a->variant == 2 || (a->variant == 0 && a->rows <= 80 * cus));
+    // Inference batches take the five-tiles-per-CU kernel where it is faster.  Measured (tools/actor_bench.py, graph
+    // replays, 256 CUs): it needs ~7 + 13 r us for r = ceil(rows / (80 CUs)) rounds, the 32-row kernel ~7 + 19 w us for
+    // w = ceil(rows / (128 CUs)) tiles per SIMD — 20 480 rows: 20.6 vs 26.1 us, 30 720: 32.4 vs 27.2, 40 960 (SAFEMADDPG's
+    // rollout at 8192 envs): 33.6 vs 44.2, 81 920: 58.9 vs 63.9, 163 840: 108 vs 101.  variant 2 asks for it whatever the
+    // size, variant 3 for the 32-row kernel whatever the size (tests, tools/actor_bench.py).
+    const int64_t r16 = (a->rows + 80 * (int64_t)cus - 1) / (80 * (int64_t)cus), w32 = (a->rows + 128 * (int64_t)cus - 1) / (128 * (int64_t)cus);
+    const bool rollout16 = !saves && (a->variant == 2 || (a->variant == 0 && 13 * r16 < 19 * w32));
     if (rollout16) {
         const int rounds = ((a->rows + 15) / 16 + 4) / 5;
         const int blocks = rounds < cus ? rounds : cus;

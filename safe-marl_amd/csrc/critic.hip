@@ -892,8 +892,9 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
                 double su = 0.0, ss = 0.0;
 #pragma unroll
                 for (int p8 = 0; p8 < 8; ++p8) { su += td_part[p8][tid]; ss += td_part[p8][TD_NA + tid]; }
-                const double mean = su / (double)td.rows;
-                double var = ss / (double)td.rows - mean * mean;                     // biased (what the normalisation uses)
+                const double nr = (double)(td.stat_rows > 0 ? td.stat_rows : (int64_t)td.rows);
+                const double mean = su / nr;
+                double var = ss / nr - mean * mean;                                  // biased (what the normalisation uses)
                 if (var < 0.0) var = 0.0;
                 m = (float)mean;
                 sc = (float)(1.0 / sqrt(var + (double)td.bn_eps)) * (td.bn_weight ? td.bn_weight[tid] : 1.0f);
@@ -1418,7 +1419,7 @@ extern "C" int flexnet_critic_td_backward(const FlexCriticTailArgs* a, const Fle
     const int nb = critic_mfma_grid(a->rows);
     if (nb < 1 || nb > 1024 || nb > TD_SQ_MAX) return FLEXNET_EHIP;
     hipStream_t s = (hipStream_t)stream;
-    if (t->normalise) flex_td_launch_stats(*t, s);
+    if (t->normalise && !t->stats_ready) flex_td_launch_stats(*t, s);
     // dz1 folded onto its sources: the partial rows of the id-column sums go behind the backward kernel's, so ONE launch
     // finishes both.  16-row kernel on a composed input (SM): it forms d_z_shared and those partial rows itself; otherwise
     // the fold kernel reads dz1 back.

@@ -19,8 +19,9 @@ __device__ __forceinline__ void td_column_stats(const FlexTdLossArgs& a, int j, 
     const double* ws = reinterpret_cast<const double*>(a.workspace);
     double s = 0.0, ss = 0.0;
     for (int b = 0; b < TD_BLOCKS; ++b) { s += ws[b * 2 * TD_NA + j]; ss += ws[b * 2 * TD_NA + TD_NA + j]; }
-    mean = s / (double)a.rows;
-    var = ss / (double)a.rows - mean * mean;                     // biased (what the normalisation uses)
+    const double rows = (double)(a.stat_rows > 0 ? a.stat_rows : (int64_t)a.rows);   // (sums over all ranks' rows: stats_ready)
+    mean = s / rows;
+    var = ss / rows - mean * mean;                               // biased (what the normalisation uses)
     if (var < 0.0) var = 0.0;
 }
 
@@ -54,7 +55,8 @@ __device__ __forceinline__ void td_finish(const FlexTdLossArgs& a, int sq_blocks
         double mean, var;
         td_column_stats(a, lane, mean, var);
         const double m = (double)a.bn_momentum;
-        const double unbiased = a.rows > 1 ? var * (double)a.rows / (double)(a.rows - 1) : var;
+        const double nr = (double)(a.stat_rows > 0 ? a.stat_rows : (int64_t)a.rows);
+        const double unbiased = nr > 1.0 ? var * nr / (nr - 1.0) : var;
         a.running_mean[lane] = (float)((1.0 - m) * (double)a.running_mean[lane] + m * mean);
         a.running_var[lane] = (float)((1.0 - m) * (double)a.running_var[lane] + m * unbiased);
     }

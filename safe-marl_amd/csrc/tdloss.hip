@@ -87,6 +87,15 @@ void flex_td_launch_finish(const FlexTdLossArgs& a, int sq_blocks, hipStream_t s
     hipLaunchKernelGGL(td_finish_kernel, dim3(1), dim3(64), 0, s, a, sq_blocks);
 }
 
+extern "C" int flexnet_td_stats(const FlexTdLossArgs* a, void* stream) {
+    if (!a || a->rows < 1 || a->n_agents < 1 || !a->reward || !a->workspace || a->workspace_floats < FLEXNET_TD_WS_FLOATS ||
+        (reinterpret_cast<uintptr_t>(a->workspace) & 7) != 0)
+        return FLEXNET_EINVAL;
+    if (a->n_agents > TD_NA) return FLEXNET_EUNSUPPORTED;
+    flex_td_launch_stats(*a, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}
+
 extern "C" int flexnet_td_loss(const FlexTdLossArgs* a, void* stream) {
     if (!a || a->rows < 1 || a->n_agents < 1 || !a->reward || !a->workspace || a->workspace_floats < FLEXNET_TD_WS_FLOATS)
         return FLEXNET_EINVAL;
@@ -98,7 +107,7 @@ extern "C" int flexnet_td_loss(const FlexTdLossArgs* a, void* stream) {
     if (a->n_agents > TD_NA) return FLEXNET_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a->workspace) & 7) != 0) return FLEXNET_EINVAL;         // holds doubles
     hipStream_t s = (hipStream_t)stream;
-    if (a->normalise) flex_td_launch_stats(*a, s);
+    if (a->normalise && !a->stats_ready) flex_td_launch_stats(*a, s);
     if (!stats_only) hipLaunchKernelGGL(td_apply_kernel, dim3(TD_BLOCKS), dim3(TD_THREADS), 0, s, *a);
     flex_td_launch_finish(*a, stats_only ? 0 : TD_BLOCKS, s);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;

@@ -22,7 +22,7 @@ import torch.nn as nn
 from .nets import (WGRAD_MIN_ROWS, CriticTail, critic_td_loss, critic_td_loss_supported, critic_policy_loss,
                    critic_policy_loss_supported, expand_agents, MLPAgent, MLPCritic, RNNAgent, critic_policy_supported, critic_replayed_supported,
                    critic_tail_supported, fused_actor_forward, tall_linear, td_loss, td_loss_supported, wide_batch_linear,
-                   batchnorm_stats_supported, batchnorm_update_running_stats)
+                   batchnorm_stats_supported, batchnorm_update_running_stats, sync_batchnorm)
 from .replay_buffer import Transition
 from .util import graph_capture, prep_obs, scale_action, select_action, translate_action, mean_all
 
@@ -504,7 +504,7 @@ class Model(nn.Module):
             # The reward columns of a packed replay row are a strided slice: the statistics kernel reads them 3x
             # slower than a contiguous copy (41 vs 14 us for [32768, 5]), so copy first.
             with th.no_grad():
-                reward = self.batchnorm(reward.contiguous())
+                reward = sync_batchnorm(self.batchnorm, reward.contiguous())     # (= self.batchnorm(reward) on one rank)
         done = batch.done.float().view(-1, 1)
         last_step = batch.last_step.float().view(-1, 1)
         # model.py:313 fills log_prob_a from batch.action; nothing downstream reads it
@@ -935,7 +935,7 @@ class MADDPG(Model):
             else:
                 if fused_td and bn is not None:                 # the raw reward was handed on: normalise it here
                     with th.no_grad():
-                        rewards = bn(rewards.contiguous())
+                        rewards = sync_batchnorm(bn, rewards.contiguous())
                 returns = rewards + self.args.gamma * (1 - done) * next_values
                 assert returns.size() == values.size()
                 value_loss = mean_all((returns - values).pow(2))
@@ -1193,7 +1193,7 @@ class MATD3(MADDPG):
             else:
                 if on_gpu:                  # the raw reward was handed on: normalise it here
                     with th.no_grad():
-                        rewards = self.batchnorm(rewards.contiguous())
+                        rewards = sync_batchnorm(self.batchnorm, rewards.contiguous())
                 returns = rewards + self.args.gamma * (1 - done) * next_min
                 assert returns.size() == values1.size() == values2.size()
                 value_loss = 0.5 * (mean_all((returns - values1).pow(2)) + mean_all((returns - values2).pow(2)))

@@ -324,6 +324,59 @@ def tall_linear(x, w, b=None):
 _TD_WS = {}
 
 
+# Cross-rank reward statistics ("or all-reduce 2 x 5 moments"; off unless the trainer switches it on):
+# model.py:321-322 normalises the reward with BATCH statistics; with data-parallel ranks each rank's batch is a shard, and
+# the full-batch statistics are the sums over the ranks of the per-rank sums.  GPU path: the statistics pass of
+# csrc/tdloss.hip leaves its per-block partial sums in the workspace, ONE all-reduce of those 8 KB makes them global
+# (flexnet_td_stats -> all-reduce -> the call with stats_ready / stat_rows); CPU path: sync_batchnorm below.
+REWARD_BN_SYNC = False
+
+
+def _sync_active():
+    import torch.distributed as dist
+    return REWARD_BN_SYNC and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _td_sync_stats(a, ws):
+    """If cross-rank statistics are on: statistics pass, all-reduce of the partial sums, and mark ``a`` (FlexTdLossArgs)
+    so that the call that follows uses them instead of computing its own.  ``ws``: the fp64 workspace tensor of ``a``."""
+    if not (a.normalise and _sync_active()):
+        return
+    import ctypes as C
+    import torch.distributed as dist
+    from . import _lib
+    _lib.check(_lib.load().flexnet_td_stats(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_td_stats")
+    dist.all_reduce(ws[:_lib.FLEXNET_TD_STAT_DOUBLES], op=dist.ReduceOp.SUM)
+    a.stats_ready, a.stat_rows = 1, int(a.rows) * dist.get_world_size()
+
+
+def sync_batchnorm(bn, x):
+    """``bn(x)`` of a training-mode nn.BatchNorm1d on [rows, n] with the batch statistics taken over ALL ranks' rows (equal
+    shards): normalised output, running statistics and num_batches_tracked moved as the module moves them.  Plain tensor
+    ops (the eager / CPU path); without an initialised process group of more than one rank it is ``bn(x)``."""
+    if not (_sync_active() and bn.training):
+        return bn(x)
+    import torch.distributed as dist
+    xd = x.double()
+    mom = th.cat([xd.sum(0), (xd * xd).sum(0)])
+    dist.all_reduce(mom, op=dist.ReduceOp.SUM)
+    rows = x.shape[0] * dist.get_world_size()
+    n = x.shape[1]
+    mean = mom[:n] / rows
+    var = (mom[n:] / rows - mean * mean).clamp_min(0.0)
+    out = (xd - mean) / th.sqrt(var + bn.eps)
+    if bn.affine:
+        out = out * bn.weight.double() + bn.bias.double()
+    if bn.track_running_stats:
+        with th.no_grad():
+            m = bn.momentum
+            unbiased = var * rows / (rows - 1) if rows > 1 else var
+            bn.running_mean.mul_(1 - m).add_((m * mean).to(bn.running_mean.dtype))
+            bn.running_var.mul_(1 - m).add_((m * unbiased).to(bn.running_var.dtype))
+            bn.num_batches_tracked += 1
+    return out.to(x.dtype)
+
+
 class _TdLossFn(th.autograd.Function):
     """mean((BatchNorm(reward) + gamma (1 - done) next_q - q)^2) (maddpg.py:100-123 behind model.py:308-323) with its
     gradient w.r.t. q, in three small launches (csrc/tdloss.hip); the BatchNorm module's running statistics are
@@ -354,6 +407,7 @@ class _TdLossFn(th.autograd.Function):
                 a.num_batches_tracked = bn.num_batches_tracked.data_ptr()
         a.dq, a.loss = dq.data_ptr(), loss.data_ptr()
         a.workspace, a.workspace_floats = ws.data_ptr(), 2 * ws.numel()
+        _td_sync_stats(a, ws)
         _lib.check(lib.flexnet_td_loss(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_td_loss")
         ctx.save_for_backward(dq)
         ctx.q_shape = q.shape
@@ -400,6 +454,7 @@ def batchnorm_update_running_stats(bn, x):
     a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
     a.num_batches_tracked = bn.num_batches_tracked.data_ptr()
     a.workspace, a.workspace_floats = ws.data_ptr(), 2 * ws.numel()
+    _td_sync_stats(a, ws)
     _lib.check(lib.flexnet_td_loss(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_td_loss")
 
 
@@ -973,6 +1028,7 @@ class _CriticTdLossFn(th.autograd.Function):
         loss = th.empty((), dtype=th.float32, device=dev)
         t = _td_args(r, d, nq, gamma, bn, update_stats=True)
         t.loss = loss.data_ptr()
+        _td_sync_stats(t, _TD_WS[r.device])
         _lib.check(lib.flexnet_critic_td_backward(C.byref(args), C.byref(t), stream), "flexnet_critic_td_backward")
         d_bias = th.empty(64, dtype=th.float32, device=dev)
         tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias, x2=act2d, out2=dW[:, no + n:no + n + na_])

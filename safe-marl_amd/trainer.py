@@ -33,7 +33,7 @@ _RMSPROP = dict(alpha=0.99, eps=1e-5)       # trainer.py:34-35
 
 class PGTrainer(object):
     def __init__(self, args, model, env, logger, batch_scale=None, replay_capacity=None, graph_rollout=True,
-                 graph_updates=True):
+                 graph_updates=True, sync_reward_bn=None):
         if args.episodic:
             raise NotImplementedError("episodic replay is outside the MADDPG hot path (default.yaml:9)")
         self.args, self.env, self.logger = args, env, logger
@@ -59,6 +59,15 @@ class PGTrainer(object):
                                    and fdist.backend() == "nccl")
         self.entr = args.entr
         self.world = fdist.world_size()
+        # Reward BatchNorm over ALL ranks' batches ("or all-reduce 2 x 5 moments"): off by default (per-rank
+        # statistics, the documented deviation); on (argument or FLEX_SYNC_REWARD_BN=1) every reward normalisation sums its
+        # moments over the ranks first — one more 8 KB all-reduce per sub-update, inside the update graph where the gradient
+        # all-reduce is (nccl), eager sub-updates otherwise
+        if sync_reward_bn is None:
+            sync_reward_bn = os.environ.get("FLEX_SYNC_REWARD_BN") == "1"
+        self.sync_reward_bn = bool(sync_reward_bn) and self.world > 1
+        from . import nets as _nets
+        _nets.REWARD_BN_SYNC = self.sync_reward_bn
 
         # behaviour net (+ target replica), trainer.py:16-28: SAFEMADDPG also receives the env
         ctor_args = (args, env) if args.alg == "safemaddpg" else (args,)
@@ -275,6 +284,8 @@ class PGTrainer(object):
                 self._sub_update(which, out, batch, fresh_leaves=True)
         else:
             fused = False
+            if self.sync_reward_bn and not self.allreduce_in_graph:
+                raise RuntimeError("cross-rank reward statistics need the all-reduces inside the update graph (nccl)")
             if self.allreduce_in_graph:
                 try:
                     with graph_capture(graph):
@@ -283,6 +294,8 @@ class PGTrainer(object):
                         self._apply_grads(which, out, flat=flat)
                     fused = True
                 except Exception as exc:
+                    if self.sync_reward_bn:      # the statistics' all-reduce sits inside graph A: no split form — eager sub-updates
+                        raise
                     import warnings
                     warnings.warn(f"all-reduce inside the sub-update graph could not be captured ({exc}); splitting the graph at it")
                     self.allreduce_in_graph = False

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, sync_bn=False):
     import safe_marl_amd  # noqa: F401
     from safe_marl_amd import dist as fdist
     from safe_marl_amd.learner import MADDPG
@@ -35,20 +35,25 @@ def _worker(rank, world, port, out):
         n_envs = 1
 
     th.manual_seed(100 + rank)                    # different initial weights per rank on purpose
-    trainer = PGTrainer(args, MADDPG, Env(), None)
+    trainer = PGTrainer(args, MADDPG, Env(), None, sync_reward_bn=sync_bn)
     w0 = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.parameters()])
     z = np.load(os.path.join(G, "learner_batch.npz"))
     lo, hi = (0, 16) if rank == 0 else (16, 32)   # each rank sees its own half of the batch
     batch = Transition(**{k: th.from_numpy(z[k]).float()[lo:hi] for k in Transition._fields})
     stat = {}
-    # reward BatchNorm uses per-rank batch statistics (documented deviation): switch it off here so
-    # that the two half-batches average to the full-batch gradient exactly
-    trainer.behaviour_net.args = trainer.args = args._replace(reward_normalisation=False)
+    # reward BatchNorm uses per-rank batch statistics by default (documented deviation): switched off here so
+    # that the two half-batches average to the full-batch gradient exactly — or left ON with the cross-rank statistics
+    # (sync_reward_bn), under which the same must hold
+    if not sync_bn:
+        trainer.behaviour_net.args = trainer.args = args._replace(reward_normalisation=False)
     trainer.value_transition_process(stat, batch)
     trainer.policy_transition_process(stat, batch)
     w1 = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.parameters()])
     start, per = fdist.shard_envs(8192)
-    out[rank] = dict(w0=w0.numpy(), w1=w1.numpy(), vnorm=float(stat["mean_train_value_grad_norm"]), shard=(start, per))
+    bn = trainer.behaviour_net.batchnorm
+    out[rank] = dict(w0=w0.numpy(), w1=w1.numpy(), vnorm=float(stat["mean_train_value_grad_norm"]), shard=(start, per),
+                     bn_mean=bn.running_mean.numpy().copy(), bn_var=bn.running_var.numpy().copy(),
+                     bn_n=int(bn.num_batches_tracked))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -87,6 +92,79 @@ def test_two_ranks_stay_identical_and_average_gradients():
     w = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.parameters()]).numpy()
     assert np.allclose(w, a["w1"], atol=2e-6)
     assert abs(float(stat["mean_train_value_grad_norm"]) - a["vnorm"]) < 1e-4 * max(1.0, a["vnorm"])
+
+
+def test_cross_rank_reward_statistics_make_two_half_batches_the_full_batch():
+    """SURVEY.md 8e / VERDICT r02 item 8b: with ``sync_reward_bn`` the reward BatchNorm's batch statistics are summed over
+    the ranks (2 x 5 moments per normalisation), so two ranks on half a batch each take the step one process takes on the
+    whole batch WITH the normalisation on — weights, gradient norm and the module's running statistics."""
+    import safe_marl_amd  # noqa: F401
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.replay_buffer import Transition
+    from safe_marl_amd.trainer import PGTrainer
+    from safe_marl_amd.util import convert
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out, True), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    assert np.array_equal(a["w1"], b["w1"]) and np.array_equal(a["bn_mean"], b["bn_mean"])
+    args = convert(json.load(open(os.path.join(G, "learner_args.json"))))
+    assert args.reward_normalisation
+
+    class Env:
+        n_envs = 1
+
+    trainer = PGTrainer(args, MADDPG, Env(), None)
+    with th.no_grad():
+        off = 0
+        for p in trainer.behaviour_net.parameters():
+            p.copy_(th.from_numpy(a["w0"][off:off + p.numel()]).view_as(p))
+            off += p.numel()
+    z = np.load(os.path.join(G, "learner_batch.npz"))
+    batch = Transition(**{k: th.from_numpy(z[k]).float() for k in Transition._fields})
+    stat = {}
+    trainer.value_transition_process(stat, batch)
+    trainer.policy_transition_process(stat, batch)
+    w = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.parameters()]).numpy()
+    assert np.allclose(w, a["w1"], atol=2e-6)
+    assert abs(float(stat["mean_train_value_grad_norm"]) - a["vnorm"]) < 1e-4 * max(1.0, a["vnorm"])
+    bn = trainer.behaviour_net.batchnorm
+    assert int(bn.num_batches_tracked) == a["bn_n"] == 2          # one normalisation per get_loss call (value, policy)
+    assert np.allclose(bn.running_mean.numpy(), a["bn_mean"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(bn.running_var.numpy(), a["bn_var"], rtol=1e-5, atol=1e-7)
+    # ... and per-rank statistics (the default) do NOT give the full-batch step: the deviation DESIGN.md documents
+    out2 = mgr.dict()
+    mp.spawn(_worker_per_rank_bn, args=(2, _free_port(), out2), nprocs=2, join=True)
+    assert not np.allclose(out2[0]["w1"], a["w1"], atol=2e-6)
+
+
+def _worker_per_rank_bn(rank, world, port, out):
+    """As _worker with the normalisation ON and per-rank statistics (sync off)."""
+    import safe_marl_amd  # noqa: F401
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.replay_buffer import Transition
+    from safe_marl_amd.trainer import PGTrainer
+    from safe_marl_amd.util import convert
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = convert(json.load(open(os.path.join(G, "learner_args.json"))))
+
+    class Env:
+        n_envs = 1
+
+    th.manual_seed(100 + rank)
+    trainer = PGTrainer(args, MADDPG, Env(), None, sync_reward_bn=False)
+    z = np.load(os.path.join(G, "learner_batch.npz"))
+    lo, hi = (0, 16) if rank == 0 else (16, 32)
+    batch = Transition(**{k: th.from_numpy(z[k]).float()[lo:hi] for k in Transition._fields})
+    stat = {}
+    trainer.value_transition_process(stat, batch)
+    trainer.policy_transition_process(stat, batch)
+    out[rank] = dict(w1=th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.parameters()]).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 class _StubVecEnv:

@@ -138,3 +138,43 @@ def test_unit_seed_is_the_gradient_of_one_without_the_launches():
     loss = td_loss(q, nq, r, d, 0.99, bn)
     names = audit_graph_body(lambda: torch.autograd.grad(loss, q, grad_outputs=seed))
     assert not [k for k in names if "elementwise" in k], names
+
+
+def test_cross_rank_statistics_path_with_two_identical_ranks(monkeypatch):
+    """include/flexnet.h stats_ready / stat_rows (trainer.sync_reward_bn): flexnet_td_stats, an all-reduce of the per-block
+    partial sums, then the loss call on the summed statistics.  Emulated on one GPU with a stand-in all-reduce that doubles
+    its argument — two ranks holding the same shard: the batch mean and the biased variance are those of one shard (sums
+    and row count both double: exact in fp64), so loss and gradient equal the single-rank call BIT FOR BIT, and the running
+    variance moves with the unbiased factor of 2 rows instead of rows.  Same for the critic's fused TD backward."""
+    import torch.distributed as dist
+    from safe_marl_amd import nets
+    from safe_marl_amd.nets import td_loss
+    rows, n = 32768, 5
+    g = torch.Generator(device="cuda").manual_seed(77)
+    reward = torch.randn(rows, n, device="cuda", generator=g) * 2.0 + 1.0
+    done = (torch.rand(rows, device="cuda", generator=g) < 0.1).float()
+    next_q = torch.randn(rows, n, device="cuda", generator=g)
+    q0 = torch.randn(rows, n, device="cuda", generator=g)
+
+    def run(sync):
+        bn = torch.nn.BatchNorm1d(n).cuda()
+        q = q0.clone().requires_grad_(True)
+        if sync:
+            monkeypatch.setattr(nets, "_sync_active", lambda: True)
+            monkeypatch.setattr(dist, "all_reduce", lambda t, op=None: t.mul_(2.0))
+            monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 2)
+        try:
+            loss = td_loss(q, next_q, reward, done, 0.99, bn)
+            gq, = torch.autograd.grad(loss, [q])
+        finally:
+            monkeypatch.undo()
+        return loss, gq, bn
+
+    la, ga, bna = run(False)
+    lb, gb, bnb = run(True)
+    assert torch.equal(la, lb) and torch.equal(ga, gb)
+    assert torch.allclose(bna.running_mean, bnb.running_mean, rtol=0, atol=1e-7)
+    var = reward.double().var(0, unbiased=False)
+    want = 0.9 * 1.0 + 0.1 * var * (2 * rows) / (2 * rows - 1)
+    assert torch.allclose(bnb.running_var.double(), want, rtol=1e-6)
+    assert not torch.equal(bna.running_var, bnb.running_var) or rows > 10 ** 7

@@ -62,3 +62,17 @@ for b, n in ((1024, 5), (2048, 5), (4096, 3), (4096, 5), (6144, 5), (8192, 5), (
         t16 = graph_timed(lambda: fused_actor_forward(ag, obs, hid, n, True, variant=2))
         t32 = graph_timed(lambda: fused_actor_forward(ag, obs, hid, n, True, variant=3))
     print(f"{b * n:7d} rows: {t16:7.1f} us | {t32:7.1f} us", flush=True)
+
+# what the rollout adds to the 20 480-row call: the exploration epilogue with in-kernel noise, and cold caches (the env step
+# between two policy calls streams ~40 MB: emulated by a 64 MB copy between calls)
+b, n = 4096, 5
+obs = torch.randn(b, n, 144, device="cuda"); hid = torch.randn(b, n, 64, device="cuda")
+rng = torch.tensor([1234, 0], dtype=torch.int64, device="cuda")
+src, dst = torch.randn(16 << 20, device="cuda"), torch.empty(16 << 20, device="cuda")
+with torch.no_grad():
+    t_plain = graph_timed(lambda: fused_actor_forward(agent, obs, hid, n, True, variant=2))
+    t_noise = graph_timed(lambda: fused_actor_forward(agent, obs, hid, n, True, variant=2, rng_state=rng))
+    t_copy = graph_timed(lambda: dst.copy_(src))
+    t_cold = graph_timed(lambda: (dst.copy_(src), fused_actor_forward(agent, obs, hid, n, True, variant=2, rng_state=rng)))
+print(f"20480 rows, five-tiles-per-CU kernel: plain {t_plain:.1f} us; with in-kernel exploration noise {t_noise:.1f} us; "
+      f"behind a 64 MB copy ({t_copy:.1f} us) {t_cold - t_copy:.1f} us")
