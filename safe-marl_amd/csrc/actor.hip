@@ -752,6 +752,9 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
     //      are requested.  fc1 needs only its own 39 KB: those (and the small vectors) are requested first — loads return in
     //      order — and published with a first barrier; the gate weights, requested right behind, arrive while the first
     //      tile's fc1 runs and are published by a second barrier after it.
+    const uint64_t rng_seed = a.rng_state ? a.rng_state[0] : 0ull, rng_step = a.rng_state ? a.rng_state[1] : 0ull;
+    const bool draws = !a.noise && a.rng_state && 4 * g < ad && (!coop || cq == 0);
+    float zr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int NGB = 2 * (3 * HID / 4) * (HID / 4) / (64 * R16_W);      // 3 blocks per thread over both gate matrices
     static_assert(NGB * 64 * R16_W == 2 * (3 * HID / 4) * (HID / 4), "gate blocks split evenly");
     float4 vg[NGB][4];
@@ -804,6 +807,11 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
 #pragma unroll
             for (int i = 0; i < 4; ++i) vg[t][i] = *reinterpret_cast<const float4*>(src + i * HID);
         }
+        // the exploration noise of this wavefront's first tile depends on nothing but (seed, step, row): drawn HERE, with
+        // every load in flight and before the first wait — Philox + Box-Muller behind fc2 was 2.8 us of a 22.8 us call, and
+        // drawn between the stage-1 stores and their barrier it still delayed the barrier (tools/actor_bench.py)
+        if (draws && tile_of(rnd) < n_tiles) actor_noise4(rng_seed, rng_step, (uint32_t)(tile_of(rnd) * 16 + j), (uint32_t)g, zr);
+        asm volatile("" : "+v"(zr[0]), "+v"(zr[1]), "+v"(zr[2]), "+v"(zr[3]));        // (the draws stay here)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int e = tid + 64 * R16_W * t, rest = e >> 6;
@@ -831,12 +839,6 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
     for (int idx = tid; idx < (16 * nq - od) * HID; idx += 64 * R16_W)     // fc1 runs over 16-column groups: zero rows behind obs_dim
         s.w1t[(od + idx / HID) * R16_P1 + (idx % HID)] = 0.0f;
     if (tid < 2) s.sync[tid] = 0;
-    // the exploration noise of this wavefront's first tile depends on nothing but (seed, step, row): drawn here, underneath
-    // the wait for the weights — Philox + Box-Muller behind fc2 was 2.8 us of a 22.8 us call (tools/actor_bench.py)
-    const uint64_t rng_seed = a.rng_state ? a.rng_state[0] : 0ull, rng_step = a.rng_state ? a.rng_state[1] : 0ull;
-    const bool draws = !a.noise && a.rng_state && 4 * g < ad && (!coop || cq == 0);
-    float zr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (draws && tile_of(rnd) < n_tiles) actor_noise4(rng_seed, rng_step, (uint32_t)(tile_of(rnd) * 16 + j), (uint32_t)g, zr);
     __syncthreads();
     ASTAMP(1); ASTAMP_C(1);
 
@@ -983,7 +985,7 @@ __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorAr
                     const int64_t at = (int64_t)(r0 + j) * ad + k;
                     a.means[at] = o;
                     if (a.action) {                                           // util.py:57-64, 125-128
-                        const float act = tanhf(o + a.std * (a.noise ? a.noise[at] : zr[r]));
+                        const float act = fast_tanh(o + a.std * (a.noise ? a.noise[at] : zr[r]));     // (~1 ulp, as the gates)
                         a.action[at] = act;
                         a.env_action[at] = 0.5f * (fminf(fmaxf(act, a.action_low), a.action_high) + 1.0f) * (a.action_high - a.action_low) + a.action_low;
                     }

@@ -458,6 +458,8 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     const int env0 = wave * EPW;                               // first environment of this wavefront
     if (env0 >= a.n_envs) return;
+    // (tried in round 3: s_setprio 1 for one of the two hardware wave slots of a SIMD, either parity — 13.5-13.8 us per
+    //  launch with and without: the end spread of this kernel is not an arbitration effect)
     if (a.obs_slabs > 0) {
         // FLEX_STEP_OBS_RING (launch-uniform): the observations go straight into the consumer's slab ring, one slab past
         // the one it is reading; nobody in this launch writes the cursor

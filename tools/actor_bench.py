@@ -72,7 +72,10 @@ src, dst = torch.randn(16 << 20, device="cuda"), torch.empty(16 << 20, device="c
 with torch.no_grad():
     t_plain = graph_timed(lambda: fused_actor_forward(agent, obs, hid, n, True, variant=2))
     t_noise = graph_timed(lambda: fused_actor_forward(agent, obs, hid, n, True, variant=2, rng_state=rng))
+    nz = torch.randn(b, n, 4, device="cuda")
+    t_tensor_noise = graph_timed(lambda: fused_actor_forward(agent, obs, hid, n, True, variant=2, noise=nz))
     t_copy = graph_timed(lambda: dst.copy_(src))
     t_cold = graph_timed(lambda: (dst.copy_(src), fused_actor_forward(agent, obs, hid, n, True, variant=2, rng_state=rng)))
-print(f"20480 rows, five-tiles-per-CU kernel: plain {t_plain:.1f} us; with in-kernel exploration noise {t_noise:.1f} us; "
+print(f"20480 rows, five-tiles-per-CU kernel: plain {t_plain:.1f} us; exploration epilogue on a noise tensor {t_tensor_noise:.1f} us; "
+      f"with in-kernel exploration noise {t_noise:.1f} us; "
       f"behind a 64 MB copy ({t_copy:.1f} us) {t_cold - t_copy:.1f} us")
