@@ -199,6 +199,17 @@ typedef struct {
     int32_t act_w, hid_w, small_w, pad0;
 } FlexReplaySink;
 int flexenv_set_replay_sink(FlexEnv* env, const FlexReplaySink* sink /* NULL: off */);
+/* A burst of `steps` rollout steps — policy evaluation (madrl/models/model.py:102-143, agents/rnn_agent.py:25-33, exploration
+ * utils/util.py:57-64, translate_action utils/util.py:125-128), environment step with restart (env:218-276, model.py:255-262),
+ * transition into the replay ring (model.py:230-254, utils/replay_buffer.py:23-27) — in ONE launch instead of 2 * steps: block
+ * b owns environments 16 b .. 16 b + 15 for the whole burst and stages the policy's weights into its CU once.  `actor` is
+ * the FlexActorArgs (include/flexnet.h) of the ring-mode flexnet_actor_forward call this replaces, with ring_slabs set; the
+ * env must be configured as for flexenv_step(FLEX_STEP_AUTORESET | FLEX_STEP_OBS_RING | FLEX_STEP_REPLAY_SINK) behind that
+ * call (obs ring on actor->cursor_out, sink reading actor->action / actor->hidden_out and writing actor->cursor, its
+ * aux_counter = actor->rng_state + 1 or NULL), n_agents <= 5, steps < slabs.  Afterwards every buffer and both cursor cells
+ * hold what `steps` repetitions of the two launches leave, bit for bit (tests/test_rollout_gpu.py). FLEX_EINVAL otherwise. */
+int flexenv_rollout_burst(FlexEnv* env, const void* actor /* const FlexActorArgs* */, double* reward, uint8_t* done,
+                          double* info, uint8_t* failed, float* obs_ring, int32_t steps, void* stream);
 int32_t flexenv_obs_size(const FlexEnv* env);    /* 6*history, env:71 */
 int32_t flexenv_state_size(const FlexEnv* env);  /* env:72 */
 

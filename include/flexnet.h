@@ -80,6 +80,8 @@ typedef struct {
     float* save_z;
     float* save_n;
     float* save_hn;
+    int64_t ring_slabs;        /* flexenv_rollout_burst only (include/flexenv.h): slabs of the two input rings, for the wrap of
+                                  the slab index from one step of the burst to the next; 0 elsewhere */
 } FlexActorArgs;
 
 /* rnn_agent.py:25-33 + model.py:102-116 for all rows. */

@@ -68,7 +68,7 @@ class ResetSpec(C.Structure):
 # every symbol include/flexenv.h declares
 SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
-    "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_obs_size", "flexenv_state_size",
+    "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_rollout_burst", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_td_stats", "flexnet_critic_td_backward",
     "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gru_backward",
@@ -83,7 +83,8 @@ class FlexActorArgs(C.Structure):
                [("std", C.c_float), ("action_low", C.c_float), ("action_high", C.c_float), ("pad1", C.c_float),
                 ("rng_state", C.c_void_p), ("cursor", C.c_void_p), ("obs_slab_stride", C.c_int64),
                 ("hid_slab_stride", C.c_int64), ("cursor_out", C.c_void_p)] + \
-               [(k, C.c_void_p) for k in ("save_z1", "save_x", "save_r", "save_z", "save_n", "save_hn")]
+               [(k, C.c_void_p) for k in ("save_z1", "save_x", "save_r", "save_z", "save_n", "save_hn")] + \
+               [("ring_slabs", C.c_int64)]
 
 
 class FlexGruBwdArgs(C.Structure):
@@ -250,6 +251,8 @@ def load():
     lib.flexenv_set_obs_ring.restype = C.c_int
     lib.flexenv_set_replay_sink.argtypes = [vp, C.POINTER(FlexReplaySink)]
     lib.flexenv_set_replay_sink.restype = C.c_int
+    lib.flexenv_rollout_burst.argtypes = [vp, C.POINTER(FlexActorArgs), vp, vp, vp, vp, vp, i32, vp]
+    lib.flexenv_rollout_burst.restype = C.c_int
     lib.flexnet_critic_td_backward.argtypes = [C.POINTER(FlexCriticTailArgs), C.POINTER(FlexTdLossArgs), vp]
     lib.flexnet_critic_td_backward.restype = C.c_int
     lib.flexnet_wgrad.argtypes = [C.POINTER(FlexWgradArgs), vp]

@@ -20,7 +20,7 @@ SRC = [os.path.join(CSRC, f) for f in ("flexenv.hip", "actor.hip", "critic.hip",
                                        "optim.hip", "tdloss.hip", "gru.hip")]
 SRC = [f for f in SRC if os.path.exists(f)]
 HEADERS = [os.path.join(CSRC, "flex_device.h"), os.path.join(CSRC, "flex_reduce.h"), os.path.join(CSRC, "flex_launch.h"),
-           os.path.join(CSRC, "flex_td.h"),
+           os.path.join(CSRC, "flex_td.h"), os.path.join(CSRC, "actor_r16.h"),
            os.path.join(ROOT, "include", "flexenv.h"), os.path.join(ROOT, "include", "flexnet.h")]
 DEPS = SRC + HEADERS
 OUT = os.path.join(HERE, "libflexenv_hip.so")

@@ -7,6 +7,8 @@
 #include <string.h>
 #include <vector>
 #include "flex_device.h"
+#include "flexnet.h"
+#include "actor_r16.h"
 
 #define FLEX_MAX_DEVICES 16
 #define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { \
@@ -137,8 +139,10 @@ __device__ __forceinline__ void st_nt2(float2* p, float2 v) {
 // The kernel's first parameter (KArgs, by value) sits at offset 0 of the kernarg segment.  Re-deriving its address
 // through an opaque asm makes later reads fresh scalar loads at the point of use instead of values kept live
 // (and spilled to VGPR lanes) from kernel entry.
-template <typename T> __device__ __forceinline__ const T* relaunder_kernarg() {
-    unsigned long long v = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+// `base`: the kernarg segment's address — __builtin_amdgcn_kernarg_segment_ptr() in a kernel; a called function is HANDED
+// it (the builtin is null outside kernels).
+template <typename T> __device__ __forceinline__ const T* relaunder_kernarg(unsigned long long base) {
+    unsigned long long v = base;
     asm volatile("" : "+s"(v));
     return (const T*)(const __attribute__((address_space(4))) T*)v;
 }
@@ -448,14 +452,16 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
 // Measured on a 45-bus feeder (tools/epw1_bench.py, profiles/r03_epw1_bench.txt): the 256-register build, which spills
 // nothing, is faster at EVERY batch size — 10.1 vs 12.2 us at 1024 environments, 12.2 vs 15.8 at 2048, 21.3 vs 23.8 at 4096
 // (two rounds of wavefronts) and 38.2 vs 40.7 at 8192 — so it is the only one.
-template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK = false>
-__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, 8 / FLEX_WAVES_PER_BLOCK)
-void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restrict__ reward,
-                      uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
-                      ObsT* __restrict__ obs, int want_obs, int auto_reset) {
+// The body of a step for the environments of wavefront `wave` (of the whole batch).  `slab` >= 0: the replay ring's slab
+// index is handed in (flex_rollout_burst_kernel, which walks it itself) instead of read from the cursor cell; `cells`: this
+// call maintains the device-side cursor / counter cells (the one-step kernel does, through one lane of the grid).
+template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK>
+__device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, const ActT* __restrict__ actions,
+                                               double* __restrict__ reward, uint8_t* __restrict__ done, double* __restrict__ info,
+                                               uint8_t* __restrict__ failed, ObsT* __restrict__ obs, int want_obs, int auto_reset,
+                                               const int64_t slab, const bool cells, const unsigned long long kbase) {
     constexpr int LW = FLEX_WAVE / EPW;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     const int env0 = wave * EPW;                               // first environment of this wavefront
     if (env0 >= a.n_envs) return;
     // (tried in round 3: s_setprio 1 for one of the two hardware wave slots of a SIMD, either parity — 13.5-13.8 us per
@@ -463,7 +469,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     if (a.obs_slabs > 0) {
         // FLEX_STEP_OBS_RING (launch-uniform): the observations go straight into the consumer's slab ring, one slab past
         // the one it is reading; nobody in this launch writes the cursor
-        const int64_t p = *a.obs_cursor + 1;
+        const int64_t p = (slab >= 0 ? slab : *a.obs_cursor) + 1;
         obs += (p >= a.obs_slabs ? 0 : p) * a.obs_slab_stride;
     }
     // the spare group of an odd batch computes on env0's inputs (no out-of-bounds reads) and stores nothing
@@ -554,7 +560,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     float sk_av = 0.0f;
     int64_t sk_p = 0;                                                           // the slab this step files into
     if constexpr (SINK) {
-        sk_p = *a.obs_cursor;
+        sk_p = slab >= 0 ? slab : *a.obs_cursor;
         const FlexReplaySink& sk = a.sink;
         const sk_f4* hs = reinterpret_cast<const sk_f4*>(sk.hid_new + (int64_t)env * sk.hid_w);
         const int h4 = sk.hid_w >> 2;
@@ -577,7 +583,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     FLEX_STAMP(2);
 
     // the epilogue re-reads its configuration and rebuilds its bases from fresh kernarg loads (see relaunder_kernarg)
-    const KArgs& z = *relaunder_kernarg<KArgs>();
+    const KArgs& z = *relaunder_kernarg<KArgs>(kbase);
     const FlexCfg& cz = z.cfg;
     double* const e_agent = z.st.agent + (int64_t)env0 * (AF_COUNT * FLEX_MAX_AGENTS);
     float2* const e_vw = z.st.vw + (int64_t)env0 * 64;
@@ -641,7 +647,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
         // the small record into the slab the policy read, the masked recurrent state into the next one, the episode
         // statistics into per-environment running sums.  Everything is re-read from the kernarg segment: nothing of it
         // is live across the solve.
-        const KArgs& zs = *relaunder_kernarg<KArgs>();
+        const KArgs& zs = *relaunder_kernarg<KArgs>(kbase);
         const FlexReplaySink& sk = zs.sink;
         const int64_t p = sk_p;
         const int64_t pn = p + 1 >= zs.obs_slabs ? 0 : p + 1;
@@ -666,7 +672,7 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
                 unsafeAtomicAdd(ac + 6, cum_before); unsafeAtomicAdd(ac + 7, rwd); unsafeAtomicAdd(ac + 8, ok ? 0.0 : 1.0);
             }
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (cells && blockIdx.x == 0 && threadIdx.x == 0) {
             if (sk.cursor_out) *sk.cursor_out = pn;
             if (sk.aux_counter) *sk.aux_counter += 1;
         }
@@ -690,13 +696,13 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
         const DevResetSpec none = {nullptr, nullptr, nullptr, nullptr, nullptr};
         // the restart reads its configuration through a freshly "discovered" kernarg pointer: otherwise the compiler
         // loads every field the (rare) restart needs at kernel entry and carries them — spilled — across the hot path
-        const KArgs& ar = *relaunder_kernarg<KArgs>();
+        const KArgs& ar = *relaunder_kernarg<KArgs>(kbase);
         flex_reset_body<EPW, ObsT>(ar, env, restart, ln0, none, obs, want_obs, failed, true);
     }
     // launch counter for consumers that index by vector step (flexnet_rollout_pack's ring cursor): one lane of the whole
     // grid, pointer re-read from the kernarg segment so that it is not carried across the solve
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const KArgs* const ac = relaunder_kernarg<KArgs>();
+    if (cells && blockIdx.x == 0 && threadIdx.x == 0) {
+        const KArgs* const ac = relaunder_kernarg<KArgs>(kbase);
         int64_t* const sc = ac->step_counter;
         if (sc) {
             const int64_t nx = *sc + 1;
@@ -708,6 +714,104 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
 #endif
     FLEX_STAMP(4);
     FLEX_STAMP_RT(6);
+}
+
+template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK = false>
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, 8 / FLEX_WAVES_PER_BLOCK)
+void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restrict__ reward,
+                      uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
+                      ObsT* __restrict__ obs, int want_obs, int auto_reset) {
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    flex_step_body<EPW, ObsT, ActT, NA_CAP, SINK>(a, wave, actions, reward, done, info, failed, obs, want_obs, auto_reset, -1, true,
+                                                  (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+}
+
+// -------------------------------------------------------------------------------------------------
+// A burst of rollout steps in ONE persistent launch (round 3): block b owns environments 16 b .. 16 b + 15 — eight
+// wavefronts of two environments for the step, n_agents <= 5 tiles of 16 rows for the policy (csrc/actor_r16.h) — and
+// alternates policy evaluation and environment step for `n_steps` vector steps.  The policy's weights (156 KB) are staged
+// into the CU's LDS once per burst instead of once per step (a third of a rollout-size policy call), nothing is launched
+// between the two halves of a step, and the hand-overs (env action, new hidden state, observation) stay in the CU's L2.
+// The arithmetic of both halves is the code of the two stand-alone kernels: same results bit for bit
+// (tests/test_rollout_gpu.py).  KArgs is the first parameter: the step body re-reads it through relaunder_kernarg.
+// -------------------------------------------------------------------------------------------------
+// Producer and consumer of every hand-over are wavefronts of ONE work-group, i.e. of one CU, whose vector L1 they share
+// (write-through: a store updates the line in place): work-group scope is all the ordering needed — stores issued and
+// complete (release: s_waitcnt), everybody there (barrier).  An AGENT-scope fence here writes back the XCD's whole L2
+// (buffer_wbl2) twice per step: measured 180 us per vector step instead of 30.
+__device__ __forceinline__ void burst_handover() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Everything the burst needs, as ONE kernel parameter: the environment step below is a real call (its own register
+// allocation: inlined into the policy's body it shared 256 VGPRs with it, spilled 150 of them, and the reloads — which wait
+// on the memory counter — serialised the step's load phases: 54 k cycles instead of the stand-alone kernel's 26 k) and reads
+// its arguments from the kernarg segment with scalar loads instead of receiving them in vector registers.
+struct BurstArgs {
+    KArgs k;                    // first: flex_step_body re-reads it through relaunder_kernarg
+    FlexActorArgs act;
+    double* reward;
+    uint8_t* done;
+    double* info;
+    uint8_t* failed;
+    float* obs_ring;
+    int n_steps;
+};
+
+template <int NA_CAP>
+__device__ __attribute__((noinline)) void flex_burst_env_step(int slab_v, unsigned kbase_lo, unsigned kbase_hi) {
+    // (arguments of a call arrive in vector registers: back to scalars)
+    const unsigned long long kbase = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)kbase_lo) |
+                                     ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)kbase_hi) << 32);
+    const BurstArgs& b = *relaunder_kernarg<BurstArgs>(kbase);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * R16_W + (threadIdx.x >> 6));
+    const int64_t slab = __builtin_amdgcn_readfirstlane(slab_v);
+    flex_step_body<2, float, float, NA_CAP, true>(b.k, wave, b.act.env_action, b.reward, b.done, b.info, b.failed, b.obs_ring, 1, 1,
+                                                  slab, false, kbase);
+}
+
+template <int NA_CAP>
+__global__ __launch_bounds__(64 * R16_W)
+void flex_rollout_burst_kernel(BurstArgs b) {
+    __shared__ ActorLds16 s;
+#ifdef FLEX_STAMPS
+    // diagnostic build: phase boundaries of the LAST step, per wavefront, in slots 8-12 of its first environment's row
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * R16_W + (threadIdx.x >> 6));
+    const int n_steps = b.n_steps;
+    const KArgs& a = b.k;
+#define BSTAMP(slot, cond) do { unsigned long long _t; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    if (a.stamps && (threadIdx.x & 63) == 0 && 2 * wave < a.n_envs && (cond)) a.stamps[(int64_t)(2 * wave) * 16 + (slot)] = _t; } while (0)
+#else
+#define BSTAMP(slot, cond) do { } while (0)
+#endif
+    actor_r16_body<true>(b.act, s, b.n_steps, [&](int step, int64_t slab) {
+        // the policy's outputs (env action, action, new hidden state: global memory) -> the step of the same environments
+        // (burst_handover: work-group scope)
+        BSTAMP(8, step == n_steps - 1);
+        burst_handover();
+        BSTAMP(9, step == n_steps - 1);
+        const unsigned long long kb = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+        flex_burst_env_step<NA_CAP>((int)slab, (unsigned)kb, (unsigned)(kb >> 32));
+        // ... and its outputs (observation and masked hidden state in the next slab) -> the next policy evaluation
+        BSTAMP(10, step == n_steps - 1);
+        burst_handover();
+        BSTAMP(11, step == n_steps - 1);
+        BSTAMP(12, step == n_steps - 2);
+    });
+#undef BSTAMP
+}
+
+// the cells a burst leaves as `steps` single steps would: cell 0 = the slab the policy reads next, cell 1 = the slab the last
+// step filed into, the noise stream's step counter advanced
+__global__ void flex_burst_finish_kernel(int64_t* cell0, int64_t* cell1, uint64_t* rng_state, int steps, int slabs) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t p0 = *cell0;
+    *cell0 = (p0 + steps) % slabs;
+    *cell1 = (p0 + steps - 1) % slabs;
+    if (rng_state) rng_state[1] += (uint64_t)steps;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1222,6 +1326,41 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
         default: FLEX_LAUNCH_STEP(2, double, double); break;
     }
 #undef FLEX_LAUNCH_STEP
+    HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+int flexenv_rollout_burst(FlexEnv* e, const void* actor, double* reward, uint8_t* done, double* info,
+                          uint8_t* failed, float* obs_ring, int32_t steps, void* stream) {
+    if (!e || !actor || !reward || !done || !obs_ring || steps < 1) return FLEX_EINVAL;
+    const FlexActorArgs& p = *static_cast<const FlexActorArgs*>(actor);
+    const int na = e->cfg.n_agents;
+    // the configuration of the two-launch sink step (flexenv_step with FLEX_STEP_OBS_RING | FLEX_STEP_REPLAY_SINK behind
+    // flexnet_actor_forward in ring mode), and the policy's tiles of a block = the block's sixteen environments
+    if (!e->has_sink || e->obs_slabs < 2 || e->hnet.epw != 2 || na > 5) return FLEX_EINVAL;
+    if (p.rows != (int64_t)e->n_envs * na || p.n_agents != na || p.obs_dim < 1 || p.obs_dim > FLEXNET_MAX_OBS || (p.obs_dim & 3) ||
+        p.act_dim < 1 || p.act_dim > FLEXNET_MAX_ACT) return FLEX_EINVAL;
+    if (!p.obs || !p.hidden_in || !p.hidden_out || !p.means || !p.action || !p.env_action || !p.cursor || !p.cursor_out ||
+        !p.fc1_w || !p.fc1_b || !p.w_ih || !p.w_hh || !p.b_ih || !p.b_hh || !p.fc2_w || !p.fc2_b ||
+        (p.layernorm && (!p.ln_w || !p.ln_b)) || (!p.noise && !p.rng_state)) return FLEX_EINVAL;
+    if (p.ring_slabs != e->obs_slabs || p.obs_slab_stride != e->obs_slab_stride || steps >= e->obs_slabs) return FLEX_EINVAL;
+    if (p.cursor_out != e->obs_cursor || p.cursor != e->sink.cursor_out || p.hidden_out != e->sink.hid_new ||
+        p.action != e->sink.policy_action || p.noise) return FLEX_EINVAL;
+    if (e->sink.aux_counter && (!p.rng_state || (const void*)e->sink.aux_counter != (const void*)(p.rng_state + 1))) return FLEX_EINVAL;
+    if (p.save_z1) return FLEX_EINVAL;
+    KArgs k = make_args(e);
+    k.obs_cursor = e->obs_cursor; k.obs_slab_stride = e->obs_slab_stride; k.obs_slabs = e->obs_slabs;
+    k.sink = e->sink;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((e->n_envs + 15) / 16), block(64 * R16_W);
+    const bool small_obs = na == FLEX_OBS_AGENTS_SMALL && 3 * e->cfg.history <= FLEX_OBS_CLASSES(2) * (FLEX_WAVE / 2);
+    BurstArgs b;
+    b.k = k; b.act = p; b.reward = reward; b.done = done; b.info = info; b.failed = failed; b.obs_ring = obs_ring; b.n_steps = (int)steps;
+    if (small_obs) hipLaunchKernelGGL((flex_rollout_burst_kernel<FLEX_OBS_AGENTS_SMALL>), grid, block, 0, s, b);
+    else hipLaunchKernelGGL((flex_rollout_burst_kernel<FLEX_OBS_AGENTS_LARGE>), grid, block, 0, s, b);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(flex_burst_finish_kernel, dim3(1), dim3(64), 0, s, const_cast<int64_t*>(p.cursor), p.cursor_out,
+                       e->sink.aux_counter ? const_cast<uint64_t*>(p.rng_state) : nullptr, (int)steps, (int)e->obs_slabs);
     HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }

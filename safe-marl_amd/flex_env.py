@@ -201,6 +201,15 @@ class VecFlexProvisionEnv:
                                          self._dtype_tag(out) if out is not None else 0, flags, _stream()), "flexenv_step")
         return self.reward, self.done, self.info
 
+    def rollout_burst(self, actor_args, steps, obs_ring):
+        """``steps`` vector steps of policy + environment in ONE launch (include/flexenv.h: flexenv_rollout_burst):
+        ``actor_args`` is the FlexActorArgs of the ring-mode policy call the burst replaces (nets.fused_actor_forward builds
+        it), the env's obs ring and replay sink are configured as for ``step(..., obs_ring=..., replay_sink=True)``."""
+        self.calls += int(steps)
+        _lib.check(self.lib.flexenv_rollout_burst(self.handle, C.byref(actor_args), _ptr(self.reward), _ptr(self.done),
+                                                  _ptr(self.info), _ptr(self.failed), _ptr(obs_ring), int(steps), _stream()),
+                   "flexenv_rollout_burst")
+
     def set_step_counter(self, counter, modulo=0):
         """Every later step() adds 1 to ``counter[0]`` (int64 device tensor, or None to switch it off) from inside the
         step kernel, wrapping to 0 at ``modulo`` (0 = never) — how a replayed HIP graph keeps the replay ring's cursor

@@ -15,6 +15,8 @@ The N=1 path through ``FlexibilityProvisionEnv`` reproduces the reference's cade
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch as th
 import torch.nn as nn
@@ -105,6 +107,14 @@ class RolloutGraph:
             self.act_buf = th.zeros(N * n, a, device=dev)
             self.hid_buf = th.zeros(N * n, h, device=dev)
             self.acc = th.zeros(N, 10, dtype=th.float64, device=dev)
+        # Burst launch (round 3): with the sink, plain MADDPG (nothing between policy and environment) and at most five
+        # agents — a block's sixteen environments are then at most five 16-row policy tiles, what one CU's LDS-resident
+        # weights serve — run(m) is ONE persistent launch per m steps (include/flexenv.h: flexenv_rollout_burst).
+        self.burst_launch = bool(self.sink and not self.safe and n <= 5 and o % 4 == 0 and hasattr(env, "rollout_burst")
+                                 and os.environ.get("FLEX_ROLLOUT_BURST", "1") != "0")
+        if self.burst_launch:
+            self.means_buf = th.zeros(N * n, a, device=dev)
+            self.burst_env_act = th.zeros(N * n, a, device=dev)
         self._configure_env()
 
     def _configure_env(self):
@@ -147,6 +157,10 @@ class RolloutGraph:
     @property
     def sink_active(self):
         return self.sink and self.fast
+
+    @property
+    def fused_burst(self):
+        return self.burst_launch and self.sink_active and not self._torch_noise
 
     # episode statistics: block sums of the pack kernel, or (sink) the env step's per-environment running sums, added up
     # when asked for (outside any graph)
@@ -207,9 +221,12 @@ class RolloutGraph:
         N = self.env.n_envs
         return buf.slab_window((buf.k - 1) * N, N)
 
-    def body(self):
+    def body(self, burst=0):
+        """One vector step (``burst`` = 0), or ``burst`` of them in the fused launch (``fused_burst`` configurations only)."""
         m, env = self.model, self.env
         N = env.n_envs
+        if burst and not self.fused_burst:
+            raise RuntimeError("rollout burst launch outside its configuration")
         if self.fast:
             with th.no_grad():
                 # exploration noise: drawn by the actor kernel from its own Philox stream (seeded from torch's generator
@@ -224,11 +241,18 @@ class RolloutGraph:
                 hid_in = buf.hid_ring[0].view(N, m.n_, m.hid_dim) if self.ring_active else self._hid
                 if self.sink_active:           # static outputs the env step reads back (registered with its replay sink)
                     ring.update(cursor_out=buf.cursor[1:], out=dict(hidden_out=self.hid_buf, action=self.act_buf))
+                if burst:
+                    # policy and environment for `burst` steps in one persistent launch (include/flexenv.h:
+                    # flexenv_rollout_burst): the policy call's arguments, handed to the env's launch instead of its own
+                    ring["out"].update(means=self.means_buf, env_action=self.burst_env_act)
+                    ring.update(ring_slabs=buf.slabs, launch=lambda args: env.rollout_burst(args, burst, buf.obs_ring))
                 out = fused_actor_forward(m.policy_dicts[0], obs_in, hid_in, m.n_, m.args.agent_id, noise=noise,
                                           std=self.std, low=m.args.action_low, high=m.args.action_high,
                                           rng_state=None if self.torch_noise else self.rng_state, **ring)
                 if out is None:
                     raise RuntimeError("the fused actor kernel declined a configuration RolloutGraph.fast admitted")
+                if burst:
+                    return
                 _, hid, action, env_action = out
                 if self.safe:
                     # safemaddpg.py:90-111: the proposed action goes through the safety layer (HIP closed form,
@@ -278,6 +302,7 @@ class RolloutGraph:
         return self.buf.stepped()
 
     BURSTS = (16, 8, 4, 2)
+    BURST_MAX = 96                                       # fused burst launch: steps per launch (an episode of the env)
 
     def run(self, m):
         """``m`` consecutive vector steps with nothing for the host to do in between: graphs of 16 / 8 / 4 / 2 bodies
@@ -286,7 +311,12 @@ class RolloutGraph:
         minus k - 1 graph launches (~8 us of idle GPU each at 4096 envs).  Returns the slabs completed, in order."""
         done = []
         while m > 0:
-            k = next((b for b in self.BURSTS if b <= m), 1) if self.graph is not None else 1
+            if self.graph is None:
+                k = 1
+            elif self.fused_burst:                       # any length in one launch (below the ring's size)
+                k = min(m, self.BURST_MAX, self.buf.slabs - 1)
+            else:
+                k = next((b for b in self.BURSTS if b <= m), 1)
             if k == 1:
                 done.append(self.step())
                 m -= 1
@@ -306,8 +336,11 @@ class RolloutGraph:
         calls = getattr(self.env, "calls", None)
         g = th.cuda.CUDAGraph()
         with graph_capture(g, pool=self.graph.pool()):
-            for _ in range(k):
-                self.body()
+            if self.fused_burst:
+                self.body(burst=k)
+            else:
+                for _ in range(k):
+                    self.body()
         if calls is not None:
             self.env.calls = calls
         self.bursts[k] = g
@@ -338,7 +371,7 @@ class RolloutGraph:
         # every burst size NOW, not at first use: a first use falls into somebody's timed region (a 16-body capture is
         # milliseconds of host work — BENCH_r02's SAFEMADDPG leg, timed from the second episode on, carried the 8 / 4 / 2
         # captures and read 0.366 ms per vector step on the driver's box against 0.25-0.32 on others)
-        for k in self.BURSTS:
+        for k in (range(2, min(self.BURST_MAX, self.buf.slabs - 1) + 1) if self.fused_burst else self.BURSTS):
             self._capture_burst(k)
         self.buf.cursor.copy_(cursor0)
 

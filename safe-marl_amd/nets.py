@@ -163,9 +163,13 @@ class MLPCritic(nn.Module):
         return self.forward_from_hidden(self.fc1(inputs))
 
 
-def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=1.0, low=0.0, high=1.0, variant=0,
+# FlexActorArgs.variant when the caller names none (include/flexnet.h: 0 = the library's choice by size; tests pin 2 / 3)
+ACTOR_VARIANT = 0
+
+
+def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=1.0, low=0.0, high=1.0, variant=None,
                         rng_state=None, ring_cursor=None, obs_slab_stride=0, hid_slab_stride=0, cursor_out=None,
-                        out=None):
+                        out=None, ring_slabs=0, launch=None):
     """rnn_agent.py:25-33 + model.py:102-116 without an autograd graph, in one HIP launch.
 
     ``obs`` [b, n, obs_dim] fp32 on the GPU WITHOUT the one-hot id columns (the kernel adds fc1's id column of
@@ -177,7 +181,9 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
     (Philox4x32-10 + Box-Muller, csrc/actor.hip actor_noise4); the caller advances ``rng_state[1]`` per call —
     flexnet_rollout_pack does when handed the same tensor.  With ``ring_cursor`` (int64 device tensor) ``obs`` and ``hidden``
     are slab 0 of two slab rings and the launch reads slab ``ring_cursor[0]`` of each (strides in floats), resolved on the
-    device — the rollout graph's way of reading the observation where the environment kernel wrote it."""
+    device — the rollout graph's way of reading the observation where the environment kernel wrote it.
+    ``launch`` (with ``ring_slabs``): called with the filled FlexActorArgs INSTEAD of flexnet_actor_forward — the rollout
+    burst, which runs this policy evaluation inside the environment's persistent launch (flex_env.rollout_burst)."""
     import ctypes as C
     from . import _lib
     a = agent.args
@@ -191,14 +197,16 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
     rows = obs.shape[0] * obs.shape[1]
     obs = obs.contiguous()
     hidden = hidden.reshape(rows, 64).to(th.float32).contiguous()
-    means = th.empty(rows, a.action_dim, dtype=th.float32, device=obs.device)
+    means = (out or {}).get("means")
+    if means is None:
+        means = th.empty(rows, a.action_dim, dtype=th.float32, device=obs.device)
     hid_out = (out or {}).get("hidden_out")
     if hid_out is None:
         hid_out = th.empty(rows, 64, dtype=th.float32, device=obs.device)
     args = _lib.FlexActorArgs()
     args.rows, args.n_agents, args.obs_dim, args.act_dim = rows, n_agents, obs.shape[-1], a.action_dim
     args.agent_id, args.layernorm, args.ln_eps = int(bool(agent_id)), int(bool(a.layernorm)), 1e-5
-    args.variant = int(variant)
+    args.variant = int(ACTOR_VARIANT if variant is None else variant)
     action = env_action = None
     explore = noise is not None or rng_state is not None
     if noise is not None:
@@ -212,7 +220,9 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
         if cursor_out is not None:
             args.cursor_out = cursor_out.data_ptr()
     if explore:
-        action, env_action = (out or {}).get("action"), th.empty_like(means)
+        action, env_action = (out or {}).get("action"), (out or {}).get("env_action")
+        if env_action is None:
+            env_action = th.empty_like(means)
         if action is None:
             action = th.empty_like(means)
         args.std, args.action_low, args.action_high = float(std), float(low), float(high)
@@ -229,6 +239,10 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
             note_fallback("actor_forward", f"non-contiguous {name}")
             return None
         setattr(args, name, None if t is None else t.data_ptr())
+    args.ring_slabs = int(ring_slabs)
+    if launch is not None:
+        launch(args)
+        return (means, hid_out, action, env_action) if explore else (means, hid_out)
     rc = lib.flexnet_actor_forward(C.byref(args), C.c_void_p(th.cuda.current_stream().cuda_stream))
     if rc == _lib.FLEXNET_EUNSUPPORTED:
         note_fallback("actor_forward", "FLEXNET_EUNSUPPORTED from flexnet_actor_forward")

@@ -401,12 +401,17 @@ def test_bursts_of_steps_equal_single_steps_bit_for_bit(fast):
         assert torch.equal(a.buf.cursor, b.buf.cursor)
         for ring in ("obs_ring", "hid_ring", "small_ring"):
             assert torch.equal(getattr(a.buf, ring), getattr(b.buf, ring)), (m, ring)
-    assert sorted(a.bursts) == [2, 4, 8, 16] == sorted(b.bursts)   # all captured with the one-step graph; b never replayed one
+    # all captured with the one-step graph; b never replayed one.  (fast, five agents: run(m) is the fused burst launch of
+    # flexenv_rollout_burst, any length below the ring's eight slabs — the comparison above is that launch against
+    # single policy + environment launches)
+    want = list(range(2, 8)) if a.fused_burst else [2, 4, 8, 16]
+    assert a.fused_burst == fast and sorted(a.bursts) == want == sorted(b.bursts)
     assert a.env.calls == calls                                # replays never go through env.step; recording is undone
 
 
-def test_training_loop_schedule_is_unchanged_by_bursts():
-    """train_process with bursts against the step-by-step loop (BURSTS emptied): the same update events at the same
+def test_training_loop_schedule_is_unchanged_by_bursts(monkeypatch):
+    """train_process with bursts (five agents: the fused burst launch, one launch per run of steps between two update
+    events) against the step-by-step loop (BURSTS emptied, FLEX_ROLLOUT_BURST=0): the same update events at the same
     steps — identical parameters, optimiser state and replay ring after two episodes with updates every 7 steps and
     target updates every 11."""
     import numpy as np
@@ -428,6 +433,7 @@ def test_training_loop_schedule_is_unchanged_by_bursts():
     try:
         for bursts in (saved, ()):
             RolloutGraph.BURSTS = bursts
+            monkeypatch.setenv("FLEX_ROLLOUT_BURST", "1" if bursts else "0")
             torch.manual_seed(3)
             np.random.seed(3)                                  # replay windows are drawn with numpy (utils/replay_buffer.py:17-21)
             env = VecFlexProvisionEnv({}, 256, net=net, series=series, seed=9, warm_start=True)
@@ -436,7 +442,7 @@ def test_training_loop_schedule_is_unchanged_by_bursts():
                 tr.behaviour_net.train_process({}, tr)
             torch.cuda.synchronize()
             rg = tr.behaviour_net._rollout_graph
-            assert bool(rg.bursts) == bool(bursts)
+            assert bool(rg.bursts) == bool(bursts) == rg.fused_burst
             res.append((tr.steps, [p.detach().clone() for p in tr.behaviour_net.parameters()],
                         [p.detach().clone() for p in tr.behaviour_net.target_net.parameters()],
                         tr.replay_buffer.small_ring.clone(), tr.replay_buffer.obs_ring.clone()))
@@ -553,3 +559,52 @@ def test_seven_agents_take_the_pack_path(monkeypatch):
     # the ring holds what the policy did: actions of the last slab are tanh-bounded, rewards finite, 7 agents wide
     t = rg.last_transition()
     assert t.action.shape == (128, 7, 4) and t.action.abs().max().item() <= 1.0 and torch.isfinite(t.reward).all()
+
+
+@pytest.mark.parametrize("n_envs,buildings", [(4100, None), (531, [3, 17, 28])])
+def test_burst_launch_equals_two_launches_per_step_bit_for_bit(n_envs, buildings, monkeypatch):
+    """flexenv_rollout_burst (policy + environment for m steps in one persistent launch, weights staged once per CU)
+    against the same trainer with FLEX_ROLLOUT_BURST=0 (policy launch + environment launch per step): a batch that is not a
+    multiple of a block's sixteen environments (tail block), more blocks than CUs (4100 -> 257), three agents (wavefronts
+    3-7 idle in the policy phase); 40 + 23 + 60 steps with the episodes' restart inside the last burst.  Every
+    ring, cursor, statistic, the noise position and the environments' own state afterwards: identical bits."""
+    import numpy as np
+    from safe_marl_amd import nets
+    from safe_marl_amd.learner import RolloutGraph
+    runs = []
+    # the two-launch side on the 16-row-tile policy kernel whatever the batch (above 80 rows per CU the library would pick
+    # its 32-row kernel, whose LayerNorm sums are grouped differently: equal to 2e-6, not to the bit)
+    monkeypatch.setattr(nets, "ACTOR_VARIANT", 2)
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FLEX_ROLLOUT_BURST", flag)
+        tr = _trainer(n_envs, buildings)
+        m = tr.behaviour_net
+        with torch.no_grad():
+            for p in m.policy_dicts.parameters():
+                p.mul_(10.0)
+        rg = RolloutGraph(m, tr.env, tr.replay_buffer)
+        assert rg.fused_burst == (flag == "1") and rg.sink_active
+        rng = np.random.default_rng(4)
+        na = tr.env.n_agents
+        spec = dict(day=rng.integers(0, 20, n_envs).astype(np.int32), hour=rng.integers(0, 24, n_envs).astype(np.int32),
+                    interval=rng.integers(0, 4, n_envs).astype(np.int32), e0=0.0125 + 0.001 * rng.random((n_envs, na)),
+                    a0=0.5 + 0.5 * rng.random((n_envs, 4 * na)))
+        rg.start_episode(tr.env.reset())
+        rg.capture()
+        rg.start_episode(tr.env.reset(spec=spec))
+        rg.rng_state.copy_(torch.tensor([1234, 5], dtype=torch.int64))
+        slabs = rg.run(40) + rg.run(23) + rg.run(60)         # (every episode ends at step 96: restarts inside the third burst)
+        torch.cuda.synchronize()
+        runs.append((rg, slabs, tr))
+    (a, sa, ta), (b, sb, tb) = runs
+    assert sa == sb and a.buf.k == b.buf.k
+    assert torch.equal(a.buf.cursor, b.buf.cursor) and torch.equal(a.rng_state, b.rng_state)
+    assert int(a.rng_state[1].item()) == 5 + 123
+    for ring in ("obs_ring", "hid_ring", "small_ring"):
+        assert torch.equal(getattr(a.buf, ring), getattr(b.buf, ring)), ring
+    for name in ("acc", "act_buf", "hid_buf"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for name in ("reward", "done", "info", "failed"):
+        assert torch.equal(getattr(ta.env, name), getattr(tb.env, name)), name
+    assert torch.equal(ta.env.get_obs().clone(), tb.env.get_obs().clone())
+    assert float(a.acc[:, 7].abs().sum().item()) > 0
