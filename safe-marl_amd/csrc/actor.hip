@@ -569,7 +569,7 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * R16_W) void actor_rollout16_kernel(FlexActorArgs a) {
     __shared__ ActorLds16 s;
-    actor_r16_body<false>(a, s, 1, [](int, int64_t) {});
+    actor_r16_body(a, s);
 }
 
 

@@ -153,12 +153,43 @@ __device__ __forceinline__ f32x4 r16_gru_tile(const float* wg_l, const float* gb
 }
 
 
-// The kernel body.  FUSED = false: flexnet_actor_forward's launch (one step, rounds of five tiles over the grid).  FUSED = true
-// (csrc/flexenv.hip, flexenv_rollout_burst): block b owns environments 16 b .. 16 b + 15 — its n_agents <= 5 tiles — for
-// `n_steps` consecutive vector steps; the weights are staged ONCE, `after_step(k, p)` runs the environment step of those
-// environments between two policy evaluations (slab p of the rings), and the inputs of step k + 1 are read from slab p + 1.
-template <bool FUSED, typename AfterStep>
-__device__ __forceinline__ void actor_r16_body(FlexActorArgs a, ActorLds16& s, const int n_steps, AfterStep&& after_step) {
+// fc1 of one 16-row tile, all 64 units (four independent chains over the observation's 16-column groups in xq), bias and
+// the agent's id column added: rnn_agent.py:26 with model.py:105-108's one-hot columns folded into w1id
+__device__ __forceinline__ void r16_fc1_tile(const float* w1_l, const float* b1_l, const float* w1id_l, const f32x4* xq, int nq,
+                                             f32x4* x) {
+#pragma unroll
+    for (int T = 0; T < 4; ++T) x[T] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // the four weights of step s + 1 are requested before the MFMAs of step s (as in the GRU)
+    float w[4], wn[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) w[T] = w1_l[16 * T];
+#pragma unroll
+    for (int q = 0; q < FLEXNET_MAX_OBS / 16; ++q) {
+        if (q < nq) {                                                      // wavefront-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nx = 4 * q + r + 1;                              // next step: its rows of w1t are zero past obs_dim
+                if (nx < 4 * (FLEXNET_MAX_OBS / 16)) {
+#pragma unroll
+                    for (int T = 0; T < 4; ++T) wn[T] = w1_l[(16 * (nx >> 2) + (nx & 3)) * R16_P1 + 16 * T];
+                }
+                const float b = xq[q][r];
+#pragma unroll
+                for (int T = 0; T < 4; ++T) x[T] = MFMA16(w[T], b, x[T]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int T = 0; T < 4; ++T) w[T] = wn[T];
+            }
+        }
+    }
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[T][r] += b1_l[16 * T + r] + w1id_l[16 * T + r];
+}
+
+// The stand-alone kernel's body (flexnet_actor_forward at rollout sizes): rounds of five tiles over the grid.
+__device__ __forceinline__ void actor_r16_body(FlexActorArgs a, ActorLds16& s) {
     ASTAMP(0); ASTAMP_C(0);
     // the slab cursor (inputs in a slab ring): requested here, USED only after the weight loads below are in flight — they
     // do not depend on it, and the cell was written by the launch before this one (a cold scalar load, ~1 us, that used to
@@ -172,13 +203,10 @@ __device__ __forceinline__ void actor_r16_body(FlexActorArgs a, ActorLds16& s, c
     const int n_tiles = (a.rows + 15) / 16;
     const bool coop = wave >= 4;
     const int cq = wave & 3;                                               // cooperative wavefronts: their unit tile
-    // this wavefront's tile in round `rnd`: 5 rnd + wave for wavefronts 0-3, 5 rnd + 4 for the cooperating four (FUSED: a
-    // round is the block's n_agents tiles; with fewer than five there is no shared tile and wavefronts >= n_agents idle)
+    // this wavefront's tile in round `rnd`: 5 rnd + wave for wavefronts 0-3, 5 rnd + 4 for the cooperating four
     int rnd = blockIdx.x;
-    const int tpr = FUSED ? na : 5;
-    const float* const obs_base = a.obs;
-    const float* const hid_base = a.hidden_in;
-    auto tile_of = [&](int r_) { return (coop ? tpr == 5 : wave < tpr) ? tpr * r_ + (coop ? 4 : wave) : n_tiles; };
+    constexpr int tpr = 5;
+    auto tile_of = [&](int r_) { return tpr * r_ + (coop ? 4 : wave); };
     f32x4 xq[FLEXNET_MAX_OBS / 16];
     __amdgpu_buffer_rsrc_t robs;
     auto load_obs = [&](int tile) {
@@ -250,7 +278,7 @@ __device__ __forceinline__ void actor_r16_body(FlexActorArgs a, ActorLds16& s, c
         // weights; this is where the slab cursor is first needed
         if (a.cursor) {
             a.obs += cur_p * a.obs_slab_stride; a.hidden_in += cur_p * a.hid_slab_stride;
-            if (!FUSED && a.cursor_out && blockIdx.x == 0 && threadIdx.x == 0) *a.cursor_out = cur_p;
+            if (a.cursor_out && blockIdx.x == 0 && threadIdx.x == 0) *a.cursor_out = cur_p;
         }
         {
             const int64_t obs_bytes = (int64_t)a.rows * od * 4;
@@ -316,36 +344,7 @@ __device__ __forceinline__ void actor_r16_body(FlexActorArgs a, ActorLds16& s, c
         const int ag = min(tile * 16 + j, a.rows - 1) % na;
         const float* w1id_l = s.w1id + ag * HID + 4 * g;
         if (!coop) {
-            // ---- fc1, all 64 units: four independent chains ------------------------------------------------------------
-#pragma unroll
-            for (int T = 0; T < 4; ++T) x[T] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            // the four weights of step s + 1 are requested before the MFMAs of step s (as in the GRU below)
-            float w[4], wn[4];
-#pragma unroll
-            for (int T = 0; T < 4; ++T) w[T] = w1_l[16 * T];
-#pragma unroll
-            for (int q = 0; q < FLEXNET_MAX_OBS / 16; ++q) {
-                if (q < nq) {                                              // wavefront-uniform
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int nx = 4 * q + r + 1;                      // next step: its rows of w1t are zero past obs_dim
-                        if (nx < 4 * (FLEXNET_MAX_OBS / 16)) {
-#pragma unroll
-                            for (int T = 0; T < 4; ++T) wn[T] = w1_l[(16 * (nx >> 2) + (nx & 3)) * R16_P1 + 16 * T];
-                        }
-                        const float b = xq[q][r];
-#pragma unroll
-                        for (int T = 0; T < 4; ++T) x[T] = MFMA16(w[T], b, x[T]);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int T = 0; T < 4; ++T) w[T] = wn[T];
-                    }
-                }
-            }
-#pragma unroll
-            for (int T = 0; T < 4; ++T)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[T][r] += b1_l[16 * T + r] + w1id_l[16 * T + r];
+            r16_fc1_tile(w1_l, b1_l, w1id_l, xq, nq, x);
         } else {
             // ---- fc1, this wavefront's 16 units (one chain: the order the full-tile wavefronts sum in) -------------------
             zq = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -376,8 +375,6 @@ __device__ __forceinline__ void actor_r16_body(FlexActorArgs a, ActorLds16& s, c
         *reinterpret_cast<float4*>(dst + 3 * R16_PG) = make_float4(vg[t][0].w, vg[t][1].w, vg[t][2].w, vg[t][3].w);
     }
     __syncthreads();
-    int64_t slab = cur_p;
-    for (int step = 0; step < n_steps; ++step) {
     for (rnd = blockIdx.x; tpr * rnd < n_tiles; rnd += gridDim.x) {
         const int tile = tile_of(rnd);
         if (tile >= n_tiles) break;                                        // (uniform per wavefront; for the cooperating four: all of them)
@@ -456,24 +453,186 @@ __device__ __forceinline__ void actor_r16_body(FlexActorArgs a, ActorLds16& s, c
         ASTAMP(5); ASTAMP_C(5);
         // (a block with more than one round: the next tile's draws, now)
         if (draws && tile_of(rnd + gridDim.x) < n_tiles && tpr * (rnd + gridDim.x) < n_tiles)
-            actor_noise4(rng_seed, rng_step + step, (uint32_t)(tile_of(rnd + gridDim.x) * 16 + j), (uint32_t)g, zr);
+            actor_noise4(rng_seed, rng_step, (uint32_t)(tile_of(rnd + gridDim.x) * 16 + j), (uint32_t)g, zr);
     }
-    if constexpr (FUSED) {
-        // the environment step of this block's environments on slab `slab`, then the next policy evaluation's inputs from the
-        // slab behind it (written by that step: after_step ends with a fence and a barrier)
-        after_step(step, slab);
-        if (step + 1 < n_steps) {
-            slab = slab + 1 >= a.ring_slabs ? 0 : slab + 1;
-            a.obs = obs_base + slab * a.obs_slab_stride; a.hidden_in = hid_base + slab * a.hid_slab_stride;
-            const int64_t obs_bytes = (int64_t)a.rows * od * 4;
-            robs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.obs), 0,
-                                                     obs_bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)obs_bytes, 0x00027000);
-            const int t0 = tile_of(blockIdx.x);
-            load_obs(t0);
-            load_hid(t0);
-            if (draws && t0 < n_tiles) actor_noise4(rng_seed, rng_step + step + 1, (uint32_t)(t0 * 16 + j), (uint32_t)g, zr);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The policy inside the rollout burst (csrc/flexenv.hip, flexenv_rollout_burst).  A block owns sixteen environments for the
+// whole burst and is TWO independent groups of four wavefronts — group q: environments 16 b + 8 q .. + 7, their 8 n_agents
+// <= 40 policy rows as up to three 16-row tiles (wavefront w < 3 of the group: rows 16 w ..), wavefront 3 of the group draws
+// the NEXT step's exploration noise for those tiles into LDS meanwhile (Philox + Box-Muller cost a tile's wavefront 6.7 k
+// cycles per step when it drew its own).  Each group alternates policy and environment step (env_step: its four wavefronts x
+// two environments) on its own, meeting only its own four wavefronts in between, and group 1 starts half a period late: at
+// any time one wavefront of a SIMD is in the policy (matrix pipe, LDS) and the other in the environment step (fp64 VALU,
+// memory latency) instead of both competing for the same pipe in lockstep.  Same arithmetic per row as actor_r16_body: a
+// row's result does not depend on the tile it sits in (tests/test_actor_gpu.py), so the burst equals the stand-alone
+// launches bit for bit (tests/test_rollout_gpu.py).
+// ------------------------------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) ActorLds16B {
+    float w1t[FLEXNET_MAX_OBS * R16_P1];
+    float wg[HID * R16_PG];
+    float w2p[HID * R16_P2];
+    float b1[HID], lnw[HID], lnb[HID];
+    float w1id[FLEXNET_MAX_AGENTS * HID];
+    float gb[4 * HID];
+    float b2[FLEXNET_MAX_ACT];
+    float noise[2][2][3][16][FLEXNET_MAX_ACT];   // [step parity][group][tile][row][action]
+    int gsync[2];                                // arrivals of each group's wavefronts (monotonic)
+};
+
+// the LDS image actor_r16_body stages (same values in the same places), without its choreography: once per burst
+__device__ __forceinline__ void r16_stage_simple(const FlexActorArgs& a, ActorLds16B& s, int tid) {
+    const int od = a.obs_dim, na = a.n_agents, ad = a.act_dim;
+    const int ld1 = od + (a.agent_id ? na : 0);
+    const int nq = (od + 15) >> 4;
+    for (int idx = tid; idx < HID * ld1; idx += 64 * R16_W) {
+        const int u = idx / ld1, k = idx - u * ld1;
+        if (k < od) s.w1t[k * R16_P1 + u] = a.fc1_w[idx];
+    }
+    for (int idx = tid; idx < (16 * nq - od) * HID; idx += 64 * R16_W) s.w1t[(od + idx / HID) * R16_P1 + (idx % HID)] = 0.0f;
+    for (int idx = tid; idx < 3 * HID * HID; idx += 64 * R16_W) {
+        const int u = idx / HID, k = idx % HID;
+        s.wg[k * R16_PG + u] = a.w_ih[idx];
+        s.wg[k * R16_PG + 3 * HID + u] = a.w_hh[idx];
+    }
+    for (int idx = tid; idx < 16 * HID; idx += 64 * R16_W) {
+        const int o = idx / HID, k = idx % HID;
+        s.w2p[k * R16_P2 + o] = o < ad ? a.fc2_w[o * HID + k] : 0.0f;
+    }
+    if (tid < HID) {
+        s.gb[tid] = a.b_ih[tid] + a.b_hh[tid];
+        s.gb[HID + tid] = a.b_ih[HID + tid] + a.b_hh[HID + tid];
+        s.gb[2 * HID + tid] = a.b_ih[2 * HID + tid];
+        s.gb[3 * HID + tid] = a.b_hh[2 * HID + tid];
+        s.b1[tid] = a.fc1_b[tid];
+        s.lnw[tid] = a.layernorm ? a.ln_w[tid] : 1.0f;
+        s.lnb[tid] = a.layernorm ? a.ln_b[tid] : 0.0f;
+    }
+    static_assert(FLEXNET_MAX_AGENTS * HID == 64 * R16_W, "one id-column element per thread");
+    {
+        const int ag = tid / HID, u = tid % HID;
+        s.w1id[tid] = (a.agent_id && ag < na) ? a.fc1_w[u * ld1 + od + ag] : 0.0f;
+    }
+    if (tid < ad) s.b2[tid] = a.fc2_b[tid];
+}
+
+template <typename EnvStep, typename Mark>
+__device__ __forceinline__ void actor_r16_burst(const FlexActorArgs& a, ActorLds16B& s, const int n_steps, EnvStep&& env_step,
+                                                Mark&& mark) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int grp = wave >> 2, w = wave & 3;
+    const int od = a.obs_dim, na = a.n_agents, ad = a.act_dim;
+    const int nq = (od + 15) >> 4;
+    const uint64_t rng_seed = a.rng_state[0], rng_step = a.rng_state[1];
+    // this group's rows, this wavefront's tile
+    const int grow0 = (16 * (int)blockIdx.x + 8 * grp) * na;
+    const int grows = min(8 * na, a.rows - grow0);                         // (<= 0: a tail block's empty group)
+    const bool has_tile = w < 3 && 16 * w < grows;
+    const int r0 = grow0 + 16 * w;
+    const bool live = has_tile && 16 * w + j < grows;
+    const int row = live ? r0 + j : max(min(r0 + j, grow0 + grows - 1), 0);   // (idle lanes compute on a valid row, store nothing)
+    // wavefront 3: the noise of `for_step` for the group's tiles — lane (tile, row) = (lane >> 4, lane & 15), all action groups
+    auto draw = [&](uint64_t for_step) {
+        const int tt = lane >> 4;
+        if (tt < 3 && 16 * tt + j < grows) {
+            float* dst = s.noise[for_step & 1][grp][tt][j];
+#pragma unroll
+            for (int q = 0; q < FLEXNET_MAX_ACT / 4; ++q) {
+                if (4 * q < ad) {
+                    float z[4];
+                    actor_noise4(rng_seed, for_step, (uint32_t)(grow0 + 16 * tt + j), (uint32_t)q, z);
+                    *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(z[0], z[1], z[2], z[3]);
+                }
+            }
         }
-    }
+    };
+    r16_stage_simple(a, s, tid);
+    if (w == 3) draw(rng_step);
+    if (tid < 2) s.gsync[tid] = 0;
+    __syncthreads();
+
+    const float* w1_l = s.w1t + (4 * g) * R16_P1 + j;
+    const float* wg_l = s.wg + (4 * g) * R16_PG + j;
+    const float* w2_l = s.w2p + (4 * g) * R16_P2 + j;
+    const float* gb_l = s.gb + 4 * g;
+    const float* b1_l = s.b1 + 4 * g;
+    const float* lnw_l = s.lnw + 4 * g;
+    const float* lnb_l = s.lnb + 4 * g;
+    const float* w1id_l = s.w1id + (row % na) * HID + 4 * g;
+    int64_t slab = *a.cursor;
+    int meets = 0;
+    // group 1 starts when group 0 has finished its first policy phase: the two stay half a period apart
+    if (grp == 1)
+        while (__hip_atomic_load(&s.gsync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(8);
+    for (int step = 0; step < n_steps; ++step) {
+        mark(12, step);
+        if (has_tile) {
+            const float* hid_p = a.hidden_in + slab * a.hid_slab_stride + (int64_t)row * HID + 4 * g;
+            f32x4 xq[FLEXNET_MAX_OBS / 16], hv[4], x[4], hnew[4];
+            {
+                // (the loads of actor_r16_body: whole-slab descriptor, a 16-column group behind obs_dim reads what follows the
+                //  row — against zero weights — or zero behind the slab)
+                const int64_t obs_bytes = (int64_t)a.rows * od * 4;
+                const __amdgpu_buffer_rsrc_t robs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(a.obs + slab * a.obs_slab_stride), 0, obs_bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)obs_bytes, 0x00027000);
+                const int xoff = (row * od + 4 * g) * 4;
+#pragma unroll
+                for (int q = 0; q < FLEXNET_MAX_OBS / 16; ++q)
+                    xq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(robs, q < nq ? xoff + 64 * q : -1, 0, 0));
+            }
+#pragma unroll
+            for (int S = 0; S < 4; ++S) {
+                const float4 t = *reinterpret_cast<const float4*>(hid_p + 16 * S);
+                hv[S] = f32x4{t.x, t.y, t.z, t.w};
+            }
+            r16_fc1_tile(w1_l, b1_l, w1id_l, xq, nq, x);
+            r16_ln_relu(x, a.layernorm != 0, a.ln_eps, lnw_l, lnb_l);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                hnew[T] = r16_gru_tile(wg_l, gb_l, T, x, hv);
+                if (live)
+                    *reinterpret_cast<float4*>(a.hidden_out + (int64_t)row * HID + 16 * T + 4 * g) =
+                        make_float4(hnew[T][0], hnew[T][1], hnew[T][2], hnew[T][3]);
+            }
+            f32x4 mo = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int st = 0; st < 16; ++st)
+                mo = MFMA16(w2_l[(16 * (st >> 2) + (st & 3)) * R16_P2], hnew[st >> 2][st & 3], mo);
+            if (live && 4 * g < ad) {
+                const float4 zv = *reinterpret_cast<const float4*>(&s.noise[(rng_step + step) & 1][grp][w][j][4 * g]);
+                const float zr[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * g + r;
+                    if (k < ad) {
+                        const float o = mo[r] + s.b2[k];
+                        const int64_t at = (int64_t)row * ad + k;
+                        a.means[at] = o;
+                        const float act = fast_tanh(o + a.std * zr[r]);                       // util.py:57-64, 125-128
+                        a.action[at] = act;
+                        a.env_action[at] = 0.5f * (fminf(fmaxf(act, a.action_low), a.action_high) + 1.0f) * (a.action_high - a.action_low) + a.action_low;
+                    }
+                }
+            }
+        } else if (w == 3 && step + 1 < n_steps) {
+            draw(rng_step + step + 1);                                     // (the other parity: read in the next policy phase)
+        }
+        // policy outputs (global memory: env action, action, new hidden state) and the noise (LDS) -> the group's other
+        // wavefronts: release / acquire at work-group scope on the group's counter (one CU, one vector L1)
+        mark(8, step);
+        ++meets;
+        r16_rendezvous(&s.gsync[grp], 4 * meets, lane);
+        mark(9, step);
+        env_step(slab);
+        mark(10, step);
+        // ... and the step's outputs (observation, masked hidden state: slab + 1) -> the next policy phase
+        ++meets;
+        r16_rendezvous(&s.gsync[grp], 4 * meets, lane);
+        mark(11, step);
+        slab = slab + 1 >= a.ring_slabs ? 0 : slab + 1;
     }
 }
 

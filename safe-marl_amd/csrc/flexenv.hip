@@ -727,9 +727,9 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
 }
 
 // -------------------------------------------------------------------------------------------------
-// A burst of rollout steps in ONE persistent launch (round 3): block b owns environments 16 b .. 16 b + 15 — eight
-// wavefronts of two environments for the step, n_agents <= 5 tiles of 16 rows for the policy (csrc/actor_r16.h) — and
-// alternates policy evaluation and environment step for `n_steps` vector steps.  The policy's weights (156 KB) are staged
+// A burst of rollout steps in ONE persistent launch (round 3): block b owns environments 16 b .. 16 b + 15 as two groups
+// of four wavefronts (two environments per wavefront for the step, up to three 16-row tiles per group for the policy:
+// csrc/actor_r16.h, actor_r16_burst), each group alternating policy evaluation and environment step for `n_steps` steps.  The policy's weights (156 KB) are staged
 // into the CU's LDS once per burst instead of once per step (a third of a rollout-size policy call), nothing is launched
 // between the two halves of a step, and the hand-overs (env action, new hidden state, observation) stay in the CU's L2.
 // The arithmetic of both halves is the code of the two stand-alone kernels: same results bit for bit
@@ -768,40 +768,35 @@ __device__ __attribute__((noinline)) void flex_burst_env_step(int slab_v, unsign
     const BurstArgs& b = *relaunder_kernarg<BurstArgs>(kbase);
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * R16_W + (threadIdx.x >> 6));
     const int64_t slab = __builtin_amdgcn_readfirstlane(slab_v);
+    // the step is one long dependent chain of short fp64 operations; the wavefront it shares its SIMD with is (mostly) in the
+    // other group's policy phase, a dense stream of matrix and LDS instructions that fills every issue slot it is given:
+    // the chain goes first, the stream takes the gaps
+    __builtin_amdgcn_s_setprio(3);
     flex_step_body<2, float, float, NA_CAP, true>(b.k, wave, b.act.env_action, b.reward, b.done, b.info, b.failed, b.obs_ring, 1, 1,
                                                   slab, false, kbase);
+    __builtin_amdgcn_s_setprio(0);
 }
 
 template <int NA_CAP>
 __global__ __launch_bounds__(64 * R16_W)
 void flex_rollout_burst_kernel(BurstArgs b) {
-    __shared__ ActorLds16 s;
+    __shared__ ActorLds16B s;
+    const unsigned long long kb = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    auto env_step = [&](int64_t slab) { flex_burst_env_step<NA_CAP>((int)slab, (unsigned)kb, (unsigned)(kb >> 32)); };
 #ifdef FLEX_STAMPS
     // diagnostic build: phase boundaries of the LAST step, per wavefront, in slots 8-12 of its first environment's row
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * R16_W + (threadIdx.x >> 6));
-    const int n_steps = b.n_steps;
-    const KArgs& a = b.k;
-#define BSTAMP(slot, cond) do { unsigned long long _t; __builtin_amdgcn_sched_barrier(0); \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-    if (a.stamps && (threadIdx.x & 63) == 0 && 2 * wave < a.n_envs && (cond)) a.stamps[(int64_t)(2 * wave) * 16 + (slot)] = _t; } while (0)
-#else
-#define BSTAMP(slot, cond) do { } while (0)
-#endif
-    actor_r16_body<true>(b.act, s, b.n_steps, [&](int step, int64_t slab) {
-        // the policy's outputs (env action, action, new hidden state: global memory) -> the step of the same environments
-        // (burst_handover: work-group scope)
-        BSTAMP(8, step == n_steps - 1);
-        burst_handover();
-        BSTAMP(9, step == n_steps - 1);
-        const unsigned long long kb = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-        flex_burst_env_step<NA_CAP>((int)slab, (unsigned)kb, (unsigned)(kb >> 32));
-        // ... and its outputs (observation and masked hidden state in the next slab) -> the next policy evaluation
-        BSTAMP(10, step == n_steps - 1);
-        burst_handover();
-        BSTAMP(11, step == n_steps - 1);
-        BSTAMP(12, step == n_steps - 2);
+    actor_r16_burst(b.act, s, b.n_steps, env_step, [&](int slot, int step) {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (b.k.stamps && (threadIdx.x & 63) == 0 && 2 * wave < b.k.n_envs && step == b.n_steps - 1)
+            b.k.stamps[(int64_t)(2 * wave) * 16 + slot] = t;
     });
-#undef BSTAMP
+#else
+    actor_r16_burst(b.act, s, b.n_steps, env_step, [](int, int) {});
+#endif
 }
 
 // the cells a burst leaves as `steps` single steps would: cell 0 = the slab the policy reads next, cell 1 = the slab the last
