@@ -561,12 +561,12 @@ def test_seven_agents_take_the_pack_path(monkeypatch):
     assert t.action.shape == (128, 7, 4) and t.action.abs().max().item() <= 1.0 and torch.isfinite(t.reward).all()
 
 
-@pytest.mark.parametrize("n_envs,buildings", [(4100, None), (531, [3, 17, 28])])
+@pytest.mark.parametrize("n_envs,buildings", [(4100, None), (531, [3, 17, 28]), (77, [5]), (203, [3, 9, 17, 28])])
 def test_burst_launch_equals_two_launches_per_step_bit_for_bit(n_envs, buildings, monkeypatch):
     """flexenv_rollout_burst (policy + environment for m steps in one persistent launch, weights staged once per CU)
     against the same trainer with FLEX_ROLLOUT_BURST=0 (policy launch + environment launch per step): a batch that is not a
-    multiple of a block's sixteen environments (tail block), more blocks than CUs (4100 -> 257), three agents (wavefronts
-    3-7 idle in the policy phase); 40 + 23 + 60 steps with the episodes' restart inside the last burst.  Every
+    multiple of a block's sixteen environments (tail block, empty second group), more blocks than CUs (4100 -> 257), one /
+    three / four agents (8 / 24 / 32 policy rows per group: one or two tiles, the last one partly filled); 40 + 23 + 60 steps with the episodes' restart inside the last burst.  Every
     ring, cursor, statistic, the noise position and the environments' own state afterwards: identical bits."""
     import numpy as np
     from safe_marl_amd import nets

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def main():
     n_envs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     agents = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    short = len(sys.argv) > 3 and sys.argv[3] == "short"           # (a counter pass: few launches, all of 16 steps)
     from test_rollout_gpu import _trainer
     from safe_marl_amd.learner import RolloutGraph
     for flag in ("0", "1"):
@@ -21,11 +22,11 @@ def main():
         rg = RolloutGraph(tr.behaviour_net, tr.env, tr.replay_buffer)
         rg.start_episode(tr.env.reset())
         rg.capture()
-        for m in (60, 36, 16, 96):
+        for m in ((16,) if short else (60, 36, 16, 96)):
             rg.run(m)                                       # warm
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 20
+            reps = 3 if short else 20
             t0 = time.perf_counter()
             e0.record()
             for _ in range(reps):
