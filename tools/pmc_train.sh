@@ -17,6 +17,6 @@ for fn in f:
         k=r["Kernel_Name"][:64]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in sorted(agg.items()):
-    if any(t in k for t in ("flex_step", "critic_tail_pgrad16", "actor_forward_mfma")):
+    if any(t in k for t in ("flex_step", "flex_rollout_burst", "critic_tail", "actor_forward_mfma", "actor_rollout16", "wgrad_kernel", "Cijk")):
         print(k, {c:(round(sum(x)/len(x),1), len(x)) for c,x in v.items()})
 PY

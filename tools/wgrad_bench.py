@@ -33,3 +33,10 @@ for k, m, n in [(163840, 64, 149), (163840, 192, 64), (163840, 4, 64), (32768, 6
     t_lib = bench_eager(lambda: dy.t() @ x); print("library done", flush=True)
     gb = k * (m + n) * 4 / 1e9; fl = 2.0 * k * m * n / 1e12
     print("k=%6d m=%3d n=%3d  hip %7.1f us (%5.2f TB/s, %5.1f TFLOP/s)   library %7.1f us" % (k, m, n, t_hip, gb / t_hip * 1e3, fl / t_hip * 1e6, t_lib))
+
+# the critic's first layer as the value sub-update calls it: [obs block | action block] as ONE operand (two views), column sums
+k, m = 32768, 64
+dy = torch.randn(k, m, device="cuda"); x = torch.randn(k, 720, device="cuda"); x2 = torch.randn(k, 20, device="cuda")
+out = torch.empty(m, 745, device="cuda"); cs = torch.empty(m, device="cuda")
+t_two = bench(lambda: tall_wgrad(dy, x, out=out[:, :720], colsum=cs, x2=x2, out2=out[:, 725:745]))
+print("k=%6d m=%3d n=720+20 (two views, column sums)  hip %7.1f us" % (k, m, t_two))
