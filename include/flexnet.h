@@ -108,6 +108,28 @@ typedef struct {
     const float* h_prev;       /* [rows, 64] */
     float* d_gi;               /* out [rows, 192] */
     float* d_gh;               /* out [rows, 192] */
+    /* Round 3, optional (dz NULL: the pointwise pass above): the first layer's backward in the same launch —
+     * dx = d_gi @ W_ih on the matrix cores (never stored), then the backward of x = ReLU(LayerNorm(z1 + fc1.bias + id column
+     * of row % n_agents)) (rnn_agent.py:25-29; flexnet_lnrelu_backward's arithmetic): dz [rows, 64] (the gradient of fc1's
+     * raw output: flexnet_wgrad against the observations gives fc1's weight gradient) and the four parameter gradients, the
+     * id-column sums written through strides (e.g. straight into fc1's gradient: agent stride 1, unit stride its row pitch). */
+    const float* w_ih;         /* [192, 64] */
+    const float* z1;           /* [rows, 64]  save_z1 of flexnet_actor_forward */
+    const float* x;            /* [rows, 64]  save_x, or NULL: ReLU's mask is then recomputed from z1 */
+    const float* fc1_w;        /* [64, fc1_ld]: the id columns are read in place (agent_id) */
+    const float* fc1_b;        /* [64] or NULL */
+    const float* ln_w;         /* [64] (layernorm) */
+    const float* ln_b;
+    float* dz;                 /* out [rows, 64] */
+    float* d_ln_w;             /* out [64] or NULL */
+    float* d_ln_b;
+    float* d_fc1_b;
+    float* d_id;               /* out, n_agents x 64 elements through the two strides below, or NULL */
+    float* workspace;          /* >= FLEXNET_LNRELU_WS_FLOATS floats */
+    int64_t workspace_floats;
+    int64_t d_id_agent_stride, d_id_unit_stride;
+    int32_t fc1_ld, obs_dim, n_agents, agent_id, layernorm;
+    float ln_eps;
 } FlexGruBwdArgs;
 
 int flexnet_gru_backward(const FlexGruBwdArgs* args, void* stream);

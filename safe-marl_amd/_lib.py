@@ -90,7 +90,12 @@ class FlexActorArgs(C.Structure):
 class FlexGruBwdArgs(C.Structure):
     """include/flexnet.h"""
     _fields_ = [("rows", C.c_int32), ("act_dim", C.c_int32)] + \
-               [(k, C.c_void_p) for k in ("d_means", "d_hidden", "fc2_w", "r", "z", "n", "hn", "h_prev", "d_gi", "d_gh")]
+               [(k, C.c_void_p) for k in ("d_means", "d_hidden", "fc2_w", "r", "z", "n", "hn", "h_prev", "d_gi", "d_gh",
+                                          "w_ih", "z1", "x", "fc1_w", "fc1_b", "ln_w", "ln_b", "dz", "d_ln_w", "d_ln_b", "d_fc1_b",
+                                          "d_id", "workspace")] + \
+               [("workspace_floats", C.c_int64), ("d_id_agent_stride", C.c_int64), ("d_id_unit_stride", C.c_int64),
+                ("fc1_ld", C.c_int32), ("obs_dim", C.c_int32), ("n_agents", C.c_int32), ("agent_id", C.c_int32),
+                ("layernorm", C.c_int32), ("ln_eps", C.c_float)]
 
 
 class FlexCriticTailArgs(C.Structure):

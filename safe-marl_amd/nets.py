@@ -546,6 +546,12 @@ class _LnReluFn(th.autograd.Function):
                 None if ln_w is None else small[0], None if ln_w is None else small[1], None, None)
 
 
+# the first layer's backward inside the gate-gradient launch (csrc/gru.hip, gru_backward_fused_kernel); False: the round-2
+# composition (pointwise gate gradients, library GEMM for dx, csrc/lnrelu.hip) — kept as the cross-check of tests/test_gru_gpu.py
+GRU_BWD_FUSED = True
+_DEBUG_KEEP = None                # tools/gru_diag.py: a dict that receives the backward's dz
+
+
 class _ActorTrainFn(th.autograd.Function):
     """The whole actor of rnn_agent.py:25-33 for an update batch as ONE autograd node: the forward is the fused
     matrix-core kernel of csrc/actor.hip (fc1 -> LayerNorm -> ReLU -> GRUCell -> fc2 chained through registers) with its
@@ -601,6 +607,28 @@ class _ActorTrainFn(th.autograd.Function):
         g.d_means, g.fc2_w = d_means.data_ptr(), fc2_w.data_ptr()
         g.r, g.z, g.n, g.hn = saved[2].data_ptr(), saved[3].data_ptr(), saved[4].data_ptr(), saved[5].data_ptr()
         g.h_prev, g.d_gi, g.d_gh = hidden.data_ptr(), d_gi.data_ptr(), d_gh.data_ptr()
+        fused = GRU_BWD_FUSED
+        if fused:
+            # ... and the first layer's backward in the same launch (round 3): dx = d_gi @ W_ih on the matrix cores, never
+            # stored; LayerNorm / ReLU / bias / id columns backward; the id-column sums land in fc1's gradient through strides
+            dz = th.empty(rows, 64, dtype=th.float32, device=dev)
+            small = th.empty(3, 64, dtype=th.float32, device=dev)
+            d_fc1_w = th.empty_like(fc1_w)
+            if dev not in _LNRELU_WS:
+                _LNRELU_WS[dev] = th.empty(_lib.FLEXNET_LNRELU_WS_FLOATS, dtype=th.float32, device=dev)
+            ws = _LNRELU_WS[dev]
+            g.w_ih, g.z1, g.fc1_w, g.dz = w_ih.data_ptr(), saved[0].data_ptr(), fc1_w.data_ptr(), dz.data_ptr()
+            g.x = saved[1].data_ptr()                  # ReLU's mask: the forward's own output
+            g.fc1_b = fc1_b.data_ptr() if fc1_b is not None else None
+            g.fc1_ld, g.obs_dim, g.n_agents, g.agent_id = fc1_w.shape[1], o, n, int(ctx.agent_id)
+            g.layernorm, g.ln_eps = int(ln_w is not None), ctx.ln_eps
+            if ln_w is not None:
+                g.ln_w, g.ln_b, g.d_ln_w, g.d_ln_b = ln_w.data_ptr(), ln_b.data_ptr(), small[0].data_ptr(), small[1].data_ptr()
+            g.d_fc1_b = small[2].data_ptr()
+            if ctx.agent_id:
+                g.d_id = d_fc1_w.data_ptr() + 4 * o
+                g.d_id_agent_stride, g.d_id_unit_stride = 1, fc1_w.shape[1]
+            g.workspace, g.workspace_floats = ws.data_ptr(), ws.numel()
         _lib.check(lib.flexnet_gru_backward(C.byref(g), stream), "flexnet_gru_backward")
         # fc2: weight and bias gradients from one pass over d_means
         d_fc2_b = th.empty(fc2_w.shape[0], dtype=th.float32, device=dev)
@@ -610,6 +638,13 @@ class _ActorTrainFn(th.autograd.Function):
         d_w_ih = tall_wgrad(d_gi, saved[1], colsum=d_b_ih)
         d_b_hh = th.empty(192, dtype=th.float32, device=dev)
         d_w_hh = tall_wgrad(d_gh, hidden, colsum=d_b_hh)
+        if fused:
+            if _DEBUG_KEEP is not None:
+                _DEBUG_KEEP["dz"] = dz
+            tall_wgrad(dz, obs, out=d_fc1_w[:, :o])
+            has_ln = ln_w is not None
+            return (None, None, None, None, d_fc1_w, small[2], small[0] if has_ln else None, small[1] if has_ln else None, None,
+                    d_w_ih, d_w_hh, d_b_ih, d_b_hh, d_fc2_w, d_fc2_b)
         # first layer: dx = d_gi @ W_ih, then the LayerNorm / ReLU / bias / id-column epilogue backward and fc1's weight
         dx = d_gi @ w_ih
         dz = th.empty(rows, 64, dtype=th.float32, device=dev)
@@ -627,6 +662,8 @@ class _ActorTrainFn(th.autograd.Function):
         ws = _LNRELU_WS[dev]
         la.workspace, la.workspace_floats = ws.data_ptr(), ws.numel()
         _lib.check(lib.flexnet_lnrelu_backward(C.byref(la), stream), "flexnet_lnrelu_backward")
+        if _DEBUG_KEEP is not None:
+            _DEBUG_KEEP["dz"] = dz
         d_fc1_w = th.empty_like(fc1_w)
         tall_wgrad(dz, obs, out=d_fc1_w[:, :o])
         if ctx.agent_id:

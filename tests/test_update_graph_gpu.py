@@ -89,7 +89,7 @@ def test_graphed_regions_contain_no_aten_multiblock_reduction(monkeypatch):
     torch.cuda.synchronize()
     assert tr.graph_updates and set(tr._update_graphs) == {"value", "policy"}
     for which, must in (("value", ("td_", "critic_tail", "clip_rmsprop", "actor_")),
-                        ("policy", ("lnrelu", "wgrad", "clip_rmsprop", "sum_partial"))):
+                        ("policy", ("gru_backward_fused", "wgrad", "clip_rmsprop", "sum_partial"))):
         names = tr.graph_audit[which]
         for m in must:
             assert any(m in k for k in names), (which, m, names)
