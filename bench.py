@@ -194,6 +194,19 @@ def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, m
     events = sum(1 for st in range(steps0, trainer.steps) if st > 0 and st % freq == 0)
     per_event = trainer.args.value_update_epochs + trainer.args.policy_update_epochs
     rg = getattr(trainer.behaviour_net, "_rollout_graph", None)
+    # the rollout alone, after the timed region (the leg is over: the extra steps go nowhere): runs of 60 vector steps, the
+    # distance between two update events, as the training loop issues them (one burst launch, or graphs of 16 / 8 / 4 bodies)
+    rollout_us = None
+    if rg is not None and rg.graph is not None:
+        rg.run(60)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            rg.run(60)
+        e1.record()
+        torch.cuda.synchronize()
+        rollout_us = e0.elapsed_time(e1) * 1e3 / 300
     out = {"alg": alg, "n_agents": env.n_agents, "envs_per_gpu": envs, "n_gpus": world, "episodes": episodes,
            "vector_steps": steps, "ms_per_vector_step": dt / steps * 1e3,
            "env_steps_per_s": envs * world * steps / dt, "grad_steps": events * per_event,
@@ -202,6 +215,9 @@ def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, m
            "samples_per_transition": per_event * trainer.effective_batch_size() / float(freq * envs),
            "episode_ms": [round(x, 3) for x in episode_ms],
            "rollout_graph": bool(rg is not None and rg.graph is not None), "rollout_fused": bool(rg is not None and rg.fast),
+           # policy + environment for a whole run of steps in ONE persistent launch (flexenv_rollout_burst; plain MADDPG)
+           "rollout_burst_launch": bool(rg is not None and rg.fused_burst),
+           "rollout_us_per_vector_step": None if rollout_us is None else round(rollout_us, 2),
            "graphed_updates": sorted(trainer._update_graphs), "split_update_graphs": bool(world > 1 and trainer._update_graphs and
                                         not all(g.get("allreduce_in_graph") for g in trainer._update_graphs.values())),
            "allreduce_in_graph": bool(world > 1 and trainer._update_graphs and
