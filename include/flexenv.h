@@ -208,8 +208,21 @@ int flexenv_set_replay_sink(FlexEnv* env, const FlexReplaySink* sink /* NULL: of
  * call (obs ring on actor->cursor_out, sink reading actor->action / actor->hidden_out and writing actor->cursor, its
  * aux_counter = actor->rng_state + 1 or NULL), n_agents <= 5, steps < slabs.  Afterwards every buffer and both cursor cells
  * hold what `steps` repetitions of the two launches leave, bit for bit (tests/test_rollout_gpu.py). FLEX_EINVAL otherwise. */
+/* `safety` non-NULL: SAFEMADDPG's step (madrl/models/safemaddpg.py:90-111) — between policy and environment every
+ * environment's proposed action (actor->action) goes through flexenv_safety_project_env's arithmetic (same arguments, same
+ * results) and the environment steps on `env_action`; the replay keeps the policy's own action (model.py:232). */
+typedef struct {
+    const double* s_p;         /* dev [n_agents] */
+    const double* s_q;
+    const double* beta;
+    double v_min, v_max, penalty;
+    double* adjusted;          /* dev [N, 4 n_agents] out */
+    float* env_action;         /* dev [N, 4 n_agents] out: what the step of the same launch reads */
+    float act_low, act_high;
+} FlexBurstSafety;
 int flexenv_rollout_burst(FlexEnv* env, const void* actor /* const FlexActorArgs* */, double* reward, uint8_t* done,
-                          double* info, uint8_t* failed, float* obs_ring, int32_t steps, void* stream);
+                          double* info, uint8_t* failed, float* obs_ring, int32_t steps,
+                          const FlexBurstSafety* safety /* NULL: plain MADDPG */, void* stream);
 int32_t flexenv_obs_size(const FlexEnv* env);    /* 6*history, env:71 */
 int32_t flexenv_state_size(const FlexEnv* env);  /* env:72 */
 

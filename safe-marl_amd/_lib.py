@@ -87,6 +87,13 @@ class FlexActorArgs(C.Structure):
                [("ring_slabs", C.c_int64)]
 
 
+class FlexBurstSafety(C.Structure):
+    """include/flexenv.h"""
+    _fields_ = [("s_p", C.c_void_p), ("s_q", C.c_void_p), ("beta", C.c_void_p), ("v_min", C.c_double), ("v_max", C.c_double),
+                ("penalty", C.c_double), ("adjusted", C.c_void_p), ("env_action", C.c_void_p), ("act_low", C.c_float),
+                ("act_high", C.c_float)]
+
+
 class FlexGruBwdArgs(C.Structure):
     """include/flexnet.h"""
     _fields_ = [("rows", C.c_int32), ("act_dim", C.c_int32)] + \
@@ -256,7 +263,7 @@ def load():
     lib.flexenv_set_obs_ring.restype = C.c_int
     lib.flexenv_set_replay_sink.argtypes = [vp, C.POINTER(FlexReplaySink)]
     lib.flexenv_set_replay_sink.restype = C.c_int
-    lib.flexenv_rollout_burst.argtypes = [vp, C.POINTER(FlexActorArgs), vp, vp, vp, vp, vp, i32, vp]
+    lib.flexenv_rollout_burst.argtypes = [vp, C.POINTER(FlexActorArgs), vp, vp, vp, vp, vp, i32, C.POINTER(FlexBurstSafety), vp]
     lib.flexenv_rollout_burst.restype = C.c_int
     lib.flexnet_critic_td_backward.argtypes = [C.POINTER(FlexCriticTailArgs), C.POINTER(FlexTdLossArgs), vp]
     lib.flexnet_critic_td_backward.restype = C.c_int

@@ -726,91 +726,6 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
                                                   (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
-// -------------------------------------------------------------------------------------------------
-// A burst of rollout steps in ONE persistent launch (round 3): block b owns environments 16 b .. 16 b + 15 as two groups
-// of four wavefronts (two environments per wavefront for the step, up to three 16-row tiles per group for the policy:
-// csrc/actor_r16.h, actor_r16_burst), each group alternating policy evaluation and environment step for `n_steps` steps.  The policy's weights (156 KB) are staged
-// into the CU's LDS once per burst instead of once per step (a third of a rollout-size policy call), nothing is launched
-// between the two halves of a step, and the hand-overs (env action, new hidden state, observation) stay in the CU's L2.
-// The arithmetic of both halves is the code of the two stand-alone kernels: same results bit for bit
-// (tests/test_rollout_gpu.py).  KArgs is the first parameter: the step body re-reads it through relaunder_kernarg.
-// -------------------------------------------------------------------------------------------------
-// Producer and consumer of every hand-over are wavefronts of ONE work-group, i.e. of one CU, whose vector L1 they share
-// (write-through: a store updates the line in place): work-group scope is all the ordering needed — stores issued and
-// complete (release: s_waitcnt), everybody there (barrier).  An AGENT-scope fence here writes back the XCD's whole L2
-// (buffer_wbl2) twice per step: measured 180 us per vector step instead of 30.
-__device__ __forceinline__ void burst_handover() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// Everything the burst needs, as ONE kernel parameter: the environment step below is a real call (its own register
-// allocation: inlined into the policy's body it shared 256 VGPRs with it, spilled 150 of them, and the reloads — which wait
-// on the memory counter — serialised the step's load phases: 54 k cycles instead of the stand-alone kernel's 26 k) and reads
-// its arguments from the kernarg segment with scalar loads instead of receiving them in vector registers.
-struct BurstArgs {
-    KArgs k;                    // first: flex_step_body re-reads it through relaunder_kernarg
-    FlexActorArgs act;
-    double* reward;
-    uint8_t* done;
-    double* info;
-    uint8_t* failed;
-    float* obs_ring;
-    int n_steps;
-};
-
-// (Inlined again since the policy became actor_r16_burst, which keeps almost nothing live across the step: 12 spilled
-//  registers, none in the step's loops, against the 64 the called version saved and restored per step — 34.4 -> 31.8 us per
-//  vector step.  The argument plumbing of the called version stays: it is what keeps the step's scalars out of the policy's.)
-template <int NA_CAP>
-__device__ __forceinline__ void flex_burst_env_step(int slab_v, unsigned kbase_lo, unsigned kbase_hi) {
-    // (arguments of a call arrive in vector registers: back to scalars)
-    const unsigned long long kbase = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)kbase_lo) |
-                                     ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)kbase_hi) << 32);
-    const BurstArgs& b = *relaunder_kernarg<BurstArgs>(kbase);
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * R16_W + (threadIdx.x >> 6));
-    const int64_t slab = __builtin_amdgcn_readfirstlane(slab_v);
-    // the step is one long dependent chain of short fp64 operations; the wavefront it shares its SIMD with is (mostly) in the
-    // other group's policy phase, a dense stream of matrix and LDS instructions that fills every issue slot it is given:
-    // the chain goes first, the stream takes the gaps
-    __builtin_amdgcn_s_setprio(3);
-    flex_step_body<2, float, float, NA_CAP, true>(b.k, wave, b.act.env_action, b.reward, b.done, b.info, b.failed, b.obs_ring, 1, 1,
-                                                  slab, false, kbase);
-    __builtin_amdgcn_s_setprio(0);
-}
-
-template <int NA_CAP>
-__global__ __launch_bounds__(64 * R16_W)
-void flex_rollout_burst_kernel(BurstArgs b) {
-    __shared__ ActorLds16B s;
-    const unsigned long long kb = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    auto env_step = [&](int64_t slab) { flex_burst_env_step<NA_CAP>((int)slab, (unsigned)kb, (unsigned)(kb >> 32)); };
-#ifdef FLEX_STAMPS
-    // diagnostic build: phase boundaries of the LAST step, per wavefront, in slots 8-12 of its first environment's row
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * R16_W + (threadIdx.x >> 6));
-    actor_r16_burst(b.act, s, b.n_steps, env_step, [&](int slot, int step) {
-        unsigned long long t;
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (b.k.stamps && (threadIdx.x & 63) == 0 && 2 * wave < b.k.n_envs && step == b.n_steps - 1)
-            b.k.stamps[(int64_t)(2 * wave) * 16 + slot] = t;
-    });
-#else
-    actor_r16_burst(b.act, s, b.n_steps, env_step, [](int, int) {});
-#endif
-}
-
-// the cells a burst leaves as `steps` single steps would: cell 0 = the slab the policy reads next, cell 1 = the slab the last
-// step filed into, the noise stream's step counter advanced
-__global__ void flex_burst_finish_kernel(int64_t* cell0, int64_t* cell1, uint64_t* rng_state, int steps, int slabs) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int64_t p0 = *cell0;
-    *cell0 = (p0 + steps) % slabs;
-    *cell1 = (p0 + steps - 1) % slabs;
-    if (rng_state) rng_state[1] += (uint64_t)steps;
-}
 
 // -------------------------------------------------------------------------------------------------
 // get_obs(): env:370-403 standalone
@@ -978,15 +893,13 @@ __device__ __forceinline__ void qp_side(const double x0[4], const double cvec[4]
     for (int t = 0; t < 4; ++t) xout[t] = found ? fmax(best[t], t < 3 ? 0.0 : -1e300) : xfree[t];
 }
 
-__global__ void flex_safety_kernel(KArgs a, const void* __restrict__ proposed, int dtype,
-                                   const double* __restrict__ s_p, const double* __restrict__ s_q,
-                                   const double* __restrict__ beta, double v_min, double v_max, double rho,
-                                   double* __restrict__ adjusted, uint8_t* __restrict__ intervened,
-                                   float* __restrict__ env_action, float act_low, float act_span) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+// one (environment, building) of the safety layer; the kernel below maps threads to them, the rollout burst its wavefronts' lanes
+__device__ __forceinline__ void flex_safety_one(const KArgs& a, const int env, const int ag, const void* __restrict__ proposed,
+                                                int dtype, const double* __restrict__ s_p, const double* __restrict__ s_q,
+                                                const double* __restrict__ beta, double v_min, double v_max, double rho,
+                                                double* __restrict__ adjusted, uint8_t* __restrict__ intervened,
+                                                float* __restrict__ env_action, float act_low, float act_span) {
     const int na = a.cfg.n_agents;
-    if (tid >= a.n_envs * na) return;
-    const int env = tid / na, ag = tid - env * na;
     const FlexCfg& c = a.cfg;
     const int nb = a.n_bus;
     const int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
@@ -1022,6 +935,127 @@ __global__ void flex_safety_kernel(KArgs a, const void* __restrict__ proposed, i
         }
     }
     if (intervened && (ch_up || ch_lo)) intervened[env] = 1;
+}
+
+__global__ void flex_safety_kernel(KArgs a, const void* __restrict__ proposed, int dtype,
+                                   const double* __restrict__ s_p, const double* __restrict__ s_q,
+                                   const double* __restrict__ beta, double v_min, double v_max, double rho,
+                                   double* __restrict__ adjusted, uint8_t* __restrict__ intervened,
+                                   float* __restrict__ env_action, float act_low, float act_span) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int na = a.cfg.n_agents;
+    if (tid >= a.n_envs * na) return;
+    const int env = tid / na;
+    flex_safety_one(a, env, tid - env * na, proposed, dtype, s_p, s_q, beta, v_min, v_max, rho, adjusted, intervened, env_action,
+                    act_low, act_span);
+}
+
+// -------------------------------------------------------------------------------------------------
+// A burst of rollout steps in ONE persistent launch (round 3): block b owns environments 16 b .. 16 b + 15 as two groups
+// of four wavefronts (two environments per wavefront for the step, up to three 16-row tiles per group for the policy:
+// csrc/actor_r16.h, actor_r16_burst), each group alternating policy evaluation and environment step for `n_steps` steps.  The policy's weights (156 KB) are staged
+// into the CU's LDS once per burst instead of once per step (a third of a rollout-size policy call), nothing is launched
+// between the two halves of a step, and the hand-overs (env action, new hidden state, observation) stay in the CU's L2.
+// The arithmetic of both halves is the code of the two stand-alone kernels: same results bit for bit
+// (tests/test_rollout_gpu.py).  KArgs is the first parameter: the step body re-reads it through relaunder_kernarg.
+// -------------------------------------------------------------------------------------------------
+// Producer and consumer of every hand-over are wavefronts of ONE work-group, i.e. of one CU, whose vector L1 they share
+// (write-through: a store updates the line in place): work-group scope is all the ordering needed — stores issued and
+// complete (release: s_waitcnt), everybody there (barrier).  An AGENT-scope fence here writes back the XCD's whole L2
+// (buffer_wbl2) twice per step: measured 180 us per vector step instead of 30.
+__device__ __forceinline__ void burst_handover() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Everything the burst needs, as ONE kernel parameter: the environment step below is a real call (its own register
+// allocation: inlined into the policy's body it shared 256 VGPRs with it, spilled 150 of them, and the reloads — which wait
+// on the memory counter — serialised the step's load phases: 54 k cycles instead of the stand-alone kernel's 26 k) and reads
+// its arguments from the kernarg segment with scalar loads instead of receiving them in vector registers.
+struct BurstArgs {
+    KArgs k;                    // first: flex_step_body re-reads it through relaunder_kernarg
+    FlexActorArgs act;
+    double* reward;
+    uint8_t* done;
+    double* info;
+    uint8_t* failed;
+    float* obs_ring;
+    int n_steps;
+    // SAFEMADDPG (safemaddpg.py:90-111): the safety layer between policy and environment — each wavefront projects the
+    // proposed actions of its own two environments (flex_safety_one) and steps them on the result
+    int safety;                 // 0: the step reads the policy's env action
+    const double* s_p;
+    const double* s_q;
+    const double* beta;
+    double v_min, v_max, rho;
+    double* adjusted;           // [N, 4 n_agents] (the replay keeps the policy's own action: nothing reads this)
+    float* safe_env_action;     // [N, 4 n_agents] translate_action of the projected vector: what the step reads
+    float act_low, act_span;
+};
+
+// (Inlined again since the policy became actor_r16_burst, which keeps almost nothing live across the step: 12 spilled
+//  registers, none in the step's loops, against the 64 the called version saved and restored per step — 34.4 -> 31.8 us per
+//  vector step.  The argument plumbing of the called version stays: it is what keeps the step's scalars out of the policy's.)
+template <int NA_CAP, bool SAFE>
+__device__ __forceinline__ void flex_burst_env_step(int slab_v, unsigned kbase_lo, unsigned kbase_hi) {
+    // (arguments of a call arrive in vector registers: back to scalars)
+    const unsigned long long kbase = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)kbase_lo) |
+                                     ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)kbase_hi) << 32);
+    const BurstArgs& b = *relaunder_kernarg<BurstArgs>(kbase);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * R16_W + (threadIdx.x >> 6));
+    const int64_t slab = __builtin_amdgcn_readfirstlane(slab_v);
+    // the step is one long dependent chain of short fp64 operations; the wavefront it shares its SIMD with is (mostly) in the
+    // other group's policy phase, a dense stream of matrix and LDS instructions that fills every issue slot it is given:
+    // the chain goes first, the stream takes the gaps
+    __builtin_amdgcn_s_setprio(3);
+    const float* actions = b.act.env_action;
+    if constexpr (SAFE) {
+        const int na = b.k.cfg.n_agents, lane = threadIdx.x & 63;
+        const int env = 2 * wave + lane / na;
+        if (lane < 2 * na && env < b.k.n_envs)
+            flex_safety_one(b.k, env, lane % na, b.act.action, FLEX_F32, b.s_p, b.s_q, b.beta, b.v_min, b.v_max, b.rho, b.adjusted,
+                            nullptr, b.safe_env_action, b.act_low, b.act_span);
+        // (this wavefront's own stores, read back by its own step: complete before the loads go out)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        actions = b.safe_env_action;
+    }
+    flex_step_body<2, float, float, NA_CAP, true>(b.k, wave, actions, b.reward, b.done, b.info, b.failed, b.obs_ring, 1, 1,
+                                                  slab, false, kbase);
+    __builtin_amdgcn_s_setprio(0);
+}
+
+template <int NA_CAP, bool SAFE>
+__global__ __launch_bounds__(64 * R16_W)
+void flex_rollout_burst_kernel(BurstArgs b) {
+    __shared__ ActorLds16B s;
+    const unsigned long long kb = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    auto env_step = [&](int64_t slab) { flex_burst_env_step<NA_CAP, SAFE>((int)slab, (unsigned)kb, (unsigned)(kb >> 32)); };
+#ifdef FLEX_STAMPS
+    // diagnostic build: phase boundaries of the LAST step, per wavefront, in slots 8-12 of its first environment's row
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * R16_W + (threadIdx.x >> 6));
+    actor_r16_burst(b.act, s, b.n_steps, env_step, [&](int slot, int step) {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (b.k.stamps && (threadIdx.x & 63) == 0 && 2 * wave < b.k.n_envs && step == b.n_steps - 1)
+            b.k.stamps[(int64_t)(2 * wave) * 16 + slot] = t;
+    });
+#else
+    actor_r16_burst(b.act, s, b.n_steps, env_step, [](int, int) {});
+#endif
+}
+
+// the cells a burst leaves as `steps` single steps would: cell 0 = the slab the policy reads next, cell 1 = the slab the last
+// step filed into, the noise stream's step counter advanced
+__global__ void flex_burst_finish_kernel(int64_t* cell0, int64_t* cell1, uint64_t* rng_state, int steps, int slabs) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t p0 = *cell0;
+    *cell0 = (p0 + steps) % slabs;
+    *cell1 = (p0 + steps - 1) % slabs;
+    if (rng_state) rng_state[1] += (uint64_t)steps;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1329,7 +1363,7 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
 }
 
 int flexenv_rollout_burst(FlexEnv* e, const void* actor, double* reward, uint8_t* done, double* info,
-                          uint8_t* failed, float* obs_ring, int32_t steps, void* stream) {
+                          uint8_t* failed, float* obs_ring, int32_t steps, const FlexBurstSafety* safety, void* stream) {
     if (!e || !actor || !reward || !done || !obs_ring || steps < 1) return FLEX_EINVAL;
     const FlexActorArgs& p = *static_cast<const FlexActorArgs*>(actor);
     const int na = e->cfg.n_agents;
@@ -1354,8 +1388,23 @@ int flexenv_rollout_burst(FlexEnv* e, const void* actor, double* reward, uint8_t
     const bool small_obs = na == FLEX_OBS_AGENTS_SMALL && 3 * e->cfg.history <= FLEX_OBS_CLASSES(2) * (FLEX_WAVE / 2);
     BurstArgs b;
     b.k = k; b.act = p; b.reward = reward; b.done = done; b.info = info; b.failed = failed; b.obs_ring = obs_ring; b.n_steps = (int)steps;
-    if (small_obs) hipLaunchKernelGGL((flex_rollout_burst_kernel<FLEX_OBS_AGENTS_SMALL>), grid, block, 0, s, b);
-    else hipLaunchKernelGGL((flex_rollout_burst_kernel<FLEX_OBS_AGENTS_LARGE>), grid, block, 0, s, b);
+    b.safety = 0; b.s_p = b.s_q = b.beta = nullptr; b.v_min = b.v_max = b.rho = 0.0; b.adjusted = nullptr; b.safe_env_action = nullptr;
+    b.act_low = b.act_span = 0.0f;
+    if (safety) {
+        if (!safety->s_p || !safety->s_q || !safety->beta || !safety->adjusted || !safety->env_action ||
+            !(safety->act_high >= safety->act_low)) return FLEX_EINVAL;
+        b.safety = 1; b.s_p = safety->s_p; b.s_q = safety->s_q; b.beta = safety->beta;
+        b.v_min = safety->v_min; b.v_max = safety->v_max; b.rho = safety->penalty;
+        b.adjusted = safety->adjusted; b.safe_env_action = safety->env_action;
+        b.act_low = safety->act_low; b.act_span = safety->act_high - safety->act_low;
+    }
+    if (b.safety) {
+        if (small_obs) hipLaunchKernelGGL((flex_rollout_burst_kernel<FLEX_OBS_AGENTS_SMALL, true>), grid, block, 0, s, b);
+        else hipLaunchKernelGGL((flex_rollout_burst_kernel<FLEX_OBS_AGENTS_LARGE, true>), grid, block, 0, s, b);
+    } else {
+        if (small_obs) hipLaunchKernelGGL((flex_rollout_burst_kernel<FLEX_OBS_AGENTS_SMALL, false>), grid, block, 0, s, b);
+        else hipLaunchKernelGGL((flex_rollout_burst_kernel<FLEX_OBS_AGENTS_LARGE, false>), grid, block, 0, s, b);
+    }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(flex_burst_finish_kernel, dim3(1), dim3(64), 0, s, const_cast<int64_t*>(p.cursor), p.cursor_out,
                        e->sink.aux_counter ? const_cast<uint64_t*>(p.rng_state) : nullptr, (int)steps, (int)e->obs_slabs);

@@ -201,13 +201,30 @@ class VecFlexProvisionEnv:
                                          self._dtype_tag(out) if out is not None else 0, flags, _stream()), "flexenv_step")
         return self.reward, self.done, self.info
 
-    def rollout_burst(self, actor_args, steps, obs_ring):
+    def rollout_burst(self, actor_args, steps, obs_ring, safety=None):
         """``steps`` vector steps of policy + environment in ONE launch (include/flexenv.h: flexenv_rollout_burst):
         ``actor_args`` is the FlexActorArgs of the ring-mode policy call the burst replaces (nets.fused_actor_forward builds
-        it), the env's obs ring and replay sink are configured as for ``step(..., obs_ring=..., replay_sink=True)``."""
+        it), the env's obs ring and replay sink are configured as for ``step(..., obs_ring=..., replay_sink=True)``.
+        ``safety`` (SAFEMADDPG): dict(s_p, s_q, beta: float64 device tensors [n_agents]; v_min, v_max, penalty; adjusted
+        [N, 4 n] float64 and env_action [N, 4 n] float32 device tensors; act_low, act_high) — safety_project(...,
+        env_action_range=...) between policy and step, inside the launch."""
         self.calls += int(steps)
+        sf = None
+        if safety is not None:
+            sf = _lib.FlexBurstSafety()
+            for k in ("s_p", "s_q", "beta", "adjusted", "env_action"):
+                t = safety[k]
+                want = torch.float32 if k == "env_action" else torch.float64
+                if not (t.is_cuda and t.is_contiguous() and t.dtype == want):
+                    raise ValueError(f"rollout_burst safety: {k} must be a contiguous {want} device tensor")
+                setattr(sf, k, t.data_ptr())
+            if safety["adjusted"].numel() != self.n_envs * 4 * self.n_agents or safety["env_action"].numel() != self.n_envs * 4 * self.n_agents:
+                raise ValueError("rollout_burst safety: adjusted / env_action must hold n_envs x 4 n_agents elements")
+            sf.v_min, sf.v_max, sf.penalty = float(safety["v_min"]), float(safety["v_max"]), float(safety.get("penalty", 1000.0))
+            sf.act_low, sf.act_high = float(safety["act_low"]), float(safety["act_high"])
         _lib.check(self.lib.flexenv_rollout_burst(self.handle, C.byref(actor_args), _ptr(self.reward), _ptr(self.done),
-                                                  _ptr(self.info), _ptr(self.failed), _ptr(obs_ring), int(steps), _stream()),
+                                                  _ptr(self.info), _ptr(self.failed), _ptr(obs_ring), int(steps),
+                                                  C.byref(sf) if sf is not None else None, _stream()),
                    "flexenv_rollout_burst")
 
     def set_step_counter(self, counter, modulo=0):

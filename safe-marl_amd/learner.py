@@ -110,11 +110,15 @@ class RolloutGraph:
         # Burst launch (round 3): with the sink, plain MADDPG (nothing between policy and environment) and at most five
         # agents — a block's sixteen environments are then at most five 16-row policy tiles, what one CU's LDS-resident
         # weights serve — run(m) is ONE persistent launch per m steps (include/flexenv.h: flexenv_rollout_burst).
-        self.burst_launch = bool(self.sink and not self.safe and n <= 5 and o % 4 == 0 and hasattr(env, "rollout_burst")
-                                 and os.environ.get("FLEX_ROLLOUT_BURST", "1") != "0")
+        # SAFEMADDPG: the safety projection is a phase of the same launch (each wavefront projects its own two environments)
+        self.burst_launch = bool(self.sink and n <= 5 and o % 4 == 0 and hasattr(getattr(env, "vec", env), "rollout_burst")
+                                 and (not self.safe or a == 4) and os.environ.get("FLEX_ROLLOUT_BURST", "1") != "0")
         if self.burst_launch:
             self.means_buf = th.zeros(N * n, a, device=dev)
             self.burst_env_act = th.zeros(N * n, a, device=dev)
+            if self.safe:
+                self.burst_adjusted = th.zeros(N, 4 * n, dtype=th.float64, device=dev)
+                self.burst_safe_env_act = th.zeros(N, 4 * n, device=dev)
         self._configure_env()
 
     def _configure_env(self):
@@ -160,7 +164,8 @@ class RolloutGraph:
 
     @property
     def fused_burst(self):
-        return self.burst_launch and self.sink_active and not self._torch_noise
+        return (self.burst_launch and self.sink_active and not self._torch_noise
+                and not (self.safe and self.model.intended_actions))       # (that routing transposes in torch)
 
     # episode statistics: block sums of the pack kernel, or (sink) the env step's per-environment running sums, added up
     # when asked for (outside any graph)
@@ -245,7 +250,14 @@ class RolloutGraph:
                     # policy and environment for `burst` steps in one persistent launch (include/flexenv.h:
                     # flexenv_rollout_burst): the policy call's arguments, handed to the env's launch instead of its own
                     ring["out"].update(means=self.means_buf, env_action=self.burst_env_act)
-                    ring.update(ring_slabs=buf.slabs, launch=lambda args: env.rollout_burst(args, burst, buf.obs_ring))
+                    vec = env.vec if hasattr(env, "vec") else env
+                    safety = None
+                    if self.safe:          # safemaddpg.py:90-111 inside the launch: what the three-launch body below calls
+                        s_p, s_q, beta = self.predictor
+                        safety = dict(s_p=s_p, s_q=s_q, beta=beta, v_min=m.V_min, v_max=m.V_max, adjusted=self.burst_adjusted,
+                                      env_action=self.burst_safe_env_act, act_low=m.args.action_low, act_high=m.args.action_high)
+                    ring.update(ring_slabs=buf.slabs,
+                                launch=lambda args: vec.rollout_burst(args, burst, buf.obs_ring, safety=safety))
                 out = fused_actor_forward(m.policy_dicts[0], obs_in, hid_in, m.n_, m.args.agent_id, noise=noise,
                                           std=self.std, low=m.args.action_low, high=m.args.action_high,
                                           rng_state=None if self.torch_noise else self.rng_state, **ring)

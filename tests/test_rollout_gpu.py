@@ -608,3 +608,58 @@ def test_burst_launch_equals_two_launches_per_step_bit_for_bit(n_envs, buildings
         assert torch.equal(getattr(ta.env, name), getattr(tb.env, name)), name
     assert torch.equal(ta.env.get_obs().clone(), tb.env.get_obs().clone())
     assert float(a.acc[:, 7].abs().sum().item()) > 0
+
+
+@pytest.mark.parametrize("N", [8200, 75])
+def test_safemaddpg_burst_equals_three_launches_per_step_bit_for_bit(N, monkeypatch):
+    """SAFEMADDPG through flexenv_rollout_burst (the safety projection as a phase of the persistent launch: each wavefront
+    projects its own two environments between the policy and the step) against policy launch + flexenv_safety_project_env +
+    environment launch per step, with a voltage predictor that makes the layer intervene: 8200 environments (513 blocks: two
+    rounds of persistent blocks and a tail block) and 75; 40 + 70 steps through the episodes' restart.  Identical bits in every
+    ring, cursor, statistic and in the environments' state."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from train_maddpg import DEFAULT_ALG_ARGS
+    from safe_marl_amd import nets
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.learner import SAFEMADDPG, RolloutGraph
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.replay_buffer import TransReplayBuffer
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.util import convert
+    net = create_network()
+    series = make_synthetic_series(net, n_days=30)
+    alg = dict(DEFAULT_ALG_ARGS)
+    alg.update(alg="safemaddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4, v_min=0.9, v_max=1.1)
+    pred = (torch.full((5,), -0.08, dtype=torch.float64), torch.full((5,), -0.05, dtype=torch.float64),
+            torch.full((5,), 0.915, dtype=torch.float64))
+    monkeypatch.setattr(nets, "ACTOR_VARIANT", 2)            # (the two-launch side on the 16-row policy kernel at every size)
+    runs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FLEX_ROLLOUT_BURST", flag)
+        env = VecFlexProvisionEnv({"alg": "safemaddpg"}, N, net=net, series=series, seed=9, warm_start=True)
+        torch.manual_seed(21)
+        m = SAFEMADDPG(convert(alg), env, predictor=pred).cuda()
+        with torch.no_grad():
+            for p in m.policy_dicts.parameters():
+                p.mul_(10.0)
+        rg = RolloutGraph(m, env, TransReplayBuffer(N * 128, device="cuda"))
+        assert rg.safe and rg.sink_active and rg.fused_burst == (flag == "1")
+        rg.start_episode(env.reset())
+        rg.capture()
+        rg.start_episode(env.reset())
+        rg.rng_state.copy_(torch.tensor([77, 3], dtype=torch.int64))
+        slabs = rg.run(40) + rg.run(70)
+        torch.cuda.synchronize()
+        runs.append((rg, slabs, env))
+    (a, sa, ea), (b, sb, eb) = runs
+    assert sa == sb and torch.equal(a.buf.cursor, b.buf.cursor) and torch.equal(a.rng_state, b.rng_state)
+    for ring in ("obs_ring", "hid_ring", "small_ring"):
+        assert torch.equal(getattr(a.buf, ring), getattr(b.buf, ring)), ring
+    for name in ("acc", "act_buf", "hid_buf"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for name in ("reward", "done", "info", "failed"):
+        assert torch.equal(getattr(ea, name), getattr(eb, name)), name
+    assert torch.equal(ea.get_obs().clone(), eb.get_obs().clone())
+    # the layer did act: the step's action differs from translate_action of the policy's own action somewhere
+    own = 0.5 * (a.act_buf.clamp(0.0, 1.0) + 1.0)
+    assert (a.burst_safe_env_act.view(N, 4, 5).transpose(1, 2).reshape(N * 5, 4) - own).abs().max().item() > 1e-3
