@@ -464,8 +464,8 @@ __device__ __forceinline__ void actor_r16_body(FlexActorArgs a, ActorLds16& s) {
 // <= 40 policy rows as up to three 16-row tiles (wavefront w < 3 of the group: rows 16 w ..), wavefront 3 of the group draws
 // the NEXT step's exploration noise for those tiles into LDS meanwhile (Philox + Box-Muller cost a tile's wavefront 6.7 k
 // cycles per step when it drew its own).  Each group alternates policy and environment step (env_step: its four wavefronts x
-// two environments) on its own, meeting only its own four wavefronts in between, and group 1 starts half a period late: at
-// any time one wavefront of a SIMD is in the policy (matrix pipe, LDS) and the other in the environment step (fp64 VALU,
+// two environments) on its own, meeting only its own four wavefronts in between: the two groups free-run, so that most of
+// the time one wavefront of a SIMD is in the policy (matrix pipe, LDS) and the other in the environment step (fp64 VALU,
 // memory latency) instead of both competing for the same pipe in lockstep.  Same arithmetic per row as actor_r16_body: a
 // row's result does not depend on the tile it sits in (tests/test_actor_gpu.py), so the burst equals the stand-alone
 // launches bit for bit (tests/test_rollout_gpu.py).
@@ -564,9 +564,9 @@ __device__ __forceinline__ void actor_r16_burst(const FlexActorArgs& a, ActorLds
     const float* w1id_l = s.w1id + (row % na) * HID + 4 * g;
     int64_t slab = *a.cursor;
     int meets = 0;
-    // group 1 starts when group 0 has finished its first policy phase: the two stay half a period apart
-    if (grp == 1)
-        while (__hip_atomic_load(&s.gsync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(8);
+    // (Both groups start together and drift apart on their own — their steps take different times.  Holding group 1 back
+    //  by half a period at the start was measured: the same 31.6 us per step in a long burst, 0.6 us per step more in a
+    //  16-step one.)
     for (int step = 0; step < n_steps; ++step) {
         mark(12, step);
         if (has_tile) {
