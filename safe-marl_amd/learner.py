@@ -322,32 +322,36 @@ class RolloutGraph:
         finds its slabs through the device-side cursors, so k bodies in one graph are k replays of the one-step graph
         minus k - 1 graph launches (~8 us of idle GPU each at 4096 envs).  Returns the slabs completed, in order."""
         done = []
-        while m > 0:
-            if self.graph is None:
-                k = 1
-            elif self.fused_burst:                       # any length in one launch (below the ring's size)
-                k = min(m, self.BURST_MAX, self.buf.slabs - 1)
-            else:
-                k = next((b for b in self.BURSTS if b <= m), 1)
+        for k in (self.burst_chunks(m) if self.graph is not None else [1] * m):
             if k == 1:
                 done.append(self.step())
-                m -= 1
                 continue
             g = self.bursts.get(k)
             if g is None:
                 g = self._capture_burst(k)
             g.replay()
             done.extend(self.buf.stepped() for _ in range(k))
-            m -= k
         return done
 
-    def _capture_burst(self, k):
+    def burst_chunks(self, m):
+        """The graph sizes run(m) replays, in order (1 = the one-step graph)."""
+        out = []
+        while m > 0:
+            if self.fused_burst:
+                k = min(m, self.BURST_MAX, self.buf.slabs - 1)
+            else:
+                k = next((b for b in self.BURSTS if b <= m), 1)
+            out.append(k)
+            m -= k
+        return out
+
+    def _capture_burst(self, k, collect=True):
         """A graph of ``k`` bodies, sharing the one-step graph's memory pool.  Recording launches nothing: the environment,
         the ring and the cursors are untouched (the bodies were warmed up when the one-step graph was captured); only the
         env's host-side call counter would move."""
         calls = getattr(self.env, "calls", None)
         g = th.cuda.CUDAGraph()
-        with graph_capture(g, pool=self.graph.pool()):
+        with graph_capture(g, collect=collect, pool=self.graph.pool()):
             if self.fused_burst:
                 self.body(burst=k)
             else:
@@ -358,9 +362,12 @@ class RolloutGraph:
         self.bursts[k] = g
         return g
 
-    def capture(self):
+    def capture(self, lengths=None):
         """Warm-up + capture.  The warm-up steps are real steps of the environment; the ring cursor and the statistics
-        they moved are put back afterwards (the slabs they wrote are overwritten by the steps that follow)."""
+        they moved are put back afterwards (the slabs they wrote are overwritten by the steps that follow).
+        ``lengths``: the run lengths the caller will ask run() for (the training loop knows its schedule: the distances
+        between update events and episode ends) — with the one-launch burst every length is a graph of its own, and they are
+        all recorded NOW rather than inside somebody's timed region; other lengths are recorded at first use."""
         import os
         if not self.packable:
             raise RuntimeError("observation / hidden sizes outside flexnet_rollout_pack: the statistics would go through "
@@ -383,8 +390,14 @@ class RolloutGraph:
         # every burst size NOW, not at first use: a first use falls into somebody's timed region (a 16-body capture is
         # milliseconds of host work — BENCH_r02's SAFEMADDPG leg, timed from the second episode on, carried the 8 / 4 / 2
         # captures and read 0.366 ms per vector step on the driver's box against 0.25-0.32 on others)
-        for k in (range(2, min(self.BURST_MAX, self.buf.slabs - 1) + 1) if self.fused_burst else self.BURSTS):
-            self._capture_burst(k)
+        if self.fused_burst:
+            sizes = sorted({k for m in (lengths or ()) for k in self.burst_chunks(int(m)) if k > 1})
+        else:
+            sizes = list(self.BURSTS)
+        import gc
+        gc.collect()
+        for k in sizes:
+            self._capture_burst(k, collect=False)
         self.buf.cursor.copy_(cursor0)
 
     def release(self):
@@ -669,6 +682,23 @@ class Model(nn.Module):
             return type(self).get_actions is SAFEMADDPG.get_actions and bool(self.args.action_enforcebound)
         return True                                      # MADDPG: fused path; MATD3 / IDDPG / others: their get_actions
 
+    def _run_lengths(self, steps, horizon):
+        """Every run length the loop of _train_process_graph will ask the rollout for, from step counter ``steps`` on: the
+        schedule repeats once the counter's phase against the update frequencies repeats at an episode start."""
+        freqs = [int(self.args.behaviour_update_freq)] + ([int(self.args.target_update_freq)] if self.args.target else [])
+        freqs = [f for f in freqs if f > 0]
+        period = int(np.lcm.reduce(freqs)) if freqs else 1
+        seen, lengths, s = set(), set(), int(steps)
+        while s % period not in seen and len(seen) < 4096:
+            seen.add(s % period)
+            t = 0
+            while t < horizon:
+                m = min([horizon - t] + [(-s) % f + 1 for f in freqs])
+                lengths.add(m)
+                t += m
+                s += m
+        return sorted(lengths)
+
     def _train_process_graph(self, stat, trainer, horizon):
         env, buf = trainer.env, trainer.replay_buffer
         N = env.n_envs
@@ -678,7 +708,7 @@ class Model(nn.Module):
             try:
                 rg = RolloutGraph(self, env, buf)
                 rg.start_episode(env.reset())             # the warm-up steps of capture() need a live episode
-                rg.capture()
+                rg.capture(lengths=self._run_lengths(trainer.steps, horizon))
             except Exception as exc:                      # capture unsupported here: fall back to the eager loop
                 import warnings
                 warnings.warn(f"rollout graph capture failed ({exc}); using the eager rollout")

@@ -26,12 +26,14 @@ class graph_capture:
     thread and the process dies with "operation not permitted when stream is capturing" (seen in bench.py's sixth training
     leg: a trainer per leg).  This PyTorch build no longer collects at capture begin by itself."""
 
-    def __init__(self, graph, **kw):
+    def __init__(self, graph, collect=True, **kw):
         self.ctx = th.cuda.graph(graph, capture_error_mode=CAPTURE_MODE, **kw)
+        self.collect = collect                        # False: the caller collected already (a run of captures in a row)
 
     def __enter__(self):
         import gc
-        gc.collect()
+        if self.collect:
+            gc.collect()
         self.was_enabled = gc.isenabled()
         gc.disable()
         try:

@@ -266,3 +266,24 @@ def test_iddpg_matches_reference(gold, args):
     for k, p in model.policy_dicts.named_parameters():
         ref = gold["iddpg_pgrad." + k]
         assert np.allclose(p.grad.numpy(), ref, atol=2e-7 + 1e-4 * np.abs(ref).max()), k
+
+
+def test_run_lengths_cover_the_training_loops_schedule():
+    """Model._run_lengths (which burst graphs the rollout records up front) against the loop of _train_process_graph itself,
+    simulated for 500 episodes from several starting counters."""
+    import types
+    from safe_marl_amd.learner import Model
+    for freqs, horizon in (((60, 120), 95), ((60, 120), 96), ((7, 11), 95), ((30, 0), 10)):
+        me = types.SimpleNamespace(args=types.SimpleNamespace(behaviour_update_freq=freqs[0], target_update_freq=freqs[1],
+                                                              target=freqs[1] > 0))
+        fs = [f for f in freqs if f > 0]
+        for start in (0, 17, 190):
+            want, s = set(), start
+            for _ in range(500):
+                t = 0
+                while t < horizon:
+                    m = min([horizon - t] + [(-s) % f + 1 for f in fs])
+                    want.add(m)
+                    t += m
+                    s += m
+            assert Model._run_lengths(me, start, horizon) == sorted(want)
