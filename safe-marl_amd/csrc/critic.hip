@@ -822,10 +822,10 @@ __device__ __forceinline__ void critic16_layer(const float* wl, const cf32x4* in
 // diagnostic build (-DCRITIC_STAMPS, tools/critic_stamps.py): s_memtime between the phases of block 0's first wavefront,
 // summed over its tiles (never timed, never shipped; the stamps' own s_waitcnt drains the LDS queue at every boundary)
 #ifdef CRITIC_STAMPS
-__device__ unsigned long long critic_stamps[16];
+__device__ unsigned long long critic_stamps[8 * 16];          // [wavefront of block 0][phase]
 #define CSTAMP_DECL unsigned long long cs_last = __builtin_amdgcn_s_memtime(), cs_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define CSTAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cs_acc[k] += t_ - cs_last; cs_last = t_; } while (0)
-#define CSTAMP_OUT do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int k_ = 0; k_ < 10; ++k_) critic_stamps[k_] = cs_acc[k_]; } } while (0)
+#define CSTAMP_OUT do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 10; ++k_) critic_stamps[(threadIdx.x >> 6) * 16 + k_] = cs_acc[k_]; } } while (0)
 extern "C" int flexnet_debug_critic_stamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(critic_stamps), sizeof(critic_stamps)) == hipSuccess ? 0 : -2;
 }
@@ -953,7 +953,9 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
     float* xs_l = pool + TR_FLOATS + (SM ? wave * 16 * HID + j * HID + 4 * g : 0);   // this lane's 4 x 16 bytes of its sample's row
     // static priority for the second-dispatched half: at equal priority the older wavefront of a SIMD wins every issue
     // arbitration, finishes first and leaves the younger one to run its tail alone (67.7 -> 66.5 us for the TD backward's
-    // launches at the update batch; alternating the priority per tile measured the same)
+    // launches at the update batch; alternating the priority per tile measured the same.  Round 3, on the sample-major
+    // kernel: no priority 67.1, this 68.2, the other half raised 67.3 us — inside the noise; per-wavefront stamps show the
+    // first-dispatched four waiting ~15 k of 123 k cycles at the final barrier either way: tools/critic_stamps.py)
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     CSTAMP(0);                                                                 // staging, barriers
     while (ot < n_ot) {
@@ -1174,7 +1176,9 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
     float b3t = g == 0 ? sb3 : 0.0f;                                           // rows live in the g == 0 lanes
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) b3t += __shfl_xor(b3t, off, 64);
+    CSTAMP(7);                                                                 // per-wavefront sums after the last tile
     __syncthreads();                                                           // all tiles done: tr becomes the fold area
+    CSTAMP(8);                                                                 // ... waiting for the block's other wavefronts
     if constexpr (TD) {
         if (tid == 0) {
             double v = td_sqw[0];
@@ -1234,7 +1238,7 @@ __global__ __launch_bounds__(64 * C16W) void critic_tail_pgrad16_kernel(FlexCrit
     float* out = a.workspace + (int64_t)blockIdx.x * CRITIC_WS_PITCH;
     for (int e = tid; e < HID * HID + 4 * HID + 1; e += 64 * C16W)
         out[e] = ((a0[e] + a0[CRITIC_WS_PITCH + e]) + a0[2 * CRITIC_WS_PITCH + e]) + a0[3 * CRITIC_WS_PITCH + e];
-    CSTAMP(7);                                                                 // end-of-kernel fold
+    CSTAMP(9);                                                                 // end-of-kernel fold
     CSTAMP_OUT;
 }
 

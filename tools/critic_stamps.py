@@ -48,13 +48,13 @@ def timed(fn, n=50):
 
 
 r = bench.critic_backward_roofline(timed)
-t = (C.c_ulonglong * 16)()
+t = (C.c_ulonglong * 128)()
 stamped.flexnet_debug_critic_stamps(t)
 names = ["staging + barrier", "first-layer row, LayerNorm, a1, transpose store", "fc2 forward chain (64 MFMAs / tile)",
          "bias, q, TD error, dz2, transpose store", "da1 chain (64 MFMAs / tile)", "ReLU / LayerNorm backward, dz1 store",
-         "phase B: dW2 (64 MFMAs / tile)", "end-of-kernel fold"]
-tot = sum(t[k] for k in range(8))
-print(f"stamped build: {r['launch_us']:.1f} us for the four launches; block 0, wavefront 0: {tot} cycles")
+         "phase B: dW2 (64 MFMAs / tile)", "sums after the last tile", "wait for the block's other wavefronts", "end-of-kernel fold"]
+tot = [sum(t[16 * w + k] for k in range(10)) for w in range(8)]
+print(f"stamped build: {r['launch_us']:.1f} us for the launches; block 0, cycles per wavefront (0-7), summed over its tiles; total {tot}")
 for k, nm in enumerate(names):
-    print(f"  {nm:45s} {t[k]:8d} cycles  {100.0 * t[k] / max(tot, 1):5.1f} %")
+    print(f"  {nm:48s} " + " ".join(f"{t[16 * w + k]:7d}" for w in range(8)) + f"   {100.0 * t[k] / max(tot[0], 1):5.1f} % of wavefront 0")
 print("MFMA issue bound per chain: 5 tiles x 64 x 32 = 10240 cycles")
