@@ -338,7 +338,7 @@ class RolloutGraph:
         out = []
         while m > 0:
             if self.fused_burst:
-                k = min(m, self.BURST_MAX, self.buf.slabs - 1)
+                k = max(1, min(m, self.BURST_MAX, self.buf.slabs - 1))     # (a burst stays below the ring's size)
             else:
                 k = next((b for b in self.BURSTS if b <= m), 1)
             out.append(k)
