@@ -1392,7 +1392,7 @@ int flexenv_rollout_burst(FlexEnv* e, const void* actor, double* reward, uint8_t
     b.act_low = b.act_span = 0.0f;
     if (safety) {
         if (!safety->s_p || !safety->s_q || !safety->beta || !safety->adjusted || !safety->env_action ||
-            !(safety->act_high >= safety->act_low)) return FLEX_EINVAL;
+            !(safety->act_high >= safety->act_low) || p.act_dim != 4) return FLEX_EINVAL;      // (four controls per building)
         b.safety = 1; b.s_p = safety->s_p; b.s_q = safety->s_q; b.beta = safety->beta;
         b.v_min = safety->v_min; b.v_max = safety->v_max; b.rho = safety->penalty;
         b.adjusted = safety->adjusted; b.safe_env_action = safety->env_action;
