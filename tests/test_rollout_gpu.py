@@ -665,3 +665,32 @@ def test_safemaddpg_burst_equals_three_launches_per_step_bit_for_bit(N, monkeypa
     # the layer did act: the step's action differs from translate_action of the policy's own action somewhere
     own = 0.5 * (a.act_buf.clamp(0.0, 1.0) + 1.0)
     assert (a.burst_safe_env_act.view(N, 4, 5).transpose(1, 2).reshape(N * 5, 4) - own).abs().max().item() > 1e-3
+
+
+def test_burst_entry_refuses_what_it_cannot_run(monkeypatch):
+    """flexenv_rollout_burst's argument checks (include/flexenv.h): a burst as long as the ring, an env without the replay
+    sink, a safety block with another action width — FLEX_EINVAL, nothing launched, the state untouched."""
+    from safe_marl_amd import _lib
+    from safe_marl_amd.learner import RolloutGraph
+    tr = _trainer(64)
+    rg = RolloutGraph(tr.behaviour_net, tr.env, tr.replay_buffer)
+    assert rg.fused_burst
+    rg.start_episode(tr.env.reset())
+    rg.capture()
+    rg.run(5)
+    torch.cuda.synchronize()
+    cursor, calls = rg.buf.cursor.clone(), tr.env.calls
+    with pytest.raises(_lib.FlexLibraryError, match="flexenv_rollout_burst failed with code -22"):      # FLEX_EINVAL
+        rg.body(burst=rg.buf.slabs)                           # steps >= slabs
+    tr.env.calls = calls
+    tr.env.set_replay_sink(None, None, None, None, None)      # sink off
+    with pytest.raises(_lib.FlexLibraryError, match="code -22"):
+        rg.body(burst=4)
+    tr.env.calls = calls
+    rg._configure_env()                                       # sink back on: the next burst runs
+    torch.cuda.synchronize()
+    assert torch.equal(rg.buf.cursor, cursor)
+    before = rg.buf.k
+    rg.run(6)
+    torch.cuda.synchronize()
+    assert rg.buf.k == before + 6
