@@ -23,6 +23,7 @@
 #define FLEXENV_H
 
 #include <stdint.h>
+#include "flexnet.h"           /* FlexActorArgs: flexenv_rollout_burst runs the policy inside the environment's launch */
 
 #ifdef __cplusplus
 extern "C" {
@@ -220,7 +221,7 @@ typedef struct {
     float* env_action;         /* dev [N, 4 n_agents] out: what the step of the same launch reads */
     float act_low, act_high;
 } FlexBurstSafety;
-int flexenv_rollout_burst(FlexEnv* env, const void* actor /* const FlexActorArgs* */, double* reward, uint8_t* done,
+int flexenv_rollout_burst(FlexEnv* env, const FlexActorArgs* actor, double* reward, uint8_t* done,
                           double* info, uint8_t* failed, float* obs_ring, int32_t steps,
                           const FlexBurstSafety* safety /* NULL: plain MADDPG */, void* stream);
 int32_t flexenv_obs_size(const FlexEnv* env);    /* 6*history, env:71 */

@@ -1362,10 +1362,10 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     return FLEX_OK;
 }
 
-int flexenv_rollout_burst(FlexEnv* e, const void* actor, double* reward, uint8_t* done, double* info,
+int flexenv_rollout_burst(FlexEnv* e, const FlexActorArgs* actor, double* reward, uint8_t* done, double* info,
                           uint8_t* failed, float* obs_ring, int32_t steps, const FlexBurstSafety* safety, void* stream) {
     if (!e || !actor || !reward || !done || !obs_ring || steps < 1) return FLEX_EINVAL;
-    const FlexActorArgs& p = *static_cast<const FlexActorArgs*>(actor);
+    const FlexActorArgs& p = *actor;
     const int na = e->cfg.n_agents;
     // the configuration of the two-launch sink step (flexenv_step with FLEX_STEP_OBS_RING | FLEX_STEP_REPLAY_SINK behind
     // flexnet_actor_forward in ring mode), and the policy's tiles of a block = the block's sixteen environments
