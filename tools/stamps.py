@@ -6,7 +6,7 @@ import sys, os; sys.path.insert(0,'.')
 import numpy as np, torch, ctypes as C
 import safe_marl_amd
 from safe_marl_amd import _lib
-_lib.LIB_PATH = os.path.abspath('tools/libflexenv_hip_stamps.so')
+_lib.LIB_PATH = os.path.abspath(os.environ.get('FLEX_STAMPS_LIB', 'tools/libflexenv_hip_stamps.so'))
 from safe_marl_amd.network import create_network
 from safe_marl_amd.series import make_synthetic_series
 from safe_marl_amd.flex_env import VecFlexProvisionEnv
