@@ -103,7 +103,14 @@ class RolloutGraph:
         # outside them the pack kernel files the transition (three launches per step)
         self.sink = bool(self.ring_io and hasattr(env, "set_replay_sink") and n * a <= 32 and n * h <= 384
                          and getattr(env, "n_bus", 33) - 1 <= 32)
-        if self.sink:
+        # MATD3 / IDDPG with the one-launch action selection (`summed`): the same ring I/O and sink — policy kernel (slab at the
+        # cursor -> means, new hidden state), agent_sum_explore_kernel (-> the action the replay keeps, the env's action), env
+        # step (files the transition): three launches, no pack kernel, the observation written once (round 3)
+        self.summed_sink = bool(self.summed and self.cursor_stepped and hasattr(env, "set_obs_ring")
+                                and hasattr(env, "set_replay_sink") and n * a <= 32 and n * h <= 384
+                                and getattr(env, "n_bus", 33) - 1 <= 32 and h == 64 and o <= 144
+                                and os.environ.get("FLEX_SUMMED_SINK", "1") != "0")
+        if self.sink or self.summed_sink:
             self.act_buf = th.zeros(N * n, a, device=dev)
             self.hid_buf = th.zeros(N * n, h, device=dev)
             self.acc = th.zeros(N, 10, dtype=th.float64, device=dev)
@@ -132,7 +139,7 @@ class RolloutGraph:
             env.set_step_counter(None)                      # the env step sets cursor[0] itself in this mode
             env.set_obs_ring(buf.cursor[1:], N * n * o, buf.slabs)
             env.set_replay_sink(self.act_buf, self.hid_buf, buf.small_ring, buf.hid_ring, self.acc, cursor_out=buf.cursor[0:1],
-                                aux_counter=None if self._torch_noise else self.rng_state[1:2])
+                                aux_counter=None if (self._torch_noise or self.summed_sink) else self.rng_state[1:2])
         else:
             env.set_step_counter(buf.cursor[1:], buf.slabs)
             if self.ring_io:
@@ -160,7 +167,7 @@ class RolloutGraph:
 
     @property
     def sink_active(self):
-        return self.sink and self.fast
+        return (self.sink and self.fast) or self.summed_sink
 
     @property
     def fused_burst(self):
@@ -183,7 +190,8 @@ class RolloutGraph:
 
     @property
     def ring_active(self):
-        return self.ring_io and self.fast          # (tests switch `fast` off to run the general body on the same object)
+        # (tests switch `fast` off to run the general body on the same object)
+        return (self.ring_io and self.fast) or self.summed_sink
 
     @property
     def obs(self):
@@ -284,6 +292,20 @@ class RolloutGraph:
                 if not self.sink_active:
                     self._pack(action, hid)
                 return
+        if self.summed and self.summed_sink:
+            with th.no_grad():
+                buf = self.buf
+                out = fused_actor_forward(m.policy_dicts[0], buf.obs_ring[0].view(N, m.n_, m.obs_dim),
+                                          buf.hid_ring[0].view(N, m.n_, m.hid_dim), m.n_, m.args.agent_id,
+                                          ring_cursor=buf.cursor, obs_slab_stride=buf.obs_ring.stride(0),
+                                          hid_slab_stride=buf.hid_ring.stride(0), cursor_out=buf.cursor[1:],
+                                          out=dict(hidden_out=self.hid_buf))
+                if out is None:
+                    raise RuntimeError("the fused actor kernel declined a configuration RolloutGraph.summed_sink admitted")
+                summed_exploration(m, out[0].view(N, m.n_, m.act_dim), env_action=self.env_act_buf,
+                                   action_out=self.act_buf.view(N, m.n_, m.act_dim))
+                env.step(self.env_act_buf, fuse_obs=True, auto_reset=True, obs_ring=buf.obs_ring, replay_sink=True)
+            return
         if self.summed:
             with th.no_grad():
                 means, _, hid = m.policy(self.obs, last_hid=self.hid)
@@ -423,7 +445,7 @@ class RolloutGraph:
             self._hid.zero_()
             self.buf.begin_stream(first_obs)
         self._info_sum.zero_(); self._rew_sum.zero_(); self._fail_sum.zero_()
-        if self.sink:
+        if self.sink or self.summed_sink:
             self.acc.zero_()
 
 

@@ -233,7 +233,10 @@ def test_general_graph_body_follows_get_actions(alg, N):
         rg.capture()
     finally:
         del os.environ["FLEX_GRAPH_AUDIT"]
-    assert any("rollout_pack_kernel" in k for k in rg.audit) and any("flex_step_kernel" in k for k in rg.audit)
+    # round 3: the env step files the transition itself here too (three launches: policy, action selection, environment)
+    assert rg.summed_sink and rg.sink_active
+    assert not any("rollout_pack_kernel" in k for k in rg.audit) and any("flex_step_kernel" in k for k in rg.audit)
+    assert any("agent_sum_explore" in k for k in rg.audit) and any("actor_" in k for k in rg.audit)
     rg.start_episode(envs[0].reset())
     before = rg.obs.clone()
     want_info = torch.zeros_like(rg.info_sum)
