@@ -218,6 +218,9 @@ def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, m
            # policy + environment for a whole run of steps in ONE persistent launch (flexenv_rollout_burst; plain MADDPG)
            "rollout_burst_launch": bool(rg is not None and rg.fused_burst),
            "rollout_us_per_vector_step": None if rollout_us is None else round(rollout_us, 2),
+           # update events whose value sub-updates read Q'(s', pi(s')) filed once for the union of their windows
+           # (trainer.replay_event; chosen per event where the windows overlap enough — the reference's sample reuse)
+           "bootstrap_cached_events": int(getattr(trainer, "bootstrap_cached_events", 0)),
            "graphed_updates": sorted(trainer._update_graphs), "split_update_graphs": bool(world > 1 and trainer._update_graphs and
                                         not all(g.get("allreduce_in_graph") for g in trainer._update_graphs.values())),
            "allreduce_in_graph": bool(world > 1 and trainer._update_graphs and

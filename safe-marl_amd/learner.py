@@ -908,7 +908,10 @@ class MADDPG(Model):
     # (reward in both: unpack_data's batch-norm running statistics move on every get_loss call, model.py:308-323)
     graph_safe_updates = True       # trainer._graphed_sub_update: the gradient path uses no multi-block PyTorch reduction
     update_fields = {"policy": ("state", "reward", "last_hid"),
-                     "value": ("state", "action", "reward", "next_state", "done", "hid")}
+                     "value": ("state", "action", "reward", "next_state", "done", "hid"),
+                     # trainer.replay_event with the bootstrap values filed per transition first (round 3)
+                     "value_cached": ("state", "action", "reward", "done", "next_value"),
+                     "bootstrap": ("next_state", "hid")}
 
     def construct_model(self):
         self.construct_value_net()
@@ -983,6 +986,17 @@ class MADDPG(Model):
             restore_actions = restore_mask * actions
         return actions, restore_actions, log_prob_a, (means, log_stds), hiddens
 
+    bootstrap_from_batch = False     # set by trainer.replay_event while it captures / replays value sub-updates on filed values
+
+    def bootstrap_values(self, next_state, actions_avail, hids):
+        """Q'(s', pi(s')) [b, n] of maddpg.py:108-111: the next action from the behaviour policy (double_q) or the target
+        policy, valued by the target critic; no gradient (maddpg.py:110,115: .detach())."""
+        with th.no_grad():
+            _, next_actions, _, _, _ = self.get_actions(next_state, status="train", exploration=False,
+                                                        actions_avail=actions_avail, target=not self.args.double_q,
+                                                        last_hid=hids)
+            return self.target_net.value(next_state, next_actions).view(-1, self.n_)
+
     def get_loss(self, batch, need="both"):
         """maddpg.py:100-123: policy_loss = -Q(s, pi(s)).mean(); value_loss = (r + gamma (1-done) Q'(s', pi(s')) - Q(s,a))^2.mean().
 
@@ -1015,11 +1029,12 @@ class MADDPG(Model):
                     advantages = self.batchnorm(advantages)
                 policy_loss = mean_all(advantages, sign=-1.0)
         if need in ("both", "value"):
-            with th.no_grad():          # the bootstrap target carries no gradient (maddpg.py:110,115: .detach())
-                _, next_actions, _, _, _ = self.get_actions(next_state, status="train", exploration=False,
-                                                            actions_avail=actions_avail, target=not self.args.double_q,
-                                                            last_hid=hids)
-                next_values = self.target_net.value(next_state, next_actions).view(-1, self.n_)
+            if self.bootstrap_from_batch and need == "value":
+                # trainer.replay_event filed Q'(s', pi(s')) for this window already (bootstrap_values below, on the same
+                # networks: they do not change between the value sub-updates of one update event)
+                next_values = batch.next_value.view(-1, self.n_)
+            else:
+                next_values = self.bootstrap_values(next_state, actions_avail, hids)
             bn = self.batchnorm if self.args.reward_normalisation else None
             if fused_td:
                 # update batches: Q(s, a), the TD error and the critic's whole backward in one pass (nets._CriticTdLossFn)

@@ -74,6 +74,9 @@ class DeviceReplayBuffer:
         self.obs_ring = th.zeros(self.slabs, n_envs, no, dtype=th.float32, device=dev)
         self.hid_ring = th.zeros(self.slabs, n_envs, nh, dtype=th.float32, device=dev)
         self.small_ring = th.zeros(self.slabs, n_envs, self.small_w, dtype=th.float32, device=dev)
+        # bootstrap values r + gamma (1 - done) Q'(s', pi(s')) needs, per transition, filed by the trainer for the windows of
+        # ONE update event (trainer.replay_event: the networks behind them do not change between its value sub-updates)
+        self.nv_ring = th.zeros(self.slabs, n_envs, n_agents, dtype=th.float32, device=dev)
         # physical slab indices on the device (include/flexnet.h): [0] the slab the policy reads, [1] the slab being filled
         self.cursor = th.zeros(2, dtype=th.int64, device=dev)
         self.k = 0                   # host mirror of cursor[0]
@@ -93,7 +96,7 @@ class DeviceReplayBuffer:
     def release_slabs(self):
         """Back to the field-by-field mode (the graph rollout could not be captured): the rings and their bookkeeping go,
         ``add_batch`` allocates its own store on the next call.  Transitions the ring held are dropped."""
-        self.obs_ring = self.hid_ring = self.small_ring = self.cursor = None
+        self.obs_ring = self.hid_ring = self.small_ring = self.nv_ring = self.cursor = None
         self.k = self.first = 0
         self.gaps = []
         self.consts, self.const_shapes = {}, {}
@@ -201,12 +204,14 @@ class DeviceReplayBuffer:
         return {"state": ("obs_ring", 0, None, 0), "next_state": ("obs_ring", 0, None, 1),
                 "last_hid": ("hid_ring", 0, None, 0), "hid": ("hid_ring", 0, None, 1),
                 "action": ("small_ring", 0, na, 0), "reward": ("small_ring", na, n, 0),
-                "done": ("small_ring", na + n, 1, 0), "last_step": ("small_ring", na + n + 1, 1, 0)}[name]
+                "done": ("small_ring", na + n, 1, 0), "last_step": ("small_ring", na + n + 1, 1, 0),
+                "next_value": ("nv_ring", 0, None, 0)}[name]
 
     def field_shape(self, name):
         n = self.n_agents
         return {"state": (n, self.obs_dim), "next_state": (n, self.obs_dim), "last_hid": (n, self.hid_dim),
-                "hid": (n, self.hid_dim), "action": (n, self.act_dim), "reward": (n,), "done": (), "last_step": ()}[name]
+                "hid": (n, self.hid_dim), "action": (n, self.act_dim), "reward": (n,), "done": (), "last_step": (),
+                "next_value": (n, 1)}[name]
 
     STORED = ("state", "action", "reward", "next_state", "done", "last_step", "last_hid", "hid")
 
@@ -236,6 +241,25 @@ class DeviceReplayBuffer:
                 a.rows[j], a.width[j], a.src_stride[j], a.dst_stride[j] = c, width, stride, width
             a.n_jobs = len(chunk)
             _lib.check(_lib.load().flexnet_gather_rows(C.byref(a), stream), "flexnet_gather_rows")
+
+    def scatter(self, ring_name, src, slot, rows):
+        """The reverse of one gather job: rows of the contiguous [rows, width] tensor ``src`` into the ring's slots of the
+        global slot range [slot, slot + rows) (two pieces at the seam): one launch of flexnet_gather_rows."""
+        import ctypes as C
+        from . import _lib
+        ring = getattr(self, ring_name)
+        stride = ring.shape[2]
+        if not (src.is_contiguous() and src.dtype == th.float32 and src.numel() == rows * stride):
+            raise ValueError("scatter: src must be a contiguous fp32 [rows, row width of the ring] tensor")
+        a = _lib.FlexGatherArgs()
+        done_rows = 0
+        for j, (p, c) in enumerate(self.segments(slot, rows)):
+            a.src[j], a.dst[j] = src.data_ptr() + 4 * done_rows * stride, ring.data_ptr() + 4 * p * stride
+            a.rows[j], a.width[j], a.src_stride[j], a.dst_stride[j] = c, stride, stride, stride
+            done_rows += c
+            a.n_jobs = j + 1
+        _lib.check(_lib.load().flexnet_gather_rows(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_gather_rows")
 
     def _logical_to_slot(self, index):
         """Global slot of logical transition ``index`` (0 = oldest), skipping gaps."""

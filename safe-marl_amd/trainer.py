@@ -51,6 +51,11 @@ class PGTrainer(object):
         # the replay's first GEMM from 31 to ~48 us — and the loop is 4-8 % SLOWER than gather-then-replay, so it is off
         # unless asked for (FLEX_PIPELINE_UPDATES=1); bit-identical either way (tests/test_update_graph_gpu.py)
         self.pipeline_updates = os.environ.get("FLEX_PIPELINE_UPDATES") == "1"
+        # replay_event: bootstrap values filed once per update event where the windows overlap enough (FLEX_BOOTSTRAP_CACHE=0: never)
+        self.cache_bootstrap = os.environ.get("FLEX_BOOTSTRAP_CACHE", "1") != "0"
+        self._bootstrap_graph = None
+        self._cached_graphs = {}
+        self.bootstrap_cached_events = 0
         # more than one rank: first try to capture a sub-update as ONE graph with the gradient all-reduce inside it (RCCL
         # collectives can be stream-captured: ProcessGroupNCCL joins its stream to the capture and does not hand captured
         # work to its watchdog); if that capture fails (gloo: a host round trip; or an RCCL build that refuses) the region
@@ -124,16 +129,25 @@ class PGTrainer(object):
             return None
         bs = self.effective_batch_size()
         store = self._update_graphs if slot == 0 else self._update_graphs_alt
-        g = store.get(which)
+        if which == "value_cached":                   # (kept apart: _update_graphs lists the sub-updates of model.py:47-50)
+            store = self._cached_graphs
+            which_key = (which, slot)
+        else:
+            which_key = which
+        g = store.get(which_key)
         if g is None or g["bs"] != bs or g["buf"] is not buf:
             try:
                 g = self._capture_sub_update(which, bs)
             except Exception as exc:                  # capture not possible here: stay eager from now on
                 import warnings
+                if which == "value_cached":           # ... or just without the filed bootstrap values
+                    warnings.warn(f"capture of the value sub-update on filed bootstrap values failed ({exc}); computing them per sub-update")
+                    self.cache_bootstrap = False
+                    return None
                 warnings.warn(f"sub-update graph capture failed ({exc}); using eager sub-updates")
                 self.graph_updates = False
                 return None
-            store[which] = g
+            store[which_key] = g
         return g
 
     def _replay(self, g, stat):
@@ -161,36 +175,66 @@ class PGTrainer(object):
 
     def replay_event(self, stat, n_value, n_policy):
         """One update event of model.py:47-50 — ``n_value`` value sub-updates, then ``n_policy`` policy sub-updates.
-        With graphed updates the event is software-pipelined: the window of sub-update j + 1 is sampled and gathered into
-        the OTHER static batch of its kind on a side stream while the graph of sub-update j runs, so the HBM-bound gather
-        (50 us of a 570 us value step at 4096 envs) hides in the bubbles of the replay instead of preceding it.  Windows
-        are drawn in the same order from the same NumPy stream as by the one-at-a-time calls, the gathered data and the
-        replayed graphs are the same: the result is bit-identical (tests/test_update_graph_gpu.py)."""
-        kinds = ["value"] * int(n_value) + ["policy"] * int(n_policy)
-        if not self.pipeline_updates or len(kinds) < 2 or self._ensure_graph(kinds[0]) is None:
+
+        Round 3, bootstrap values filed once per event: Q'(s', pi(s')) is 43 % of a value sub-update, and the networks behind
+        it (behaviour or target policy, target critic) do not change before the event's policy sub-update.  The windows of the
+        value sub-updates are drawn up front (same NumPy draws, same order), the UNION of their transitions is valued in
+        passes of one batch into the ring's ``nv_ring`` (a graph of MADDPG.bootstrap_values, the very lines the loss runs), and
+        the value sub-updates read their window's values from there ("value_cached" graphs).  At the reference's sample reuse
+        (32 slabs per window in a ring of 192) ten windows overlap to ~6 passes; at batch_scale = N / 4 they hardly overlap, the
+        passes would outnumber what they save, and the event runs as before.  Same values either way — same kernels on the
+        same rows — so the choice is made per event (tests/test_update_graph_gpu.py).
+
+        With FLEX_PIPELINE_UPDATES=1 the event is also software-pipelined: the window of sub-update j + 1 is gathered into
+        the OTHER static batch of its kind on a side stream while the graph of sub-update j runs (bit-identical; measured
+        4-8 % slower than gather-then-replay, hence off by default)."""
+        n_value, n_policy = int(n_value), int(n_policy)
+        kinds = ["value"] * n_value + ["policy"] * n_policy
+        if not kinds or self._ensure_graph(kinds[0]) is None:
             for which in kinds:
                 (self.value_replay_process if which == "value" else self.policy_replay_process)(stat)
             return
         buf = self.replay_buffer
+        bs_all = self.effective_batch_size()
+        starts, chunks, boot = {}, [], None
+        net = self.behaviour_net
+        if (self.cache_bootstrap and n_value >= 3 and getattr(buf, "nv_ring", None) is not None
+                and "value_cached" in (getattr(net, "update_fields", None) or {}) and hasattr(net, "bootstrap_values")):
+            vstarts = [buf.sample_slot(bs_all) for _ in range(n_value)]
+            starts = dict(enumerate(vstarts))
+            chunks = self.bootstrap_chunks(vstarts, bs_all)
+            if len(chunks) + 1 < n_value:
+                boot = self._ensure_bootstrap(bs_all)
+                if boot is not None and (self._ensure_graph("value_cached") is None or
+                                         (self.pipeline_updates and self._ensure_graph("value_cached", 1) is None)):
+                    boot = None
+        if boot is not None:
+            kinds = ["value_cached"] * n_value + ["policy"] * n_policy
+            for c in chunks:                            # the union of the value windows, valued once
+                buf.gather(boot["plan"], c)
+                boot["graph"].replay()
+                buf.scatter("nv_ring", boot["nv"], c, bs_all)
+            self.bootstrap_cached_events += 1
+        if not self.pipeline_updates or len(kinds) < 2:
+            return self._replay_event_plain(stat, kinds, starts)
         seen, graphs = {}, []
         for which in kinds:                             # every (kind, slot) graph exists before the pipeline starts
             slot = seen.get(which, 0) % 2
             seen[which] = seen.get(which, 0) + 1
             g = self._ensure_graph(which, slot)
             if g is None:                               # capture failed half-way: plain calls for the whole event
-                for w in kinds:
-                    (self.value_replay_process if w == "value" else self.policy_replay_process)(stat)
-                return
+                return self._replay_event_plain(stat, kinds, starts)
             graphs.append(g)
         main = th.cuda.current_stream()
         if self._side_stream is None:
             self._side_stream = th.cuda.Stream()
         side = self._side_stream
-        side.wait_stream(main)                          # the ring writes of the rollout so far
+        side.wait_stream(main)                          # the ring writes of the rollout so far (and the filed values)
 
         def launch_gather(j):
             g = graphs[j]
-            slot_start = buf.sample_slot(g["bs"])       # drawn in sub-update order, like the one-at-a-time calls
+            # drawn in sub-update order, like the one-at-a-time calls (the value windows possibly up front, above)
+            slot_start = starts[j] if j in starts else buf.sample_slot(g["bs"])
             with th.cuda.stream(side):
                 if g.get("free") is not None:
                     side.wait_event(g["free"])          # the last replay that read this static batch has finished
@@ -207,6 +251,55 @@ class PGTrainer(object):
             g["free"] = th.cuda.Event()
             g["free"].record(main)
             ready = nxt
+
+    def _replay_event_plain(self, stat, kinds, starts):
+        """Gather, then replay, one sub-update at a time; ``starts``: windows already drawn (index in ``kinds`` -> slot)."""
+        buf = self.replay_buffer
+        for j, which in enumerate(kinds):
+            g = self._ensure_graph(which)
+            if g is None:                               # (graphs went away mid-event: the eager step on the same window)
+                need = "value" if which == "value_cached" else which
+                slot = starts[j] if j in starts else buf.sample_slot(self.effective_batch_size())
+                self._sub_update(need, stat, buf.slab_window(slot, self.effective_batch_size()))
+                continue
+            buf.gather(g["plan"], starts[j] if j in starts else buf.sample_slot(g["bs"]))
+            self._replay(g, stat)
+
+    @staticmethod
+    def bootstrap_chunks(starts, bs):
+        """Starts of the passes of ``bs`` consecutive transitions that cover the union of the windows [s, s + bs): the
+        intervals merged, each cut from its left end, its last pass flush with its right end."""
+        chunks = []
+        ivals = sorted((int(s), int(s) + bs) for s in starts)
+        a, b = ivals[0]
+        merged = []
+        for x, y in ivals[1:]:
+            if x <= b:
+                b = max(b, y)
+            else:
+                merged.append((a, b))
+                a, b = x, y
+        merged.append((a, b))
+        for a, b in merged:
+            c = a
+            while c + bs < b:
+                chunks.append(c)
+                c += bs
+            chunks.append(b - bs)
+        return chunks
+
+    def _ensure_bootstrap(self, bs):
+        g = self._bootstrap_graph
+        if g is None or g["bs"] != bs or g["buf"] is not self.replay_buffer:
+            try:
+                g = self._capture_bootstrap(bs)
+            except Exception as exc:
+                import warnings
+                warnings.warn(f"bootstrap-value graph capture failed ({exc}); value sub-updates compute their own")
+                self.cache_bootstrap = False
+                return None
+            self._bootstrap_graph = g
+        return g
 
     def _static_batch(self, which, bs):
         """Static tensors a captured sub-update reads, and the gather plan that refreshes them.  Every observation sits
@@ -241,15 +334,55 @@ class PGTrainer(object):
                 shape = buf.field_shape(k)
                 fields[k] = th.zeros((1,) + tuple(1 for _ in shape), device=dev).expand((bs,) + shape)
         for k, c in buf.consts.items():
+            if k in fields:                           # (next_value: a constant of the ring, a gathered field of value_cached)
+                continue
             shape = buf.const_shapes.get(k, ())
             fields[k] = th.full((1,) + tuple(1 for _ in shape), float(c), device=dev).expand((bs,) + tuple(shape))
             fields[k]._flex_const = float(c)
         return fields, plan
 
+    def _capture_bootstrap(self, bs):
+        """The graph that files Q'(s', pi(s')) for ``bs`` consecutive transitions: next observations and hidden states of the
+        window gathered into a static batch, MADDPG.bootstrap_values on it (the very lines the value loss runs), the result
+        left in a static [bs, n] tensor that replay_event scatters into the ring's ``nv_ring``."""
+        from .replay_buffer import Transition
+        buf = self.replay_buffer
+        net = self.behaviour_net
+        fields, plan = self._static_batch("bootstrap", bs)
+        buf.gather(plan, buf.warmup_slot(bs + buf.n_envs))
+        batch = Transition(**fields)
+        nv = th.zeros(bs, buf.n_agents, dtype=th.float32, device=self.device)
+
+        def body():
+            nv.copy_(net.bootstrap_values(batch.next_state, batch.action_avail, batch.hid))
+
+        side = th.cuda.Stream()
+        side.wait_stream(th.cuda.current_stream())
+        with th.cuda.stream(side):
+            for _ in range(2):
+                body()
+        th.cuda.current_stream().wait_stream(side)
+        graph = th.cuda.CUDAGraph()
+        with graph_capture(graph):
+            body()
+        return dict(graph=graph, plan=plan, bs=bs, buf=buf, batch=batch, nv=nv)
+
     def _capture_sub_update(self, which, bs):
         from .replay_buffer import Transition
         buf = self.replay_buffer
-        fields, plan = self._static_batch(which, bs)
+        # "value_cached": the value sub-update on bootstrap values filed by replay_event (MADDPG.bootstrap_from_batch)
+        kind, cached = which, which == "value_cached"
+        which = "value" if cached else which
+        self.behaviour_net.bootstrap_from_batch = cached
+        try:
+            return self._capture_sub_update_body(kind, which, bs)
+        finally:
+            self.behaviour_net.bootstrap_from_batch = False
+
+    def _capture_sub_update_body(self, kind, which, bs):
+        from .replay_buffer import Transition
+        buf = self.replay_buffer
+        fields, plan = self._static_batch(kind, bs)
         buf.gather(plan, buf.warmup_slot(bs + buf.n_envs))  # real transitions for the warm-up steps: a window whose
         #                          next_state rows (N slots further on) exist too; no draw from the NumPy stream
         batch = Transition(**fields)
@@ -264,7 +397,7 @@ class PGTrainer(object):
         if os.environ.get("FLEX_GRAPH_AUDIT") == "1":     # the body about to be captured launches no ATen multi-block reduction
             from .util import audit_graph_body
             self.graph_audit = getattr(self, "graph_audit", {})
-            self.graph_audit[which] = audit_graph_body(lambda: self._sub_update(which, {}, batch, fresh_leaves=True))
+            self.graph_audit[kind] = audit_graph_body(lambda: self._sub_update(which, {}, batch, fresh_leaves=True))
         flat = None
         if self.world > 1:
             flat = th.zeros(sum(p.numel() for p in opt.param_groups[0]["params"]), dtype=th.float32, device=self.device)

@@ -216,3 +216,41 @@ def test_value_steps_with_the_td_error_formed_in_the_backward_track_the_sequence
         sa, sb = oa[k]["square_avg"], ob[k]["square_avg"]
         assert (sa - sb).abs().max().item() <= 1e-3 * sb.abs().max().item() + 1e-12, k
     assert type(a.behaviour_net)._critic_td_loss is learner._maddpg_critic_td_loss
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_bootstrap_values_filed_once_per_event_change_nothing(pipelined):
+    """Round 3, trainer.replay_event at the reference's sample reuse (batch = 32 x n_envs transitions = 32 slabs of a ring
+    that holds 95): the windows of the ten value sub-updates are drawn up front, the union of their transitions gets its
+    Q'(s', pi(s')) in a few passes of one batch (a graph of MADDPG.bootstrap_values) into the replay's nv_ring, and the
+    value sub-updates read them from there — against the same trainer computing them inside every sub-update: same windows,
+    same kernels on the same rows: weights, optimiser state and statistics bit-identical over three events; and the cached
+    form really ran (fewer passes than sub-updates), while at the default batch (8 slabs per window) it does not."""
+    from safe_marl_amd.trainer import PGTrainer
+    assert PGTrainer.bootstrap_chunks([0, 10, 100, 105], 20) == [0, 10, 100, 105]
+    assert PGTrainer.bootstrap_chunks([50, 0, 10, 95], 40) == [0, 40, 50, 95]           # [0, 90) in three passes, [95, 135)
+    a, b = _trainer(True, 1024), _trainer(True, 1024)
+    for tr in (a, b):
+        tr.batch_scale = 1024
+        tr.pipeline_updates = pipelined
+    b.cache_bootstrap = False
+    for ev in range(3):
+        stats = []
+        for tr in (a, b):
+            np.random.seed(70 + ev)
+            st = {}
+            tr.replay_event(st, 10, 1)
+            torch.cuda.synchronize()
+            stats.append({k: float(v) for k, v in st.items()})
+        assert stats[0] == stats[1], (ev, stats)
+        for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
+            assert torch.equal(va, vb), (ev, ka)
+        for pa, pb in zip(a.value_optimizer.param_groups[0]["params"], b.value_optimizer.param_groups[0]["params"]):
+            assert torch.equal(a.value_optimizer.state[pa]["square_avg"], b.value_optimizer.state[pb]["square_avg"])
+    assert a.bootstrap_cached_events == 3 and b.bootstrap_cached_events == 0
+    assert sorted(a._update_graphs) == ["policy", "value"]                       # (the cached form is kept apart)
+    c = _trainer(True, 1024)                                                     # default batch: windows hardly overlap
+    np.random.seed(1)
+    c.replay_event({}, 10, 1)
+    torch.cuda.synchronize()
+    assert c.bootstrap_cached_events == 0
