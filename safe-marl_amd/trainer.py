@@ -55,6 +55,7 @@ class PGTrainer(object):
         self.cache_bootstrap = os.environ.get("FLEX_BOOTSTRAP_CACHE", "1") != "0"
         self._bootstrap_graph = None
         self._cached_graphs = {}
+        self._cached_ready = False
         self.bootstrap_cached_events = 0
         # more than one rank: first try to capture a sub-update as ONE graph with the gradient all-reduce inside it (RCCL
         # collectives can be stream-captured: ProcessGroupNCCL joins its stream to the capture and does not hand captured
@@ -198,8 +199,18 @@ class PGTrainer(object):
         bs_all = self.effective_batch_size()
         starts, chunks, boot = {}, [], None
         net = self.behaviour_net
-        if (self.cache_bootstrap and n_value >= 3 and getattr(buf, "nv_ring", None) is not None
-                and "value_cached" in (getattr(net, "update_fields", None) or {}) and hasattr(net, "bootstrap_values")):
+        eligible = (self.cache_bootstrap and n_value >= 3 and getattr(buf, "nv_ring", None) is not None
+                    and "value_cached" in (getattr(net, "update_fields", None) or {}) and hasattr(net, "bootstrap_values"))
+        if eligible and self.world > 1 and not self._cached_ready:
+            # more than one rank: a capture's warm-up steps all-reduce, so every rank captures the cached form at the same
+            # point — its first eligible event — whether or not ITS windows overlap enough this time
+            self._cached_ready = True
+            ok = self._ensure_graph("value_cached") is not None and self._ensure_bootstrap(bs_all) is not None
+            if ok and self.pipeline_updates:
+                ok = self._ensure_graph("value_cached", 1) is not None
+            if not ok:
+                self.cache_bootstrap = eligible = False
+        if eligible:
             vstarts = [buf.sample_slot(bs_all) for _ in range(n_value)]
             starts = dict(enumerate(vstarts))
             chunks = self.bootstrap_chunks(vstarts, bs_all)
