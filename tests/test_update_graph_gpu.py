@@ -218,22 +218,26 @@ def test_value_steps_with_the_td_error_formed_in_the_backward_track_the_sequence
     assert type(a.behaviour_net)._critic_td_loss is learner._maddpg_critic_td_loss
 
 
-@pytest.mark.parametrize("pipelined", [False, True])
-def test_bootstrap_values_filed_once_per_event_change_nothing(pipelined):
+@pytest.mark.parametrize("pipelined,episodes", [(False, 1), (True, 1), (False, 3)])
+def test_bootstrap_values_filed_once_per_event_change_nothing(pipelined, episodes):
     """Round 3, trainer.replay_event at the reference's sample reuse (batch = 32 x n_envs transitions = 32 slabs of a ring
     that holds 95): the windows of the ten value sub-updates are drawn up front, the union of their transitions gets its
     Q'(s', pi(s')) in a few passes of one batch (a graph of MADDPG.bootstrap_values) into the replay's nv_ring, and the
     value sub-updates read them from there — against the same trainer computing them inside every sub-update: same windows,
-    same kernels on the same rows: weights, optimiser state and statistics bit-identical over three events; and the cached
+    same kernels on the same rows: weights, optimiser state and statistics bit-identical over three events (also with the ring
+    wrapped, where passes and windows lie astride its seam); and the cached
     form really ran (fewer passes than sub-updates), while at the default batch (8 slabs per window) it does not."""
     from safe_marl_amd.trainer import PGTrainer
     assert PGTrainer.bootstrap_chunks([0, 10, 100, 105], 20) == [0, 10, 100, 105]
     assert PGTrainer.bootstrap_chunks([50, 0, 10, 95], 40) == [0, 40, 50, 95]           # [0, 90) in three passes, [95, 135)
     a, b = _trainer(True, 1024), _trainer(True, 1024)
     for tr in (a, b):
+        for _ in range(episodes - 1):                 # three episodes = 285 slabs into a ring of 192: windows astride its seam
+            tr.behaviour_net.train_process({}, tr)
         tr.batch_scale = 1024
         tr.pipeline_updates = pipelined
     b.cache_bootstrap = False
+    assert (a.replay_buffer.k > a.replay_buffer.slabs) == (episodes == 3)
     for ev in range(3):
         stats = []
         for tr in (a, b):
