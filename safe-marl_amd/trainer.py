@@ -201,9 +201,11 @@ class PGTrainer(object):
         net = self.behaviour_net
         eligible = (self.cache_bootstrap and n_value >= 3 and getattr(buf, "nv_ring", None) is not None
                     and "value_cached" in (getattr(net, "update_fields", None) or {}) and hasattr(net, "bootstrap_values"))
-        if eligible and self.world > 1 and not self._cached_ready:
-            # more than one rank: a capture's warm-up steps all-reduce, so every rank captures the cached form at the same
-            # point — its first eligible event — whether or not ITS windows overlap enough this time
+        if eligible and not self._cached_ready:
+            # The cached form is captured at the FIRST eligible event, whether or not its windows overlap enough: a capture
+            # at first use would land in the middle of somebody's timed region (what round 2's config-4 figure suffered
+            # from), and with more than one rank a capture's warm-up steps all-reduce, so every rank must capture at the
+            # same point.
             self._cached_ready = True
             ok = self._ensure_graph("value_cached") is not None and self._ensure_bootstrap(bs_all) is not None
             if ok and self.pipeline_updates:

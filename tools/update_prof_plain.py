@@ -41,3 +41,23 @@ for which in ("value", "policy"):
         fn(st)
     torch.cuda.synchronize()
     print(which, "sub-update", (time.perf_counter() - t) / 20 * 1e3, "ms")
+
+# EVENTS=n [BATCH_DIV=d]: n whole update events (ten value sub-updates + one policy sub-update, model.py:47-50) at
+# batch_scale = N / d through trainer.replay_event — with d = 1 (the reference's sample reuse) the bootstrap values are filed
+# once per event for the union of the windows (FLEX_BOOTSTRAP_CACHE=0: per sub-update)
+if os.environ.get("EVENTS"):
+    import numpy as np
+    tr.batch_scale = max(1, N // int(os.environ.get("BATCH_DIV", "1")))
+    for _ in range(int(os.environ.get("FILL_EPISODES", "1"))):
+        tr.behaviour_net.train_process(st, tr)
+    np.random.seed(0)
+    for _ in range(2):
+        tr.replay_event(st, 10, 1)
+    torch.cuda.synchronize()
+    n_ev = int(os.environ["EVENTS"])
+    t = time.perf_counter()
+    for _ in range(n_ev):
+        tr.replay_event(st, 10, 1)
+    torch.cuda.synchronize()
+    print(f"update event at batch {tr.effective_batch_size()}: {(time.perf_counter() - t) / n_ev * 1e3:.3f} ms "
+          f"({tr.bootstrap_cached_events} of {n_ev + 2} events on filed bootstrap values)")
