@@ -987,6 +987,7 @@ class MADDPG(Model):
         return actions, restore_actions, log_prob_a, (means, log_stds), hiddens
 
     bootstrap_from_batch = False     # set by trainer.replay_event while it captures / replays value sub-updates on filed values
+    bootstrap_cacheable = True       # get_loss below honours bootstrap_from_batch (a subclass with its own get_loss says False)
 
     def bootstrap_values(self, next_state, actions_avail, hids):
         """Q'(s', pi(s')) [b, n] of maddpg.py:108-111: the next action from the behaviour policy (double_q) or the target
@@ -1174,6 +1175,7 @@ class MATD3(MADDPG):
     a trailing 0/1 input flag (matd3.py:64-67), clipped-double-Q target min(Q1', Q2') (matd3.py:139-140) and a
     value loss averaged over the twins (matd3.py:148).  Bug-compatible with the reference's action selection, which
     sums the policy means over the AGENT axis before sampling (matd3.py:92-97)."""
+    bootstrap_cacheable = False      # own get_loss (min of twins, target-smoothing noise drawn inside): values are per sub-update
 
     # since round 2 the GPU path of both losses reduces only through this project's fixed-order kernels (twin critic
     # nodes, flexnet_td_loss, flexnet_scaled_sum, pointwise agent sums): sub-updates replay as HIP graphs like MADDPG's

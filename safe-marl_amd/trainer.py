@@ -200,7 +200,8 @@ class PGTrainer(object):
         starts, chunks, boot = {}, [], None
         net = self.behaviour_net
         eligible = (self.cache_bootstrap and n_value >= 3 and getattr(buf, "nv_ring", None) is not None
-                    and "value_cached" in (getattr(net, "update_fields", None) or {}) and hasattr(net, "bootstrap_values"))
+                    and "value_cached" in (getattr(net, "update_fields", None) or {}) and hasattr(net, "bootstrap_values")
+                    and getattr(net, "bootstrap_cacheable", False) and getattr(net, "target_net", None) is not None)
         if eligible and not self._cached_ready:
             # The cached form is captured at the FIRST eligible event, whether or not its windows overlap enough: a capture
             # at first use would land in the middle of somebody's timed region (what round 2's config-4 figure suffered

@@ -218,8 +218,9 @@ def test_value_steps_with_the_td_error_formed_in_the_backward_track_the_sequence
     assert type(a.behaviour_net)._critic_td_loss is learner._maddpg_critic_td_loss
 
 
-@pytest.mark.parametrize("pipelined,episodes", [(False, 1), (True, 1), (False, 3)])
-def test_bootstrap_values_filed_once_per_event_change_nothing(pipelined, episodes):
+@pytest.mark.parametrize("pipelined,episodes,alg", [(False, 1, "maddpg"), (True, 1, "maddpg"), (False, 3, "maddpg"),
+                                                    (False, 1, "iddpg")])
+def test_bootstrap_values_filed_once_per_event_change_nothing(pipelined, episodes, alg):
     """Round 3, trainer.replay_event at the reference's sample reuse (batch = 32 x n_envs transitions = 32 slabs of a ring
     that holds 95): the windows of the ten value sub-updates are drawn up front, the union of their transitions gets its
     Q'(s', pi(s')) in a few passes of one batch (a graph of MADDPG.bootstrap_values) into the replay's nv_ring, and the
@@ -230,7 +231,7 @@ def test_bootstrap_values_filed_once_per_event_change_nothing(pipelined, episode
     from safe_marl_amd.trainer import PGTrainer
     assert PGTrainer.bootstrap_chunks([0, 10, 100, 105], 20) == [0, 10, 100, 105]
     assert PGTrainer.bootstrap_chunks([50, 0, 10, 95], 40) == [0, 40, 50, 95]           # [0, 90) in three passes, [95, 135)
-    a, b = _trainer(True, 1024), _trainer(True, 1024)
+    a, b = _trainer(True, 1024, alg), _trainer(True, 1024, alg)
     for tr in (a, b):
         for _ in range(episodes - 1):                 # three episodes = 285 slabs into a ring of 192: windows astride its seam
             tr.behaviour_net.train_process({}, tr)
@@ -258,3 +259,9 @@ def test_bootstrap_values_filed_once_per_event_change_nothing(pipelined, episode
     c.replay_event({}, 10, 1)
     torch.cuda.synchronize()
     assert c.bootstrap_cached_events == 0
+    # MATD3's value loss has its own get_loss (min of twins, target-smoothing noise drawn inside): never on filed values
+    m = _trainer(True, 1024, "matd3")
+    m.batch_scale = 1024
+    m.replay_event({}, 10, 1)
+    torch.cuda.synchronize()
+    assert m.bootstrap_cached_events == 0 and not m._cached_graphs
