@@ -53,7 +53,7 @@ class PGTrainer(object):
         self.pipeline_updates = os.environ.get("FLEX_PIPELINE_UPDATES") == "1"
         # replay_event: bootstrap values filed once per update event where the windows overlap enough (FLEX_BOOTSTRAP_CACHE=0: never)
         self.cache_bootstrap = os.environ.get("FLEX_BOOTSTRAP_CACHE", "1") != "0"
-        self._bootstrap_graph = None
+        self._bootstrap_graphs = {}                    # pass size -> graph of MADDPG.bootstrap_values on a static batch
         self._cached_graphs = {}
         self._cached_ready = False
         self.bootstrap_cached_events = 0
@@ -199,6 +199,10 @@ class PGTrainer(object):
         bs_all = self.effective_batch_size()
         starts, chunks, boot = {}, [], None
         net = self.behaviour_net
+        # Passes of ONE size, the sub-update's batch: quarter passes for what an interval leaves over were tried (12.4 -> 12.0
+        # ms per event at the reference's reuse) and given up — at another row count the library picks another first-layer
+        # GEMM kernel, the values differ in the seventh digit, and the event is no longer bit-identical to the plain one.
+        small = 0
         eligible = (self.cache_bootstrap and n_value >= 3 and getattr(buf, "nv_ring", None) is not None
                     and "value_cached" in (getattr(net, "update_fields", None) or {}) and hasattr(net, "bootstrap_values")
                     and getattr(net, "bootstrap_cacheable", False) and getattr(net, "target_net", None) is not None)
@@ -209,6 +213,8 @@ class PGTrainer(object):
             # same point.
             self._cached_ready = True
             ok = self._ensure_graph("value_cached") is not None and self._ensure_bootstrap(bs_all) is not None
+            if ok and small:
+                ok = self._ensure_bootstrap(small) is not None
             if ok and self.pipeline_updates:
                 ok = self._ensure_graph("value_cached", 1) is not None
             if not ok:
@@ -216,18 +222,22 @@ class PGTrainer(object):
         if eligible:
             vstarts = [buf.sample_slot(bs_all) for _ in range(n_value)]
             starts = dict(enumerate(vstarts))
-            chunks = self.bootstrap_chunks(vstarts, bs_all)
-            if len(chunks) + 1 < n_value:
-                boot = self._ensure_bootstrap(bs_all)
-                if boot is not None and (self._ensure_graph("value_cached") is None or
-                                         (self.pipeline_updates and self._ensure_graph("value_cached", 1) is None)):
+            chunks = self.bootstrap_chunks(vstarts, bs_all, small)
+            # in units of whole passes (a quarter pass costs more than a quarter: gather, scatter, launch floor); a pass costs
+            # about what a value sub-update saves, so the cached form has to save at least two of them to be chosen
+            cost = sum(size / float(bs_all) + (0.1 if size != bs_all else 0.0) for _, size in chunks)
+            if cost + 2 < n_value:
+                boot = {size: self._ensure_bootstrap(size) for size in {size for _, size in chunks}}
+                if (any(g is None for g in boot.values()) or self._ensure_graph("value_cached") is None or
+                        (self.pipeline_updates and self._ensure_graph("value_cached", 1) is None)):
                     boot = None
         if boot is not None:
             kinds = ["value_cached"] * n_value + ["policy"] * n_policy
-            for c in chunks:                            # the union of the value windows, valued once
-                buf.gather(boot["plan"], c)
-                boot["graph"].replay()
-                buf.scatter("nv_ring", boot["nv"], c, bs_all)
+            for c, size in chunks:                      # the union of the value windows, valued once
+                g = boot[size]
+                buf.gather(g["plan"], c)
+                g["graph"].replay()
+                buf.scatter("nv_ring", g["nv"], c, size)
             self.bootstrap_cached_events += 1
         if not self.pipeline_updates or len(kinds) < 2:
             return self._replay_event_plain(stat, kinds, starts)
@@ -280,13 +290,13 @@ class PGTrainer(object):
             self._replay(g, stat)
 
     @staticmethod
-    def bootstrap_chunks(starts, bs):
-        """Starts of the passes of ``bs`` consecutive transitions that cover the union of the windows [s, s + bs): the
-        intervals merged, each cut from its left end, its last pass flush with its right end."""
-        chunks = []
+    def bootstrap_chunks(starts, bs, small=0):
+        """Passes that cover the union of the windows [s, s + bs): [(start, size)] with size = ``bs`` or ``small`` (a divisor of
+        bs; 0 = none).  The windows are merged into intervals; an interval is cut into whole passes from its left end, what
+        is left over (< bs) into ``small`` passes, the last pass flush with the interval's right end."""
         ivals = sorted((int(s), int(s) + bs) for s in starts)
-        a, b = ivals[0]
         merged = []
+        a, b = ivals[0]
         for x, y in ivals[1:]:
             if x <= b:
                 b = max(b, y)
@@ -294,17 +304,25 @@ class PGTrainer(object):
                 merged.append((a, b))
                 a, b = x, y
         merged.append((a, b))
+        chunks = []
         for a, b in merged:
             c = a
-            while c + bs < b:
-                chunks.append(c)
+            while c + bs <= b:
+                chunks.append((c, bs))
                 c += bs
-            chunks.append(b - bs)
+            if c < b:
+                if small and b - c <= bs - small:             # (otherwise the small passes would cover a whole one anyway)
+                    while c + small < b:
+                        chunks.append((c, small))
+                        c += small
+                    chunks.append((b - small, small))
+                else:
+                    chunks.append((b - bs, bs))
         return chunks
 
     def _ensure_bootstrap(self, bs):
-        g = self._bootstrap_graph
-        if g is None or g["bs"] != bs or g["buf"] is not self.replay_buffer:
+        g = self._bootstrap_graphs.get(bs)
+        if g is None or g["buf"] is not self.replay_buffer:
             try:
                 g = self._capture_bootstrap(bs)
             except Exception as exc:
@@ -312,7 +330,7 @@ class PGTrainer(object):
                 warnings.warn(f"bootstrap-value graph capture failed ({exc}); value sub-updates compute their own")
                 self.cache_bootstrap = False
                 return None
-            self._bootstrap_graph = g
+            self._bootstrap_graphs[bs] = g
         return g
 
     def _static_batch(self, which, bs):

@@ -146,7 +146,8 @@ def test_pipelined_update_event_equals_one_at_a_time_sub_updates():
         assert stats[0] == stats[1], (ev, stats)
         for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
             assert torch.equal(va, vb), (ev, ka)
-    assert set(a._update_graphs_alt) == {"value"} and not b._update_graphs_alt      # the double buffer really was used
+    # the double buffer really was used (of the plain value sub-update, or of its form on filed bootstrap values)
+    assert (set(a._update_graphs_alt) == {"value"} or ("value_cached", 1) in a._cached_graphs) and not b._update_graphs_alt
 
 
 @pytest.mark.parametrize("alg", ["matd3", "iddpg"])
@@ -229,8 +230,10 @@ def test_bootstrap_values_filed_once_per_event_change_nothing(pipelined, episode
     wrapped, where passes and windows lie astride its seam); and the cached
     form really ran (fewer passes than sub-updates), while at the default batch (8 slabs per window) it does not."""
     from safe_marl_amd.trainer import PGTrainer
-    assert PGTrainer.bootstrap_chunks([0, 10, 100, 105], 20) == [0, 10, 100, 105]
-    assert PGTrainer.bootstrap_chunks([50, 0, 10, 95], 40) == [0, 40, 50, 95]           # [0, 90) in three passes, [95, 135)
+    # [0, 30) and [100, 125): a whole pass each, the rest flush right — or in quarter passes
+    assert PGTrainer.bootstrap_chunks([0, 10, 100, 105], 20) == [(0, 20), (10, 20), (100, 20), (105, 20)]
+    assert PGTrainer.bootstrap_chunks([0, 10, 100, 105], 20, 5) == [(0, 20), (20, 5), (25, 5), (100, 20), (120, 5)]
+    assert PGTrainer.bootstrap_chunks([50, 0, 10, 95], 40, 10) == [(0, 40), (40, 40), (80, 10), (95, 40)]   # [0, 90), [95, 135)
     a, b = _trainer(True, 1024, alg), _trainer(True, 1024, alg)
     for tr in (a, b):
         for _ in range(episodes - 1):                 # three episodes = 285 slabs into a ring of 192: windows astride its seam
