@@ -199,10 +199,9 @@ class PGTrainer(object):
         bs_all = self.effective_batch_size()
         starts, chunks, boot = {}, [], None
         net = self.behaviour_net
-        # Passes of ONE size, the sub-update's batch: quarter passes for what an interval leaves over were tried (12.4 -> 12.0
-        # ms per event at the reference's reuse) and given up — at another row count the library picks another first-layer
-        # GEMM kernel, the values differ in the seventh digit, and the event is no longer bit-identical to the plain one.
-        small = 0
+        # (Passes of ONE size, the sub-update's batch: quarter passes for what an interval leaves over were tried — 12.4 -> 12.0
+        # ms per event at the reference's reuse — and given up: at another row count the library picks another first-layer
+        # GEMM kernel, the values differ in the seventh digit, and the event is no longer bit-identical to the plain one.)
         eligible = (self.cache_bootstrap and n_value >= 3 and getattr(buf, "nv_ring", None) is not None
                     and "value_cached" in (getattr(net, "update_fields", None) or {}) and hasattr(net, "bootstrap_values")
                     and getattr(net, "bootstrap_cacheable", False) and getattr(net, "target_net", None) is not None)
@@ -213,8 +212,6 @@ class PGTrainer(object):
             # same point.
             self._cached_ready = True
             ok = self._ensure_graph("value_cached") is not None and self._ensure_bootstrap(bs_all) is not None
-            if ok and small:
-                ok = self._ensure_bootstrap(small) is not None
             if ok and self.pipeline_updates:
                 ok = self._ensure_graph("value_cached", 1) is not None
             if not ok:
@@ -222,11 +219,10 @@ class PGTrainer(object):
         if eligible:
             vstarts = [buf.sample_slot(bs_all) for _ in range(n_value)]
             starts = dict(enumerate(vstarts))
-            chunks = self.bootstrap_chunks(vstarts, bs_all, small)
-            # in units of whole passes (a quarter pass costs more than a quarter: gather, scatter, launch floor); a pass costs
-            # about what a value sub-update saves, so the cached form has to save at least two of them to be chosen
-            cost = sum(size / float(bs_all) + (0.1 if size != bs_all else 0.0) for _, size in chunks)
-            if cost + 2 < n_value:
+            N = buf.n_envs
+            chunks = self.bootstrap_chunks(vstarts, bs_all, [(a * N, b * N) for a, b in buf._runs()])
+            # a pass costs about what a value sub-update saves: the cached form has to save at least two of them to be chosen
+            if len(chunks) + 2 < n_value:
                 boot = {size: self._ensure_bootstrap(size) for size in {size for _, size in chunks}}
                 if (any(g is None for g in boot.values()) or self._ensure_graph("value_cached") is None or
                         (self.pipeline_updates and self._ensure_graph("value_cached", 1) is None)):
@@ -290,10 +286,11 @@ class PGTrainer(object):
             self._replay(g, stat)
 
     @staticmethod
-    def bootstrap_chunks(starts, bs, small=0):
-        """Passes that cover the union of the windows [s, s + bs): [(start, size)] with size = ``bs`` or ``small`` (a divisor of
-        bs; 0 = none).  The windows are merged into intervals; an interval is cut into whole passes from its left end, what
-        is left over (< bs) into ``small`` passes, the last pass flush with the interval's right end."""
+    def bootstrap_chunks(starts, bs, runs=()):
+        """Passes of ``bs`` consecutive transitions that cover the union of the windows [s, s + bs): [(start, bs)].  The windows
+        are merged into intervals; two neighbouring intervals inside the same run of complete transitions (``runs``: [(lo,
+        hi)] global slot ranges, TransReplayBuffer._runs) are joined across the gap between them when that takes fewer
+        passes; an interval is cut into passes from its left end, the last one flush with its right end."""
         ivals = sorted((int(s), int(s) + bs) for s in starts)
         merged = []
         a, b = ivals[0]
@@ -304,20 +301,28 @@ class PGTrainer(object):
                 merged.append((a, b))
                 a, b = x, y
         merged.append((a, b))
+
+        def passes(lo, hi):
+            return -(-(hi - lo) // bs)
+
+        def same_run(lo, hi):
+            return any(r0 <= lo and hi <= r1 for r0, r1 in runs)
+
+        joined = [merged[0]]
+        for x, y in merged[1:]:
+            a, b = joined[-1]
+            if same_run(a, y) and passes(a, y) < passes(a, b) + passes(x, y):
+                joined[-1] = (a, y)
+            else:
+                joined.append((x, y))
         chunks = []
-        for a, b in merged:
+        for a, b in joined:
             c = a
             while c + bs <= b:
                 chunks.append((c, bs))
                 c += bs
             if c < b:
-                if small and b - c <= bs - small:             # (otherwise the small passes would cover a whole one anyway)
-                    while c + small < b:
-                        chunks.append((c, small))
-                        c += small
-                    chunks.append((b - small, small))
-                else:
-                    chunks.append((b - bs, bs))
+                chunks.append((b - bs, bs))
         return chunks
 
     def _ensure_bootstrap(self, bs):

@@ -230,10 +230,15 @@ def test_bootstrap_values_filed_once_per_event_change_nothing(pipelined, episode
     wrapped, where passes and windows lie astride its seam); and the cached
     form really ran (fewer passes than sub-updates), while at the default batch (8 slabs per window) it does not."""
     from safe_marl_amd.trainer import PGTrainer
-    # [0, 30) and [100, 125): a whole pass each, the rest flush right — or in quarter passes
+    # [0, 30) and [100, 125): a whole pass each and one flush right
     assert PGTrainer.bootstrap_chunks([0, 10, 100, 105], 20) == [(0, 20), (10, 20), (100, 20), (105, 20)]
-    assert PGTrainer.bootstrap_chunks([0, 10, 100, 105], 20, 5) == [(0, 20), (20, 5), (25, 5), (100, 20), (120, 5)]
-    assert PGTrainer.bootstrap_chunks([50, 0, 10, 95], 40, 10) == [(0, 40), (40, 40), (80, 10), (95, 40)]   # [0, 90), [95, 135)
+    # [0, 90) and [95, 135): three passes + one — joined across the gap [90, 95) (same run of transitions): 135 / 40 -> four
+    assert PGTrainer.bootstrap_chunks([50, 0, 10, 95], 40) == [(0, 40), (40, 40), (50, 40), (95, 40)]
+    assert PGTrainer.bootstrap_chunks([50, 0, 10, 80], 40, [(0, 500)]) == [(0, 40), (40, 40), (80, 40)]
+    assert PGTrainer.bootstrap_chunks([0, 45, 100], 40, [(0, 500)]) == [(0, 40), (45, 40), (100, 40)]      # joining: 4 > 3
+    # [0, 45) and [50, 95): two passes each, three joined — but not across two runs of transitions
+    assert PGTrainer.bootstrap_chunks([0, 5, 50, 55], 40, [(0, 500)]) == [(0, 40), (40, 40), (55, 40)]
+    assert PGTrainer.bootstrap_chunks([0, 5, 50, 55], 40, [(0, 48), (48, 500)]) == [(0, 40), (5, 40), (50, 40), (55, 40)]
     a, b = _trainer(True, 1024, alg), _trainer(True, 1024, alg)
     for tr in (a, b):
         for _ in range(episodes - 1):                 # three episodes = 285 slabs into a ring of 192: windows astride its seam
