@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--strict", action="store_true",
                     help="exit non-zero when a training leg fails or runs without its rollout graph / both update graphs")
     ap.add_argument("--kernel-shares-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-seconds", type=float, default=1.5, help="stepping time of the CPU baseline sample (x cores = CPU work)")
+    ap.add_argument("--cpu-seconds", type=float, default=1.0, help="stepping time of ONE CPU baseline sample (7 samples after 2 s of warm-up; x cores = CPU work)")
     ap.add_argument("--warm-start", type=int, default=1)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a one-GPU box together with FLEX_BENCH_ONE_DEVICE=1)")
@@ -91,12 +91,20 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(net, series, seconds):
-    """The oracle's C restatement timed on this box's host cores (rank 0, N=1 only)."""
+def cpu_baseline(net, series, seconds, samples=7, warmup_s=2.0):
+    """The oracle's C restatement timed on this box's host cores (rank 0, N=1 only): after ``warmup_s`` seconds of stepping
+    (page-in, OpenMP team, clock ramp), ``samples`` samples of >= ``seconds`` s of whole 90-step episodes each; `value` is the
+    MEDIAN sample (other tenants' bursts on the host land in single samples, not in the figure — three runs of round 3's
+    single 1.5-s sample read 61 k, 118 k and 91 k), `spread` says how far the samples lie apart.  One thread per granted
+    core, pinned (OMP_PROC_BIND / OMP_PLACES; the oracle's library is loaded after they are set)."""
     import numpy as np
-    from oracle import c_oracle
     cores = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    os.environ.setdefault("OMP_DYNAMIC", "false")
+    from oracle import c_oracle
+    cores = c_oracle.set_threads(cores)                # (libgomp may have read its environment long ago: set it by call)
     n = 64 * cores
     rng = np.random.default_rng(1234)
     env = c_oracle.COracleEnv(net, series.table, n)
@@ -107,21 +115,31 @@ def cpu_baseline(net, series, seconds):
         start = rng.integers(0, 4, n) + rng.integers(0, 24, n) * 4 + day * 96
         env.reset(start, rng.uniform(0.01125, 0.01375, (n, 5)), rng.uniform(0, 1, (n, 20)))
 
-    fresh_episodes()
-    for k in range(4):                                   # page in, spin up the OpenMP team
-        env.step(acts[k % 8])
-    # bounded sample: whole 90-step episodes (no resets inside the timed steps) until `seconds` of stepping
-    busy, done_steps = 0.0, 0
-    while busy < seconds:
-        fresh_episodes()
-        t0 = time.perf_counter()
-        for k in range(90):
-            env.step(acts[k % 8])
-        busy += time.perf_counter() - t0
-        done_steps += 90
-    return {"value": n * done_steps / busy, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {done_steps} steps of step()+get_obs() (C restatement oracle/flexenv_oracle.c, dense polar "
-                      f"NR, OpenMP over envs, {cores} threads), {busy:.1f} s = {busy * cores:.0f} core-seconds"}
+    def sample(min_s):
+        """whole 90-step episodes (no resets inside the timed steps) until ``min_s`` seconds of stepping"""
+        busy, steps = 0.0, 0
+        while busy < min_s:
+            fresh_episodes()
+            t0 = time.perf_counter()
+            for k in range(90):
+                env.step(acts[k % 8])
+            busy += time.perf_counter() - t0
+            steps += 90
+        return n * steps / busy, busy, steps
+
+    sample(warmup_s)
+    got = [sample(seconds) for _ in range(max(1, int(samples)))]
+    rates = sorted(r for r, _, _ in got)
+    busy = sum(b for _, b, _ in got)
+    steps = sum(st for _, _, st in got)
+    med = rates[len(rates) // 2]
+    return {"value": med, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "samples": [round(r) for r in rates], "spread": (rates[-1] - rates[0]) / med,
+            "sample": f"median of {len(rates)} samples (each >= {seconds:g} s of whole 90-step episodes, {n} envs; {steps} steps in "
+                      f"all) after {warmup_s:g} s of warm-up: step()+get_obs() of the C restatement oracle/flexenv_oracle.c (dense "
+                      f"polar NR, OpenMP over envs, {cores} pinned threads), {busy:.1f} s = {busy * cores:.0f} core-seconds; "
+                      "kind 'port': the reference's own path (Pyomo model build + IPOPT subprocess per step, utils/pf.py:101-102) "
+                      "cannot run on this box (BASELINE.md §2)"}
 
 
 TRAIN_ALG_ARGS = dict(  # madrl/args/default.yaml merged with alg_args/maddpg.yaml (examples/train_maddpg.py)
@@ -443,6 +461,80 @@ def launch_ranks(a):
     sys.exit(r.returncode)
 
 
+# SURVEY.md 8(d), tree-structured solve: algorithmic floating-point operations per env-step, counted from the sweep's
+# arithmetic (csrc/flex_device.h pf_sweep / zbus_apply): per bus and sweep ~60 (current conj(S/V) 10, subtree scan 5 x 2 + 4,
+# line drop 6, path scan 5 x 2 fma + 2, voltage update 2, mismatch test 8, re/im bookkeeping), 32 buses, x sweeps per
+# solve (measured: pf_sweeps_mean), + the fp64 Ybus verification (~50 per bus) + actions / reward / ESS (~400 per env)
+def flops_per_env_step(sweeps_mean):
+    return 32 * 60 * sweeps_mean + 32 * 50 + 400
+
+
+def roofline_details(a, env, kern_ms):
+    """What bounds the dominant kernel, from the build and from counters (FLOP/s, waves per SIMD, register /
+    LDS occupancy next to the bandwidth figure): the compiler's resource report of the library being timed
+    (safe-marl_amd/kernel_resources.json, written by build.py), and the committed counter passes of tools/env_counters.sh
+    (profiles/pmc_traffic.json) — used only when they were taken on THIS build (source digest) at this batch size;
+    otherwise `traffic`, `valu_issue_frac` and the counter-derived `limiter` are null and `counters_stale` says why."""
+    from safe_marl_amd import build
+    out = {"traffic": None, "kernel": None, "limiter": None}
+    # the instantiation flexenv_step launches for this configuration (csrc/flexenv.hip: EPW, ObsT, ActT, NA_CAP, SINK)
+    epw = 2 if env.n_bus - 1 <= 32 else 1
+    lw = 64 // epw
+    small = env.n_agents == 5 and 3 * env.history <= (3 if epw == 2 else 2) * lw
+    want = f"flex_step_kernel<{epw}, float, float, {5 if small else 8}, false>"
+    res = [v for v in build.kernel_resources("flex_step_kernel<").values() if v.get("name") == want]
+    out["kernel"] = want
+    waves = (a.envs + epw - 1) // epw
+    out["waves_launched"] = waves
+    out["resident_waves_per_simd"] = waves / 1024.0                  # 256 CUs x 4 SIMDs
+    if res:
+        r = res[0]
+        out.update(vgprs=r.get("vgprs"), agprs=r.get("agprs"), sgprs=r.get("sgprs"),
+                   scratch_bytes_per_lane=r.get("scratch_bytes_per_lane"), lds_bytes_per_block=r.get("lds_bytes_per_block"),
+                   max_waves_per_simd=r.get("waves_per_simd"))
+    sweeps = float(env.peek("PF_SWEEPS").float().mean().item())
+    fl = flops_per_env_step(sweeps)
+    out["flops_per_env_step"] = round(fl)
+    out["achieved_gflops"] = fl * a.envs / (kern_ms * 1e-3) / 1e9      # mixed fp64 / fp32 (fp64 vector peak: 78.6 TFLOP/s)
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        t = json.load(open(tpath))
+    except Exception:
+        out["counters_stale"] = "profiles/pmc_traffic.json missing"
+        return out
+    if t.get("source_digest") != build.built_digest():
+        out["counters_stale"] = "counter passes were taken on another build (source digest differs)"
+        return out
+    if int(t.get("envs_per_launch", -1)) != a.envs or a.solver != "sweep":
+        out["counters_stale"] = "counter passes were taken at another batch size / solver"
+        return out
+    out["traffic"] = t.get("flex_step_kernel_bytes_per_launch")
+    c = t.get("counters_per_launch", {})
+    wave_q, valu_q = c.get("SQ_WAVE_CYCLES"), c.get("SQ_ACTIVE_INST_VALU")
+    if wave_q and valu_q:
+        gui = c.get("GRBM_GUI_ACTIVE")
+        kern_cycles = gui / 8.0 if gui else None                    # summed over the 8 XCDs (MI355X_MICROARCH.md)
+        out["valu_insts_per_wave"] = c.get("SQ_INSTS_VALU", 0) / max(1.0, c.get("SQ_WAVES", waves))
+        # SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES count quad-cycles (same guide): fractions of a wavefront's lifetime
+        f_valu = valu_q / wave_q
+        f_mem = c.get("SQ_WAIT_ANY", 0.0) / wave_q
+        f_dep = c.get("SQ_WAIT_INST_ANY", 0.0) / wave_q
+        out["wave_cycle_split"] = {"valu_issue": round(f_valu, 3), "other_issue": round(max(0.0, c.get("SQ_ACTIVE_INST_ANY", valu_q) - valu_q) / wave_q, 3),
+                                   "waiting_on_memory_or_lds": round(f_mem, 3), "issue_stalled": round(f_dep, 3)}
+        if kern_cycles:
+            # VALU-issue cycles of ALL the SIMD's wavefronts over the SIMD-cycles of the launch (1024 SIMDs)
+            out["valu_issue_frac"] = 4.0 * valu_q / (1024.0 * kern_cycles)
+            out["kernel_cycles"] = round(kern_cycles)
+        per_simd = out["resident_waves_per_simd"]
+        parts = sorted((("VALU issue", f_valu), ("waits on memory / LDS", f_mem), ("issue stalls (dependencies)", f_dep)),
+                       key=lambda kv: -kv[1])
+        out["limiter"] = ("%s (%.0f %% of wavefront cycles; then %s %.0f %%, %s %.0f %%) at %.1f resident wavefronts per SIMD; not "
+                          "HBM bandwidth: counter traffic is %.1f MB per launch" % (
+                              parts[0][0], 100 * parts[0][1], parts[1][0], 100 * parts[1][1], parts[2][0], 100 * parts[2][1],
+                              per_simd, (out["traffic"] or 0) / 1e6))
+    return out
+
+
 def main():
     a = parse_args()
     if a.kernel_shares_child:
@@ -683,15 +775,7 @@ def main():
     if rank == 0:
         total_env_steps = a.envs * world * a.steps
         achieved = B_ALG_WITH_OBS * a.envs / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                t = json.load(open(tpath))
-                if int(t.get("envs_per_launch", -1)) == a.envs:      # PMC figure collected at this batch size only
-                    traffic = t.get("flex_step_kernel_bytes_per_launch")
-            except Exception:
-                traffic = None
+        roof_extra = roofline_details(a, env, kern_ms)
         out = {
             # BASELINE.json's metric string verbatim; the "+ PF-kernel HBM GB/s" half is `roofline.achieved`
             "metric": "env-steps/sec (33-bus, 4096 envs/GPU) at 1/2/4/8 MI355X + PF-kernel HBM GB/s",
@@ -721,15 +805,15 @@ def main():
                 "pf_newton_iters_mean": iters_mean, "pf_sweeps_mean": sweeps_mean,
                 "solver_failed_frac": failed_frac,
             },
-            "roofline": {
-                "bound": "hbm", "limiter": "latency (dependent chain of one wavefront at 2 waves/SIMD; DESIGN.md §4.7)",
-                "kernel": "flex_step_kernel<2, float, float, 5>",
+            "roofline": dict({
+                "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                # the same launch time against SURVEY.md 8(d)'s core bytes (no stacked observation): reported next to `frac`
+                # so that the figure stays comparable whatever form the observation leaves the kernel in
+                "frac_core_bytes": B_ALG_CORE * a.envs / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_env_step": B_ALG_WITH_OBS, "algorithmic_bytes_per_env_step_no_obs": B_ALG_CORE,
                 "avg_launch_ms": kern_ms, "bracketed_launch_ms": durs[len(durs) // 2],
-                "note": "latency/issue-bound fp64 kernel: ~4 KB per env-step cannot approach HBM peak (SURVEY.md §8d)",
-            },
+            }, **roof_extra),
             "sustained": sustained,
             "solver_sibling": sibling,
             "train": train,

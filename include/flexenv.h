@@ -207,7 +207,8 @@ int flexenv_set_replay_sink(FlexEnv* env, const FlexReplaySink* sink /* NULL: of
  * the FlexActorArgs (include/flexnet.h) of the ring-mode flexnet_actor_forward call this replaces, with ring_slabs set; the
  * env must be configured as for flexenv_step(FLEX_STEP_AUTORESET | FLEX_STEP_OBS_RING | FLEX_STEP_REPLAY_SINK) behind that
  * call (obs ring on actor->cursor_out, sink reading actor->action / actor->hidden_out and writing actor->cursor, its
- * aux_counter = actor->rng_state + 1 or NULL), n_agents <= 5, steps < slabs.  Afterwards every buffer and both cursor cells
+ * aux_counter = actor->rng_state + 1: the noise stream's step counter, which the burst advances by `steps`), n_agents <= 5,
+ * steps < slabs; `info` and `failed` may be NULL.  Afterwards every buffer, both cursor cells and the noise position
  * hold what `steps` repetitions of the two launches leave, bit for bit (tests/test_rollout_gpu.py). FLEX_EINVAL otherwise. */
 /* `safety` non-NULL: SAFEMADDPG's step (madrl/models/safemaddpg.py:90-111) — between policy and environment every
  * environment's proposed action (actor->action) goes through flexenv_safety_project_env's arithmetic (same arguments, same

@@ -51,6 +51,13 @@ def load():
     return _lib
 
 
+def set_threads(n):
+    """Pin the OpenMP team of the batch calls to ``n`` threads; returns the team size actually in force."""
+    lib = load()
+    lib.oracle_set_threads(int(n))
+    return int(lib.oracle_get_threads())
+
+
 def make_cfg(net, cfg=None, alg=None, pf_tol=1e-12, pf_max_iter=20):
     c = dict(DEFAULT_CFG)
     c.update(cfg or {})

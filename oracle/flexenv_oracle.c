@@ -318,5 +318,18 @@ int oracle_env_step_batch(const OCfg* c, OState* s, int n, const double* actions
     return 0;
 }
 
+/* thread count of the OpenMP team the batch calls run on (bench.py's cpu_baseline pins it and reports what it got) */
+#include <omp.h>
+void oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int oracle_get_threads(void) {
+    int t = 1;
+#pragma omp parallel
+    {
+#pragma omp single
+        t = omp_get_num_threads();
+    }
+    return t;
+}
+
 int oracle_sizeof_cfg(void) { return (int)sizeof(OCfg); }
 int oracle_sizeof_state(void) { return (int)sizeof(OState); }

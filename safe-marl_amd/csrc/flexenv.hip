@@ -1384,7 +1384,10 @@ int flexenv_rollout_burst(FlexEnv* e, const FlexActorArgs* actor, double* reward
     if (p.ring_slabs != e->obs_slabs || p.obs_slab_stride != e->obs_slab_stride || steps >= e->obs_slabs) return FLEX_EINVAL;
     if (p.cursor_out != e->obs_cursor || p.cursor != e->sink.cursor_out || p.hidden_out != e->sink.hid_new ||
         p.action != e->sink.policy_action || p.noise) return FLEX_EINVAL;
-    if (e->sink.aux_counter && (!p.rng_state || (const void*)e->sink.aux_counter != (const void*)(p.rng_state + 1))) return FLEX_EINVAL;
+    // the burst draws the noise of steps rng_state[1] .. rng_state[1] + steps - 1 in the kernel and the finish launch advances the
+    // step counter through the sink's aux_counter: the two must be the same cell, or the next burst would repeat the draws
+    // (a NULL aux_counter used to pass)
+    if (!p.rng_state || !e->sink.aux_counter || (const void*)e->sink.aux_counter != (const void*)(p.rng_state + 1)) return FLEX_EINVAL;
     if (p.save_z1) return FLEX_EINVAL;
     KArgs k = make_args(e);
     k.obs_cursor = e->obs_cursor; k.obs_slab_stride = e->obs_slab_stride; k.obs_slabs = e->obs_slabs;

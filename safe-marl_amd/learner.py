@@ -101,14 +101,15 @@ class RolloutGraph:
         # ... within the sink's own limits (flexenv_set_replay_sink: action row <= 32 floats, recurrent row <= 384 floats —
         # seven agents x 64 units is 448 — and the two-environments-per-wavefront instantiation, i.e. <= 32 PQ buses);
         # outside them the pack kernel files the transition (three launches per step)
-        self.sink = bool(self.ring_io and hasattr(env, "set_replay_sink") and n * a <= 32 and n * h <= 384
-                         and getattr(env, "n_bus", 33) - 1 <= 32)
+        n_bus = getattr(getattr(env, "vec", env), "n_bus", None)       # (a wrapped env without it: not eligible — pack path)
+        two_per_wave = n_bus is not None and n_bus - 1 <= 32
+        self.sink = bool(self.ring_io and hasattr(env, "set_replay_sink") and n * a <= 32 and n * h <= 384 and two_per_wave)
         # MATD3 / IDDPG with the one-launch action selection (`summed`): the same ring I/O and sink — policy kernel (slab at the
         # cursor -> means, new hidden state), agent_sum_explore_kernel (-> the action the replay keeps, the env's action), env
         # step (files the transition): three launches, no pack kernel, the observation written once (round 3)
         self.summed_sink = bool(self.summed and self.cursor_stepped and hasattr(env, "set_obs_ring")
                                 and hasattr(env, "set_replay_sink") and n * a <= 32 and n * h <= 384
-                                and getattr(env, "n_bus", 33) - 1 <= 32 and h == 64 and o <= 144
+                                and two_per_wave and h == 64 and o <= 144
                                 and os.environ.get("FLEX_SUMMED_SINK", "1") != "0")
         if self.sink or self.summed_sink:
             self.act_buf = th.zeros(N * n, a, device=dev)
@@ -348,8 +349,8 @@ class RolloutGraph:
             if k == 1:
                 done.append(self.step())
                 continue
-            g = self.bursts.get(k)
-            if g is None:
+            g = self.bursts.get((k, self.fused_burst))      # (keyed by the body's form too: a flag flipped after capture()
+            if g is None:                                    #  must not replay a graph recorded for the other body)
                 g = self._capture_burst(k)
             g.replay()
             done.extend(self.buf.stepped() for _ in range(k))
@@ -381,7 +382,7 @@ class RolloutGraph:
                     self.body()
         if calls is not None:
             self.env.calls = calls
-        self.bursts[k] = g
+        self.bursts[(k, self.fused_burst)] = g
         return g
 
     def capture(self, lengths=None):

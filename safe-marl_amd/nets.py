@@ -343,18 +343,27 @@ _TD_WS = {}
 # the full-batch statistics are the sums over the ranks of the per-rank sums.  GPU path: the statistics pass of
 # csrc/tdloss.hip leaves its per-block partial sums in the workspace, ONE all-reduce of those 8 KB makes them global
 # (flexnet_td_stats -> all-reduce -> the call with stats_ready / stat_rows); CPU path: sync_batchnorm below.
-REWARD_BN_SYNC = False
+# The switch lives on the BatchNorm MODULE (``bn.flex_sync_ranks``, set by the trainer that owns the model): a second
+# trainer in the same process (bench legs, an evaluation trainer, tests) cannot change the behaviour of the first one,
+# and a trainer's graphed and eager paths read the same flag (it used to be a module global).
 
 
-def _sync_active():
+def set_reward_bn_sync(bn, on):
+    if bn is not None:
+        object.__setattr__(bn, "flex_sync_ranks", bool(on))
+
+
+def _sync_active(bn):
     import torch.distributed as dist
-    return REWARD_BN_SYNC and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return (bn is not None and getattr(bn, "flex_sync_ranks", False) and dist.is_available() and dist.is_initialized()
+            and dist.get_world_size() > 1)
 
 
-def _td_sync_stats(a, ws):
-    """If cross-rank statistics are on: statistics pass, all-reduce of the partial sums, and mark ``a`` (FlexTdLossArgs)
-    so that the call that follows uses them instead of computing its own.  ``ws``: the fp64 workspace tensor of ``a``."""
-    if not (a.normalise and _sync_active()):
+def _td_sync_stats(a, ws, bn):
+    """If cross-rank statistics are on for ``bn``: statistics pass, all-reduce of the partial sums, and mark ``a``
+    (FlexTdLossArgs) so that the call that follows uses them instead of computing its own.  ``ws``: the fp64 workspace
+    tensor of ``a``."""
+    if not (a.normalise and _sync_active(bn)):
         return
     import ctypes as C
     import torch.distributed as dist
@@ -368,7 +377,7 @@ def sync_batchnorm(bn, x):
     """``bn(x)`` of a training-mode nn.BatchNorm1d on [rows, n] with the batch statistics taken over ALL ranks' rows (equal
     shards): normalised output, running statistics and num_batches_tracked moved as the module moves them.  Plain tensor
     ops (the eager / CPU path); without an initialised process group of more than one rank it is ``bn(x)``."""
-    if not (_sync_active() and bn.training):
+    if not (_sync_active(bn) and bn.training):
         return bn(x)
     import torch.distributed as dist
     xd = x.double()
@@ -421,7 +430,7 @@ class _TdLossFn(th.autograd.Function):
                 a.num_batches_tracked = bn.num_batches_tracked.data_ptr()
         a.dq, a.loss = dq.data_ptr(), loss.data_ptr()
         a.workspace, a.workspace_floats = ws.data_ptr(), 2 * ws.numel()
-        _td_sync_stats(a, ws)
+        _td_sync_stats(a, ws, bn)
         _lib.check(lib.flexnet_td_loss(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_td_loss")
         ctx.save_for_backward(dq)
         ctx.q_shape = q.shape
@@ -468,7 +477,7 @@ def batchnorm_update_running_stats(bn, x):
     a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
     a.num_batches_tracked = bn.num_batches_tracked.data_ptr()
     a.workspace, a.workspace_floats = ws.data_ptr(), 2 * ws.numel()
-    _td_sync_stats(a, ws)
+    _td_sync_stats(a, ws, bn)
     _lib.check(lib.flexnet_td_loss(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_td_loss")
 
 
@@ -1079,7 +1088,7 @@ class _CriticTdLossFn(th.autograd.Function):
         loss = th.empty((), dtype=th.float32, device=dev)
         t = _td_args(r, d, nq, gamma, bn, update_stats=True)
         t.loss = loss.data_ptr()
-        _td_sync_stats(t, _TD_WS[r.device])
+        _td_sync_stats(t, _TD_WS[r.device], bn)
         _lib.check(lib.flexnet_critic_td_backward(C.byref(args), C.byref(t), stream), "flexnet_critic_td_backward")
         d_bias = th.empty(64, dtype=th.float32, device=dev)
         tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias, x2=act2d, out2=dW[:, no + n:no + n + na_])

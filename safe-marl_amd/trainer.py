@@ -72,8 +72,6 @@ class PGTrainer(object):
         if sync_reward_bn is None:
             sync_reward_bn = os.environ.get("FLEX_SYNC_REWARD_BN") == "1"
         self.sync_reward_bn = bool(sync_reward_bn) and self.world > 1
-        from . import nets as _nets
-        _nets.REWARD_BN_SYNC = self.sync_reward_bn
 
         # behaviour net (+ target replica), trainer.py:16-28: SAFEMADDPG also receives the env
         ctor_args = (args, env) if args.alg == "safemaddpg" else (args,)
@@ -84,6 +82,9 @@ class PGTrainer(object):
         if self.world > 1:                      # identical replicas: rank 0's weights everywhere
             fdist.broadcast_module(self.behaviour_net)
         net = self.behaviour_net
+        from .nets import set_reward_bn_sync
+        for m in (net, getattr(net, "target_net", None)):          # the flag lives on THIS trainer's BatchNorm modules
+            set_reward_bn_sync(getattr(m, "batchnorm", None), self.sync_reward_bn)
         cap = dict(capturable=True) if self.device.type == "cuda" else {}       # optimiser steps inside HIP graphs
         self.policy_optimizer = RMSprop(net.policy_dicts.parameters(), lr=args.policy_lrate, **_RMSPROP, **cap)
         self.value_optimizer = RMSprop(net.value_dicts.parameters(), lr=args.value_lrate, **_RMSPROP, **cap)
@@ -430,62 +431,75 @@ class PGTrainer(object):
         net_snap = {k: v.clone() for k, v in self.behaviour_net.state_dict().items()}
         had_state = {p: {k: (v.clone() if th.is_tensor(v) else v) for k, v in opt.state[p].items()}
                      for p in opt.param_groups[0]["params"] if p in opt.state}
-        import os
-        if os.environ.get("FLEX_GRAPH_AUDIT") == "1":     # the body about to be captured launches no ATen multi-block reduction
-            from .util import audit_graph_body
-            self.graph_audit = getattr(self, "graph_audit", {})
-            self.graph_audit[kind] = audit_graph_body(lambda: self._sub_update(which, {}, batch, fresh_leaves=True))
         flat = None
         if self.world > 1:
             flat = th.zeros(sum(p.numel() for p in opt.param_groups[0]["params"]), dtype=th.float32, device=self.device)
-        side = th.cuda.Stream()
-        side.wait_stream(th.cuda.current_stream())
-        with th.cuda.stream(side):
-            for _ in range(2):                        # warm-up off the capturing stream (allocator, rocBLAS handles)
-                self._sub_update(which, out, batch, fresh_leaves=True, flat=flat)
-        th.cuda.current_stream().wait_stream(side)
-        if self.world > 1:
-            th.cuda.synchronize()                     # no collective of the warm-up is outstanding when capture begins
-        graph = th.cuda.CUDAGraph()
-        apply_graph = None
-        out = {}
-        if flat is None:
-            with graph_capture(graph):
-                self._sub_update(which, out, batch, fresh_leaves=True)
-        else:
-            fused = False
+            # (checked BEFORE the warm-up's real optimiser steps — ADVICE r03: raised behind them it left two unrestored
+            #  critic updates on this rank only)
             if self.sync_reward_bn and not self.allreduce_in_graph:
                 raise RuntimeError("cross-rank reward statistics need the all-reduces inside the update graph (nccl)")
-            if self.allreduce_in_graph:
-                try:
+
+        def restore():
+            with th.no_grad():
+                for k, v in self.behaviour_net.state_dict().items():
+                    v.copy_(net_snap[k])
+                for p in opt.param_groups[0]["params"]:
+                    for k, v in opt.state.get(p, {}).items():
+                        if th.is_tensor(v):
+                            old = had_state.get(p, {}).get(k)
+                            v.copy_(old) if old is not None else v.zero_()
+
+        # Whatever happens between here and the end of the capture — a refused capture, an exception out of a loss — the
+        # warm-up's steps (weights, RMSprop state, reward-BatchNorm running statistics) are undone: the invariant "capturing
+        # adds no update to the schedule of model.py:43-50" also holds on the failure paths (eager fallback, value_cached
+        # fallback), and with more than one rank a failure on one rank cannot leave the replicas apart.
+        try:
+            if os.environ.get("FLEX_GRAPH_AUDIT") == "1":     # the body about to be captured launches no ATen multi-block reduction
+                from .util import audit_graph_body
+                self.graph_audit = getattr(self, "graph_audit", {})
+                self.graph_audit[kind] = audit_graph_body(lambda: self._sub_update(which, {}, batch, fresh_leaves=True, flat=flat))
+            side = th.cuda.Stream()
+            side.wait_stream(th.cuda.current_stream())
+            with th.cuda.stream(side):
+                for _ in range(2):                        # warm-up off the capturing stream (allocator, rocBLAS handles)
+                    self._sub_update(which, out, batch, fresh_leaves=True, flat=flat)
+            th.cuda.current_stream().wait_stream(side)
+            if self.world > 1:
+                th.cuda.synchronize()                     # no collective of the warm-up is outstanding when capture begins
+            graph = th.cuda.CUDAGraph()
+            apply_graph = None
+            out = {}
+            if flat is None:
+                with graph_capture(graph):
+                    self._sub_update(which, out, batch, fresh_leaves=True)
+            else:
+                fused = False
+                if self.allreduce_in_graph:
+                    try:
+                        with graph_capture(graph):
+                            self._loss_and_grads(which, out, batch, fresh_leaves=True, flat=flat)
+                            fdist.allreduce_flat(flat)
+                            self._apply_grads(which, out, flat=flat)
+                        fused = True
+                    except Exception as exc:
+                        if self.sync_reward_bn:      # the statistics' all-reduce sits inside graph A: no split form — eager sub-updates
+                            raise
+                        import warnings
+                        warnings.warn(f"all-reduce inside the sub-update graph could not be captured ({exc}); splitting the graph at it")
+                        self.allreduce_in_graph = False
+                        th.cuda.synchronize()
+                        graph = th.cuda.CUDAGraph()
+                        out = {}
+                if not fused:
                     with graph_capture(graph):
                         self._loss_and_grads(which, out, batch, fresh_leaves=True, flat=flat)
-                        fdist.allreduce_flat(flat)
+                    apply_graph = th.cuda.CUDAGraph()
+                    with graph_capture(apply_graph, pool=graph.pool()):
                         self._apply_grads(which, out, flat=flat)
-                    fused = True
-                except Exception as exc:
-                    if self.sync_reward_bn:      # the statistics' all-reduce sits inside graph A: no split form — eager sub-updates
-                        raise
-                    import warnings
-                    warnings.warn(f"all-reduce inside the sub-update graph could not be captured ({exc}); splitting the graph at it")
-                    self.allreduce_in_graph = False
-                    th.cuda.synchronize()
-                    graph = th.cuda.CUDAGraph()
-                    out = {}
-            if not fused:
-                with graph_capture(graph):
-                    self._loss_and_grads(which, out, batch, fresh_leaves=True, flat=flat)
-                apply_graph = th.cuda.CUDAGraph()
-                with graph_capture(apply_graph, pool=graph.pool()):
-                    self._apply_grads(which, out, flat=flat)
-        with th.no_grad():
-            for k, v in self.behaviour_net.state_dict().items():
-                v.copy_(net_snap[k])
-            for p in opt.param_groups[0]["params"]:
-                for k, v in opt.state.get(p, {}).items():
-                    if th.is_tensor(v):
-                        old = had_state.get(p, {}).get(k)
-                        v.copy_(old) if old is not None else v.zero_()
+        finally:
+            if self.device.type == "cuda":
+                th.cuda.synchronize()                     # (a failed capture may leave warm-up work in flight)
+            restore()
         # `batch` stays referenced: its constant fields (action_avail, ...) were allocated eagerly and are baked into the
         # graph by address; released, the allocator would hand their memory to the next eager tensor
         return dict(graph=graph, apply=apply_graph, flat=flat, plan=plan, stat=out, bs=bs, buf=buf, batch=batch,

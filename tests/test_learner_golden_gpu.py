@@ -32,9 +32,9 @@ def gold():
     return dict(np.load(os.path.join(G, "learner_golden.npz")))
 
 
-def _args(**over):
+def _args(prefix="learner", **over):
     from safe_marl_amd.util import convert
-    d = json.load(open(os.path.join(G, "learner_args.json")))
+    d = json.load(open(os.path.join(G, prefix + "_args.json")))
     d.update(cuda=True)
     d.update(over)
     return convert(d)
@@ -45,9 +45,9 @@ def _load_sd(name):
     return {k: th.from_numpy(z[k]) for k in z.files}
 
 
-def _batch(tile=1):
+def _batch(tile=1, prefix="learner"):
     from safe_marl_amd.replay_buffer import Transition
-    z = np.load(os.path.join(G, "learner_batch.npz"))
+    z = np.load(os.path.join(G, prefix + "_batch.npz"))
     out = {}
     for k in Transition._fields:
         t = th.from_numpy(z[k]).float().cuda()
@@ -58,12 +58,15 @@ def _batch(tile=1):
 class StubEnv:
     n_envs = 1
 
+    def __init__(self, n=5):
+        self.n = n
+
     def get_num_of_agents(self):
-        return 5
+        return self.n
 
 
-def _model(cls, sd_name):
-    args = _args()
+def _model(cls, sd_name, prefix="learner"):
+    args = _args(prefix)
     model = cls(args, cls(args).cuda()).cuda()
     res = model.load_state_dict(_load_sd(sd_name), strict=True)
     assert not res.missing_keys and not res.unexpected_keys
@@ -135,13 +138,13 @@ def _expected_running_var(rv_gold, n_rows):
     return 0.81 + 0.19 * u32 * (31.0 / 32.0) * n_rows / (n_rows - 1.0)
 
 
-def _check_after_step(gold, trainer, stat, n_rows, label):
+def _check_after_step(gold, trainer, stat, n_rows, label, fixtures="learner"):
     args = trainer.args
     for k in ("mean_train_value_grad_norm", "mean_train_value_loss", "mean_train_policy_grad_norm",
               "mean_train_policy_loss", "mean_train_entropy"):
         assert abs(float(stat[k]) - gold["stat." + k]) < 1e-4 * max(1.0, abs(gold["stat." + k])), (label, k)
-    after = _load_sd("learner_state_dict_after_step.npz")
-    before = _load_sd("learner_state_dict.npz")
+    after = _load_sd(fixtures + "_state_dict_after_step.npz")
+    before = _load_sd(fixtures + "_state_dict.npz")
     mine = {k: v.detach().cpu() for k, v in trainer.behaviour_net.state_dict().items()}
     # RMSprop's first step is lr * g / (0.1 |g| + eps): for |g| >> 10 eps it is +-10 lr whatever g is, for a near-zero
     # gradient it moves by (lr eps / (0.1 |g| + eps)^2) per unit of gradient error.  Tolerance = 3e-6 (the CPU test's) +
@@ -307,3 +310,126 @@ def test_iddpg_matches_the_reference_on_the_gpu(gold, tile):
     for k, g in zip(names, _grads(pl, model.policy_dicts.parameters())):
         r = gold["iddpg_pgrad." + k]
         assert np.allclose(g, r, atol=2e-7 + 1e-4 * np.abs(r).max()), (tile, k, np.abs(g - r).max())
+
+
+# ---- BASELINE.json config 3: MADDPG with THREE agents (critic input (obs + act) * 3 + 3, maddpg.py:18-27) --------------
+# fixtures: tests/golden/learner3_* = make_learner_golden.py --agents 3 (the reference's own modules, imported)
+@pytest.fixture(scope="module")
+def gold3():
+    return dict(np.load(os.path.join(G, "learner3_golden.npz")))
+
+
+@pytest.mark.parametrize("tile", TILES)
+def test_maddpg_3_agents_losses_grads_step_and_target_match_the_reference(gold3, tile):
+    """maddpg.py:18-27,33-123 + utils/trainer.py:81-108 + model.py:28-38 with agent_num = 3 on the HIP path: values, both
+    losses, every parameter gradient, one value + one policy sub-update, the soft target update."""
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.trainer import PGTrainer
+    from safe_marl_amd import util
+    _loaded_lib()
+    gold, P = gold3, "learner3"
+    b = _batch(tile, P)
+    assert b.state.shape[1:] == (3, 144) and b.action.shape[1:] == (3, 4)
+    model = _model(MADDPG, P + "_state_dict.npz", P)
+    assert model.value_dicts[0].fc1.weight.shape == (64, (144 + 4) * 3 + 3)
+    assert np.allclose(_np(model.unpack_data(b)[5])[:32], gold["unpack_reward_bn"], atol=2e-5)
+    model = _model(MADDPG, P + "_state_dict.npz", P)
+    with th.no_grad():
+        means, _, hid = model.policy(b.state, last_hid=b.last_hid)
+        v = model.value(b.state, b.action)
+    assert np.allclose(_np(means)[:32], gold["policy_means"], atol=5e-6)
+    assert np.allclose(_np(hid)[:32], gold["policy_hiddens"], atol=5e-6)
+    assert np.allclose(_np(v)[:32], gold["value_sa"], atol=2e-5)
+    _, vl, _ = model.get_loss(b, need="value")
+    assert abs(vl.item() - gold["value_loss"]) < 1e-5 * max(1.0, abs(gold["value_loss"]))
+    names = [k for k, _ in model.value_dicts.named_parameters()]
+    for k, g in zip(names, _grads(vl, model.value_dicts.parameters())):
+        ref = gold["vgrad." + k]
+        assert np.allclose(g, ref, atol=2e-6 + 1e-4 * np.abs(ref).max()), (tile, k, np.abs(g - ref).max())
+    pl, _, _ = model.get_loss(b, need="policy")
+    assert abs(pl.item() - gold["policy_loss"]) < 1e-5
+    names = [k for k, _ in model.policy_dicts.named_parameters()]
+    for k, g in zip(names, _grads(pl, model.policy_dicts.parameters())):
+        ref = gold["pgrad." + k]
+        assert np.allclose(g, ref, atol=2e-7 + 1e-4 * np.abs(ref).max()), (tile, k, np.abs(g - ref).max())
+    # one optimiser step of each kind through the trainer, then the target update
+    trainer = PGTrainer(_args(P), MADDPG, StubEnv(3), None)
+    trainer.behaviour_net.load_state_dict(_load_sd(P + "_state_dict.npz"))
+    stat = {}
+    trainer.value_transition_process(stat, b)
+    trainer.policy_transition_process(stat, b)
+    _check_after_step(gold, trainer, stat, 32 * tile, f"3 agents x{tile}", P)
+    trainer.behaviour_net.update_target()
+    tgt = _load_sd(P + "_target_after_update.npz")
+    mine_t = trainer.behaviour_net.target_net.state_dict()
+    for k, ref in tgt.items():
+        if ref.is_floating_point() and "batchnorm" not in k:
+            assert th.allclose(mine_t[k].cpu(), ref, atol=3e-6, rtol=1e-5), k
+    assert not util.FALLBACKS, util.FALLBACKS              # no fused path declined the 3-agent shapes
+
+
+def test_config3_maddpg_3_agents_4096_envs_trains_on_graphs():
+    """BASELINE.json config 3 as stated: MADDPG, 3 agents (buildings [5, 15, 25]), 4096 environments on one GPU, device
+    replay, graphed rollout and sub-updates (what bench.py's config-3 leg builds).  Two training episodes (190 vector steps:
+    three update events) on the product path, then one more value and one more policy sub-update on the SAME replay
+    window taken twice — as HIP-graph replays and eagerly from identical weights / optimiser state — must agree, and the
+    critic that trained has the reference's shape (maddpg.py:18-27)."""
+    import copy
+    from safe_marl_amd import util
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.trainer import PGTrainer
+    _loaded_lib()
+    util.FALLBACKS.clear()
+    n_envs, blds = 4096, [5, 15, 25]
+    env_args = {"buildings": blds, "pv_nodes": blds, "ess_nodes": blds}
+    net3 = create_network(env_args)
+    series = make_synthetic_series(net3, n_days=60)
+    env = VecFlexProvisionEnv(env_args, n_envs, net=net3, series=series, seed=1234, warm_start=True)
+    d = json.load(open(os.path.join(G, "learner3_args.json")))
+    d.update(cuda=True, agent_num=env.n_agents, obs_size=env.obs_size, state_size=env.state_size, v_min=0.9, v_max=1.1)
+    th.manual_seed(0)
+    np.random.seed(0)
+    trainer = PGTrainer(util.convert(d), MADDPG, env, None, batch_scale=n_envs // 4, replay_capacity=n_envs * 96 * 2)
+    model = trainer.behaviour_net
+    assert model.n_ == 3 and tuple(model.value_dicts[0].fc1.weight.shape) == (64, (144 + 4) * 3 + 3)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    stat = {}
+    for _ in range(2):
+        model.train_process(stat, trainer)
+    th.cuda.synchronize()
+    assert trainer.steps == 190
+    for k in ("mean_train_reward", "mean_train_value_loss", "mean_train_policy_loss"):
+        assert np.isfinite(float(stat[k])), (k, stat[k])
+    assert float(stat["mean_train_solver_failed"]) == 0.0 if "mean_train_solver_failed" in stat else True
+    moved = [k for k, v in model.state_dict().items() if v.is_floating_point() and not th.equal(v, before[k])]
+    assert any(k.startswith("value_dicts.") for k in moved) and any(k.startswith("policy_dicts.") for k in moved)
+    assert any(k.startswith("target_net.") for k in moved)                                    # soft update at step 120
+    assert sorted(trainer._update_graphs) == ["policy", "value"]                             # graphed sub-updates ran
+    assert model._rollout_graph.graph is not None                                            # graphed rollout ran
+    assert not util.FALLBACKS, util.FALLBACKS
+    # graph replay == eager launches, from the same state on the same window
+    snap = copy.deepcopy(model.state_dict())
+    osnap = (copy.deepcopy(trainer.value_optimizer.state_dict()), copy.deepcopy(trainer.policy_optimizer.state_dict()))
+    rs = np.random.get_state()
+    s1 = {}
+    trainer.value_replay_process(s1)
+    trainer.policy_replay_process(s1)
+    th.cuda.synchronize()
+    graphed = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(snap)
+    trainer.value_optimizer.load_state_dict(osnap[0])
+    trainer.policy_optimizer.load_state_dict(osnap[1])
+    np.random.set_state(rs)
+    trainer.graph_updates = False
+    s2 = {}
+    trainer.value_replay_process(s2)
+    trainer.policy_replay_process(s2)
+    th.cuda.synchronize()
+    for k, v in model.state_dict().items():
+        if v.is_floating_point():
+            assert th.allclose(v, graphed[k], atol=1e-6, rtol=1e-5), k
+    for k in ("mean_train_value_loss", "mean_train_policy_loss", "mean_train_value_grad_norm", "mean_train_policy_grad_norm"):
+        assert abs(float(s1[k]) - float(s2[k])) <= 1e-5 * max(1.0, abs(float(s2[k]))), (k, float(s1[k]), float(s2[k]))

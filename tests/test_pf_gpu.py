@@ -202,3 +202,53 @@ def test_full_size_batch_satisfies_reference_constraints(net, base_loads):
         worst = max(worst, np.abs(vs[:, par[b]] - 2 * (t.r[b] * pl[:, b] + t.x[b] * ql[:, b])
                                   - (t.r[b] ** 2 + t.x[b] ** 2) * isq[:, b] - vs[:, b]).max())
     assert worst < 1e-11
+
+
+def test_hip_power_flow_against_the_reference_nlp_statement(net, base_loads):
+    """The shortest chain to utils/pf.py this container allows: the HIP solvers (pf_solve_batch through the C ABI, all
+    three: tree-Newton, sweeps, dense LU) against oracle/pf_nlp_oracle.ReferenceNLP — the variables, bounds, objective and
+    constraints of pf.py:39-94 written out verbatim and solved by SciPy's SLSQP from the start point Pyomo + IPOPT use —
+    on the run_pf.py:37-54 inputs, the base case, heavy load, reverse flow and 8 random cases.  (a) voltages, line flows
+    and squared currents agree <= 1e-8 (SLSQP's own accuracy; north_star's bar is 1e-6); (b) the HIP result, put into the
+    NLP's variables, satisfies every constraint of pf.py:65-94 to 1e-11 — no solver in between."""
+    from oracle.pf_nlp_oracle import ReferenceNLP
+    from safe_marl_amd.network import build_tables
+    p, q = base_loads
+    rng = np.random.default_rng(44)
+    buses = net["bus_numbers"]
+    blds = [buses.index(b) for b in net["buildings"]]
+    run_pf_p = np.array([0.0 if net["bus_types"][b] == 1 else 0.1 for b in buses])
+    run_pf_p[blds] -= 0.05 + 0.075 - 0.005                                   # Pred, Ppv, -Pesc of run_pf.py:37-54
+    run_pf_q = np.array([0.0 if net["bus_types"][b] == 1 else 0.005 for b in buses])
+    cases = [("run_pf", run_pf_p, run_pf_q), ("base", p, q), ("heavy", 1.5 * p, 1.5 * q),
+             ("reverse", p - 0.25 * (np.arange(len(p)) > 0) * rng.uniform(0.5, 1.0, len(p)), 0.3 * q)]
+    for _ in range(8):
+        cases.append(("random", p * rng.uniform(0.0, 1.6, len(p)), q * rng.uniform(-0.5, 1.6, len(p))))
+    P = np.stack([c[1] for c in cases])
+    Q = np.stack([c[2] for c in cases])
+    t = build_tables(net)
+    lines = list(net["line_connections"])
+    bus_of_line = [next(b for b in range(t.n_bus) if t.line_of_bus[b] == l) for l in lines]      # receiving bus of line l
+    nlp = [ReferenceNLP(net, P[i], Q[i]) for i in range(len(cases))]
+    ref = [m.solve("SLSQP") for m in nlp]
+    for i, r in enumerate(ref):
+        assert r["residual"] < 1e-10 and r["vm"].min() > 0.8, (cases[i][0], r["residual"])
+    for solver in (0, 2, 3):
+        out = _solve(net, P, Q, want_branch=(solver != 3), solver=solver)
+        assert out["failed"].sum() == 0
+        for i, (name, _, _) in enumerate(cases):
+            assert np.abs(out["v"][i] - ref[i]["vm"]).max() < 1e-8, (solver, name)
+            if solver == 3:
+                continue
+            pl, ql, isq = out["pl"][i][bus_of_line], out["ql"][i][bus_of_line], out["isqr"][i][bus_of_line]
+            assert np.abs(pl - ref[i]["Pl"]).max() < 1e-8 and np.abs(ql - ref[i]["Ql"]).max() < 1e-8, (solver, name)
+            assert np.abs(isq - ref[i]["Isqr"]).max() < 1e-8, (solver, name)
+            # (b) HIP result in the NLP's variables: [Vsqr (non-slack) | Pl | Ql | Isqr | Ps | Qs]
+            m = nlp[i]
+            vs = out["v"][i] ** 2
+            fr_slack = m.fr == m.slack
+            ps = (pl + m.R * isq)[fr_slack].sum() + P[i][m.slack]             # what the slack must supply (pf.py:65-72)
+            qs = (ql + m.X * isq)[fr_slack].sum() + Q[i][m.slack]
+            x = np.concatenate([vs[m.free_v], pl, ql, isq, [ps, qs]])
+            assert np.abs(m.constraints(x)).max() < 1e-11, (solver, name, np.abs(m.constraints(x)).max())
+            assert (x >= m.lb).all()

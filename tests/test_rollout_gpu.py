@@ -408,9 +408,9 @@ def test_bursts_of_steps_equal_single_steps_bit_for_bit(fast):
     # below the ring's eight slabs — the comparison above is that launch against single policy + environment launches)
     assert a.fused_burst == fast
     if fast:       # every length is a graph of its own, recorded at first use here (capture() was given no schedule):
-        assert sorted(a.bursts) == [2, 3, 7] and not b.bursts          # 31 = 4 x 7 + 3, 7, 16 = 7 + 7 + 2 under an 8-slab ring
+        assert sorted(k for k, _ in a.bursts) == [2, 3, 7] and not b.bursts          # 31 = 4 x 7 + 3, 7, 16 = 7 + 7 + 2 under an 8-slab ring
     else:
-        assert sorted(a.bursts) == [2, 4, 8, 16] == sorted(b.bursts)
+        assert sorted(k for k, _ in a.bursts) == [2, 4, 8, 16] == sorted(k for k, _ in b.bursts)
     assert a.env.calls == calls                                # replays never go through env.step; recording is undone
 
 

@@ -273,3 +273,47 @@ def test_bootstrap_values_filed_once_per_event_change_nothing(pipelined, episode
     m.replay_event({}, 10, 1)
     torch.cuda.synchronize()
     assert m.bootstrap_cached_events == 0 and not m._cached_graphs
+
+
+@pytest.mark.parametrize("which", ["value", "value_cached"])
+def test_a_failed_capture_leaves_weights_optimiser_state_and_statistics_untouched(which, monkeypatch):
+    """the warm-up steps a capture needs are REAL optimiser steps; whatever ends the capture — here an exception
+    injected into the captured region itself, after the warm-up has run — they are undone (try / finally), so the eager
+    fallback ("value") and the fall-back to per-sub-update bootstrap values ("value_cached") start from the weights, RMSprop
+    state and reward-BatchNorm running statistics the schedule of model.py:43-50 had reached."""
+    import warnings
+    from safe_marl_amd import util
+    tr = _trainer(True, 256)
+    if which == "value_cached":
+        tr.batch_scale = 256
+    net = tr.behaviour_net
+    # (the optimiser state exists already: one eager value step)
+    np.random.seed(5)
+    tr._sub_update("value", {}, tr.replay_buffer.get_batch_tensors(tr.effective_batch_size()))
+    before = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    opt_before = [tr.value_optimizer.state[p]["square_avg"].clone() for p in tr.value_optimizer.param_groups[0]["params"]]
+    real, calls = util.graph_capture.__enter__, []
+
+    def failing_enter(self):
+        calls.append(1)
+        raise RuntimeError("injected: capture refused")
+
+    monkeypatch.setattr(util.graph_capture, "__enter__", failing_enter)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        g = tr._ensure_graph(which)
+    monkeypatch.setattr(util.graph_capture, "__enter__", real)
+    torch.cuda.synchronize()
+    assert g is None and calls and any("capture" in str(x.message) for x in w)
+    assert tr.graph_updates == (which == "value_cached") and tr.cache_bootstrap == (which != "value_cached")
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), k                     # incl. batchnorm.running_mean / running_var / num_batches_tracked
+    for p, sq in zip(tr.value_optimizer.param_groups[0]["params"], opt_before):
+        assert torch.equal(tr.value_optimizer.state[p]["square_avg"], sq)
+    assert net.bootstrap_from_batch is False
+    # and the trainer still trains: the next sub-update runs (eagerly, or as a graph on freshly computed bootstrap values)
+    st = {}
+    tr.value_replay_process(st)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(st["mean_train_value_loss"]))
+    assert any(not torch.equal(v, before[k]) for k, v in net.state_dict().items() if k.startswith("value_dicts."))
