@@ -73,6 +73,8 @@ def parse_args():
     ap.add_argument("--pf-tol", type=float, default=1e-12, help="power-flow convergence threshold (inf-norm power "
                     "mismatch, pu); 1e-12 is the headline setting, the parity bar is 1e-6 on voltages and rewards")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--stacked-obs", action="store_true",
+                    help="get_obs() as a stacked [n_agents, 6 * history] copy per step (the round-3 kernel) instead of the row push")
     ap.add_argument("--solver", choices=["sweep", "newton"], default="sweep",
                     help="sweep: backward/forward sweeps + Newton verification; newton: NR with tree elimination")
     return ap.parse_args()
@@ -326,16 +328,22 @@ def learner_rooflines():
     out.append(critic_backward_roofline(timed))
     N, bs = 4096, 32768
     buf = TransReplayBuffer(N * 24, device="cuda")
-    buf.alloc_slabs(N, 5, 144, 4, 64)
-    buf.k, buf.first = 20, 0
+    buf.alloc_slabs(N, 5, 144, 4, 64, history=24)          # row mode: the layout the fused rollout writes
+    buf.row_ring.normal_()
+    buf.row_ring.view(buf.slabs, N, 5, buf.ROW_W)[..., 6] = 23.0
+    buf.k, buf.first = 40, 23
     win = torch.zeros(bs + N, 720, device="cuda")
     hidw = torch.zeros(bs, 320, device="cuda")
-    plan = [("obs_ring", 0, None, 0, bs + N, win), ("hid_ring", 0, None, N, bs, hidw)]
-    t = timed(lambda: buf.gather(plan, 2 * N + 17))
-    moved = 4.0 * ((bs + N) * 720 + bs * 320)
-    out.append({"kernel": "gather_rows_kernel", "what": "replay window -> static batch of a value sub-update", "bound": "hbm",
-                "achieved": 2.0 * moved / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 2.0 * moved / t / 1e9 / HBM_PEAK_GBS,
-                "launch_us": t * 1e6, "note": "bytes read + written"})
+    plan = [(buf.obs_source_ring, 0, None, 0, bs + N, win), ("hid_ring", 0, None, N, bs, hidw)]
+    t = timed(lambda: buf.gather(plan, 25 * N + 17))
+    # algorithmic bytes: every feature row of the window's reach once in (window + 23 + 1 slabs of 32-byte records), the
+    # stacked static batch out, the hidden block in and out
+    moved = 4.0 * ((bs + N) * 720 + 2 * bs * 320) + 32.0 * 5 * (bs + N + 23 * N)
+    out.append({"kernel": "gather_window_kernel + gather_rows_kernel",
+                "what": "replay window -> static batch of a value sub-update: stacked observations formed from the row ring "
+                        "(the gather is the im2col), hidden states copied", "bound": "hbm",
+                "achieved": moved / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / t / 1e9 / HBM_PEAK_GBS,
+                "launch_us": t * 1e6, "note": "bytes read (each row record once) + written"})
     return out
 
 
@@ -481,7 +489,8 @@ def roofline_details(a, env, kern_ms):
     epw = 2 if env.n_bus - 1 <= 32 else 1
     lw = 64 // epw
     small = env.n_agents == 5 and 3 * env.history <= (3 if epw == 2 else 2) * lw
-    want = f"flex_step_kernel<{epw}, float, float, {5 if small else 8}, false>"
+    want = (f"flex_step_kernel<{epw}, float, float, {5 if small else 8}, false, false>" if a.stacked_obs else
+            f"flex_step_kernel<{epw}, float, float, 5, false, true>")
     res = [v for v in build.kernel_resources("flex_step_kernel<").values() if v.get("name") == want]
     out["kernel"] = want
     waves = (a.envs + epw - 1) // epw
@@ -505,7 +514,7 @@ def roofline_details(a, env, kern_ms):
     if t.get("source_digest") != build.built_digest():
         out["counters_stale"] = "counter passes were taken on another build (source digest differs)"
         return out
-    if int(t.get("envs_per_launch", -1)) != a.envs or a.solver != "sweep":
+    if int(t.get("envs_per_launch", -1)) != a.envs or a.solver != "sweep" or want not in (t.get("kernel") or []):
         out["counters_stale"] = "counter passes were taken at another batch size / solver"
         return out
     out["traffic"] = t.get("flex_step_kernel_bytes_per_launch")
@@ -586,8 +595,14 @@ def main():
     env.reset()
 
     def one_step(k):
-        # ONE launch: step + get_obs; envs that terminate restart inside the same launch (FLEX_STEP_AUTORESET)
-        env.step(pool[k % ACTION_POOL], fuse_obs=True, auto_reset=True)
+        # ONE launch: step + get_obs; envs that terminate restart inside the same launch (FLEX_STEP_AUTORESET).  get_obs() is
+        # the ROW PUSH of round 4 (FLEX_STEP_OBS_ROWS): the step appends its 6-feature row per agent to the env's history, where
+        # the policy kernels read the stacked [5, 144] observation in place; `--stacked-obs` times the round-3 form (a stacked
+        # copy per step) instead, and `stacked_sibling` in the JSON line carries that figure either way
+        if a.stacked_obs:
+            env.step(pool[k % ACTION_POOL], fuse_obs=True, auto_reset=True)
+        else:
+            env.step(pool[k % ACTION_POOL], obs_rows=True, auto_reset=True)
 
     # The loop is launch-issue sensitive (9 us of Python + ctypes per launch against a 14 us kernel), so consecutive steps
     # are captured as HIP graphs and replayed: blocks of ACTION_POOL steps plus ONE graph for the remainder (K mod 16); a
@@ -685,7 +700,7 @@ def main():
     torch.cuda.synchronize()
     for k, (s, e) in enumerate(evs):
         s.record()
-        env.step(pool[k % ACTION_POOL], fuse_obs=True, auto_reset=True)
+        one_step(k)
         e.record()
     torch.cuda.synchronize()
     durs = sorted(s.elapsed_time(e) for s, e in evs)
@@ -741,6 +756,49 @@ def main():
         except Exception as exc:
             print(f"[bench] rank {rank}: solver sibling leg failed: {exc!r}", file=sys.stderr)
 
+    # sibling figure with the OTHER observation form (stacked copy per step <-> row push): same step, same inputs
+    obs_sibling = None
+    if not a.no_sustained:
+        try:
+            env3 = VecFlexProvisionEnv({}, a.envs, device=f"cuda:{local_rank}", net=net, series=series,
+                                       seed=1234 + 1000 * rank, warm_start=bool(a.warm_start), pf_tol=a.pf_tol,
+                                       solver={"sweep": 2, "newton": 0}[a.solver])
+            env3.reset()
+            kw3 = dict(obs_rows=True) if a.stacked_obs else dict(fuse_obs=True)
+
+            def step3(k):
+                env3.step(pool[k % ACTION_POOL], auto_reset=True, **kw3)
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step3(0)
+            torch.cuda.current_stream().wait_stream(side)
+            g3 = torch.cuda.CUDAGraph()
+            with graph_capture(g3):
+                for j in range(ACTION_POOL):
+                    step3(j)
+            for _ in range(8):
+                g3.replay()
+            n3 = 1024
+            barrier()
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t3 = time.perf_counter()
+            q0.record()
+            for _ in range(n3 // ACTION_POOL):
+                g3.replay()
+            q1.record()
+            barrier()
+            el3 = max_over_ranks(time.perf_counter() - t3)
+            ms3 = q0.elapsed_time(q1) / n3
+            b3 = B_ALG_CORE if a.stacked_obs else B_ALG_WITH_OBS
+            obs_sibling = {"observation": "row push (FLEX_STEP_OBS_ROWS)" if a.stacked_obs else "stacked [n_agents, 6 * history] fp32 copy per step (round-3 form)",
+                           "steps": n3, "value": a.envs * world * n3 / el3, "unit": "env-steps/s", "device_ms_per_step": ms3,
+                           "algorithmic_bytes_per_env_step": b3, "frac": b3 * a.envs / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del env3, g3
+        except Exception as exc:
+            print(f"[bench] rank {rank}: observation-form sibling leg failed: {exc!r}", file=sys.stderr)
+
     # training legs LAST: the headline (which the scaling curve is computed from) is already measured if a leg fails; every
     # rank takes part — with N > 1 the gradient bucket goes through RCCL — and a failure is recorded, not fatal
     train = None
@@ -774,7 +832,10 @@ def main():
 
     if rank == 0:
         total_env_steps = a.envs * world * a.steps
-        achieved = B_ALG_WITH_OBS * a.envs / (kern_ms * 1e-3) / 1e9
+        # algorithmic bytes per env-step of the kernel AS IT RUNS: 1 340 B with get_obs() as a row push (the 240 B
+        # of new observation features are the two fp32 mirror rows), 4 220 B when the stacked fp32 observation is materialised
+        b_alg = B_ALG_WITH_OBS if a.stacked_obs else B_ALG_CORE
+        achieved = b_alg * a.envs / (kern_ms * 1e-3) / 1e9
         roof_extra = roofline_details(a, env, kern_ms)
         out = {
             # BASELINE.json's metric string verbatim; the "+ PF-kernel HBM GB/s" half is `roofline.achieved`
@@ -792,8 +853,11 @@ def main():
             "data": "synthetic (stand-in IEEE-33 Baran-Wu network, SURVEY.md App. C; generated series, SURVEY.md §8d)",
             "config": {
                 "workload": ("flex_provision.step()+get_obs() batched, %d envs/GPU, 33-bus AC power flow, 5 agents, in-launch "
-                             "auto-reset; solver: %s, inf-norm power mismatch < %g pu") % (
+                             "auto-reset; get_obs(): %s; solver: %s, inf-norm power mismatch < %g pu") % (
                                  a.envs,
+                                 "stacked [5, 144] fp32 copy per step" if a.stacked_obs else
+                                 "row push — the step appends its [5, 6] feature row to the env's observation history (mirror ring); "
+                                 "consumers read the stacked [5, 144] window in place (policy kernels) or via flexenv_obs_view",
                                  "backward/forward sweeps (fp64 anchor sweeps, fp32 increment sweeps between them) + fp64 Newton "
                                  "verification of the Ybus mismatch (%.3g Newton steps, %.2f sweeps per solve)" % (iters_mean, sweeps_mean)
                                  if a.solver == "sweep" else
@@ -808,12 +872,15 @@ def main():
             "roofline": dict({
                 "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                # the same launch time against SURVEY.md 8(d)'s core bytes (no stacked observation): reported next to `frac`
-                # so that the figure stays comparable whatever form the observation leaves the kernel in
-                "frac_core_bytes": B_ALG_CORE * a.envs / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_env_step": B_ALG_WITH_OBS, "algorithmic_bytes_per_env_step_no_obs": B_ALG_CORE,
+                "algorithmic_bytes_per_env_step": b_alg,
+                # the SAME launch time priced at the other byte convention of SURVEY.md 8(d), so that the figure stays
+                # comparable across rounds (rounds 1-3 materialised the stacked observation and quoted 4 220 B: 0.154 / 0.159 /
+                # 0.164); `stacked_sibling` below is the kernel that really moves those bytes, timed in this run
+                "frac_at_4220_bytes": B_ALG_WITH_OBS * a.envs / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "frac_at_1340_bytes": B_ALG_CORE * a.envs / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "avg_launch_ms": kern_ms, "bracketed_launch_ms": durs[len(durs) // 2],
             }, **roof_extra),
+            "stacked_sibling" if not a.stacked_obs else "rows_sibling": obs_sibling,
             "sustained": sustained,
             "solver_sibling": sibling,
             "train": train,

@@ -149,10 +149,20 @@ int flexenv_reset(FlexEnv* env, const uint8_t* mask /*dev [N] or NULL*/, const R
  * into the same launch. */
 #define FLEX_STEP_AUTORESET 1   /* an env that terminates in this step restarts (Philox stream) inside the same
                                   launch; its `obs` row then holds the FIRST observation of the new episode */
-#define FLEX_STEP_OBS_RING 2    /* `obs` is the BASE of the slab ring registered with flexenv_set_obs_ring: this launch writes its
-                                  observations into slab (cursor[0] + 1) mod slabs, read on the device (replayable HIP graph) */
+#define FLEX_STEP_OBS_RING 2    /* implies FLEX_STEP_OBS_ROWS; `obs` is the BASE of the ROW ring registered with flexenv_set_obs_ring:
+                                  this launch also writes one record per (env, agent) into slab (cursor[0] + 1) mod slabs,
+                                  read on the device (replayable HIP graph):
+                                      [Pd, Qd, Ppv, V, price, E, older, 0]   (FLEX_ROW_FLOATS fp32)
+                                  the step's feature row (env:377-382) and `older` = min(rows pushed before it in its
+                                  episode, history - 1): the stacked observation of env:387-401 at that slab is the rows
+                                  of the `older` slabs before it, this one, and zeros in front */
 #define FLEX_STEP_REPLAY_SINK 4 /* with FLEX_STEP_OBS_RING: the launch also files this step's transition in the consumer's slab ring
                                   (flexenv_set_replay_sink) — no bookkeeping launch follows the step */
+#define FLEX_STEP_OBS_ROWS 8    /* get_obs() as a ROW PUSH: the step appends its feature row (120 B per env) to the env's
+                                  observation history and writes no stacked copy; `obs` is ignored.  Consumers read the
+                                  stacked observation in place (flexenv_obs_source: the policy kernels of include/flexnet.h
+                                  do) or materialise it with flexenv_obs_view.  Same history, same values as `obs` non-NULL. */
+#define FLEX_ROW_FLOATS 8
 int flexenv_step(FlexEnv* env, const void* actions, int32_t act_dtype,
                  double* reward /*dev [N]*/, uint8_t* done /*dev [N]*/,
                  double* info /*dev [N, FLEX_INFO_W] or NULL*/, uint8_t* failed /*dev [N] or NULL*/,
@@ -160,6 +170,21 @@ int flexenv_step(FlexEnv* env, const void* actions, int32_t act_dtype,
 
 /* Replaces get_obs() (env:370-403): stateful, appends to the history on every call. */
 int flexenv_obs(FlexEnv* env, void* obs /*dev [N, n_agents, 6*history]*/, int32_t obs_dtype, void* stream);
+
+/* The stacked observation as the last push left it (env:387-401), WITHOUT appending to the history: flexenv_step(...,
+ * FLEX_STEP_OBS_ROWS) followed by flexenv_obs_view writes what flexenv_step(..., obs) writes. */
+int flexenv_obs_view(FlexEnv* env, void* obs /*dev [N, n_agents, 6*history]*/, int32_t obs_dtype, void* stream);
+/* Where the observation history lives, for consumers that read it in place.  Row r = env * n_agents + agent owns
+ * `row_stride` floats at ring + r * row_stride: 2 * slots slots of slot_w floats, a MIRROR ring — the k-th row pushed in an
+ * episode sits in slots k mod slots and slots + k mod slots, slots 1 .. slots-1 are zeroed at every episode start — so
+ * with c = pushed[env * pushed_stride] (rows pushed so far, >= 1) the stacked observation is the slots * slot_w
+ * CONTIGUOUS floats starting at float ((c - 1) mod slots + 1) * slot_w of the row.  Device pointers owned by the handle. */
+typedef struct {
+    const float* ring;
+    const int32_t* pushed;
+    int32_t row_stride, pushed_stride, slots, slot_w;
+} FlexObsSource;
+int flexenv_obs_source(const FlexEnv* env, FlexObsSource* out);
 
 /* Replaces get_state() (env:358-368): [Pd | Qd | Ppv | V | price | E]. */
 int flexenv_state(FlexEnv* env, double* state /*dev [N, 3*n_bus + 2*n_agents + 1]*/, void* stream);
@@ -176,10 +201,10 @@ int32_t flexenv_num_envs(const FlexEnv* env);
  * — the replay ring cursor of flexnet_rollout_pack (include/flexnet.h) — follow the steps of a replayed HIP graph
  * without a launch of its own. */
 int flexenv_set_step_counter(FlexEnv* env, int64_t* counter, int64_t modulo);
-/* Observation ring for FLEX_STEP_OBS_RING: `cursor` (device int64, caller-owned, never written by this library) holds the
- * slab the consumer is reading; a step writes slab (cursor[0] + 1) mod slabs of a ring whose slabs are
- * `slab_stride` elements apart — the observation lands where the replay keeps it, once, and nothing copies it again.
- * slabs = 0 switches it off. */
+/* Row ring for FLEX_STEP_OBS_RING: `cursor` (device int64, caller-owned, never written by this library) holds the
+ * slab the consumer is reading; a step writes slab (cursor[0] + 1) mod slabs of a ring [slabs][N][n_agents][FLEX_ROW_FLOATS]
+ * whose slabs are `slab_stride` floats apart (>= N * n_agents * FLEX_ROW_FLOATS) — every feature row is stored once, where
+ * the replay keeps it; a stacked observation is never copied.  slabs = 0 switches it off. */
 int flexenv_set_obs_ring(FlexEnv* env, const int64_t* cursor, int64_t slab_stride, int32_t slabs);
 /* Replay sink for FLEX_STEP_REPLAY_SINK (madrl/models/model.py:230-262 + utils/replay_buffer.py:23-27 inside the step
  * launch): with p = the obs-ring cursor and p' = (p + 1) mod slabs, every environment e of the launch writes

@@ -82,6 +82,13 @@ typedef struct {
     float* save_hn;
     int64_t ring_slabs;        /* flexenv_rollout_burst only (include/flexenv.h): slabs of the two input rings, for the wrap of
                                   the slab index from one step of the burst to the next; 0 elsewhere */
+    /* Observations read IN PLACE from an environment's history (include/flexenv.h: flexenv_obs_source; FLEX_STEP_OBS_ROWS):
+     * with obs_pushed non-NULL row r's observation is the obs_dim CONTIGUOUS floats at
+     *     obs + r * obs_row_stride + ((obs_pushed[(r / n_agents) * obs_pushed_stride] - 1) mod obs_slots + 1) * obs_slot_w
+     * (the last obs_slots rows of a mirror ring: no wrap, zeros where the episode had not begun) instead of obs + r * obs_dim;
+     * `cursor` / the slab strides then apply to hidden_in only.  obs_slots * obs_slot_w == obs_dim. */
+    const int32_t* obs_pushed; /* device, or NULL: obs is [rows, obs_dim] */
+    int32_t obs_row_stride, obs_pushed_stride, obs_slots, obs_slot_w;
 } FlexActorArgs;
 
 /* rnn_agent.py:25-33 + model.py:102-116 for all rows. */
@@ -408,6 +415,22 @@ typedef struct {
 } FlexAgentSumArgs;
 
 int flexnet_agent_sum_explore(const FlexAgentSumArgs* args, void* stream);
+
+/* Stacked observations of a replay window out of the ROW ring (include/flexenv.h: FLEX_STEP_OBS_RING) — the gather of the
+ * window IS the im2col: the replay keeps every feature row once, [slabs][N][n_agents][FLEX_ROW_FLOATS] =
+ * [Pd, Qd, Ppv, V, price, E, older, 0], and output row i (global slot first_slot + i: slab (slot / N) mod slabs, environment
+ * slot mod N) becomes env:387-401's [n_agents, 6 * history] observation of that slab:
+ *     dst[i][a][h * 6 + f] = row_ring[slab - (history - 1 - h)][env][a][f]   if history - 1 - h <= older(slab, env, a)
+ *                          = 0                                              otherwise (before the episode began)
+ * (slab indices modulo `slabs`).  The caller keeps the history - 1 slabs behind every window it asks for intact. */
+typedef struct {
+    const float* row_ring;
+    float* dst;                /* out [rows, n_agents * 6 * history], 8-byte aligned */
+    int64_t rows;
+    int64_t first_slot;
+    int32_t n_envs, n_agents, history, slabs;
+} FlexWindowArgs;
+int flexnet_gather_window(const FlexWindowArgs* args, void* stream);
 
 /* Replay-window refresh: up to FLEXNET_GATHER_MAX_JOBS strided row copies in one launch.  A sampled window of the slab
  * ring (utils/replay_buffer.py:17-21: consecutive transitions) becomes the contiguous static batch a captured sub-update

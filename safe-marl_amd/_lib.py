@@ -19,6 +19,8 @@ FLEX_F64, FLEX_F32 = 0, 1
 FLEX_STEP_AUTORESET = 1
 FLEX_STEP_OBS_RING = 2
 FLEX_STEP_REPLAY_SINK = 4
+FLEX_STEP_OBS_ROWS = 8
+FLEX_ROW_FLOATS = 8
 FLEX_SOLVER_TREE, FLEX_SOLVER_DENSE, FLEX_SOLVER_SWEEP = 0, 1, 2
 
 PEEK = dict(V=0, E=1, E_INIT=2, PRED=3, CH=4, DIS=5, QPV=6, PCT=7, CUMREW=8, STEPS=9, ROW=10, START=11,
@@ -67,11 +69,11 @@ class ResetSpec(C.Structure):
 
 # every symbol include/flexenv.h declares
 SYMBOLS = (
-    "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_state",
+    "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_obs_view", "flexenv_obs_source", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_rollout_burst", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_td_stats", "flexnet_critic_td_backward",
-    "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gru_backward",
+    "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gather_window", "flexnet_gru_backward",
 )
 
 class FlexActorArgs(C.Structure):
@@ -84,7 +86,20 @@ class FlexActorArgs(C.Structure):
                 ("rng_state", C.c_void_p), ("cursor", C.c_void_p), ("obs_slab_stride", C.c_int64),
                 ("hid_slab_stride", C.c_int64), ("cursor_out", C.c_void_p)] + \
                [(k, C.c_void_p) for k in ("save_z1", "save_x", "save_r", "save_z", "save_n", "save_hn")] + \
-               [("ring_slabs", C.c_int64)]
+               [("ring_slabs", C.c_int64), ("obs_pushed", C.c_void_p), ("obs_row_stride", C.c_int32),
+                ("obs_pushed_stride", C.c_int32), ("obs_slots", C.c_int32), ("obs_slot_w", C.c_int32)]
+
+
+class FlexObsSource(C.Structure):
+    """include/flexenv.h"""
+    _fields_ = [("ring", C.c_void_p), ("pushed", C.c_void_p), ("row_stride", C.c_int32), ("pushed_stride", C.c_int32),
+                ("slots", C.c_int32), ("slot_w", C.c_int32)]
+
+
+class FlexWindowArgs(C.Structure):
+    """include/flexnet.h"""
+    _fields_ = [("row_ring", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int64), ("first_slot", C.c_int64),
+                ("n_envs", C.c_int32), ("n_agents", C.c_int32), ("history", C.c_int32), ("slabs", C.c_int32)]
 
 
 class FlexBurstSafety(C.Structure):
@@ -293,6 +308,12 @@ def load():
     lib.flexenv_step.restype = C.c_int
     lib.flexenv_obs.argtypes = [vp, vp, i32, vp]
     lib.flexenv_obs.restype = C.c_int
+    lib.flexenv_obs_view.argtypes = [vp, vp, i32, vp]
+    lib.flexenv_obs_view.restype = C.c_int
+    lib.flexenv_obs_source.argtypes = [vp, C.POINTER(FlexObsSource)]
+    lib.flexenv_obs_source.restype = C.c_int
+    lib.flexnet_gather_window.argtypes = [C.POINTER(FlexWindowArgs), vp]
+    lib.flexnet_gather_window.restype = C.c_int
     lib.flexenv_state.argtypes = [vp, vp, vp]
     lib.flexenv_state.restype = C.c_int
     lib.flexenv_peek.argtypes = [vp, i32, vp, vp]

@@ -80,7 +80,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 __global__ __launch_bounds__(64 * AW, 1) void actor_forward_kernel(FlexActorArgs a) {
     __shared__ ActorLds s;
-    if (a.cursor) { const int64_t p = *a.cursor; a.obs += p * a.obs_slab_stride; a.hidden_in += p * a.hid_slab_stride; }
+    if (a.cursor) { const int64_t p = *a.cursor; if (!a.obs_pushed) a.obs += p * a.obs_slab_stride; a.hidden_in += p * a.hid_slab_stride; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int od = a.obs_dim, na = a.n_agents, ad = a.act_dim;
     const int ld1 = od + (a.agent_id ? na : 0);
@@ -114,9 +114,9 @@ __global__ __launch_bounds__(64 * AW, 1) void actor_forward_kernel(FlexActorArgs
     const int n_tiles = (a.rows + RT - 1) / RT;
     for (int tile = wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * AW) {
         const int r0 = tile * RT;
-        int row[RT];
+        int row[RT], xo[RT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) row[r] = min(r0 + r, a.rows - 1);             // spare rows of the last tile recompute a valid one
+        for (int r = 0; r < RT; ++r) { row[r] = min(r0 + r, a.rows - 1); xo[r] = actor_obs_off(a, row[r]); }   // spare rows of the last tile recompute a valid one
         // ---- fc1: acc[r] = sum_i W1[j][i] obs[r][i], inputs staged KC columns at a time ----------------------
         float acc[RT];
 #pragma unroll
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64 * AW, 1) void actor_forward_kernel(FlexActorArgs
             const int kc = min(KC, od - c0);
             float v[RT];
 #pragma unroll
-            for (int r = 0; r < RT; ++r) v[r] = lane < kc ? a.obs[(int64_t)row[r] * od + c0 + lane] : 0.0f;
+            for (int r = 0; r < RT; ++r) v[r] = lane < kc ? a.obs[xo[r] + c0 + lane] : 0.0f;
             st_rows(st + lane * RT, v);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll UNR
@@ -242,7 +242,8 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
     ASTAMP(0);
     if (a.cursor) {
         const int64_t p = *a.cursor;
-        a.obs += p * a.obs_slab_stride; a.hidden_in += p * a.hid_slab_stride;
+        if (!a.obs_pushed) a.obs += p * a.obs_slab_stride;
+        a.hidden_in += p * a.hid_slab_stride;
         if (a.cursor_out && blockIdx.x == 0 && threadIdx.x == 0) *a.cursor_out = p;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
     // end of the previous tile's fc1: the load latency never sits at the head of a tile.
     typedef float v4f_ __attribute__((ext_vector_type(4)));
     constexpr int QB = 6;
-    const int64_t obs_bytes = (int64_t)a.rows * od * 4;
+    const int64_t obs_bytes = actor_obs_bytes(a);
     const __amdgpu_buffer_rsrc_t robs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.obs), 0, obs_bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)obs_bytes, 0x00027000);
     const int nq = (od + 7) >> 3;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
     int tile = wave * gridDim.x + blockIdx.x;
     v4f_ xc[QB];
     {
-        const int xoff0 = (min(tile * 32 + rb, a.rows - 1) * od + 4 * hf) * 4;
+        const int xoff0 = (actor_obs_off(a, min(tile * 32 + rb, a.rows - 1)) + 4 * hf) * 4;
 #pragma unroll
         for (int e = 0; e < QB; ++e)
             xc[e] = __builtin_bit_cast(v4f_, __builtin_amdgcn_raw_buffer_load_b128(
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
         // MFMA step (q, j) is (8q + j, 8q + 4 + j), as in the layers behind — so the observation goes from row-major memory
         // straight into B operands: no LDS hand-over, no barriers.  Six groups (24 registers) in flight, the next six
         // requested before the current ones are multiplied.
-        const int xoff = (row * od + 4 * hf) * 4;
+        const int xoff = (actor_obs_off(a, row) + 4 * hf) * 4;
         v4f_ xn[QB];
         for (int q0 = 0; q0 < nq; q0 += QB) {
 #pragma unroll
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(64 * MW, 2) void actor_forward_mfma_kernel(FlexActo
         }
         {   // the NEXT tile's first six groups go out now and land underneath LayerNorm and the GRU
             const int nt = tile + gridDim.x * MW;
-            const int nxoff = (min(nt * 32 + rb, a.rows - 1) * od + 4 * hf) * 4;
+            const int nxoff = (actor_obs_off(a, min(nt * 32 + rb, a.rows - 1)) + 4 * hf) * 4;
 #pragma unroll
             for (int e = 0; e < QB; ++e)
                 xc[e] = __builtin_bit_cast(v4f_, __builtin_amdgcn_raw_buffer_load_b128(
@@ -585,8 +586,13 @@ extern "C" int flexnet_actor_forward(const FlexActorArgs* a, void* stream) {
     if (a->obs_dim < 1 || a->obs_dim > FLEXNET_MAX_OBS || a->n_agents < 1 || a->n_agents > FLEXNET_MAX_AGENTS ||
         a->act_dim < 1 || a->act_dim > FLEXNET_MAX_ACT)
         return FLEXNET_EUNSUPPORTED;
+    if (a->obs_pushed) {                                  // observations read in place from an environment's history
+        if (a->obs_slots < 1 || a->obs_slot_w < 1 || a->obs_slots * a->obs_slot_w != a->obs_dim || a->obs_pushed_stride < 1 ||
+            a->obs_row_stride < 2 * a->obs_dim || a->rows % a->n_agents != 0) return FLEXNET_EINVAL;
+        if ((int64_t)a->rows * a->obs_row_stride * 4 >= 0x7ffffff0ll) return FLEXNET_EUNSUPPORTED;
+    }
     if ((int64_t)a->rows * a->obs_dim * 4 >= 0x7ffffff0ll) return FLEXNET_EUNSUPPORTED;   // observations are addressed with 32-bit byte offsets
-    if (a->cursor && (a->obs_slab_stride < (int64_t)a->rows * a->obs_dim || a->hid_slab_stride < 0)) return FLEXNET_EINVAL;
+    if (a->cursor && ((!a->obs_pushed && a->obs_slab_stride < (int64_t)a->rows * a->obs_dim) || a->hid_slab_stride < 0)) return FLEXNET_EINVAL;
     if (a->cursor_out && (!a->cursor || a->variant == 1 || a->cursor_out == a->cursor)) return FLEXNET_EINVAL;
     {
         const int saves = (a->save_z1 != nullptr) + (a->save_x != nullptr) + (a->save_r != nullptr) + (a->save_z != nullptr) +

@@ -153,6 +153,18 @@ __device__ __forceinline__ f32x4 r16_gru_tile(const float* wg_l, const float* gb
 }
 
 
+// float offset of row r's observation behind FlexActorArgs::obs: [rows, obs_dim], or — obs_pushed — the window of the
+// environment's mirror ring (include/flexnet.h)
+__device__ __forceinline__ int actor_obs_off(const FlexActorArgs& a, int row) {
+    if (!a.obs_pushed) return row * a.obs_dim;
+    const int c = a.obs_pushed[(int64_t)(row / a.n_agents) * a.obs_pushed_stride];
+    const int s = c > 0 ? (c - 1) % a.obs_slots : 0;
+    return row * a.obs_row_stride + (s + 1) * a.obs_slot_w;
+}
+__device__ __forceinline__ int64_t actor_obs_bytes(const FlexActorArgs& a) {
+    return (int64_t)a.rows * (a.obs_pushed ? a.obs_row_stride : a.obs_dim) * 4;
+}
+
 // fc1 of one 16-row tile, all 64 units (four independent chains over the observation's 16-column groups in xq), bias and
 // the agent's id column added: rnn_agent.py:26 with model.py:105-108's one-hot columns folded into w1id
 __device__ __forceinline__ void r16_fc1_tile(const float* w1_l, const float* b1_l, const float* w1id_l, const f32x4* xq, int nq,
@@ -211,7 +223,7 @@ __device__ __forceinline__ void actor_r16_body(FlexActorArgs a, ActorLds16& s) {
     __amdgpu_buffer_rsrc_t robs;
     auto load_obs = [&](int tile) {
         const int row = min(tile * 16 + j, a.rows - 1);
-        const int xoff = (row * od + 4 * g) * 4;
+        const int xoff = (actor_obs_off(a, row) + 4 * g) * 4;
 #pragma unroll
         for (int q = 0; q < FLEXNET_MAX_OBS / 16; ++q)
             xq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -277,11 +289,12 @@ __device__ __forceinline__ void actor_r16_body(FlexActorArgs a, ActorLds16& s) {
         // the first tile's observations, behind fc1's weights in the queue (what fc1 needs first) and in front of the gate
         // weights; this is where the slab cursor is first needed
         if (a.cursor) {
-            a.obs += cur_p * a.obs_slab_stride; a.hidden_in += cur_p * a.hid_slab_stride;
+            if (!a.obs_pushed) a.obs += cur_p * a.obs_slab_stride;
+            a.hidden_in += cur_p * a.hid_slab_stride;
             if (a.cursor_out && blockIdx.x == 0 && threadIdx.x == 0) *a.cursor_out = cur_p;
         }
         {
-            const int64_t obs_bytes = (int64_t)a.rows * od * 4;
+            const int64_t obs_bytes = actor_obs_bytes(a);
             robs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.obs), 0,
                                                      obs_bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)obs_bytes, 0x00027000);
         }
@@ -575,10 +588,13 @@ __device__ __forceinline__ void actor_r16_burst(const FlexActorArgs& a, ActorLds
             {
                 // (the loads of actor_r16_body: whole-slab descriptor, a 16-column group behind obs_dim reads what follows the
                 //  row — against zero weights — or zero behind the slab)
-                const int64_t obs_bytes = (int64_t)a.rows * od * 4;
+                // (ring of stacked observations: slab `slab`; in place — obs_pushed — the environment's own history, whose
+                //  push count this block's environment step left a rendezvous ago)
+                const int64_t obs_bytes = actor_obs_bytes(a);
                 const __amdgpu_buffer_rsrc_t robs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float*>(a.obs + slab * a.obs_slab_stride), 0, obs_bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)obs_bytes, 0x00027000);
-                const int xoff = (row * od + 4 * g) * 4;
+                    const_cast<float*>(a.obs + (a.obs_pushed ? 0 : slab * a.obs_slab_stride)), 0,
+                    obs_bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)obs_bytes, 0x00027000);
+                const int xoff = (actor_obs_off(a, row) + 4 * g) * 4;
 #pragma unroll
                 for (int q = 0; q < FLEXNET_MAX_OBS / 16; ++q)
                     xq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(robs, q < nq ? xoff + 64 * q : -1, 0, 0));

@@ -29,7 +29,11 @@ struct DevState {
     double* agent;     // [N, AF_COUNT, FLEX_MAX_AGENTS]
     double* cumrew;    // [N]
     int32_t* ienv;     // [N, IF_COUNT]
-    float* ring;       // [N, n_agents, history, 6]  observation history ring (env:387-401)
+    float* ring;       // [N, n_agents, 2 * history, 6]  observation history (env:387-401) as a MIRROR ring: the row pushed k-th
+                       //              in its episode sits in slots k mod H and H + k mod H, so the last H rows are always ONE
+                       //              contiguous run — slots (k mod H) + 1 .. (k mod H) + H — and the stacked observation of
+                       //              env:387-401 is that run, read in place (no rotation); slots 1 .. H-1 are zeroed at
+                       //              every episode start: the zero left-padding of SURVEY A16 is physically there
 };
 
 struct FlexEnv {
@@ -162,8 +166,8 @@ __device__ __forceinline__ void st_at2(void* base, uint32_t off, float2 v) {
 }
 __device__ __forceinline__ int clamp_row32(int r, int rows) { return r < 0 ? 0 : (r >= rows ? rows - 1 : r); }
 
-// get_obs (env:370-403): the stacked [n_agents, history*6] observation is, per agent, the ring of the last `history`
-// feature rows rotated into place, with zero left-padding (A16), plus this step's row.
+// get_obs (env:370-403): the stacked [n_agents, history*6] observation is, per agent, the last `history` feature rows
+// with zero left-padding (A16).  The environment keeps them as a mirror ring (DevState::ring): a contiguous run.
 // x mod m for small non-negative x (< 2^20): one float multiply by the host's 1/m and a correction.
 __device__ __forceinline__ int small_mod(int x, int m, float inv_m) {
     int r = x - (int)((float)x * inv_m) * m;
@@ -171,22 +175,26 @@ __device__ __forceinline__ int small_mod(int x, int m, float inv_m) {
     return r >= m ? r - m : r;
 }
 
-// History part of the stacked observation: everything except this step's own row.  It depends on nothing the solve
-// produces, so it is copied BEFORE the solve and drains to HBM underneath it.
+// Row-ring record (FLEX_STEP_OBS_RING): what a step files per (environment, agent) where the replay keeps observations —
+// the newest feature row and the number of OLDER rows of its episode that belong to its stacked observation:
+//     [Pd, Qd, Ppv, V | price, E, older, 0]        (two 16-byte stores; include/flexenv.h)
+#define FLEX_ROW_W FLEX_ROW_FLOATS
+
+// Stacked-output mode only (flexenv_step with an output buffer, no FLEX_STEP_OBS_ROWS): the history part of the stacked
+// observation — everything except this step's own row — depends on nothing the solve produces: its loads are requested
+// before the solve, its stores go out right after it.
 //
 // Work split: in float2 units an agent's block is 3*history units long; group lane l owns the units l, l+LW, l+2LW
-// of EVERY agent's block (three classes of 32 lanes, or two of 64, cover history <= 32 resp. 42 rows).
-// With s1 = (k mod history) + 1 the unit `rem` of the output comes from ring unit rem + 3*s1, minus one block length
-// if that runs past the block's end — the same three offsets for every agent, so the per-lane address arithmetic is
-// done three times per step and the agent index only moves the scalar offset of the access.
+// of EVERY agent's block (three classes of 32 lanes, or two of 64, cover history <= 32 resp. 42 rows).  With the mirror
+// ring the source of unit `rem` is ring unit 3 * ((k mod H) + 1) + rem of the same agent — the same offset for every agent,
+// no wrap, no padding test (the zeros are in the ring).
 //
 // Both directions go through buffer descriptors that cover just this wavefront's environments: a raw buffer access
 // is never turned into a branch by the compiler (a conditional global access is — for a load with a full s_waitcnt
-// behind every one of them), an out-of-range offset (-1) reads zeros — exactly the zero padding — or drops the
-// store, and the 32-bit range limit of a descriptor applies per wavefront, not to the whole batch.  The slots of
-// this step's own row are written too (with whatever the ring holds there): obs_store_new overwrites them
-// afterwards, in program order.  The stores are nontemporal: nothing in this launch reads them back, and lines that
-// do not sit dirty in the L2s shorten the write-back at the end of the launch.
+// behind every one of them), an out-of-range offset (-1) reads zeros or drops the store, and the 32-bit range limit of a
+// descriptor applies per wavefront, not to the whole batch.  The slots of this step's own row are written too (with
+// whatever the ring holds there): obs_store_new overwrites them afterwards, in program order.  The stores are
+// nontemporal: nothing in this launch reads them back.
 typedef int flex_v2i __attribute__((ext_vector_type(2)));
 typedef int flex_v4i __attribute__((ext_vector_type(4)));
 #define FLEX_BUF_FLAGS 0x00020000
@@ -204,27 +212,25 @@ struct ObsHist {
 
     __device__ __forceinline__ void load(const KArgs& a, int env0, int g, bool valid, bool enable, const LaneNet& ln, int k) {
         const int H = a.cfg.history, na = a.cfg.n_agents, H3 = 3 * H;
-        const int env_floats = na * H * 6;
-        const int span = enable ? EPW * env_floats : 0;                         // `enable` is launch-uniform
+        const int ring_floats = na * H * 12, out_floats = na * H * 6;            // per environment
+        const int span = enable ? EPW * ring_floats : 0;                        // `enable` is launch-uniform
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.st.ring + (int64_t)env0 * env_floats), 0, span * 4, FLEX_BUF_FLAGS);
-        const int s1 = small_mod(k, H, a.inv_h) + 1;
-        const int wrap_at = 3 * (H - s1);                    // rem >= wrap_at: the ring slot wrapped around
-        const int lo = 3 * (H - 1 - k > 0 ? H - 1 - k : 0);  // rem <  lo: before the episode began -> zero padding (A16)
+            (void*)(a.st.ring + (int64_t)env0 * ring_floats), 0, span * 4, FLEX_BUF_FLAGS);
+        const int first = 3 * (small_mod(k, H, a.inv_h) + 1);                   // ring unit of the oldest row of the window
         int src[CLS];
 #pragma unroll
         for (int i = 0; i < CLS; ++i) {
             const int rem = ln.l + LW * i;
             const bool have = valid && rem < H3;
-            src[i] = (have && rem >= lo) ? g * env_floats * 4 + 8 * (rem + 3 * s1) - (rem >= wrap_at ? 8 * H3 : 0) : -1;
-            dst[i] = have ? g * env_floats * (int)sizeof(OutT) + 2 * (int)sizeof(OutT) * rem : -1;
+            src[i] = have ? g * ring_floats * 4 + 8 * (first + rem) : -1;
+            dst[i] = have ? g * out_floats * (int)sizeof(OutT) + 2 * (int)sizeof(OutT) * rem : -1;
         }
 #pragma unroll
         for (int ag = 0; ag < NA_CAP; ++ag) {
             const bool live = NA_EXACT || ag < na;           // scalar
 #pragma unroll
             for (int i = 0; i < CLS; ++i) {
-                const flex_v2i r = __builtin_amdgcn_raw_buffer_load_b64(rin, live ? src[i] : -1, ag * H3 * 8, 0);
+                const flex_v2i r = __builtin_amdgcn_raw_buffer_load_b64(rin, live ? src[i] : -1, ag * H3 * 16, 0);
                 buf[ag][i] = make_float2(__int_as_float(r.x), __int_as_float(r.y));
             }
         }
@@ -254,60 +260,99 @@ struct ObsHist {
     }
 };
 
-// This step's row [Pd, Qd, Ppv, V, price, E] (env:377-382) into the ring and the newest slot of the observation.
+// This step's row [Pd, Qd, Ppv, V, price, E] (env:377-382), pushed as row k of its episode: both mirror slots of the
+// environment's ring (building lanes; 24 contiguous bytes, three 8-byte stores each), the record of the replay's row ring
+// when one is given (`rows`: this launch's slab, [N, n_agents, FLEX_ROW_W]), the newest slot of a stacked output when
+// one is given (`out`).
 template <int EPW, typename OutT>
 __device__ __forceinline__ void obs_store_new(const KArgs& a, int env0, int g, bool valid, const LaneNet& ln, int k,
                                               double pd, double qd, double ppv, double v, double price, double e,
-                                              OutT* __restrict__ out) {
+                                              OutT* __restrict__ out, float* __restrict__ rows) {
     const int H = a.cfg.history, na = a.cfg.n_agents;
-    const int env_floats = na * H * 6;
-    float* const ring = a.st.ring + (int64_t)env0 * env_floats;          // wavefront-uniform bases
-    OutT* const o = out + (int64_t)env0 * env_floats;
+    const int ring_floats = na * H * 12, env_floats = na * H * 6;
+    float* const ring = a.st.ring + (int64_t)env0 * ring_floats;          // wavefront-uniform bases
     const int slot = small_mod(k, H, a.inv_h);
     if (valid && ln.agent >= 0) {
-        // 24 contiguous bytes, three 8-byte stores each
         const float2 r0 = make_float2((float)pd, (float)qd), r1 = make_float2((float)ppv, (float)v);
         const float2 r2 = make_float2((float)price, (float)e);
-        const uint32_t ro = (uint32_t)(g * env_floats + (ln.agent * H + slot) * 6) * 4;
+        const uint32_t ro = (uint32_t)(g * ring_floats + (ln.agent * 2 * H + slot) * 6) * 4, mo = ro + (uint32_t)H * 24;
         st_at2(ring, ro, r0); st_at2(ring, ro + 8, r1); st_at2(ring, ro + 16, r2);
-        const uint32_t oo = (uint32_t)(g * env_floats + (ln.agent * H + (H - 1)) * 6) * (uint32_t)sizeof(OutT);
-        if constexpr (sizeof(OutT) == 4) {
-            st_at2(o, oo, r0); st_at2(o, oo + 8, r1); st_at2(o, oo + 16, r2);
-        } else {
-            st_at<double>(o, oo, pd); st_at<double>(o, oo + 8, qd); st_at<double>(o, oo + 16, ppv);
-            st_at<double>(o, oo + 24, v); st_at<double>(o, oo + 32, price); st_at<double>(o, oo + 40, e);
+        st_at2(ring, mo, r0); st_at2(ring, mo + 8, r1); st_at2(ring, mo + 16, r2);
+        if (rows) {
+            typedef float rw_f4 __attribute__((ext_vector_type(4)));
+            float* const rb = rows + (int64_t)env0 * (na * FLEX_ROW_W);
+            const uint32_t wo = (uint32_t)((g * na + ln.agent) * FLEX_ROW_W) * 4;
+            const float older = (float)(k < H - 1 ? k : H - 1);
+            st_at<rw_f4>(rb, wo, rw_f4{r0.x, r0.y, r1.x, r1.y});
+            st_at<rw_f4>(rb, wo + 16, rw_f4{r2.x, r2.y, older, 0.0f});
+        }
+        if (out) {
+            OutT* const o = out + (int64_t)env0 * env_floats;
+            const uint32_t oo = (uint32_t)(g * env_floats + (ln.agent * H + (H - 1)) * 6) * (uint32_t)sizeof(OutT);
+            if constexpr (sizeof(OutT) == 4) {
+                st_at2(o, oo, r0); st_at2(o, oo + 8, r1); st_at2(o, oo + 16, r2);
+            } else {
+                st_at<double>(o, oo, pd); st_at<double>(o, oo + 8, qd); st_at<double>(o, oo + 16, ppv);
+                st_at<double>(o, oo + 24, v); st_at<double>(o, oo + 32, price); st_at<double>(o, oo + 40, e);
+            }
         }
     }
     if (valid && ln.l == 0) st_at<int>(a.st.ienv + (int64_t)env0 * IF_COUNT, (uint32_t)(g * IF_COUNT + IF_OBSCNT) * 4, k + 1);
 }
 
-// General path (history/agent counts beyond the register budget, or no output wanted): same result, ring reads late.
+// Episode start (reset, restart inside a step): slots 1 .. H-1 of every agent's ring are zeroed — the rows "before the
+// episode began" of every window of the new episode (A16); slot 0 and the mirror half are overwritten before they are read.
+template <int EPW>
+__device__ __forceinline__ void obs_ring_clear(const KArgs& a, int env, bool valid, const LaneNet& ln) {
+    constexpr int LW = FLEX_WAVE / EPW;
+    const int H = a.cfg.history, na = a.cfg.n_agents;
+    float* ring = a.st.ring + (int64_t)env * na * H * 12;
+    const int per_agent = (H - 1) * 6;
+    if (valid)
+        for (int idx = ln.l; idx < na * per_agent; idx += LW) {
+            const int ag = idx / per_agent, rem = idx - ag * per_agent;
+            ring[(ag * 2 * H + 1) * 6 + rem] = 0.0f;
+        }
+}
+
+// General path (history/agent counts beyond the register budget, the stand-alone get_obs(), the episode start): the same
+// push, and the stacked output read from the ring afterwards.  `fresh`: row 0 of an episode whose ring this wavefront has
+// just cleared (obs_ring_clear) — the older rows of its window are zeros, written out directly.
 template <int EPW, typename OutT>
 __device__ __forceinline__ void push_and_emit_obs(const KArgs& a, int env, bool valid, const LaneNet& ln, int k,
                                                   double pd, double qd, double ppv, double v, double price,
-                                                  double e, OutT* __restrict__ out) {
+                                                  double e, OutT* __restrict__ out, float* __restrict__ rows, bool fresh) {
     constexpr int LW = FLEX_WAVE / EPW;
     const int H = a.cfg.history, na = a.cfg.n_agents;
     int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
     const int slot = k % H;
-    float* ring = a.st.ring + (int64_t)env * na * H * 6;
+    float* ring = a.st.ring + (int64_t)env * na * H * 12;
     OutT* o = out ? out + (int64_t)env * na * H * 6 : nullptr;
-    const int total = na * H * 6;
-    for (int idx = ln.l; idx < total; idx += LW) {
-        const int ag = idx / (H * 6), rem = idx - ag * (H * 6), h = rem / 6, ft = rem - h * 6;
-        if (h == H - 1 || !o || !valid) continue;
-        const int src = k - (H - 1) + h;
-        float val = 0.0f;
-        if (src >= 0) val = ring[(ag * H + (src % H)) * 6 + ft];
-        o[idx] = (OutT)val;
-    }
     if (valid && ln.agent >= 0) {
         const double feat[6] = {pd, qd, ppv, v, price, e};
-        float* r = ring + (ln.agent * H + slot) * 6;
+        float* r = ring + (ln.agent * 2 * H + slot) * 6;
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             r[t] = (float)feat[t];
+            r[H * 6 + t] = (float)feat[t];
             if (o) o[(ln.agent * H + (H - 1)) * 6 + t] = (OutT)feat[t];
+        }
+        if (rows) {
+            float* w = rows + ((int64_t)env * na + ln.agent) * FLEX_ROW_W;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) w[t] = (float)feat[t];
+            w[6] = (float)(k < H - 1 ? k : H - 1);
+            w[7] = 0.0f;
+        }
+    }
+    if (o && valid) {
+        // the H - 1 older rows of the window: ring slots slot + 1 .. slot + H - 1 (none of them written above); the first
+        // observation of an episode is zeros there (A16) — written out directly, not read back from the zero-fill
+        const int total = na * H * 6;
+        for (int idx = ln.l; idx < total; idx += LW) {
+            const int ag = idx / (H * 6), rem = idx - ag * (H * 6);
+            if (rem >= (H - 1) * 6) continue;
+            o[idx] = fresh ? (OutT)0 : (OutT)ring[(ag * 2 * H + slot + 1) * 6 + rem];
         }
     }
     if (valid && ln.l == 0) ie[IF_OBSCNT] = k + 1;
@@ -331,7 +376,7 @@ struct DevResetSpec { const int32_t *day, *hour, *interval; const double *e0, *a
 template <int EPW, typename ObsT>
 __device__ __forceinline__ void flex_reset_body(const KArgs& a, int env, bool valid, const LaneNet& ln0,
                                                 const DevResetSpec& inj, ObsT* __restrict__ obs, int want_obs,
-                                                uint8_t* __restrict__ failed, bool or_failed) {
+                                                float* __restrict__ rows, uint8_t* __restrict__ failed, bool or_failed) {
     const FlexCfg& c = a.cfg;
     LaneNet ln = ln0;
     ln.pq = ln.pq && valid;
@@ -422,7 +467,8 @@ __device__ __forceinline__ void flex_reset_body(const KArgs& a, int env, bool va
         ie[IF_SWEEPS] = sweeps;
         if (failed) { if (or_failed) { if (!ok) failed[env] = 1; } else failed[env] = ok ? 0 : 1; }
     }
-    if (want_obs) push_and_emit_obs<EPW, ObsT>(a, env, valid, ln, 0, pd, qd, ppv, v, price, e_new, obs);
+    obs_ring_clear<EPW>(a, env, valid, ln);               // env:79-80: the history starts empty
+    if (want_obs) push_and_emit_obs<EPW, ObsT>(a, env, valid, ln, 0, pd, qd, ppv, v, price, e_new, obs, rows, true);
 }
 
 template <int EPW, typename ObsT>
@@ -436,7 +482,7 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
     if (__ballot(valid) == 0ull) return;
     LaneNet ln;
     load_lane_net<EPW>(a.net, slot.lane, ln);
-    flex_reset_body<EPW, ObsT>(a, slot.env, valid, ln, inj, obs, want_obs, failed, false);
+    flex_reset_body<EPW, ObsT>(a, slot.env, valid, ln, inj, obs, want_obs, nullptr, failed, false);
 }
 
 
@@ -455,7 +501,12 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
 // The body of a step for the environments of wavefront `wave` (of the whole batch).  `slab` >= 0: the replay ring's slab
 // index is handed in (flex_rollout_burst_kernel, which walks it itself) instead of read from the cursor cell; `cells`: this
 // call maintains the device-side cursor / counter cells (the one-step kernel does, through one lane of the grid).
-template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK, bool HIST_LATE>
+// ROWS (FLEX_STEP_OBS_ROWS / FLEX_STEP_OBS_RING): get_obs() is the push of this step's feature row — 120 B per environment
+// into its mirror ring (where the policy kernels read the stacked observation in place) and, with a row ring registered, a
+// 160-B record into the replay's slab — instead of a [n_agents, 6 * history] copy of the whole window per step (2 760 B
+// read + 2 880 B written per env-step: 0.65 x the kernel's algorithmic bytes, 15 of its 53 vector loads and 15 of its 58
+// stores).  `obs` is then the row ring's base (or NULL).  !ROWS: the stacked copy into `obs`.
+template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK, bool ROWS>
 __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, const ActT* __restrict__ actions,
                                                double* __restrict__ reward, uint8_t* __restrict__ done, double* __restrict__ info,
                                                uint8_t* __restrict__ failed, ObsT* __restrict__ obs, int want_obs, int auto_reset,
@@ -466,11 +517,14 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     if (env0 >= a.n_envs) return;
     // (tried in round 3: s_setprio 1 for one of the two hardware wave slots of a SIMD, either parity — 13.5-13.8 us per
     //  launch with and without: the end spread of this kernel is not an arbitration effect)
-    if (a.obs_slabs > 0) {
-        // FLEX_STEP_OBS_RING (launch-uniform): the observations go straight into the consumer's slab ring, one slab past
-        // the one it is reading; nobody in this launch writes the cursor
-        const int64_t p = (slab >= 0 ? slab : *a.obs_cursor) + 1;
-        obs += (p >= a.obs_slabs ? 0 : p) * a.obs_slab_stride;
+    float* rowrec = nullptr;
+    if constexpr (ROWS) {
+        if (a.obs_slabs > 0 && obs) {
+            // FLEX_STEP_OBS_RING (launch-uniform): the row records go straight into the replay's slab ring, one slab past
+            // the one the policy is reading; nobody in this launch writes the cursor
+            const int64_t p = (slab >= 0 ? slab : *a.obs_cursor) + 1;
+            rowrec = reinterpret_cast<float*>(obs) + (p >= a.obs_slabs ? 0 : p) * a.obs_slab_stride;
+        }
     }
     // the spare group of an odd batch computes on env0's inputs (no out-of-bounds reads) and stores nothing
     const bool valid = env0 + lane / LW < a.n_envs;
@@ -533,10 +587,9 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     double n_pd = ld_at<double>(a.series, nrow_off + o_bus), n_qd = ld_at<double>(a.series, nrow_off + o_qbus);
     double n_ppv = ld_at<double>(a.series, nrow_off + o_pv);
     const double n_price = ld_at<double>(a.series, nrow_off + o_price);
-    const bool obs_fast = want_obs && na <= NA_CAP && 3 * c.history <= FLEX_OBS_CLASSES(EPW) * LW;
-    ObsHist<EPW, NA_CAP, ObsT> hist;
-    hist.load(a, env0, g, valid, obs_fast, ln, obs_cnt);
-    if constexpr (!HIST_LATE) hist.store(a, env0, obs_fast, obs);
+    const bool obs_fast = want_obs && (ROWS || (na <= NA_CAP && 3 * c.history <= FLEX_OBS_CLASSES(EPW) * LW));
+    ObsHist<EPW, ROWS ? 1 : NA_CAP, ObsT> hist;
+    if constexpr (!ROWS) hist.load(a, env0, g, valid, obs_fast, ln, obs_cnt);
 
     const bool warm = c.warm_start != 0 && ln.pq;
     double e = warm ? we : 1.0, f = warm ? wf : 0.0;
@@ -584,12 +637,10 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
 
     // the epilogue re-reads its configuration and rebuilds its bases from fresh kernarg loads (see relaunder_kernarg)
     const KArgs& z = *relaunder_kernarg<KArgs>(kbase);
-    // HIST_LATE (the one-step kernels): the history copy's stores go out HERE, its loads having been requested before the
-    // solve — issued in the prologue (round 2) the stores made the wavefront wait for those loads, a second memory round trip
-    // in front of the solve, to let them drain underneath it: 13.63 -> 13.18 us per launch, 300 -> 310 M env-steps/s.  The
-    // 33 registers held across the solve cost nothing (207 / 211 VGPRs, no scratch).  Inside the rollout burst the early
-    // stores stay: there the step's tail is what the group's other wavefronts wait for.
-    if constexpr (HIST_LATE) hist.store(z, env0, obs_fast, obs);
+    // stacked-output mode: the history copy's stores go out HERE, its loads having been requested before the solve — issued
+    // in the prologue (round 2) the stores made the wavefront wait for those loads, a second memory round trip in front of
+    // the solve, to let them drain underneath it: 13.63 -> 13.18 us per launch (round 3)
+    if constexpr (!ROWS) hist.store(z, env0, obs_fast, obs);
     const FlexCfg& cz = z.cfg;
     double* const e_agent = z.st.agent + (int64_t)env0 * (AF_COUNT * FLEX_MAX_AGENTS);
     float2* const e_vw = z.st.vw + (int64_t)env0 * 64;
@@ -693,8 +744,9 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     if (want_obs) {
         n_pd = is_bus ? n_pd : 0.0; n_qd = is_bus ? n_qd : 0.0; n_ppv = is_bld ? n_ppv : 0.0;
         const bool emit = valid && !restart;
-        if (obs_fast) obs_store_new<EPW, ObsT>(z, env0, g, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
-        else push_and_emit_obs<EPW, ObsT>(z, env, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, obs);
+        ObsT* const out = ROWS ? nullptr : obs;
+        if (obs_fast) obs_store_new<EPW, ObsT>(z, env0, g, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, out, rowrec);
+        else push_and_emit_obs<EPW, ObsT>(z, env, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, out, rowrec, false);
     }
     if (auto_reset && __ballot(restart) != 0ull) {       // wavefront-uniform, taken once per episode
         LaneNet ln0;
@@ -703,7 +755,7 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
         // the restart reads its configuration through a freshly "discovered" kernarg pointer: otherwise the compiler
         // loads every field the (rare) restart needs at kernel entry and carries them — spilled — across the hot path
         const KArgs& ar = *relaunder_kernarg<KArgs>(kbase);
-        flex_reset_body<EPW, ObsT>(ar, env, restart, ln0, none, obs, want_obs, failed, true);
+        flex_reset_body<EPW, ObsT>(ar, env, restart, ln0, none, ROWS ? nullptr : obs, want_obs, rowrec, failed, true);
     }
     // launch counter for consumers that index by vector step (flexnet_rollout_pack's ring cursor): one lane of the whole
     // grid, pointer re-read from the kernarg segment so that it is not carried across the solve
@@ -722,13 +774,13 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     FLEX_STAMP_RT(6);
 }
 
-template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK = false>
+template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK = false, bool ROWS = false>
 __global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, 8 / FLEX_WAVES_PER_BLOCK)
 void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restrict__ reward,
                       uint8_t* __restrict__ done, double* __restrict__ info, uint8_t* __restrict__ failed,
                       ObsT* __restrict__ obs, int want_obs, int auto_reset) {
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
-    flex_step_body<EPW, ObsT, ActT, NA_CAP, SINK, true>(a, wave, actions, reward, done, info, failed, obs, want_obs, auto_reset, -1, true,
+    flex_step_body<EPW, ObsT, ActT, NA_CAP, SINK, ROWS>(a, wave, actions, reward, done, info, failed, obs, want_obs, auto_reset, -1, true,
                                                   (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
@@ -753,7 +805,22 @@ void flex_obs_kernel(KArgs a, ObsT* __restrict__ obs) {
     push_and_emit_obs<EPW, ObsT>(a, env, slot.valid, ln, ie[IF_OBSCNT], is_bus ? sr[ln.bus] : 0.0,
                                  is_bus ? sr[nb + ln.bus] : 0.0, is_bld ? sr[2 * nb + ag] : 0.0,
                                  is_bus ? a.st.vm[(int64_t)env * nb + ln.bus] : 0.0, sr[2 * nb + na],
-                                 is_bld ? agst[AF_E * FLEX_MAX_AGENTS + ag] : 0.0, obs);
+                                 is_bld ? agst[AF_E * FLEX_MAX_AGENTS + ag] : 0.0, obs, nullptr, false);
+}
+
+// The stacked observation the last push left (env:387-401), WITHOUT pushing a row: what step(FLEX_STEP_OBS_ROWS) + a read
+// of the environment's mirror ring amounts to, materialised [N, n_agents, 6 * history] for consumers that want the copy
+// (the N = 1 drop-in view, tests, evaluation).  One thread per output element; not a hot kernel.
+template <typename ObsT>
+__global__ __launch_bounds__(256) void flex_obs_view_kernel(KArgs a, ObsT* __restrict__ obs) {
+    const int H = a.cfg.history, na = a.cfg.n_agents, w = H * 6;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)a.n_envs * na * w) return;
+    const int64_t row = idx / w;                       // env * na + agent
+    const int rem = (int)(idx - row * w);
+    const int cnt = a.st.ienv[(row / na) * IF_COUNT + IF_OBSCNT];
+    const int start = cnt > 0 ? (cnt - 1) % H + 1 : 0;
+    obs[idx] = cnt > 0 ? (ObsT)a.st.ring[row * (2 * w) + start * 6 + rem] : (ObsT)0;
 }
 
 // get_state(): env:358-368  [Pd | Qd | Ppv | V | price | E]   (one wavefront per environment; not a hot kernel)
@@ -1027,7 +1094,7 @@ __device__ __forceinline__ void flex_burst_env_step(int slab_v, unsigned kbase_l
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         actions = b.safe_env_action;
     }
-    flex_step_body<2, float, float, NA_CAP, true, false>(b.k, wave, actions, b.reward, b.done, b.info, b.failed, b.obs_ring, 1, 1,
+    flex_step_body<2, float, float, NA_CAP, true, true>(b.k, wave, actions, b.reward, b.done, b.info, b.failed, b.obs_ring, 1, 1,
                                                   slab, false, kbase);
     __builtin_amdgcn_s_setprio(0);
 }
@@ -1230,7 +1297,7 @@ int flexenv_create(const FlexCfg* cfg, const NetFix* net, const SeriesTab* serie
     const int64_t N = n_envs;
     const size_t sz_vm = N * net->n_bus * sizeof(double), sz_v = N * 64 * sizeof(float2);
     const size_t sz_ag = N * AF_COUNT * FLEX_MAX_AGENTS * sizeof(double), sz_cr = N * sizeof(double);
-    const size_t sz_ie = N * IF_COUNT * sizeof(int32_t), sz_ring = N * cfg->n_agents * cfg->history * 6 * sizeof(float);
+    const size_t sz_ie = N * IF_COUNT * sizeof(int32_t), sz_ring = N * cfg->n_agents * cfg->history * 12 * sizeof(float);
     hipError_t err = hipSetDevice(device);
     if (err == hipSuccess) err = hipMalloc(&e->net, sizeof(DevNet));
     if (err == hipSuccess) err = hipMemcpy(e->net, &e->hnet, sizeof(DevNet), hipMemcpyHostToDevice);
@@ -1283,7 +1350,7 @@ int flexenv_set_replay_sink(FlexEnv* e, const FlexReplaySink* sink) {
     return FLEX_OK;
 }
 int flexenv_set_obs_ring(FlexEnv* e, const int64_t* cursor, int64_t slab_stride, int32_t slabs) {
-    if (!e || slabs < 0 || (slabs > 0 && (!cursor || slabs < 2 || slab_stride < (int64_t)e->n_envs * e->cfg.n_agents * e->cfg.history * 6)))
+    if (!e || slabs < 0 || (slabs > 0 && (!cursor || slabs < 2 || slab_stride < (int64_t)e->n_envs * e->cfg.n_agents * FLEX_ROW_W)))
         return FLEX_EINVAL;
     e->obs_cursor = slabs > 0 ? cursor : nullptr;
     e->obs_slab_stride = slab_stride;
@@ -1324,9 +1391,12 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     if (obs && obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64) return FLEX_EINVAL;
     KArgs k = make_args(e);
     k.step_counter = e->step_counter; k.step_modulo = e->step_modulo;
+    const bool rows = (flags & (FLEX_STEP_OBS_RING | FLEX_STEP_OBS_ROWS)) != 0;
     if (flags & FLEX_STEP_OBS_RING) {
-        if (!obs || e->obs_slabs < 2 || obs_dtype != FLEX_F32) return FLEX_EINVAL;      // ring registered, fp32 slabs
+        if (!obs || e->obs_slabs < 2 || obs_dtype != FLEX_F32) return FLEX_EINVAL;      // row ring registered (fp32 records)
         k.obs_cursor = e->obs_cursor; k.obs_slab_stride = e->obs_slab_stride; k.obs_slabs = e->obs_slabs;
+    } else if (rows) {
+        obs = nullptr;                               // FLEX_STEP_OBS_ROWS alone: the environment's own ring is the observation
     }
     const bool sink = (flags & FLEX_STEP_REPLAY_SINK) != 0;
     if (sink) {
@@ -1337,6 +1407,19 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     hipStream_t s = (hipStream_t)stream;
     const int epw = e->hnet.epw;
     const dim3 grid = env_grid(e->n_envs, epw);
+    if (rows) {
+        // get_obs() as a row push (ROWS instantiations: no ObsHist, the observation dtype plays no part)
+#define FLEX_LAUNCH_ROWS(EPW_, ACT_, SINK_) hipLaunchKernelGGL((flex_step_kernel<EPW_, float, ACT_, FLEX_OBS_AGENTS_SMALL, SINK_, true>), \
+            grid, env_block(), 0, s, k, (const ACT_*)actions, reward, done, info, failed, (float*)obs, 1, auto_reset)
+        if (sink) FLEX_LAUNCH_ROWS(2, float, true);
+        else if (epw == 2 && act_dtype == FLEX_F32) FLEX_LAUNCH_ROWS(2, float, false);
+        else if (epw == 2) FLEX_LAUNCH_ROWS(2, double, false);
+        else if (act_dtype == FLEX_F32) FLEX_LAUNCH_ROWS(1, float, false);
+        else FLEX_LAUNCH_ROWS(1, double, false);
+#undef FLEX_LAUNCH_ROWS
+        HIP_TRY(hipGetLastError());
+        return FLEX_OK;
+    }
     const bool f64 = obs && obs_dtype == FLEX_F64;
     const int want = obs ? 1 : 0;
 #define FLEX_LAUNCH_STEP(EPW_, OBS_, ACT_) do { \
@@ -1351,14 +1434,7 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
         case 1: FLEX_LAUNCH_STEP(1, float, double); break;
         case 2: FLEX_LAUNCH_STEP(1, double, float); break;
         case 3: FLEX_LAUNCH_STEP(1, double, double); break;
-        case 4:
-            if (sink) {
-                if (small_obs) hipLaunchKernelGGL((flex_step_kernel<2, float, float, FLEX_OBS_AGENTS_SMALL, true>), grid, env_block(), 0, s, k,
-                    (const float*)actions, reward, done, info, failed, (float*)obs, want, auto_reset);
-                else hipLaunchKernelGGL((flex_step_kernel<2, float, float, FLEX_OBS_AGENTS_LARGE, true>), grid, env_block(), 0, s, k,
-                    (const float*)actions, reward, done, info, failed, (float*)obs, want, auto_reset);
-            } else FLEX_LAUNCH_STEP(2, float, float);
-            break;
+        case 4: FLEX_LAUNCH_STEP(2, float, float); break;
         case 5: FLEX_LAUNCH_STEP(2, float, double); break;
         case 6: FLEX_LAUNCH_STEP(2, double, float); break;
         default: FLEX_LAUNCH_STEP(2, double, double); break;
@@ -1378,10 +1454,10 @@ int flexenv_rollout_burst(FlexEnv* e, const FlexActorArgs* actor, double* reward
     if (!e->has_sink || e->obs_slabs < 2 || e->hnet.epw != 2 || na > 5) return FLEX_EINVAL;
     if (p.rows != (int64_t)e->n_envs * na || p.n_agents != na || p.obs_dim < 1 || p.obs_dim > FLEXNET_MAX_OBS || (p.obs_dim & 3) ||
         p.act_dim < 1 || p.act_dim > FLEXNET_MAX_ACT) return FLEX_EINVAL;
-    if (!p.obs || !p.hidden_in || !p.hidden_out || !p.means || !p.action || !p.env_action || !p.cursor || !p.cursor_out ||
+    if (!p.hidden_in || !p.hidden_out || !p.means || !p.action || !p.env_action || !p.cursor || !p.cursor_out ||
         !p.fc1_w || !p.fc1_b || !p.w_ih || !p.w_hh || !p.b_ih || !p.b_hh || !p.fc2_w || !p.fc2_b ||
         (p.layernorm && (!p.ln_w || !p.ln_b)) || (!p.noise && !p.rng_state)) return FLEX_EINVAL;
-    if (p.ring_slabs != e->obs_slabs || p.obs_slab_stride != e->obs_slab_stride || steps >= e->obs_slabs) return FLEX_EINVAL;
+    if (p.ring_slabs != e->obs_slabs || steps >= e->obs_slabs || p.obs_dim != 6 * e->cfg.history) return FLEX_EINVAL;
     if (p.cursor_out != e->obs_cursor || p.cursor != e->sink.cursor_out || p.hidden_out != e->sink.hid_new ||
         p.action != e->sink.policy_action || p.noise) return FLEX_EINVAL;
     // the burst draws the noise of steps rng_state[1] .. rng_state[1] + steps - 1 in the kernel and the finish launch advances the
@@ -1396,7 +1472,11 @@ int flexenv_rollout_burst(FlexEnv* e, const FlexActorArgs* actor, double* reward
     const dim3 grid((e->n_envs + 15) / 16), block(64 * R16_W);
     const bool small_obs = na == FLEX_OBS_AGENTS_SMALL && 3 * e->cfg.history <= FLEX_OBS_CLASSES(2) * (FLEX_WAVE / 2);
     BurstArgs b;
-    b.k = k; b.act = p; b.reward = reward; b.done = done; b.info = info; b.failed = failed; b.obs_ring = obs_ring; b.n_steps = (int)steps;
+    b.k = k; b.act = p;
+    // the policy reads the stacked observation IN PLACE from this environment's history (what flexenv_obs_source hands out)
+    b.act.obs = e->st.ring; b.act.obs_pushed = e->st.ienv + IF_OBSCNT;
+    b.act.obs_row_stride = e->cfg.history * 12; b.act.obs_pushed_stride = IF_COUNT; b.act.obs_slots = e->cfg.history; b.act.obs_slot_w = 6;
+    b.reward = reward; b.done = done; b.info = info; b.failed = failed; b.obs_ring = obs_ring; b.n_steps = (int)steps;
     b.safety = 0; b.s_p = b.s_q = b.beta = nullptr; b.v_min = b.v_max = b.rho = 0.0; b.adjusted = nullptr; b.safe_env_action = nullptr;
     b.act_low = b.act_span = 0.0f;
     if (safety) {
@@ -1435,6 +1515,28 @@ int flexenv_obs(FlexEnv* e, void* obs, int32_t obs_dtype, void* stream) {
         else hipLaunchKernelGGL((flex_obs_kernel<1, float>), grid, env_block(), 0, s, k, (float*)obs);
     }
     HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+int flexenv_obs_view(FlexEnv* e, void* obs, int32_t obs_dtype, void* stream) {
+    if (!e || !obs || (obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64)) return FLEX_EINVAL;
+    KArgs k = make_args(e);
+    const int64_t tot = (int64_t)e->n_envs * e->cfg.n_agents * e->cfg.history * 6;
+    const dim3 grid((unsigned)((tot + 255) / 256));
+    if (obs_dtype == FLEX_F64) hipLaunchKernelGGL(flex_obs_view_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, k, (double*)obs);
+    else hipLaunchKernelGGL(flex_obs_view_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, k, (float*)obs);
+    HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+int flexenv_obs_source(const FlexEnv* e, FlexObsSource* out) {
+    if (!e || !out) return FLEX_EINVAL;
+    out->ring = e->st.ring;
+    out->pushed = e->st.ienv + IF_OBSCNT;
+    out->row_stride = e->cfg.history * 12;
+    out->pushed_stride = IF_COUNT;
+    out->slots = e->cfg.history;
+    out->slot_w = 6;
     return FLEX_OK;
 }
 

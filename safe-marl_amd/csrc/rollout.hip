@@ -184,6 +184,49 @@ extern "C" int flexnet_agent_sum_explore(const FlexAgentSumArgs* a, void* stream
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 
+// ---- stacked observations of a replay window from the row ring (flexnet_gather_window) -------------------------------------
+// One thread per 24-byte chunk (output row, agent, history slot): consecutive lanes write consecutive chunks (a wavefront
+// stores 1 536 contiguous bytes), each reads ONE 32-byte record of the slab `history - 1 - h` steps back — a slab region of
+// (window + history) x N x n x 32 B (21 MB at the update batch) that every XCD re-reads from cache; the launch is bound by
+// its 106 MB of stores.
+#define WINDOW_THREADS 256
+typedef float win_f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(WINDOW_THREADS) void gather_window_kernel(FlexWindowArgs a) {
+    const int H = a.history, n = a.n_agents, per_row = n * H;
+    const int64_t gid = (int64_t)blockIdx.x * WINDOW_THREADS + threadIdx.x;
+    if (gid >= a.rows * per_row) return;
+    const int64_t row = gid / per_row;
+    const int c = (int)(gid - row * per_row), ag = c / H, h = c - ag * H;
+    const int64_t slot = a.first_slot + row;
+    const int64_t sl = slot / a.n_envs;
+    const int env = (int)(slot - sl * a.n_envs), slab = (int)(sl % a.slabs);
+    const int back = H - 1 - h;
+    const float older = a.row_ring[(((int64_t)slab * a.n_envs + env) * n + ag) * 8 + 6];
+    int src = slab - back;
+    src = src < 0 ? src + a.slabs : src;
+    const float* r = a.row_ring + (((int64_t)src * a.n_envs + env) * n + ag) * 8;
+    const pack_f4 v0 = *reinterpret_cast<const pack_f4*>(r);
+    const win_f2 v1 = *reinterpret_cast<const win_f2*>(r + 4);
+    const bool live = (float)back <= older;
+    win_f2* o = reinterpret_cast<win_f2*>(a.dst + gid * 6);
+    o[0] = live ? win_f2{v0.x, v0.y} : win_f2{0.0f, 0.0f};
+    o[1] = live ? win_f2{v0.z, v0.w} : win_f2{0.0f, 0.0f};
+    o[2] = live ? v1 : win_f2{0.0f, 0.0f};
+}
+
+extern "C" int flexnet_gather_window(const FlexWindowArgs* a, void* stream) {
+    if (!a || !a->row_ring || !a->dst || a->rows < 0 || a->first_slot < 0 || a->n_envs < 1 || a->n_agents < 1 ||
+        a->n_agents > FLEXNET_MAX_AGENTS || a->history < 1 || a->slabs < a->history ||
+        ((reinterpret_cast<uintptr_t>(a->row_ring) & 15) | (reinterpret_cast<uintptr_t>(a->dst) & 7)))
+        return FLEXNET_EINVAL;
+    if (a->rows == 0) return FLEXNET_OK;
+    const int64_t chunks = a->rows * a->n_agents * a->history;
+    if (chunks > 0x7fffffffll * WINDOW_THREADS) return FLEXNET_EUNSUPPORTED;
+    hipLaunchKernelGGL(gather_window_kernel, dim3((unsigned)((chunks + WINDOW_THREADS - 1) / WINDOW_THREADS)), dim3(WINDOW_THREADS), 0,
+                       (hipStream_t)stream, *a);
+    return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}
+
 #define GATHER_THREADS 256
 struct GatherPlan { int first_block[FLEXNET_GATHER_MAX_JOBS + 1]; };
 

@@ -178,10 +178,15 @@ class VecFlexProvisionEnv:
                                           _ptr(self.failed), _stream()), "flexenv_reset")
         return out
 
-    def step(self, actions, obs_out=None, fuse_obs=False, auto_reset=False, obs_ring=None, replay_sink=False):
+    def step(self, actions, obs_out=None, fuse_obs=False, auto_reset=False, obs_ring=None, replay_sink=False, obs_rows=False):
         """auto_reset: environments that terminate in this step restart inside the same launch (their row of the
-        fused observation is then the first observation of the new episode).  obs_ring: base tensor of the slab ring
-        registered with set_obs_ring — the fused observation goes into the slab after the cursor instead of ``self.obs``."""
+        fused observation is then the first observation of the new episode).
+        fuse_obs: the get_obs() that follows every step (model.py:223) in the same launch, as a stacked copy into
+        ``self.obs`` / ``obs_out``.  obs_rows: the same get_obs() as a ROW PUSH — the step appends its 6-feature row per agent
+        to the environment's history (120 B per env instead of a 2 880 B copy) and consumers read the stacked observation in
+        place (``obs_source()``: the policy kernels do) or materialise it on demand (``obs_view()``).  obs_ring: base
+        tensor of the ROW ring registered with set_obs_ring — implies obs_rows, and the step also files one record per
+        (env, agent) in the slab after the cursor (include/flexenv.h: FLEX_STEP_OBS_RING)."""
         self.calls += 1
         if actions.device != self.device:
             actions = actions.to(self.device)
@@ -194,6 +199,8 @@ class VecFlexProvisionEnv:
             out, flags = obs_ring, flags | _lib.FLEX_STEP_OBS_RING
             if replay_sink:                  # the step files its own transition (set_replay_sink)
                 flags |= _lib.FLEX_STEP_REPLAY_SINK
+        elif obs_rows:
+            flags |= _lib.FLEX_STEP_OBS_ROWS
         elif fuse_obs:
             out = self.obs if obs_out is None else obs_out
         _lib.check(self.lib.flexenv_step(self.handle, _ptr(actions), self._dtype_tag(actions), _ptr(self.reward),
@@ -277,6 +284,20 @@ class VecFlexProvisionEnv:
         out = self.obs if obs_out is None else obs_out
         _lib.check(self.lib.flexenv_obs(self.handle, _ptr(out), self._dtype_tag(out), _stream()), "flexenv_obs")
         return out
+
+    def obs_view(self, obs_out=None):
+        """The stacked observation as the last push left it (env:387-401), WITHOUT appending to the history: what
+        ``step(..., obs_rows=True)`` leaves for consumers that want the [N, n_agents, 6 * history] copy."""
+        out = self.obs if obs_out is None else obs_out
+        _lib.check(self.lib.flexenv_obs_view(self.handle, _ptr(out), self._dtype_tag(out), _stream()), "flexenv_obs_view")
+        return out
+
+    def obs_source(self):
+        """Where the observation history lives on the device (include/flexenv.h: FlexObsSource), for kernels that read the
+        stacked observation in place (nets.fused_actor_forward(..., obs_source=...))."""
+        src = _lib.FlexObsSource()
+        _lib.check(self.lib.flexenv_obs_source(self.handle, C.byref(src)), "flexenv_obs_source")
+        return src
 
     def get_state(self):
         out = torch.empty(self.n_envs, self.state_size, dtype=torch.float64, device=self.device)

@@ -42,10 +42,16 @@ class RolloutGraph:
         self.model, self.env, self.buf = model, env, buf
         N, n, o, a, h = env.n_envs, model.n_, model.obs_dim, model.act_dim, model.hid_dim
         dev = model.device
+        # Row mode (round 4): where the env's step kernel files observations itself (ring I/O below) the replay keeps every
+        # feature ROW once and the policy kernels read the stacked observation in place from the env's own history —
+        # nothing copies a [n, 6 H] window per step any more; elsewhere (general bodies) slabs hold stacked observations
+        self.history = getattr(getattr(env, "vec", env), "history", None)
+        self.rows_capable = bool(hasattr(env, "obs_source") and hasattr(env, "set_obs_ring") and env.obs.is_cuda
+                                 and self.history and o == 6 * self.history)
         if not buf.slab_mode:
             if buf.store is not None:
                 raise RuntimeError("replay buffer already holds field-by-field transitions; the graph rollout needs slab mode")
-            buf.alloc_slabs(N, n, o, a, h)
+            buf.alloc_slabs(N, n, o, a, h)                    # (re-made in row mode by _configure_env where that applies)
         if (buf.n_envs, buf.n_agents, buf.obs_dim, buf.act_dim, buf.hid_dim) != (N, n, o, a, h):
             raise RuntimeError("replay buffer was allocated for another environment batch")
         self._obs = env.obs                         # [N, n, o]: written by the env kernel, read by the policy (tensor mode)
@@ -92,7 +98,7 @@ class RolloutGraph:
         # Ring I/O (the fused path): the env kernel writes its observation straight into the slab after the cursor, the
         # actor kernel reads observation and hidden state from the slab at the cursor — the observation is written once,
         # where the replay keeps it, and never copied.
-        self.ring_io = bool(self._fast and self.cursor_stepped and hasattr(env, "set_obs_ring"))
+        self.ring_io = bool(self._fast and self.cursor_stepped and self.rows_capable)
         # Sink (ring I/O + an env that files transitions): the env step kernel also writes the small record, the masked
         # hidden state and the per-environment statistics — a vector step is TWO launches, policy and environment, and no
         # bookkeeping kernel.  Cursor cells then follow the two-kernel protocol of include/flexenv.h: cursor[0] is read by
@@ -107,7 +113,7 @@ class RolloutGraph:
         # MATD3 / IDDPG with the one-launch action selection (`summed`): the same ring I/O and sink — policy kernel (slab at the
         # cursor -> means, new hidden state), agent_sum_explore_kernel (-> the action the replay keeps, the env's action), env
         # step (files the transition): three launches, no pack kernel, the observation written once (round 3)
-        self.summed_sink = bool(self.summed and self.cursor_stepped and hasattr(env, "set_obs_ring")
+        self.summed_sink = bool(self.summed and self.cursor_stepped and self.rows_capable
                                 and hasattr(env, "set_replay_sink") and n * a <= 32 and n * h <= 384
                                 and two_per_wave and h == 64 and o <= 144
                                 and os.environ.get("FLEX_SUMMED_SINK", "1") != "0")
@@ -136,15 +142,23 @@ class RolloutGraph:
         if not self.cursor_stepped:
             return
         N, n, o = env.n_envs, self.model.n_, self.model.obs_dim
+        # the replay's layout follows the mode: feature rows where the env files observations itself, stacked slabs otherwise
+        if bool(self.ring_active) != bool(buf.row_mode):
+            if buf.k != 0 or buf.length != 0:
+                raise RuntimeError("the rollout body changed between ring I/O and tensor hand-over with transitions in the replay")
+            buf.alloc_slabs(N, n, o, self.model.act_dim, self.model.hid_dim, history=self.history if self.ring_active else None)
+        if self.ring_active:
+            self.obs_src = env.obs_source()                 # the policy kernels read the stacked observation in place
+        row_stride = N * n * buf.ROW_W
         if self.sink_active:
             env.set_step_counter(None)                      # the env step sets cursor[0] itself in this mode
-            env.set_obs_ring(buf.cursor[1:], N * n * o, buf.slabs)
+            env.set_obs_ring(buf.cursor[1:], row_stride, buf.slabs)
             env.set_replay_sink(self.act_buf, self.hid_buf, buf.small_ring, buf.hid_ring, self.acc, cursor_out=buf.cursor[0:1],
                                 aux_counter=None if (self._torch_noise or self.summed_sink) else self.rng_state[1:2])
         else:
             env.set_step_counter(buf.cursor[1:], buf.slabs)
-            if self.ring_io:
-                env.set_obs_ring(buf.cursor, N * n * o, buf.slabs)
+            if self.ring_active:
+                env.set_obs_ring(buf.cursor, row_stride, buf.slabs)
             if hasattr(env, "set_replay_sink"):
                 env.set_replay_sink(None, None, None, None, None)
 
@@ -197,8 +211,8 @@ class RolloutGraph:
     @property
     def obs(self):
         """The observation the next policy evaluation reads: [N, n, o]."""
-        if self.ring_active:
-            return self.buf.obs_ring[self.buf.k % self.buf.slabs].view(self.env.n_envs, self.model.n_, self.model.obs_dim)
+        if self.ring_active:                                # (a materialised copy: the policy kernels read the env's history)
+            return self.env.obs_view().view(self.env.n_envs, self.model.n_, self.model.obs_dim)
         return self._obs
 
     @property
@@ -218,7 +232,8 @@ class RolloutGraph:
         a.slabs, a.small_w, a.info_w, a.cursor_stepped = buf.slabs, buf.small_w, env.info.shape[1], self.cursor_stepped
         for name, t in (("action", action), ("reward", env.reward), ("obs_next", None if self.ring_active else env.obs),
                         ("done", env.done), ("hid_new", hid), ("info", env.info), ("failed", env.failed),
-                        ("obs_ring", buf.obs_ring), ("hid_ring", buf.hid_ring), ("small_ring", buf.small_ring),
+                        ("obs_ring", buf.row_ring if buf.row_mode else buf.obs_ring), ("hid_ring", buf.hid_ring),
+                        ("small_ring", buf.small_ring),
                         ("hid_state", None if self.ring_active else self._hid), ("cursor", buf.cursor),
                         ("info_sum", self._info_sum), ("rew_sum", self._rew_sum), ("fail_sum", self._fail_sum)):
             if t is not None:
@@ -249,9 +264,10 @@ class RolloutGraph:
                 # costs a launch plus two seed/offset fill kernels per replay.
                 buf = self.buf
                 noise = th.randn(N, m.n_, m.act_dim, device=env.obs.device) if self.torch_noise else None
-                ring = dict(ring_cursor=buf.cursor, obs_slab_stride=buf.obs_ring.stride(0),
-                            hid_slab_stride=buf.hid_ring.stride(0)) if self.ring_active else {}
-                obs_in = buf.obs_ring[0].view(N, m.n_, m.obs_dim) if self.ring_active else self._obs
+                # ring I/O: the hidden state from the slab at the cursor, the stacked observation IN PLACE from the env's history
+                ring = dict(ring_cursor=buf.cursor, obs_slab_stride=0, hid_slab_stride=buf.hid_ring.stride(0),
+                            obs_source=self.obs_src) if self.ring_active else {}
+                obs_in = self._obs                           # (ring I/O: only its shape is used)
                 hid_in = buf.hid_ring[0].view(N, m.n_, m.hid_dim) if self.ring_active else self._hid
                 if self.sink_active:           # static outputs the env step reads back (registered with its replay sink)
                     ring.update(cursor_out=buf.cursor[1:], out=dict(hidden_out=self.hid_buf, action=self.act_buf))
@@ -266,7 +282,7 @@ class RolloutGraph:
                         safety = dict(s_p=s_p, s_q=s_q, beta=beta, v_min=m.V_min, v_max=m.V_max, adjusted=self.burst_adjusted,
                                       env_action=self.burst_safe_env_act, act_low=m.args.action_low, act_high=m.args.action_high)
                     ring.update(ring_slabs=buf.slabs,
-                                launch=lambda args: vec.rollout_burst(args, burst, buf.obs_ring, safety=safety))
+                                launch=lambda args: vec.rollout_burst(args, burst, buf.row_ring, safety=safety))
                 out = fused_actor_forward(m.policy_dicts[0], obs_in, hid_in, m.n_, m.args.agent_id, noise=noise,
                                           std=self.std, low=m.args.action_low, high=m.args.action_high,
                                           rng_state=None if self.torch_noise else self.rng_state, **ring)
@@ -289,23 +305,23 @@ class RolloutGraph:
                                                               env_action_range=(m.args.action_low, m.args.action_high),
                                                               want_hit=False)
                 env.step(env_action.view(N, m.n_, m.act_dim), fuse_obs=True, auto_reset=True,
-                         obs_ring=buf.obs_ring if self.ring_active else None, replay_sink=self.sink_active)
+                         obs_ring=buf.row_ring if self.ring_active else None, replay_sink=self.sink_active)
                 if not self.sink_active:
                     self._pack(action, hid)
                 return
         if self.summed and self.summed_sink:
             with th.no_grad():
                 buf = self.buf
-                out = fused_actor_forward(m.policy_dicts[0], buf.obs_ring[0].view(N, m.n_, m.obs_dim),
+                out = fused_actor_forward(m.policy_dicts[0], self._obs,
                                           buf.hid_ring[0].view(N, m.n_, m.hid_dim), m.n_, m.args.agent_id,
-                                          ring_cursor=buf.cursor, obs_slab_stride=buf.obs_ring.stride(0),
+                                          ring_cursor=buf.cursor, obs_slab_stride=0, obs_source=self.obs_src,
                                           hid_slab_stride=buf.hid_ring.stride(0), cursor_out=buf.cursor[1:],
                                           out=dict(hidden_out=self.hid_buf))
                 if out is None:
                     raise RuntimeError("the fused actor kernel declined a configuration RolloutGraph.summed_sink admitted")
                 summed_exploration(m, out[0].view(N, m.n_, m.act_dim), env_action=self.env_act_buf,
                                    action_out=self.act_buf.view(N, m.n_, m.act_dim))
-                env.step(self.env_act_buf, fuse_obs=True, auto_reset=True, obs_ring=buf.obs_ring, replay_sink=True)
+                env.step(self.env_act_buf, fuse_obs=True, auto_reset=True, obs_ring=buf.row_ring, replay_sink=True)
             return
         if self.summed:
             with th.no_grad():

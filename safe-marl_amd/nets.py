@@ -169,7 +169,7 @@ ACTOR_VARIANT = 0
 
 def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=1.0, low=0.0, high=1.0, variant=None,
                         rng_state=None, ring_cursor=None, obs_slab_stride=0, hid_slab_stride=0, cursor_out=None,
-                        out=None, ring_slabs=0, launch=None):
+                        out=None, ring_slabs=0, launch=None, obs_source=None):
     """rnn_agent.py:25-33 + model.py:102-116 without an autograd graph, in one HIP launch.
 
     ``obs`` [b, n, obs_dim] fp32 on the GPU WITHOUT the one-hot id columns (the kernel adds fc1's id column of
@@ -183,7 +183,9 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
     are slab 0 of two slab rings and the launch reads slab ``ring_cursor[0]`` of each (strides in floats), resolved on the
     device — the rollout graph's way of reading the observation where the environment kernel wrote it.
     ``launch`` (with ``ring_slabs``): called with the filled FlexActorArgs INSTEAD of flexnet_actor_forward — the rollout
-    burst, which runs this policy evaluation inside the environment's persistent launch (flex_env.rollout_burst)."""
+    burst, which runs this policy evaluation inside the environment's persistent launch (flex_env.rollout_burst).
+    ``obs_source`` (a ``_lib.FlexObsSource``, VecFlexProvisionEnv.obs_source()): the observations are read IN PLACE from
+    the environment's history (``obs`` then only gives the shape [b, n, obs_dim]; it is not read)."""
     import ctypes as C
     from . import _lib
     a = agent.args
@@ -240,6 +242,10 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
             return None
         setattr(args, name, None if t is None else t.data_ptr())
     args.ring_slabs = int(ring_slabs)
+    if obs_source is not None:
+        args.obs, args.obs_pushed = obs_source.ring, obs_source.pushed
+        args.obs_row_stride, args.obs_pushed_stride = obs_source.row_stride, obs_source.pushed_stride
+        args.obs_slots, args.obs_slot_w = obs_source.slots, obs_source.slot_w
     if launch is not None:
         launch(args)
         return (means, hid_out, action, env_action) if explore else (means, hid_out)

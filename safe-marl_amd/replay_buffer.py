@@ -55,23 +55,41 @@ class DeviceReplayBuffer:
                       for k, s in shapes.items()}
 
     # -- slab mode: the vectorised, graph-captured rollout ------------------------------------------------------------
-    def alloc_slabs(self, n_envs, n_agents, obs_dim, act_dim, hid_dim):
+    ROW_W = 8                      # floats per row record: [Pd, Qd, Ppv, V, price, E, older, 0] (include/flexenv.h)
+
+    def alloc_slabs(self, n_envs, n_agents, obs_dim, act_dim, hid_dim, history=None):
         """Slab-structured ring for N environments stepping in lockstep (include/flexnet.h: flexnet_rollout_pack writes it
-        at a device-side cursor).  Slab k = vector step k: ``obs_ring[k]`` the observation acted on, ``hid_ring[k]`` the
-        hidden state going in, ``small_ring[k]`` = [action | reward | done | last_step].  Every observation is stored
-        once: next_state of slab k is ``obs_ring[k + 1]``, model.py:241's ``hid`` is ``hid_ring[k + 1]``.
+        at a device-side cursor).  Slab k = vector step k: the observation acted on, ``hid_ring[k]`` the hidden state going
+        in, ``small_ring[k]`` = [action | reward | done | last_step].  Every observation is stored once: next_state of slab
+        k is the observation of slab k + 1, model.py:241's ``hid`` is ``hid_ring[k + 1]``.
+
+        ``history`` = H (row mode; the flexibility-provision env's observation is its last H feature rows, env:387-401): the
+        ring keeps every feature ROW once — ``row_ring[k]`` = one 32-byte record per (env, agent), written by the env's
+        step kernel (FLEX_STEP_OBS_RING) — 1/18 of the bytes of a stacked observation per slab; a window's stacked
+        observations are formed when it is gathered (flexnet_gather_window: the gather is the im2col).  The H - 1 slabs
+        behind the oldest transition stay in the ring for that (H - 1 physical slabs on top of ``size // n_envs``).
+        ``history`` None: ``obs_ring[k]`` holds the stacked observation itself (general rollout bodies, hand-filled rings).
 
         Host-side bookkeeping mirrors the device cursor: slab counter ``k`` (monotone), the slab being filled is
         ``k % slabs``; transitions are the COMPLETE slabs still in the ring.  A slab left without an action (the rollout
         was restarted from a hard reset instead of continuing) is a *gap*; sampled windows never span one."""
         self.n_envs, self.n_agents, self.obs_dim, self.act_dim, self.hid_dim = n_envs, n_agents, obs_dim, act_dim, hid_dim
-        self.slabs = self.size // n_envs
-        if self.slabs < 4:
+        self.history = int(history) if history else None
+        if self.history is not None and (obs_dim % self.history != 0 or obs_dim // self.history != 6):
+            raise ValueError("row mode stores 6-feature rows: obs_dim must be 6 * history")
+        self.keep_back = self.history - 1 if self.history else 0      # slabs behind a transition its observation reaches into
+        self.slabs = self.size // n_envs + self.keep_back
+        if self.slabs - self.keep_back < 4:
             raise ValueError("slab replay needs room for at least 4 vector steps")
         no, nh = n_agents * obs_dim, n_agents * hid_dim
         self.small_w = ((n_agents * act_dim + n_agents + 2 + 3) // 4) * 4       # 16-byte rows
         dev = self.device
-        self.obs_ring = th.zeros(self.slabs, n_envs, no, dtype=th.float32, device=dev)
+        if self.history is None:
+            self.obs_ring = th.zeros(self.slabs, n_envs, no, dtype=th.float32, device=dev)
+            self.row_ring = None
+        else:
+            self.obs_ring = None
+            self.row_ring = th.zeros(self.slabs, n_envs, n_agents * self.ROW_W, dtype=th.float32, device=dev)
         self.hid_ring = th.zeros(self.slabs, n_envs, nh, dtype=th.float32, device=dev)
         self.small_ring = th.zeros(self.slabs, n_envs, self.small_w, dtype=th.float32, device=dev)
         # bootstrap values r + gamma (1 - done) Q'(s', pi(s')) needs, per transition, filed by the trainer for the windows of
@@ -91,12 +109,16 @@ class DeviceReplayBuffer:
 
     @property
     def slab_mode(self):
-        return getattr(self, "obs_ring", None) is not None
+        return getattr(self, "hid_ring", None) is not None
+
+    @property
+    def row_mode(self):
+        return getattr(self, "row_ring", None) is not None
 
     def release_slabs(self):
         """Back to the field-by-field mode (the graph rollout could not be captured): the rings and their bookkeeping go,
         ``add_batch`` allocates its own store on the next call.  Transitions the ring held are dropped."""
-        self.obs_ring = self.hid_ring = self.small_ring = self.nv_ring = self.cursor = None
+        self.obs_ring = self.row_ring = self.hid_ring = self.small_ring = self.nv_ring = self.cursor = None
         self.k = self.first = 0
         self.gaps = []
         self.consts, self.const_shapes = {}, {}
@@ -111,7 +133,13 @@ class DeviceReplayBuffer:
             self.gaps.append(self.k)
             self.k += 1
         p = self.k % self.slabs
-        self.obs_ring[p].copy_(first_obs.reshape(self.n_envs, -1))
+        if self.row_mode:
+            # the first observation of an episode: its newest feature row, no older ones (zero left-padding)
+            rec = self.row_ring[p].view(self.n_envs, self.n_agents, self.ROW_W)
+            rec.zero_()
+            rec[:, :, :6].copy_(first_obs.reshape(self.n_envs, self.n_agents, self.obs_dim)[:, :, -6:])
+        else:
+            self.obs_ring[p].copy_(first_obs.reshape(self.n_envs, -1))
         self.hid_ring[p].zero_()
         self.cursor.fill_(p)
         self._retire()
@@ -125,8 +153,9 @@ class DeviceReplayBuffer:
         return done_slab
 
     def _retire(self):
-        # the slab at the cursor (and its half-written successor after the next step) overwrite the oldest ones
-        self.first = max(self.first, self.k + 2 - self.slabs)
+        # the slab at the cursor (and its half-written successor after the next step) overwrite the oldest ones; in row mode
+        # the oldest transition's observation also reaches keep_back slabs further back
+        self.first = max(self.first, self.k + 2 - self.slabs + self.keep_back)
         self.gaps = [g for g in self.gaps if g >= self.first]
         self.length = self.n_envs * (self.k - self.first - len(self.gaps))
 
@@ -186,8 +215,12 @@ class DeviceReplayBuffer:
 
         na = n * self.act_dim
         small = take(self.small_ring, slot, batch_size)
-        out = {"state": take(self.obs_ring, slot, batch_size).view(batch_size, n, self.obs_dim),
-               "next_state": take(self.obs_ring, slot + N, batch_size).view(batch_size, n, self.obs_dim),
+        if self.row_mode:
+            state, next_state = self.stacked_obs(slot, batch_size), self.stacked_obs(slot + N, batch_size)
+        else:
+            state, next_state = take(self.obs_ring, slot, batch_size), take(self.obs_ring, slot + N, batch_size)
+        out = {"state": state.view(batch_size, n, self.obs_dim),
+               "next_state": next_state.view(batch_size, n, self.obs_dim),
                "last_hid": take(self.hid_ring, slot, batch_size).view(batch_size, n, self.hid_dim),
                "hid": take(self.hid_ring, slot + N, batch_size).view(batch_size, n, self.hid_dim),
                "action": small[:, :na].reshape(batch_size, n, self.act_dim),
@@ -198,10 +231,30 @@ class DeviceReplayBuffer:
             out[k]._flex_const = float(c)
         return Transition(**out)
 
+    def stacked_obs(self, slot, rows, out=None):
+        """Row mode: the stacked observations [rows, n_agents * obs_dim] of the global slot range [slot, slot + rows), formed
+        from the row ring by ONE launch of flexnet_gather_window (include/flexnet.h); the ring's seam is the kernel's business."""
+        import ctypes as C
+        from . import _lib
+        if out is None:
+            out = th.empty(rows, self.n_agents * self.obs_dim, dtype=th.float32, device=self.device)
+        a = _lib.FlexWindowArgs()
+        a.row_ring, a.dst, a.rows, a.first_slot = self.row_ring.data_ptr(), out.data_ptr(), rows, int(slot)
+        a.n_envs, a.n_agents, a.history, a.slabs = self.n_envs, self.n_agents, self.history, self.slabs
+        _lib.check(_lib.load().flexnet_gather_window(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)),
+                   "flexnet_gather_window")
+        return out
+
+    @property
+    def obs_source_ring(self):
+        """Name of the ring observations are gathered from: "row_ring" (row mode) or "obs_ring"."""
+        return "row_ring" if self.row_mode else "obs_ring"
+
     # what a field of the Transition is in the ring: (ring name, first column, width or None = whole row, slab offset)
     def field_source(self, name):
         n, na = self.n_agents, self.n_agents * self.act_dim
-        return {"state": ("obs_ring", 0, None, 0), "next_state": ("obs_ring", 0, None, 1),
+        obs = self.obs_source_ring
+        return {"state": (obs, 0, None, 0), "next_state": (obs, 0, None, 1),
                 "last_hid": ("hid_ring", 0, None, 0), "hid": ("hid_ring", 0, None, 1),
                 "action": ("small_ring", 0, na, 0), "reward": ("small_ring", na, n, 0),
                 "done": ("small_ring", na + n, 1, 0), "last_step": ("small_ring", na + n + 1, 1, 0),
@@ -223,6 +276,9 @@ class DeviceReplayBuffer:
         from . import _lib
         jobs = []
         for ring_name, col0, width, row_off, rows, dst in plan:
+            if ring_name == "row_ring":                  # stacked observations out of the row ring: a launch of its own kind
+                self.stacked_obs(slot + row_off, rows, out=dst)
+                continue
             ring = getattr(self, ring_name)
             stride = ring.shape[2]
             width = stride if width is None else width

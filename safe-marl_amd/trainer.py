@@ -355,7 +355,7 @@ class PGTrainer(object):
         if "state" in names and "next_state" in names:
             w = buf.n_agents * buf.obs_dim
             win = block(bs + N, w)
-            plan.append(("obs_ring", 0, None, 0, bs + N, win))
+            plan.append((buf.obs_source_ring, 0, None, 0, bs + N, win))
             fields["state"] = win[:bs].view((bs,) + buf.field_shape("state"))
             fields["next_state"] = win[N:N + bs].view((bs,) + buf.field_shape("next_state"))
         for k in names:

@@ -41,7 +41,8 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.FlexCfg) == 200          # 10 x int32 + 19 x double + uint64
     assert C.sizeof(_lib.NetFix) == 16 + 6 * 8
     assert C.sizeof(_lib.SeriesTab) == 24 and C.sizeof(_lib.ResetSpec) == 40
-    assert C.sizeof(_lib.FlexActorArgs) == 8 * 4 + 17 * 8 + 4 * 4 + 8 + 4 * 8 + 6 * 8 + 8 # include/flexnet.h (+ ring_slabs)
+    assert C.sizeof(_lib.FlexActorArgs) == 8 * 4 + 17 * 8 + 4 * 4 + 8 + 4 * 8 + 6 * 8 + 8 + 8 + 4 * 4   # include/flexnet.h (+ ring_slabs, obs_pushed ...)
+    assert C.sizeof(_lib.FlexObsSource) == 2 * 8 + 4 * 4 and C.sizeof(_lib.FlexWindowArgs) == 4 * 8 + 4 * 4
     assert C.sizeof(_lib.FlexReplaySink) == 7 * 8 + 4 * 4                                   # include/flexenv.h
     assert C.sizeof(_lib.FlexGruBwdArgs) == 2 * 4 + 23 * 8 + 3 * 8 + 6 * 4
     assert C.sizeof(_lib.FlexCriticTailArgs) == 4 * 4 + 18 * 8 + 2 * 4 + 2 * 8 + 8 + 8 + 4 * 4 + 4 * 4 + 8

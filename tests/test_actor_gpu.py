@@ -165,3 +165,34 @@ def test_rollout_size_kernel_equals_the_32_row_kernel_per_row(b):
     r16 = fused_actor_forward(agent, rot(obs), rot(hid), 5, True, noise=rot(noise), variant=2)
     for x, y in zip(o16, r16):
         assert torch.equal(rot(x.view(b, 5, -1)), y.view(b, 5, -1))
+
+
+@pytest.mark.parametrize("variant,n_envs", [(0, 64), (1, 64), (3, 64), (0, 4096), (3, 8192), (2, 1001)])
+def test_observations_read_in_place_from_the_environment_history(variant, n_envs):
+    """FlexActorArgs.obs_pushed (include/flexnet.h): the policy kernels read the stacked observation IN PLACE from the
+    environment's mirror ring (flexenv_obs_source) — same means and hidden states, bit for bit, as from the materialised
+    [N, n, 144] copy (flexenv_obs_view), with the environments at different positions of their rings (a staggered start:
+    part of the batch restarts mid-run) and after the ring has wrapped."""
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from safe_marl_amd.nets import fused_actor_forward
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.series import make_synthetic_series
+    net = create_network()
+    env = VecFlexProvisionEnv({}, n_envs, net=net, series=make_synthetic_series(net, n_days=20), seed=3, warm_start=True)
+    agent = _agent(144, 5, 4)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    env.reset()
+    hid = torch.randn(n_envs, 5, 64, device="cuda", generator=g)
+    mask = (torch.arange(n_envs, device="cuda") % 3 == 0).to(torch.uint8)
+    for t in range(40):
+        if t == 11:
+            env.reset(mask=mask, want_obs=True)                 # a third of the batch starts a new episode: rings out of phase
+        env.step(0.5 + 0.5 * torch.rand(n_envs, 5, 4, device="cuda", generator=g), obs_rows=True)
+        if t in (0, 5, 12, 22, 23, 39):
+            stacked = env.obs_view().clone()
+            want = fused_actor_forward(agent, stacked, hid, 5, True, variant=variant)
+            got = fused_actor_forward(agent, stacked, hid, 5, True, variant=variant, obs_source=env.obs_source())
+            assert want is not None and got is not None
+            assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1]), t
+    pushed = env.peek("STEPS")
+    assert int(pushed.min()) != int(pushed.max())               # the batch really was out of phase

@@ -331,7 +331,8 @@ def _philox_specs(n, episode, seed, series, na=5):
 
 def test_bench_workload_auto_reset_4096_envs_against_c_oracle_across_episode_boundaries(net):
     """The EXACT workload bench.py times (BASELINE.json config 2 as measured): 4096 envs, warm-started solver,
-    ``step(fuse_obs=True, auto_reset=True)`` — every environment terminates at vector steps 95 and 190 and restarts INSIDE
+    ``step(obs_rows=True, auto_reset=True)`` (get_obs() as a row push; the stacked observation is read back through
+    ``obs_view()``) — every environment terminates at vector steps 95 and 190 and restarts INSIDE
     the launch from the device's Philox reset stream (model.py:208,255-262: reset per episode).  205 steps = two episode
     boundaries; the C oracle is restarted at each boundary from the restated stream (episode counters 1 and 2).  Reward,
     info, V, E <= 1e-10; done exact; the fused observation (the new episode's first one at a boundary) equal after the
@@ -354,7 +355,7 @@ def test_bench_workload_auto_reset_4096_envs_against_c_oracle_across_episode_bou
     boundaries = 0
     for t in range(205):
         acts = rng.uniform(0.5, 1.0, (n, 5, 4)).astype(np.float32)    # the range bench.py draws from
-        reward, done, info = vec.step(torch.from_numpy(acts).cuda(), fuse_obs=True, auto_reset=True)
+        reward, done, info = vec.step(torch.from_numpy(acts).cuda(), obs_rows=True, auto_reset=True)    # bench.py's one_step
         r2, d2, i2 = cenv.step(acts.astype(np.float64))
         worst_r = max(worst_r, np.abs(reward.cpu().numpy() - r2).max())
         worst_i = max(worst_i, np.abs(info.cpu().numpy() - i2).max())
@@ -372,9 +373,44 @@ def test_bench_workload_auto_reset_4096_envs_against_c_oracle_across_episode_bou
         if t % 8 == 0 or d2.all() or t in (95, 96, 190, 191, 204):
             worst_v = max(worst_v, np.abs(vec.peek("V").cpu().numpy() - cenv.V).max())
             worst_e = max(worst_e, np.abs(vec.peek("E").cpu().numpy() - cenv.E).max())
-            assert np.allclose(vec.obs.cpu().numpy(), cenv.obs, rtol=2e-7, atol=0), t
+            assert np.allclose(vec.obs_view().cpu().numpy(), cenv.obs, rtol=2e-7, atol=0), t
     assert boundaries == 2
     assert worst_r < TOL and worst_v < TOL and worst_e < TOL and worst_i < 1e-9, (worst_r, worst_v, worst_e, worst_i)
+
+
+@pytest.mark.parametrize("cfg,blds,n", [({}, [5, 10, 15, 20, 25], 37), ({"episode_limit": 7}, [5, 15, 25], 64),
+                                        ({"history": 3, "episode_limit": 9}, [5, 10, 15, 20, 25], 33),
+                                        ({"history": 30, "episode_limit": 40}, [2, 6, 12, 18, 22, 25, 30, 33], 9)])
+def test_row_push_leaves_the_observation_a_stacked_copy_would(net, cfg, blds, n):
+    """FLEX_STEP_OBS_ROWS (include/flexenv.h): get_obs() as a push of the step's feature row into the env's mirror ring +
+    ``obs_view()`` == get_obs() as a stacked copy (``fuse_obs``), bit for bit, step by step, across in-launch restarts, for
+    history / agent counts on both sides of the register path; and the two forms can be mixed on one environment."""
+    import torch
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    args = dict(cfg, buildings=blds, pv_nodes=blds, ess_nodes=blds)
+    netx = create_network(args)
+    sx = make_synthetic_series(netx, n_days=8)
+    a = VecFlexProvisionEnv(args, n, series=sx, net=netx, seed=7, warm_start=True)
+    b = VecFlexProvisionEnv(args, n, series=sx, net=netx, seed=7, warm_start=True)
+    c = VecFlexProvisionEnv(args, n, series=sx, net=netx, seed=7, warm_start=True)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    first = a.reset().clone()
+    b.reset(want_obs=True)
+    c.reset()
+    assert torch.equal(first, b.obs_view().clone()) and torch.equal(first, c.obs)
+    steps = 3 * int(cfg.get("episode_limit", 96)) + 5 if "episode_limit" in cfg else 60
+    for t in range(steps):
+        acts = 0.5 + 0.5 * torch.rand(n, len(blds), 4, device="cuda", generator=g)
+        ra, da, _ = a.step(acts, fuse_obs=True, auto_reset=True)
+        rb, db, _ = b.step(acts, obs_rows=True, auto_reset=True)
+        (c.step(acts, fuse_obs=True, auto_reset=True) if t % 3 else c.step(acts, obs_rows=True, auto_reset=True))
+        assert torch.equal(ra, rb) and torch.equal(da, db)
+        want = a.obs.clone()
+        assert torch.equal(b.obs_view(), want), t
+        assert torch.equal(c.obs if t % 3 else c.obs_view(), want), t
+    assert int(da.sum()) == 0 or "episode_limit" in cfg
 
 
 @pytest.mark.parametrize("cfg,blds", [

@@ -94,11 +94,13 @@ def test_graph_capture_with_the_fused_step():
     torch.cuda.synchronize()
     assert not torch.equal(before, fast.obs) and all(torch.isfinite(v).all() for v in _fields(fast).values())
     assert fast.buf.k == 3 and fast.buf.cursor.tolist() == [3, 2]
-    # the exploration noise is drawn anew on every replay (graph-safe Philox offsets), not frozen at capture
-    o0, h0 = fast.obs.clone(), fast.hid.clone()
+    # the exploration noise is drawn anew on every replay (graph-safe Philox offsets), not frozen at capture: with a policy
+    # that ignores its inputs (all weights zero: mean = fc2's bias = 0) two replays differ exactly by their draws
+    with torch.no_grad():
+        for p_ in fast.model.policy_dicts.parameters():
+            p_.zero_()
     acts = []
     for _ in range(2):
-        fast.obs.copy_(o0); fast.hid.copy_(h0)
         fast.step()
         torch.cuda.synchronize()
         acts.append(_fields(fast)["action"].clone())
@@ -112,10 +114,11 @@ def test_graph_replays_with_torch_noise_too():
     fast.start_episode(fast.env.reset())
     fast.capture()
     fast.start_episode(fast.env.reset())
-    o0, h0 = fast.obs.clone(), fast.hid.clone()
+    with torch.no_grad():                                  # (a policy that ignores its inputs: replays differ by their draws)
+        for p_ in fast.model.policy_dicts.parameters():
+            p_.zero_()
     acts = []
     for _ in range(2):
-        fast.obs.copy_(o0); fast.hid.copy_(h0)
         fast.step()
         torch.cuda.synchronize()
         acts.append(_fields(fast)["action"].clone())
@@ -284,28 +287,32 @@ def test_graph_replays_equal_eager_steps_bit_for_bit():
 
 
 def test_ring_wraps_and_windows_stay_consecutive():
-    """Slab ring bookkeeping on the device and its host mirror: 30 steps through a ring of 12 slabs, a hard restart in
-    the middle (gap), sampled windows are consecutive transitions of one stream (utils/replay_buffer.py:17-21) whose
-    next_state is the following slab's state, and the gathered static batch equals the window read eagerly."""
+    """Slab ring bookkeeping on the device and its host mirror: 80 steps through a ring of 12 + 23 slabs (row mode: the 23
+    slabs behind the oldest transition stay, its stacked observation reaches into them), two hard restarts on the way
+    (gaps), sampled windows are consecutive transitions of one stream (utils/replay_buffer.py:17-21) whose next_state is
+    the following slab's state — every stacked observation formed from the row ring equals what the policy saw — and the
+    gathered static batch equals the window read eagerly."""
     import numpy as np
     from safe_marl_amd.replay_buffer import TransReplayBuffer
     from safe_marl_amd.learner import RolloutGraph
     (rg, _), N = _setup(16), 16
     rg = RolloutGraph(rg.model, rg.env, TransReplayBuffer(N * 12, device="cuda"))
     buf = rg.buf
-    assert buf.slabs == 12
+    assert buf.row_mode and buf.keep_back == 23 and buf.slabs == 12 + 23
+    S = buf.slabs
     rg.start_episode(rg.env.reset())
     states = {}
-    for t in range(30):
-        if t == 17:
-            rg.start_episode(rg.env.reset())          # hard restart: slab 17 stays half-written -> gap
+    for t in range(80):
+        if t in (17, 61):
+            rg.start_episode(rg.env.reset())          # hard restart: the slab at the cursor stays half-written -> gap
         k = buf.k
         states[k] = rg.obs.clone()
         rg.step()
     torch.cuda.synchronize()
+    K = 82                                            # 80 steps + 2 gap slabs
     assert buf.gaps == [] or all(g >= buf.first for g in buf.gaps)
-    assert buf.k == 31 and buf.cursor.tolist() == [31 % 12, 30 % 12] and buf.first == 31 + 2 - 12
-    assert len(buf.buffer) == N * (31 - buf.first - len(buf.gaps))
+    assert buf.k == K and buf.cursor.tolist() == [K % S, (K - 1) % S] and buf.first == K + 2 - 12
+    assert len(buf.buffer) == N * (K - buf.first - len(buf.gaps))
     np.random.seed(0)
     for _ in range(50):
         bs = 3 * N + 5
@@ -319,10 +326,12 @@ def test_ring_wraps_and_windows_stay_consecutive():
             assert torch.equal(w.state[r], states[j][e])
             if j + 1 in states:
                 assert torch.equal(w.next_state[r], states[j + 1][e])
-    # one gather launch fills a static batch with exactly that window (seam of the ring included)
+    # one gather launch per kind fills a static batch with exactly that window (seam of the ring included)
     bs = 2 * N
     plan_out = {k: torch.zeros((bs,) + buf.field_shape(k), device="cuda") for k in buf.STORED}
-    for slot in (buf.first * N + 3, (buf.k - 3) * N + 1, 23 * N + 9):          # 24 % 12 == 0: the third one crosses the seam
+    seam = (K // S) * S                                # a slab counter at physical slab 0
+    assert buf.first < seam - 1 and seam + 1 < buf.k
+    for slot in (buf.first * N + 3, (buf.k - 3) * N + 1, (seam - 1) * N + 9):    # the third one crosses the seam
         if any(slot // N <= g <= (slot + bs - 1) // N for g in buf.gaps):
             continue
         plan = []
@@ -402,13 +411,15 @@ def test_bursts_of_steps_equal_single_steps_bit_for_bit(fast):
         for name in ("obs", "hid", "info_sum", "rew_sum", "fail_sum", "rng_state"):
             assert torch.equal(getattr(a, name), getattr(b, name)), (m, name)
         assert torch.equal(a.buf.cursor, b.buf.cursor)
-        for ring in ("obs_ring", "hid_ring", "small_ring"):
+        assert a.buf.obs_source_ring == b.buf.obs_source_ring
+        for ring in (a.buf.obs_source_ring, "hid_ring", "small_ring"):
             assert torch.equal(getattr(a.buf, ring), getattr(b.buf, ring)), (m, ring)
     # b never replayed a burst.  (fast, five agents: run(m) is the fused burst launch of flexenv_rollout_burst, any length
     # below the ring's eight slabs — the comparison above is that launch against single policy + environment launches)
     assert a.fused_burst == fast
     if fast:       # every length is a graph of its own, recorded at first use here (capture() was given no schedule):
-        assert sorted(k for k, _ in a.bursts) == [2, 3, 7] and not b.bursts          # 31 = 4 x 7 + 3, 7, 16 = 7 + 7 + 2 under an 8-slab ring
+        assert a.buf.slabs == 8 + 23                   # row mode: 23 slabs of history behind the 8 of the ring
+        assert sorted(k for k, _ in a.bursts) == [7, 16, 30] and not b.bursts        # 31 = 30 + 1 under a 31-slab ring, 7, 16
     else:
         assert sorted(k for k, _ in a.bursts) == [2, 4, 8, 16] == sorted(k for k, _ in b.bursts)
     assert a.env.calls == calls                                # replays never go through env.step; recording is undone
@@ -450,7 +461,7 @@ def test_training_loop_schedule_is_unchanged_by_bursts(monkeypatch):
             assert bool(rg.bursts) == bool(bursts) == rg.fused_burst
             res.append((tr.steps, [p.detach().clone() for p in tr.behaviour_net.parameters()],
                         [p.detach().clone() for p in tr.behaviour_net.target_net.parameters()],
-                        tr.replay_buffer.small_ring.clone(), tr.replay_buffer.obs_ring.clone()))
+                        tr.replay_buffer.small_ring.clone(), getattr(tr.replay_buffer, tr.replay_buffer.obs_source_ring).clone()))
     finally:
         RolloutGraph.BURSTS = saved
     assert res[0][0] == res[1][0] == 190
@@ -605,7 +616,8 @@ def test_burst_launch_equals_two_launches_per_step_bit_for_bit(n_envs, buildings
     assert sa == sb and a.buf.k == b.buf.k
     assert torch.equal(a.buf.cursor, b.buf.cursor) and torch.equal(a.rng_state, b.rng_state)
     assert int(a.rng_state[1].item()) == 5 + 123
-    for ring in ("obs_ring", "hid_ring", "small_ring"):
+    assert a.buf.row_mode and b.buf.row_mode             # the env's step files feature rows; nothing copies an observation
+    for ring in ("row_ring", "hid_ring", "small_ring"):
         assert torch.equal(getattr(a.buf, ring), getattr(b.buf, ring)), ring
     for name in ("acc", "act_buf", "hid_buf"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
@@ -658,7 +670,8 @@ def test_safemaddpg_burst_equals_three_launches_per_step_bit_for_bit(N, monkeypa
         runs.append((rg, slabs, env))
     (a, sa, ea), (b, sb, eb) = runs
     assert sa == sb and torch.equal(a.buf.cursor, b.buf.cursor) and torch.equal(a.rng_state, b.rng_state)
-    for ring in ("obs_ring", "hid_ring", "small_ring"):
+    assert a.buf.row_mode and b.buf.row_mode             # the env's step files feature rows; nothing copies an observation
+    for ring in ("row_ring", "hid_ring", "small_ring"):
         assert torch.equal(getattr(a.buf, ring), getattr(b.buf, ring)), ring
     for name in ("acc", "act_buf", "hid_buf"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name

@@ -38,7 +38,7 @@ def test_graphed_sub_updates_equal_eager_ones(n_envs):
     a, b = _trainer(True, n_envs), _trainer(False, n_envs)
     for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
         assert torch.equal(va, vb), ka                           # same start
-    for ring in ("obs_ring", "hid_ring", "small_ring"):
+    for ring in (a.replay_buffer.obs_source_ring, "hid_ring", "small_ring"):
         assert torch.equal(getattr(a.replay_buffer, ring), getattr(b.replay_buffer, ring)), ring
     for which in ("value", "value", "policy", "policy", "value", "policy"):
         stats = []

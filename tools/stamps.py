@@ -22,20 +22,21 @@ env.reset()
 kw = {}
 if sink:
     from safe_marl_amd.replay_buffer import TransReplayBuffer
-    buf = TransReplayBuffer(N * 16, device='cuda'); buf.alloc_slabs(N, 5, 144, 4, 64)
+    buf = TransReplayBuffer(N * 16, device='cuda'); buf.alloc_slabs(N, 5, 144, 4, 64, history=24)
     act_buf = torch.rand(N * 5, 4, device='cuda'); hid_buf = torch.randn(N * 5, 64, device='cuda')
     acc = torch.zeros(N, 10, dtype=torch.float64, device='cuda')
-    env.set_obs_ring(buf.cursor[1:], N * 5 * 144, buf.slabs)
+    env.set_obs_ring(buf.cursor[1:], N * 5 * buf.ROW_W, buf.slabs)
     env.set_replay_sink(act_buf, hid_buf, buf.small_ring, buf.hid_ring, acc, cursor_out=buf.cursor[0:1])
-    kw = dict(obs_ring=buf.obs_ring, replay_sink=True)
+    kw = dict(obs_ring=buf.row_ring, replay_sink=True)
     def adv():                      # the policy kernel's part of the cursor protocol: cell 1 = the slab it just read
         buf.cursor[1] = buf.cursor[0]
 else:
     def adv(): pass
-for k in range(30): adv(); env.step(pool[k%8], fuse_obs=True, auto_reset=True, **kw)
+kw.setdefault('obs_rows', True)
+for k in range(30): adv(); env.step(pool[k%8], auto_reset=True, **kw)
 lib.flexenv_debug_set_stamps.argtypes=[C.c_void_p]
 lib.flexenv_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
-adv(); env.step(pool[0], fuse_obs=True, auto_reset=True, **kw)
+adv(); env.step(pool[0], auto_reset=True, **kw)
 torch.cuda.synchronize()
 st=stamps.cpu().numpy().astype(np.float64)
 t0=st[:,0].min()
