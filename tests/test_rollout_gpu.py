@@ -287,7 +287,7 @@ def test_graph_replays_equal_eager_steps_bit_for_bit():
 
 
 def test_ring_wraps_and_windows_stay_consecutive():
-    """Slab ring bookkeeping on the device and its host mirror: 80 steps through a ring of 12 + 23 slabs (row mode: the 23
+    """Slab ring bookkeeping on the device and its host mirror: 73 steps through a ring of 12 + 23 slabs (row mode: the 23
     slabs behind the oldest transition stay, its stacked observation reaches into them), two hard restarts on the way
     (gaps), sampled windows are consecutive transitions of one stream (utils/replay_buffer.py:17-21) whose next_state is
     the following slab's state — every stacked observation formed from the row ring equals what the policy saw — and the
@@ -302,14 +302,14 @@ def test_ring_wraps_and_windows_stay_consecutive():
     S = buf.slabs
     rg.start_episode(rg.env.reset())
     states = {}
-    for t in range(80):
-        if t in (17, 61):
+    for t in range(73):
+        if t in (17, 55):
             rg.start_episode(rg.env.reset())          # hard restart: the slab at the cursor stays half-written -> gap
         k = buf.k
         states[k] = rg.obs.clone()
         rg.step()
     torch.cuda.synchronize()
-    K = 82                                            # 80 steps + 2 gap slabs
+    K = 75                                            # 73 steps + 2 gap slabs
     assert buf.gaps == [] or all(g >= buf.first for g in buf.gaps)
     assert buf.k == K and buf.cursor.tolist() == [K % S, (K - 1) % S] and buf.first == K + 2 - 12
     assert len(buf.buffer) == N * (K - buf.first - len(buf.gaps))

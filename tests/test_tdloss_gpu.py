@@ -160,7 +160,7 @@ def test_cross_rank_statistics_path_with_two_identical_ranks(monkeypatch):
         bn = torch.nn.BatchNorm1d(n).cuda()
         q = q0.clone().requires_grad_(True)
         if sync:
-            monkeypatch.setattr(nets, "_sync_active", lambda: True)
+            monkeypatch.setattr(nets, "_sync_active", lambda bn=None: True)
             monkeypatch.setattr(dist, "all_reduce", lambda t, op=None: t.mul_(2.0))
             monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 2)
         try:
