@@ -185,50 +185,53 @@ extern "C" int flexnet_agent_sum_explore(const FlexAgentSumArgs* a, void* stream
 }
 
 // ---- stacked observations of a replay window from the row ring (flexnet_gather_window) -------------------------------------
-// A block forms the stacked observations of 64 consecutive (output row, agent) pairs — 64 x 576 B, contiguous in the
-// output.  Reads: wavefront w takes history offsets h = w, w + 4, ...; for one h its 64 lanes read the 32-byte records of 64
-// consecutive (env, agent) pairs of ONE slab — 2 KB contiguous (the first version, one thread per 24-byte chunk with
-// consecutive lanes on consecutive h, read 64 different slabs per wavefront load: 64 separate 32-byte requests, and took as
-// long as the copy of stacked observations it replaced: 49.8 us at the update batch).  The 24-byte chunks are transposed
-// through LDS (pitch 146 floats: 8-byte aligned, lanes on 16 distinct bank pairs) and leave as coalesced 8-byte stores.
-// The slab region a launch re-reads — (window + history) x N x n x 32 B = 21 MB at the update batch — stays in cache; the
-// launch is bound by its 106 MB of stores.
+// A block owns 16 consecutive (env, agent) pairs for a run of up to 16 consecutive slabs of the window: it stages the
+// 16 + history - 1 slabs of 32-byte records those outputs reach into in LDS ONCE (each record is used by up to `history`
+// outputs: 2.4 records read per stacked row written instead of 24) and writes, per slab, the 16 pairs' stacked
+// observations — 16 x 576 B contiguous in the output — as coalesced 8-byte stores.  Round-4 history of this launch at the
+// update batch (36 864 rows): one thread per 24-byte chunk with lanes on consecutive history slots (64 different slabs per
+// wavefront load) 36 us; lanes on consecutive pairs + an LDS transpose, every record still read `history` times from
+// cache, 31.8 us (the reads cross the fabric: 141 MB next to 106 MB of stores); time-blocked as here: see DESIGN.md §4.8.
 #define WINDOW_THREADS 256
-#define WINDOW_PAIRS 64
+#define WINDOW_PAIRS 16
+#define WINDOW_SLABS 16
 #define WINDOW_MAX_H 32
+#define WINDOW_PITCH (WINDOW_PAIRS * 8 + 2)          // floats per staged slab: + 2 keeps the history slots of a store on different banks
 typedef float win_f2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(WINDOW_THREADS) void gather_window_kernel(FlexWindowArgs a) {
-    const int H = a.history, n = a.n_agents, w = H * 6, pitch = w + 2;
-    __shared__ float tile[WINDOW_PAIRS * (WINDOW_MAX_H * 6 + 2)];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t pairs = a.rows * n, pair0 = (int64_t)blockIdx.x * WINDOW_PAIRS;
-    const int64_t pair = pair0 + lane < pairs ? pair0 + lane : pairs - 1;          // (clamped: loads stay in bounds)
-    const int64_t row = pair / n;
-    const int ag = (int)(pair - row * n);
-    const int64_t slot = a.first_slot + row, sl = slot / a.n_envs;
-    const int env = (int)(slot - sl * a.n_envs), slab = (int)(sl % a.slabs);
-    const float older = a.row_ring[(((int64_t)slab * a.n_envs + env) * n + ag) * 8 + 6];
-    for (int h = wave; h < H; h += WINDOW_THREADS / 64) {
-        const int back = H - 1 - h;
-        int src = slab - back;
-        src = src < 0 ? src + a.slabs : src;
-        const float* r = a.row_ring + (((int64_t)src * a.n_envs + env) * n + ag) * 8;
-        const pack_f4 v0 = *reinterpret_cast<const pack_f4*>(r);
-        const win_f2 v1 = *reinterpret_cast<const win_f2*>(r + 4);
-        const bool live = (float)back <= older;
-        win_f2* t = reinterpret_cast<win_f2*>(tile + lane * pitch + h * 6);
-        t[0] = live ? win_f2{v0.x, v0.y} : win_f2{0.0f, 0.0f};
-        t[1] = live ? win_f2{v0.z, v0.w} : win_f2{0.0f, 0.0f};
-        t[2] = live ? v1 : win_f2{0.0f, 0.0f};
+    __shared__ float rec[(WINDOW_SLABS + WINDOW_MAX_H - 1) * WINDOW_PITCH];
+    const int H = a.history, n = a.n_agents, tid = threadIdx.x;
+    const int64_t npairs = (int64_t)a.n_envs * n;                      // (env, agent) pairs of one slab
+    const int64_t q0 = (int64_t)blockIdx.x * WINDOW_PAIRS;
+    const int np = npairs - q0 < WINDOW_PAIRS ? (int)(npairs - q0) : WINDOW_PAIRS;
+    const int64_t sl_lo = a.first_slot / a.n_envs, sl_hi = (a.first_slot + a.rows - 1) / a.n_envs;
+    const int64_t sl0 = sl_lo + (int64_t)blockIdx.y * WINDOW_SLABS;     // first slab (counter) of this block's run
+    const int nt = sl_hi - sl0 + 1 < WINDOW_SLABS ? (int)(sl_hi - sl0 + 1) : WINDOW_SLABS;
+    // stage slabs sl0 - (H - 1) .. sl0 + nt - 1: 16 pairs x 32 B contiguous per slab, as 16-byte loads
+    const int ns = nt + H - 1;
+    for (int i = tid; i < ns * np * 2; i += WINDOW_THREADS) {
+        const int s = i / (np * 2), r = i - s * (np * 2);
+        int64_t sl = (sl0 - (H - 1) + s) % a.slabs;
+        sl = sl < 0 ? sl + a.slabs : sl;
+        const pack_f4 v = *reinterpret_cast<const pack_f4*>(a.row_ring + (sl * npairs + q0) * 8 + 4 * r);
+        float* d = rec + s * WINDOW_PITCH + 4 * r;
+        *reinterpret_cast<win_f2*>(d) = win_f2{v.x, v.y};
+        *reinterpret_cast<win_f2*>(d + 2) = win_f2{v.z, v.w};
     }
     __syncthreads();
-    const int64_t left = pairs - pair0;
-    const int np = left < WINDOW_PAIRS ? (int)left : WINDOW_PAIRS;
-    const int w2 = w >> 1;                                                         // 8-byte units per pair
-    win_f2* out = reinterpret_cast<win_f2*>(a.dst + pair0 * w);
-    for (int i = tid; i < np * w2; i += WINDOW_THREADS) {
-        const int p = i / w2, c = i - p * w2;
-        out[i] = *reinterpret_cast<const win_f2*>(tile + p * pitch + 2 * c);
+    const int w2 = 3 * H;                                              // 8-byte units of one stacked observation
+    const int per_slab = np * w2;
+    for (int i = tid; i < nt * per_slab; i += WINDOW_THREADS) {
+        const int ts = i / per_slab, j = i - ts * per_slab;            // j: 8-byte unit within the slab's 16 pairs (contiguous output)
+        const int p = j / w2, c = j - p * w2, h = c / 3, f2 = c - 3 * h;
+        // output row of (slab sl0 + ts, env of pair q0 + p): inside the window?
+        const int64_t q = q0 + p, env = q / n;
+        const int64_t row = (sl0 + ts) * a.n_envs + env - a.first_slot;
+        if (row < 0 || row >= a.rows) continue;
+        const float older = rec[(ts + H - 1) * WINDOW_PITCH + p * 8 + 6];
+        const win_f2 v = *reinterpret_cast<const win_f2*>(rec + (ts + h) * WINDOW_PITCH + p * 8 + 2 * f2);
+        const bool live = (float)(H - 1 - h) <= older;
+        reinterpret_cast<win_f2*>(a.dst + (row * n + (q - env * n)) * (int64_t)(6 * H))[c] = live ? v : win_f2{0.0f, 0.0f};
     }
 }
 
@@ -238,9 +241,12 @@ extern "C" int flexnet_gather_window(const FlexWindowArgs* a, void* stream) {
         ((reinterpret_cast<uintptr_t>(a->row_ring) & 15) | (reinterpret_cast<uintptr_t>(a->dst) & 7)))
         return FLEXNET_EINVAL;
     if (a->rows == 0) return FLEXNET_OK;
-    const int64_t blocks = (a->rows * a->n_agents + WINDOW_PAIRS - 1) / WINDOW_PAIRS;
-    if (blocks > 0x7fffffffll) return FLEXNET_EUNSUPPORTED;
-    hipLaunchKernelGGL(gather_window_kernel, dim3((unsigned)blocks), dim3(WINDOW_THREADS), 0, (hipStream_t)stream, *a);
+    const int64_t npairs = (int64_t)a->n_envs * a->n_agents;
+    const int64_t bx = (npairs + WINDOW_PAIRS - 1) / WINDOW_PAIRS;
+    const int64_t nslabs = (a->first_slot + a->rows - 1) / a->n_envs - a->first_slot / a->n_envs + 1;
+    const int64_t by = (nslabs + WINDOW_SLABS - 1) / WINDOW_SLABS;
+    if (bx > 0x7fffffffll || by > 65535) return FLEXNET_EUNSUPPORTED;
+    hipLaunchKernelGGL(gather_window_kernel, dim3((unsigned)bx, (unsigned)by), dim3(WINDOW_THREADS), 0, (hipStream_t)stream, *a);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 
