@@ -198,40 +198,69 @@ extern "C" int flexnet_agent_sum_explore(const FlexAgentSumArgs* a, void* stream
 #define WINDOW_MAX_H 32
 #define WINDOW_PITCH (WINDOW_PAIRS * 8 + 2)          // floats per staged slab: + 2 keeps the history slots of a store on different banks
 typedef float win_f2 __attribute__((ext_vector_type(2)));
+// HC: history as a compile-time constant (24: the reference's), 0: a.history at run time.  All index arithmetic of the
+// store loop is hoisted out of it (the first time-blocked version divided by run-time values per 8-byte store and was
+// instruction-bound: 48.9 us).
+template <int HC>
 __global__ __launch_bounds__(WINDOW_THREADS) void gather_window_kernel(FlexWindowArgs a) {
     __shared__ float rec[(WINDOW_SLABS + WINDOW_MAX_H - 1) * WINDOW_PITCH];
-    const int H = a.history, n = a.n_agents, tid = threadIdx.x;
+    __shared__ int64_t obase[WINDOW_PAIRS];          // (row * n + agent) of pair p at the block's first slab
+    __shared__ int penv[WINDOW_PAIRS];
+    const int H = HC ? HC : a.history, n = a.n_agents, tid = threadIdx.x;
     const int64_t npairs = (int64_t)a.n_envs * n;                      // (env, agent) pairs of one slab
     const int64_t q0 = (int64_t)blockIdx.x * WINDOW_PAIRS;
     const int np = npairs - q0 < WINDOW_PAIRS ? (int)(npairs - q0) : WINDOW_PAIRS;
     const int64_t sl_lo = a.first_slot / a.n_envs, sl_hi = (a.first_slot + a.rows - 1) / a.n_envs;
     const int64_t sl0 = sl_lo + (int64_t)blockIdx.y * WINDOW_SLABS;     // first slab (counter) of this block's run
     const int nt = sl_hi - sl0 + 1 < WINDOW_SLABS ? (int)(sl_hi - sl0 + 1) : WINDOW_SLABS;
+    if (tid < np) {
+        const int64_t q = q0 + tid, env = q / n;
+        penv[tid] = (int)env;
+        obase[tid] = (sl0 * a.n_envs + env - a.first_slot) * n + (q - env * n);
+    }
     // stage slabs sl0 - (H - 1) .. sl0 + nt - 1: 16 pairs x 32 B contiguous per slab, as 16-byte loads
-    const int ns = nt + H - 1;
-    for (int i = tid; i < ns * np * 2; i += WINDOW_THREADS) {
-        const int s = i / (np * 2), r = i - s * (np * 2);
-        int64_t sl = (sl0 - (H - 1) + s) % a.slabs;
-        sl = sl < 0 ? sl + a.slabs : sl;
-        const pack_f4 v = *reinterpret_cast<const pack_f4*>(a.row_ring + (sl * npairs + q0) * 8 + 4 * r);
-        float* d = rec + s * WINDOW_PITCH + 4 * r;
-        *reinterpret_cast<win_f2*>(d) = win_f2{v.x, v.y};
-        *reinterpret_cast<win_f2*>(d + 2) = win_f2{v.z, v.w};
+    const int ns = nt + H - 1, per_stage = np * 2;
+    for (int s = tid / 32, r = tid % 32; s < ns; s += WINDOW_THREADS / 32) {
+        if (r < per_stage) {
+            int64_t sl = (sl0 - (H - 1) + s) % a.slabs;
+            sl = sl < 0 ? sl + a.slabs : sl;
+            const pack_f4 v = *reinterpret_cast<const pack_f4*>(a.row_ring + (sl * npairs + q0) * 8 + 4 * r);
+            float* d = rec + s * WINDOW_PITCH + 4 * r;
+            *reinterpret_cast<win_f2*>(d) = win_f2{v.x, v.y};
+            *reinterpret_cast<win_f2*>(d + 2) = win_f2{v.z, v.w};
+        }
     }
     __syncthreads();
     const int w2 = 3 * H;                                              // 8-byte units of one stacked observation
     const int per_slab = np * w2;
-    for (int i = tid; i < nt * per_slab; i += WINDOW_THREADS) {
-        const int ts = i / per_slab, j = i - ts * per_slab;            // j: 8-byte unit within the slab's 16 pairs (contiguous output)
-        const int p = j / w2, c = j - p * w2, h = c / 3, f2 = c - 3 * h;
-        // output row of (slab sl0 + ts, env of pair q0 + p): inside the window?
-        const int64_t q = q0 + p, env = q / n;
-        const int64_t row = (sl0 + ts) * a.n_envs + env - a.first_slot;
-        if (row < 0 || row >= a.rows) continue;
-        const float older = rec[(ts + H - 1) * WINDOW_PITCH + p * 8 + 6];
-        const win_f2 v = *reinterpret_cast<const win_f2*>(rec + (ts + h) * WINDOW_PITCH + p * 8 + 2 * f2);
-        const bool live = (float)(H - 1 - h) <= older;
-        reinterpret_cast<win_f2*>(a.dst + (row * n + (q - env * n)) * (int64_t)(6 * H))[c] = live ? v : win_f2{0.0f, 0.0f};
+    constexpr int KMAX = (WINDOW_PAIRS * 3 * (HC ? HC : WINDOW_MAX_H) + WINDOW_THREADS - 1) / WINDOW_THREADS;
+    int src_off[KMAX], old_off[KMAX], back[KMAX], pp[KMAX];
+    int64_t dst_off[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int j = tid + WINDOW_THREADS * k;
+        const bool in = j < per_slab;
+        const int jc = in ? j : 0;
+        const int p = jc / w2, c = jc - p * w2, h = c / 3, f2 = c - 3 * h;
+        pp[k] = in ? p : -1;
+        src_off[k] = h * WINDOW_PITCH + p * 8 + 2 * f2;
+        old_off[k] = (H - 1) * WINDOW_PITCH + p * 8 + 6;
+        back[k] = H - 1 - h;
+        dst_off[k] = obase[p] * (int64_t)(6 * H) + 2 * c;
+    }
+    const int64_t slab_floats = npairs * (int64_t)(6 * H);
+    for (int ts = 0; ts < nt; ++ts) {
+        const float* rs = rec + ts * WINDOW_PITCH;
+        const int64_t row0 = (sl0 + ts) * a.n_envs - a.first_slot;    // + env = output row
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (pp[k] < 0) continue;
+            const int64_t row = row0 + penv[pp[k]];
+            if (row < 0 || row >= a.rows) continue;
+            const win_f2 v = *reinterpret_cast<const win_f2*>(rs + src_off[k]);
+            const bool live = (float)back[k] <= rs[old_off[k]];
+            *reinterpret_cast<win_f2*>(a.dst + dst_off[k] + ts * slab_floats) = live ? v : win_f2{0.0f, 0.0f};
+        }
     }
 }
 
@@ -246,7 +275,8 @@ extern "C" int flexnet_gather_window(const FlexWindowArgs* a, void* stream) {
     const int64_t nslabs = (a->first_slot + a->rows - 1) / a->n_envs - a->first_slot / a->n_envs + 1;
     const int64_t by = (nslabs + WINDOW_SLABS - 1) / WINDOW_SLABS;
     if (bx > 0x7fffffffll || by > 65535) return FLEXNET_EUNSUPPORTED;
-    hipLaunchKernelGGL(gather_window_kernel, dim3((unsigned)bx, (unsigned)by), dim3(WINDOW_THREADS), 0, (hipStream_t)stream, *a);
+    if (a->history == 24) hipLaunchKernelGGL(gather_window_kernel<24>, dim3((unsigned)bx, (unsigned)by), dim3(WINDOW_THREADS), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(gather_window_kernel<0>, dim3((unsigned)bx, (unsigned)by), dim3(WINDOW_THREADS), 0, (hipStream_t)stream, *a);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 
