@@ -191,6 +191,15 @@ class _StubVecEnv:
         self._draw_obs()
         return self.obs
 
+    def safety_project(self, proposed, s_p, s_q, beta, v_min, v_max, penalty=1000.0, env_action_range=None, want_hit=True):
+        """A CPU stand-in with the HIP layer's interface and output layout (flex_env.safety_project: [N, 4 n] float64,
+        type-major, safemaddpg.py:297): percentage / charge / discharge clipped at zero, q shifted by the predictor's
+        offset — enough for SAFEMADDPG's control flow (safemaddpg.py:90-111) to run through the data-parallel trainer."""
+        p = proposed.detach().double().reshape(self.n_envs, self.n_agents, 4)
+        adj = th.cat([p[:, :, 0].clamp_min(0), p[:, :, 1].clamp_min(0), p[:, :, 2].clamp_min(0),
+                      p[:, :, 3] + th.as_tensor(beta, dtype=th.float64) * 0.0], dim=1)
+        return adj, th.zeros(self.n_envs, dtype=th.uint8)
+
     def step(self, actions, fuse_obs=True, auto_reset=True):
         self.t += 1
         self.reward = (0.03 + 0.1 * actions.double().mean((1, 2)) + 0.02 * th.randn(self.n_envs, generator=self.gen).double())
@@ -200,9 +209,9 @@ class _StubVecEnv:
         return self.reward, self.done, self.info
 
 
-def _train_worker(rank, world, port, out):
+def _train_worker(rank, world, port, out, alg="maddpg", sync_bn=False):
     import safe_marl_amd  # noqa: F401
-    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.learner import MADDPG, SAFEMADDPG
     from safe_marl_amd.trainer import PGTrainer
     from safe_marl_amd.util import convert
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -210,19 +219,29 @@ def _train_worker(rank, world, port, out):
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     d = json.load(open(os.path.join(G, "learner_args.json")))
-    d.update(behaviour_update_freq=10, target_update_freq=20)
+    d.update(behaviour_update_freq=10, target_update_freq=20, alg=alg, v_min=0.9, v_max=1.1)
     args = convert(d)
     th.manual_seed(100 + rank)                    # different initial weights per rank: the constructor broadcast fixes that
     np.random.seed(7 + rank)                      # ... and a different replay window per rank (per-rank shard)
     env = _StubVecEnv(8, seed=1000 + rank)
-    trainer = PGTrainer(args, MADDPG, env, None, batch_scale=2)
+    if alg == "safemaddpg":                       # trainer.py:16-28 hands SAFEMADDPG the env; a fixed predictor (no fit on the CPU)
+        import functools
+        pred = (th.full((5,), -0.05, dtype=th.float64), th.full((5,), -0.03, dtype=th.float64), th.full((5,), 1.0, dtype=th.float64))
+        cls = functools.partial(SAFEMADDPG, predictor=pred)
+        cls.__name__ = "SAFEMADDPG"
+    else:
+        cls = MADDPG
+    trainer = PGTrainer(args, cls, env, None, batch_scale=2, sync_reward_bn=sync_bn)
     w0 = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.parameters()]).clone()
     stat = {}
     trainer.behaviour_net.train_process(stat, trainer)        # 24 vector steps: update events at steps 10 and 20
     w1 = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.parameters()])
     tgt = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.target_net.parameters()])
+    bn = trainer.behaviour_net.batchnorm
     out[rank] = dict(w0=w0.numpy(), w1=w1.numpy(), tgt=tgt.numpy(), steps=trainer.steps, buf=len(trainer.replay_buffer.buffer),
-                     vloss=float(stat["mean_train_value_loss"]), reward=float(stat["mean_train_reward"]))
+                     vloss=float(stat["mean_train_value_loss"]), reward=float(stat["mean_train_reward"]),
+                     bn_mean=bn.running_mean.numpy().copy(), bn_var=bn.running_var.numpy().copy(), bn_n=int(bn.num_batches_tracked),
+                     model=type(trainer.behaviour_net).__name__)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -246,3 +265,27 @@ def test_train_process_on_two_ranks_keeps_replicas_identical():
     solo = mgr.dict()
     mp.spawn(_train_worker, args=(1, _free_port(), solo), nprocs=1, join=True)
     assert np.array_equal(solo[0]["w0"], a["w0"]) and not np.array_equal(solo[0]["w1"], a["w1"])
+
+
+@pytest.mark.parametrize("alg,sync_bn", [("safemaddpg", False), ("maddpg", True), ("safemaddpg", True)])
+def test_train_process_on_two_ranks_safemaddpg_and_cross_rank_reward_statistics(alg, sync_bn):
+    """the two-rank train_process test for SAFEMADDPG (BASELINE config 4's algorithm under config 5's data
+    parallelism: the safety layer between policy and env, safemaddpg.py:90-111, through a CPU stand-in with the HIP layer's
+    interface) and with ``sync_reward_bn`` — every reward normalisation of the 22 sub-updates sums its moments over the ranks
+    first: replicas AND the reward BatchNorm's running statistics end bit-identical on ranks that saw different data; with
+    per-rank statistics (the default) the running statistics differ."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_train_worker, args=(2, port, out, alg, sync_bn), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    assert a["model"] == b["model"] == ("SAFEMADDPG" if alg == "safemaddpg" else "MADDPG")
+    assert a["steps"] == b["steps"] == 24 and a["buf"] == b["buf"] == 24 * 8
+    assert np.array_equal(a["w0"], b["w0"]) and not np.array_equal(a["w0"], a["w1"])
+    assert np.array_equal(a["w1"], b["w1"]) and np.array_equal(a["tgt"], b["tgt"])
+    assert a["vloss"] != b["vloss"] and a["reward"] != b["reward"]          # the ranks really saw different data
+    assert a["bn_n"] == b["bn_n"] == 22                                     # one normalisation per sub-update
+    if sync_bn:
+        assert np.array_equal(a["bn_mean"], b["bn_mean"]) and np.array_equal(a["bn_var"], b["bn_var"])
+    else:
+        assert not np.array_equal(a["bn_mean"], b["bn_mean"])               # per-rank statistics: the documented deviation
