@@ -1,0 +1,106 @@
+"""GPU: the HIP environment (through the C ABI) against fixtures produced by RUNNING THE REFERENCE'S OWN ENVIRONMENT CODE
+(tests/golden/make_env_golden.py; see tests/test_env_golden_cpu.py for what the three substitutions of that script leave
+pinned: everything of SURVEY §8 rows a3-a12 but the numerical solve, whose voltages are the oracle's Newton-Raphson).
+(1) the vectorised env on the recorded episodes — injected reset draws, the recorded actions — step by step;
+(2) the N = 1 drop-in view constructed and seeded exactly as the reference's env was: same global-NumPy draws, same
+    episode, same return types, over a whole episode, a second reset() and a manual_reset().
+Tolerances: reward / info / V / E / state <= 1e-10 (north_star: 1e-6); done / steps exact; observations equal after the
+fp32 cast their consumer applies (util.py:145)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden", "env_golden.npz")
+TOL = 1e-10
+INFO = ("reward", "revenue", "der_cost", "ess_cost", "discomfort_penalty", "voltage_penalty", "cumulative_reward")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(G, allow_pickle=False))
+
+
+def _series(gold):
+    from safe_marl_amd.series import SeriesTable
+    a, r, pv, pr = gold["series.active"], gold["series.reactive"], gold["series.pv"], gold["series.price"]
+    z = np.zeros((a.shape[0], 1))
+    return SeriesTable(np.ascontiguousarray(np.hstack([z, a, z, r, pv, pr])), 33, 5, int(gold["series.time_delta"]))
+
+
+def _episode(gold, tag, j):
+    p = f"{tag}.ep{j}."
+    return {k[len(p):]: v for k, v in gold.items() if k.startswith(p)}
+
+
+@pytest.mark.parametrize("tags,alg,solver,warm", [((("A", 0), ("A", 1), ("B", 0), ("B", 1)), None, 2, True),
+                                                  ((("A", 0), ("B", 1), ("A", 1)), None, 0, False),
+                                                  ((("C", 0),), "safemaddpg", 2, True)])
+def test_vectorised_env_reproduces_the_reference_episodes(net, gold, tags, alg, solver, warm):
+    import torch
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    eps = [_episode(gold, t, j) for t, j in tags]
+    n, T = len(eps), min(len(e["reward"]) for e in eps)
+    vec = VecFlexProvisionEnv({"alg": alg} if alg else {}, n, series=_series(gold), net=net, solver=solver, warm_start=warm)
+    spec = dict(day=np.array([e["start"][0] for e in eps], np.int32), hour=np.array([e["start"][1] for e in eps], np.int32),
+                interval=np.array([e["start"][2] for e in eps], np.int32), e0=np.stack([e["e0"] for e in eps]),
+                a0=np.stack([e["a0"] for e in eps]))
+    obs = vec.reset(spec=spec).cpu().numpy()
+    assert vec.failed.sum().item() == 0
+    for i, e in enumerate(eps):
+        assert np.allclose(obs[i], e["obs"][0].astype(np.float32), rtol=2e-7, atol=0)
+    assert np.abs(vec.get_state().cpu().numpy() - np.stack([e["state"][0] for e in eps])).max() < TOL
+    assert np.abs(vec.peek("V").cpu().numpy() - np.stack([e["V"][0] for e in eps])).max() < TOL
+    assert np.array_equal(vec.peek("E_INIT").cpu().numpy(), np.stack([e["Einit"][0] for e in eps]))        # A5
+    for t in range(T):
+        acts = np.stack([e["actions"][t] for e in eps]).reshape(n, 5, 4)
+        # alternate the two forms of get_obs(): the stacked copy and the row push + view (bit-identical by test_env_gpu.py)
+        if t % 2:
+            reward, done, info = vec.step(torch.from_numpy(acts).cuda(), fuse_obs=True)
+            obs = vec.obs.cpu().numpy()
+        else:
+            reward, done, info = vec.step(torch.from_numpy(acts).cuda(), obs_rows=True)
+            obs = vec.obs_view().cpu().numpy()
+        reward, done, info = reward.cpu().numpy(), done.cpu().numpy(), info.cpu().numpy()
+        state, v, en = vec.get_state().cpu().numpy(), vec.peek("V").cpu().numpy(), vec.peek("E").cpu().numpy()
+        for i, e in enumerate(eps):
+            assert abs(reward[i] - e["reward"][t]) < TOL, (t, i)
+            assert bool(done[i]) == bool(e["done"][t])
+            assert np.abs(info[i] - e["info"][t]).max() < TOL, (t, i)
+            assert np.allclose(obs[i], e["obs"][t + 1].astype(np.float32), rtol=2e-7, atol=0), (t, i)
+            assert np.abs(state[i] - e["state"][t + 1]).max() < TOL and np.abs(v[i] - e["V"][t + 1]).max() < TOL
+            assert np.abs(en[i] - e["E"][t + 1]).max() < TOL
+        assert np.array_equal(vec.peek("STEPS").cpu().numpy(), np.array([e["steps"][t + 1] for e in eps]))
+    assert vec.failed.sum().item() == 0
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_drop_in_env_replays_the_reference_run_from_its_seed(net, gold, tag):
+    """FlexibilityProvisionEnv(kwargs) with the reference's seed: np.random.seed (env:49), the draws of reset (env:85-87,
+    100,103) in the reference's order from the GLOBAL NumPy stream, then the recorded actions — the reference's own run."""
+    from safe_marl_amd.flex_env import FlexibilityProvisionEnv
+    seed = int(gold[tag + ".seed"])
+    env = FlexibilityProvisionEnv({"seed": seed}, net=net, series=_series(gold), warm_start=True)
+    np.random.seed(seed)                     # (make_env_golden.py re-seeds and resets once more after construction)
+    first = env.reset()
+    n_eps = int(gold[tag + ".episodes"])
+    for j in range(n_eps):
+        e = _episode(gold, tag, j)
+        if j > 0:
+            first = env.manual_reset(*[int(x) for x in e["start"]]) if tag == "B" else env.reset()
+        obs, state = first
+        assert isinstance(obs, list) and len(obs) == 5 and obs[0].shape == (144,)
+        assert env.vec.peek("START").item() == int(e["start"][2]) + int(e["start"][1]) * 4 + int(e["start"][0]) * 96
+        assert np.allclose(np.stack(obs).astype(np.float32), e["obs"][0].astype(np.float32), rtol=2e-7, atol=0)
+        assert np.abs(state - e["state"][0]).max() < TOL
+        for t in range(len(e["reward"])):
+            r, d, info = env.step(e["actions"][t].astype(np.float32).reshape(5, 4))
+            assert isinstance(r, float) and isinstance(d, bool)
+            assert abs(r - e["reward"][t]) < TOL and d == bool(e["done"][t])
+            assert np.abs(np.array([info[k] for k in INFO]) - e["info"][t]).max() < TOL
+            nxt = env.get_obs()
+            assert np.allclose(np.stack(nxt).astype(np.float32), e["obs"][t + 1].astype(np.float32), rtol=2e-7, atol=0)
+            assert np.abs(env.get_state() - e["state"][t + 1]).max() < TOL
+        assert env.steps == 96
+    env.close()
