@@ -2,13 +2,18 @@
 environment.  Not product code: only tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg may import it.
 
-PARITY UNPINNED against a run of the reference: the reference env cannot be
-imported here (it imports utils/pf.py -> pyomo, and reads LFS-pointer data
-files) and the reference holds no tests or fixtures.  This file
-follows the reference line by line instead; every block cites what it restates
-(paths under /root/reference/madrl/environments/flex_provision/
-flexibility_provision_env.py unless noted).  The power flow is
-oracle/pf_oracle.py.
+PINNED (round 4) to the reference's EXECUTED environment code for everything but the
+numerical power-flow solve: tests/golden/make_env_golden.py imports and runs
+flexibility_provision_env.py and create_net.py from /root/reference — with the
+solve rebound to oracle/pf_oracle.py (pyomo / IPOPT are absent) and stand-in
+workbooks / CSVs (the reference's are LFS pointers) — and tests/test_env_golden_cpu.py
+holds this file to those runs at 1e-12: whole episodes of reset / step / get_obs /
+get_state / reward terms, a second reset, manual_reset, the raw-action branch, an
+injected solver failure, the global-NumPy draw order.  PARITY UNPINNED for the solve
+itself against IPOPT (oracle/pf_oracle.py, oracle/pf_nlp_oracle.py).  This file
+follows the reference line by line; every block cites what it restates (paths under
+/root/reference/madrl/environments/flex_provision/flexibility_provision_env.py
+unless noted).
 
 Deliberately bug-compatible: A2 data-row lag, A4 ESS clip
 without dt, A5 initial_ess_energy not refreshed by reset, A6 signed der_cost,

@@ -3,9 +3,13 @@
  * large-N checker and as bench.py's cpu_baseline ("port").  Not product code: nothing under
  * safe-marl_amd/ may link or call it.
  *
- * PARITY UNPINNED against a run of the reference (pyomo/ipopt/data absent); it is
- * pinned against oracle/pf_oracle.py + oracle/env_oracle.py in tests/test_oracle_cpu.py, which are
- * in turn pinned by two-algorithm agreement and the reference's own constraint residuals.
+ * PINNED (round 4) to runs of the reference's own environment code for everything but the numerical
+ * solve: tests/test_env_golden_cpu.py holds it to tests/golden/env_golden.npz — whole episodes of the
+ * reference's flexibility_provision_env.py executed from /root/reference with its power_flow_solver call
+ * rebound to oracle/pf_oracle.py (pyomo / IPOPT absent; tests/golden/make_env_golden.py) — at 1e-11.
+ * PARITY UNPINNED for the solve itself against IPOPT: there it is pinned against oracle/pf_oracle.py
+ * (tests/test_oracle_cpu.py), in turn by two-algorithm agreement, the reference's own constraint
+ * residuals and its NLP statement through SciPy (oracle/pf_nlp_oracle.py).
  *
  * Algorithm: Newton-Raphson in POLAR form on the dense Ybus with a dense partial-pivot LU — the
  * textbook formulation, deliberately different from the HIP kernel's rectangular current-mismatch /

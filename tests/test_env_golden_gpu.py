@@ -104,3 +104,68 @@ def test_drop_in_env_replays_the_reference_run_from_its_seed(net, gold, tag):
             assert np.abs(env.get_state() - e["state"][t + 1]).max() < TOL
         assert env.steps == 96
     env.close()
+
+
+def test_whole_training_loop_replays_the_reference_run(net, gold):
+    """End to end, against the reference's EXECUTED training loop (tests/golden/make_loop_golden.py: utils/trainer.PGTrainer +
+    MADDPG + TransReplayBuffer + the reference env, three episodes of model.py:198-267 = 285 env steps, four update events of
+    ten value + one policy sub-update, two soft target updates, on CPU from fixed seeds; solve := the oracle's NR):
+    the PRODUCT's N = 1 path — the drop-in env on the HIP kernels, the package's trainer / learner / replay on CPU tensors (so
+    that torch's CPU generator draws the reference's exploration noise and the global NumPy stream its episode draws and
+    replay windows) — from the same initial weights and seeds lands on the same 285 actions, rewards and dones, the same
+    episode statistics and the same final weights of behaviour AND target networks."""
+    import json
+    import torch as th
+    from safe_marl_amd.flex_env import FlexibilityProvisionEnv
+    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.trainer import PGTrainer
+    from safe_marl_amd.util import convert
+    lg = dict(np.load(os.path.join(os.path.dirname(G), "loop_golden.npz"), allow_pickle=False))
+    env = FlexibilityProvisionEnv({"seed": 11}, net=net, series=_series(gold), warm_start=True)
+    argd = json.loads(str(lg["alg_args_json"]))
+    assert argd["cuda"] is False and argd["obs_size"] == env.get_obs_size() and argd["state_size"] == env.get_state_size()
+    th.manual_seed(2024)
+    trainer = PGTrainer(convert(argd), MADDPG, env, None)
+    assert trainer.device.type == "cpu"
+    sd = {k[len("init."):]: th.from_numpy(v) for k, v in lg.items() if k.startswith("init.")}
+    res = trainer.behaviour_net.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    log = {"action": [], "reward": [], "done": []}
+    real_step = env.step
+
+    def step(actions):
+        r, d, info = real_step(actions)
+        log["action"].append(np.array(actions, dtype=np.float64).reshape(-1).copy())
+        log["reward"].append(float(r)); log["done"].append(bool(d))
+        return r, d, info
+
+    env.step = step
+    np.random.seed(11)
+    th.manual_seed(7)
+    stats = []
+    for _ in range(3):
+        stat = {}
+        trainer.behaviour_net.train_process(stat, trainer)
+        stats.append({k: float(v) for k, v in stat.items()})
+    assert trainer.steps == int(lg["steps"]) == 285
+    act, rew, done = np.array(log["action"]), np.array(log["reward"]), np.array(log["done"])
+    assert np.array_equal(done, lg["done"])
+    d_act, d_rew = np.abs(act - lg["action"]).max(), np.abs(rew - lg["reward"]).max()
+    # fp32 policy arithmetic in two summation orders through 285 steps and 44 optimiser steps: measured 1e-6 / 1e-8
+    assert d_act < 2e-5 and d_rew < 2e-7, (d_act, d_rew)
+    keys = [str(k) for k in lg["stat_keys"]]
+    for j, s in enumerate(stats):
+        for i, k in enumerate(keys):
+            ref = float(lg["stats"][j, i])
+            if np.isfinite(ref) and k in s:
+                assert abs(s[k] - ref) <= 2e-5 * max(1.0, abs(ref)), (j, k, s[k], ref)
+    worst = 0.0
+    for k, v in trainer.behaviour_net.state_dict().items():
+        ref = th.from_numpy(lg["final." + k])
+        if ref.is_floating_point():
+            worst = max(worst, float((v.cpu() - ref).abs().max()))
+            assert th.allclose(v.cpu(), ref, atol=2e-5, rtol=1e-4), (k, float((v.cpu() - ref).abs().max()))
+        else:
+            assert th.equal(v.cpu(), ref), k
+    print(f"loop replay: |d action| {d_act:.2e}, |d reward| {d_rew:.2e}, |d weight| {worst:.2e}")
+    env.close()
