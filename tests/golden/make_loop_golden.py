@@ -8,8 +8,9 @@ read_excel := the package's xlsx reader on stand-in workbooks, synthetic CSVs) a
 
     cd /root/reference && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_loop_golden.py
 
-Recorded: the initial state_dict (behaviour + target), every step's env action / reward / done, every episode's statistics,
-the final state_dict.  The GPU test drives the PRODUCT's N = 1 path (drop-in env on the HIP kernels, the package's trainer /
+Then Model.evaluation (model.py:269-306): ten test-mode episodes.  Recorded: the initial state_dict (behaviour + target),
+every step's env action / reward / done (training and evaluation), every episode's statistics, the evaluation's mean_test_*
+dictionary, the final state_dict.  The GPU test drives the PRODUCT's N = 1 path (drop-in env on the HIP kernels, the package's trainer /
 learner / replay on CPU tensors so that torch's CPU generator draws the reference's exploration noise) from the same seeds
 and must land on the same trajectory and the same weights.
 """
@@ -75,6 +76,13 @@ def main():
         with contextlib.redirect_stdout(io.StringIO()):
             trainer.behaviour_net.train_process(stat, trainer)
         stats.append({k: float(v) for k, v in stat.items()})
+    # model.py:269-306: num_eval_episodes test-mode episodes (tanh(mean), no exploration), the global NumPy stream continuing
+    with contextlib.redirect_stdout(io.StringIO()):
+        ev = {}
+        trainer.behaviour_net.evaluation(ev, trainer)
+    g["eval_keys"] = np.array(sorted(ev))
+    g["eval"] = np.array([float(ev[k]) for k in sorted(ev)])
+    g["eval_steps"] = np.array(len(log["reward"]) - 285)
     g["steps"] = np.array(trainer.steps)
     g["action"], g["reward"], g["done"] = np.array(log["action"]), np.array(log["reward"]), np.array(log["done"])
     keys = sorted(stats[-1])

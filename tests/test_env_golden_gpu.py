@@ -109,11 +109,12 @@ def test_drop_in_env_replays_the_reference_run_from_its_seed(net, gold, tag):
 def test_whole_training_loop_replays_the_reference_run(net, gold):
     """End to end, against the reference's EXECUTED training loop (tests/golden/make_loop_golden.py: utils/trainer.PGTrainer +
     MADDPG + TransReplayBuffer + the reference env, three episodes of model.py:198-267 = 285 env steps, four update events of
-    ten value + one policy sub-update, two soft target updates, on CPU from fixed seeds; solve := the oracle's NR):
+    ten value + one policy sub-update, two soft target updates, then Model.evaluation's ten test-mode episodes
+    (model.py:269-306), on CPU from fixed seeds; solve := the oracle's NR):
     the PRODUCT's N = 1 path — the drop-in env on the HIP kernels, the package's trainer / learner / replay on CPU tensors (so
     that torch's CPU generator draws the reference's exploration noise and the global NumPy stream its episode draws and
-    replay windows) — from the same initial weights and seeds lands on the same 285 actions, rewards and dones, the same
-    episode statistics and the same final weights of behaviour AND target networks."""
+    replay windows) — from the same initial weights and seeds lands on the same 285 + 950 actions, rewards and dones, the same
+    episode and evaluation statistics and the same final weights of behaviour AND target networks."""
     import json
     import torch as th
     from safe_marl_amd.flex_env import FlexibilityProvisionEnv
@@ -148,6 +149,11 @@ def test_whole_training_loop_replays_the_reference_run(net, gold):
         trainer.behaviour_net.train_process(stat, trainer)
         stats.append({k: float(v) for k, v in stat.items()})
     assert trainer.steps == int(lg["steps"]) == 285
+    ev = {}
+    trainer.behaviour_net.evaluation(ev, trainer)                 # model.py:269-306: ten test-mode episodes
+    assert len(log["reward"]) == 285 + int(lg["eval_steps"]) == 285 + 950
+    for k, ref in zip([str(k) for k in lg["eval_keys"]], lg["eval"]):
+        assert abs(float(ev[k]) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (k, float(ev[k]), float(ref))
     act, rew, done = np.array(log["action"]), np.array(log["reward"]), np.array(log["done"])
     assert np.array_equal(done, lg["done"])
     d_act, d_rew = np.abs(act - lg["action"]).max(), np.abs(rew - lg["reward"]).max()
