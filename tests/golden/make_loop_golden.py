@@ -10,7 +10,7 @@ read_excel := the package's xlsx reader on stand-in workbooks, synthetic CSVs) a
 
 Then Model.evaluation (model.py:269-306): ten test-mode episodes.  Recorded: the initial state_dict (behaviour + target),
 every step's env action / reward / done (training and evaluation), every episode's statistics, the evaluation's mean_test_*
-dictionary, the final state_dict.  The GPU test drives the PRODUCT's N = 1 path (drop-in env on the HIP kernels, the package's trainer /
+dictionary, the record of utils/tester.PGTester.run(3, 7, 1) (tester.py:23-33 keys), the final state_dict.  The GPU test drives the PRODUCT's N = 1 path (drop-in env on the HIP kernels, the package's trainer /
 learner / replay on CPU tensors so that torch's CPU generator draws the reference's exploration noise) from the same seeds
 and must land on the same trajectory and the same weights.
 """
@@ -83,6 +83,12 @@ def main():
     g["eval_keys"] = np.array(sorted(ev))
     g["eval"] = np.array([float(ev[k]) for k in sorted(ev)])
     g["eval_steps"] = np.array(len(log["reward"]) - 285)
+    # utils/tester.py:16-70: one test-mode episode from a manual reset, recorded through the env's _get_* accessors (env:740-778)
+    from utils.tester import PGTester
+    with contextlib.redirect_stdout(io.StringIO()):
+        record = PGTester(args, trainer.behaviour_net, env).run(3, 7, 1)
+    for k, v in record.items():
+        g["record." + k] = np.array([np.asarray(x, dtype=np.float64).reshape(-1) for x in v])
     g["steps"] = np.array(trainer.steps)
     g["action"], g["reward"], g["done"] = np.array(log["action"]), np.array(log["reward"]), np.array(log["done"])
     keys = sorted(stats[-1])

@@ -154,9 +154,18 @@ def test_whole_training_loop_replays_the_reference_run(net, gold):
     assert len(log["reward"]) == 285 + int(lg["eval_steps"]) == 285 + 950
     for k, ref in zip([str(k) for k in lg["eval_keys"]], lg["eval"]):
         assert abs(float(ev[k]) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (k, float(ev[k]), float(ref))
-    act, rew, done = np.array(log["action"]), np.array(log["reward"]), np.array(log["done"])
-    assert np.array_equal(done, lg["done"])
-    d_act, d_rew = np.abs(act - lg["action"]).max(), np.abs(rew - lg["reward"]).max()
+    # utils/tester.py:16-70 on the trained net: the record test_agent.py pickles, key by key (env:740-778 accessors)
+    from safe_marl_amd.tester import PGTester, RECORD_KEYS
+    record = PGTester(convert(argd), trainer.behaviour_net, env).run(3, 7, 1)
+    assert set(record) == set(RECORD_KEYS) == {k[len("record."):] for k in lg if k.startswith("record.")}
+    for k in RECORD_KEYS:
+        mine = np.array([np.asarray(x, dtype=np.float64).reshape(-1) for x in record[k]])
+        assert mine.shape == lg["record." + k].shape == (96, lg["record." + k].shape[1]), k
+        assert np.abs(mine - lg["record." + k]).max() < 1e-6, (k, np.abs(mine - lg["record." + k]).max())
+    n_rec = 95
+    act, rew, done = np.array(log["action"])[:-n_rec], np.array(log["reward"])[:-n_rec], np.array(log["done"])[:-n_rec]
+    assert np.array_equal(done, lg["done"][:len(done)]) and len(done) == 285 + 950
+    d_act, d_rew = np.abs(act - lg["action"][:len(act)]).max(), np.abs(rew - lg["reward"][:len(rew)]).max()
     # fp32 policy arithmetic in two summation orders through 285 steps and 44 optimiser steps: measured 1e-6 / 1e-8
     assert d_act < 2e-5 and d_rew < 2e-7, (d_act, d_rew)
     keys = [str(k) for k in lg["stat_keys"]]
