@@ -21,7 +21,7 @@ import numpy as np
 import torch as th
 import torch.nn as nn
 
-from .nets import (WGRAD_MIN_ROWS, CriticTail, critic_td_loss, critic_td_loss_supported, critic_policy_loss,
+from .nets import (WGRAD_MIN_ROWS, CriticTail, critic_first_layer, critic_td_loss, critic_td_loss_supported, critic_policy_loss,
                    critic_policy_loss_supported, expand_agents, MLPAgent, MLPCritic, RNNAgent, critic_policy_supported, critic_replayed_supported,
                    critic_tail_supported, fused_actor_forward, tall_linear, td_loss, td_loss_supported, wide_batch_linear,
                    batchnorm_stats_supported, batchnorm_update_running_stats, sync_batchnorm)
@@ -965,9 +965,10 @@ class MADDPG(Model):
                 # value loss on replayed actions: the whole critic as one autograd node (nets._CriticReplayedFn)
                 return CriticTail.apply_replayed(obs_cols, act_cols, n, net).view(b, n, 1)
             if not th.is_grad_enabled() or not (W.requires_grad or act.requires_grad or obs.requires_grad):
-                # bootstrap targets: no graph — two GEMMs, the bias rides the first, the second accumulates
-                shared = th.addmm(bias, obs_cols, W_obs.t())
-                shared.addmm_(act_cols, W_act.t())
+                # bootstrap targets: no graph — one launch of csrc/linear.hip at update sizes (nets.critic_first_layer), else
+                # two library GEMMs (the bias rides the first, the second accumulates)
+                with th.no_grad():
+                    shared = critic_first_layer(bias, obs_cols, act_cols, W, off)
             else:
                 shared = wide_batch_linear(obs_cols, W_obs) + wide_batch_linear(act_cols, W_act) + bias      # [b, hid]
             if not act.requires_grad and self.args.agent_id and critic_tail_supported(net, shared):

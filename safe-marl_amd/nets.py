@@ -341,6 +341,39 @@ def tall_linear(x, w, b=None):
     return F.linear(x, w, b)
 
 
+LINEAR2_MIN_ROWS = 2048      # below: the library call (a launch of this kernel stages 189 KB of weights per CU)
+CRITIC_FC1_FUSED = True      # (tests switch it off to compare with the two library GEMMs)
+
+
+def critic_first_layer(bias, obs2d, act2d, W, c_act):
+    """``bias + obs2d @ W[:, :no].T + act2d @ W[:, c_act:c_act + na].T`` — the shared part of the centralised critic's
+    first layer (mlp_critic.py:25-26 on maddpg.py:33-54's input).  On the GPU at update sizes: ONE launch of
+    csrc/linear.hip (include/flexnet.h: flexnet_linear2; exact fp32 on the matrix cores, no second pass over the [b, 64]
+    result); otherwise the two library GEMMs of rounds 1-3."""
+    no, na_ = obs2d.shape[1], act2d.shape[1]
+    ok = (CRITIC_FC1_FUSED and obs2d.is_cuda and obs2d.dtype == th.float32 and act2d.dtype == th.float32 and W.dtype == th.float32
+          and obs2d.shape[0] >= LINEAR2_MIN_ROWS and W.shape[0] == 64 and no % 4 == 0 and na_ % 4 == 0
+          and obs2d.stride(1) == 1 and act2d.stride(1) == 1 and W.stride(1) == 1 and bias.is_contiguous()
+          and not th.is_grad_enabled())
+    if ok:
+        import ctypes as C
+        from . import _lib
+        out = th.empty(obs2d.shape[0], 64, dtype=th.float32, device=obs2d.device)
+        a = _lib.FlexLinear2Args()
+        a.rows, a.k1, a.k2 = obs2d.shape[0], no, na_
+        a.ld1, a.ld2, a.ldw, a.c1, a.c2 = obs2d.stride(0), act2d.stride(0), W.stride(0), 0, int(c_act)
+        a.x1, a.x2, a.w, a.bias, a.out = obs2d.data_ptr(), act2d.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr()
+        rc = _lib.load().flexnet_linear2(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream))
+        if rc == 0:
+            return out
+        if rc != _lib.FLEXNET_EUNSUPPORTED:
+            _lib.check(rc, "flexnet_linear2")
+        note_fallback("critic_fc1", "FLEXNET_EUNSUPPORTED from flexnet_linear2")
+    shared = th.addmm(bias, obs2d, W[:, :no].t())
+    shared.addmm_(act2d, W[:, c_act:c_act + na_].t())
+    return shared
+
+
 _TD_WS = {}
 
 
@@ -905,8 +938,7 @@ class _CriticReplayedFn(th.autograd.Function):
         from . import _lib
         lib = _lib.load()
         no, na_ = obs2d.shape[1], act2d.shape[1]
-        shared = th.addmm(bias, obs2d, W[:, :no].t())
-        shared.addmm_(act2d, W[:, no + n_agents:no + n_agents + na_].t())
+        shared = critic_first_layer(bias, obs2d, act2d, W, no + n_agents)
         # twin (matd3.py:64-67): the second head is the same network with the trailing 0/1 input flag set — fc1's last
         # column joins every agent's id column
         id_cols = (W[:, no:no + n_agents] + W[:, -1:]).t().contiguous() if twin else None
@@ -988,8 +1020,7 @@ class _CriticReplayedTwinFn(th.autograd.Function):
         stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
         n = n_agents
         no, na_ = obs2d.shape[1], act2d.shape[1]
-        shared = th.addmm(bias, obs2d, W[:, :no].t())
-        shared.addmm_(act2d, W[:, no + n:no + n + na_].t())
+        shared = critic_first_layer(bias, obs2d, act2d, W, no + n)
         id2 = (W[:, no:no + n] + W[:, -1:]).t().contiguous()
         rows = shared.shape[0] * n
         q = th.empty(2 * rows, 1, dtype=th.float32, device=shared.device)
@@ -1070,8 +1101,7 @@ class _CriticTdLossFn(th.autograd.Function):
         n = n_agents
         no, na_ = obs2d.shape[1], act2d.shape[1]
         dev = obs2d.device
-        shared = th.addmm(bias, obs2d, W[:, :no].t())
-        shared.addmm_(act2d, W[:, no + n:no + n + na_].t())
+        shared = critic_first_layer(bias, obs2d, act2d, W, no + n)
         rows = shared.shape[0] * n
         dz1 = th.empty(rows, 64, dtype=th.float32, device=dev)
         grads = th.empty(64 * 64 + 64 * 4 + 1, dtype=th.float32, device=dev)
@@ -1199,8 +1229,7 @@ class _CriticPolicyFn(th.autograd.Function):
         b, n, na_ = act.shape
         no = obs2d.shape[1]
         act2d = act.reshape(b, n * na_)
-        shared = th.addmm(bias, obs2d, W[:, :no].t())
-        shared.addmm_(act2d, W[:, no + n:no + n + n * na_].t())
+        shared = critic_first_layer(bias, obs2d, act2d, W, no + n)
         rows = b * n
         q = th.empty(rows, 1, dtype=th.float32, device=shared.device)
         args = _critic_args(shared, ln_w, ln_b, w2, b2, w3, b3, eps)
@@ -1249,8 +1278,7 @@ class _CriticPolicyLossFn(th.autograd.Function):
         b, n, na_ = act.shape
         no = obs2d.shape[1]
         act2d = act.reshape(b, n * na_)
-        shared = th.addmm(bias, obs2d, W[:, :no].t())
-        shared.addmm_(act2d, W[:, no + n:no + n + n * na_].t())
+        shared = critic_first_layer(bias, obs2d, act2d, W, no + n)
         rows = b * n
         dz1 = th.empty(rows, 64, dtype=th.float32, device=shared.device)
         loss = th.empty((), dtype=th.float32, device=shared.device)
