@@ -8,9 +8,11 @@
 // output element), evaluated transposed like the policy kernels (csrc/actor_r16.h): D[unit][row] = W X^T with the weights as
 // the A operand from LDS ([k][unit], pitch 68) and a lane's 16-byte loads of its row as B operands of four k-steps — MFMA
 // step (q, r) contracts over columns {16 q + 4 g + r : g = 0..3}, the weights are read in the matching order.  The weight
-// matrix (64 x 740 fp32 = 189 KB) does not fit a CU's LDS: it is staged in chunks of 192 k-columns (52 KB), double-buffered,
-// chunk c + 1 requested before the MFMAs of chunk c and written behind them.  A wavefront carries two 16-row tiles through
-// the K loop (every A operand read serves both), 8 wavefronts per block, one block per CU.
+// matrix (64 x 740 fp32 = 189 KB) does not fit a CU's LDS: it is staged in chunks of 96 k-columns (26 KB), double-buffered,
+// chunk c + 1 (and the wavefront's own rows of it) requested before the MFMAs of chunk c and written behind them — the first
+// version requested a chunk's inputs at the head of its own MFMAs and sat through the memory latency eight times: 48.4 us
+// at 32 768 rows against 39.8 us for the library pair.  A wavefront carries two 16-row tiles through the K loop (every A
+// operand read serves both), 8 wavefronts per block, one block per CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -19,7 +21,7 @@
 
 #define L2_WAVES 8
 #define L2_P 68
-#define L2_KC 192                    // k-columns per staged chunk = 12 groups of 16
+#define L2_KC 96                     // k-columns per staged chunk = 6 groups of 16
 #define L2_GC (L2_KC / 16)
 #define L2_NT 2                      // 16-row tiles per wavefront and round
 #define L2_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
@@ -43,77 +45,64 @@ __global__ __launch_bounds__(64 * L2_WAVES, 1) void linear2_kernel(FlexLinear2Ar
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x2 ? a.x2 : a.x1), 0,
                                                                         a.x2 ? (x2b > 0x7ffffff0ll ? 0x7ffffff0 : (int)x2b) : 0, 0x00027000);
     // ---- weight staging: 4 x 4 blocks (four units x four k-columns): four 16-byte reads along k, four 16-byte LDS writes
-    //      along the units of the transposed image; 768 blocks per chunk over 512 threads
-    l2_f4 wv[2][4];
+    //      along the units of the transposed image; 384 blocks per chunk, one per thread of the first six wavefronts
+    l2_f4 wv[4];
+    const int se = tid, srest = se >> 6;
+    const int sub = 8 * (srest & 1) + (se & 7), sk4 = 8 * (srest >> 1) + ((se >> 3) & 7);
+    const bool stager = se < 16 * (L2_KC / 4);
     auto stage_load = [&](int c) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int e = tid + 64 * L2_WAVES * t, rest = e >> 6;
-            const int ub = 8 * (rest & 1) + (e & 7), k4 = 8 * (rest >> 1) + ((e >> 3) & 7);
-            const int kk = c * L2_KC + 4 * k4;                              // first of this block's four k-columns
-            int col = -1;
-            if (e < 16 * (L2_KC / 4)) {
-                if (kk < 16 * kg1) col = kk < a.k1 ? a.c1 + kk : -1;
-                else { const int k2 = kk - 16 * kg1; col = k2 < a.k2 ? a.c2 + k2 : -1; }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                wv[t][i] = __builtin_bit_cast(l2_f4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rw, col >= 0 ? ((4 * ub + i) * a.ldw + col) * 4 : -1, 0, 0));
+        const int kk = c * L2_KC + 4 * sk4;                                 // first of this block's four k-columns
+        int col = -1;
+        if (stager) {
+            if (kk < 16 * kg1) col = kk < a.k1 ? a.c1 + kk : -1;
+            else { const int k2 = kk - 16 * kg1; col = k2 < a.k2 ? a.c2 + k2 : -1; }
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            wv[i] = __builtin_bit_cast(l2_f4, __builtin_amdgcn_raw_buffer_load_b128(
+                rw, col >= 0 ? ((4 * sub + i) * a.ldw + col) * 4 : -1, 0, 0));
     };
     auto stage_store = [&](int buf) {
+        if (stager) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int e = tid + 64 * L2_WAVES * t, rest = e >> 6;
-            const int ub = 8 * (rest & 1) + (e & 7), k4 = 8 * (rest >> 1) + ((e >> 3) & 7);
-            if (e < 16 * (L2_KC / 4)) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    *reinterpret_cast<l2_f4*>(&s.w[buf][(4 * k4 + kk) * L2_P + 4 * ub]) =
-                        l2_f4{wv[t][0][kk], wv[t][1][kk], wv[t][2][kk], wv[t][3][kk]};
-            }
+            for (int kk = 0; kk < 4; ++kk)
+                *reinterpret_cast<l2_f4*>(&s.w[buf][(4 * sk4 + kk) * L2_P + 4 * sub]) = l2_f4{wv[0][kk], wv[1][kk], wv[2][kk], wv[3][kk]};
         }
     };
 
     for (int round = 0; (int64_t)round * waves_total * L2_NT < n_tiles; ++round) {
         // this wavefront's tiles of the round: spread over all wavefronts first (a small batch uses every SIMD)
-        int tile[L2_NT], row[L2_NT];
-        bool live[L2_NT];
+        int row[L2_NT];
+        bool live[L2_NT], in[L2_NT];
         l2_f4 acc[L2_NT][4];
 #pragma unroll
         for (int i = 0; i < L2_NT; ++i) {
-            tile[i] = (round * L2_NT + i) * waves_total + blockIdx.x * L2_WAVES + wave;
-            live[i] = tile[i] < n_tiles;                                    // wavefront-uniform
-            row[i] = tile[i] * 16 + j;
+            const int tile = (round * L2_NT + i) * waves_total + blockIdx.x * L2_WAVES + wave;
+            live[i] = tile < n_tiles;                                       // wavefront-uniform
+            row[i] = tile * 16 + j;
+            in[i] = live[i] && row[i] < a.rows;
 #pragma unroll
             for (int T = 0; T < 4; ++T) {
                 const float4 b = *reinterpret_cast<const float4*>(a.bias + 16 * T + 4 * g);
                 acc[i][T] = l2_f4{b.x, b.y, b.z, b.w};
             }
         }
-        __syncthreads();                                                    // (the previous round's last chunk has been read)
-        stage_load(0);
-        stage_store(0);
-        __syncthreads();
-        for (int c = 0; c < n_chunks; ++c) {
-            if (c + 1 < n_chunks) stage_load(c + 1);
-            const float* w_l = s.w[c & 1] + (4 * g) * L2_P + j;
-            l2_f4 xq[L2_NT][L2_GC];
+        // a lane's 16-byte pieces of its rows for chunk c (column group q = c * 6 + qq of the [x1 | x2] space)
+        auto load_x = [&](int c, l2_f4 (&xq)[L2_NT][L2_GC]) {
 #pragma unroll
             for (int i = 0; i < L2_NT; ++i) {
-                const bool in = live[i] && row[i] < a.rows;
 #pragma unroll
                 for (int qq = 0; qq < L2_GC; ++qq) {
                     const int q = c * L2_GC + qq, col = (q < kg1 ? 16 * q : 16 * (q - kg1)) + 4 * g;
-                    l2_f4 v;
-                    if (q < kg1) v = __builtin_bit_cast(l2_f4, __builtin_amdgcn_raw_buffer_load_b128(
-                        r1, in && col < a.k1 ? (row[i] * a.ld1 + col) * 4 : -1, 0, 0));
-                    else v = __builtin_bit_cast(l2_f4, __builtin_amdgcn_raw_buffer_load_b128(
-                        r2, in && q < KG && col < a.k2 ? (row[i] * a.ld2 + col) * 4 : -1, 0, 0));
-                    xq[i][qq] = v;
+                    if (q < kg1) xq[i][qq] = __builtin_bit_cast(l2_f4, __builtin_amdgcn_raw_buffer_load_b128(
+                        r1, in[i] && col < a.k1 ? (row[i] * a.ld1 + col) * 4 : -1, 0, 0));
+                    else xq[i][qq] = __builtin_bit_cast(l2_f4, __builtin_amdgcn_raw_buffer_load_b128(
+                        r2, in[i] && q < KG && col < a.k2 ? (row[i] * a.ld2 + col) * 4 : -1, 0, 0));
                 }
             }
+        };
+        auto multiply = [&](int buf, const l2_f4 (&xq)[L2_NT][L2_GC]) {
+            const float* w_l = s.w[buf] + (4 * g) * L2_P + j;
             float w[4], wn[4];
 #pragma unroll
             for (int T = 0; T < 4; ++T) w[T] = w_l[16 * T];
@@ -135,12 +124,28 @@ __global__ __launch_bounds__(64 * L2_WAVES, 1) void linear2_kernel(FlexLinear2Ar
 #pragma unroll
                 for (int T = 0; T < 4; ++T) w[T] = wn[T];
             }
-            if (c + 1 < n_chunks) stage_store((c + 1) & 1);
+        };
+        l2_f4 xa[L2_NT][L2_GC], xb[L2_NT][L2_GC];
+        __syncthreads();                                                    // (the previous round's last chunk has been read)
+        stage_load(0);
+        load_x(0, xa);
+        stage_store(0);
+        __syncthreads();
+        for (int c = 0; c < n_chunks; c += 2) {                             // two chunks per trip: the input registers alternate
+            if (c + 1 < n_chunks) { stage_load(c + 1); load_x(c + 1, xb); }
+            multiply(0, xa);
+            if (c + 1 < n_chunks) stage_store(1);
             __syncthreads();
+            if (c + 1 < n_chunks) {
+                if (c + 2 < n_chunks) { stage_load(c + 2); load_x(c + 2, xa); }
+                multiply(1, xb);
+                if (c + 2 < n_chunks) stage_store(0);
+                __syncthreads();
+            }
         }
 #pragma unroll
         for (int i = 0; i < L2_NT; ++i) {
-            if (live[i] && row[i] < a.rows) {
+            if (in[i]) {
 #pragma unroll
                 for (int T = 0; T < 4; ++T)
                     *reinterpret_cast<float4*>(a.out + (int64_t)row[i] * FLEXNET_HID + 16 * T + 4 * g) =
