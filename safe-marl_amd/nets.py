@@ -341,34 +341,12 @@ def tall_linear(x, w, b=None):
     return F.linear(x, w, b)
 
 
-LINEAR2_MIN_ROWS = 2048      # below: the library call (a launch of this kernel stages 189 KB of weights per CU)
-CRITIC_FC1_FUSED = True      # (tests switch it off to compare with the two library GEMMs)
-
-
 def critic_first_layer(bias, obs2d, act2d, W, c_act):
     """``bias + obs2d @ W[:, :no].T + act2d @ W[:, c_act:c_act + na].T`` — the shared part of the centralised critic's
-    first layer (mlp_critic.py:25-26 on maddpg.py:33-54's input).  On the GPU at update sizes: ONE launch of
-    csrc/linear.hip (include/flexnet.h: flexnet_linear2; exact fp32 on the matrix cores, no second pass over the [b, 64]
-    result); otherwise the two library GEMMs of rounds 1-3."""
+    first layer (mlp_critic.py:25-26 on maddpg.py:33-54's input) as two library GEMMs: the bias rides the first, the second
+    accumulates in place (no concatenated input, no second pass over the [b, 64] result).  A hand-written one-launch form was
+    measured in round 4 and not adopted."""
     no, na_ = obs2d.shape[1], act2d.shape[1]
-    ok = (CRITIC_FC1_FUSED and obs2d.is_cuda and obs2d.dtype == th.float32 and act2d.dtype == th.float32 and W.dtype == th.float32
-          and obs2d.shape[0] >= LINEAR2_MIN_ROWS and W.shape[0] == 64 and no % 4 == 0 and na_ % 4 == 0
-          and obs2d.stride(1) == 1 and act2d.stride(1) == 1 and W.stride(1) == 1 and bias.is_contiguous()
-          and not th.is_grad_enabled())
-    if ok:
-        import ctypes as C
-        from . import _lib
-        out = th.empty(obs2d.shape[0], 64, dtype=th.float32, device=obs2d.device)
-        a = _lib.FlexLinear2Args()
-        a.rows, a.k1, a.k2 = obs2d.shape[0], no, na_
-        a.ld1, a.ld2, a.ldw, a.c1, a.c2 = obs2d.stride(0), act2d.stride(0), W.stride(0), 0, int(c_act)
-        a.x1, a.x2, a.w, a.bias, a.out = obs2d.data_ptr(), act2d.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr()
-        rc = _lib.load().flexnet_linear2(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream))
-        if rc == 0:
-            return out
-        if rc != _lib.FLEXNET_EUNSUPPORTED:
-            _lib.check(rc, "flexnet_linear2")
-        note_fallback("critic_fc1", "FLEXNET_EUNSUPPORTED from flexnet_linear2")
     shared = th.addmm(bias, obs2d, W[:, :no].t())
     shared.addmm_(act2d, W[:, c_act:c_act + na_].t())
     return shared
