@@ -74,6 +74,7 @@ SYMBOLS = (
     "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_td_stats", "flexnet_critic_td_backward",
     "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gather_window", "flexnet_gru_backward",
+    "flexopf_qp_work_doubles", "flexopf_qp_solve",
 )
 
 class FlexActorArgs(C.Structure):
@@ -100,6 +101,17 @@ class FlexWindowArgs(C.Structure):
     """include/flexnet.h"""
     _fields_ = [("row_ring", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int64), ("first_slot", C.c_int64),
                 ("n_envs", C.c_int32), ("n_agents", C.c_int32), ("history", C.c_int32), ("slabs", C.c_int32)]
+
+
+class FlexQpArgs(C.Structure):
+    """include/flexopf.h"""
+    _fields_ = [(k, C.c_int32) for k in ("batch", "periods", "n_agents", "rows", "max_iter", "pad0")] + \
+               [(k, C.c_double) for k in ("tol", "reg", "chain_a", "chain_b")] + \
+               [(k, C.c_void_p) for k in ("q", "c", "lo", "hi", "free_mask", "jv", "v_lo", "v_hi", "ji", "i_hi", "e_lo", "e_hi",
+                                          "x0", "x", "duals", "info", "work")]
+
+
+FLEXOPF_INFO = 6
 
 
 class FlexBurstSafety(C.Structure):
@@ -314,6 +326,10 @@ def load():
     lib.flexenv_obs_source.restype = C.c_int
     lib.flexnet_gather_window.argtypes = [C.POINTER(FlexWindowArgs), vp]
     lib.flexnet_gather_window.restype = C.c_int
+    lib.flexopf_qp_work_doubles.argtypes = [i32, i32, i32]
+    lib.flexopf_qp_work_doubles.restype = C.c_int64
+    lib.flexopf_qp_solve.argtypes = [C.POINTER(FlexQpArgs), vp]
+    lib.flexopf_qp_solve.restype = C.c_int
     lib.flexenv_state.argtypes = [vp, vp, vp]
     lib.flexenv_state.restype = C.c_int
     lib.flexenv_peek.argtypes = [vp, i32, vp, vp]

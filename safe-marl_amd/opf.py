@@ -35,6 +35,8 @@ import torch as th
 from .flex_env import pf_solve_batch
 from .network import build_tables
 
+NATIVE_QP = True          # the QP of every outer iteration through csrc/opf.hip (tests switch it off to compare with qp_ipm)
+
 ENV_DEFAULTS = dict(episode_limit=96, v_min=0.9, v_max=1.1, pv_cost=0.05, ess_cost=0.03, discomfort_coeff=0.15,
                     eta_ch=0.9, eta_dis=0.9, max_power_reduction=0.5, e_min=0.0, e_max=0.025, p_ch_max=0.005,
                     p_dis_max=0.005, cos_phi_max=0.95)           # flex_provision.yaml:4-27, read at opf.py:10-11
@@ -241,14 +243,97 @@ def _factor_structured(Qblk, sets, s, z, fmask, reg):
     return solve
 
 
-def qp_ipm(Qblk, c, blocks, x0, free=None, max_iter=80, tol=1e-11, reg=1e-12, verbose=False):
+def _factor_riccati(Qblk, sets, s, z, fmask, reg):
+    """The same system by a Riccati recursion over the periods — the algorithm of csrc/opf.hip in torch (CPU-runnable; the tests
+    pin the kernel's algebra with it).  N = blockdiag(P_t) + C' diag(D) C is the optimality condition of a linear-quadratic
+    problem with the n_agents energy offsets as state: per period (in parallel) L_t = chol(P_t), W_t = L_t^-1 G', M_t = W_t' W_t;
+    backward S_t = L_S L_S', B_t = I + L_S' M_t L_S, S_{t-1} = D_{t-1} + L_S B_t^-1 L_S'; every product stays factored (the
+    textbook forms I - H M and S e cancel catastrophically once z / s spans twenty decades), and each solve is followed by one
+    step of iterative refinement against N applied through its operators."""
+    B, T, w, _ = Qblk.shape
+    dt = Qblk.dtype
+    chain = next(rows for rows, _, _ in sets if isinstance(rows, _EnergyChain))
+    na = chain.na
+    P = Qblk.clone()
+    D = th.zeros(B, T, na, dtype=dt, device=Qblk.device)
+    for (rows, sg, h), si, zi in zip(sets, s, z):
+        d = zi / si
+        if isinstance(rows, _Identity):
+            P.diagonal(dim1=2, dim2=3).add_(d.view(B, T, w))
+        elif isinstance(rows, _PeriodBlocks):
+            P += th.einsum("btrv,btr,btrw->btvw", rows.J, d.view(B, T, rows.R), rows.J)
+        else:
+            D += d.view(B, T, na)
+    fm = fmask.view(B, T, w)
+    P *= fm.unsqueeze(-1) * fm.unsqueeze(-2)
+    pd_ = P.diagonal(dim1=2, dim2=3)
+    regv = reg * pd_.amax(dim=(1, 2), keepdim=True)             # [B, 1, 1]
+    pd_.add_(regv + (1.0 - fm))
+    G = th.zeros(T, na, w, dtype=dt, device=Qblk.device)
+    idx = th.arange(na, device=Qblk.device)
+    G[1:, idx, 2 * na + idx] = chain.a                          # (period 0 has no coefficient: opf.py:140-142)
+    G[1:, idx, 3 * na + idx] = -chain.b
+    G = G.unsqueeze(0) * fm.unsqueeze(2)                        # [B, T, na, w]
+    L = th.linalg.cholesky(P)
+    W = th.linalg.solve_triangular(L, G.transpose(2, 3), upper=False)           # [B, T, w, na]
+    M = W.transpose(2, 3) @ W
+    eye = th.eye(na, dtype=dt, device=Qblk.device)
+    LS, LB = [None] * T, [None] * T
+    S = th.diag_embed(D[:, T - 1])
+    for t in range(T - 1, 0, -1):
+        LS[t] = th.linalg.cholesky(S)
+        LB[t] = th.linalg.cholesky(eye + LS[t].transpose(1, 2) @ M[:, t] @ LS[t])
+        Z = th.linalg.solve_triangular(LB[t], LS[t].transpose(1, 2), upper=False)
+        S = th.diag_embed(D[:, t - 1]) + Z.transpose(1, 2) @ Z
+
+    def mv(A, v):
+        return (A @ v.unsqueeze(-1)).squeeze(-1)
+
+    def lsolve(Lm, v, transpose=False):
+        if transpose:
+            return th.linalg.solve_triangular(Lm.transpose(1, 2), v.unsqueeze(-1), upper=True).squeeze(-1)
+        return th.linalg.solve_triangular(Lm, v.unsqueeze(-1), upper=False).squeeze(-1)
+
+    def once(rhs):
+        y = th.linalg.solve_triangular(L, rhs.view(B, T, w, 1), upper=False)
+        g = (W.transpose(2, 3) @ y).squeeze(-1)                                 # [B, T, na]
+        sv = [None] * T
+        sv[T - 1] = th.zeros(B, na, dtype=dt, device=Qblk.device)
+        for t in range(T - 1, 0, -1):
+            a = mv(LS[t].transpose(1, 2), g[:, t]) + lsolve(LS[t], sv[t])
+            sv[t - 1] = mv(LS[t], lsolve(LB[t], lsolve(LB[t], a), transpose=True))
+        e = th.zeros(B, na, dtype=dt, device=Qblk.device)
+        nu = th.zeros(B, T, na, dtype=dt, device=Qblk.device)
+        for t in range(1, T):
+            v = e + g[:, t] - mv(M[:, t], sv[t])
+            q = lsolve(LB[t], lsolve(LB[t], mv(LS[t].transpose(1, 2), v)), transpose=True)
+            nu[:, t] = -(mv(LS[t], q) + sv[t])
+            e = lsolve(LS[t], q, transpose=True)
+        dx = th.linalg.solve_triangular(L.transpose(2, 3), y + W @ nu.unsqueeze(-1), upper=True)
+        return dx.reshape(B, T * w)
+
+    def apply_n(v):
+        out = th.einsum("btvw,btw->btv", Qblk, v.view(B, T, w)).reshape(B, -1) + regv.view(B, 1) * v
+        for (rows, sg, h), si, zi in zip(sets, s, z):
+            out = out + rows.apply_t((zi / si) * rows.apply(v))
+        return out * fmask
+
+    def solve(rhs):
+        x = once(rhs)
+        return x + once((rhs - apply_n(x)) * fmask)
+
+    return solve
+
+
+def qp_ipm(Qblk, c, blocks, x0, free=None, max_iter=80, tol=1e-11, reg=1e-12, verbose=False, factor=None):
     """Mehrotra predictor-corrector on a batch of convex QPs.
 
     Qblk [B, T, w, w]: block-diagonal Hessian;  c [B, n];  blocks: list of (rows, lower [B, m] or None,
     upper [B, m] or None);  x0 [B, n] start;  free [B, n] bool: variables that may move (the others stay at x0 —
     their rows and columns leave the Newton system).  Returns x [B, n] and a dict with the duality measures.
     Instances that have converged are frozen (zero step) while the slowest ones finish: pushing a converged
-    instance further only ruins the conditioning of its normal matrix."""
+    instance further only ruins the conditioning of its normal matrix.  ``factor="riccati"`` solves the Newton system by
+    :func:`_factor_riccati` (the kernel's algorithm) instead of a Cholesky factorisation."""
     B, T, w, _ = Qblk.shape
     n = T * w
     dev, dt = c.device, c.dtype
@@ -290,7 +375,12 @@ def qp_ipm(Qblk, c, blocks, x0, free=None, max_iter=80, tol=1e-11, reg=1e-12, ve
                   f"done {int(done.sum())}/{B}")
         if bool(done.all()):
             break
-        solve = (_factor_structured if structured else _factor_dense)(Qblk, sets, s, z, fmask, reg)
+        if factor == "riccati":
+            if not structured:
+                raise ValueError("the Riccati recursion needs period-local rows plus one energy chain")
+            solve = _factor_riccati(Qblk, sets, s, z, fmask, reg)
+        else:
+            solve = (_factor_structured if structured else _factor_dense)(Qblk, sets, s, z, fmask, reg)
 
         def newton(r_c):
             rhs = -r_d
@@ -328,6 +418,53 @@ def qp_ipm(Qblk, c, blocks, x0, free=None, max_iter=80, tol=1e-11, reg=1e-12, ve
     if not bool(done.all()) and bool((info["res_p"][~done] > 1e-6).any()):
         raise RuntimeError("Solver failed to find a solution (constraints cannot be met)")           # opf.py:155-157
     return x, info
+
+
+def qp_ipm_native(Qblk, c, lo, hi, free, jv, v_lo, v_hi, ji, i_hi, chain_a, chain_b, e_lo, e_hi, x0, max_iter=80, tol=1e-11,
+                  reg=1e-12):
+    """The OPF's QP through ``flexopf_qp_solve`` (include/flexopf.h, csrc/opf.hip): the same predictor-corrector iteration as
+    :func:`qp_ipm` with the row blocks [box | Jv (two-sided) | Ji (upper) | energy chain (two-sided)], one persistent
+    work-group per instance for the WHOLE iteration (no launch, no host decision per iteration) and the Newton system by a
+    Riccati recursion over the periods instead of a dense factorisation.  Qblk [B, T, w, w]; c, lo, hi, x0 [B, T w]; free
+    [B, T w] bool; jv, ji [B, T, R, w]; v_lo, v_hi, i_hi [B, T R]; e_lo, e_hi [B, T na].  Returns (x, info) like qp_ipm;
+    ``info["duals"]`` in qp_ipm's order (upper, lower of every block that has them)."""
+    import ctypes as C
+    from . import _lib
+    B, T, w, _ = Qblk.shape
+    R, na = jv.shape[2], w // 4
+    dev = Qblk.device
+    if dev.type != "cuda":
+        raise RuntimeError("qp_ipm_native needs the HIP library and a GPU (qp_ipm is the torch form)")
+    lib = _lib.load()
+    per = lib.flexopf_qp_work_doubles(T, na, R)
+    if per < 0:
+        raise ValueError(f"flexopf_qp_solve: sizes out of range (T {T}, agents {na}, rows {R}; include/flexopf.h)")
+    f64 = dict(dtype=th.float64, device=dev)
+    mp = 2 * w + 3 * R + 2 * na
+    keep = [t.to(th.float64).contiguous() for t in (Qblk, c, lo, hi, jv, v_lo, v_hi, ji, i_hi, e_lo, e_hi, x0)]
+    fm = free.to(th.uint8).contiguous()
+    x = th.empty(B, T * w, **f64)
+    duals = th.empty(B, T, mp, **f64)
+    info = th.empty(B, _lib.FLEXOPF_INFO, **f64)
+    work = th.empty(B * per, **f64)
+    a = _lib.FlexQpArgs()
+    a.batch, a.periods, a.n_agents, a.rows, a.max_iter = B, T, na, R, int(max_iter)
+    a.tol, a.reg, a.chain_a, a.chain_b = float(tol), float(reg), float(chain_a), float(chain_b)
+    (a.q, a.c, a.lo, a.hi, a.jv, a.v_lo, a.v_hi, a.ji, a.i_hi, a.e_lo, a.e_hi, a.x0) = [t.data_ptr() for t in keep]
+    a.free_mask, a.x, a.duals, a.info, a.work = fm.data_ptr(), x.data_ptr(), duals.data_ptr(), info.data_ptr(), work.data_ptr()
+    _lib.check(lib.flexopf_qp_solve(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexopf_qp_solve")
+    res = info.cpu()                                      # (synchronises: the scratch and the inputs outlive the launch)
+    conv = res[:, 4] > 0.5
+    out = dict(iters=int(res[:, 0].max().item()), mu=res[:, 1].to(dev), res_d=res[:, 2].to(dev), res_p=res[:, 3].to(dev),
+               converged=conv.to(dev), floored_pivots=res[:, 5])
+    o = [0, w, 2 * w, 2 * w + R, 2 * w + 2 * R, 2 * w + 3 * R, 2 * w + 3 * R + na, mp]
+    out["duals"] = [duals[:, :, o[i]:o[i + 1]].reshape(B, -1) for i in range(7)]
+    # an infeasible program drives the iterates off until the factorisations break down (pivots floored, then non-finite
+    # numbers): the reference raises 'Solver failed to find a solution' there (opf.py:155-157)
+    bad = ~conv & (~(res[:, 3] <= 1e-6) | ~th.isfinite(res[:, 1:4]).all(1))
+    if bool(bad.any()) or not bool(th.isfinite(x).all()):
+        raise RuntimeError("Solver failed to find a solution (constraints cannot be met)")
+    return x, out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -505,7 +642,11 @@ class BatchedOPF:
                       (_PeriodBlocks(lin["ji"]), None, i_hi),
                       (_EnergyChain(T, self.na, self.dt * c["eta_ch"], self.dt / c["eta_dis"]), e_lo, e_hi)]
             x0 = th.where(free, 0.5 * (lo + hi).reshape(B, n), lo.reshape(B, n))
-            xn, info = qp_ipm(Qblk, cvec, blocks, x0, free=free, verbose=verbose)
+            if self.device.type == "cuda" and NATIVE_QP:
+                xn, info = qp_ipm_native(Qblk, cvec, (lo - pin).reshape(B, n), (hi + pin).reshape(B, n), free, lin["jv"], v_lo, v_hi,
+                                         lin["ji"], i_hi, self.dt * c["eta_ch"], self.dt / c["eta_dis"], e_lo, e_hi, x0)
+            else:
+                xn, info = qp_ipm(Qblk, cvec, blocks, x0, free=free, verbose=verbose)
             xn = th.minimum(th.maximum(xn.view(B, T, 4, self.na), lo), hi)
             move = (xn - x).abs().amax().item()                                    # pu
             obj = self.objective(price, x, lin["loss"])

@@ -18,10 +18,10 @@ def lib():
 
 def _declared_functions():
     names = set()
-    for header in ("flexenv.h", "flexnet.h"):                      # every header under include/
+    for header in ("flexenv.h", "flexnet.h", "flexopf.h"):                      # every header under include/
         src = open(os.path.join(ROOT, "include", header)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        names |= set(re.findall(r"\b(?:int|void|int32_t|const char\*)\s+\*?(flexenv_\w+|flexnet_\w+|pf_solve_batch)\s*\(", src))
+        names |= set(re.findall(r"\b(?:int|void|int32_t|int64_t|const char\*)\s+\*?(flexenv_\w+|flexnet_\w+|flexopf_\w+|pf_solve_batch)\s*\(", src))
     return sorted(names)
 
 
@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(lib):
     from safe_marl_amd import _lib
     names = _declared_functions()
     assert len(names) >= 15
-    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["flexenv.h", "flexnet.h"]
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["flexenv.h", "flexnet.h", "flexopf.h"]
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_lib.SYMBOLS)
@@ -44,6 +44,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.FlexActorArgs) == 8 * 4 + 17 * 8 + 4 * 4 + 8 + 4 * 8 + 6 * 8 + 8 + 8 + 4 * 4   # include/flexnet.h (+ ring_slabs, obs_pushed ...)
     assert C.sizeof(_lib.FlexObsSource) == 2 * 8 + 4 * 4 and C.sizeof(_lib.FlexWindowArgs) == 4 * 8 + 4 * 4
     assert C.sizeof(_lib.FlexReplaySink) == 7 * 8 + 4 * 4                                   # include/flexenv.h
+    assert C.sizeof(_lib.FlexQpArgs) == 6 * 4 + 4 * 8 + 17 * 8                              # include/flexopf.h
     assert C.sizeof(_lib.FlexGruBwdArgs) == 2 * 4 + 23 * 8 + 3 * 8 + 6 * 4
     assert C.sizeof(_lib.FlexCriticTailArgs) == 4 * 4 + 18 * 8 + 2 * 4 + 2 * 8 + 8 + 8 + 4 * 4 + 4 * 4 + 8
     assert C.sizeof(_lib.FlexRolloutPackArgs) == 8 * 4 + 16 * 8

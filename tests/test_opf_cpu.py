@@ -157,3 +157,53 @@ def test_block_elimination_equals_the_dense_normal_equations():
     x2 = opf._factor_structured(Q, sets, s, z, fm, 1e-12)(rhs)
     assert (x1 - x2).abs().max().item() < 1e-9 * max(1.0, x1.abs().max().item())
     assert x2[:, 5].abs().max().item() == 0.0
+
+
+def _chain_qp(B, T, na, R, seed):
+    rng = np.random.default_rng(seed)
+    w, n = 4 * na, T * 4 * na
+    A = rng.normal(size=(B, T, w, w))
+    Q = A @ A.transpose(0, 1, 3, 2) * 0.05
+    Q[:, :, 0, :] = 0
+    Q[:, :, :, 0] = 0
+    lo, hi = -np.ones((B, T, w)), np.ones((B, T, w))
+    lo[:, ::2, na + 1] = hi[:, ::2, na + 1] = 0.0
+    t = lambda a: torch.tensor(a, dtype=torch.float64)
+    return dict(Q=t(Q), c=t(rng.normal(size=(B, n))), lo=t(lo.reshape(B, n)), hi=t(hi.reshape(B, n)),
+                jv=t(rng.normal(size=(B, T, R, w))), ji=t(rng.normal(size=(B, T, R, w))),
+                v_hi=t(np.abs(rng.normal(size=(B, T * R))) + 0.2), v_lo=t(-np.abs(rng.normal(size=(B, T * R))) - 0.2),
+                i_hi=t(np.abs(rng.normal(size=(B, T * R))) + 0.2), e_hi=t(np.abs(rng.normal(size=(B, T * na))) * 0.3 + 0.05),
+                e_lo=t(-np.abs(rng.normal(size=(B, T * na))) * 0.3 - 0.05))
+
+
+def test_riccati_recursion_solves_the_newton_system_of_the_dense_factorisation():
+    """The algorithm of csrc/opf.hip (include/flexopf.h) in torch: its Newton step equals the dense Cholesky one while z / s
+    spans twelve decades, and the interior-point iteration on top of it ends where the dense one ends, in as many steps."""
+    from safe_marl_amd.opf import _EnergyChain, _Identity, _PeriodBlocks, _factor_dense, _factor_riccati, qp_ipm
+    B, T, na, R = 2, 9, 5, 6
+    p = _chain_qp(B, T, na, R, 11)
+    w, n = 4 * na, T * 4 * na
+    chain = _EnergyChain(T, na, 0.25 * 0.9, 0.25 / 0.9)
+    sets = [(_Identity(), 1.0, None), (_Identity(), -1.0, None), (_PeriodBlocks(p["jv"]), 1.0, None), (_PeriodBlocks(p["jv"]), -1.0, None),
+            (_PeriodBlocks(p["ji"]), 1.0, None), (chain, 1.0, None), (chain, -1.0, None)]
+    g = torch.Generator().manual_seed(4)
+    sizes = [n, n, T * R, T * R, T * R, T * na, T * na]
+    s = [torch.rand(B, m, dtype=torch.float64, generator=g) + 0.1 for m in sizes]
+    z = [torch.rand(B, m, dtype=torch.float64, generator=g) * 10.0 ** torch.randint(-6, 6, (B, m), generator=g).double() for m in sizes]
+    fmask = ((p["hi"] - p["lo"]) >= 1e-9).double()
+    rhs = torch.randn(B, n, dtype=torch.float64, generator=g) * fmask
+    xd = _factor_dense(p["Q"], sets, s, z, fmask, 1e-12)(rhs) * fmask
+    xr = _factor_riccati(p["Q"], sets, s, z, fmask, 1e-12)(rhs) * fmask
+    assert (xd - xr).abs().max().item() < 1e-8 * max(1.0, xd.abs().max().item())
+    free = fmask > 0.5
+    pin = (~free).double()
+    blocks = [(_Identity(), p["lo"] - pin, p["hi"] + pin), (_PeriodBlocks(p["jv"]), p["v_lo"], p["v_hi"]),
+              (_PeriodBlocks(p["ji"]), None, p["i_hi"]), (chain, p["e_lo"], p["e_hi"])]
+    x0 = torch.where(free, 0.5 * (p["lo"] + p["hi"]), p["lo"])
+    xa, ia = qp_ipm(p["Q"], p["c"], blocks, x0, free=free)
+    xb, ib = qp_ipm(p["Q"], p["c"], blocks, x0, free=free, factor="riccati")
+    assert bool(ia["converged"].all()) and bool(ib["converged"].all())
+    assert ib["iters"] <= ia["iters"] + 1
+    f = lambda x: 0.5 * torch.einsum("btv,btvw,btw->b", x.view(B, T, w), p["Q"], x.view(B, T, w)) + (p["c"] * x).sum(1)
+    assert (f(xa) - f(xb)).abs().max().item() < 1e-8
+    assert (xa - xb).abs().max().item() < 2e-5

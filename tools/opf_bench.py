@@ -19,7 +19,7 @@ T = 96
 opf = BatchedOPF(net)
 # time the two phases by wrapping them
 acc = dict(pf=0.0, ipm=0.0, pf_solves=0, ipm_iters=0)
-_lin, _ipm = BatchedOPF.linearise, opf_mod.qp_ipm
+_lin, _ipm, _ipm_native = BatchedOPF.linearise, opf_mod.qp_ipm, opf_mod.qp_ipm_native
 
 
 def lin(self, pd, qd, ppv, x, **kw):
@@ -38,8 +38,20 @@ def ipm(*a, **kw):
     return x, info
 
 
+def ipm_native(*a, **kw):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    x, info = _ipm_native(*a, **kw)
+    torch.cuda.synchronize(); acc["ipm"] += time.perf_counter() - t0
+    acc["ipm_iters"] += info["iters"]
+    acc["qp_solves"] = acc.get("qp_solves", 0) + 1
+    return x, info
+
+
 BatchedOPF.linearise = lin
 opf_mod.qp_ipm = ipm
+opf_mod.qp_ipm_native = ipm_native
+if os.environ.get("FLEX_OPF_TORCH_QP") == "1":
+    opf_mod.NATIVE_QP = False
 for B in batches:
     rows = np.stack([tab[96 * (3 + b):96 * (3 + b) + T] for b in range(B)])
     args = (rows[:, :, 71], rows[:, :, :33], rows[:, :, 33:66], rows[:, :, 66:71], np.full((B, 5), 0.0125))
