@@ -139,10 +139,11 @@ __device__ __forceinline__ double row_bound(const QpCtx& c, int idx) {
 
 // ---- the Jacobian blocks stream through LDS -------------------------------------------------------------------------------
 // Every parallel phase that needs Jv_t / Ji_t walks the same sequence of chunks (a wavefront's periods t = wv, wv + 8, ...;
-// per period the chunks of Jv, then of Ji; 32 rows each): the chunk is fetched with 16-byte loads coalesced over the
-// wavefront into registers, handed to LDS for the compute, and the NEXT chunk's loads are in flight while the current one is
-// computed on (a wavefront's inner loops then run on LDS only — the first form, 8-byte loads with the arithmetic waiting on
-// each, spent 80 % of an iteration in memory latency).
+// per period the chunks of Jv, then of Ji; 32 rows each): QP_GROUP chunks are fetched at once with 16-byte loads coalesced
+// over the wavefront into registers (with the few per-row operands the phase needs), then handed to LDS one after the other
+// for the compute, whose inner loops run on LDS only.  (The first form — 8-byte loads with the arithmetic waiting on each,
+// the row passes decoding their row type per element — took 3.1 ms per interior-point step; this one 1.7 ms.  What is left is
+// the bandwidth one CU draws with everything else of the day's state streaming past as well: DESIGN.md §9.)
 struct QpChunk { int t, set, r0, nr; };
 __device__ __forceinline__ bool qp_chunk_at(const QpCtx& c, int wv, int idx, QpChunk& k) {
     const int cps = (c.R + QP_CHUNK - 1) / QP_CHUNK, per = 2 * cps;
