@@ -57,11 +57,13 @@ class PGTrainer(object):
         self._cached_graphs = {}
         self._cached_ready = False
         self.bootstrap_cached_events = 0
-        # more than one rank: first try to capture a sub-update as ONE graph with the gradient all-reduce inside it (RCCL
-        # collectives can be stream-captured: ProcessGroupNCCL joins its stream to the capture and does not hand captured
-        # work to its watchdog); if that capture fails (gloo: a host round trip; or an RCCL build that refuses) the region
-        # is split at the exchange step — graph A, eager all-reduce, graph B — as in round 2
-        self.allreduce_in_graph = (os.environ.get("FLEX_ALLREDUCE_IN_GRAPH", "1") == "1" and fdist.world_size() > 0
+        # more than one rank: the sub-update region is split at the exchange step — graph A (loss, gradients into one flat
+        # bucket), eager all-reduce, graph B (clip, RMSprop) — the form that has run on hardware (gloo ranks on one GPU, RCCL
+        # at world size 1).  FLEX_ALLREDUCE_IN_GRAPH=1 opts in to ONE graph with the all-reduce captured inside it (RCCL
+        # collectives can be stream-captured: ProcessGroupNCCL joins its stream to the capture); it stays opt-in until a
+        # multi-GPU RCCL run of tests/test_dist_gpu.py exists, and falls back to the split form if the capture
+        # fails
+        self.allreduce_in_graph = (os.environ.get("FLEX_ALLREDUCE_IN_GRAPH", "0") == "1" and fdist.world_size() > 0
                                    and fdist.backend() == "nccl")
         self.entr = args.entr
         self.world = fdist.world_size()

@@ -51,9 +51,9 @@ def test_two_ranks_train_with_split_update_graphs(tmp_path):
 @pytest.mark.parametrize("in_graph", ["1", "0"])
 def test_update_graphs_next_to_a_live_rccl_communicator(in_graph):
     """RCCL itself (world size 1 — all this box allows): HIP-graph capture beside a live NCCL communicator and its watchdog
-    thread for three training episodes.  in_graph = 1 (the default since round 3): the trainer first tries ONE graph per
+    thread for three training episodes.  in_graph = 1 (opt-in, FLEX_ALLREDUCE_IN_GRAPH=1): the trainer first tries ONE graph per
     sub-update with ncclAllReduce of the flat bucket captured inside it, and falls back to graph A | all-reduce | graph B
-    if RCCL refuses the capture; in_graph = 0 forces the split form of round 2.  Either way the probe must finish and say
+    if RCCL refuses the capture; in_graph = 0 is the default split form.  Either way the probe must finish and say
     which of the two ran."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
