@@ -631,6 +631,13 @@ def main():
                 sizes.add(a.steps)                    # a short timed region (the driver's --steps 20) is ONE graph launch
             for n_steps in sorted(sizes - {0}):
                 graphs[n_steps] = capture(n_steps)
+            # A graph's FIRST launch uploads it to the device (measured, tools/launch_region_probe.py: ~40 us once, i.e. 2 us
+            # per step of a 20-step region, against 242-252 us for every later launch of the same graph).  Instantiation is
+            # setup like the capture itself: every graph is launched once here, untimed, as hipGraphUpload would do (PyTorch
+            # does not expose it).  The W warm-up steps and the K timed steps follow unchanged.
+            for g in graphs.values():
+                g.replay()
+            torch.cuda.synchronize()
         except Exception as exc:                      # capture not available: eager launches
             print(f"[bench] HIP graph capture failed ({exc}); eager launches", file=sys.stderr)
             graphs = {}
@@ -864,7 +871,7 @@ def main():
                                  "fp64 Newton-Raphson on the Ybus, tree-structured elimination (%.2f Newton steps per solve)" % iters_mean,
                                  a.pf_tol),
                 "envs_per_gpu": a.envs, "n_agents": n_agents_env, "n_bus": n_bus_env,
-                "warm_start": bool(a.warm_start), "launches_per_step": 1, "hip_graph": used_graph,
+                "warm_start": bool(a.warm_start), "launches_per_step": 1, "hip_graph": used_graph, "hip_graph_uploaded": used_graph,
                 "device_ms_per_step": dev_ms / a.steps, "solver": ("sweep (mixed fp64/fp32 increments) + fp64 Newton verification" if a.solver == "sweep" else "newton (fp64, tree elimination)"),
                 "pf_newton_iters_mean": iters_mean, "pf_sweeps_mean": sweeps_mean,
                 "solver_failed_frac": failed_frac,
