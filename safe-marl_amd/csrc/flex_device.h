@@ -564,7 +564,14 @@ __device__ __forceinline__ bool pf_solve(const DevNet* __restrict__ net, const L
     if (solver == FLEX_SOLVER_SWEEP) {
         // sweeps stop on their LOCAL mismatch estimate at tol/4 so that the Ybus re-evaluation below (different
         // rounding) confirms it at tol instead of spending a full Newton step on a borderline case
-        sweeps = pf_sweep<EPW>(net, ln, pnet, qnet, e, f, 0.25 * tol, FLEX_MAX_SWEEPS);
+        // (Thresholds between 2.5e-11 and 2e-8 can be met by the fp32 increments while the iterate still hangs on its FIRST
+        //  anchor, up to ~1e-9 from the fp64 fixed point: measured at pf_tol 1e-9 / 1e-8, 56 % / 31 % of the solves then failed
+        //  the verification and paid a Newton step, 18.5 us per launch instead of 11.  Such tolerances sweep to the 1e-10
+        //  level, which always re-anchors first; looser ones are met on the first anchor for real, tighter ones never were.
+        //  Decided here, once per solve: a test inside the increment loop cost the default tolerance 3 %.)
+        double sweep_tol = 0.25 * tol;
+        if (sweep_tol < 2e-8 && sweep_tol > 2.5e-11) sweep_tol = 2.5e-11;
+        sweeps = pf_sweep<EPW>(net, ln, pnet, qnet, e, f, sweep_tol, FLEX_MAX_SWEEPS);
         if (sweeps >= FLEX_MAX_SWEEPS) { e = 1.0; f = 0.0; }   // sweeps stalled: Newton from a flat start
     }
     return pf_newton_tree<EPW>(net, ln, pnet, qnet, e, f, tol, max_iter, iters);

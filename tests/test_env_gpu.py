@@ -77,29 +77,35 @@ def test_full_episode_matches_oracle(net, series_small, action_range, solver, wa
         assert np.abs(state[i] - o.get_state()).max() < TOL
 
 
-def test_north_star_tolerance_operating_point(net, series_small):
+@pytest.mark.parametrize("pf_tol,bound", [(1e-6, 1e-7), (1e-8, 1e-9)])
+def test_looser_power_flow_tolerances(net, series_small, pf_tol, bound):
     """BASELINE.json's north_star asks for bus voltages and step() rewards within 1e-6 of the CPU reference.  The product
     default iterates the power flow to a mismatch of 1e-12 pu (every other test here: 1e-10 against the oracle); `pf_tol` is
-    a constructor argument, and at pf_tol = 1e-6 — `tolerance_sibling` in bench.py's line, 25 % more env-steps/s — a whole
-    warm-started episode still sits two orders of magnitude inside the contract: reward, every info term, voltages and ESS
-    energy against the oracle (which solves to 1e-12), done exactly."""
+    a constructor argument.  At pf_tol = 1e-6 — `tolerance_sibling` in bench.py's line, 25 % more env-steps/s — a whole
+    warm-started episode still sits an order of magnitude inside the contract, and at 1e-8 (the default tolerance of the
+    reference's own IPOPT solve, pf.py:101-102) within 1e-9: reward, every info term, voltages and ESS energy against the
+    oracle (which solves to 1e-12), done exactly.  At neither tolerance may the sweeps hand an unconverged iterate to the
+    Newton verification (round 4: at 1e-9 / 1e-8 the fp32 convergence estimate was accepted on a far anchor, a third to a
+    half of the solves then took a Newton step, and the launch 18.5 us instead of 11)."""
     import torch
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
     n, na = 47, 5
     rng = np.random.default_rng(8)
-    vec = VecFlexProvisionEnv({}, n, series=series_small, net=net, warm_start=True, pf_tol=1e-6)
+    vec = VecFlexProvisionEnv({}, n, series=series_small, net=net, warm_start=True, pf_tol=pf_tol)
     oracles = _oracle_envs(net, series_small, n)
     spec = _spec(rng, n, series_small, na)
     vec.reset(spec=spec)
     for i, o in enumerate(oracles):
         o.reset(spec=(spec["day"][i], spec["hour"][i], spec["interval"][i], spec["e0"][i], spec["a0"][i]))
     worst_r = worst_v = 0.0
+    newton = 0
     for t in range(95):
         acts = rng.uniform(0.0, 1.0, (n, na, 4)).astype(np.float32)
         reward, done, info = vec.step(torch.from_numpy(acts).cuda())
         reward, done, info = reward.cpu().numpy(), done.cpu().numpy(), info.cpu().numpy()
         v = vec.peek("V").cpu().numpy()
         e = vec.peek("E").cpu().numpy()
+        newton += int(vec.peek("PF_ITERS").sum().item())
         for i, o in enumerate(oracles):
             r, d, inf = o.step(acts[i].astype(np.float64))
             assert d == bool(done[i])
@@ -110,7 +116,8 @@ def test_north_star_tolerance_operating_point(net, series_small):
                           np.abs(np.asarray(o.current_ess_energy) - e[i]).max())
     assert vec.failed.sum().item() == 0
     assert worst_r < 1e-6 and worst_v < 1e-6, (worst_r, worst_v)          # north_star's tolerance
-    assert worst_r < 1e-7 and worst_v < 1e-7, (worst_r, worst_v)          # (measured: a few 1e-8)
+    assert worst_r < bound and worst_v < bound, (worst_r, worst_v)
+    assert newton == 0
 
 
 def test_fused_obs_equals_separate(net, series_small):
