@@ -118,3 +118,25 @@ def test_opf_on_the_native_qp_equals_opf_on_the_torch_qp():
         assert (out["objective"] - ref["objective"]).abs().max().item() < 1e-9
         assert (out["x"] - ref["x"]).abs().max().item() < 5e-6
         assert out["outer_iters"] <= ref["outer_iters"] + 1
+
+
+def test_more_days_than_compute_units():
+    """One work-group per day, no co-operation between work-groups: a batch larger than the chip (300 days on 256 CUs) just
+    queues.  Every day equals the same day solved alone in a batch of one (same launch-independent arithmetic: bit for bit)."""
+    from safe_marl_amd.opf import qp_ipm_native
+    dev = torch.device("cuda:0")
+    B, T, na, R = 300, 3, 5, 4
+    p = _random_qp(B, T, na, R, 9)
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
+    lo, hi = t(p["lo"]), t(p["hi"])
+    free = (hi - lo) >= 1e-9
+    pin = (~free).double()
+    x0 = torch.where(free, 0.5 * (lo + hi), lo)
+    args = [t(p["Q"]), t(p["c"]), lo - pin, hi + pin, free, t(p["jv"]), t(p["v_lo"]), t(p["v_hi"]), t(p["ji"]), t(p["i_hi"])]
+    tail = [t(p["e_lo"]), t(p["e_hi"]), x0]
+    x, info = qp_ipm_native(*args, p["a"], p["b"], *tail)
+    assert bool(info["converged"].all()) and bool(torch.isfinite(x).all())
+    for b in (0, 137, 255, 256, 299):
+        xb, ib = qp_ipm_native(*[a[b:b + 1] for a in args], p["a"], p["b"], *[a[b:b + 1] for a in tail])
+        assert torch.equal(xb[0], x[b])
+        assert torch.equal(ib["duals"][3][0], info["duals"][3][b])
