@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--strict", action="store_true",
                     help="exit non-zero when a training leg fails or runs without its rollout graph / both update graphs")
     ap.add_argument("--kernel-shares-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-seconds", type=float, default=1.0, help="stepping time of ONE CPU baseline sample (7 samples after 2 s of warm-up; x cores = CPU work)")
+    ap.add_argument("--cpu-seconds", type=float, default=1.0, help="stepping time of ONE CPU baseline sample (C3: 5 samples per solver after 1 s of warm-up, C2: 3; x threads = CPU work)")
     ap.add_argument("--warm-start", type=int, default=1)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a one-GPU box together with FLEX_BENCH_ONE_DEVICE=1)")
@@ -93,12 +93,18 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(net, series, seconds, samples=7, warmup_s=2.0):
-    """The oracle's C restatement timed on this box's host cores (rank 0, N=1 only): after ``warmup_s`` seconds of stepping
-    (page-in, OpenMP team, clock ramp), ``samples`` samples of >= ``seconds`` s of whole 90-step episodes each; `value` is the
-    MEDIAN sample (other tenants' bursts on the host land in single samples, not in the figure — three runs of round 3's
-    single 1.5-s sample read 61 k, 118 k and 91 k), `spread` says how far the samples lie apart.  One thread per granted
-    core, pinned (OMP_PROC_BIND / OMP_PLACES; the oracle's library is loaded after they are set)."""
+def cpu_baseline(net, series, seconds, envs=4096, samples=5, warmup_s=1.0):
+    """The oracle's CPU restatements timed on this box's host cores (rank 0, N=1 only), following BASELINE.md §3:
+
+      C1  NumPy / Python, ONE env, one core — the structural analogue of the reference (oracle/env_oracle.py);
+      C2  the C restatement (oracle/flexenv_oracle.c), one thread, `envs` environments;
+      C3  the same with OpenMP over the environments on every core the cgroup grants, pinned.
+
+    C2 / C3 are timed with BOTH of the oracle's solvers: `dense_nr` (polar Newton-Raphson, dense LU: O(n^3) per iteration — the
+    checker the parity tests use) and `distflow_sweep` (backward/forward sweep in the reference's own DistFlow variables: O(n)
+    per iteration, the class of algorithm the HIP kernel runs).  `value` is C3 with the FASTER of the two — the like-for-like
+    figure; the dense one sits beside it.  Every figure is the median of `samples` samples of >=
+    `seconds` s of stepping (resets outside the timed region) after `warmup_s` s of warm-up; `spread` = (max - min) / median."""
     import numpy as np
     cores = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
@@ -106,42 +112,77 @@ def cpu_baseline(net, series, seconds, samples=7, warmup_s=2.0):
     os.environ.setdefault("OMP_PLACES", "cores")
     os.environ.setdefault("OMP_DYNAMIC", "false")
     from oracle import c_oracle
-    cores = c_oracle.set_threads(cores)                # (libgomp may have read its environment long ago: set it by call)
-    n = 64 * cores
+    from oracle.env_oracle import FlexEnvOracle
     rng = np.random.default_rng(1234)
-    env = c_oracle.COracleEnv(net, series.table, n)
+    n = int(envs)
     acts = rng.uniform(0.5, 1.0, (8, n, 5, 4))
+    busy_total = [0.0]
 
-    def fresh_episodes():
-        day = rng.integers(0, series.n_start_days(96), n)
-        start = rng.integers(0, 4, n) + rng.integers(0, 24, n) * 4 + day * 96
-        env.reset(start, rng.uniform(0.01125, 0.01375, (n, 5)), rng.uniform(0, 1, (n, 20)))
+    def time_c(solver, threads, min_s, n_samples, warm):
+        got_threads = c_oracle.set_threads(threads)        # (libgomp may have read its environment long ago: set it by call)
+        env = c_oracle.COracleEnv(net, series.table, n, solver=solver)
 
-    def sample(min_s):
-        """whole 90-step episodes (no resets inside the timed steps) until ``min_s`` seconds of stepping"""
-        busy, steps = 0.0, 0
-        while busy < min_s:
-            fresh_episodes()
-            t0 = time.perf_counter()
-            for k in range(90):
-                env.step(acts[k % 8])
-            busy += time.perf_counter() - t0
-            steps += 90
-        return n * steps / busy, busy, steps
+        def fresh():
+            day = rng.integers(0, series.n_start_days(96), n)
+            start = rng.integers(0, 4, n) + rng.integers(0, 24, n) * 4 + day * 96
+            env.reset(start, rng.uniform(0.01125, 0.01375, (n, 5)), rng.uniform(0, 1, (n, 20)))
 
-    sample(warmup_s)
-    got = [sample(seconds) for _ in range(max(1, int(samples)))]
-    rates = sorted(r for r, _, _ in got)
-    busy = sum(b for _, b, _ in got)
-    steps = sum(st for _, _, st in got)
-    med = rates[len(rates) // 2]
-    return {"value": med, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "samples": [round(r) for r in rates], "spread": (rates[-1] - rates[0]) / med,
-            "sample": f"median of {len(rates)} samples (each >= {seconds:g} s of whole 90-step episodes, {n} envs; {steps} steps in "
-                      f"all) after {warmup_s:g} s of warm-up: step()+get_obs() of the C restatement oracle/flexenv_oracle.c (dense "
-                      f"polar NR, OpenMP over envs, {cores} pinned threads), {busy:.1f} s = {busy * cores:.0f} core-seconds; "
-                      "kind 'port': the reference's own path (Pyomo model build + IPOPT subprocess per step, utils/pf.py:101-102) "
-                      "cannot run on this box (BASELINE.md §2)"}
+        state = {"k": 90}
+
+        def sample(min_t):
+            busy, steps = 0.0, 0
+            while busy < min_t:
+                if state["k"] >= 90:                       # a whole episode is used up: restart outside the timed steps
+                    fresh()
+                    state["k"] = 0
+                t0 = time.perf_counter()
+                env.step(acts[state["k"] % 8])
+                busy += time.perf_counter() - t0
+                state["k"] += 1
+                steps += 1
+            busy_total[0] += busy * got_threads
+            return n * steps / busy
+
+        if warm > 0:
+            sample(warm)
+        rates = sorted(sample(min_s) for _ in range(n_samples))
+        med = rates[len(rates) // 2]
+        return {"value": med, "threads": got_threads, "envs": n, "samples": [round(r) for r in rates],
+                "spread": (rates[-1] - rates[0]) / med}
+
+    out_c = {}
+    for solver in ("distflow_sweep", "dense_nr"):
+        out_c[solver] = {"C3": time_c(solver, cores, seconds, samples, warmup_s),
+                         "C2": time_c(solver, 1, seconds, 3, 0.3)}
+    # C1: one Python environment, scalar loop
+    one = FlexEnvOracle(net, {}, series.active, series.reactive, series.pv, series.price)
+    c1_rates = []
+    a1 = rng.uniform(0.5, 1.0, (8, 5, 4))
+    for _ in range(3):
+        one.reset()
+        t0 = time.perf_counter()
+        k = 0
+        while k < 90 and time.perf_counter() - t0 < max(0.5, seconds / 2):
+            one.step(a1[k % 8]); one.get_obs(); k += 1
+        dt1 = time.perf_counter() - t0
+        busy_total[0] += dt1
+        c1_rates.append(k / dt1)
+    c1_rates.sort()
+    best = max(out_c, key=lambda sv: out_c[sv]["C3"]["value"])
+    algo = {"distflow_sweep": "DistFlow backward/forward sweep, O(n)/iteration (reference variables pf.py:65-94), cold start",
+            "dense_nr": "polar Newton-Raphson on the dense Ybus, O(n^3) LU/iteration"}
+    main = out_c[best]["C3"]
+    return {"value": main["value"], "unit": "env-steps/s", "cores": main["threads"], "kind": "port", "algo": algo[best],
+            "envs": n, "samples": main["samples"], "spread": main["spread"],
+            "sample": (f"C3 of BASELINE.md §3: median of {len(main['samples'])} x >= {seconds:g} s of step()+get_obs() (stacked copy), "
+                       f"{n} envs, oracle/flexenv_oracle.c, OpenMP, {main['threads']} pinned threads; {busy_total[0]:.0f} core-seconds "
+                       "in all legs; kind 'port': Pyomo + IPOPT (utils/pf.py:101-102) cannot run on this box (BASELINE.md §2)"),
+            "obs_form": "stacked [5, 144] copy per step — the GPU leg with the same observation form is `stacked_sibling`",
+            "C1_numpy_one_env": {"value": c1_rates[len(c1_rates) // 2], "threads": 1, "envs": 1, "algo": algo["dense_nr"] + " (NumPy)",
+                                 "what": "oracle/env_oracle.py, one Python env, scalar loop: the structural analogue of the reference"},
+            "C2_one_thread": {k: out_c[k]["C2"] for k in out_c},
+            "C3_all_cores": {k: out_c[k]["C3"] for k in out_c},
+            "algos": algo}
 
 
 TRAIN_ALG_ARGS = dict(  # madrl/args/default.yaml merged with alg_args/maddpg.yaml (examples/train_maddpg.py)
@@ -942,7 +983,12 @@ def main():
             "learner_rooflines": learner,
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(net, series, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(net, series, a.cpu_seconds, envs=a.envs)
+            cb = out["cpu_baseline"]
+            # the ratio is reported for orientation only (the roofline fraction is the figure of merit); like for like in the
+            # observation form too: the CPU legs write the stacked copy, so `stacked` divides the stacked sibling's rate
+            cb["gpu_over_cpu"] = {"headline_row_push": out["value"] / cb["value"],
+                                  "stacked": (obs_sibling["value"] / cb["value"]) if obs_sibling and not a.stacked_obs else None}
         print(json.dumps(out), flush=True)
     if distributed:
         try:

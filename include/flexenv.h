@@ -34,6 +34,18 @@ extern "C" {
 #define FLEX_MAX_CHILDREN 8
 #define FLEX_INFO_W 7        /* reward, revenue, der_cost, ess_cost, discomfort, voltage_penalty, cumulative_reward (env:696-704) */
 
+/* Bumped whenever the meaning of an argument, flag or registered buffer changes (flexenv_abi_version() returns the
+ * value the library was built with).  2 = round 4's row-ring contract: FLEX_STEP_OBS_RING slabs hold FLEX_ROW_FLOATS
+ * records, not stacked observations (ABI 1), and the flag moved from value 2 to 16 so that a caller built against ABI 1
+ * gets FLEX_EINVAL from flexenv_step instead of row records in a ring it reads as stacked observations. */
+#define FLEX_ABI_VERSION 2
+
+/* pf.py:41-45 declares Vsqr, Isqr and E_next NonNegativeReals; E_next is pinned by the equality pf.py:96-98, so a step
+ * or reset whose E_next falls below -FLEX_DOMAIN_EPS is an infeasible NLP in the reference (IPOPT status != ok,
+ * pf.py:104-105) and takes the solver_failed path here.  The margin is IPOPT's default bound relaxation
+ * (bound_relax_factor 1e-8; the reference sets no solver options, pf.py:101). */
+#define FLEX_DOMAIN_EPS 1e-8
+
 #define FLEX_OK 0
 #define FLEX_EINVAL (-22)
 #define FLEX_ENOMEM (-12)
@@ -113,7 +125,8 @@ typedef struct FlexEnv FlexEnv;
 enum FlexField {
     FLEX_PEEK_V = 0,            /* f64 [N, n_bus]   current_voltage           env:740 */
     FLEX_PEEK_E = 1,            /* f64 [N, n_agents] current_ess_energy       env:760 */
-    FLEX_PEEK_E_INIT = 2,       /* f64 [N, n_agents] initial_ess_energy       env:100,354 */
+    FLEX_PEEK_E_INIT = 2,       /* f64 [N, n_agents] initial_ess_energy       env:100,354 — differs from E only between a
+                                   reset and the first step; a poke of it is honoured in that interval only */
     FLEX_PEEK_PRED = 3,         /* f64 [N, n_agents] power_reduction          env:764 */
     FLEX_PEEK_CH = 4,           /* f64 [N, n_agents] ess_charging             env:768 */
     FLEX_PEEK_DIS = 5,          /* f64 [N, n_agents] ess_discharging          env:772 */
@@ -149,7 +162,7 @@ int flexenv_reset(FlexEnv* env, const uint8_t* mask /*dev [N] or NULL*/, const R
  * into the same launch. */
 #define FLEX_STEP_AUTORESET 1   /* an env that terminates in this step restarts (Philox stream) inside the same
                                   launch; its `obs` row then holds the FIRST observation of the new episode */
-#define FLEX_STEP_OBS_RING 2    /* implies FLEX_STEP_OBS_ROWS; `obs` is the BASE of the ROW ring registered with flexenv_set_obs_ring:
+#define FLEX_STEP_OBS_RING 16   /* (value 2 until ABI 1, now rejected) implies FLEX_STEP_OBS_ROWS; `obs` is the BASE of the ROW ring registered with flexenv_set_obs_ring:
                                   this launch also writes one record per (env, agent) into slab (cursor[0] + 1) mod slabs,
                                   read on the device (replayable HIP graph):
                                       [Pd, Qd, Ppv, V, price, E, older, 0]   (FLEX_ROW_FLOATS fp32)
@@ -168,7 +181,9 @@ int flexenv_step(FlexEnv* env, const void* actions, int32_t act_dtype,
                  double* info /*dev [N, FLEX_INFO_W] or NULL*/, uint8_t* failed /*dev [N] or NULL*/,
                  void* obs /*dev [N, n_agents, 6*history] or NULL*/, int32_t obs_dtype, int32_t flags, void* stream);
 
-/* Replaces get_obs() (env:370-403): stateful, appends to the history on every call. */
+/* Replaces get_obs() (env:370-403): stateful, appends to the history on every call.  FLEX_EINVAL while a row ring is
+ * registered (flexenv_set_obs_ring): a push outside flexenv_step would leave the replay's row records behind the history.
+ * The same holds for a MASKED flexenv_reset; a full reset (mask NULL) restarts every history and is allowed. */
 int flexenv_obs(FlexEnv* env, void* obs /*dev [N, n_agents, 6*history]*/, int32_t obs_dtype, void* stream);
 
 /* The stacked observation as the last push left it (env:387-401), WITHOUT appending to the history: flexenv_step(...,
@@ -284,6 +299,7 @@ int flexenv_safety_project_env(FlexEnv* env, const void* proposed, int32_t dtype
                                float* env_action /*dev [N, 4*n_agents] or NULL*/, void* stream);
 
 const char* flexenv_version(void);
+int32_t flexenv_abi_version(void);   /* FLEX_ABI_VERSION of the build */
 
 #ifdef __cplusplus
 }

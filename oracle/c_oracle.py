@@ -27,7 +27,7 @@ def build(force=False):
 
 class OCfg(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n_bus", "n_agents", "history", "episode_limit", "raw_actions",
-                                         "pf_max_iter", "slack", "n_lines")] + \
+                                         "pf_max_iter", "slack", "n_lines", "pf_solver", "pad0")] + \
                [(k, C.c_double) for k in ("v_min", "v_max", "e_min", "e_max", "p_ch_max", "p_dis_max", "eta_ch",
                                           "eta_dis", "tan_phi", "max_power_reduction", "pv_cost", "ess_cost",
                                           "discomfort_coeff", "voltage_coeff", "dt", "fail_penalty", "pf_tol")] + \
@@ -58,7 +58,10 @@ def set_threads(n):
     return int(lib.oracle_get_threads())
 
 
-def make_cfg(net, cfg=None, alg=None, pf_tol=1e-12, pf_max_iter=20):
+SOLVERS = {"dense_nr": 0, "distflow_sweep": 1}
+
+
+def make_cfg(net, cfg=None, alg=None, pf_tol=1e-12, pf_max_iter=20, solver="dense_nr"):
     c = dict(DEFAULT_CFG)
     c.update(cfg or {})
     buses = list(net["bus_numbers"])
@@ -67,6 +70,7 @@ def make_cfg(net, cfg=None, alg=None, pf_tol=1e-12, pf_max_iter=20):
     o.n_bus, o.n_agents, o.history, o.episode_limit = len(buses), len(net["buildings"]), c["history"], c["episode_limit"]
     o.raw_actions = 1 if alg == "safemaddpg" else 0
     o.pf_max_iter = pf_max_iter
+    o.pf_solver = SOLVERS[solver]
     o.slack = [i for i, b in enumerate(buses) if net["bus_types"][b] == 1][0]
     lines = list(net["line_connections"])
     o.n_lines = len(lines)
@@ -85,9 +89,9 @@ def make_cfg(net, cfg=None, alg=None, pf_tol=1e-12, pf_max_iter=20):
     return o
 
 
-def pf_batch(net, pnet, qnet, pf_tol=1e-12, pf_max_iter=20):
+def pf_batch(net, pnet, qnet, pf_tol=1e-12, pf_max_iter=20, solver="dense_nr"):
     lib = load()
-    o = make_cfg(net, pf_tol=pf_tol, pf_max_iter=pf_max_iter)
+    o = make_cfg(net, pf_tol=pf_tol, pf_max_iter=pf_max_iter, solver=solver)
     pnet = np.ascontiguousarray(pnet, np.float64)
     qnet = np.ascontiguousarray(qnet, np.float64)
     vm = np.empty_like(pnet)
@@ -100,9 +104,9 @@ def pf_batch(net, pnet, qnet, pf_tol=1e-12, pf_max_iter=20):
 class COracleEnv:
     """N scalar environments stepped on the host (OpenMP over envs; OMP_NUM_THREADS picks the cores)."""
 
-    def __init__(self, net, series_table, n, cfg=None, alg=None):
+    def __init__(self, net, series_table, n, cfg=None, alg=None, solver="dense_nr"):
         self.lib = load()
-        self.cfg = make_cfg(net, cfg, alg)
+        self.cfg = make_cfg(net, cfg, alg, solver=solver)
         self.n = n
         nb, na, H = self.cfg.n_bus, self.cfg.n_agents, self.cfg.history
         self.series = np.ascontiguousarray(series_table, np.float64)

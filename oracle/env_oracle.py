@@ -198,6 +198,10 @@ class FlexEnvOracle:
         dt = 24 / self.episode_limit                                               # pf.py:23-24
         e_next = [e_init[i] + dt * (self.cfg["eta_ch"] * ch[i] - (1 / self.cfg["eta_dis"]) * dis[i])
                   for i in range(self.n_agents)]                                   # pf.py:96-98
+        # pf.py:41-45: E_next is a NonNegativeReals variable pinned by the equality above: negative -> infeasible NLP ->
+        # pf.py:104-105 raises (pf_oracle.DOMAIN_EPS: IPOPT's default bound relaxation)
+        if any(not (e >= -pf_oracle.DOMAIN_EPS) for e in e_next) or not np.all(np.isfinite(vm)):
+            raise pf_oracle.SolverFailed("variable outside its declared domain (pf.py:41-45)")
         return vm, e_next
 
     # -- reset (env:74-155 / 157-239) ---------------------------------------------

@@ -29,6 +29,7 @@
 
 typedef struct {
     int32_t n_bus, n_agents, history, episode_limit, raw_actions, pf_max_iter, slack, n_lines;
+    int32_t pf_solver, pad0;      /* 0: dense polar Newton-Raphson (default, the checker); 1: DistFlow backward/forward sweep */
     double v_min, v_max, e_min, e_max, p_ch_max, p_dis_max, eta_ch, eta_dis, tan_phi, max_power_reduction;
     double pv_cost, ess_cost, discomfort_coeff, voltage_coeff, dt, fail_penalty, pf_tol;
     int32_t agent_bus[OMAXA];
@@ -138,12 +139,83 @@ static int pf_polar(const OCfg* c, const OYbus* y, const double* pnet, const dou
     return -1;
 }
 
+/* ---- second solver (pf_solver = 1): backward/forward sweep on the DistFlow recursion in the reference's own variables
+ * (utils/pf.py:65-94: Pl, Ql, Isqr, Vsqr; same iteration as oracle/pf_oracle.py distflow_sweep) — O(n) per
+ * iteration like the HIP kernel's sweeps, where the dense Newton-Raphson above is O(n^3): bench.py times both so that the
+ * CPU figure beside the GPU's is like for like.  Cold start (Vsqr = 1, Isqr = 0), iterated until no
+ * Vsqr / Isqr moves by 1e-13. */
+typedef struct { int32_t order[OMAXB], parent[OMAXB]; double R[OMAXB], X[OMAXB]; } OTree;
+typedef struct { OYbus y; OTree t; } ONet;
+
+static void build_tree(const OCfg* c, OTree* t) {
+    const int n = c->n_bus;
+    int seen[OMAXB] = {0};
+    int head = 0, tail = 0;
+    t->order[tail++] = c->slack; t->parent[c->slack] = -1; seen[c->slack] = 1;
+    t->R[c->slack] = t->X[c->slack] = 0.0;
+    while (head < tail) {
+        const int u = t->order[head++];
+        for (int l = 0; l < c->n_lines; ++l) {
+            const int a = c->line_from[l], b = c->line_to[l];
+            const int v = a == u ? b : (b == u ? a : -1);
+            if (v < 0 || seen[v]) continue;
+            seen[v] = 1; t->parent[v] = u; t->R[v] = c->line_r[l]; t->X[v] = c->line_x[l];
+            t->order[tail++] = v;
+        }
+    }
+    for (int i = tail; i < n; ++i) t->order[i] = -1;     /* unreachable buses (not a feeder): the solve reports failure */
+}
+
+static int pf_distflow(const OCfg* c, const OTree* t, const double* pnet, const double* qnet, double* vm) {
+    const int n = c->n_bus;
+    double vs[OMAXB], isq[OMAXB], P[OMAXB], Q[OMAXB];
+    if (t->order[n - 1] < 0) return -1;
+    for (int i = 0; i < n; ++i) { vs[i] = 1.0; isq[i] = 0.0; }
+    for (int it = 1; it <= 500; ++it) {
+        for (int i = 0; i < n; ++i) { P[i] = pnet[i]; Q[i] = qnet[i]; }
+        for (int k = n - 1; k >= 1; --k) {                /* leaf -> root: power received + losses of the children's lines */
+            const int v = t->order[k], u = t->parent[v];
+            P[u] += P[v] + t->R[v] * isq[v];
+            Q[u] += Q[v] + t->X[v] * isq[v];
+        }
+        double delta = 0.0;
+        for (int k = 1; k < n; ++k) {                     /* root -> leaf: pf.py:85-94 for one line given Vsqr[parent] */
+            const int v = t->order[k], u = t->parent[v];
+            const double s2 = P[v] * P[v] + Q[v] * Q[v];
+            const double a = vs[u] - 2.0 * (t->R[v] * P[v] + t->X[v] * Q[v]);
+            const double cc = (t->R[v] * t->R[v] + t->X[v] * t->X[v]) * s2;
+            const double disc = a * a - 4.0 * cc;
+            if (!(disc >= 0.0)) return -1;                /* no real root: voltage collapse (or NaN) */
+            const double vn = 0.5 * (a + sqrt(disc)), in = s2 / vn;
+            const double d1 = fabs(vn - vs[v]), d2 = fabs(in - isq[v]);
+            if (d1 > delta) delta = d1;
+            if (d2 > delta) delta = d2;
+            vs[v] = vn; isq[v] = in;
+        }
+        if (!(delta == delta)) return -1;
+        if (delta < 1e-13) {
+            for (int i = 0; i < n; ++i) vm[i] = sqrt(vs[i]);
+            return it;
+        }
+    }
+    return -1;
+}
+
+static int pf_any(const OCfg* c, const ONet* net, const double* pnet, const double* qnet, double* vm) {
+    return c->pf_solver == 1 ? pf_distflow(c, &net->t, pnet, qnet, vm) : pf_polar(c, &net->y, pnet, qnet, vm);
+}
+static ONet* build_net(const OCfg* c) {
+    ONet* net = (ONet*)malloc(sizeof(ONet));
+    build_ybus(c, &net->y);
+    build_tree(c, &net->t);
+    return net;
+}
+
 int oracle_pf_batch(const OCfg* c, int n, const double* pnet, const double* qnet, double* vm, int32_t* iters) {
-    OYbus* y = (OYbus*)malloc(sizeof(OYbus));
-    build_ybus(c, y);
+    ONet* y = build_net(c);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i)
-        iters[i] = pf_polar(c, y, pnet + (size_t)i * c->n_bus, qnet + (size_t)i * c->n_bus, vm + (size_t)i * c->n_bus);
+        iters[i] = pf_any(c, y, pnet + (size_t)i * c->n_bus, qnet + (size_t)i * c->n_bus, vm + (size_t)i * c->n_bus);
     free(y);
     return 0;
 }
@@ -217,8 +289,9 @@ static void push_obs(const OCfg* c, OState* s, int i, float* obs) {
     s->obscnt[i] = k + 1;
 }
 
-static int solve_env(const OCfg* c, const OYbus* y, const OState* s, int i, int row, const double* pred,
-                     const double* ch, const double* dis, const double* q, double* vm) {
+#define ODOMAIN_EPS 1e-8
+static int solve_env(const OCfg* c, const ONet* y, const OState* s, int i, int row, const double* pred,
+                     const double* ch, const double* dis, const double* q, const double* e_init, double* vm) {
     const int nb = c->n_bus, na = c->n_agents;
     const double* sr = s->series + (size_t)row * s->cols;
     double pnet[OMAXB], qnet[OMAXB];
@@ -229,14 +302,19 @@ static int solve_env(const OCfg* c, const OYbus* y, const OState* s, int i, int 
         qnet[b] -= q[a];
     }
     (void)i;
-    return pf_polar(c, y, pnet, qnet, vm);
+    /* pf.py:41-45: E_next is declared NonNegativeReals and pinned by the equality pf.py:96-98 -> a negative value makes the
+       NLP infeasible -> pf.py:104-105 raises.  ODOMAIN_EPS = IPOPT's default bound relaxation (oracle/pf_oracle.py). */
+    for (int a = 0; a < na; ++a) {
+        const double en = e_init[a] + c->dt * (c->eta_ch * ch[a] - (1 / c->eta_dis) * dis[a]);
+        if (!(en >= -ODOMAIN_EPS)) return -1;
+    }
+    return pf_any(c, y, pnet, qnet, vm);
 }
 
 /* reset with injected draws: start[N], e0[N][na], a0[N][4na]; returns number of failed envs */
 int oracle_env_reset_batch(const OCfg* c, OState* s, int n, const int32_t* start, const double* e0,
                            const double* a0, float* obs, uint8_t* failed) {
-    OYbus* y = (OYbus*)malloc(sizeof(OYbus));
-    build_ybus(c, y);
+    ONet* y = build_net(c);
     const int nb = c->n_bus, na = c->n_agents;
     int nfail = 0;
 #pragma omp parallel for schedule(static) reduction(+ : nfail)
@@ -248,7 +326,7 @@ int oracle_env_reset_batch(const OCfg* c, OState* s, int n, const int32_t* start
         for (int a = 0; a < na; ++a)
             parse(c, 0, a0 + ((size_t)i * na + a) * 4, sr[c->agent_bus[a]], sr[2 * nb + a], e0[(size_t)i * na + a],
                   &pred[a], &ch[a], &dis[a], &q[a]);
-        const int it = solve_env(c, y, s, i, s->row[i], pred, ch, dis, q, vm);
+        const int it = solve_env(c, y, s, i, s->row[i], pred, ch, dis, q, e0 + (size_t)i * na, vm);
         failed[i] = it < 0;
         nfail += it < 0;
         if (it >= 0) memcpy(s->V + (size_t)i * nb, vm, nb * sizeof(double));
@@ -267,8 +345,7 @@ int oracle_env_reset_batch(const OCfg* c, OState* s, int n, const int32_t* start
 /* step + get_obs for n envs; actions [n][na][4] double; info [n][7] */
 int oracle_env_step_batch(const OCfg* c, OState* s, int n, const double* actions, double* reward, uint8_t* done,
                           double* info, uint8_t* failed, float* obs) {
-    OYbus* y = (OYbus*)malloc(sizeof(OYbus));
-    build_ybus(c, y);
+    ONet* y = build_net(c);
     const int nb = c->n_bus, na = c->n_agents;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) {
@@ -278,7 +355,7 @@ int oracle_env_step_batch(const OCfg* c, OState* s, int n, const double* actions
         for (int a = 0; a < na; ++a)
             parse(c, c->raw_actions, actions + ((size_t)i * na + a) * 4, sr[c->agent_bus[a]], sr[2 * nb + a],
                   s->E[(size_t)i * na + a], &pred[a], &ch[a], &dis[a], &q[a]);
-        const int it = solve_env(c, y, s, i, s->row[i], pred, ch, dis, q, vm);
+        const int it = solve_env(c, y, s, i, s->row[i], pred, ch, dis, q, s->Einit + (size_t)i * na, vm);
         const int ok = it >= 0;
         if (ok) {
             memcpy(s->V + (size_t)i * nb, vm, nb * sizeof(double));

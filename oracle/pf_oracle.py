@@ -27,6 +27,12 @@ from __future__ import annotations
 import numpy as np
 
 
+# IPOPT relaxes variable bounds by bound_relax_factor * max(1, |bound|) = 1e-8 (its default; the reference sets no
+# solver options, pf.py:101-102): E_next in [-1e-8, 0) still counts as inside NonNegativeReals.  Unpinned like the
+# solve itself (no IPOPT here); the kernels and the C oracle use the same constant (FLEX_DOMAIN_EPS).
+DOMAIN_EPS = 1e-8
+
+
 class SolverFailed(Exception):
     """Stands for pf.py:104-105 ``raise Exception('Solver failed to find a solution')``."""
 
@@ -263,4 +269,11 @@ def power_flow_solver(network_data, active_power_demand, reactive_power_demand, 
     out["Next ESS Energy"] = {
         k: initial_ess_energy[k] + dt * (cfg["eta_ch"] * ess_charging[k] - (1 / cfg["eta_dis"]) * ess_discharging[k])
         for k in network_data["ESSs_at_buildings"]}                     # pf.py:96-98
+    # pf.py:41-45: Vsqr, Isqr, E_next are NonNegativeReals.  E_next is pinned by the equality pf.py:96-98, so a negative
+    # value makes the NLP infeasible -> IPOPT status != ok -> pf.py:104-105 raises -> the env's failure path (env:314-337).
+    # Vsqr = |V|^2 and Isqr = |J|^2 are non-negative by construction here; a non-finite one is a failure as well.
+    if any(not (e >= -DOMAIN_EPS) for e in out["Next ESS Energy"].values()):
+        raise SolverFailed("E_next outside NonNegativeReals (pf.py:45)")
+    if not all(np.isfinite(v) for v in out["Voltages"].values()):
+        raise SolverFailed("non-finite Vsqr (pf.py:41)")
     return out

