@@ -72,6 +72,7 @@ def parse_args():
                     "rehearse the multi-rank control flow on a one-GPU box together with FLEX_BENCH_ONE_DEVICE=1)")
     ap.add_argument("--pf-tol", type=float, default=1e-12, help="power-flow convergence threshold (inf-norm power "
                     "mismatch, pu); 1e-12 is the headline setting, the parity bar is 1e-6 on voltages and rewards")
+    ap.add_argument("--no-sweep-accel", action="store_true", help="plain sweeps: without the two-sweep extrapolation (A/B leg)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--stacked-obs", action="store_true",
                     help="get_obs() as a stacked [n_agents, 6 * history] copy per step (the round-3 kernel) instead of the row push")
@@ -628,7 +629,7 @@ def main():
     series = make_synthetic_series(net)                      # 1096 days x 96 rows x 72 cols fp64 (60.6 MB)
     env = VecFlexProvisionEnv({}, a.envs, device=f"cuda:{local_rank}", net=net, series=series,
                               seed=1234 + 1000 * rank, warm_start=bool(a.warm_start), pf_tol=a.pf_tol,
-                              solver={"sweep": 2, "newton": 0}[a.solver])
+                              solver={"sweep": 2, "newton": 0}[a.solver], sweep_accel=not a.no_sweep_accel)
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)
     # the range the reference's translate_action actually delivers (util.py:125-128), float32 like util.py:184

@@ -72,7 +72,7 @@ typedef struct FlexCfg {
     int32_t pf_max_iter;       /* Newton cap; beyond it the env reports solver_failed */
     int32_t solver;            /* FLEX_SOLVER_* */
     int32_t warm_start;        /* 1 = start Newton from the previous solution instead of 1∠0 */
-    int32_t reserved0;
+    int32_t no_sweep_accel;    /* 1 = plain sweeps (FLEX_SOLVER_SWEEP without the two-sweep extrapolation calibrated at create) */
     double v_min, v_max;       /* env:685 */
     double e_min, e_max;       /* env:637,647 */
     double p_ch_max, p_dis_max;/* env:630-631 */

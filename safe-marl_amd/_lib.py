@@ -35,7 +35,7 @@ class FlexCfg(C.Structure):
     _fields_ = [
         ("n_agents", C.c_int32), ("history", C.c_int32), ("episode_limit", C.c_int32), ("per_hour", C.c_int32),
         ("n_start_days", C.c_int32), ("raw_actions", C.c_int32), ("pf_max_iter", C.c_int32), ("solver", C.c_int32),
-        ("warm_start", C.c_int32), ("reserved0", C.c_int32),
+        ("warm_start", C.c_int32), ("no_sweep_accel", C.c_int32),
         ("v_min", C.c_double), ("v_max", C.c_double), ("e_min", C.c_double), ("e_max", C.c_double),
         ("p_ch_max", C.c_double), ("p_dis_max", C.c_double), ("eta_ch", C.c_double), ("eta_dis", C.c_double),
         ("tan_phi", C.c_double), ("max_power_reduction", C.c_double), ("pv_cost", C.c_double),

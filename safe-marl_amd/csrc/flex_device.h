@@ -46,6 +46,13 @@ struct DevNet {
     int32_t seg_start[FLEX_MAX_BUS], seg_par[FLEX_MAX_BUS], seg_depth[FLEX_MAX_BUS];
     int32_t anc[FLEX_JUMP_ROUNDS][FLEX_MAX_BUS];
     int32_t n_jump_rounds, n_seg_rounds;
+    // sweep acceleration (pf_sweep): the dominant eigenvalue of the TWO-sweep error map is estimated as
+    // acc_kappa * |1 - V[acc_lane]|^2 — calibrated on the host when the handle is created (calibrate_sweep_accel);
+    // acc_kappa = 0 switches the extrapolation off (bare pf_solve_batch, FlexCfg::no_sweep_accel)
+    int32_t acc_lane;
+    float acc_kappa;
+    // the sweeps stop on their local mismatch estimate at sweep_tol_frac * pf_tol (pf_solve)
+    float sweep_tol_frac, pad1;
 };
 
 // Per-lane registers: this bus's row of the Ybus and its place in the tree.
@@ -377,8 +384,22 @@ __device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, c
 // cannot reach the coarse threshold (heavy loading, cold start) still ends on fp64-exact footing.
 // After a sweep the network equations hold exactly for (V_new, I_old), so the power mismatch at V_new is
 // V_new * conj(I_old - I_new) — between anchors I_old - I_new = delta_{k-1} - delta_k: a purely local quantity.
+//
+// Two-sweep extrapolation (round 5).  The error map of a sweep, e -> A e = -Z conj(S e / V^2), is ANTI-linear, so its real
+// spectrum comes in pairs +-lambda and plain Aitken / Anderson(1) on consecutive iterates sees no single dominant mode; its
+// square A^2 is complex-linear with real positive eigenvalues mu_1 = lambda_1^2 > mu_2 > ... (IEEE-33 at the bench's
+// loading: 2.5e-3, 4e-4, 1e-4: sweeps contract by 0.05, 0.02, 0.01 per mode).  With e_{k+2} = mu e_k on the dominant mode,
+//     d* = d_{k+2} + omega (d_{k+2} - d_k),   omega = mu / (1 - mu),
+// removes that mode.  Applied to the increments once per anchor at k = 1, where d_1 = c exactly and d_3 = c + x_2, it is a
+// scaling of x_2 and of the current increment delta_2 by (1 + omega): the pair (V, I_old) still satisfies the network
+// equations exactly, so the local mismatch test stays the true mismatch.  The fixed point is untouched whatever omega is;
+// a poor mu costs sweeps, never correctness (and pf_newton_tree has the last word as before).  mu is not measured in the
+// solve (an inner product = a group reduction per solve costs what the extrapolation saves): it follows the feeder's
+// loading, and kappa |1 - V_end|^2 with the host's calibration tracks it to ~4 % (tools/sweep_sim.py: 9.06 -> 7.96 sweeps
+// per solve in the NumPy model of this loop; exact mu: 7.51; a second extrapolation for mu_2: no further gain).
 // Returns (per group) the number of sweeps until its local test passed, or max_sweeps.
 #define FLEX_SWEEP_COARSE 1e-9
+#define FLEX_SWEEP_MU_MAX 0.02f
 #ifndef FLEX_SWEEP_REANCHOR
 #define FLEX_SWEEP_REANCHOR 8
 #endif
@@ -438,6 +459,9 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
     for (int k = 0; k < 6; ++k) mkf[k] = ln.mk[k] ? 1.0f : 0.0f;
     int mine = max_sweeps, it = 0;
     bool fine = false;                          // re-anchored below the coarse threshold already
+    const float kappa = use_seg ? net->acc_kappa : 0.0f;
+    const int acc_lane = net->acc_lane;
+    float relax = 1.0f;                         // 1 + omega of the two-sweep extrapolation, set after the first anchor
     while (it < max_sweeps) {
         // ---- anchor: one fp64 sweep from (e, f)
         double inv_d = fast_rcp(e * e + f * f);
@@ -446,6 +470,19 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
         zbus_apply_f64<EPW>(net, ln, use_seg, seg_rounds, jump_rounds, ar, ai);
         e = 1.0 + ar; f = ai;
         ++it;
+        if (it == 1 && kappa > 0.0f) {          // mu_1 from the voltage drop at the feeder's end (see above)
+            const float drop = (float)((1.0 - e) * (1.0 - e) + f * f);
+            float dsel;
+            if constexpr (EPW == 1) {
+                dsel = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(drop), acc_lane));
+            } else {
+                const float d0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(drop), acc_lane));
+                const float d1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(drop), acc_lane + 32));
+                dsel = ln.grp ? d1 : d0;
+            }
+            const float mu = fminf(kappa * dsel, FLEX_SWEEP_MU_MAX);
+            relax = 1.0f + mu * __builtin_amdgcn_rcpf(1.0f - mu);
+        }
         // currents at the anchor, and the anchor's own mismatch
         inv_d = fast_rcp(e * e + f * f);
         const double ibr = (ps * e + qs * f) * inv_d, ibi = (ps * f - qs * e) * inv_d;
@@ -483,6 +520,7 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
             if (!fine && __ballot(!(m < coarsef)) == 0ull) { fine = true; break; }          // re-anchor now
             pdr = xr; pdi = xi;
             zbus_apply_f32<EPW>(ln, mkf, rf, xf, seg_rounds, xr, xi);
+            if (k == 1) { xr *= relax; xi *= relax; pdr *= relax; pdi *= relax; }          // d_3 + omega (d_3 - d_1)
             dr = cr + xr; di = ci + xi;
             ++it;
         }
@@ -569,7 +607,7 @@ __device__ __forceinline__ bool pf_solve(const DevNet* __restrict__ net, const L
         //  the verification and paid a Newton step, 18.5 us per launch instead of 11.  Such tolerances sweep to the 1e-10
         //  level, which always re-anchors first; looser ones are met on the first anchor for real, tighter ones never were.
         //  Decided here, once per solve: a test inside the increment loop cost the default tolerance 3 %.)
-        double sweep_tol = 0.25 * tol;
+        double sweep_tol = (double)net->sweep_tol_frac * tol;
         if (sweep_tol < 2e-8 && sweep_tol > 2.5e-11) sweep_tol = 2.5e-11;
         sweeps = pf_sweep<EPW>(net, ln, pnet, qnet, e, f, sweep_tol, FLEX_MAX_SWEEPS);
         if (sweeps >= FLEX_MAX_SWEEPS) { e = 1.0; f = 0.0; }   // sweeps stalled: Newton from a flat start

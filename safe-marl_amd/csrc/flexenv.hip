@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
 #include "flex_device.h"
 #include "flexnet.h"
@@ -1179,6 +1180,11 @@ static int build_devnet(const NetFix* nf, int n_agents, DevNet* dn) {
     const int npq = n - 1;
     dn->n_bus = n; dn->n_pq = npq; dn->n_levels = nf->n_levels; dn->n_agents = n_agents; dn->slack_bus = nf->slack;
     dn->epw = (npq <= FLEX_WAVE / 2) ? 2 : 1;
+    dn->sweep_tol_frac = 0.25f;
+    if (const char* fr = getenv("FLEX_SWEEP_TOL_FRAC")) {         // measurement knob, not part of the ABI
+        const float v = (float)atof(fr);
+        if (v > 0.0f && v <= 1.0f) dn->sweep_tol_frac = v;
+    }
     // depth-first preorder of the PQ buses (the slack gets no lane): the first child of a bus lands in the next lane
     std::vector<int> order, stack;
     for (int k = nf->max_children - 1; k >= 0; --k) {
@@ -1281,6 +1287,66 @@ static int build_devnet(const NetFix* nf, int n_agents, DevNet* dn) {
     return FLEX_OK;
 }
 
+// Calibration of pf_sweep's two-sweep extrapolation (flex_device.h): for the loading `pnet`, `qnet` (per bus, pu) solve the
+// feeder on the host (dense Z-bus fixed point, n <= 64), take the dominant eigenvalue mu_1 of the two-sweep error map
+// A^2 = M conj(M), M = -Z diag(conj(S) / conj(V)^2), by power iteration, and express it through the largest voltage drop:
+// acc_lane = argmax |1 - V|, acc_kappa = mu_1 / |1 - V[acc_lane]|^2.  The ratio depends on how the load is distributed over
+// the feeder, hardly on its level; the kernel multiplies it by the drop it sees.  Leaves the extrapolation off (kappa = 0)
+// when the loading is degenerate (no drop, no convergence).
+#include <complex>
+static void calibrate_sweep_accel(DevNet* dn, const double* pnet, const double* qnet) {
+    typedef std::complex<double> cd;
+    const int n = dn->n_pq;
+    dn->acc_lane = 0; dn->acc_kappa = 0.0f;
+    if (n < 1 || dn->n_seg_rounds > 2) return;
+    std::vector<cd> Z((size_t)n * n), S(n), V(n, cd(1.0, 0.0)), I(n), x(n), y(n), t(n);
+    // Z[i][j] = impedance of the common part of the paths slack -> i and slack -> j (lanes are in preorder: ancestors first)
+    std::vector<std::vector<char>> on_path(n, std::vector<char>(n, 0));
+    for (int i = 0; i < n; ++i) {
+        int l = i;
+        for (;;) { on_path[i][l] = 1; if (dn->par_slack[l]) break; l = dn->par_lane[l]; }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            cd z(0.0, 0.0);
+            for (int l = 0; l < n; ++l) if (on_path[i][l] && on_path[j][l]) z += cd(dn->r[l], dn->x[l]);
+            Z[(size_t)i * n + j] = z;
+        }
+    double tot = 0.0;
+    for (int i = 0; i < n; ++i) { S[i] = -cd(pnet[dn->bus_of_lane[i]], qnet[dn->bus_of_lane[i]]); tot += std::abs(S[i]); }
+    if (!(tot > 0.0)) return;
+    auto matvec = [&](const std::vector<cd>& in, std::vector<cd>& out) {
+        for (int i = 0; i < n; ++i) { cd a(0.0, 0.0); for (int j = 0; j < n; ++j) a += Z[(size_t)i * n + j] * in[j]; out[i] = a; }
+    };
+    for (int it = 0; it < 60; ++it) {                          // V <- 1 + Z conj(S / V)
+        for (int i = 0; i < n; ++i) I[i] = std::conj(S[i] / V[i]);
+        matvec(I, t);
+        for (int i = 0; i < n; ++i) V[i] = cd(1.0, 0.0) + t[i];
+    }
+    for (int i = 0; i < n; ++i) if (!std::isfinite(V[i].real()) || !std::isfinite(V[i].imag()) || !(std::abs(V[i]) > 0.3)) return;
+    // A(e) = -Z conj(S e / V^2)  (anti-linear); power iteration on A^2
+    auto apply_a = [&](const std::vector<cd>& in, std::vector<cd>& out) {
+        for (int i = 0; i < n; ++i) I[i] = -std::conj(S[i] * in[i] / (V[i] * V[i]));
+        matvec(I, out);
+    };
+    for (int i = 0; i < n; ++i) x[i] = cd(1.0, 0.1 * (i % 3));
+    double mu = 0.0;
+    for (int it = 0; it < 200; ++it) {
+        apply_a(x, t); apply_a(t, y);
+        cd num(0.0, 0.0); double den = 0.0, ny = 0.0;
+        for (int i = 0; i < n; ++i) { num += std::conj(x[i]) * y[i]; den += std::norm(x[i]); ny += std::norm(y[i]); }
+        mu = num.real() / den;
+        if (!(ny > 0.0)) return;
+        const double sc = 1.0 / std::sqrt(ny);
+        for (int i = 0; i < n; ++i) x[i] = y[i] * sc;
+    }
+    int best = 0; double drop = 0.0;
+    for (int i = 0; i < n; ++i) { const double d = std::norm(cd(1.0, 0.0) - V[i]); if (d > drop) { drop = d; best = i; } }
+    if (!(mu > 0.0) || !(drop > 1e-8) || !(mu < 0.25)) return;
+    dn->acc_lane = best;
+    dn->acc_kappa = (float)(mu / drop);
+}
+
 static unsigned long long* g_stamps = nullptr;
 extern "C" void flexenv_debug_set_stamps(unsigned long long* dev) { g_stamps = dev; }
 
@@ -1336,6 +1402,20 @@ int flexenv_create(const FlexCfg* cfg, const NetFix* net, const SeriesTab* serie
     const size_t sz_ag = N * agent_rec_doubles(cfg->n_agents) * sizeof(double), sz_cr = N * sizeof(double);
     const size_t sz_ie = N * IF_COUNT * sizeof(int32_t), sz_ring = N * cfg->n_agents * cfg->history * 12 * sizeof(float);
     hipError_t err = hipSetDevice(device);
+    if (err == hipSuccess && !cfg->no_sweep_accel && cfg->solver == FLEX_SOLVER_SWEEP) {
+        // sweep acceleration: calibrated on the mean loading of eight rows spread over one day in the middle of the series
+        // (demand columns only: what the agents and the PV do moves the level of the loading, which the kernel follows
+        // through the voltage drop it sees, much more than its distribution over the feeder)
+        const int nb = net->n_bus, per_day = 24 * (cfg->per_hour > 0 ? cfg->per_hour : 4);
+        std::vector<double> row(series->cols), p(nb, 0.0), q(nb, 0.0);
+        for (int k = 0; k < 8 && err == hipSuccess; ++k) {
+            int64_t r = series->rows / 2 + (int64_t)k * per_day / 8;
+            if (r >= series->rows) r = series->rows - 1;
+            err = hipMemcpy(row.data(), series->table + r * series->cols, series->cols * sizeof(double), hipMemcpyDeviceToHost);
+            for (int b = 0; b < nb; ++b) { p[b] += row[b] / 8.0; q[b] += row[nb + b] / 8.0; }
+        }
+        if (err == hipSuccess) calibrate_sweep_accel(&e->hnet, p.data(), q.data());
+    }
     if (err == hipSuccess) err = hipMalloc(&e->net, sizeof(DevNet));
     if (err == hipSuccess) err = hipMemcpy(e->net, &e->hnet, sizeof(DevNet), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMalloc(&e->st.vm, sz_vm);

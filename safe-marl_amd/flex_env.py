@@ -59,7 +59,7 @@ class VecFlexProvisionEnv:
     """
 
     def __init__(self, env_args=None, n_envs=1, device="cuda:0", net=None, series=None, pf_tol=1e-12,
-                 pf_max_iter=20, warm_start=False, solver=_lib.FLEX_SOLVER_SWEEP, seed=None):
+                 pf_max_iter=20, warm_start=False, solver=_lib.FLEX_SOLVER_SWEEP, seed=None, sweep_accel=True):
         args = dict(DEFAULT_ENV_ARGS)
         args.update(env_args or {})
         self.args_dict = args
@@ -94,6 +94,7 @@ class VecFlexProvisionEnv:
         cfg.pf_max_iter = pf_max_iter
         cfg.solver = solver
         cfg.warm_start = 1 if warm_start else 0
+        cfg.no_sweep_accel = 0 if sweep_accel else 1       # include/flexenv.h: plain sweeps, for A/B measurements and tests
         for k in ("v_min", "v_max", "e_min", "e_max", "p_ch_max", "p_dis_max", "eta_ch", "eta_dis",
                   "max_power_reduction", "pv_cost", "ess_cost", "discomfort_coeff", "voltage_coeff",
                   "action_low", "action_high"):
