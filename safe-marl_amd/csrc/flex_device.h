@@ -516,7 +516,9 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
             bool wave_miss;
             const bool grp_miss = grp_any<EPW>(!(m < tolf), ln.grp, wave_miss);
             if (!grp_miss && mine == max_sweeps) mine = it;
-            if (!wave_miss) { done = true; break; }
+            // a threshold below the coarse one is only trusted on a re-anchored iterate: with the extrapolation an increment
+            // can contract by more than coarse / tol in one step and pass the fp32 test while still hanging on its first anchor
+            if (!wave_miss && (fine || tolf >= coarsef)) { done = true; break; }
             if (!fine && __ballot(!(m < coarsef)) == 0ull) { fine = true; break; }          // re-anchor now
             pdr = xr; pdi = xi;
             zbus_apply_f32<EPW>(ln, mkf, rf, xf, seg_rounds, xr, xi);
@@ -600,8 +602,10 @@ __device__ __forceinline__ bool pf_solve(const DevNet* __restrict__ net, const L
                                          int& sweeps) {
     sweeps = 0;
     if (solver == FLEX_SOLVER_SWEEP) {
-        // sweeps stop on their LOCAL mismatch estimate at tol/4 so that the Ybus re-evaluation below (different
-        // rounding) confirms it at tol instead of spending a full Newton step on a borderline case
+        // sweeps stop on their LOCAL mismatch estimate at sweep_tol_frac * tol (0.5; 0.25 until round 4 — measured with 0.5 and
+        // 0.8: still no solve of 2 M that the verification did not confirm, a quarter / half a sweep fewer per solve) so that
+        // the Ybus re-evaluation below (different rounding) confirms it at tol instead of spending a full Newton step on a
+        // borderline case
         // (Thresholds between 2.5e-11 and 2e-8 can be met by the fp32 increments while the iterate still hangs on its FIRST
         //  anchor, up to ~1e-9 from the fp64 fixed point: measured at pf_tol 1e-9 / 1e-8, 56 % / 31 % of the solves then failed
         //  the verification and paid a Newton step, 18.5 us per launch instead of 11.  Such tolerances sweep to the 1e-10

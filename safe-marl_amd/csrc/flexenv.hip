@@ -1180,7 +1180,7 @@ static int build_devnet(const NetFix* nf, int n_agents, DevNet* dn) {
     const int npq = n - 1;
     dn->n_bus = n; dn->n_pq = npq; dn->n_levels = nf->n_levels; dn->n_agents = n_agents; dn->slack_bus = nf->slack;
     dn->epw = (npq <= FLEX_WAVE / 2) ? 2 : 1;
-    dn->sweep_tol_frac = 0.25f;
+    dn->sweep_tol_frac = 0.5f;
     if (const char* fr = getenv("FLEX_SWEEP_TOL_FRAC")) {         // measurement knob, not part of the ABI
         const float v = (float)atof(fr);
         if (v > 0.0f && v <= 1.0f) dn->sweep_tol_frac = v;

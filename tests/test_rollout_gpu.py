@@ -623,7 +623,7 @@ def test_burst_launch_equals_two_launches_per_step_bit_for_bit(n_envs, buildings
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     for name in ("reward", "done", "info", "failed"):
         assert torch.equal(getattr(ta.env, name), getattr(tb.env, name)), name
-    assert torch.equal(ta.env.get_obs().clone(), tb.env.get_obs().clone())
+    assert torch.equal(ta.env.obs_view().clone(), tb.env.obs_view().clone())
     assert float(a.acc[:, 7].abs().sum().item()) > 0
 
 
@@ -677,7 +677,7 @@ def test_safemaddpg_burst_equals_three_launches_per_step_bit_for_bit(N, monkeypa
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     for name in ("reward", "done", "info", "failed"):
         assert torch.equal(getattr(ea, name), getattr(eb, name)), name
-    assert torch.equal(ea.get_obs().clone(), eb.get_obs().clone())
+    assert torch.equal(ea.obs_view().clone(), eb.obs_view().clone())
     # the layer did act: the step's action differs from translate_action of the policy's own action somewhere
     own = 0.5 * (a.act_buf.clamp(0.0, 1.0) + 1.0)
     assert (a.burst_safe_env_act.view(N, 4, 5).transpose(1, 2).reshape(N * 5, 4) - own).abs().max().item() > 1e-3

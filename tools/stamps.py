@@ -14,7 +14,8 @@ solver = int(sys.argv[1]) if len(sys.argv)>1 else 2
 sink = len(sys.argv) > 2 and sys.argv[2] == "sink"      # the SINK instantiation: the step files its own transition
 net=create_network(); s=make_synthetic_series(net,n_days=200)
 N=4096
-env=VecFlexProvisionEnv({}, N, net=net, series=s, seed=1, warm_start=True, solver=solver)
+env=VecFlexProvisionEnv({}, N, net=net, series=s, seed=1, warm_start=True, solver=solver,
+                        sweep_accel=os.environ.get('FLEX_NO_SWEEP_ACCEL') != '1')
 lib=_lib.load()
 stamps=torch.zeros(N,16,dtype=torch.int64,device='cuda')
 pool=(0.5+0.5*torch.rand(8,N,5,4,device='cuda')).float()
@@ -48,6 +49,7 @@ rt0, rt1 = st[:,5], st[:,6]
 print('  wave lifetime cycles', (st[:,4]-st[:,0]).mean(), ' realtime ticks(100MHz) per wave', (rt1-rt0).mean(), ' => clock GHz', ((st[:,4]-st[:,0])/(rt1-rt0)).mean()*0.1)
 print('  kernel span us (realtime)', (rt1.max()-rt0.min())/100.0, ' start spread us', (rt0.max()-rt0.min())/100.0, ' end spread us', (rt1.max()-rt1.min())/100.0)
 print('  sweeps', env.peek('PF_SWEEPS').float().mean().item(), 'newton', env.peek('PF_ITERS').float().mean().item())
+sw=env.peek('PF_SWEEPS').cpu().numpy(); print('  sweeps hist', np.bincount(sw, minlength=13), ' mean of per-wavefront max', sw.reshape(-1,2).max(1).mean(), ' solve cycles by wavefront max sweeps:', {int(k): round(float(d[::2,1][sw.reshape(-1,2).max(1)==k].mean())) for k in np.unique(sw.reshape(-1,2).max(1))})
 rel=(rt0-rt0.min())/100.0
 import numpy as np
 h,edges=np.histogram(rel,bins=16)
