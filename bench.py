@@ -199,7 +199,7 @@ TRAIN_ALG_ARGS = dict(  # madrl/args/default.yaml merged with alg_args/maddpg.ya
 )
 
 
-def make_trainer(alg, n_agents, envs, rank, local_rank, batch_div=4):
+def make_trainer(alg, n_agents, envs, rank, local_rank, batch_div=4, intended=False):
     """PGTrainer(args, model, env, logger) as train_agent.py:67-107 builds it, on the vectorised HIP env.  A sub-update's batch
     is batch_size x (envs / batch_div) consecutive replay slots: batch_div = 4 is the trainer's default (1.47 samples consumed
     per transition collected), batch_div = 1 the reference's own sample reuse (5.87 = 11 x 32 / 60, model.py:43-50 x
@@ -225,21 +225,27 @@ def make_trainer(alg, n_agents, envs, rank, local_rank, batch_div=4):
     torch.manual_seed(0)
     trainer = PGTrainer(convert(d), {"maddpg": MADDPG, "safemaddpg": SAFEMADDPG}[alg], env, None,
                         batch_scale=max(1, envs // batch_div), replay_capacity=envs * 96 * 2)
+    if intended:
+        # NOT the reference's routing (under it SAFEMADDPG's policy cannot move the environment): the safety layer's
+        # output reaches env.step() as the physical values of building i, agent-major (learner.SAFEMADDPG.intended_actions)
+        trainer.behaviour_net.intended_actions = True
     return trainer, env
 
 
-def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, max_over_ranks, batch_div=4):
+def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, max_over_ranks, batch_div=4, intended=False):
     """One training configuration: TWO warm-up episodes (allocations, HIP-graph captures of the rollout, its bursts and both
     sub-updates — the first update event falls into the first episode, the first policy/value replays and the 8/4/2-step
     bursts of the second window into the second —, rocBLAS plans), then `episodes` timed episodes of 95 vector steps each
     between barriers; whole-job env-steps/s = envs x world x steps / max-rank time.  `episode_ms` lists the timed episodes
     one by one (an episode holds one or two update events, so they alternate)."""
     import torch
-    trainer, env = make_trainer(alg, n_agents, envs, rank, local_rank, batch_div)
+    trainer, env = make_trainer(alg, n_agents, envs, rank, local_rank, batch_div, intended=intended)
     stat = {}
     for _ in range(2):
         trainer.behaviour_net.train_process(stat, trainer)
     barrier()
+    from safe_marl_amd import dist as fdist
+    ar0 = dict(fdist.STATS)
     steps0 = trainer.steps
     episode_ms = []
     t0 = time.perf_counter()
@@ -255,6 +261,12 @@ def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, m
     freq = trainer.args.behaviour_update_freq
     events = sum(1 for st in range(steps0, trainer.steps) if st > 0 and st % freq == 0)
     per_event = trainer.args.value_update_epochs + trainer.args.policy_update_epochs
+    # the exchange step, checkable from the line itself: what THIS rank put through the all-reduce in the
+    # timed region against what the schedule asks for (one flat bucket per gradient step), and whether the replicas still
+    # hold the same weights afterwards — max over ranks of |theta - theta_rank0|, which must be exactly 0.0
+    ar_calls = fdist.STATS["allreduce_calls"] - ar0["allreduce_calls"]
+    ar_bytes = fdist.STATS["allreduce_bytes"] - ar0["allreduce_bytes"]
+    diverge = fdist.replica_divergence(trainer.behaviour_net) if world > 1 else {"params": 0.0, "buffers": 0.0}
     rg = getattr(trainer.behaviour_net, "_rollout_graph", None)
     # the rollout alone, after the timed region (the leg is over: the extra steps go nowhere): runs of 60 vector steps, the
     # distance between two update events, as the training loop issues them (one burst launch, or graphs of 16 / 8 / 4 bodies)
@@ -269,7 +281,9 @@ def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, m
         e1.record()
         torch.cuda.synchronize()
         rollout_us = e0.elapsed_time(e1) * 1e3 / 300
-    out = {"alg": alg, "n_agents": env.n_agents, "envs_per_gpu": envs, "n_gpus": world, "episodes": episodes,
+    out = {"alg": alg, "action_routing": ("intended (NOT the reference's routing; learner.SAFEMADDPG.intended_actions)" if intended else
+                                          "reference (bug-compatible, SURVEY A13)") if alg == "safemaddpg" else None,
+           "n_agents": env.n_agents, "envs_per_gpu": envs, "n_gpus": world, "episodes": episodes,
            "vector_steps": steps, "ms_per_vector_step": dt / steps * 1e3,
            "env_steps_per_s": envs * world * steps / dt, "grad_steps": events * per_event,
            "batch_per_gpu": trainer.effective_batch_size(),
@@ -289,6 +303,11 @@ def train_leg(alg, n_agents, envs, episodes, rank, local_rank, world, barrier, m
                                       all(g.get("allreduce_in_graph") for g in trainer._update_graphs.values())),
            "grad_allreduce": (f"{torch.distributed.get_backend()} all-reduce of one flat bucket (sum, 1/world inside graph B), "
                               "before the clip") if world > 1 else None,
+           "allreduce_calls": ar_calls if world > 1 else None, "allreduce_calls_expected": events * per_event if world > 1 else None,
+           "allreduce_bytes": ar_bytes if world > 1 else None, "graph_form_agreements": fdist.STATS["agreements"] if world > 1 else None,
+           "replica_max_abs_diff": diverge["params"] if world > 1 else None,
+           "replica_buffers_max_abs_diff": diverge["buffers"] if world > 1 else None,
+           "reward_bn_statistics": ("cross-rank" if getattr(trainer, "sync_reward_bn", False) else "per-rank (buffers differ by design)") if world > 1 else None,
            "mean_train_reward": float(stat.get("mean_train_reward", float("nan"))),
            "mean_train_value_loss": float(stat.get("mean_train_value_loss", float("nan")))}
     del trainer, env, rg
@@ -624,6 +643,16 @@ def main():
         else:
             dist.init_process_group(a.backend, timeout=datetime.timedelta(seconds=180))
     coll_dev = dev if a.backend == "nccl" else torch.device("cpu")
+    dist_info = None
+    if distributed:
+        # what the process group itself reports, and which device every rank sits on (N ranks on N distinct devices, or the
+        # one-device rehearsal) — gathered, not assumed
+        mine = {"rank": rank, "device_index": torch.cuda.current_device(), "device": torch.cuda.get_device_name(),
+                "uuid": str(getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "uuid", ""))}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        dist_info = {"world_size": dist.get_world_size(), "backend": str(dist.get_backend()),
+                     "distinct_devices": len({(g["device_index"], g["uuid"]) for g in gathered}), "ranks": gathered}
 
     net = create_network()
     series = make_synthetic_series(net)                      # 1096 days x 96 rows x 72 cols fp64 (60.6 MB)
@@ -902,15 +931,17 @@ def main():
         # (alg, agents, envs per GPU, batch divisor): every configuration at the trainer's default batch (envs / 4 x 32:
         # 1.47 samples per transition) AND at the reference's own sample reuse (envs x 32: 5.87)
         if distributed:
-            legs = [("maddpg", 5, N_ENVS, 4), ("safemaddpg", 5, 2 * N_ENVS, 4)]
+            legs = [("maddpg", 5, N_ENVS, 4, False), ("safemaddpg", 5, 2 * N_ENVS, 4, False)]
         else:
-            legs = [("maddpg", 5, N_ENVS, 4), ("maddpg", 5, N_ENVS, 1), ("maddpg", 3, N_ENVS, 4), ("maddpg", 3, N_ENVS, 1),
-                    ("safemaddpg", 5, 2 * N_ENVS, 4), ("safemaddpg", 5, 2 * N_ENVS, 1)]
+            # the last leg: config 4 with a policy that CAN act on the safety layer — labelled, no parity claim
+            legs = [("maddpg", 5, N_ENVS, 4, False), ("maddpg", 5, N_ENVS, 1, False), ("maddpg", 3, N_ENVS, 4, False),
+                    ("maddpg", 3, N_ENVS, 1, False), ("safemaddpg", 5, 2 * N_ENVS, 4, False), ("safemaddpg", 5, 2 * N_ENVS, 1, False),
+                    ("safemaddpg", 5, 2 * N_ENVS, 4, True)]
         train = []
-        for alg, n_ag, n_env, div in legs:
+        for alg, n_ag, n_env, div, intended in legs:
             try:
                 train.append(train_leg(alg, n_ag, n_env, max(2, a.train_episodes), rank, local_rank, world, barrier,
-                                       max_over_ranks, batch_div=div))
+                                       max_over_ranks, batch_div=div, intended=intended))
             except Exception as exc:                  # a failed leg must not cost the headline line
                 print(f"[bench] rank {rank}: training leg {alg}/{n_ag}/{n_env}/{div} failed: {exc!r}", file=sys.stderr)
                 train.append({"alg": alg, "n_agents": n_ag, "envs_per_gpu": n_env, "n_gpus": world, "batch_div": div,
@@ -938,6 +969,9 @@ def main():
             "value": total_env_steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
+            "world_size": dist_info["world_size"] if dist_info else 1,
+            "backend": dist_info["backend"] if dist_info else None,
+            "dist": dist_info,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
@@ -947,17 +981,25 @@ def main():
             "dtype": "f64",
             "data": "synthetic (stand-in IEEE-33 Baran-Wu network, SURVEY.md App. C; generated series, SURVEY.md §8d)",
             "config": {
-                "workload": ("flex_provision.step()+get_obs() batched, %d envs/GPU, 33-bus AC power flow, 5 agents, in-launch "
-                             "auto-reset; get_obs(): %s; solver: %s, inf-norm power mismatch < %g pu") % (
-                                 a.envs,
+                # (the driver keeps the first 120 characters of this string: envs, solver, tolerance and observation form first)
+                "workload": ("step()+get_obs() %d envs/GPU, 33-bus AC PF, %d agents; %s, pf_tol %g; %s obs; auto-reset" % (
+                    a.envs, n_agents_env, "sweeps+fp64 Newton check" if a.solver == "sweep" else "fp64 Newton (tree)", a.pf_tol,
+                    "stacked-copy" if a.stacked_obs else "row-push")),
+                "workload_detail": ("flex_provision.step()+get_obs() batched, in-launch auto-reset; get_obs(): %s; solver: %s, "
+                                    "inf-norm power mismatch < %g pu") % (
                                  "stacked [5, 144] fp32 copy per step" if a.stacked_obs else
                                  "row push — the step appends its [5, 6] feature row to the env's observation history (mirror ring); "
                                  "consumers read the stacked [5, 144] window in place (policy kernels) or via flexenv_obs_view",
-                                 "backward/forward sweeps (fp64 anchor sweeps, fp32 increment sweeps between them) + fp64 Newton "
-                                 "verification of the Ybus mismatch (%.3g Newton steps, %.2f sweeps per solve)" % (iters_mean, sweeps_mean)
+                                 "backward/forward sweeps (fp64 anchor sweeps, fp32 increment sweeps between them, two-sweep "
+                                 "extrapolation %s) + fp64 Newton verification of the Ybus mismatch (%.3g Newton steps, %.2f sweeps "
+                                 "per solve)" % ("off" if a.no_sweep_accel else "on", iters_mean, sweeps_mean)
                                  if a.solver == "sweep" else
                                  "fp64 Newton-Raphson on the Ybus, tree-structured elimination (%.2f Newton steps per solve)" % iters_mean,
                                  a.pf_tol),
+                "pf_tol": a.pf_tol,
+                "arith": ("fp64 verify / fp32 increments" if a.solver == "sweep" else "fp64"),
+                "obs_form": "stacked" if a.stacked_obs else "row_push",
+                "sweep_accel": bool(a.solver == "sweep" and not a.no_sweep_accel),
                 "envs_per_gpu": a.envs, "n_agents": n_agents_env, "n_bus": n_bus_env,
                 "warm_start": bool(a.warm_start), "launches_per_step": 1, "hip_graph": used_graph, "hip_graph_uploaded": used_graph,
                 "device_ms_per_step": dev_ms / a.steps, "solver": ("sweep (mixed fp64/fp32 increments) + fp64 Newton verification" if a.solver == "sweep" else "newton (fp64, tree elimination)"),

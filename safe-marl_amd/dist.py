@@ -37,6 +37,53 @@ def broadcast_module(module, src=0):
             off += n
 
 
+# What this rank has put through the exchange step so far: eager calls are counted where they are made, an all-reduce
+# captured inside an update graph once per REPLAY of that graph (trainer._replay).  bench.py reports them per leg so that
+# the first multi-GPU run can be checked from its own output.
+STATS = {"allreduce_calls": 0, "allreduce_bytes": 0, "agreements": 0}
+
+
+def note_allreduce(n_bytes, calls=1):
+    STATS["allreduce_calls"] += int(calls)
+    STATS["allreduce_bytes"] += int(n_bytes) * int(calls)
+
+
+def all_agree(ok, device=None):
+    """True iff EVERY rank passes ``ok`` (an all-reduce(MIN) of one flag; trivially ``ok`` on one rank).  Decisions that
+    change what a rank puts on the wire afterwards — one update graph with the all-reduce inside it, two graphs around an
+    eager one, eager sub-updates — are taken through this, never locally: a capture that fails on one rank only must move
+    every rank to the fallback, or their collectives stop matching."""
+    if world_size() <= 1:
+        return bool(ok)
+    dev = device if (device is not None and backend() == "nccl") else th.device("cpu")
+    flag = th.tensor([1 if ok else 0], dtype=th.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    STATS["agreements"] += 1
+    return bool(int(flag.item()))
+
+
+def replica_divergence(module, src=0):
+    """max |theta - theta_src| over the PARAMETERS of ``module`` and, separately, over its floating-point buffers, maximised
+    over the ranks.  Parameters must come out 0.0 exactly: every rank applies the same averaged gradient to the same
+    weights.  Buffers hold the reward BatchNorm's running statistics, which are per-rank unless sync_reward_bn is set."""
+    out = []
+    with th.no_grad():
+        for tensors in (list(module.parameters()), [b for b in module.buffers() if b.is_floating_point()]):
+            if not tensors:
+                out.append(0.0)
+                continue
+            mine = th.cat([t.detach().reshape(-1).float() for t in tensors])
+            if world_size() <= 1:
+                out.append(0.0)
+                continue
+            ref = mine.clone()
+            dist.broadcast(ref, src=src)
+            d = (mine - ref).abs().max().reshape(1)
+            dist.all_reduce(d, op=dist.ReduceOp.MAX)
+            out.append(float(d.item()))
+    return {"params": out[0], "buffers": out[1]}
+
+
 def allreduce_grads(params):
     """Mean of the gradients over ranks through ONE flattened bucket (sum, then scale)."""
     grads = [p.grad for p in params if p.grad is not None]
@@ -44,6 +91,7 @@ def allreduce_grads(params):
         return
     flat = th.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    note_allreduce(flat.numel() * flat.element_size())
     flat.div_(dist.get_world_size())
     off = 0
     for g in grads:
@@ -56,6 +104,8 @@ def allreduce_flat(flat):
     """SUM over ranks of an already-flat gradient bucket, in place (the caller scales by 1/world — inside its HIP graph
     when the update is graphed).  One ncclAllReduce on RCCL's stream, ordered after the current stream."""
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if not th.cuda.is_available() or not th.cuda.is_current_stream_capturing():
+        note_allreduce(flat.numel() * flat.element_size())          # (a captured one is counted per replay)
 
 
 def shard_envs(total_envs):

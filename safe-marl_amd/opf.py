@@ -642,7 +642,18 @@ class BatchedOPF:
                       (_PeriodBlocks(lin["ji"]), None, i_hi),
                       (_EnergyChain(T, self.na, self.dt * c["eta_ch"], self.dt / c["eta_dis"]), e_lo, e_hi)]
             x0 = th.where(free, 0.5 * (lo + hi).reshape(B, n), lo.reshape(B, n))
-            if self.device.type == "cuda" and NATIVE_QP:
+            native = self.device.type == "cuda" and NATIVE_QP
+            if native:
+                from . import _lib
+                if _lib.load().flexopf_qp_work_doubles(T, self.na, lin["jv"].shape[2]) < 0:
+                    # sizes beyond the kernel's compile-time limits (include/flexopf.h: periods, rows, agents): the torch
+                    # iteration solves them as it did before the native kernel existed — slower, same programme;
+                    # counted and reported once (util.note_fallback)
+                    from .util import note_fallback
+                    note_fallback("opf.qp_ipm_native", f"T = {T}, rows = {lin['jv'].shape[2]}, agents = {self.na} outside "
+                                  "flexopf_qp_solve's limits")
+                    native = False
+            if native:
                 xn, info = qp_ipm_native(Qblk, cvec, (lo - pin).reshape(B, n), (hi + pin).reshape(B, n), free, lin["jv"], v_lo, v_hi,
                                          lin["ji"], i_hi, self.dt * c["eta_ch"], self.dt / c["eta_dis"], e_lo, e_hi, x0)
             else:

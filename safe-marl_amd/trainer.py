@@ -63,8 +63,6 @@ class PGTrainer(object):
         # collectives can be stream-captured: ProcessGroupNCCL joins its stream to the capture); it stays opt-in until a
         # multi-GPU RCCL run of tests/test_dist_gpu.py exists, and falls back to the split form if the capture
         # fails
-        self.allreduce_in_graph = (os.environ.get("FLEX_ALLREDUCE_IN_GRAPH", "0") == "1" and fdist.world_size() > 0
-                                   and fdist.backend() == "nccl")
         self.entr = args.entr
         self.world = fdist.world_size()
         # Reward BatchNorm over ALL ranks' batches ("or all-reduce 2 x 5 moments"): off by default (per-rank
@@ -74,6 +72,11 @@ class PGTrainer(object):
         if sync_reward_bn is None:
             sync_reward_bn = os.environ.get("FLEX_SYNC_REWARD_BN") == "1"
         self.sync_reward_bn = bool(sync_reward_bn) and self.world > 1
+        # cross-rank reward statistics put an all-reduce INSIDE the loss (graph A): on nccl they imply the in-graph form
+        # (left independent, sync_reward_bn on nccl without FLEX_ALLREDUCE_IN_GRAPH silently dropped the whole run
+        # to eager sub-updates); on gloo nothing can be captured and the sub-updates run eagerly — on EVERY rank (all_agree)
+        self.allreduce_in_graph = ((os.environ.get("FLEX_ALLREDUCE_IN_GRAPH", "0") == "1" or self.sync_reward_bn)
+                                   and self.world > 1 and fdist.backend() == "nccl")
 
         # behaviour net (+ target replica), trainer.py:16-28: SAFEMADDPG also receives the env
         ctor_args = (args, env) if args.alg == "safemaddpg" else (args,)
@@ -140,15 +143,22 @@ class PGTrainer(object):
             which_key = which
         g = store.get(which_key)
         if g is None or g["bs"] != bs or g["buf"] is not buf:
+            exc = None
             try:
                 g = self._capture_sub_update(which, bs)
-            except Exception as exc:                  # capture not possible here: stay eager from now on
+            except Exception as e:                    # capture not possible here: stay eager from now on
+                g, exc = None, e
+            # every rank reaches this point at the same sub-update (same schedule): the fallback is taken by ALL of them or by
+            # none — a rank replaying graphs beside a rank stepping eagerly would still match collective for collective today,
+            # but only by accident of the two forms' call sequences
+            if not fdist.all_agree(g is not None, self.device):
                 import warnings
+                why = exc if exc is not None else "another rank's capture failed"
                 if which == "value_cached":           # ... or just without the filed bootstrap values
-                    warnings.warn(f"capture of the value sub-update on filed bootstrap values failed ({exc}); computing them per sub-update")
+                    warnings.warn(f"capture of the value sub-update on filed bootstrap values failed ({why}); computing them per sub-update")
                     self.cache_bootstrap = False
                     return None
-                warnings.warn(f"sub-update graph capture failed ({exc}); using eager sub-updates")
+                warnings.warn(f"sub-update graph capture failed ({why}); using eager sub-updates")
                 self.graph_updates = False
                 return None
             store[which_key] = g
@@ -156,6 +166,8 @@ class PGTrainer(object):
 
     def _replay(self, g, stat):
         g["graph"].replay()
+        if g["flat"] is not None and g["apply"] is None:          # the all-reduce captured inside the graph ran once more
+            fdist.note_allreduce(g["flat"].numel() * g["flat"].element_size())
         if g["apply"] is not None:
             # more than one rank: the captured region is split at the exchange step — graph A (losses, backward, gradients
             # into ONE static flat bucket), the all-reduce of that bucket through RCCL (eager: one ncclAllReduce of
@@ -477,6 +489,7 @@ class PGTrainer(object):
             else:
                 fused = False
                 if self.allreduce_in_graph:
+                    why = None
                     try:
                         with graph_capture(graph):
                             self._loss_and_grads(which, out, batch, fresh_leaves=True, flat=flat)
@@ -484,12 +497,18 @@ class PGTrainer(object):
                             self._apply_grads(which, out, flat=flat)
                         fused = True
                     except Exception as exc:
+                        why = exc
+                    # one graph with the all-reduce inside it on EVERY rank, or the split form on every rank (VERDICT r04
+                    # item 4: this used to be decided per rank)
+                    th.cuda.synchronize()
+                    if not fdist.all_agree(fused, self.device):
                         if self.sync_reward_bn:      # the statistics' all-reduce sits inside graph A: no split form — eager sub-updates
-                            raise
+                            raise RuntimeError(f"all-reduces inside the sub-update graph could not be captured on every rank ({why})")
                         import warnings
-                        warnings.warn(f"all-reduce inside the sub-update graph could not be captured ({exc}); splitting the graph at it")
+                        warnings.warn(f"all-reduce inside the sub-update graph could not be captured on every rank ({why}); "
+                                      "splitting the graph at it")
                         self.allreduce_in_graph = False
-                        th.cuda.synchronize()
+                        fused = False
                         graph = th.cuda.CUDAGraph()
                         out = {}
                 if not fused:

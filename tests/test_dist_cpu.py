@@ -238,7 +238,10 @@ def _train_worker(rank, world, port, out, alg="maddpg", sync_bn=False):
     w1 = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.parameters()])
     tgt = th.cat([p.detach().reshape(-1) for p in trainer.behaviour_net.target_net.parameters()])
     bn = trainer.behaviour_net.batchnorm
+    from safe_marl_amd import dist as fdist
+    div = fdist.replica_divergence(trainer.behaviour_net) if world > 1 else {"params": 0.0, "buffers": 0.0}
     out[rank] = dict(w0=w0.numpy(), w1=w1.numpy(), tgt=tgt.numpy(), steps=trainer.steps, buf=len(trainer.replay_buffer.buffer),
+                     allreduce_calls=fdist.STATS["allreduce_calls"], allreduce_bytes=fdist.STATS["allreduce_bytes"], div=div,
                      vloss=float(stat["mean_train_value_loss"]), reward=float(stat["mean_train_reward"]),
                      bn_mean=bn.running_mean.numpy().copy(), bn_var=bn.running_var.numpy().copy(), bn_n=int(bn.num_batches_tracked),
                      model=type(trainer.behaviour_net).__name__)
@@ -289,3 +292,67 @@ def test_train_process_on_two_ranks_safemaddpg_and_cross_rank_reward_statistics(
         assert np.array_equal(a["bn_mean"], b["bn_mean"]) and np.array_equal(a["bn_var"], b["bn_var"])
     else:
         assert not np.array_equal(a["bn_mean"], b["bn_mean"])               # per-rank statistics: the documented deviation
+
+
+def test_train_process_on_four_ranks_counts_its_all_reduces_and_keeps_replicas_identical():
+    """world 4, and the figures bench.py prints for an N > 1 leg checked where they can be checked — every
+    rank counts exactly one all-reduce of one flat bucket per gradient step (22 = two update events x (10 value + 1 policy));
+    replica_divergence reports 0.0 for the parameters on every rank and a non-zero figure for the per-rank reward statistics."""
+    world = 4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_train_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r = [out[i] for i in range(world)]
+    for x in r[1:]:
+        assert np.array_equal(x["w1"], r[0]["w1"]) and np.array_equal(x["tgt"], r[0]["tgt"])
+        assert x["vloss"] != r[0]["vloss"]
+    n_value, n_policy = 52097, 34948                       # SURVEY.md 2: critic / actor parameters of the default config
+    for x in r:
+        assert x["allreduce_calls"] == 22
+        assert x["allreduce_bytes"] == 4 * (20 * n_value + 2 * n_policy)
+        assert x["div"]["params"] == 0.0 and x["div"]["buffers"] > 0.0
+
+
+def _control_worker(rank, world, port, out):
+    import safe_marl_amd  # noqa: F401
+    from safe_marl_amd import dist as fdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {"shard": fdist.shard_envs(world * 4096), "seed": 1234 + 1000 * fdist.rank(), "world": fdist.world_size(),
+           "backend": fdist.backend()}
+    # a decision every rank must take together: one rank's failure moves everybody to the fallback
+    res["agree_all_ok"] = fdist.all_agree(True)
+    res["agree_one_bad"] = fdist.all_agree(rank != 5)
+    lin = th.nn.Linear(7, 3)
+    th.manual_seed(rank)
+    with th.no_grad():
+        lin.weight.normal_()
+    res["div_before"] = fdist.replica_divergence(lin)["params"]
+    fdist.broadcast_module(lin)
+    res["div_after"] = fdist.replica_divergence(lin)["params"]
+    flat = th.full((10,), float(rank + 1))
+    fdist.allreduce_flat(flat)
+    res["sum"] = float(flat[0])
+    res["stats"] = dict(fdist.STATS)
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_8_control_flow_on_gloo():
+    """BASELINE config 5's host-side control flow at its real world size (the 8-GPU run itself is the driver's): contiguous
+    env shards of 4096, per-rank seeds 1234 + 1000 rank (bench.py), the cross-rank agreement that decides the update-graph
+    form, replica broadcast / divergence check, the flat-bucket all-reduce and its counters."""
+    world = 8
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_control_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        x = out[r]
+        assert x["world"] == 8 and x["backend"] == "gloo"
+        assert x["shard"] == (4096 * r, 4096) and x["seed"] == 1234 + 1000 * r
+        assert x["agree_all_ok"] is True and x["agree_one_bad"] is False
+        assert x["div_before"] > 0.0 and x["div_after"] == 0.0
+        assert x["sum"] == sum(range(1, 9))
+        assert x["stats"]["allreduce_calls"] == 1 and x["stats"]["allreduce_bytes"] == 40 and x["stats"]["agreements"] == 2

@@ -140,3 +140,30 @@ def test_more_days_than_compute_units():
         xb, ib = qp_ipm_native(*[a[b:b + 1] for a in args], p["a"], p["b"], *[a[b:b + 1] for a in tail])
         assert torch.equal(xb[0], x[b])
         assert torch.equal(ib["duals"][3][0], info["duals"][3][b])
+
+
+def test_horizons_beyond_the_kernels_limits_fall_back_to_the_torch_iteration():
+    """BatchedOPF.solve on the GPU used to raise for programmes flexopf_qp_solve was not built for (T > 128, more
+    than 64 rows, more than 5 agents); it now solves them on the torch iteration, as before the native kernel existed, and
+    says so once (util.note_fallback).  T = 130 periods of a quarter hour, two days."""
+    import warnings
+    from safe_marl_amd import util
+    from safe_marl_amd.opf import BatchedOPF
+    from safe_marl_amd.network import create_network
+    from safe_marl_amd.series import make_synthetic_series
+    from tests.test_opf_gpu import _check_against_reference_expressions, _as_reference_solution
+    net = create_network()
+    s = make_synthetic_series(net, n_days=12)
+    tab = np.asarray(s.table)
+    T, B = 130, 2
+    rows = np.stack([tab[96 * (2 + 2 * b) + 30:96 * (2 + 2 * b) + 30 + T] for b in range(B)])
+    price, pd, qd, ppv, e0 = rows[:, :, 71], rows[:, :, :33], rows[:, :, 33:66], rows[:, :, 66:71], np.full((B, 5), 0.0125)
+    before = util.FALLBACKS.get("opf.qp_ipm_native", 0)
+    opf = BatchedOPF(net)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = opf.solve(price, pd, qd, ppv, e0, max_outer=6)
+    assert util.FALLBACKS.get("opf.qp_ipm_native", 0) > before
+    for b in range(B):
+        _check_against_reference_expressions(net, price[b], pd[b], qd[b], ppv[b], e0[b], _as_reference_solution(opf, r, b),
+                                             r["objective"][b].item())
