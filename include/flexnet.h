@@ -416,6 +416,25 @@ typedef struct {
 
 int flexnet_agent_sum_explore(const FlexAgentSumArgs* args, void* stream);
 
+/* The shared part of the centralised critic's first layer (madrl/critics/mlp_critic.py:25-26 on the input of
+ * madrl/models/maddpg.py:33-54) as ONE launch on the matrix cores, exact fp32 (csrc/linear.hip: weights stationary in
+ * registers, inputs straight from memory into MFMA operands):
+ *     out[b, 0:64] = bias + x1[b, 0:k1] W[:, c1:c1+k1]^T + x2[b, 0:k2] W[:, c2:c2+k2]^T
+ * x1 = every agent's observation ([b, n * obs_dim], row pitch ld1), x2 = every agent's action ([b, n * act_dim]; k2 = 0:
+ * none), W = fc1.weight as stored ([64, ldw], the id columns between the two blocks are skipped).  k1, k2, ld1, ld2
+ * multiples of 4, x1 / x2 / out 16-byte aligned, k1 + k2 <= 1280; otherwise FLEXNET_EUNSUPPORTED (the caller keeps the two
+ * library GEMMs).  Bit-reproducible: every output is a fixed-order sum of four matrix-core accumulations. */
+typedef struct {
+    int64_t rows;
+    int32_t k1, k2, ld1, ld2, ldw, c1, c2, pad0;
+    const float* x1;           /* [rows, ld1] */
+    const float* x2;           /* [rows, ld2] or NULL */
+    const float* w;            /* [64, ldw] */
+    const float* bias;         /* [64] */
+    float* out;                /* out [rows, 64] */
+} FlexLinear2Args;
+int flexnet_linear2(const FlexLinear2Args* args, void* stream);
+
 /* Stacked observations of a replay window out of the ROW ring (include/flexenv.h: FLEX_STEP_OBS_RING) — the gather of the
  * window IS the im2col: the replay keeps every feature row once, [slabs][N][n_agents][FLEX_ROW_FLOATS] =
  * [Pd, Qd, Ppv, V, price, E, older, 0], and output row i (global slot first_slot + i: slab (slot / N) mod slabs, environment

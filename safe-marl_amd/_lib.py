@@ -75,7 +75,7 @@ SYMBOLS = (
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_rollout_burst", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version", "flexenv_abi_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_td_stats", "flexnet_critic_td_backward",
-    "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gather_window", "flexnet_gru_backward",
+    "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gather_window", "flexnet_linear2", "flexnet_gru_backward",
     "flexopf_qp_work_doubles", "flexopf_qp_solve",
 )
 
@@ -114,6 +114,12 @@ class FlexQpArgs(C.Structure):
 
 
 FLEXOPF_INFO = 6
+
+
+class FlexLinear2Args(C.Structure):
+    """include/flexnet.h"""
+    _fields_ = [("rows", C.c_int64)] + [(k, C.c_int32) for k in ("k1", "k2", "ld1", "ld2", "ldw", "c1", "c2", "pad0")] + \
+               [(k, C.c_void_p) for k in ("x1", "x2", "w", "bias", "out")]
 
 
 class FlexBurstSafety(C.Structure):
@@ -328,6 +334,8 @@ def load():
     lib.flexenv_obs_source.restype = C.c_int
     lib.flexnet_gather_window.argtypes = [C.POINTER(FlexWindowArgs), vp]
     lib.flexnet_gather_window.restype = C.c_int
+    lib.flexnet_linear2.argtypes = [C.POINTER(FlexLinear2Args), vp]
+    lib.flexnet_linear2.restype = C.c_int
     lib.flexopf_qp_work_doubles.argtypes = [i32, i32, i32]
     lib.flexopf_qp_work_doubles.restype = C.c_int64
     lib.flexopf_qp_solve.argtypes = [C.POINTER(FlexQpArgs), vp]

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SRC = [os.path.join(CSRC, f) for f in ("flexenv.hip", "actor.hip", "critic.hip", "rollout.hip", "wgrad.hip", "lnrelu.hip",
-                                       "optim.hip", "tdloss.hip", "gru.hip", "opf.hip")]
+                                       "optim.hip", "tdloss.hip", "gru.hip", "linear.hip", "opf.hip")]
 SRC = [f for f in SRC if os.path.exists(f)]
 HEADERS = [os.path.join(CSRC, "flex_device.h"), os.path.join(CSRC, "flex_reduce.h"), os.path.join(CSRC, "flex_launch.h"),
            os.path.join(CSRC, "flex_td.h"), os.path.join(CSRC, "actor_r16.h"),

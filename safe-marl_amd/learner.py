@@ -965,8 +965,10 @@ class MADDPG(Model):
                 # value loss on replayed actions: the whole critic as one autograd node (nets._CriticReplayedFn)
                 return CriticTail.apply_replayed(obs_cols, act_cols, n, net).view(b, n, 1)
             if not th.is_grad_enabled() or not (W.requires_grad or act.requires_grad or obs.requires_grad):
-                # bootstrap targets: no graph — two GEMMs, the bias rides the first, the second accumulates
-                shared = critic_first_layer(bias, obs_cols, act_cols, W, off)
+                # bootstrap targets: no graph — one launch of csrc/linear.hip at update sizes (nets.critic_first_layer), else
+                # two library GEMMs (the bias rides the first, the second accumulates)
+                with th.no_grad():
+                    shared = critic_first_layer(bias, obs_cols, act_cols, W, off)
             else:
                 shared = wide_batch_linear(obs_cols, W_obs) + wide_batch_linear(act_cols, W_act) + bias      # [b, hid]
             if not act.requires_grad and self.args.agent_id and critic_tail_supported(net, shared):

@@ -341,12 +341,39 @@ def tall_linear(x, w, b=None):
     return F.linear(x, w, b)
 
 
+LINEAR2_MIN_ROWS = 8192      # below: the library call (a launch of this kernel loads 189 KB of weights into every CU's registers)
+LINEAR2_MAX_ROWS = 65536     # above: the library pair again — measured (tools/linear_bench.py, profiles/r05f_linear_bench.txt): 39.6 vs
+#                              40-47 us at 32 768 rows, 41.4 vs 71.4 at 36 864, but 138 vs 128 at 131 072 (both within 10 % of what the
+#                              fp32 matrix pipe sustains at the clock it holds under this load; the kernel's launch cost is lower, its slope
+#                              slightly higher)
+CRITIC_FC1_FUSED = True      # (tests switch it off to compare with the two library GEMMs)
+
+
 def critic_first_layer(bias, obs2d, act2d, W, c_act):
     """``bias + obs2d @ W[:, :no].T + act2d @ W[:, c_act:c_act + na].T`` — the shared part of the centralised critic's
-    first layer (mlp_critic.py:25-26 on maddpg.py:33-54's input) as two library GEMMs: the bias rides the first, the second
-    accumulates in place (no concatenated input, no second pass over the [b, 64] result).  A hand-written one-launch form was
-    measured in round 4 and not adopted."""
+    first layer (mlp_critic.py:25-26 on maddpg.py:33-54's input).  On the GPU at update sizes: ONE launch of
+    csrc/linear.hip (include/flexnet.h: flexnet_linear2 — weights stationary in registers, exact fp32 on the matrix cores, no
+    second pass over the [b, 64] result; round 5); otherwise the two library GEMMs of rounds 1-4."""
     no, na_ = obs2d.shape[1], act2d.shape[1]
+    ok = (CRITIC_FC1_FUSED and obs2d.is_cuda and obs2d.dtype == th.float32 and act2d.dtype == th.float32 and W.dtype == th.float32
+          and LINEAR2_MIN_ROWS <= obs2d.shape[0] <= LINEAR2_MAX_ROWS and W.shape[0] == 64 and no % 8 == 0 and na_ % 4 == 0
+          and obs2d.stride(0) % 4 == 0 and act2d.stride(0) % 4 == 0
+          and obs2d.stride(1) == 1 and act2d.stride(1) == 1 and W.stride(1) == 1 and bias.is_contiguous()
+          and not th.is_grad_enabled())
+    if ok:
+        import ctypes as C
+        from . import _lib
+        out = th.empty(obs2d.shape[0], 64, dtype=th.float32, device=obs2d.device)
+        a = _lib.FlexLinear2Args()
+        a.rows, a.k1, a.k2 = obs2d.shape[0], no, na_
+        a.ld1, a.ld2, a.ldw, a.c1, a.c2 = obs2d.stride(0), act2d.stride(0), W.stride(0), 0, int(c_act)
+        a.x1, a.x2, a.w, a.bias, a.out = obs2d.data_ptr(), act2d.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr()
+        rc = _lib.load().flexnet_linear2(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream))
+        if rc == 0:
+            return out
+        if rc != _lib.FLEXNET_EUNSUPPORTED:
+            _lib.check(rc, "flexnet_linear2")
+        note_fallback("critic_fc1", "FLEXNET_EUNSUPPORTED from flexnet_linear2")
     shared = th.addmm(bias, obs2d, W[:, :no].t())
     shared.addmm_(act2d, W[:, c_act:c_act + na_].t())
     return shared
