@@ -332,6 +332,12 @@ int flexnet_td_stats(const FlexTdLossArgs* args, void* stream);
  * gradients through the fixed-order workspace path, critic->rows >= 65 536); otherwise FLEXNET_EUNSUPPORTED and the caller
  * makes the two separate calls around a forward. */
 int flexnet_critic_td_backward(const FlexCriticTailArgs* critic, const FlexTdLossArgs* td, void* stream);
+/* The same in separately launchable phases, for callers that overlap the small launches with independent work on another
+ * stream (round 5: the statistics pass beside the first-layer GEMM, the finish beside the first layer's weight gradient):
+ * phases = 1: the statistics pass (unless td->stats_ready) and the backward kernel; 2: the finish launch (parameter
+ * gradients from the partial rows, loss, running statistics) — it needs phase 1 of the same arguments complete on its stream
+ * and nothing of flexnet_wgrad's; 3: both, = flexnet_critic_td_backward. */
+int flexnet_critic_td_backward_phases(const FlexCriticTailArgs* critic, const FlexTdLossArgs* td, int32_t phases, void* stream);
 
 /* out[0] = scale * sum(x[0 .. n)) in a FIXED order (fp64 partial sums of 64 blocks, one-wavefront finish): the scalar
  * means the losses report — policy_loss = -Q(s, pi(s)).mean() (madrl/models/maddpg.py:107), the entropy of

@@ -1410,7 +1410,9 @@ extern "C" int flexnet_critic_tail_backward(const FlexCriticTailArgs* a, void* s
 // The value loss and the critic's backward in one pass (maddpg.py:100-123 + mlp_critic.py:25-33): reward statistics, then
 // the matrix-core backward forming q, the TD error, dLoss/dq and the loss partial sums itself, the fixed-order second
 // stage, the loss / running-statistics finish, and (composed input) dz1 folded onto its sources.
-extern "C" int flexnet_critic_td_backward(const FlexCriticTailArgs* a, const FlexTdLossArgs* t, void* stream) {
+// phases: 1 = (statistics pass unless stats_ready) + the backward kernel, 2 = the finish launch, 3 = both (include/flexnet.h)
+extern "C" int flexnet_critic_td_backward_phases(const FlexCriticTailArgs* a, const FlexTdLossArgs* t, int32_t phases, void* stream) {
+    if (phases < 1 || phases > 3) return FLEXNET_EINVAL;
     const int rc = critic_check(a, true, false);
     if (rc != FLEXNET_OK) return rc;
     if (!t || t->rows < 1 || t->n_agents < 1 || !t->reward || !t->done || !t->next_q || !t->loss || !t->workspace ||
@@ -1423,19 +1425,21 @@ extern "C" int flexnet_critic_td_backward(const FlexCriticTailArgs* a, const Fle
     const int nb = critic_mfma_grid(a->rows);
     if (nb < 1 || nb > 1024 || nb > TD_SQ_MAX) return FLEXNET_EHIP;
     hipStream_t s = (hipStream_t)stream;
-    if (t->normalise && !t->stats_ready) flex_td_launch_stats(*t, s);
+    if ((phases & 1) && t->normalise && !t->stats_ready) flex_td_launch_stats(*t, s);
     // dz1 folded onto its sources: the partial rows of the id-column sums go behind the backward kernel's, so ONE launch
     // finishes both.  16-row kernel on a composed input (SM): it forms d_z_shared and those partial rows itself; otherwise
     // the fold kernel reads dz1 back.
     const int64_t dz_off = (int64_t)nb * CRITIC_WS_PITCH;
     const bool sm = a->variant_pgrad32 == 0 && a->d_z_shared && !a->z1;
     if (sm && (t->n_agents != a->n_agents || dz_off + (int64_t)nb * DZF_PITCH > a->workspace_floats)) return FLEXNET_EINVAL;
-    if (a->variant_pgrad32 == 1)  // the 32-row kernel (one wavefront per SIMD), kept as the cross-check and for A/B timing
-        hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<true>, dim3(nb), dim3(64 * CPW), 0, s, *a, *t);
-    else if (sm)
-        critic_launch_pgrad16<true>(nb, true, *a, *t, dz_off, s);
-    else
-        critic_launch_pgrad16<true>(nb, false, *a, *t, dz_off, s);
+    if (phases & 1) {
+        if (a->variant_pgrad32 == 1)  // the 32-row kernel (one wavefront per SIMD), kept as the cross-check and for A/B timing
+            hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<true>, dim3(nb), dim3(64 * CPW), 0, s, *a, *t);
+        else if (sm)
+            critic_launch_pgrad16<true>(nb, true, *a, *t, dz_off, s);
+        else
+            critic_launch_pgrad16<true>(nb, false, *a, *t, dz_off, s);
+    }
     int dz_blocks = 0;
     if (sm) {
         dz_blocks = nb;
@@ -1444,11 +1448,16 @@ extern "C" int flexnet_critic_td_backward(const FlexCriticTailArgs* a, const Fle
         dz_blocks = (samples + DZF_W - 1) / DZF_W;
         if (dz_blocks > 256) dz_blocks = 256;
         if (dz_off + (int64_t)dz_blocks * DZF_PITCH > a->workspace_floats) return FLEXNET_EINVAL;
-        hipLaunchKernelGGL(critic_dz_fold_kernel, dim3(dz_blocks), dim3(64 * DZF_W), 0, s, *a, dz_off);
+        if (phases & 1) hipLaunchKernelGGL(critic_dz_fold_kernel, dim3(dz_blocks), dim3(64 * DZF_W), 0, s, *a, dz_off);
     }
-    hipLaunchKernelGGL(critic_td_finish_kernel, dim3(CRITIC_RED_BLOCKS + (dz_blocks > 0 ? a->n_agents : 0) + 1), dim3(64 * RED_G),
-                       0, s, *a, *t, nb, dz_blocks, dz_off);
+    if (phases & 2)
+        hipLaunchKernelGGL(critic_td_finish_kernel, dim3(CRITIC_RED_BLOCKS + (dz_blocks > 0 ? a->n_agents : 0) + 1), dim3(64 * RED_G),
+                           0, s, *a, *t, nb, dz_blocks, dz_off);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}
+
+extern "C" int flexnet_critic_td_backward(const FlexCriticTailArgs* a, const FlexTdLossArgs* t, void* stream) {
+    return flexnet_critic_td_backward_phases(a, t, 3, stream);
 }
 
 static int critic_tail_backward_main(const FlexCriticTailArgs* a, void* stream) {

@@ -15,16 +15,49 @@
 #define OPT_THREADS 256
 #define OPT_BLOCKS 64              // partial sums of squares, one per block (= one per lane of the wavefront that folds them)
 
-// pass 1: this block's share of sum g^2 (fixed tree inside the block)
+// Both passes walk the tensors as ONE flat index space (thread g takes flat elements g, g + T, g + 2 T, ..., T = 16 384
+// threads) and handle four elements at a time with all their loads issued before the first is used.  As a loop over the
+// tensors with a grid-stride loop inside (rounds 1-4) the step kernel was a chain of up to sixteen dependent memory round
+// trips of 1-3 elements per thread: 12-14 us for 52 097 elements.
+#define OPT_UNROLL 4
+struct OptFlat {                       // prefix sums of numel in LDS: flat index -> (tensor, offset)
+    int64_t pre[FLEXNET_OPT_MAX_TENSORS + 1];
+};
+__device__ __forceinline__ void opt_build(const FlexClipRmspropArgs& a, OptFlat& f) {
+    if (threadIdx.x == 0) {
+        int64_t acc = 0;
+        for (int t = 0; t < a.n_tensors; ++t) { f.pre[t] = acc; acc += a.numel[t]; }
+        for (int t = a.n_tensors; t <= FLEXNET_OPT_MAX_TENSORS; ++t) f.pre[t] = acc;
+    }
+}
+__device__ __forceinline__ int opt_find(const OptFlat& f, int n_tensors, int64_t i) {
+    int t = 0;
+#pragma unroll
+    for (int k = 1; k < FLEXNET_OPT_MAX_TENSORS; ++k) t += (k < n_tensors && i >= f.pre[k]) ? 1 : 0;
+    return t;
+}
+
+// pass 1: this block's share of sum g^2 (fixed order per thread, fixed trees above it: bit-reproducible)
 __global__ __launch_bounds__(OPT_THREADS) void clip_norm_kernel(FlexClipRmspropArgs a, float* partial) {
     __shared__ float part[OPT_THREADS / 64];
+    __shared__ OptFlat f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t gid = (int64_t)blockIdx.x * OPT_THREADS + tid, stride = (int64_t)OPT_BLOCKS * OPT_THREADS;
+    opt_build(a, f);
+    __syncthreads();
+    const int64_t n = f.pre[FLEXNET_OPT_MAX_TENSORS];
+    const int64_t gid = (int64_t)blockIdx.x * OPT_THREADS + tid, T = (int64_t)OPT_BLOCKS * OPT_THREADS;
     float ss = 0.0f;
-    for (int t = 0; t < a.n_tensors; ++t) {
-        const float* g = a.grad[t];
-        const int64_t n = a.numel[t];
-        for (int64_t i = gid; i < n; i += stride) ss = fmaf(g[i], g[i], ss);
+    for (int64_t base = gid; base < n; base += OPT_UNROLL * T) {
+        float g[OPT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < OPT_UNROLL; ++u) {
+            const int64_t i = base + u * T;
+            const bool live = i < n;
+            const int t = opt_find(f, a.n_tensors, live ? i : 0);
+            g[u] = live ? a.grad[t][i - f.pre[t]] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < OPT_UNROLL; ++u) ss = fmaf(g[u], g[u], ss);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
@@ -41,8 +74,9 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_norm_kernel(FlexClipRmspropA
 // pass 2: norm from the partials, clip factor, RMSprop step on this block's share
 __global__ __launch_bounds__(OPT_THREADS) void clip_rmsprop_kernel(FlexClipRmspropArgs a, const float* partial) {
     const int tid = threadIdx.x;
-    const int64_t gid = (int64_t)blockIdx.x * OPT_THREADS + tid, stride = (int64_t)OPT_BLOCKS * OPT_THREADS;
     __shared__ float tot_s;
+    __shared__ OptFlat f;
+    opt_build(a, f);
     if (tid < 64) {                                                      // OPT_BLOCKS == 64: one partial per lane, fixed tree
         float t = partial[tid];
 #pragma unroll
@@ -50,25 +84,38 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_rmsprop_kernel(FlexClipRmspr
         if (tid == 0) tot_s = t;
     }
     __syncthreads();
+    const int64_t n = f.pre[FLEXNET_OPT_MAX_TENSORS];
+    const int64_t gid = (int64_t)blockIdx.x * OPT_THREADS + tid, T = (int64_t)OPT_BLOCKS * OPT_THREADS;
     const float norm = sqrtf(tot_s);
     if (gid == 0 && a.total_norm) *a.total_norm = norm;
     float coef = 1.0f;
     if (a.max_norm > 0.0f) coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);
     const float alpha = a.alpha, beta = 1.0f - a.alpha, eps = a.eps, lr = a.lr;
-    for (int t = 0; t < a.n_tensors; ++t) {
-        float* g = a.grad[t];
-        float* p = a.param[t];
-        float* v = a.square_avg[t];
-        const int64_t n = a.numel[t];
-        for (int64_t i = gid; i < n; i += stride) {
-            const float gi = g[i] * coef;
-            const float vi = fmaf(beta * gi, gi, alpha * v[i]);
-            g[i] = gi;
-            v[i] = vi;
-            p[i] = p[i] - lr * (gi / (sqrtf(vi) + eps));
+    for (int64_t base = gid; base < n; base += OPT_UNROLL * T) {
+        float *gp[OPT_UNROLL], *pp[OPT_UNROLL], *vp[OPT_UNROLL];
+        float g[OPT_UNROLL], v[OPT_UNROLL], pv[OPT_UNROLL];
+        bool live[OPT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < OPT_UNROLL; ++u) {
+            const int64_t i = base + u * T;
+            live[u] = i < n;
+            const int t = opt_find(f, a.n_tensors, live[u] ? i : 0);
+            const int64_t o = live[u] ? i - f.pre[t] : 0;
+            gp[u] = a.grad[t] + o; pp[u] = a.param[t] + o; vp[u] = a.square_avg[t] + o;
+            g[u] = *gp[u]; v[u] = *vp[u]; pv[u] = *pp[u];                 // (index 0 of tensor 0 for a dead slot: valid, unused)
         }
-        if (gid == 0 && a.step[t]) *a.step[t] += 1.0f;
+#pragma unroll
+        for (int u = 0; u < OPT_UNROLL; ++u) {
+            const float gi = g[u] * coef;
+            const float vi = fmaf(beta * gi, gi, alpha * v[u]);
+            if (live[u]) {
+                *gp[u] = gi;
+                *vp[u] = vi;
+                *pp[u] = pv[u] - lr * (gi / (sqrtf(vi) + eps));
+            }
+        }
     }
+    if (gid < a.n_tensors && a.step[gid]) *a.step[gid] += 1.0f;
 }
 
 extern "C" int flexnet_clip_rmsprop(const FlexClipRmspropArgs* a, void* stream) {

@@ -4,6 +4,7 @@ Training (autograd) runs through PyTorch-ROCm; the actor's INFERENCE pass — ev
 bootstrap target — is one fused HIP launch (csrc/actor.hip, include/flexnet.h) through ``fused_actor_forward``."""
 from __future__ import annotations
 
+import os
 import torch as th
 import torch.nn as nn
 import torch.nn.functional as F
@@ -1088,6 +1089,25 @@ class _CriticReplayedTwinFn(th.autograd.Function):
         return (None, None, None, dW, d_bias, (d_g if has_ln else None), (d_b if has_ln else None), d_w2, d_b2, d_w3, d_b3, None)
 
 
+# Measured and NOT adopted (round 5; VERDICT r04 item 1b asked for the small launches to be folded into their neighbours): the
+# value sub-update's small launches BESIDE its matrix work on a second stream — the reward-statistics pass (6.7 us, needs only
+# the batch's rewards) while the first-layer product runs, the finish launch (5.4 us: parameter gradients from the partial
+# rows, loss, running statistics) while the first layer's weight gradient runs; neither needs the other's output.  Under
+# HIP-graph capture the fork and join become graph edges, and every cross-branch edge of a replayed graph costs 4-9 us of idle
+# time on this runtime: kernel time 396 -> 370 us per value sub-update, span 404 -> 401 (profiles/r05g4_update_timeline.txt).
+# One stream is the default; FLEX_TD_FORK=1 keeps the two-stream form reachable (same kernels, same bits:
+# tests/test_critic_gpu.py).
+TD_FORK = os.environ.get("FLEX_TD_FORK", "0") == "1"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device)
+    if s is None:
+        s = _SIDE_STREAMS[device] = th.cuda.Stream(device=device)
+    return s
+
+
 class _CriticTdLossFn(th.autograd.Function):
     """mean((BatchNorm(reward) + gamma (1 - done) Q'(s', pi'(s')) - Q(s, a))^2) for the shared-parameter critic on replayed
     inputs — maddpg.py:100-123 over maddpg.py:33-76 + mlp_critic.py:25-33 — with the critic's backward run IN the forward
@@ -1106,7 +1126,20 @@ class _CriticTdLossFn(th.autograd.Function):
         n = n_agents
         no, na_ = obs2d.shape[1], act2d.shape[1]
         dev = obs2d.device
+        nq, r, d = next_q.reshape(-1, n).contiguous(), reward.contiguous(), done.reshape(-1).contiguous()
+        t = _td_args(r, d, nq, gamma, bn, update_stats=True)
+        _td_sync_stats(t, _TD_WS[r.device], bn)
+        fork = TD_FORK
+        main = th.cuda.current_stream(dev)
+        side = _side_stream(dev) if fork else None
+        if fork and t.normalise and not t.stats_ready:
+            # the statistics pass beside the first-layer product (it needs the rewards only)
+            side.wait_stream(main)
+            _lib.check(lib.flexnet_td_stats(C.byref(t), C.c_void_p(side.cuda_stream)), "flexnet_td_stats")
+            t.stats_ready = 1
         shared = critic_first_layer(bias, obs2d, act2d, W, no + n)
+        if fork:
+            main.wait_stream(side)
         rows = shared.shape[0] * n
         dz1 = th.empty(rows, 64, dtype=th.float32, device=dev)
         grads = th.empty(64 * 64 + 64 * 4 + 1, dtype=th.float32, device=dev)
@@ -1125,14 +1158,20 @@ class _CriticTdLossFn(th.autograd.Function):
         dW = th.empty_like(W)
         args.d_z_shared, args.d_z_id = d_shared.data_ptr(), dW[:, no:no + n].data_ptr()
         args.d_z_id_agent_stride, args.d_z_id_unit_stride = 1, W.shape[1]
-        nq, r, d = next_q.reshape(-1, n).contiguous(), reward.contiguous(), done.reshape(-1).contiguous()
         loss = th.empty((), dtype=th.float32, device=dev)
-        t = _td_args(r, d, nq, gamma, bn, update_stats=True)
         t.loss = loss.data_ptr()
-        _td_sync_stats(t, _TD_WS[r.device], bn)
-        _lib.check(lib.flexnet_critic_td_backward(C.byref(args), C.byref(t), stream), "flexnet_critic_td_backward")
         d_bias = th.empty(64, dtype=th.float32, device=dev)
-        tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias, x2=act2d, out2=dW[:, no + n:no + n + na_])
+        sm = args.variant_pgrad32 == 0          # (the 16-row kernel writes d_z_shared itself: the finish does not feed the weight gradient)
+        if fork and sm:
+            _lib.check(lib.flexnet_critic_td_backward_phases(C.byref(args), C.byref(t), 1, stream), "flexnet_critic_td_backward")
+            side.wait_stream(main)
+            _lib.check(lib.flexnet_critic_td_backward_phases(C.byref(args), C.byref(t), 2, C.c_void_p(side.cuda_stream)),
+                       "flexnet_critic_td_backward")
+            tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias, x2=act2d, out2=dW[:, no + n:no + n + na_])
+            main.wait_stream(side)
+        else:
+            _lib.check(lib.flexnet_critic_td_backward(C.byref(args), C.byref(t), stream), "flexnet_critic_td_backward")
+            tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias, x2=act2d, out2=dW[:, no + n:no + n + na_])
         if W.shape[1] > no + n + na_:
             dW[:, no + n + na_:] = 0.0
         has_ln = ln_w is not None

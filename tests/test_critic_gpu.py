@@ -303,6 +303,21 @@ def test_value_loss_and_critic_backward_in_one_pass(b, norm):
     loss = m._critic_td_loss(obs, act, nq, rew, done, bn)
     for a, e in zip(torch.autograd.grad(loss, params, grad_outputs=torch.full((), 0.5, device="cuda")), g1):
         assert torch.allclose(a, 0.5 * e, rtol=1e-6, atol=0)
+    # the two-stream form (nets.TD_FORK: statistics pass and finish launch beside the matrix work) runs the same kernels on the
+    # same data: the same bits — loss, every gradient, the running statistics
+    bn = nn.BatchNorm1d(n).cuda().train() if norm else None
+    nets.TD_FORK = True
+    try:
+        lf = m._critic_td_loss(obs, act, nq, rew, done, bn)
+        gf = torch.autograd.grad(lf, params, grad_outputs=unit_seed("cuda"))
+        torch.cuda.synchronize()
+    finally:
+        nets.TD_FORK = False
+    assert torch.equal(lf, l1)
+    for a, e in zip(gf, g1):
+        assert torch.equal(a, e)
+    if norm:
+        assert torch.equal(bn.running_mean, s1[0]) and torch.equal(bn.running_var, s1[1])
     # below the matrix-core batch size the node declines and the sequence runs
     assert m._critic_td_loss(obs[:1000], act[:1000], nq[:1000], rew[:1000], done[:1000], bn) is None
 
