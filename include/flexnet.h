@@ -231,6 +231,10 @@ typedef struct {
     int64_t ldb2;              /* row pitch of b2 */
     int32_t n2;
     int32_t ldc2;              /* row pitch of c2; 0 = n2 */
+    /* optional (NULL: none): B's rows are read in place from a larger row store — the replay's stacked-observation ring —
+     * starting at row *b_row_cell (device int64, read by the kernel: a replayed HIP graph follows the sampled window without
+     * a copy of it); `b` is then the store's base, rows *b_row_cell .. + k - 1 must lie inside it. */
+    const int64_t* b_row_cell;
 } FlexWgradArgs;
 
 #define FLEXNET_WGRAD_WS_FLOATS (520 * 12288 + 520 * 192)
@@ -438,6 +442,8 @@ typedef struct {
     const float* w;            /* [64, ldw] */
     const float* bias;         /* [64] */
     float* out;                /* out [rows, 64] */
+    const int64_t* x1_row_cell; /* optional (NULL: none): as FlexWgradArgs.b_row_cell — x1 is the base of a row store, the rows
+                                  of this call start at row *x1_row_cell (device int64) */
 } FlexLinear2Args;
 int flexnet_linear2(const FlexLinear2Args* args, void* stream);
 

@@ -119,7 +119,7 @@ FLEXOPF_INFO = 6
 class FlexLinear2Args(C.Structure):
     """include/flexnet.h"""
     _fields_ = [("rows", C.c_int64)] + [(k, C.c_int32) for k in ("k1", "k2", "ld1", "ld2", "ldw", "c1", "c2", "pad0")] + \
-               [(k, C.c_void_p) for k in ("x1", "x2", "w", "bias", "out")]
+               [(k, C.c_void_p) for k in ("x1", "x2", "w", "bias", "out", "x1_row_cell")]
 
 
 class FlexBurstSafety(C.Structure):
@@ -161,7 +161,7 @@ class FlexWgradArgs(C.Structure):
                 ("m", C.c_int32), ("n", C.c_int32), ("accumulate", C.c_int32), ("ldc", C.c_int32),
                 ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("workspace", C.c_void_p),
                 ("colsum", C.c_void_p), ("b2", C.c_void_p), ("c2", C.c_void_p), ("ldb2", C.c_int64), ("n2", C.c_int32),
-                ("ldc2", C.c_int32)]
+                ("ldc2", C.c_int32), ("b_row_cell", C.c_void_p)]
 
 
 FLEXNET_WGRAD_WS_FLOATS = 520 * 12288 + 520 * 192

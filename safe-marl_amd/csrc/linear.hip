@@ -92,10 +92,11 @@ __global__ __launch_bounds__(64 * L2_WAVES, 1) void linear2_wreg_kernel(Linear2K
     l2_f4 xb[R][2];
     const int kw = __builtin_amdgcn_readfirstlane(wave * (32 * SS));       // this wavefront's first input column (scalar)
     L2Rows rw;
+    const float* const x1 = a.x1 + (a.x1_row_cell ? *a.x1_row_cell * a.ld1 : 0);      // (in-place window of a row store)
     auto set_rows = [&](int tile) {
         int64_t row = (int64_t)tile * 32 + rb;
         if (row >= a.rows) row = a.rows - 1;
-        rw.obs = a.x1 + row * a.ld1;
+        rw.obs = x1 + row * a.ld1;
         rw.obs_k = rw.obs + kk;
         rw.act = a.x2 ? a.x2 + row * a.ld2 : rw.obs;
     };

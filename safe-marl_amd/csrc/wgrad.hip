@@ -47,6 +47,7 @@ struct WgradK {
     float* c2;
     int64_t ldb2, b2_floats;
     int32_t n2, ldc2;
+    const int64_t* b_cell;           // B's first row inside a larger row store (device cell), or NULL
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const float* base, int64_t floats) {
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
     if (ea < fa) fa = ea;
     if (eb < fb) fb = eb;
     const __amdgpu_buffer_rsrc_t ra = wg_rsrc(p.a + k0 * p.lda, fa);
-    const __amdgpu_buffer_rsrc_t rb = wg_rsrc(p.b + k0 * p.ldb + n0, fb);
+    const float* const pb = p.b + (p.b_cell ? *p.b_cell * p.ldb : 0);
+    const __amdgpu_buffer_rsrc_t rb = wg_rsrc(pb + k0 * p.ldb + n0, fb);
     // TWO: a lane's NT columns lie in b (virtual column < n) or in b2 (n is a multiple of NT: never astride); it loads
     // from both views every step with the offset of the other one out of range (-> zeros) and keeps its own
     int64_t fb2 = 0;
@@ -332,6 +334,7 @@ extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) {
     p.b2 = two ? a->b2 : nullptr; p.c2 = two ? a->c2 : nullptr; p.ldb2 = two ? a->ldb2 : 0;
     p.b2_floats = two && a->k > 0 ? (a->k - 1) * a->ldb2 + a->n2 : 0;
     p.n2 = two ? a->n2 : 0; p.ldc2 = two ? (a->ldc2 > 0 ? a->ldc2 : a->n2) : 0;
+    p.b_cell = a->b_row_cell;
     hipStream_t s = (hipStream_t)stream;
     switch (mt * 10 + nt) {
         case 11: return wgrad_launch<1, 1>(p, chunks, s);

@@ -1100,6 +1100,26 @@ def _maddpg_critic_policy_loss(self, state, actions_pol):
     return critic_policy_loss(obs_cols, actions_pol, net, sign=-1.0)
 
 
+def _maddpg_reads_state_in_place(self, bs):
+    """True iff a value sub-update on filed bootstrap values ("value_cached") touches ``batch.state`` ONLY through
+    nets._CriticTdLossFn — whose first layer (flexnet_linear2) and weight gradient (flexnet_wgrad) can read the window in place
+    from the replay's stacked-observation ring (nets.RING_VIEWS; trainer._static_batch then hands a NaN placeholder instead of
+    a gathered copy).  The conditions are those of _maddpg_critic_td_loss / nets.critic_td_loss_supported that do not depend on
+    the batch's values; a subclass with its own get_loss / value / critic input layout (MATD3, IDDPG) answers False."""
+    from .nets import CRITIC_TD_MIN_ROWS, CRITIC_VARIANT
+    import safe_marl_amd.nets as _nets
+    n = self.n_
+    net = self.value_dicts[0]
+    fc1 = getattr(net, "fc1", None)
+    return bool(type(self).get_loss is MADDPG.get_loss and type(self)._critic_td_loss is _maddpg_critic_td_loss
+                and type(self).value is MADDPG.value and self.args.shared_params and self.args.agent_id
+                and self.fused_td_backward and self.fused_inference and _nets.CRITIC_FC1_FUSED
+                and bs * n >= CRITIC_TD_MIN_ROWS and CRITIC_VARIANT == 0 and _nets.CRITIC_PGRAD32 == 0
+                and (n * self.obs_dim) % 8 == 0 and (n * self.act_dim) % 4 == 0 and n * (self.obs_dim + self.act_dim) <= 768
+                and fc1 is not None and fc1.weight.shape == (64, n * (self.obs_dim + self.act_dim) + n))
+
+
+MADDPG.reads_state_in_place = _maddpg_reads_state_in_place
 MADDPG._critic_td_loss = _maddpg_critic_td_loss
 MADDPG._critic_policy_loss = _maddpg_critic_policy_loss
 MADDPG.fused_eval = True                  # (tests switch it off to compare the evaluation with the tensor composition)

@@ -297,6 +297,11 @@ def tall_wgrad(dy, x, out=None, accumulate=False, colsum=None, x2=None, out2=Non
     a.k, a.m, a.n = k, m, n
     a.lda, a.ldb = (dy.stride(0), x.stride(0)) if k > 1 else (m, n)
     a.a, a.b, a.c = dy.data_ptr(), x.data_ptr(), out.data_ptr()
+    rv = ring_view_of(x)
+    if rv is not None:           # in place from the replay's stacked-observation ring (RING_VIEWS)
+        if x.stride(0) != rv[0].shape[1] or k <= 1:
+            raise RuntimeError("tall_wgrad: a placeholder of the stacked-observation ring must be read as whole rows")
+        a.b, a.b_row_cell = rv[0].data_ptr(), rv[1].data_ptr()
     a.workspace, a.workspace_floats, a.accumulate = ws.data_ptr(), ws.numel(), int(accumulate)
     a.ldc = out.stride(0) if m > 1 else n
     if colsum is not None:          # [m] <- sum_k dy[k, :], the bias gradient, from the same pass over dy
@@ -342,6 +347,31 @@ def tall_linear(x, w, b=None):
     return F.linear(x, w, b)
 
 
+# In-place windows of the replay's stacked-observation ring (replay_buffer.DeviceReplayBuffer.enable_stacked_ring; round 5).
+# A captured sub-update needs static addresses, so until round 4 every sub-update began by gathering its window's stacked
+# observations into a static batch (flexnet_gather_window: 23 us at 32 768 samples, 79 us at 131 072 — a tenth of an update event
+# at the reference's sample reuse, each observation expanded ~6 times).  With the ring kept stacked (every slab expanded ONCE,
+# when it enters the replay) the window is a contiguous run of ring rows, and the kernels that read observations take the ring's
+# base plus a DEVICE cell holding the window's first row (FlexLinear2Args.x1_row_cell, FlexWgradArgs.b_row_cell): the graph is
+# static, the window moves.  The static batch's `state` tensor is then a placeholder full of NaN, registered here by its
+# data pointer: a consumer that does not know the ring reads NaN, not yesterday's observations.
+RING_VIEWS = {}              # placeholder data_ptr -> (ring tensor [rows, width], device int64 cell)
+
+
+def ring_view_of(t):
+    """(ring, cell) if ``t`` is (a whole-row view of) a registered placeholder, else None."""
+    if not RING_VIEWS or not t.is_cuda:
+        return None
+    key = t.data_ptr()
+    rv = RING_VIEWS.get(key)
+    if rv is None:
+        return None
+    if rv[2]() is None:          # the placeholder is gone (its trainer was dropped): the address may be anybody's now
+        del RING_VIEWS[key]
+        return None
+    return rv
+
+
 LINEAR2_MIN_ROWS = 8192      # below: the library call (a launch of this kernel loads 189 KB of weights into every CU's registers)
 LINEAR2_MAX_ROWS = 65536     # above: the library pair again — measured (tools/linear_bench.py, profiles/r05f_linear_bench.txt): 39.6 vs
 #                              40-47 us at 32 768 rows, 41.4 vs 71.4 at 36 864, but 138 vs 128 at 131 072 (both within 10 % of what the
@@ -356,8 +386,11 @@ def critic_first_layer(bias, obs2d, act2d, W, c_act):
     csrc/linear.hip (include/flexnet.h: flexnet_linear2 — weights stationary in registers, exact fp32 on the matrix cores, no
     second pass over the [b, 64] result; round 5); otherwise the two library GEMMs of rounds 1-4."""
     no, na_ = obs2d.shape[1], act2d.shape[1]
+    rv = ring_view_of(obs2d)
+    if rv is not None and (th.is_grad_enabled() or obs2d.stride(0) != no or rv[0].shape[1] != no):
+        raise RuntimeError("critic_first_layer: a placeholder of the stacked-observation ring reached a path that cannot read it in place")
     ok = (CRITIC_FC1_FUSED and obs2d.is_cuda and obs2d.dtype == th.float32 and act2d.dtype == th.float32 and W.dtype == th.float32
-          and LINEAR2_MIN_ROWS <= obs2d.shape[0] <= LINEAR2_MAX_ROWS and W.shape[0] == 64 and no % 8 == 0 and na_ % 4 == 0
+          and (rv is not None or LINEAR2_MIN_ROWS <= obs2d.shape[0] <= LINEAR2_MAX_ROWS) and W.shape[0] == 64 and no % 8 == 0 and na_ % 4 == 0
           and obs2d.stride(0) % 4 == 0 and act2d.stride(0) % 4 == 0
           and obs2d.stride(1) == 1 and act2d.stride(1) == 1 and W.stride(1) == 1 and bias.is_contiguous()
           and not th.is_grad_enabled())
@@ -369,12 +402,18 @@ def critic_first_layer(bias, obs2d, act2d, W, c_act):
         a.rows, a.k1, a.k2 = obs2d.shape[0], no, na_
         a.ld1, a.ld2, a.ldw, a.c1, a.c2 = obs2d.stride(0), act2d.stride(0), W.stride(0), 0, int(c_act)
         a.x1, a.x2, a.w, a.bias, a.out = obs2d.data_ptr(), act2d.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr()
+        if rv is not None:
+            a.x1, a.x1_row_cell = rv[0].data_ptr(), rv[1].data_ptr()
         rc = _lib.load().flexnet_linear2(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream))
         if rc == 0:
             return out
+        if rv is not None:
+            raise RuntimeError(f"flexnet_linear2 declined an in-place window of the stacked-observation ring (code {rc})")
         if rc != _lib.FLEXNET_EUNSUPPORTED:
             _lib.check(rc, "flexnet_linear2")
         note_fallback("critic_fc1", "FLEXNET_EUNSUPPORTED from flexnet_linear2")
+    if rv is not None:
+        raise RuntimeError("critic_first_layer: an in-place window of the stacked-observation ring needs the fused kernel")
     shared = th.addmm(bias, obs2d, W[:, :no].t())
     shared.addmm_(act2d, W[:, c_act:c_act + na_].t())
     return shared

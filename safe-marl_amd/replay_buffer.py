@@ -119,6 +119,7 @@ class DeviceReplayBuffer:
         """Back to the field-by-field mode (the graph rollout could not be captured): the rings and their bookkeeping go,
         ``add_batch`` allocates its own store on the next call.  Transitions the ring held are dropped."""
         self.obs_ring = self.row_ring = self.hid_ring = self.small_ring = self.nv_ring = self.cursor = None
+        self.stack_ring = None
         self.k = self.first = 0
         self.gaps = []
         self.consts, self.const_shapes = {}, {}
@@ -245,6 +246,52 @@ class DeviceReplayBuffer:
                    "flexnet_gather_window")
         return out
 
+    # -- stacked-observation ring (row mode, round 5): every slab's stacked observations formed ONCE ------------------------
+    def enable_stacked_ring(self, max_window_rows):
+        """Keep, next to the row ring, the stacked observations [n_agents * obs_dim] of every slab — ``stack_ring`` [slabs * N
+        + tail, n * obs] — so that a sampled window is a contiguous run of its rows and captured sub-updates read it IN PLACE
+        (nets.RING_VIEWS) instead of gathering it into a static batch first.  A slab is expanded once, when it has entered the
+        replay (``expand_stacked``: flexnet_gather_window into the ring); at the reference's sample reuse the per-window gather
+        expanded each observation ~6 times.  The first ``tail`` rows are mirrored behind the ring's end, so a window of up to
+        ``max_window_rows`` rows that starts anywhere in the ring never wraps.  2 880 B per transition: 2.5 GB for the bench's
+        ring of 192 + 23 slabs of 4 096 environments."""
+        if not self.row_mode:
+            raise RuntimeError("the stacked-observation ring lives next to the ROW ring (row mode)")
+        N = self.n_envs
+        tail = -(-int(max_window_rows) // N) * N
+        if getattr(self, "stack_ring", None) is not None:
+            if self.stack_tail >= tail:
+                return
+            raise ValueError("the stacked ring exists with a shorter mirrored tail (placeholders registered against it would go stale)")
+        if tail > self.slabs * N:
+            raise ValueError("window longer than the ring")
+        self.stack_rows = self.slabs * N
+        self.stack_tail = tail
+        self.stack_ring = th.zeros(self.stack_rows + tail, self.n_agents * self.obs_dim, dtype=th.float32, device=self.device)
+        self.stacked_next = None         # slab counter the next expansion starts at (None: the oldest transition's)
+
+    def expand_stacked(self):
+        """Bring the stacked ring up to date: the slabs filed since the last call (the slab at the cursor included — it holds
+        the newest observation, the next_state of the last complete transition)."""
+        if getattr(self, "stack_ring", None) is None:
+            return
+        N = self.n_envs
+        lo = self.first if self.stacked_next is None else max(self.stacked_next, self.first)
+        hi = self.k
+        if hi - lo + 1 > self.slabs:
+            lo = hi - self.slabs + 1
+        tail_slabs = self.stack_tail // N
+        c = lo
+        while c <= hi:
+            p = c % self.slabs
+            run = min(hi - c + 1, self.slabs - p)
+            self.stacked_obs(c * N, run * N, out=self.stack_ring[p * N:(p + run) * N])
+            if p < tail_slabs:                            # the ring's head, mirrored behind its end
+                q = min(run, tail_slabs - p)
+                self.stack_ring[self.stack_rows + p * N:self.stack_rows + (p + q) * N].copy_(self.stack_ring[p * N:(p + q) * N])
+            c += run
+        self.stacked_next = hi + 1
+
     @property
     def obs_source_ring(self):
         """Name of the ring observations are gathered from: "row_ring" (row mode) or "obs_ring"."""
@@ -276,6 +323,13 @@ class DeviceReplayBuffer:
         from . import _lib
         jobs = []
         for ring_name, col0, width, row_off, rows, dst in plan:
+            if ring_name == "stack_ring":                # read in place (enable_stacked_ring): only the window's first row moves
+                cell, _placeholder = dst
+                self.expand_stacked()
+                if rows > self.stack_tail:
+                    raise ValueError("window longer than the stacked ring's mirrored tail")
+                cell.fill_((slot + row_off) % self.stack_rows)
+                continue
             if ring_name == "row_ring":                  # stacked observations out of the row ring: a launch of its own kind
                 self.stacked_obs(slot + row_off, rows, out=dst)
                 continue

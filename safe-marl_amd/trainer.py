@@ -366,6 +366,21 @@ class PGTrainer(object):
         def block(rows, width):
             return th.zeros(rows, width, dtype=th.float32, device=dev)
 
+        in_place = (which == "value_cached" and getattr(buf, "row_mode", False) and dev.type == "cuda"
+                    and os.environ.get("FLEX_STACKED_RING", "1") != "0" and "state" in names and "next_state" not in names
+                    and getattr(self.behaviour_net, "reads_state_in_place", lambda _bs: False)(bs))
+        if in_place:
+            # the value sub-update on filed bootstrap values reads its observations IN PLACE from the replay's stacked ring
+            # (nets.RING_VIEWS): no gather of the window, `state` is a NaN placeholder that only ring-aware kernels may touch
+            import weakref
+            from . import nets
+            w = buf.n_agents * buf.obs_dim
+            buf.enable_stacked_ring(bs + N)
+            ph = th.full((bs, w), float("nan"), dtype=th.float32, device=dev)
+            cell = th.zeros(1, dtype=th.int64, device=dev)
+            nets.RING_VIEWS[ph.data_ptr()] = (buf.stack_ring, cell, weakref.ref(ph))
+            plan.append(("stack_ring", 0, None, 0, bs, (cell, ph)))
+            fields["state"] = ph.view((bs,) + buf.field_shape("state"))
         if "state" in names and "next_state" in names:
             w = buf.n_agents * buf.obs_dim
             win = block(bs + N, w)
@@ -478,6 +493,12 @@ class PGTrainer(object):
                 for _ in range(2):                        # warm-up off the capturing stream (allocator, rocBLAS handles)
                     self._sub_update(which, out, batch, fresh_leaves=True, flat=flat)
             th.cuda.current_stream().wait_stream(side)
+            if any(p[0] == "stack_ring" for p in plan):
+                # `state` is a NaN placeholder read in place by ring-aware kernels only (nets.RING_VIEWS): a warm-up loss that is
+                # not finite means some other consumer touched it — refuse the capture rather than train on NaN
+                for v in out.values():
+                    if th.is_tensor(v) and v.numel() == 1 and not bool(th.isfinite(v).all()):
+                        raise RuntimeError("a consumer that cannot read the stacked-observation ring in place touched the placeholder")
             if self.world > 1:
                 th.cuda.synchronize()                     # no collective of the warm-up is outstanding when capture begins
             graph = th.cuda.CUDAGraph()

@@ -252,3 +252,31 @@ def test_hip_power_flow_against_the_reference_nlp_statement(net, base_loads):
             x = np.concatenate([vs[m.free_v], pl, ql, isq, [ps, qs]])
             assert np.abs(m.constraints(x)).max() < 1e-11, (solver, name, np.abs(m.constraints(x)).max())
             assert (x >= m.lb).all()
+
+
+def test_sweep_extrapolation_changes_the_count_not_the_solution(net):
+    """csrc/flex_device.h pf_sweep, round 5: the two-sweep extrapolation of the dominant error mode (calibrated at
+    flexenv_create from the series) removes sweeps; the fixed point is the same — the Newton verification confirms both at
+    1e-12 — so a whole warm-started episode with and without it agrees to 1e-12 in V and rewards, with fewer sweeps."""
+    import torch
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    s = make_synthetic_series(net, n_days=20)
+    n = 512
+    envs = [VecFlexProvisionEnv({}, n, series=s, net=net, seed=5, warm_start=True, sweep_accel=on) for on in (True, False)]
+    for e in envs:
+        e.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    sweeps = [0.0, 0.0]
+    worst_v = worst_r = 0.0
+    for t in range(60):
+        acts = (0.5 + 0.5 * torch.rand(n, 5, 4, device="cuda", generator=g)).float()
+        out = [e.step(acts, obs_rows=True, auto_reset=True) for e in envs]
+        worst_r = max(worst_r, (out[0][0] - out[1][0]).abs().max().item())
+        worst_v = max(worst_v, (envs[0].peek("V") - envs[1].peek("V")).abs().max().item())
+        assert torch.equal(out[0][1], out[1][1])
+        for k, e in enumerate(envs):
+            sweeps[k] += e.peek("PF_SWEEPS").float().mean().item() / 60
+            assert e.peek("PF_ITERS").sum().item() == 0 and e.failed.sum().item() == 0
+    assert worst_v < 1e-12 and worst_r < 1e-12, (worst_v, worst_r)
+    assert sweeps[0] < sweeps[1] - 0.5, sweeps

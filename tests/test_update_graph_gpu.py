@@ -317,3 +317,51 @@ def test_a_failed_capture_leaves_weights_optimiser_state_and_statistics_untouche
     torch.cuda.synchronize()
     assert np.isfinite(float(st["mean_train_value_loss"]))
     assert any(not torch.equal(v, before[k]) for k, v in net.state_dict().items() if k.startswith("value_dicts."))
+
+
+def test_value_sub_updates_read_their_window_in_place_from_the_stacked_ring():
+    """Round 5: with the bootstrap values filed per event, the value sub-update's observations are read IN
+    PLACE from the replay's stacked-observation ring (replay_buffer.enable_stacked_ring: every slab expanded once; the first
+    layer's flexnet_linear2 and its flexnet_wgrad take the ring's base and a device cell with the window's first row) instead
+    of being gathered into a static batch per sub-update.  Same kernels on the same values: three events — the ring wrapped,
+    windows astride its seam — leave weights, optimiser state and statistics bit-identical to the gathering form
+    (FLEX_STACKED_RING=0), and the in-place form really ran: a NaN placeholder stands where the gathered copy used to be, and
+    no gather_window launch is issued for the value sub-updates."""
+    import os
+    from safe_marl_amd import nets
+    a = _trainer(True, 1024)
+    os.environ["FLEX_STACKED_RING"] = "0"
+    try:
+        b = _trainer(True, 1024)
+        for tr in (a, b):
+            for _ in range(2):
+                tr.behaviour_net.train_process({}, tr)
+            tr.batch_scale = 1024
+        for ev in range(3):
+            stats = []
+            for tr, flag in ((a, "1"), (b, "0")):
+                os.environ["FLEX_STACKED_RING"] = flag
+                np.random.seed(90 + ev)
+                st = {}
+                tr.replay_event(st, 10, 1)
+                torch.cuda.synchronize()
+                stats.append({k: float(v) for k, v in st.items()})
+            assert stats[0] == stats[1], (ev, stats)
+            for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
+                assert torch.equal(va, vb), (ev, ka)
+    finally:
+        os.environ.pop("FLEX_STACKED_RING", None)
+    assert a.bootstrap_cached_events == 3 and b.bootstrap_cached_events == 3
+    ga, gb = a._cached_graphs[("value_cached", 0)], b._cached_graphs[("value_cached", 0)]
+    assert [p[0] for p in ga["plan"]].count("stack_ring") == 1 and "row_ring" not in [p[0] for p in ga["plan"]]
+    assert "row_ring" in [p[0] for p in gb["plan"]] and "stack_ring" not in [p[0] for p in gb["plan"]]
+    assert torch.isnan(ga["batch"].state).all()                       # the placeholder, never written
+    assert a.replay_buffer.stack_ring is not None and getattr(b.replay_buffer, "stack_ring", None) is None
+    # the ring holds what a gather of the same window forms
+    buf = a.replay_buffer
+    buf.expand_stacked()
+    slot = buf.sample_slot(4096)
+    want = buf.stacked_obs(slot, 4096)
+    p = slot % buf.stack_rows
+    assert torch.equal(buf.stack_ring[p:p + 4096], want)
+    assert nets.ring_view_of(ga["batch"].state.reshape(ga["bs"], -1)) is not None
