@@ -592,7 +592,9 @@ extern "C" int flexnet_actor_forward(const FlexActorArgs* a, void* stream) {
         if ((int64_t)a->rows * a->obs_row_stride * 4 >= 0x7ffffff0ll) return FLEXNET_EUNSUPPORTED;
     }
     if ((int64_t)a->rows * a->obs_dim * 4 >= 0x7ffffff0ll) return FLEXNET_EUNSUPPORTED;   // observations are addressed with 32-bit byte offsets
-    if (a->cursor && ((!a->obs_pushed && a->obs_slab_stride < (int64_t)a->rows * a->obs_dim) || a->hid_slab_stride < 0)) return FLEXNET_EINVAL;
+    // (obs_slab_stride: one launch's rows for the rollout's slab ring; a stride of ONE sample row — n_agents * obs_dim — makes
+    //  the cursor cell the first row of an in-place window of the replay's stacked-observation ring: nets.RING_VIEWS)
+    if (a->cursor && ((!a->obs_pushed && a->obs_slab_stride < (int64_t)a->n_agents * a->obs_dim) || a->hid_slab_stride < 0)) return FLEXNET_EINVAL;
     if (a->cursor_out && (!a->cursor || a->variant == 1 || a->cursor_out == a->cursor)) return FLEXNET_EINVAL;
     {
         const int saves = (a->save_z1 != nullptr) + (a->save_x != nullptr) + (a->save_r != nullptr) + (a->save_z != nullptr) +

@@ -1119,7 +1119,29 @@ def _maddpg_reads_state_in_place(self, bs):
                 and fc1 is not None and fc1.weight.shape == (64, n * (self.obs_dim + self.act_dim) + n))
 
 
+def _maddpg_reads_next_state_in_place(self, bs):
+    """The same question for the graph that files the bootstrap values (MADDPG.bootstrap_values on "next_state", "hid"): the
+    policy's fused inference pass (nets.fused_actor_forward) and the target critic's first layer without a graph
+    (nets.critic_first_layer) are the only readers of ``next_state``."""
+    import safe_marl_amd.nets as _nets
+    n = self.n_
+    tgt = getattr(self, "target_net", None)
+    if tgt is None or type(self).bootstrap_values is not MADDPG.bootstrap_values or type(self).policy is not Model.policy:
+        return False
+    agent, net = self.policy_dicts[0], tgt.value_dicts[0]
+    fc1 = getattr(net, "fc1", None)
+    a = agent.args
+    return bool(type(self).get_actions is MADDPG.get_actions and type(tgt).value is MADDPG.value and self.args.shared_params
+                and self.args.agent_id and self.fused_inference and tgt.fused_inference and _nets.CRITIC_FC1_FUSED
+                and isinstance(agent, _nets.RNNAgent) and a.hid_size == 64 and a.hid_activation == "relu"
+                and self.obs_dim <= 144 and n <= 8 and a.action_dim <= 8
+                and (n * self.obs_dim) % 8 == 0 and (n * self.act_dim) % 4 == 0 and n * (self.obs_dim + self.act_dim) <= 768
+                and fc1 is not None and fc1.weight.shape == (64, n * (self.obs_dim + self.act_dim) + n)
+                and bs * n >= 65536)
+
+
 MADDPG.reads_state_in_place = _maddpg_reads_state_in_place
+MADDPG.reads_next_state_in_place = _maddpg_reads_next_state_in_place
 MADDPG._critic_td_loss = _maddpg_critic_td_loss
 MADDPG._critic_policy_loss = _maddpg_critic_policy_loss
 MADDPG.fused_eval = True                  # (tests switch it off to compare the evaluation with the tensor composition)

@@ -198,7 +198,16 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
         return None
     lib = _lib.load()
     rows = obs.shape[0] * obs.shape[1]
+    obs_dim = obs.shape[-1]
     obs = obs.contiguous()
+    rv = ring_view_of(obs)
+    if rv is not None:
+        # a placeholder of the replay's stacked-observation ring (RING_VIEWS): the observations are read in place — the ring's
+        # base plus, through the kernel's cursor mechanism, the window's first row from the device cell
+        if ring_cursor is not None or obs_source is not None or rv[0].shape[1] != obs.shape[1] * obs.shape[2]:
+            raise RuntimeError("fused_actor_forward: an in-place window of the stacked-observation ring cannot be combined with a ring cursor")
+        ring_cursor, obs_slab_stride, hid_slab_stride, cursor_out = rv[1], rv[0].shape[1], 0, None
+        obs = rv[0]
     hidden = hidden.reshape(rows, 64).to(th.float32).contiguous()
     means = (out or {}).get("means")
     if means is None:
@@ -207,7 +216,7 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
     if hid_out is None:
         hid_out = th.empty(rows, 64, dtype=th.float32, device=obs.device)
     args = _lib.FlexActorArgs()
-    args.rows, args.n_agents, args.obs_dim, args.act_dim = rows, n_agents, obs.shape[-1], a.action_dim
+    args.rows, args.n_agents, args.obs_dim, args.act_dim = rows, n_agents, obs_dim, a.action_dim
     args.agent_id, args.layernorm, args.ln_eps = int(bool(agent_id)), int(bool(a.layernorm)), 1e-5
     args.variant = int(ACTOR_VARIANT if variant is None else variant)
     action = env_action = None

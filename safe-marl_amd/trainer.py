@@ -381,7 +381,36 @@ class PGTrainer(object):
             nets.RING_VIEWS[ph.data_ptr()] = (buf.stack_ring, cell, weakref.ref(ph))
             plan.append(("stack_ring", 0, None, 0, bs, (cell, ph)))
             fields["state"] = ph.view((bs,) + buf.field_shape("state"))
-        if "state" in names and "next_state" in names:
+        in_place_next = (which == "bootstrap" and getattr(buf, "row_mode", False) and dev.type == "cuda"
+                         and os.environ.get("FLEX_STACKED_RING", "1") != "0" and "next_state" in names and "state" not in names
+                         and not getattr(self, "_no_ring_bootstrap", False)
+                         and getattr(self.behaviour_net, "reads_next_state_in_place", lambda _bs: False)(bs))
+        if in_place_next:                             # the same for the passes that file the bootstrap values: next_state = slot + N
+            import weakref
+            from . import nets
+            w = buf.n_agents * buf.obs_dim
+            buf.enable_stacked_ring(bs + N)
+            ph = th.full((bs, w), float("nan"), dtype=th.float32, device=dev)
+            cell = th.zeros(1, dtype=th.int64, device=dev)
+            nets.RING_VIEWS[ph.data_ptr()] = (buf.stack_ring, cell, weakref.ref(ph))
+            plan.append(("stack_ring", 0, None, N, bs, (cell, ph)))
+            fields["next_state"] = ph.view((bs,) + buf.field_shape("next_state"))
+        in_place_both = (which == "value" and getattr(buf, "row_mode", False) and dev.type == "cuda"
+                         and os.environ.get("FLEX_STACKED_RING", "1") != "0" and "state" in names and "next_state" in names
+                         and getattr(self.behaviour_net, "reads_state_in_place", lambda _bs: False)(bs)
+                         and getattr(self.behaviour_net, "reads_next_state_in_place", lambda _bs: False)(bs))
+        if in_place_both:                             # the plain value sub-update: both views of the window, N rows apart
+            import weakref
+            from . import nets
+            w = buf.n_agents * buf.obs_dim
+            buf.enable_stacked_ring(bs + N)
+            for name, off in (("state", 0), ("next_state", N)):
+                ph = th.full((bs, w), float("nan"), dtype=th.float32, device=dev)
+                cell = th.zeros(1, dtype=th.int64, device=dev)
+                nets.RING_VIEWS[ph.data_ptr()] = (buf.stack_ring, cell, weakref.ref(ph))
+                plan.append(("stack_ring", 0, None, off, bs, (cell, ph)))
+                fields[name] = ph.view((bs,) + buf.field_shape(name))
+        if "state" in names and "next_state" in names and not in_place_both:
             w = buf.n_agents * buf.obs_dim
             win = block(bs + N, w)
             plan.append((buf.obs_source_ring, 0, None, 0, bs + N, win))
@@ -429,6 +458,14 @@ class PGTrainer(object):
             for _ in range(2):
                 body()
         th.cuda.current_stream().wait_stream(side)
+        if any(p[0] == "stack_ring" for p in plan) and not bool(th.isfinite(nv).all()):
+            # `next_state` is a NaN placeholder for ring-aware kernels (nets.RING_VIEWS); something else read it: this trainer
+            # goes back to gathering the window
+            import warnings
+            warnings.warn("a consumer that cannot read the stacked-observation ring in place touched the bootstrap pass's "
+                          "placeholder; gathering the window instead")
+            self._no_ring_bootstrap = True
+            return self._capture_bootstrap(bs)
         graph = th.cuda.CUDAGraph()
         with graph_capture(graph):
             body()

@@ -356,6 +356,12 @@ def test_value_sub_updates_read_their_window_in_place_from_the_stacked_ring():
     assert [p[0] for p in ga["plan"]].count("stack_ring") == 1 and "row_ring" not in [p[0] for p in ga["plan"]]
     assert "row_ring" in [p[0] for p in gb["plan"]] and "stack_ring" not in [p[0] for p in gb["plan"]]
     assert torch.isnan(ga["batch"].state).all()                       # the placeholder, never written
+    # ... and so do the passes that file the bootstrap values: policy and target critic read next_state in place
+    for g in a._bootstrap_graphs.values():
+        assert [p[0] for p in g["plan"]].count("stack_ring") == 1 and "row_ring" not in [p[0] for p in g["plan"]]
+        assert torch.isnan(g["batch"].next_state).all()
+    for g in b._bootstrap_graphs.values():
+        assert "row_ring" in [p[0] for p in g["plan"]]
     assert a.replay_buffer.stack_ring is not None and getattr(b.replay_buffer, "stack_ring", None) is None
     # the ring holds what a gather of the same window forms
     buf = a.replay_buffer
@@ -365,3 +371,34 @@ def test_value_sub_updates_read_their_window_in_place_from_the_stacked_ring():
     p = slot % buf.stack_rows
     assert torch.equal(buf.stack_ring[p:p + 4096], want)
     assert nets.ring_view_of(ga["batch"].state.reshape(ga["bs"], -1)) is not None
+
+
+def test_plain_value_sub_updates_read_both_views_of_their_window_in_place():
+    """The value sub-update that computes its own bootstrap values (the default batch: windows hardly overlap, nothing is filed
+    per event) reads `state` and `next_state` — N ring rows apart — in place as well: policy inference and target critic on
+    next_state, behaviour critic's first layer and its weight gradient on state.  Five sub-updates and a policy sub-update
+    against the gathering form (FLEX_STACKED_RING=0): bit-identical weights, optimiser state, statistics."""
+    import os
+    a = _trainer(True, 4096)
+    os.environ["FLEX_STACKED_RING"] = "0"
+    try:
+        b = _trainer(True, 4096)
+        for i in range(5):
+            stats = []
+            for tr, flag in ((a, "1"), (b, "0")):
+                os.environ["FLEX_STACKED_RING"] = flag
+                np.random.seed(40 + i)
+                st = {}
+                tr.value_replay_process(st)
+                if i == 4:
+                    tr.policy_replay_process(st)
+                torch.cuda.synchronize()
+                stats.append({k: float(v) for k, v in st.items()})
+            assert stats[0] == stats[1], (i, stats)
+    finally:
+        os.environ.pop("FLEX_STACKED_RING", None)
+    for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
+        assert torch.equal(va, vb), ka
+    pa, pb = [p[0] for p in a._update_graphs["value"]["plan"]], [p[0] for p in b._update_graphs["value"]["plan"]]
+    assert pa.count("stack_ring") == 2 and "row_ring" not in pa and "row_ring" in pb
+    assert torch.isnan(a._update_graphs["value"]["batch"].state).all() and torch.isnan(a._update_graphs["value"]["batch"].next_state).all()
