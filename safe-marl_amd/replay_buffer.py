@@ -259,16 +259,29 @@ class DeviceReplayBuffer:
             raise RuntimeError("the stacked-observation ring lives next to the ROW ring (row mode)")
         N = self.n_envs
         tail = -(-int(max_window_rows) // N) * N
-        if getattr(self, "stack_ring", None) is not None:
-            if self.stack_tail >= tail:
-                return
-            raise ValueError("the stacked ring exists with a shorter mirrored tail (placeholders registered against it would go stale)")
+        if getattr(self, "stack_ring", None) is not None and self.stack_tail >= tail:
+            return
         if tail > self.slabs * N:
             raise ValueError("window longer than the ring")
+        # (a longer tail than the existing ring's: a NEW ring — graphs captured against the old one have its address baked in
+        #  and are recaptured when next used, trainer._ensure_graph compares ``stack_gen``)
+        self.stack_gen = getattr(self, "stack_gen", 0) + 1
+        old = getattr(self, "stack_ring", None)
+        if old is not None:
+            from . import nets
+            old_ptr = old.untyped_storage().data_ptr()
+            for key in list(nets.RING_VIEWS):
+                ring, _cell, ref = nets.RING_VIEWS[key]
+                if ref() is None or ring.untyped_storage().data_ptr() == old_ptr:
+                    del nets.RING_VIEWS[key]
+            del old
         self.stack_rows = self.slabs * N
         self.stack_tail = tail
         self.stack_ring = th.zeros(self.stack_rows + tail, self.n_agents * self.obs_dim, dtype=th.float32, device=self.device)
         self.stacked_next = None         # slab counter the next expansion starts at (None: the oldest transition's)
+        # every possible first row, as int64: a window's cell is set by ONE 8-byte row copy inside the gather launch that
+        # refreshes the batch's other fields (no launch of its own: a fill kernel per cell was 4.5 us of a 360-us sub-update)
+        self.slot_table = th.arange(self.stack_rows, dtype=th.int64, device=self.device)
 
     def expand_stacked(self):
         """Bring the stacked ring up to date: the slabs filed since the last call (the slab at the cursor included — it holds
@@ -324,11 +337,12 @@ class DeviceReplayBuffer:
         jobs = []
         for ring_name, col0, width, row_off, rows, dst in plan:
             if ring_name == "stack_ring":                # read in place (enable_stacked_ring): only the window's first row moves
-                cell, _placeholder = dst
+                cell = dst[0]
                 self.expand_stacked()
-                if rows > self.stack_tail:
+                if rows + row_off > self.stack_tail:
                     raise ValueError("window longer than the stacked ring's mirrored tail")
-                cell.fill_((slot + row_off) % self.stack_rows)
+                p = slot % self.stack_rows               # (views further into the window shift the ring's BASE, not the cell)
+                jobs.append((self.slot_table.data_ptr() + 8 * p, cell.data_ptr(), 1, 2, 2))
                 continue
             if ring_name == "row_ring":                  # stacked observations out of the row ring: a launch of its own kind
                 self.stacked_obs(slot + row_off, rows, out=dst)

@@ -142,7 +142,7 @@ class PGTrainer(object):
         else:
             which_key = which
         g = store.get(which_key)
-        if g is None or g["bs"] != bs or g["buf"] is not buf:
+        if g is None or g["bs"] != bs or g["buf"] is not buf or g.get("ring_gen") != getattr(buf, "stack_gen", None):
             exc = None
             try:
                 g = self._capture_sub_update(which, bs)
@@ -161,6 +161,7 @@ class PGTrainer(object):
                 warnings.warn(f"sub-update graph capture failed ({why}); using eager sub-updates")
                 self.graph_updates = False
                 return None
+            g["ring_gen"] = getattr(buf, "stack_gen", None)
             store[which_key] = g
         return g
 
@@ -342,7 +343,7 @@ class PGTrainer(object):
 
     def _ensure_bootstrap(self, bs):
         g = self._bootstrap_graphs.get(bs)
-        if g is None or g["buf"] is not self.replay_buffer:
+        if g is None or g["buf"] is not self.replay_buffer or g.get("ring_gen") != getattr(self.replay_buffer, "stack_gen", None):
             try:
                 g = self._capture_bootstrap(bs)
             except Exception as exc:
@@ -350,6 +351,7 @@ class PGTrainer(object):
                 warnings.warn(f"bootstrap-value graph capture failed ({exc}); value sub-updates compute their own")
                 self.cache_bootstrap = False
                 return None
+            g["ring_gen"] = getattr(self.replay_buffer, "stack_gen", None)
             self._bootstrap_graphs[bs] = g
         return g
 
@@ -392,7 +394,7 @@ class PGTrainer(object):
             buf.enable_stacked_ring(bs + N)
             ph = th.full((bs, w), float("nan"), dtype=th.float32, device=dev)
             cell = th.zeros(1, dtype=th.int64, device=dev)
-            nets.RING_VIEWS[ph.data_ptr()] = (buf.stack_ring, cell, weakref.ref(ph))
+            nets.RING_VIEWS[ph.data_ptr()] = (buf.stack_ring[N:], cell, weakref.ref(ph))
             plan.append(("stack_ring", 0, None, N, bs, (cell, ph)))
             fields["next_state"] = ph.view((bs,) + buf.field_shape("next_state"))
         in_place_both = (which == "value" and getattr(buf, "row_mode", False) and dev.type == "cuda"
@@ -404,12 +406,14 @@ class PGTrainer(object):
             from . import nets
             w = buf.n_agents * buf.obs_dim
             buf.enable_stacked_ring(bs + N)
+            cell = th.zeros(1, dtype=th.int64, device=dev)           # ONE cell: the window's first row; next_state = N rows on
+            keep = []
             for name, off in (("state", 0), ("next_state", N)):
                 ph = th.full((bs, w), float("nan"), dtype=th.float32, device=dev)
-                cell = th.zeros(1, dtype=th.int64, device=dev)
-                nets.RING_VIEWS[ph.data_ptr()] = (buf.stack_ring, cell, weakref.ref(ph))
-                plan.append(("stack_ring", 0, None, off, bs, (cell, ph)))
+                nets.RING_VIEWS[ph.data_ptr()] = (buf.stack_ring[off:], cell, weakref.ref(ph))
+                keep.append(ph)
                 fields[name] = ph.view((bs,) + buf.field_shape(name))
+            plan.append(("stack_ring", 0, None, N, bs, (cell, keep)))
         if "state" in names and "next_state" in names and not in_place_both:
             w = buf.n_agents * buf.obs_dim
             win = block(bs + N, w)
