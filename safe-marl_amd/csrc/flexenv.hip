@@ -634,12 +634,6 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     // net load per bus (pf.py:69-73, 81-82)
     const double pnet = pd - act.pred - ppv + act.ch - act.dis;
     const double qnet = qd - act.q;
-    // pf.py:45: E_next (pf.py:96-98) is declared NonNegativeReals; a negative value makes the reference's NLP infeasible,
-    // pf.py:104-105 raises and the step takes the failure path of env:314-337 whatever the network equations say
-    bool wave_dom;
-    const bool dom_bad = grp_any<EPW>(is_bld && valid && e_init + c.dt * (c.eta_ch * act.ch - a.inv_eta_dis * act.dis) < -FLEX_DOMAIN_EPS,
-                                      ln.grp, wave_dom);
-
     // FLEX_STEP_REPLAY_SINK: what the epilogue files into the replay ring but does not compute — the policy's action and
     // its new recurrent state — is requested HERE, last in the prologue's load queue (loads return in order: nothing the
     // solve waits for queues behind these), and lands underneath the solve; issued in the epilogue these loads were a full
@@ -665,7 +659,7 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     FLEX_STAMP(1);
-    const bool ok = pf_solve<EPW>(a.net, ln, c.solver, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters, sweeps) && !dom_bad;
+    bool ok = pf_solve<EPW>(a.net, ln, c.solver, pnet, qnet, e, f, c.pf_tol, c.pf_max_iter, iters, sweeps);
 #ifdef FLEX_STAMPS
     asm volatile("" :: "v"(e), "v"(f));
 #endif
@@ -680,6 +674,15 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     if constexpr (!ROWS) hist.store(z, env0, obs_fast, obs);
     double* const e_agent = z.st.agent + (int64_t)env0 * agent_rec_doubles(cz.n_agents);
     uint32_t* const e_vw = z.st.vw + (int64_t)env0 * LW;
+    {
+        // pf.py:45: E_next (pf.py:96-98) is declared NonNegativeReals; a negative value makes the reference's NLP infeasible,
+        // pf.py:104-105 raises and the step takes the failure path of env:314-337 whatever the network equations say.
+        // (Tested AFTER the solve, from values the epilogue needs anyway: nothing extra is live across the solve.)
+        bool wave_dom;
+        const bool dom_bad = grp_any<EPW>(is_bld && valid && e_init + cz.dt * (cz.eta_ch * act.ch - z.inv_eta_dis * act.dis) < -FLEX_DOMAIN_EPS,
+                                          ln.grp, wave_dom);
+        ok = ok && !dom_bad;
+    }
     double* const e_vm = z.st.vm + (int64_t)env0 * z.n_bus;
     int32_t* const e_ienv = z.st.ienv + (int64_t)env0 * IF_COUNT;
     const uint32_t o_vm = (g * z.n_bus + busi) * 8;

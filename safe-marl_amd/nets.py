@@ -367,6 +367,16 @@ def tall_linear(x, w, b=None):
 RING_VIEWS = {}              # placeholder data_ptr -> (ring tensor [rows, width], device int64 cell)
 
 
+def register_ring_view(placeholder, ring, cell):
+    """``placeholder`` (a NaN-filled [rows, width] tensor that stands where a gathered window used to be) is read as rows
+    cell[0] .. of ``ring`` by the kernels that know how.  Entries whose placeholder has been freed are dropped first: they
+    hold a view of their ring, and a dropped trainer's 2.9 GB ring must not outlive it."""
+    import weakref
+    for key in [k for k, v in RING_VIEWS.items() if v[2]() is None]:
+        del RING_VIEWS[key]
+    RING_VIEWS[placeholder.data_ptr()] = (ring, cell, weakref.ref(placeholder))
+
+
 def ring_view_of(t):
     """(ring, cell) if ``t`` is (a whole-row view of) a registered placeholder, else None."""
     if not RING_VIEWS or not t.is_cuda:

@@ -374,13 +374,12 @@ class PGTrainer(object):
         if in_place:
             # the value sub-update on filed bootstrap values reads its observations IN PLACE from the replay's stacked ring
             # (nets.RING_VIEWS): no gather of the window, `state` is a NaN placeholder that only ring-aware kernels may touch
-            import weakref
             from . import nets
             w = buf.n_agents * buf.obs_dim
             buf.enable_stacked_ring(bs + N)
             ph = th.full((bs, w), float("nan"), dtype=th.float32, device=dev)
             cell = th.zeros(1, dtype=th.int64, device=dev)
-            nets.RING_VIEWS[ph.data_ptr()] = (buf.stack_ring, cell, weakref.ref(ph))
+            nets.register_ring_view(ph, buf.stack_ring, cell)
             plan.append(("stack_ring", 0, None, 0, bs, (cell, ph)))
             fields["state"] = ph.view((bs,) + buf.field_shape("state"))
         in_place_next = (which == "bootstrap" and getattr(buf, "row_mode", False) and dev.type == "cuda"
@@ -388,13 +387,12 @@ class PGTrainer(object):
                          and not getattr(self, "_no_ring_bootstrap", False)
                          and getattr(self.behaviour_net, "reads_next_state_in_place", lambda _bs: False)(bs))
         if in_place_next:                             # the same for the passes that file the bootstrap values: next_state = slot + N
-            import weakref
             from . import nets
             w = buf.n_agents * buf.obs_dim
             buf.enable_stacked_ring(bs + N)
             ph = th.full((bs, w), float("nan"), dtype=th.float32, device=dev)
             cell = th.zeros(1, dtype=th.int64, device=dev)
-            nets.RING_VIEWS[ph.data_ptr()] = (buf.stack_ring[N:], cell, weakref.ref(ph))
+            nets.register_ring_view(ph, buf.stack_ring[N:], cell)
             plan.append(("stack_ring", 0, None, N, bs, (cell, ph)))
             fields["next_state"] = ph.view((bs,) + buf.field_shape("next_state"))
         in_place_both = (which == "value" and getattr(buf, "row_mode", False) and dev.type == "cuda"
@@ -402,7 +400,6 @@ class PGTrainer(object):
                          and getattr(self.behaviour_net, "reads_state_in_place", lambda _bs: False)(bs)
                          and getattr(self.behaviour_net, "reads_next_state_in_place", lambda _bs: False)(bs))
         if in_place_both:                             # the plain value sub-update: both views of the window, N rows apart
-            import weakref
             from . import nets
             w = buf.n_agents * buf.obs_dim
             buf.enable_stacked_ring(bs + N)
@@ -410,7 +407,7 @@ class PGTrainer(object):
             keep = []
             for name, off in (("state", 0), ("next_state", N)):
                 ph = th.full((bs, w), float("nan"), dtype=th.float32, device=dev)
-                nets.RING_VIEWS[ph.data_ptr()] = (buf.stack_ring[off:], cell, weakref.ref(ph))
+                nets.register_ring_view(ph, buf.stack_ring[off:], cell)
                 keep.append(ph)
                 fields[name] = ph.view((bs,) + buf.field_shape(name))
             plan.append(("stack_ring", 0, None, N, bs, (cell, keep)))
