@@ -209,6 +209,13 @@ def fused_actor_forward(agent, obs, hidden, n_agents, agent_id, noise=None, std=
         ring_cursor, obs_slab_stride, hid_slab_stride, cursor_out = rv[1], rv[0].shape[1], 0, None
         obs = rv[0]
     hidden = hidden.reshape(rows, 64).to(th.float32).contiguous()
+    rvh = ring_view_of(hidden)
+    if rvh is not None:
+        # the hidden states of the same window, in place from the replay's hidden-state ring (same cell: same ring geometry)
+        if rv is None or rvh[1] is not rv[1] or rvh[0].shape[1] != n_agents * 64:
+            raise RuntimeError("fused_actor_forward: hidden states are read in place only together with the observations of the same window")
+        hid_slab_stride = rvh[0].shape[1]
+        hidden = rvh[0]
     means = (out or {}).get("means")
     if means is None:
         means = th.empty(rows, a.action_dim, dtype=th.float32, device=obs.device)

@@ -56,6 +56,7 @@ class DeviceReplayBuffer:
 
     # -- slab mode: the vectorised, graph-captured rollout ------------------------------------------------------------
     ROW_W = 8                      # floats per row record: [Pd, Qd, Ppv, V, price, E, older, 0] (include/flexenv.h)
+    HID_TAIL_SLABS = 40            # mirrored tail of the hidden-state ring: windows of up to 39 slabs (+ next) are read in place
 
     def alloc_slabs(self, n_envs, n_agents, obs_dim, act_dim, hid_dim, history=None):
         """Slab-structured ring for N environments stepping in lockstep (include/flexnet.h: flexnet_rollout_pack writes it
@@ -90,7 +91,11 @@ class DeviceReplayBuffer:
         else:
             self.obs_ring = None
             self.row_ring = th.zeros(self.slabs, n_envs, n_agents * self.ROW_W, dtype=th.float32, device=dev)
-        self.hid_ring = th.zeros(self.slabs, n_envs, nh, dtype=th.float32, device=dev)
+        # (the hidden-state ring has room for a mirrored tail behind its last slab — enable_stacked_ring uses it; everybody else
+        #  sees the ring proper)
+        self.hid_tail_slabs = min(self.slabs, self.HID_TAIL_SLABS) if self.history is not None else 0
+        self.hid_store = th.zeros(self.slabs + self.hid_tail_slabs, n_envs, nh, dtype=th.float32, device=dev)
+        self.hid_ring = self.hid_store[:self.slabs]
         self.small_ring = th.zeros(self.slabs, n_envs, self.small_w, dtype=th.float32, device=dev)
         # bootstrap values r + gamma (1 - done) Q'(s', pi(s')) needs, per transition, filed by the trainer for the windows of
         # ONE update event (trainer.replay_event: the networks behind them do not change between its value sub-updates)
@@ -118,7 +123,7 @@ class DeviceReplayBuffer:
     def release_slabs(self):
         """Back to the field-by-field mode (the graph rollout could not be captured): the rings and their bookkeeping go,
         ``add_batch`` allocates its own store on the next call.  Transitions the ring held are dropped."""
-        self.obs_ring = self.row_ring = self.hid_ring = self.small_ring = self.nv_ring = self.cursor = None
+        self.obs_ring = self.row_ring = self.hid_ring = self.hid_store = self.small_ring = self.nv_ring = self.cursor = None
         self.stack_ring = None
         self.k = self.first = 0
         self.gaps = []
@@ -302,6 +307,9 @@ class DeviceReplayBuffer:
             if p < tail_slabs:                            # the ring's head, mirrored behind its end
                 q = min(run, tail_slabs - p)
                 self.stack_ring[self.stack_rows + p * N:self.stack_rows + (p + q) * N].copy_(self.stack_ring[p * N:(p + q) * N])
+            if p < self.hid_tail_slabs:                   # ... and the hidden states of the same slabs (read in place as well)
+                q = min(run, self.hid_tail_slabs - p)
+                self.hid_store[self.slabs + p:self.slabs + p + q].copy_(self.hid_store[p:p + q])
             c += run
         self.stacked_next = hi + 1
 

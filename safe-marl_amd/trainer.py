@@ -393,8 +393,10 @@ class PGTrainer(object):
             ph = th.full((bs, w), float("nan"), dtype=th.float32, device=dev)
             cell = th.zeros(1, dtype=th.int64, device=dev)
             nets.register_ring_view(ph, buf.stack_ring[N:], cell)
-            plan.append(("stack_ring", 0, None, N, bs, (cell, ph)))
+            keep = [ph]
             fields["next_state"] = ph.view((bs,) + buf.field_shape("next_state"))
+            keep += self._hid_in_place(buf, names, fields, cell, bs)
+            plan.append(("stack_ring", 0, None, N, bs, (cell, keep)))
         in_place_both = (which == "value" and getattr(buf, "row_mode", False) and dev.type == "cuda"
                          and os.environ.get("FLEX_STACKED_RING", "1") != "0" and "state" in names and "next_state" in names
                          and getattr(self.behaviour_net, "reads_state_in_place", lambda _bs: False)(bs)
@@ -410,6 +412,7 @@ class PGTrainer(object):
                 nets.register_ring_view(ph, buf.stack_ring[off:], cell)
                 keep.append(ph)
                 fields[name] = ph.view((bs,) + buf.field_shape(name))
+            keep += self._hid_in_place(buf, names, fields, cell, bs)
             plan.append(("stack_ring", 0, None, N, bs, (cell, keep)))
         if "state" in names and "next_state" in names and not in_place_both:
             w = buf.n_agents * buf.obs_dim
@@ -437,6 +440,23 @@ class PGTrainer(object):
             fields[k] = th.full((1,) + tuple(1 for _ in shape), float(c), device=dev).expand((bs,) + tuple(shape))
             fields[k]._flex_const = float(c)
         return fields, plan
+
+    @staticmethod
+    def _hid_in_place(buf, names, fields, cell, bs):
+        """``hid`` (the hidden state the policy starts from at next_state: slab + 1) read in place from the replay's
+        hidden-state ring beside the observations of the same window — its only reader on these paths is the policy's fused
+        inference pass (nets.fused_actor_forward).  Needs the window (and its + N view) inside the ring's mirrored tail."""
+        from . import nets
+        N = buf.n_envs
+        if ("hid" not in names or "hid" in fields or os.environ.get("FLEX_HID_IN_PLACE", "1") == "0"
+                or -(-(bs + N) // N) + 1 > getattr(buf, "hid_tail_slabs", 0)):
+            return []
+        w = buf.n_agents * buf.hid_dim
+        flat = buf.hid_store.view(-1, w)
+        ph = th.full((bs, w), float("nan"), dtype=th.float32, device=flat.device)
+        nets.register_ring_view(ph, flat[N:], cell)
+        fields["hid"] = ph.view((bs,) + buf.field_shape("hid"))
+        return [ph]
 
     def _capture_bootstrap(self, bs):
         """The graph that files Q'(s', pi(s')) for ``bs`` consecutive transitions: next observations and hidden states of the

@@ -360,6 +360,7 @@ def test_value_sub_updates_read_their_window_in_place_from_the_stacked_ring():
     for g in a._bootstrap_graphs.values():
         assert [p[0] for p in g["plan"]].count("stack_ring") == 1 and "row_ring" not in [p[0] for p in g["plan"]]
         assert torch.isnan(g["batch"].next_state).all()
+        assert torch.isnan(g["batch"].hid).all()                      # the hidden states too (mirrored tail of the hidden-state ring)
     for g in b._bootstrap_graphs.values():
         assert "row_ring" in [p[0] for p in g["plan"]]
     assert a.replay_buffer.stack_ring is not None and getattr(b.replay_buffer, "stack_ring", None) is None
@@ -402,3 +403,5 @@ def test_plain_value_sub_updates_read_both_views_of_their_window_in_place():
     pa, pb = [p[0] for p in a._update_graphs["value"]["plan"]], [p[0] for p in b._update_graphs["value"]["plan"]]
     assert pa.count("stack_ring") == 1 and "row_ring" not in pa and "row_ring" in pb
     assert torch.isnan(a._update_graphs["value"]["batch"].state).all() and torch.isnan(a._update_graphs["value"]["batch"].next_state).all()
+    assert torch.isnan(a._update_graphs["value"]["batch"].hid).all()
+    assert "hid_ring" not in pa and "hid_ring" in pb
