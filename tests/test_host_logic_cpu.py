@@ -110,3 +110,91 @@ def test_update_fields_cover_what_each_loss_reads(alg):
             p, v, _ = m.get_loss(Transition(**f), need=which)
             losses.append((v if which == "value" else p).item())
         assert losses[0] == losses[1], which
+
+
+def test_stacked_ring_bookkeeping_expands_every_slab_once_and_mirrors_the_head():
+    """replay_buffer.enable_stacked_ring / expand_stacked (round 5) on CPU tensors, with flexnet_gather_window replaced by a
+    NumPy restatement of include/flexnet.h's definition (dst[i][a][h*6+f] = row_ring[slab - (H-1-h)][env][a][f] while
+    H-1-h <= older, else 0): after every batch of vector steps the ring holds each expanded slab's stacked observations at
+    its physical position, the first `tail` rows are mirrored behind the ring's end (also for the hidden-state ring), slabs are
+    expanded once (the restatement counts), a window that starts anywhere is contiguous, and a longer tail makes a new ring
+    generation."""
+    from safe_marl_amd.replay_buffer import DeviceReplayBuffer
+    N, n, H = 4, 2, 3
+    buf = DeviceReplayBuffer(N * 10, device="cpu")
+    buf.alloc_slabs(N, n, 6 * H, 4, 8, history=H)                  # 10 + 2 slabs
+    S = buf.slabs
+    calls = []
+
+    def stacked_obs(slot, rows, out=None):
+        calls.append((slot, rows))
+        rr = buf.row_ring.view(S, N, n, buf.ROW_W).numpy()
+        res = np.zeros((rows, n, H * 6), np.float32)
+        for i in range(rows):
+            g = slot + i
+            slab, env = (g // N) % S, g % N
+            for a in range(n):
+                older = int(rr[slab, env, a, 6])
+                for h in range(H):
+                    back = H - 1 - h
+                    if back <= older:
+                        res[i, a, h * 6:(h + 1) * 6] = rr[(slab - back) % S, env, a, :6]
+        t = torch.from_numpy(res.reshape(rows, -1))
+        if out is None:
+            return t
+        out.copy_(t)
+        return out
+
+    buf.stacked_obs = stacked_obs
+    buf.enable_stacked_ring(3 * N + N)
+    assert buf.stack_rows == S * N and buf.stack_tail == 4 * N and buf.stack_gen == 1
+    rng = np.random.default_rng(0)
+    first = torch.from_numpy(rng.normal(size=(N, n, 6 * H)).astype(np.float32))
+    buf.begin_stream(first)
+    step = [0]
+
+    def roll(m):
+        for _ in range(m):
+            p = (buf.k + 1) % S                                   # the step files the NEXT slab's record and hidden state
+            rec = buf.row_ring[p].view(N, n, buf.ROW_W)
+            rec[:, :, :6] = torch.from_numpy(rng.normal(size=(N, n, 6)).astype(np.float32))
+            step[0] += 1
+            rec[:, :, 6] = float(min(step[0], H - 1))
+            buf.hid_ring[p] = torch.from_numpy(rng.normal(size=(N, n * 8)).astype(np.float32))
+            buf.stepped()
+
+    def check():
+        lo = buf.first
+        for c in range(lo, buf.k + 1):
+            p = c % S
+            want = stacked_obs(c * N, N)
+            assert torch.equal(buf.stack_ring[p * N:(p + 1) * N], want), c
+            if p * N < buf.stack_tail:
+                assert torch.equal(buf.stack_ring[buf.stack_rows + p * N:buf.stack_rows + (p + 1) * N], want), c
+            if p < buf.hid_tail_slabs:
+                assert torch.equal(buf.hid_store[S + p], buf.hid_ring[p]), c
+
+    roll(5)
+    calls.clear()
+    buf.expand_stacked()
+    assert sum(r for _, r in calls) == 6 * N                       # slabs 0..5, the cursor's included, once
+    check()
+    calls.clear()
+    buf.expand_stacked()
+    assert calls == []                                             # nothing new
+    roll(9)                                                        # the ring (12 slabs) wraps
+    calls.clear()
+    buf.expand_stacked()
+    assert sum(r for _, r in calls) == 9 * N
+    calls.clear()
+    check()
+    # a window astride the seam is contiguous in the ring + tail
+    slot = (buf.k - 3) * N + 1
+    p = slot % buf.stack_rows
+    got = buf.stack_ring[p:p + 3 * N]
+    assert torch.equal(got, stacked_obs(slot, 3 * N))
+    # a longer tail: a new ring and a new generation; everything is expanded again
+    buf.enable_stacked_ring(6 * N)
+    assert buf.stack_gen == 2 and buf.stack_tail == 6 * N and buf.stacked_next is None
+    buf.expand_stacked()
+    check()
