@@ -741,19 +741,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    run_steps(a.warmup)
-
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run_steps(a.steps)                                    # exactly K steps
-    ev1.record()
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    dev_ms = ev0.elapsed_time(ev1)
-
-    # `sustained`: the same step over >= 2048 launches, HIP events on the launch stream around the whole region
+    # `sustained`: the same step over >= 2048 launches, HIP events on the launch stream around the whole region.  It runs FIRST
+    # (round 5): the device then enters the W warm-up steps and the K timed steps at its operating clocks, as it would in any
+    # use where environment steps follow one another.  Measured (tools/launch_seq_probe.py, profiles/r05w_launch_seq_probe.txt):
+    # the 20-step region the driver asks for takes 245-252 us on a busy device and 283-293 us on one that idled for 50-500 ms
+    # of host-side set-up (W = 5 steps = 60 us do not bring the clocks back); `config.timed_after` says so in the line.
     sustained = None
     if not a.no_sustained:
         n_sus = max(2048, ACTION_POOL * (a.steps // ACTION_POOL))
@@ -767,6 +759,18 @@ def main():
         sus_elapsed = max_over_ranks(time.perf_counter() - t1)
         sustained = {"steps": n_sus, "value": a.envs * world * n_sus / sus_elapsed, "unit": "env-steps/s",
                      "ms_per_step": sus_elapsed / n_sus * 1e3, "device_ms_per_step": s0.elapsed_time(s1) / n_sus}
+
+    run_steps(a.warmup)                                   # W untimed warm-up steps
+
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()                                          # (on an idle stream: done before the first step is enqueued)
+    t0 = time.perf_counter()
+    run_steps(a.steps)                                    # exactly K steps
+    ev1.record()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    dev_ms = ev0.elapsed_time(ev1)
 
     # roofline leg.  The timed region above is K back-to-back launches of ONE kernel (flex_step_kernel) on one
     # stream, bracketed by the HIP events ev0/ev1 on that stream: dev_ms / K is its average launch duration
@@ -1002,6 +1006,7 @@ def main():
                 "sweep_accel": bool(a.solver == "sweep" and not a.no_sweep_accel),
                 "envs_per_gpu": a.envs, "n_agents": n_agents_env, "n_bus": n_bus_env,
                 "warm_start": bool(a.warm_start), "launches_per_step": 1, "hip_graph": used_graph, "hip_graph_uploaded": used_graph,
+                "timed_after": ("the `sustained` leg (%d steps), then W warm-up steps" % sustained["steps"]) if sustained else "W warm-up steps",
                 "device_ms_per_step": dev_ms / a.steps, "solver": ("sweep (mixed fp64/fp32 increments) + fp64 Newton verification" if a.solver == "sweep" else "newton (fp64, tree elimination)"),
                 "pf_newton_iters_mean": iters_mean, "pf_sweeps_mean": sweeps_mean,
                 "solver_failed_frac": failed_frac,
