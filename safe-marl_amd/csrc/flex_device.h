@@ -161,28 +161,42 @@ template <int CTRL, int ROW_MASK, bool BOUND_CTRL>
 __device__ __forceinline__ float dpp_mov_f32(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, BOUND_CTRL));
 }
+// Round 5: written out as the instructions wanted.  From the C++ form the compiler (a) packed the two components' fma into
+// v_pk_fma_f32 behind two v_mov_b32_dpp — three issue slots per step where two v_fmac_f32_dpp do — and (b) could not fold the
+// row_bcast step (rows 1 and 3 only) into its add, because x + 0.0 is not an identity for x = -0.0: zero, v_mov_b32_dpp, add
+// per component.  A DPP instruction with a partial row_mask leaves the destination of the other rows alone, which is the
+// wanted result outright.  DPP reads of a VGPR need two wait states behind the VALU write: the other component's
+// instruction is one, s_nop 0 the other (the assembler does not insert them in inline code).  11 issue slots less per sweep.
+#define FLEX_DPP_ROW(n) " row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define FLEX_DPP_BC15 " row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+#define FLEX_DPP_BC31 " row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
 template <int EPW>
 __device__ __forceinline__ void grp_scan_sum2_f32(float& x, float& y) {
-#define FLEX_SCAN2F_STEP(CTRL, RM, BC) { const float tx = dpp_mov_f32<CTRL, RM, BC>(x), ty = dpp_mov_f32<CTRL, RM, BC>(y); x += tx; y += ty; }
-    FLEX_SCAN2F_STEP(0x111, 0xF, true)
-    FLEX_SCAN2F_STEP(0x112, 0xF, true)
-    FLEX_SCAN2F_STEP(0x114, 0xF, true)
-    FLEX_SCAN2F_STEP(0x118, 0xF, true)
-    FLEX_SCAN2F_STEP(0x142, 0xA, false)
-    if constexpr (EPW == 1) FLEX_SCAN2F_STEP(0x143, 0xC, false)
-#undef FLEX_SCAN2F_STEP
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0" FLEX_DPP_ROW(1) "v_add_f32_dpp %1, %1, %1" FLEX_DPP_ROW(1) "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0" FLEX_DPP_ROW(2) "v_add_f32_dpp %1, %1, %1" FLEX_DPP_ROW(2) "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0" FLEX_DPP_ROW(4) "v_add_f32_dpp %1, %1, %1" FLEX_DPP_ROW(4) "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0" FLEX_DPP_ROW(8) "v_add_f32_dpp %1, %1, %1" FLEX_DPP_ROW(8) "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0" FLEX_DPP_BC15 "v_add_f32_dpp %1, %1, %1" FLEX_DPP_BC15
+                 : "+v"(x), "+v"(y));
+    if constexpr (EPW == 1)
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0" FLEX_DPP_BC31 "v_add_f32_dpp %1, %1, %1" FLEX_DPP_BC31
+                     : "+v"(x), "+v"(y));
 }
 template <int EPW>
 __device__ __forceinline__ void grp_segscan_sum2_f32(float& x, float& y, const float (&m)[6]) {
-#define FLEX_SEG2F_STEP(CTRL, RM, BC, K) { const float tx = dpp_mov_f32<CTRL, RM, BC>(x), ty = dpp_mov_f32<CTRL, RM, BC>(y); \
-    x = fmaf(tx, m[K], x); y = fmaf(ty, m[K], y); }
-    FLEX_SEG2F_STEP(0x111, 0xF, true, 0)
-    FLEX_SEG2F_STEP(0x112, 0xF, true, 1)
-    FLEX_SEG2F_STEP(0x114, 0xF, true, 2)
-    FLEX_SEG2F_STEP(0x118, 0xF, true, 3)
-    FLEX_SEG2F_STEP(0x142, 0xA, false, 4)
-    if constexpr (EPW == 1) FLEX_SEG2F_STEP(0x143, 0xC, false, 5)
-#undef FLEX_SEG2F_STEP
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %0, %2" FLEX_DPP_ROW(1) "v_fmac_f32_dpp %1, %1, %2" FLEX_DPP_ROW(1) "s_nop 0\n\t"
+                 "v_fmac_f32_dpp %0, %0, %3" FLEX_DPP_ROW(2) "v_fmac_f32_dpp %1, %1, %3" FLEX_DPP_ROW(2) "s_nop 0\n\t"
+                 "v_fmac_f32_dpp %0, %0, %4" FLEX_DPP_ROW(4) "v_fmac_f32_dpp %1, %1, %4" FLEX_DPP_ROW(4) "s_nop 0\n\t"
+                 "v_fmac_f32_dpp %0, %0, %5" FLEX_DPP_ROW(8) "v_fmac_f32_dpp %1, %1, %5" FLEX_DPP_ROW(8) "s_nop 0\n\t"
+                 "v_fmac_f32_dpp %0, %0, %6" FLEX_DPP_BC15 "v_fmac_f32_dpp %1, %1, %6" FLEX_DPP_BC15
+                 : "+v"(x), "+v"(y) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]));
+    if constexpr (EPW == 1)
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f32_dpp %0, %0, %2" FLEX_DPP_BC31 "v_fmac_f32_dpp %1, %1, %2" FLEX_DPP_BC31
+                     : "+v"(x), "+v"(y) : "v"(m[5]));
 }
 __device__ __forceinline__ double readlane_f64(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
@@ -457,7 +471,9 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
     float mkf[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) mkf[k] = ln.mk[k] ? 1.0f : 0.0f;
-    int mine = max_sweeps, it = 0;
+    // the sweep at which each group's own mismatch test first passed (statistics: PF_SWEEPS), kept per GROUP in scalar registers
+    // and handed to the lanes at the end — as a per-lane value it cost seven vector instructions per sweep
+    int mine0 = max_sweeps, mine1 = max_sweeps, it = 0;
     bool fine = false;                          // re-anchored below the coarse threshold already
     const float kappa = use_seg ? net->acc_kappa : 0.0f;
     const int acc_lane = net->acc_lane;
@@ -489,9 +505,14 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
         {
             const double dr = iar - ibr, di = iai - ibi;
             const double m = fmax(fabs(e * dr + f * di), fabs(f * dr - e * di));
-            bool wave_miss;
-            const bool grp_miss = grp_any<EPW>(!(m < tol), ln.grp, wave_miss);
-            if (!grp_miss && mine == max_sweeps) mine = it;
+            const unsigned long long miss = __ballot(!(m < tol));
+            const bool wave_miss = miss != 0ull;
+            if constexpr (EPW == 1) {
+                if (!wave_miss && mine0 == max_sweeps) mine0 = it;
+            } else {
+                if ((unsigned)miss == 0u && mine0 == max_sweeps) mine0 = it;
+                if ((unsigned)(miss >> 32) == 0u && mine1 == max_sweeps) mine1 = it;
+            }
             if (!wave_miss) break;
             if (!use_seg) continue;
             if (!fine && __ballot(!(m < FLEX_SWEEP_COARSE)) == 0ull) fine = true;
@@ -513,23 +534,30 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
             float xr = -ur * rr, xi = ui * rr;                                              // delta = -conj(S d / P)
             const float gr = pdr - xr, gi = pdi - xi;
             const float m = fmaxf(fabsf(vr * gr + vi * gi), fabsf(vi * gr - vr * gi));
-            bool wave_miss;
-            const bool grp_miss = grp_any<EPW>(!(m < tolf), ln.grp, wave_miss);
-            if (!grp_miss && mine == max_sweeps) mine = it;
+            const unsigned long long miss = __ballot(!(m < tolf));
+            const bool wave_miss = miss != 0ull;
+            if constexpr (EPW == 1) {
+                if (!wave_miss && mine0 == max_sweeps) mine0 = it;
+            } else {
+                if ((unsigned)miss == 0u && mine0 == max_sweeps) mine0 = it;
+                if ((unsigned)(miss >> 32) == 0u && mine1 == max_sweeps) mine1 = it;
+            }
             // a threshold below the coarse one is only trusted on a re-anchored iterate: with the extrapolation an increment
             // can contract by more than coarse / tol in one step and pass the fp32 test while still hanging on its first anchor
             if (!wave_miss && (fine || tolf >= coarsef)) { done = true; break; }
             if (!fine && __ballot(!(m < coarsef)) == 0ull) { fine = true; break; }          // re-anchor now
             pdr = xr; pdi = xi;
             zbus_apply_f32<EPW>(ln, mkf, rf, xf, seg_rounds, xr, xi);
-            if (k == 1) { xr *= relax; xi *= relax; pdr *= relax; pdi *= relax; }          // d_3 + omega (d_3 - d_1)
+            const float fac = k == 1 ? relax : 1.0f;                                        // d_3 + omega (d_3 - d_1); x * 1.0f is exact
+            xr *= fac; xi *= fac; pdr *= fac; pdi *= fac;
             dr = cr + xr; di = ci + xi;
             ++it;
         }
         e = ea + (double)dr; f = fa + (double)di;
         if (done) break;
     }
-    return mine;
+    if constexpr (EPW == 1) return mine0;
+    else return ln.grp ? mine1 : mine0;
 }
 
 // ---- Newton-Raphson with a DENSE LU of the 2n x 2n Jacobian (the north-star's "small batched dense solve") ----
