@@ -19,6 +19,9 @@
 #include "flexenv.h"
 
 #define FLEX_WAVE 64
+#if defined(FLEX_STAMPS) && !defined(FLEX_GROUP_SWEEP_STAT)
+#define FLEX_GROUP_SWEEP_STAT 1
+#endif
 #ifndef FLEX_WAVES_PER_BLOCK
 #define FLEX_WAVES_PER_BLOCK 4
 #endif
@@ -430,9 +433,13 @@ __device__ __forceinline__ void zbus_apply_f64(const DevNet* __restrict__ net, c
     double ar = ln.r * tr - ln.x * ti, ai = ln.r * ti + ln.x * tr;
     if (use_seg) {                                                // path sum slack -> bus
         grp_segscan_sum2<EPW>(ar, ai, ln.mk);
-        for (int d = 1; d <= seg_rounds; ++d) {
+        if (seg_rounds >= 1) {                                    // (use_seg: at most two rounds; written out — no loop counter)
             const double br = __shfl(ar, ln.seg_par, FLEX_WAVE), bi = __shfl(ai, ln.seg_par, FLEX_WAVE);
-            if (ln.seg_depth == d) { ar += br; ai += bi; }
+            if (ln.seg_depth == 1) { ar += br; ai += bi; }
+        }
+        if (seg_rounds >= 2) {
+            const double br = __shfl(ar, ln.seg_par, FLEX_WAVE), bi = __shfl(ai, ln.seg_par, FLEX_WAVE);
+            if (ln.seg_depth == 2) { ar += br; ai += bi; }
         }
     } else {
         for (int k = 0; k < jump_rounds; ++k) {
@@ -453,9 +460,13 @@ __device__ __forceinline__ void zbus_apply_f32(const LaneNet& ln, const float (&
     const float ti = __shfl(si, ln.sub_end, FLEX_WAVE) - (si - xi);
     float ar = rf * tr - xf * ti, ai = rf * ti + xf * tr;
     grp_segscan_sum2_f32<EPW>(ar, ai, mkf);
-    for (int d = 1; d <= seg_rounds; ++d) {
+    if (seg_rounds >= 1) {                      // (laterals off the main line — IEEE-33 — need exactly this one round)
         const float br = __shfl(ar, ln.seg_par, FLEX_WAVE), bi = __shfl(ai, ln.seg_par, FLEX_WAVE);
-        if (ln.seg_depth == d) { ar += br; ai += bi; }
+        if (ln.seg_depth == 1) { ar += br; ai += bi; }
+    }
+    if (seg_rounds >= 2) {
+        const float br = __shfl(ar, ln.seg_par, FLEX_WAVE), bi = __shfl(ai, ln.seg_par, FLEX_WAVE);
+        if (ln.seg_depth == 2) { ar += br; ai += bi; }
     }
     xr = ar; xi = ai;
 }
@@ -471,9 +482,21 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
     float mkf[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) mkf[k] = ln.mk[k] ? 1.0f : 0.0f;
-    // the sweep at which each group's own mismatch test first passed (statistics: PF_SWEEPS), kept per GROUP in scalar registers
-    // and handed to the lanes at the end — as a per-lane value it cost seven vector instructions per sweep
-    int mine0 = max_sweeps, mine1 = max_sweeps, it = 0;
+    // Statistics (PF_SWEEPS): the sweeps this wavefront EXECUTED — with two environments per wavefront both run until the slower
+    // one's test has passed, and that is what either of them cost.  The sweep at which each environment's OWN test first passed
+    // (7.75 on the bench's loading where 8.16 are executed) is kept by the diagnostic build only (FLEX_GROUP_SWEEP_STAT, implied
+    // by FLEX_STAMPS): as two scalar counters it cost a dozen scalar instructions per sweep, 3.4 % of the launch
+    // (profiles/r05ag_env_variants.txt).
+    int it = 0;
+#ifdef FLEX_GROUP_SWEEP_STAT
+    int mine0 = max_sweeps, mine1 = max_sweeps;
+#define FLEX_SWEEP_NOTE_PASS(miss, itv) do { \
+        if constexpr (EPW == 1) { if ((miss) == 0ull && mine0 == max_sweeps) mine0 = (itv); } \
+        else { if ((unsigned)(miss) == 0u && mine0 == max_sweeps) mine0 = (itv); \
+               if ((unsigned)((miss) >> 32) == 0u && mine1 == max_sweeps) mine1 = (itv); } } while (0)
+#else
+#define FLEX_SWEEP_NOTE_PASS(miss, itv) do { } while (0)
+#endif
     bool fine = false;                          // re-anchored below the coarse threshold already
     const float kappa = use_seg ? net->acc_kappa : 0.0f;
     const int acc_lane = net->acc_lane;
@@ -507,12 +530,7 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
             const double m = fmax(fabs(e * dr + f * di), fabs(f * dr - e * di));
             const unsigned long long miss = __ballot(!(m < tol));
             const bool wave_miss = miss != 0ull;
-            if constexpr (EPW == 1) {
-                if (!wave_miss && mine0 == max_sweeps) mine0 = it;
-            } else {
-                if ((unsigned)miss == 0u && mine0 == max_sweeps) mine0 = it;
-                if ((unsigned)(miss >> 32) == 0u && mine1 == max_sweeps) mine1 = it;
-            }
+            FLEX_SWEEP_NOTE_PASS(miss, it);
             if (!wave_miss) break;
             if (!use_seg) continue;
             if (!fine && __ballot(!(m < FLEX_SWEEP_COARSE)) == 0ull) fine = true;
@@ -525,7 +543,17 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
         ++it;
         float dr = cr, di = ci, pdr = 0.0f, pdi = 0.0f;
         bool done = false;
-        for (int k = 0; k < FLEX_SWEEP_REANCHOR && it < max_sweeps; ++k) {
+        // ONE test per sweep against the threshold this phase can act on.  A threshold below the coarse one is only trusted on a
+        // re-anchored iterate (with the extrapolation an increment can contract by more than coarse / tol in one step and pass
+        // the fp32 test while still hanging on its first anchor): before that, passing the coarse threshold ends the phase and
+        // re-anchors; afterwards (or when tol itself is not below coarse) passing tol ends the solve.  One counter bounds the
+        // phase (re-anchor distance and what is left of max_sweeps).  Round 5: the two tests, two counters and their flags were
+        // 28 scalar instructions and six branches per sweep — the launch is issue-bound and they are not free (HISTORY 15.5).
+        const bool to_tol = fine || tolf >= coarsef;
+        const float thr = to_tol ? tolf : coarsef;
+        const int k_end = min((int)FLEX_SWEEP_REANCHOR, max_sweeps - it);
+        int k = 0;
+        for (; k < k_end; ++k) {
             const float vr = ear + dr, vi = eai + di;                                       // V = V_a + d
             const float pr = vr * ear - vi * eai, pi = vr * eai + vi * ear;                 // P = V V_a
             const float rr = __builtin_amdgcn_rcpf(pr * pr + pi * pi);
@@ -534,30 +562,27 @@ __device__ __forceinline__ int pf_sweep(const DevNet* __restrict__ net, const La
             float xr = -ur * rr, xi = ui * rr;                                              // delta = -conj(S d / P)
             const float gr = pdr - xr, gi = pdi - xi;
             const float m = fmaxf(fabsf(vr * gr + vi * gi), fabsf(vi * gr - vr * gi));
-            const unsigned long long miss = __ballot(!(m < tolf));
-            const bool wave_miss = miss != 0ull;
-            if constexpr (EPW == 1) {
-                if (!wave_miss && mine0 == max_sweeps) mine0 = it;
-            } else {
-                if ((unsigned)miss == 0u && mine0 == max_sweeps) mine0 = it;
-                if ((unsigned)(miss >> 32) == 0u && mine1 == max_sweeps) mine1 = it;
-            }
-            // a threshold below the coarse one is only trusted on a re-anchored iterate: with the extrapolation an increment
-            // can contract by more than coarse / tol in one step and pass the fp32 test while still hanging on its first anchor
-            if (!wave_miss && (fine || tolf >= coarsef)) { done = true; break; }
-            if (!fine && __ballot(!(m < coarsef)) == 0ull) { fine = true; break; }          // re-anchor now
+#ifdef FLEX_GROUP_SWEEP_STAT
+            { const unsigned long long miss = __ballot(!(m < tolf)); FLEX_SWEEP_NOTE_PASS(miss, it + k); }
+#endif
+            if (__ballot(!(m < thr)) == 0ull) { done = to_tol; fine = true; break; }       // (fine: re-anchor now, or moot)
             pdr = xr; pdi = xi;
             zbus_apply_f32<EPW>(ln, mkf, rf, xf, seg_rounds, xr, xi);
             const float fac = k == 1 ? relax : 1.0f;                                        // d_3 + omega (d_3 - d_1); x * 1.0f is exact
             xr *= fac; xi *= fac; pdr *= fac; pdi *= fac;
             dr = cr + xr; di = ci + xi;
-            ++it;
         }
+        it += k;                                    // (each completed pass of the loop is one sweep)
         e = ea + (double)dr; f = fa + (double)di;
         if (done) break;
     }
+#undef FLEX_SWEEP_NOTE_PASS
+#ifdef FLEX_GROUP_SWEEP_STAT
     if constexpr (EPW == 1) return mine0;
     else return ln.grp ? mine1 : mine0;
+#else
+    return it;
+#endif
 }
 
 // ---- Newton-Raphson with a DENSE LU of the 2n x 2n Jacobian (the north-star's "small batched dense solve") ----
