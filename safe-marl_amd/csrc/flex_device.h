@@ -64,7 +64,9 @@ struct LaneNet {
     int bus, par, lev, agent;
     bool pq, par_slack;
     double g, b, gd, bd, r, x;
-    int ch[FLEX_MAX_CHILDREN];   // wavefront lanes of the children (-1: none)
+    int cha[FLEX_MAX_CHILDREN];  // ds_bpermute byte addresses (4 x wavefront lane) of the children, -1: none.  Only the slots
+                                 // the feeder uses (net->max_children: 2 on IEEE-33) are loaded; the others are never read
+    int par_addr;                // the parent's, likewise
     int sub_end, seg_par, seg_depth;
     int mk[6];                   // high words (1.0 or 0.0) of the segmented-scan step masks
 };
@@ -82,10 +84,24 @@ __device__ __forceinline__ void load_lane_net(const DevNet* __restrict__ net, in
     ln.pq = ln.bus >= 0;
     ln.g = net->g[l]; ln.b = net->b[l]; ln.gd = net->gd[l]; ln.bd = net->bd[l];
     ln.r = net->r[l]; ln.x = net->x[l];
+    ln.par_addr = ln.par << 2;
+    // Child slots 0 and 1 unconditionally (a conditional load is a branch with a full s_waitcnt behind it: a memory round trip
+    // of its own in the prologue); the other six in ONE uniform branch, which IEEE-33 (two children at most) never takes
 #pragma unroll
     for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) {
-        const int c = net->child_lane[k][l];
-        ln.ch[k] = c >= 0 ? c + base : -1;
+        if (k < 2) {
+            const int c = net->child_lane[k][l];
+            ln.cha[k] = c >= 0 ? (c + base) << 2 : -1;
+        } else {
+            ln.cha[k] = -1;
+        }
+    }
+    if (net->max_children > 2) {
+        int c[FLEX_MAX_CHILDREN];
+#pragma unroll
+        for (int k = 2; k < FLEX_MAX_CHILDREN; ++k) c[k] = net->child_lane[k][l];
+#pragma unroll
+        for (int k = 2; k < FLEX_MAX_CHILDREN; ++k) ln.cha[k] = c[k] >= 0 ? (c[k] + base) << 2 : -1;
     }
     ln.sub_end = net->sub_end[l] + base;
     ln.seg_par = net->seg_par[l] + base;
@@ -205,6 +221,12 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
                             __builtin_amdgcn_readlane(__double2loint(x), l));
 }
+// the value lane `byte_addr / 4` holds (ds_bpermute on both words; the address is precomputed: __shfl rebuilds it —
+// mask, or, shift — at every call)
+__device__ __forceinline__ double pull_f64(double x, int byte_addr) {
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(x)),
+                            __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(x)));
+}
 // sum over the lanes of each group, returned in every lane of that group
 template <int EPW>
 __device__ __forceinline__ double grp_sum(double v, int grp) {
@@ -218,7 +240,10 @@ __device__ __forceinline__ double grp_sum(double v, int grp) {
 }
 // Five independent group sums advanced step by step (the reward's five terms): issued one after the other each
 // scan is a chain of dependent DPP moves and adds; interleaved, the chains hide each other's latency.
-template <int EPW>
+// BROADCAST = false: the sums are left where the inclusive scan puts them — in the LAST lane of each group — and the caller
+// lets that lane do the stores (round 5: handing them to every lane was four v_readlane, two moves and two selects per
+// value, forty instructions for results one lane writes).
+template <int EPW, bool BROADCAST = true>
 __device__ __forceinline__ void grp_sum5(double (&v)[5], int grp) {
 #define FLEX_SUM5_STEP(CTRL, RM, BC) { double t[5]; \
     _Pragma("unroll") for (int i = 0; i < 5; ++i) t[i] = dpp_mov_f64<CTRL, RM, BC>(v[i]); \
@@ -230,6 +255,7 @@ __device__ __forceinline__ void grp_sum5(double (&v)[5], int grp) {
     FLEX_SUM5_STEP(0x142, 0xA, false)
     if constexpr (EPW == 1) FLEX_SUM5_STEP(0x143, 0xC, false)
 #undef FLEX_SUM5_STEP
+    if constexpr (!BROADCAST) return;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         if constexpr (EPW == 1) {
@@ -269,20 +295,21 @@ struct NewtonLocal { double rhs0, rhs1, d11, d12, d21, d22; bool miss; };
 __device__ __forceinline__ NewtonLocal newton_local(const LaneNet& ln, int maxc, double ps, double qs, double e,
                                                     double f, double tol) {
     NewtonLocal o;
-    const double ep0 = __shfl(e, ln.par, FLEX_WAVE), fp0 = __shfl(f, ln.par, FLEX_WAVE);
+    const double ep0 = pull_f64(e, ln.par_addr), fp0 = pull_f64(f, ln.par_addr);
     const double ep = ln.par_slack ? 1.0 : ep0, fp = ln.par_slack ? 0.0 : fp0;
     const double de = ep - e, df = fp - f;
     const double jr = ln.g * de - ln.b * df, ji = ln.b * de + ln.g * df;   // branch current parent -> bus
     double ir = -jr, ii = -ji;   // current injected at this bus = children's inflow - own inflow
+    // (the child slots in use are 0 .. maxc - 1: leave at the first unused one — as eight independently guarded blocks the
+    //  unused slots cost a scalar test and a branch each on every evaluation)
 #pragma unroll
     for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) {
-        if (k < maxc) {
-            const bool has = ln.ch[k] >= 0;
-            const int src = has ? ln.ch[k] : ln.lane;
-            const double tr = __shfl(jr, src, FLEX_WAVE), ti = __shfl(ji, src, FLEX_WAVE);
-            ir += has ? tr : 0.0;
-            ii += has ? ti : 0.0;
-        }
+        if (k >= maxc) break;
+        const bool has = ln.cha[k] >= 0;
+        const int src = has ? ln.cha[k] : (ln.lane << 2);
+        const double tr = pull_f64(jr, src), ti = pull_f64(ji, src);
+        ir += has ? tr : 0.0;
+        ii += has ? ti : 0.0;
     }
     // power mismatch  S_calc - S_spec,  S_calc = V conj(I);  NaN counts as a miss
     const double dP = e * ir + f * ii - ps;
@@ -343,11 +370,11 @@ __device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, c
 #pragma unroll
             for (int k = 0; k < FLEX_MAX_CHILDREN; ++k) {
                 if (k < nslots) {
-                    const bool has = (ln.ch[k] >= 0) && (ln.lev == L - 1);
-                    const int src = (ln.ch[k] >= 0) ? ln.ch[k] : lane;
-                    const double a11 = __shfl(s11, src, FLEX_WAVE), a12 = __shfl(s12, src, FLEX_WAVE);
-                    const double a21 = __shfl(s21, src, FLEX_WAVE), a22 = __shfl(s22, src, FLEX_WAVE);
-                    const double b0 = __shfl(u0, src, FLEX_WAVE), b1 = __shfl(u1, src, FLEX_WAVE);
+                    const bool has = (ln.cha[k] >= 0) && (ln.lev == L - 1);
+                    const int src = (ln.cha[k] >= 0) ? ln.cha[k] : (lane << 2);
+                    const double a11 = pull_f64(s11, src), a12 = pull_f64(s12, src);
+                    const double a21 = pull_f64(s21, src), a22 = pull_f64(s22, src);
+                    const double b0 = pull_f64(u0, src), b1 = pull_f64(u1, src);
                     if (has) {
                         d11 -= a11; d12 -= a12; d21 -= a21; d22 -= a22;
                         rhs0 += b0; rhs1 += b1;
@@ -360,7 +387,7 @@ __device__ __forceinline__ bool pf_newton_tree(const DevNet* __restrict__ net, c
         const double i11 = d22 * idet, i12 = -d12 * idet, i21 = -d21 * idet, i22 = d11 * idet;
         double dx0 = 0.0, dx1 = 0.0;
         for (int L = 1; L < n_levels; ++L) {
-            const double q0 = __shfl(dx0, ln.par, FLEX_WAVE), q1 = __shfl(dx1, ln.par, FLEX_WAVE);
+            const double q0 = pull_f64(dx0, ln.par_addr), q1 = pull_f64(dx1, ln.par_addr);
             const double p0 = ln.par_slack ? 0.0 : q0, p1 = ln.par_slack ? 0.0 : q1;
             const double w0 = rhs0 + ln.g * p0 - ln.b * p1, w1 = rhs1 + ln.b * p0 + ln.g * p1;
             if (ln.lev == L) {

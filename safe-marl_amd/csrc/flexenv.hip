@@ -126,7 +126,7 @@ struct EnvSlot {
 
 // Reward terms, env:679-706.  Building terms live in building lanes, voltages in PQ lanes; the slack bus
 // (|V| = 1 exactly) contributes max(0, 1 - v_max, v_min - 1) to the penalty over ALL buses.
-struct RewardOut { double reward, revenue, der, ess, disc, vpen; };
+struct RewardOut { double reward, revenue, der, ess, disc, vpen; };     // (valid in the last lane of each group)
 template <int EPW>
 __device__ __forceinline__ RewardOut reward_terms(const FlexCfg& c, const LaneNet& ln, bool is_bld, double price,
                                                   double pred, double ch, double dis, double q, double v) {
@@ -136,7 +136,7 @@ __device__ __forceinline__ RewardOut reward_terms(const FlexCfg& c, const LaneNe
                    is_bld ? c.ess_cost * (ch + dis) : 0.0,
                    is_bld ? c.discomfort_coeff * pred * pred : 0.0,
                    ln.pq ? c.voltage_coeff * fmax(0.0, fmax(v - c.v_max, c.v_min - v)) : 0.0};
-    grp_sum5<EPW>(t, ln.grp);
+    grp_sum5<EPW, false>(t, ln.grp);                          // valid in the group's LAST lane only: that lane stores them
     const double slack_pen = c.voltage_coeff * fmax(0.0, fmax(1.0 - c.v_max, c.v_min - 1.0));
     r.revenue = t[0]; r.der = t[1]; r.ess = t[2]; r.disc = t[3]; r.vpen = t[4] + slack_pen;
     r.reward = r.revenue - r.der - r.ess - r.disc - r.vpen;
@@ -484,7 +484,6 @@ __device__ __forceinline__ void flex_reset_body(const KArgs& a, int env, bool va
     }
     if (ln.l == 0 && valid) {
         a.st.vm[(int64_t)env * nb + a.net->slack_bus] = 1.0;   // pf.py:53: Vsqr[slack] = 1
-        a.st.cumrew[env] = 0.0;                             // env:77
         ie[IF_STEPS] = 1;                                   // env:76
         ie[IF_START] = start;
         ie[IF_ROW] = (int32_t)row;
@@ -494,6 +493,7 @@ __device__ __forceinline__ void flex_reset_body(const KArgs& a, int env, bool va
         ie[IF_SWEEPS] = sweeps;
         if (failed) { if (or_failed) { if (!ok) failed[env] = 1; } else failed[env] = ok ? 0 : 1; }
     }
+    if (ln.l == FLEX_WAVE / EPW - 1 && valid) a.st.cumrew[env] = 0.0;   // env:77 (the lane that writes it in the step, too)
     obs_ring_clear<EPW>(a, env, valid, ln);               // env:79-80: the history starts empty
     if (want_obs) push_and_emit_obs<EPW, ObsT>(a, env, valid, ln, 0, pd, qd, ppv, v, price, e_new, obs, rows, true);
 }
@@ -723,10 +723,10 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     // FLEX_STEP_AUTORESET: an environment that just terminated restarts inside this launch; its observation row
     // then holds the first observation of the new episode (the terminal observation is not materialised)
     const bool restart = auto_reset && term && valid;
-    if (ln.l == 0 && valid) {
+    // The group's LAST lane holds the reward terms (reward_terms: the scan's totals stay where they fall) and writes what is
+    // made of them; lane 0 writes the rest.  cumrew is the one cell a restart below writes as well — from the same lane.
+    if (ln.l == LW - 1 && valid) {
         st_at<double>(reward + env0, g * 8, rwd);
-        done[env] = term ? 1 : 0;
-        if (failed) failed[env] = ok ? 0 : 1;
         if (info) {
             double* const io = info + (int64_t)env0 * FLEX_INFO_W;
             const uint32_t oi = g * (FLEX_INFO_W * 8);
@@ -735,6 +735,10 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
             st_at<double>(io, oi + 48, cum_before);                                    // A9
         }
         st_at<double>(b_cum, g * 8, cum_before + rwd);                                 // env:343
+    }
+    if (ln.l == 0 && valid) {
+        done[env] = term ? 1 : 0;
+        if (failed) failed[env] = ok ? 0 : 1;
         // steps (env:342), start, row (env:340 reads row `steps`: A2) and the push count of the fast observation paths in ONE
         // 16-byte store, the solver statistics in one 8-byte store (five 4-byte stores until round 4); an environment that
         // restarts below overwrites them afterwards — same lane, program order
@@ -759,7 +763,7 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
 #pragma unroll
             for (int r = 0; r < 3; ++r) { const int i = ln.l + LW * r; if (i < h4) hd[i] = sk_hv[r] * keep; }
             if (ln.l < sk.act_w) sm[ln.l] = sk_av;                                      // model.py:232
-            if (ln.l == 0) {
+            if (ln.l == LW - 1) {                                                       // (the lane that holds the reward terms)
                 const int na_ = cz.n_agents;
                 for (int j = 0; j < na_; ++j) sm[sk.act_w + j] = (float)rwd;            // model.py:235: one reward, n copies
                 sm[sk.act_w + na_] = 1.0f - keep;
