@@ -1009,6 +1009,7 @@ def main():
                 "timed_after": ("the `sustained` leg (%d steps), then W warm-up steps" % sustained["steps"]) if sustained else "W warm-up steps",
                 "device_ms_per_step": dev_ms / a.steps, "solver": ("sweep (mixed fp64/fp32 increments) + fp64 Newton verification" if a.solver == "sweep" else "newton (fp64, tree elimination)"),
                 "pf_newton_iters_mean": iters_mean, "pf_sweeps_mean": sweeps_mean,
+                "pf_sweeps_counts": "sweeps executed by the environment's wavefront (two environments per wavefront run until both have passed)",
                 "solver_failed_frac": failed_frac,
             },
             "roofline": dict({

@@ -138,7 +138,9 @@ enum FlexField {
     FLEX_PEEK_START = 11,       /* i32 [N]          episode start row         env:477 */
     FLEX_PEEK_PF_ITERS = 12,    /* i32 [N]          Newton iterations of the last solve */
     FLEX_PEEK_EPISODE = 13,     /* i32 [N]          reset-attempt counter of the Philox stream */
-    FLEX_PEEK_PF_SWEEPS = 14    /* i32 [N]          sweeps of the last solve (FLEX_SOLVER_SWEEP) */
+    FLEX_PEEK_PF_SWEEPS = 14    /* i32 [N]          sweeps the environment's wavefront executed in the last solve
+                                 *                   (FLEX_SOLVER_SWEEP; with two environments per wavefront both run until the slower
+                                 *                   one's test has passed) */
 };
 
 /* Replaces FlexibilityProvisionEnv.__init__ (env:34-72) minus its reset; `series.table` must stay
