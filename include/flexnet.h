@@ -342,6 +342,12 @@ int flexnet_critic_td_backward(const FlexCriticTailArgs* critic, const FlexTdLos
  * gradients from the partial rows, loss, running statistics) — it needs phase 1 of the same arguments complete on its stream
  * and nothing of flexnet_wgrad's; 3: both, = flexnet_critic_td_backward. */
 int flexnet_critic_td_backward_phases(const FlexCriticTailArgs* critic, const FlexTdLossArgs* td, int32_t phases, void* stream);
+/* Phase 2 of the above riding in the second-stage launch of the critic's first-layer weight gradient (round 5): what
+ * flexnet_critic_td_backward_phases(critic, td, 2, stream) followed by flexnet_wgrad(w, stream) compute, in one launch fewer
+ * (model.py:43-50 runs ten value sub-updates per event; a replayed graph's small launches each wait for the one before).
+ * Needs phase 1 of the same (critic, td) complete on `stream`.  Only the weight gradient of a 64-unit layer over more than
+ * 64 input columns carries the rider: FLEXNET_EUNSUPPORTED otherwise, with nothing launched. */
+int flexnet_wgrad_critic_finish(const FlexWgradArgs* w, const FlexCriticTailArgs* critic, const FlexTdLossArgs* td, void* stream);
 
 /* out[0] = scale * sum(x[0 .. n)) in a FIXED order (fp64 partial sums of 64 blocks, one-wavefront finish): the scalar
  * means the losses report — policy_loss = -Q(s, pi(s)).mean() (madrl/models/maddpg.py:107), the entropy of
@@ -478,6 +484,11 @@ typedef struct {
 } FlexGatherArgs;
 
 int flexnet_gather_rows(const FlexGatherArgs* args, void* stream);
+/* The same launch carrying the reward-statistics pass of the value loss (= flexnet_td_stats(td), model.py:308-323) as extra
+ * blocks (round 5): jobs reward_job .. reward_job + reward_jobs - 1 (one, or two for a window that wraps the ring's seam)
+ * are the copies of the [td->rows, td->n_agents] reward rows; the statistics are taken from the rows those jobs read, in the
+ * partition flexnet_td_stats uses (bit-identical sums), into td->workspace.  The consumer then runs with stats_ready = 1. */
+int flexnet_gather_rows_td(const FlexGatherArgs* args, int32_t reward_job, int32_t reward_jobs, const FlexTdLossArgs* td, void* stream);
 
 #ifdef __cplusplus
 }

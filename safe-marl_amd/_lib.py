@@ -74,8 +74,8 @@ SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_obs_view", "flexenv_obs_source", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_rollout_burst", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version", "flexenv_abi_version",
-    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_td_stats", "flexnet_critic_td_backward", "flexnet_critic_td_backward_phases",
-    "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gather_window", "flexnet_linear2", "flexnet_gru_backward",
+    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_td_stats", "flexnet_critic_td_backward", "flexnet_critic_td_backward_phases", "flexnet_wgrad_critic_finish",
+    "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gather_rows_td", "flexnet_gather_window", "flexnet_linear2", "flexnet_gru_backward",
     "flexopf_qp_work_doubles", "flexopf_qp_solve",
 )
 
@@ -290,6 +290,8 @@ def load():
     lib.flexnet_rollout_pack.restype = C.c_int
     lib.flexnet_gather_rows.argtypes = [C.POINTER(FlexGatherArgs), vp]
     lib.flexnet_gather_rows.restype = C.c_int
+    lib.flexnet_gather_rows_td.argtypes = [C.POINTER(FlexGatherArgs), i32, i32, C.POINTER(FlexTdLossArgs), vp]
+    lib.flexnet_gather_rows_td.restype = C.c_int
     lib.flexnet_gru_backward.argtypes = [C.POINTER(FlexGruBwdArgs), vp]
     lib.flexnet_gru_backward.restype = C.c_int
     lib.flexenv_set_step_counter.argtypes = [vp, vp, C.c_int64]
@@ -304,6 +306,8 @@ def load():
     lib.flexnet_critic_td_backward.restype = C.c_int
     lib.flexnet_critic_td_backward_phases.argtypes = [C.POINTER(FlexCriticTailArgs), C.POINTER(FlexTdLossArgs), i32, vp]
     lib.flexnet_critic_td_backward_phases.restype = C.c_int
+    lib.flexnet_wgrad_critic_finish.argtypes = [C.POINTER(FlexWgradArgs), C.POINTER(FlexCriticTailArgs), C.POINTER(FlexTdLossArgs), vp]
+    lib.flexnet_wgrad_critic_finish.restype = C.c_int
     lib.flexnet_wgrad.argtypes = [C.POINTER(FlexWgradArgs), vp]
     lib.flexnet_wgrad.restype = C.c_int
     lib.flexnet_clip_rmsprop.argtypes = [C.POINTER(FlexClipRmspropArgs), vp]

@@ -15,6 +15,7 @@
 #include "flex_reduce.h"
 #include "flex_td.h"
 #include "flex_launch.h"
+#include "critic_finish.h"
 
 #define HID FLEXNET_HID
 #define CRT 4                      // rows per wavefront tile
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_fwd_kernel(FlexCriticT
 // after a barrier wavefront w accumulates ITS 16 columns of dW2 (dW2[j][i] += sum_r dz2[r][j] a1[r][i], i in
 // [16 w, 16 w + 16)) over all 16 rows — 16 register accumulators per lane instead of 64, no fold across wavefronts.
 #define BT (CW * CRT)
-#define CRITIC_WS_PITCH 4416                // floats per block in the workspace (4353 used)
+// (CRITIC_WS_PITCH: floats per block in the workspace, 4353 used — csrc/critic_finish.h)
 // PGRAD = false: dz1 only (the policy loss differentiates THROUGH the critic; its parameters take no step there).
 template <bool PGRAD>
 __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticTailArgs a) {
@@ -247,28 +248,10 @@ __global__ __launch_bounds__(64 * CW, 2) void critic_tail_bwd_kernel(FlexCriticT
     }
 }
 
-// second stage of the deterministic path: element e of every block's partial row, summed in a fixed order, ADDED to
-// the caller's gradient tensor (or stored there: overwrite_grads).  64 elements x 16 block groups per thread block: each thread walks its group's rows
-// with eight loads in flight, the 16 group sums are folded through LDS in index order.
+// second stage of the deterministic path (critic_reduce: csrc/critic_finish.h)
 #define RED_G FLEX_RED_G
-__device__ __forceinline__ void critic_reduce(const FlexCriticTailArgs& a, int blocks, int chunk);
-
 __global__ __launch_bounds__(64 * RED_G) void critic_reduce_kernel(FlexCriticTailArgs a, int blocks) {
     critic_reduce(a, blocks, blockIdx.x);
-}
-
-__device__ __forceinline__ void critic_reduce(const FlexCriticTailArgs& a, int blocks, int chunk) {
-    const int e = chunk * 64 + (threadIdx.x & 63);
-    float sum;
-    if (!flex_reduce_rows(a.workspace + e, CRITIC_WS_PITCH, blocks, e < HID * HID + 4 * HID + 1, sum)) return;
-    float* dst;
-    if (e < HID * HID) dst = a.d_fc2_w + e;
-    else if (e < HID * HID + HID) dst = a.d_fc2_b + (e - HID * HID);
-    else if (e < HID * HID + 2 * HID) dst = a.d_fc3_w + (e - HID * HID - HID);
-    else if (e < HID * HID + 3 * HID) { if (!a.layernorm) return; dst = a.d_ln_w + (e - HID * HID - 2 * HID); }
-    else if (e < HID * HID + 4 * HID) { if (!a.layernorm) return; dst = a.d_ln_b + (e - HID * HID - 3 * HID); }
-    else dst = a.d_fc3_b;
-    *dst = a.overwrite_grads ? sum : *dst + sum;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1268,7 +1251,6 @@ static int critic_mfma_grid(int rows) {
 // d_z_shared[b] = sum_i dz1[b n + i] (stored), d_z_id[i] = sum_b dz1[b n + i] (per-block partial rows in the workspace,
 // then summed over blocks in a fixed order) — instead of two library reductions that each read dz1 again.
 #define DZF_W 4
-#define DZF_PITCH (FLEXNET_MAX_AGENTS * HID)
 static_assert(DZF_PITCH == C16_IDW, "the 16-row kernel writes the fold kernel's partial rows itself (SM)");
 __global__ __launch_bounds__(64 * DZF_W) void critic_dz_fold_kernel(FlexCriticTailArgs a, int64_t ws_off) {
     __shared__ float fold[DZF_W][DZF_PITCH];
@@ -1299,16 +1281,6 @@ __global__ __launch_bounds__(64 * DZF_W) void critic_dz_fold_kernel(FlexCriticTa
     }
 }
 
-// agent `agent`'s id-column sums from the fold kernel's per-block partial rows (fixed order)
-__device__ __forceinline__ void critic_dz_reduce(const FlexCriticTailArgs& a, const float* partials, int blocks, int agent) {
-    const int e = agent * 64 + (threadIdx.x & 63);                        // unit ex
-    float sum;
-    if (!flex_reduce_rows(partials + e, DZF_PITCH, blocks, true, sum)) return;
-    const int sa = a.d_z_id_agent_stride, su = a.d_z_id_unit_stride;
-    if (sa == 0 && su == 0) a.d_z_id[e] = sum;
-    else a.d_z_id[(int64_t)agent * sa + (int64_t)(threadIdx.x & 63) * su] = sum;
-}
-
 __global__ __launch_bounds__(64 * RED_G) void critic_dz_reduce_kernel(FlexCriticTailArgs a, int blocks) {
     critic_dz_reduce(a, a.workspace, blocks, blockIdx.x);
 }
@@ -1326,16 +1298,8 @@ static int critic_dz_fold(const FlexCriticTailArgs& k, hipStream_t stream) {
 // Everything that follows the two first-stage kernels of flexnet_critic_td_backward in ONE launch: the parameter gradients'
 // fixed-order sums (blocks 0 .. CRITIC_RED_BLOCKS - 1), the id-column sums (one block per agent) and the loss / running
 // statistics finish (last block, one wavefront).
-#define CRITIC_RED_BLOCKS ((HID * HID + 4 * HID + 1 + 63) / 64)
-__global__ __launch_bounds__(64 * RED_G) void critic_td_finish_kernel(FlexCriticTailArgs a, FlexTdLossArgs td, int nb, int dz_blocks,
-                                                                      int64_t dz_off) {
-    const int bx = blockIdx.x;
-    if (bx < CRITIC_RED_BLOCKS) { critic_reduce(a, nb, bx); return; }
-    if (bx < CRITIC_RED_BLOCKS + (dz_blocks > 0 ? a.n_agents : 0)) {
-        critic_dz_reduce(a, a.workspace + dz_off, dz_blocks, bx - CRITIC_RED_BLOCKS);
-        return;
-    }
-    if (threadIdx.x < 64) td_finish(td, nb, threadIdx.x);
+__global__ __launch_bounds__(64 * RED_G) void critic_td_finish_kernel(CriticFinishK k) {
+    critic_finish_block(k, blockIdx.x);
 }
 
 static int critic_check(const FlexCriticTailArgs* a, bool backward, bool need_dq = true) {
@@ -1407,12 +1371,8 @@ extern "C" int flexnet_critic_tail_backward(const FlexCriticTailArgs* a, void* s
     return critic_dz_fold(*a, (hipStream_t)stream);        // after the main launches: it reuses their workspace
 }
 
-// The value loss and the critic's backward in one pass (maddpg.py:100-123 + mlp_critic.py:25-33): reward statistics, then
-// the matrix-core backward forming q, the TD error, dLoss/dq and the loss partial sums itself, the fixed-order second
-// stage, the loss / running-statistics finish, and (composed input) dz1 folded onto its sources.
-// phases: 1 = (statistics pass unless stats_ready) + the backward kernel, 2 = the finish launch, 3 = both (include/flexnet.h)
-extern "C" int flexnet_critic_td_backward_phases(const FlexCriticTailArgs* a, const FlexTdLossArgs* t, int32_t phases, void* stream) {
-    if (phases < 1 || phases > 3) return FLEXNET_EINVAL;
+// the checks and the launch geometry both halves of flexnet_critic_td_backward share (csrc/critic_finish.h)
+int critic_finish_prepare(const FlexCriticTailArgs* a, const FlexTdLossArgs* t, CriticFinishK* out) {
     const int rc = critic_check(a, true, false);
     if (rc != FLEXNET_OK) return rc;
     if (!t || t->rows < 1 || t->n_agents < 1 || !t->reward || !t->done || !t->next_q || !t->loss || !t->workspace ||
@@ -1424,22 +1384,12 @@ extern "C" int flexnet_critic_td_backward_phases(const FlexCriticTailArgs* a, co
     if (!a->d_fc2_w || !two_stage || a->variant != 0 || a->rows < CRITIC_MFMA_MIN_ROWS) return FLEXNET_EUNSUPPORTED;
     const int nb = critic_mfma_grid(a->rows);
     if (nb < 1 || nb > 1024 || nb > TD_SQ_MAX) return FLEXNET_EHIP;
-    hipStream_t s = (hipStream_t)stream;
-    if ((phases & 1) && t->normalise && !t->stats_ready) flex_td_launch_stats(*t, s);
     // dz1 folded onto its sources: the partial rows of the id-column sums go behind the backward kernel's, so ONE launch
     // finishes both.  16-row kernel on a composed input (SM): it forms d_z_shared and those partial rows itself; otherwise
     // the fold kernel reads dz1 back.
     const int64_t dz_off = (int64_t)nb * CRITIC_WS_PITCH;
     const bool sm = a->variant_pgrad32 == 0 && a->d_z_shared && !a->z1;
     if (sm && (t->n_agents != a->n_agents || dz_off + (int64_t)nb * DZF_PITCH > a->workspace_floats)) return FLEXNET_EINVAL;
-    if (phases & 1) {
-        if (a->variant_pgrad32 == 1)  // the 32-row kernel (one wavefront per SIMD), kept as the cross-check and for A/B timing
-            hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<true>, dim3(nb), dim3(64 * CPW), 0, s, *a, *t);
-        else if (sm)
-            critic_launch_pgrad16<true>(nb, true, *a, *t, dz_off, s);
-        else
-            critic_launch_pgrad16<true>(nb, false, *a, *t, dz_off, s);
-    }
     int dz_blocks = 0;
     if (sm) {
         dz_blocks = nb;
@@ -1448,11 +1398,34 @@ extern "C" int flexnet_critic_td_backward_phases(const FlexCriticTailArgs* a, co
         dz_blocks = (samples + DZF_W - 1) / DZF_W;
         if (dz_blocks > 256) dz_blocks = 256;
         if (dz_off + (int64_t)dz_blocks * DZF_PITCH > a->workspace_floats) return FLEXNET_EINVAL;
-        if (phases & 1) hipLaunchKernelGGL(critic_dz_fold_kernel, dim3(dz_blocks), dim3(64 * DZF_W), 0, s, *a, dz_off);
+    }
+    out->a = *a; out->td = *t; out->nb = nb; out->dz_blocks = dz_blocks; out->dz_off = dz_off; out->pad = 0;
+    out->blocks = CRITIC_RED_BLOCKS + (dz_blocks > 0 ? a->n_agents : 0) + 1;
+    return FLEXNET_OK;
+}
+
+// The value loss and the critic's backward in one pass (maddpg.py:100-123 + mlp_critic.py:25-33): reward statistics, then
+// the matrix-core backward forming q, the TD error, dLoss/dq and the loss partial sums itself, the fixed-order second
+// stage, the loss / running-statistics finish, and (composed input) dz1 folded onto its sources.
+// phases: 1 = (statistics pass unless stats_ready) + the backward kernel, 2 = the finish launch, 3 = both (include/flexnet.h)
+extern "C" int flexnet_critic_td_backward_phases(const FlexCriticTailArgs* a, const FlexTdLossArgs* t, int32_t phases, void* stream) {
+    if (phases < 1 || phases > 3) return FLEXNET_EINVAL;
+    CriticFinishK k;
+    const int rc = critic_finish_prepare(a, t, &k);
+    if (rc != FLEXNET_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if ((phases & 1) && t->normalise && !t->stats_ready) flex_td_launch_stats(*t, s);
+    const bool sm = a->variant_pgrad32 == 0 && a->d_z_shared && !a->z1;
+    if (phases & 1) {
+        if (a->variant_pgrad32 == 1)  // the 32-row kernel (one wavefront per SIMD), kept as the cross-check and for A/B timing
+            hipLaunchKernelGGL(critic_tail_pgrad_mfma_kernel<true>, dim3(k.nb), dim3(64 * CPW), 0, s, *a, *t);
+        else
+            critic_launch_pgrad16<true>(k.nb, sm, *a, *t, k.dz_off, s);
+        if (!sm && a->d_z_shared)
+            hipLaunchKernelGGL(critic_dz_fold_kernel, dim3(k.dz_blocks), dim3(64 * DZF_W), 0, s, *a, k.dz_off);
     }
     if (phases & 2)
-        hipLaunchKernelGGL(critic_td_finish_kernel, dim3(CRITIC_RED_BLOCKS + (dz_blocks > 0 ? a->n_agents : 0) + 1), dim3(64 * RED_G),
-                           0, s, *a, *t, nb, dz_blocks, dz_off);
+        hipLaunchKernelGGL(critic_td_finish_kernel, dim3(k.blocks), dim3(64 * RED_G), 0, s, k);
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 

@@ -62,6 +62,42 @@ __device__ __forceinline__ void td_finish(const FlexTdLossArgs& a, int sq_blocks
     }
 }
 
+// The statistics pass of block `block` of TD_BLOCKS (TD_THREADS threads): per-block column sums and sums of squares of the
+// reward (fp64, fixed order) into the workspace.  The [rows, n_agents] reward rows may lie in up to TWO pieces (a window that
+// wraps a ring's seam, read where the replay keeps it): rows [0, rows0) at src0 + b * stride0, the rest at src1 + (b - rows0)
+// * stride1.  td_stats_kernel runs it on a.reward itself; as blocks riding in flexnet_gather_rows_td's launch it reads the
+// rows the same launch copies into a.reward — same values, same partition of the rows over blocks and threads, same sums.
+struct TdRewardRows { const float* src0; const float* src1; int64_t rows0; int32_t stride0, stride1; };
+__device__ __forceinline__ void td_stats_block(const FlexTdLossArgs& a, const TdRewardRows& rr, int block) {
+    const int tid = threadIdx.x, n = a.n_agents;
+    double s[TD_NA], ss[TD_NA];
+#pragma unroll
+    for (int j = 0; j < TD_NA; ++j) { s[j] = 0.0; ss[j] = 0.0; }
+    for (int b = block * TD_THREADS + tid; b < a.rows; b += TD_BLOCKS * TD_THREADS) {
+        const float* r = b < rr.rows0 ? rr.src0 + (int64_t)b * rr.stride0 : rr.src1 + ((int64_t)b - rr.rows0) * rr.stride1;
+#pragma unroll
+        for (int j = 0; j < TD_NA; ++j)
+            if (j < n) { const double v = (double)r[j]; s[j] += v; ss[j] += v * v; }
+    }
+    // wavefront sums by shuffles (fixed tree), then the block's four wavefronts in index order
+    __shared__ double part[TD_THREADS / 64][2 * TD_NA];
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 2 * TD_NA; ++q) {
+        double v = q < TD_NA ? s[q < TD_NA ? q : 0] : ss[q < TD_NA ? 0 : q - TD_NA];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) part[wave][q] = v;
+    }
+    __syncthreads();
+    if (tid < 2 * TD_NA) {
+        double t = part[0][tid];
+#pragma unroll
+        for (int w = 1; w < TD_THREADS / 64; ++w) t += part[w][tid];
+        reinterpret_cast<double*>(a.workspace)[(int64_t)block * 2 * TD_NA + tid] = t;
+    }
+}
+
 // csrc/tdloss.hip: the statistics pass (per-block column sums of the reward) and the one-wavefront finish (loss from
 // `sq_blocks` partial sums of squared errors; running statistics moved as nn.BatchNorm1d moves them)
 void flex_td_launch_stats(const FlexTdLossArgs& a, hipStream_t s);

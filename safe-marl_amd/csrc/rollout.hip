@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "flexnet.h"
+#include "flex_td.h"
 
 #define PACK_THREADS 256
 #define PACK_ENVS 4                // environments per copy block: all their loads are in flight before the first store
@@ -283,7 +284,21 @@ extern "C" int flexnet_gather_window(const FlexWindowArgs* a, void* stream) {
 #define GATHER_THREADS 256
 struct GatherPlan { int first_block[FLEXNET_GATHER_MAX_JOBS + 1]; };
 
-__global__ __launch_bounds__(GATHER_THREADS) void gather_rows_kernel(FlexGatherArgs a, GatherPlan p) {
+// TD: the reward-statistics pass of the value loss (csrc/flex_td.h: td_stats_block) rides behind the copy blocks, reading the
+// reward rows from where job td_job (and td_job + 1, a window that wraps the ring) copies them FROM
+static_assert(GATHER_THREADS == TD_THREADS, "the statistics blocks ride in the gather launch");
+struct GatherTd { FlexTdLossArgs td; int32_t job, jobs; };
+template <bool TD>
+__global__ __launch_bounds__(GATHER_THREADS) void gather_rows_kernel(FlexGatherArgs a, GatherPlan p, GatherTd t) {
+    if constexpr (TD) {
+        const int copy_blocks = p.first_block[a.n_jobs];
+        if ((int)blockIdx.x >= copy_blocks) {
+            const int j1 = t.jobs > 1 ? t.job + 1 : t.job;
+            const TdRewardRows rr = {a.src[t.job], a.src[j1], a.rows[t.job], a.src_stride[t.job], a.src_stride[j1]};
+            td_stats_block(t.td, rr, blockIdx.x - copy_blocks);
+            return;
+        }
+    }
     int j = 0;
     while (j + 1 < a.n_jobs && (int)blockIdx.x >= p.first_block[j + 1]) ++j;
     const int nb = p.first_block[j + 1] - p.first_block[j], b = blockIdx.x - p.first_block[j];
@@ -324,9 +339,9 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_rows_kernel(FlexGatherA
     }
 }
 
-extern "C" int flexnet_gather_rows(const FlexGatherArgs* a, void* stream) {
+static int gather_rows_run(const FlexGatherArgs* a, const GatherTd* t, void* stream) {
     if (!a || a->n_jobs < 0 || a->n_jobs > FLEXNET_GATHER_MAX_JOBS) return FLEXNET_EINVAL;
-    if (a->n_jobs == 0) return FLEXNET_OK;
+    if (a->n_jobs == 0) return t ? FLEXNET_EINVAL : FLEXNET_OK;
     GatherPlan p;
     int blocks = 0;
     for (int j = 0; j < a->n_jobs; ++j) {
@@ -342,6 +357,35 @@ extern "C" int flexnet_gather_rows(const FlexGatherArgs* a, void* stream) {
     }
     p.first_block[a->n_jobs] = blocks;
     for (int j = a->n_jobs + 1; j <= FLEXNET_GATHER_MAX_JOBS; ++j) p.first_block[j] = blocks;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(GATHER_THREADS), 0, (hipStream_t)stream, *a, p);
+    if (t) hipLaunchKernelGGL(gather_rows_kernel<true>, dim3(blocks + TD_BLOCKS), dim3(GATHER_THREADS), 0, (hipStream_t)stream, *a, p, *t);
+    else {
+        GatherTd none;
+        none.job = none.jobs = 0;                                // (never read without TD)
+        hipLaunchKernelGGL(gather_rows_kernel<false>, dim3(blocks), dim3(GATHER_THREADS), 0, (hipStream_t)stream, *a, p, none);
+    }
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}
+
+extern "C" int flexnet_gather_rows(const FlexGatherArgs* a, void* stream) { return gather_rows_run(a, nullptr, stream); }
+
+// flexnet_gather_rows with the statistics pass of flexnet_td_loss / flexnet_critic_td_backward (= flexnet_td_stats(td)) riding
+// in the launch: jobs reward_job .. reward_job + reward_jobs - 1 (one, or two for a window that wraps the ring) copy the
+// [td->rows, td->n_agents] reward rows into td->reward; the statistics are taken from the rows those jobs READ, so the caller
+// hands `td` on with stats_ready = 1.
+extern "C" int flexnet_gather_rows_td(const FlexGatherArgs* a, int32_t reward_job, int32_t reward_jobs, const FlexTdLossArgs* td,
+                                      void* stream) {
+    if (!a || !td || reward_jobs < 1 || reward_jobs > 2 || reward_job < 0 || reward_job + reward_jobs > a->n_jobs)
+        return FLEXNET_EINVAL;
+    if (td->rows < 1 || td->n_agents < 1 || td->n_agents > TD_NA || !td->workspace || td->workspace_floats < FLEXNET_TD_WS_FLOATS ||
+        (reinterpret_cast<uintptr_t>(td->workspace) & 7) != 0)
+        return FLEXNET_EINVAL;
+    int64_t rows = 0;
+    for (int j = reward_job; j < reward_job + reward_jobs; ++j) {
+        if (a->width[j] != td->n_agents || a->rows[j] < 0) return FLEXNET_EINVAL;
+        rows += a->rows[j];
+    }
+    if (rows != td->rows) return FLEXNET_EINVAL;
+    GatherTd t;
+    t.td = *td; t.job = reward_job; t.jobs = reward_jobs;
+    return gather_rows_run(a, &t, stream);
 }

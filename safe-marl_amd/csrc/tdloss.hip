@@ -16,33 +16,8 @@
 #include "flex_td.h"
 
 __global__ __launch_bounds__(TD_THREADS) void td_stats_kernel(FlexTdLossArgs a) {
-    const int tid = threadIdx.x, n = a.n_agents;
-    double s[TD_NA], ss[TD_NA];
-#pragma unroll
-    for (int j = 0; j < TD_NA; ++j) { s[j] = 0.0; ss[j] = 0.0; }
-    for (int b = blockIdx.x * TD_THREADS + tid; b < a.rows; b += TD_BLOCKS * TD_THREADS) {
-        const float* r = a.reward + (int64_t)b * n;
-#pragma unroll
-        for (int j = 0; j < TD_NA; ++j)
-            if (j < n) { const double v = (double)r[j]; s[j] += v; ss[j] += v * v; }
-    }
-    // wavefront sums by shuffles (fixed tree), then the block's four wavefronts in index order
-    __shared__ double part[TD_THREADS / 64][2 * TD_NA];
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int q = 0; q < 2 * TD_NA; ++q) {
-        double v = q < TD_NA ? s[q < TD_NA ? q : 0] : ss[q < TD_NA ? 0 : q - TD_NA];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) part[wave][q] = v;
-    }
-    __syncthreads();
-    if (tid < 2 * TD_NA) {
-        double t = part[0][tid];
-#pragma unroll
-        for (int w = 1; w < TD_THREADS / 64; ++w) t += part[w][tid];
-        reinterpret_cast<double*>(a.workspace)[(int64_t)blockIdx.x * 2 * TD_NA + tid] = t;
-    }
+    const TdRewardRows rr = {a.reward, a.reward, (int64_t)a.rows, a.n_agents, a.n_agents};
+    td_stats_block(a, rr, blockIdx.x);
 }
 
 __global__ __launch_bounds__(TD_THREADS) void td_apply_kernel(FlexTdLossArgs a) {

@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include "flexnet.h"
 #include "flex_reduce.h"
+#include "critic_finish.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -251,11 +252,20 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void wgrad_kernel(WgradK p) {
 
 // element e of the slabs' register images, summed in a fixed order, stored at its place in C; the thread blocks past
 // the image (column chunk 0 only, when column sums were asked for) sum the blocks' column-sum partials the same way
+// RIDER (flexnet_wgrad_critic_finish): the finish blocks of flexnet_critic_td_backward ride behind this launch's own blocks
+// (row 0 of the grid) — same thread-block shape, nothing shared with them but the launch
 #define WG_RED FLEX_RED_G
-template <int MT, int NT>
-__global__ __launch_bounds__(64 * WG_RED) void wgrad_reduce_kernel(WgradK p) {
+template <int MT, int NT, bool RIDER = false>
+__global__ __launch_bounds__(64 * WG_RED) void wgrad_reduce_kernel(WgradK p, CriticFinishK f) {
     constexpr int IMG_BLOCKS = WG_IMG(MT, NT) / 64;
     float sum;
+    if constexpr (RIDER) {
+        const int own = IMG_BLOCKS + (p.cs ? (32 * MT + 63) / 64 : 0);
+        if ((int)blockIdx.x >= own) {
+            if (blockIdx.y == 0 && (int)blockIdx.x - own < f.blocks) critic_finish_block(f, blockIdx.x - own);
+            return;
+        }
+    }
     if (blockIdx.x >= IMG_BLOCKS) {
         if (blockIdx.y != 0) return;
         const int m = (blockIdx.x - IMG_BLOCKS) * 64 + (threadIdx.x & 63);
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(64 * WG_RED) void wgrad_reduce_kernel(WgradK p) {
 }
 
 template <int MT, int NT>
-static int wgrad_launch(WgradK p, int chunks, hipStream_t s) {
+static int wgrad_launch(WgradK p, int chunks, hipStream_t s, const CriticFinishK* rider) {
     if (p.b2) {
         if constexpr (MT == 2 && NT == 5) {
             if (p.cs) hipLaunchKernelGGL((wgrad_kernel<MT, NT, true, true>), dim3(p.slabs, chunks), dim3(64 * WG_WAVES), 0, s, p);
@@ -289,11 +299,20 @@ static int wgrad_launch(WgradK p, int chunks, hipStream_t s) {
     else hipLaunchKernelGGL((wgrad_kernel<MT, NT, false>), dim3(p.slabs, chunks), dim3(64 * WG_WAVES), 0, s, p);
     // the column-sum blocks ride at the end of every grid row; those of column chunks > 0 return at once
     const int cs_blocks = p.cs ? (32 * MT + 63) / 64 : 0;
-    hipLaunchKernelGGL((wgrad_reduce_kernel<MT, NT>), dim3(WG_IMG(MT, NT) / 64 + cs_blocks, chunks), dim3(64 * WG_RED), 0, s, p);
+    if (rider) {
+        if constexpr (MT == 2 && NT == 5)
+            hipLaunchKernelGGL((wgrad_reduce_kernel<MT, NT, true>), dim3(WG_IMG(MT, NT) / 64 + cs_blocks + rider->blocks, chunks),
+                               dim3(64 * WG_RED), 0, s, p, *rider);
+        else return FLEXNET_EUNSUPPORTED;
+    } else {
+        CriticFinishK none;
+        none.blocks = 0;                                          // (never read without RIDER)
+        hipLaunchKernelGGL((wgrad_reduce_kernel<MT, NT>), dim3(WG_IMG(MT, NT) / 64 + cs_blocks, chunks), dim3(64 * WG_RED), 0, s, p, none);
+    }
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }
 
-extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) {
+static int wgrad_run(const FlexWgradArgs* a, void* stream, const CriticFinishK* rider) {
     if (!a || !a->a || !a->b || !a->c || !a->workspace || a->k < 0 || a->m < 1 || a->n < 1) return FLEXNET_EINVAL;
     if (a->lda < a->m || a->ldb < a->n || (a->ldc != 0 && a->ldc < a->n)) return FLEXNET_EINVAL;
     if (a->m > 192 || a->lda >= (1 << 24) || a->ldb >= (1 << 24)) return FLEXNET_EUNSUPPORTED;
@@ -337,14 +356,31 @@ extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) {
     p.b_cell = a->b_row_cell;
     hipStream_t s = (hipStream_t)stream;
     switch (mt * 10 + nt) {
-        case 11: return wgrad_launch<1, 1>(p, chunks, s);
-        case 12: return wgrad_launch<1, 2>(p, chunks, s);
-        case 15: return wgrad_launch<1, 5>(p, chunks, s);
-        case 21: return wgrad_launch<2, 1>(p, chunks, s);
-        case 22: return wgrad_launch<2, 2>(p, chunks, s);
-        case 25: return wgrad_launch<2, 5>(p, chunks, s);
-        case 61: return wgrad_launch<6, 1>(p, chunks, s);
-        case 62: return wgrad_launch<6, 2>(p, chunks, s);
+        case 11: return wgrad_launch<1, 1>(p, chunks, s, rider);
+        case 12: return wgrad_launch<1, 2>(p, chunks, s, rider);
+        case 15: return wgrad_launch<1, 5>(p, chunks, s, rider);
+        case 21: return wgrad_launch<2, 1>(p, chunks, s, rider);
+        case 22: return wgrad_launch<2, 2>(p, chunks, s, rider);
+        case 25: return wgrad_launch<2, 5>(p, chunks, s, rider);
+        case 61: return wgrad_launch<6, 1>(p, chunks, s, rider);
+        case 62: return wgrad_launch<6, 2>(p, chunks, s, rider);
     }
     return FLEXNET_EUNSUPPORTED;
+}
+
+extern "C" int flexnet_wgrad(const FlexWgradArgs* a, void* stream) { return wgrad_run(a, stream, nullptr); }
+
+// The critic's first-layer weight gradient with the finish of flexnet_critic_td_backward riding in its second-stage launch
+// (include/flexnet.h): call flexnet_critic_td_backward_phases(critic, td, 1, stream) first — this is its phase 2 plus
+// flexnet_wgrad(w), one launch fewer.  Only for the [64, 5 n] form the critic's first layer takes (else FLEXNET_EUNSUPPORTED,
+// nothing launched: the caller falls back to the two separate calls).
+extern "C" int flexnet_wgrad_critic_finish(const FlexWgradArgs* w, const FlexCriticTailArgs* critic, const FlexTdLossArgs* td, void* stream) {
+    if (!w || !critic || !td) return FLEXNET_EINVAL;
+    const int mt = w->m <= 32 ? 1 : w->m <= 64 ? 2 : 6;
+    const int nt = w->n <= 32 ? 1 : w->n <= 64 ? 2 : (mt == 6 ? 2 : 5);
+    if (mt != 2 || nt != 5) return FLEXNET_EUNSUPPORTED;
+    CriticFinishK k;
+    const int rc = critic_finish_prepare(critic, td, &k);
+    if (rc != FLEXNET_OK) return rc;
+    return wgrad_run(w, stream, &k);
 }

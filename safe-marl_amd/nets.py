@@ -278,6 +278,11 @@ _WGRAD_WS = {}
 WGRAD_MIN_ROWS = 2048          # below this the library GEMM is launch-bound either way
 
 
+# the finish of the fused value loss rides in the first-layer weight gradient's second-stage launch (FLEX_WGRAD_FINISH_RIDER=0:
+# two launches, the A/B switch)
+WGRAD_FINISH_RIDER = os.environ.get("FLEX_WGRAD_FINISH_RIDER", "1") != "0"
+
+
 def tall_wgrad_supported(dy, x):
     return (dy.is_cuda and x.is_cuda and dy.dtype == th.float32 and x.dtype == th.float32 and dy.dim() == 2
             and x.dim() == 2 and dy.shape[0] == x.shape[0] and 1 <= dy.shape[1] <= 192 and x.shape[1] >= 1
@@ -285,12 +290,14 @@ def tall_wgrad_supported(dy, x):
                                       and x.stride(0) >= x.shape[1] and max(dy.stride(0), x.stride(0)) < (1 << 24))))
 
 
-def tall_wgrad(dy, x, out=None, accumulate=False, colsum=None, x2=None, out2=None):
+def tall_wgrad(dy, x, out=None, accumulate=False, colsum=None, x2=None, out2=None, critic_finish=None):
     """dW[m, n] = sum_k dy[k, m] * x[k, n] (csrc/wgrad.hip: include/flexnet.h flexnet_wgrad) — the weight gradient of
     y = x @ W.T over a tall batch.  Row-strided views (column slices of the packed replay rows) are read in place.
     The workspace is per device: calls are expected on one stream at a time (the update's).
     ``x2`` / ``out2``: a second input block of the same layer (out2 = dy.T @ x2) — in the same launch where the kernel
-    takes [x | x2] as one operand (64 output rows, x wider than 64 columns and a multiple of 5), else a second call."""
+    takes [x | x2] as one operand (64 output rows, x wider than 64 columns and a multiple of 5), else a second call.
+    ``critic_finish`` = (FlexCriticTailArgs, FlexTdLossArgs): phase 2 of flexnet_critic_td_backward_phases rides in this
+    call's second-stage launch (flexnet_wgrad_critic_finish) — or is launched on its own first where the rider does not apply."""
     import ctypes as C
     from . import _lib
     lib = _lib.load()
@@ -324,7 +331,16 @@ def tall_wgrad(dy, x, out=None, accumulate=False, colsum=None, x2=None, out2=Non
         a.colsum = colsum.data_ptr()
     if x2 is not None:
         a.b2, a.c2, a.ldb2, a.n2, a.ldc2 = x2.data_ptr(), out2.data_ptr(), x2.stride(0), x2.shape[1], out2.stride(0)
-    _lib.check(lib.flexnet_wgrad(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_wgrad")
+    stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
+    if critic_finish is not None:
+        cargs, targs = critic_finish
+        rc = lib.flexnet_wgrad_critic_finish(C.byref(a), C.byref(cargs), C.byref(targs), stream) if WGRAD_FINISH_RIDER else _lib.FLEXNET_EUNSUPPORTED
+        if rc == 0:
+            return out
+        if rc != _lib.FLEXNET_EUNSUPPORTED:
+            _lib.check(rc, "flexnet_wgrad_critic_finish")
+        _lib.check(lib.flexnet_critic_td_backward_phases(C.byref(cargs), C.byref(targs), 2, stream), "flexnet_critic_td_backward")
+    _lib.check(lib.flexnet_wgrad(C.byref(a), stream), "flexnet_wgrad")
     return out
 
 
@@ -467,6 +483,37 @@ def _sync_active(bn):
     import torch.distributed as dist
     return (bn is not None and getattr(bn, "flex_sync_ranks", False) and dist.is_available() and dist.is_initialized()
             and dist.get_world_size() > 1)
+
+
+# Reward statistics filed ahead of the loss (round 5).  The trainer's captured value sub-update refreshes its static batch with
+# ONE gather launch per window; the statistics pass of the fused value loss needs the batch's rewards only, so it rides in that
+# launch (flexnet_gather_rows_td) instead of being the graph's own 6.5-us launch between the first-layer product and the
+# backward kernel.  Protocol: the trainer OFFERS the static reward tensor (offer_td_stats) before the warm-up steps;
+# _CriticTdLossFn.forward, meeting that tensor, takes the offer — stats_ready = 1, no statistics launch — and records that it
+# did; the trainer then keeps the rider for every refresh of that batch (TransReplayBuffer.gather(td=...)) or withdraws it.
+TD_OFFERS = {}              # data_ptr of a static [rows, n] reward tensor -> {"taken": bool}
+
+
+def offer_td_stats(reward):
+    """Offer to file the reward statistics of ``reward`` (a static batch tensor) with every refresh of it.  Returns
+    (record, FlexTdLossArgs for the rider); record["taken"] says after a loss has run whether the fused value loss used them."""
+    from . import _lib
+    import weakref
+    r2 = reward.reshape(reward.shape[0], -1)
+    rec = {"taken": False, "ref": weakref.ref(reward)}        # (a dead tensor's address may be handed out again: checked on use)
+    TD_OFFERS[r2.data_ptr()] = rec
+    rows, n = r2.shape
+    if r2.device not in _TD_WS:
+        _TD_WS[r2.device] = th.empty(_lib.FLEXNET_TD_WS_FLOATS // 2, dtype=th.float64, device=r2.device)
+    ws = _TD_WS[r2.device]
+    a = _lib.FlexTdLossArgs()
+    a.rows, a.n_agents, a.normalise, a.reward = rows, n, 1, r2.data_ptr()
+    a.workspace, a.workspace_floats = ws.data_ptr(), 2 * ws.numel()
+    return rec, a
+
+
+def withdraw_td_stats(reward):
+    TD_OFFERS.pop(reward.reshape(reward.shape[0], -1).data_ptr(), None)
 
 
 def _td_sync_stats(a, ws, bn):
@@ -1194,6 +1241,12 @@ class _CriticTdLossFn(th.autograd.Function):
         nq, r, d = next_q.reshape(-1, n).contiguous(), reward.contiguous(), done.reshape(-1).contiguous()
         t = _td_args(r, d, nq, gamma, bn, update_stats=True)
         _td_sync_stats(t, _TD_WS[r.device], bn)
+        offer = TD_OFFERS.get(r.data_ptr())
+        if offer is not None and offer["ref"]() is None:
+            del TD_OFFERS[r.data_ptr()]
+            offer = None
+        if offer is not None and t.normalise and not t.stats_ready:
+            t.stats_ready, offer["taken"] = 1, True           # filed by the launch that refreshed this batch (offer_td_stats)
         fork = TD_FORK
         main = th.cuda.current_stream(dev)
         side = _side_stream(dev) if fork else None
@@ -1234,6 +1287,11 @@ class _CriticTdLossFn(th.autograd.Function):
                        "flexnet_critic_td_backward")
             tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias, x2=act2d, out2=dW[:, no + n:no + n + na_])
             main.wait_stream(side)
+        elif sm:
+            # the finish (phase 2) depends on the backward kernel alone: it rides in the weight gradient's second-stage launch
+            _lib.check(lib.flexnet_critic_td_backward_phases(C.byref(args), C.byref(t), 1, stream), "flexnet_critic_td_backward")
+            tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias, x2=act2d, out2=dW[:, no + n:no + n + na_],
+                       critic_finish=(args, t))
         else:
             _lib.check(lib.flexnet_critic_td_backward(C.byref(args), C.byref(t), stream), "flexnet_critic_td_backward")
             tall_wgrad(d_shared, obs2d, out=dW[:, :no], colsum=d_bias, x2=act2d, out2=dW[:, no + n:no + n + na_])

@@ -336,14 +336,18 @@ class DeviceReplayBuffer:
 
     STORED = ("state", "action", "reward", "next_state", "done", "last_step", "last_hid", "hid")
 
-    def gather(self, plan, slot):
+    def gather(self, plan, slot, td=None):
         """Refresh static batch tensors from the window starting at global slot ``slot``: ONE launch of
         flexnet_gather_rows (include/flexnet.h).  ``plan`` = [(ring name, first column, width, row offset, rows, dst)],
-        dst a contiguous [rows, width] fp32 tensor."""
+        dst a contiguous [rows, width] fp32 tensor.  ``td`` = (reward tensor of the plan, FlexTdLossArgs): the value loss's
+        reward-statistics pass rides in the same launch (flexnet_gather_rows_td; nets.offer_td_stats)."""
         import ctypes as C
         from . import _lib
         jobs = []
+        td_first = td_count = None
         for ring_name, col0, width, row_off, rows, dst in plan:
+            if td is not None and dst is td[0]:
+                td_first = len(jobs)
             if ring_name == "stack_ring":                # read in place (enable_stacked_ring): only the window's first row moves
                 cell = dst[0]
                 self.expand_stacked()
@@ -362,6 +366,8 @@ class DeviceReplayBuffer:
             for p, c in self.segments(slot + row_off, rows):
                 jobs.append((base + 4 * (p * stride + col0), out + 4 * done_rows * width, c, width, stride))
                 done_rows += c
+            if td is not None and dst is td[0]:
+                td_count = len(jobs) - td_first
         # a window that wraps the ring's seam splits every field in two: up to 2 x 8 stored fields = 16 jobs against the
         # launch's FLEXNET_GATHER_MAX_JOBS (12) — the rest goes out as a second launch instead of an intermittent error
         stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
@@ -372,7 +378,15 @@ class DeviceReplayBuffer:
                 a.src[j], a.dst[j] = src, dst_p
                 a.rows[j], a.width[j], a.src_stride[j], a.dst_stride[j] = c, width, stride, width
             a.n_jobs = len(chunk)
-            _lib.check(_lib.load().flexnet_gather_rows(C.byref(a), stream), "flexnet_gather_rows")
+            if td_count and lo <= td_first and td_first + td_count <= lo + len(chunk):
+                _lib.check(_lib.load().flexnet_gather_rows_td(C.byref(a), td_first - lo, td_count, C.byref(td[1]), stream),
+                           "flexnet_gather_rows_td")
+                td_count = 0
+            else:
+                _lib.check(_lib.load().flexnet_gather_rows(C.byref(a), stream), "flexnet_gather_rows")
+        if td is not None and td_count != 0:
+            # (the reward's copies fell across two launches, or the plan does not gather the tensor: the pass on its own)
+            _lib.check(_lib.load().flexnet_td_stats(C.byref(td[1]), stream), "flexnet_td_stats")
 
     def scatter(self, ring_name, src, slot, rows):
         """The reverse of one gather job: rows of the contiguous [rows, width] tensor ``src`` into the ring's slots of the

@@ -186,7 +186,7 @@ class PGTrainer(object):
         if g is None:
             return False
         buf = self.replay_buffer
-        buf.gather(g["plan"], buf.sample_slot(g["bs"]))       # only the ring columns this sub-update reads
+        buf.gather(g["plan"], buf.sample_slot(g["bs"]), td=g.get("td"))       # only the ring columns this sub-update reads
         self._replay(g, stat)
         return True
 
@@ -274,7 +274,7 @@ class PGTrainer(object):
             with th.cuda.stream(side):
                 if g.get("free") is not None:
                     side.wait_event(g["free"])          # the last replay that read this static batch has finished
-                buf.gather(g["plan"], slot_start)
+                buf.gather(g["plan"], slot_start, td=g.get("td"))
                 ev = th.cuda.Event()
                 ev.record(side)
             return ev
@@ -298,7 +298,7 @@ class PGTrainer(object):
                 slot = starts[j] if j in starts else buf.sample_slot(self.effective_batch_size())
                 self._sub_update(need, stat, buf.slab_window(slot, self.effective_batch_size()))
                 continue
-            buf.gather(g["plan"], starts[j] if j in starts else buf.sample_slot(g["bs"]))
+            buf.gather(g["plan"], starts[j] if j in starts else buf.sample_slot(g["bs"]), td=g.get("td"))
             self._replay(g, stat)
 
     @staticmethod
@@ -508,7 +508,32 @@ class PGTrainer(object):
         from .replay_buffer import Transition
         buf = self.replay_buffer
         fields, plan = self._static_batch(kind, bs)
-        buf.gather(plan, buf.warmup_slot(bs + buf.n_envs))  # real transitions for the warm-up steps: a window whose
+        # the value loss's reward-statistics pass rides in the launch that refreshes this batch (nets.offer_td_stats): offered
+        # here, kept if the warm-up's loss takes it.  Not with the refresh on a side stream (the rider writes the statistics
+        # the previous sub-update may still be reading) and not with cross-rank statistics (they are all-reduced per loss).
+        td = offer = None
+        from . import nets
+        if (which == "value" and self.world == 1 and not self.pipeline_updates and self.device.type == "cuda"
+                and os.environ.get("FLEX_TD_STATS_RIDER", "1") != "0" and th.is_tensor(fields.get("reward"))):
+            blk = next((p[5] for p in plan if th.is_tensor(p[5]) and p[5].data_ptr() == fields["reward"].data_ptr()), None)
+            if blk is not None:
+                offer, targs = nets.offer_td_stats(blk)
+                td = (blk, targs)
+        try:
+            g = self._capture_sub_update_graph(kind, which, bs, fields, plan, td)
+        except Exception:
+            if td is not None:
+                nets.withdraw_td_stats(td[0])
+            raise
+        if td is not None and not offer["taken"]:
+            nets.withdraw_td_stats(td[0])
+            g["td"] = None
+        return g
+
+    def _capture_sub_update_graph(self, kind, which, bs, fields, plan, td):
+        from .replay_buffer import Transition
+        buf = self.replay_buffer
+        buf.gather(plan, buf.warmup_slot(bs + buf.n_envs), td=td)  # real transitions for the warm-up steps: a window whose
         #                          next_state rows (N slots further on) exist too; no draw from the NumPy stream
         batch = Transition(**fields)
         out = {}
@@ -602,7 +627,7 @@ class PGTrainer(object):
             restore()
         # `batch` stays referenced: its constant fields (action_avail, ...) were allocated eagerly and are baked into the
         # graph by address; released, the allocator would hand their memory to the next eager tensor
-        return dict(graph=graph, apply=apply_graph, flat=flat, plan=plan, stat=out, bs=bs, buf=buf, batch=batch,
+        return dict(graph=graph, apply=apply_graph, flat=flat, plan=plan, stat=out, bs=bs, buf=buf, batch=batch, td=td,
                     allreduce_in_graph=bool(flat is not None and apply_graph is None))
 
     # kept for callers that hand over a batch themselves (trainer.py:81,99)

@@ -318,6 +318,22 @@ def test_value_loss_and_critic_backward_in_one_pass(b, norm):
         assert torch.equal(a, e)
     if norm:
         assert torch.equal(bn.running_mean, s1[0]) and torch.equal(bn.running_var, s1[1])
+    # the finish riding in the weight gradient's second-stage launch (flexnet_wgrad_critic_finish, the default) against the
+    # finish as a launch of its own (nets.WGRAD_FINISH_RIDER off): the same blocks on the same data — the same bits
+    bn = nn.BatchNorm1d(n).cuda().train() if norm else None
+    assert nets.WGRAD_FINISH_RIDER
+    nets.WGRAD_FINISH_RIDER = False
+    try:
+        lr_ = m._critic_td_loss(obs, act, nq, rew, done, bn)
+        gr_ = torch.autograd.grad(lr_, params, grad_outputs=unit_seed("cuda"))
+        torch.cuda.synchronize()
+    finally:
+        nets.WGRAD_FINISH_RIDER = True
+    assert torch.equal(lr_, l1)
+    for a, e in zip(gr_, g1):
+        assert torch.equal(a, e)
+    if norm:
+        assert torch.equal(bn.running_mean, s1[0]) and torch.equal(bn.running_var, s1[1])
     # below the matrix-core batch size the node declines and the sequence runs
     assert m._critic_td_loss(obs[:1000], act[:1000], nq[:1000], rew[:1000], done[:1000], bn) is None
 

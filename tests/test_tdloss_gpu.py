@@ -178,3 +178,52 @@ def test_cross_rank_statistics_path_with_two_identical_ranks(monkeypatch):
     want = 0.9 * 1.0 + 0.1 * var * (2 * rows) / (2 * rows - 1)
     assert torch.allclose(bnb.running_var.double(), want, rtol=1e-6)
     assert not torch.equal(bna.running_var, bnb.running_var) or rows > 10 ** 7
+
+
+@pytest.mark.parametrize("rows,wrap", [(32768, False), (32768, True), (4099, True)])
+def test_statistics_ride_in_the_gather_launch(rows, wrap):
+    """include/flexnet.h: flexnet_gather_rows_td — the statistics pass of the value loss (model.py:308-323) as extra blocks of
+    the launch that copies the sampled window's small columns out of the replay ring (utils/replay_buffer.py:17-21).  The
+    statistics are taken from the rows the copy READS, in flexnet_td_stats' partition: the workspace must hold the same bits
+    as flexnet_td_stats run on the copied tensor, for a window in one piece and for one that wraps the ring's seam."""
+    import ctypes as C
+    from safe_marl_amd import _lib
+    lib = _lib.load()
+    n, act_w, stride, cap = 5, 20, 27, 40000
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    ring = torch.randn(cap, stride, device="cuda", generator=g) * 2.0 + 0.5
+    first = cap - rows // 3 if wrap else 1234
+    segs = [(first, min(rows, cap - first))] + ([(0, rows - (cap - first))] if first + rows > cap else [])
+    reward = torch.full((rows, n), float("nan"), device="cuda")
+    action = torch.full((rows, act_w), float("nan"), device="cuda")
+    a = _lib.FlexGatherArgs()
+    jobs, done_rows = [], 0
+    for p, c in segs:                                  # the action columns first, then the reward's one or two pieces
+        jobs.append((ring.data_ptr() + 4 * p * stride, action.data_ptr() + 4 * done_rows * act_w, c, act_w))
+        done_rows += c
+    reward_job, done_rows = len(jobs), 0
+    for p, c in segs:
+        jobs.append((ring.data_ptr() + 4 * (p * stride + act_w), reward.data_ptr() + 4 * done_rows * n, c, n))
+        done_rows += c
+    for j, (src, dst, c, w) in enumerate(jobs):
+        a.src[j], a.dst[j], a.rows[j], a.width[j], a.src_stride[j], a.dst_stride[j] = src, dst, c, w, stride, w
+    a.n_jobs = len(jobs)
+    ws = [torch.zeros(_lib.FLEXNET_TD_WS_FLOATS // 2, dtype=torch.float64, device="cuda") for _ in range(2)]
+    t = _lib.FlexTdLossArgs()
+    t.rows, t.n_agents, t.normalise, t.reward = rows, n, 1, reward.data_ptr()
+    t.workspace, t.workspace_floats = ws[0].data_ptr(), 2 * ws[0].numel()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.flexnet_gather_rows_td(C.byref(a), reward_job, len(segs), C.byref(t), stream), "flexnet_gather_rows_td")
+    torch.cuda.synchronize()
+    idx = (first + torch.arange(rows, device="cuda")) % cap
+    assert torch.equal(reward, ring[idx, act_w:act_w + n]) and torch.equal(action, ring[idx, :act_w])
+    t.workspace = ws[1].data_ptr()
+    _lib.check(lib.flexnet_td_stats(C.byref(t), stream), "flexnet_td_stats")
+    torch.cuda.synchronize()
+    k = _lib.FLEXNET_TD_STAT_DOUBLES
+    assert torch.equal(ws[0][:k], ws[1][:k]) and bool(ws[1][:k].abs().sum() > 0)
+    # arguments that do not describe the reward's copies are refused before any launch
+    assert lib.flexnet_gather_rows_td(C.byref(a), 0, 1, C.byref(t), stream) != 0            # job 0 copies the action columns
+    assert lib.flexnet_gather_rows_td(C.byref(a), reward_job, 3, C.byref(t), stream) != 0
+    t.rows = rows - 1
+    assert lib.flexnet_gather_rows_td(C.byref(a), reward_job, len(segs), C.byref(t), stream) != 0

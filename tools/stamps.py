@@ -13,7 +13,7 @@ from safe_marl_amd.flex_env import VecFlexProvisionEnv
 solver = int(sys.argv[1]) if len(sys.argv)>1 else 2
 sink = len(sys.argv) > 2 and sys.argv[2] == "sink"      # the SINK instantiation: the step files its own transition
 net=create_network(); s=make_synthetic_series(net,n_days=200)
-N=4096
+N=int(os.environ.get("FLEX_STAMPS_N", "4096"))
 env=VecFlexProvisionEnv({}, N, net=net, series=s, seed=1, warm_start=True, solver=solver,
                         sweep_accel=os.environ.get('FLEX_NO_SWEEP_ACCEL') != '1')
 lib=_lib.load()

@@ -8,7 +8,7 @@ def short(n):
     n = n.split("(")[0]
     return n[-70:]
 # a sub-update starts at its gather_rows_kernel
-starts = [i for i, n in enumerate(names) if n.startswith("gather_rows_kernel")]
+starts = [i for i, n in enumerate(names) if "gather_rows_kernel" in n.split("(")[0]]
 segs = [(a, b) for a, b in zip(starts, starts[1:] + [len(rows)])]
 kinds = {}
 for a, b in segs:
