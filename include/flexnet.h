@@ -490,6 +490,33 @@ int flexnet_gather_rows(const FlexGatherArgs* args, void* stream);
  * partition flexnet_td_stats uses (bit-identical sums), into td->workspace.  The consumer then runs with stats_ready = 1. */
 int flexnet_gather_rows_td(const FlexGatherArgs* args, int32_t reward_job, int32_t reward_jobs, const FlexTdLossArgs* td, void* stream);
 
+/* The refresh of a captured sub-update's static batch with the window's first slot read from DEVICE memory (round 5): the
+ * form of flexnet_gather_rows a HIP graph can hold — one graph then runs ALL the value sub-updates of an update event
+ * (model.py:47-50), each refreshing its batch from its own cell of a device array of window starts, instead of one graph
+ * launch per sub-update with a host-side refresh in between (8 us of graph hand-over each).
+ * Job j copies rows [start + row_off[j], + rows[j]) (taken modulo ring_rows: a window may wrap the ring's seam) of a ring
+ * whose rows are src_stride[j] floats apart, columns base[j] .. + width[j] - 1, into the contiguous dst[j]; cell[k] <-
+ * start modulo cell_mod[k] (the in-place windows' first-row cells, nets.RING_VIEWS).  td != NULL: the reward-statistics pass
+ * rides in the launch as in flexnet_gather_rows_td, on job reward_job. */
+#define FLEXNET_WINDOW_MAX_JOBS 8
+#define FLEXNET_WINDOW_MAX_CELLS 4
+typedef struct {
+    int32_t n_jobs, n_cells;
+    const int64_t* start;                                  /* device: the window's first global slot (>= 0) */
+    int64_t ring_rows;                                     /* rows of every ring the jobs read (slabs * n_envs) */
+    const float* base[FLEXNET_WINDOW_MAX_JOBS];            /* ring row 0, first column of the job */
+    float* dst[FLEXNET_WINDOW_MAX_JOBS];
+    int64_t rows[FLEXNET_WINDOW_MAX_JOBS];
+    int64_t row_off[FLEXNET_WINDOW_MAX_JOBS];
+    int32_t width[FLEXNET_WINDOW_MAX_JOBS];
+    int32_t src_stride[FLEXNET_WINDOW_MAX_JOBS];
+    int64_t* cell[FLEXNET_WINDOW_MAX_CELLS];
+    int64_t cell_mod[FLEXNET_WINDOW_MAX_CELLS];
+    int32_t reward_job, pad0;                              /* used with td only */
+} FlexWindowRefreshArgs;
+
+int flexnet_window_refresh(const FlexWindowRefreshArgs* args, const FlexTdLossArgs* td /* NULL: none */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,7 +75,7 @@ SYMBOLS = (
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_rollout_burst", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version", "flexenv_abi_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_td_stats", "flexnet_critic_td_backward", "flexnet_critic_td_backward_phases", "flexnet_wgrad_critic_finish",
-    "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gather_rows_td", "flexnet_gather_window", "flexnet_linear2", "flexnet_gru_backward",
+    "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gather_rows_td", "flexnet_window_refresh", "flexnet_gather_window", "flexnet_linear2", "flexnet_gru_backward",
     "flexopf_qp_work_doubles", "flexopf_qp_solve",
 )
 
@@ -237,6 +237,20 @@ class FlexGatherArgs(C.Structure):
                 ("src_stride", C.c_int32 * FLEXNET_GATHER_MAX_JOBS), ("dst_stride", C.c_int32 * FLEXNET_GATHER_MAX_JOBS)]
 
 
+FLEXNET_WINDOW_MAX_JOBS = 8
+FLEXNET_WINDOW_MAX_CELLS = 4
+
+
+class FlexWindowRefreshArgs(C.Structure):
+    """include/flexnet.h"""
+    _fields_ = [("n_jobs", C.c_int32), ("n_cells", C.c_int32), ("start", C.c_void_p), ("ring_rows", C.c_int64),
+                ("base", C.c_void_p * FLEXNET_WINDOW_MAX_JOBS), ("dst", C.c_void_p * FLEXNET_WINDOW_MAX_JOBS),
+                ("rows", C.c_int64 * FLEXNET_WINDOW_MAX_JOBS), ("row_off", C.c_int64 * FLEXNET_WINDOW_MAX_JOBS),
+                ("width", C.c_int32 * FLEXNET_WINDOW_MAX_JOBS), ("src_stride", C.c_int32 * FLEXNET_WINDOW_MAX_JOBS),
+                ("cell", C.c_void_p * FLEXNET_WINDOW_MAX_CELLS), ("cell_mod", C.c_int64 * FLEXNET_WINDOW_MAX_CELLS),
+                ("reward_job", C.c_int32), ("pad0", C.c_int32)]
+
+
 FLEXNET_EUNSUPPORTED = -3
 
 _lib = None
@@ -292,6 +306,8 @@ def load():
     lib.flexnet_gather_rows.restype = C.c_int
     lib.flexnet_gather_rows_td.argtypes = [C.POINTER(FlexGatherArgs), i32, i32, C.POINTER(FlexTdLossArgs), vp]
     lib.flexnet_gather_rows_td.restype = C.c_int
+    lib.flexnet_window_refresh.argtypes = [C.POINTER(FlexWindowRefreshArgs), C.POINTER(FlexTdLossArgs), vp]
+    lib.flexnet_window_refresh.restype = C.c_int
     lib.flexnet_gru_backward.argtypes = [C.POINTER(FlexGruBwdArgs), vp]
     lib.flexnet_gru_backward.restype = C.c_int
     lib.flexenv_set_step_counter.argtypes = [vp, vp, C.c_int64]

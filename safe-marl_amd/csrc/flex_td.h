@@ -73,11 +73,26 @@ __device__ __forceinline__ void td_stats_block(const FlexTdLossArgs& a, const Td
     double s[TD_NA], ss[TD_NA];
 #pragma unroll
     for (int j = 0; j < TD_NA; ++j) { s[j] = 0.0; ss[j] = 0.0; }
-    for (int b = block * TD_THREADS + tid; b < a.rows; b += TD_BLOCKS * TD_THREADS) {
-        const float* r = b < rr.rows0 ? rr.src0 + (int64_t)b * rr.stride0 : rr.src1 + ((int64_t)b - rr.rows0) * rr.stride1;
+    // four rows' loads in flight per thread, added in row order (the order of the plain loop: the sums keep their bits) — as a
+    // rider the pass reads rows a ring keeps 108 bytes apart, and a 131 072-row batch is eight dependent round trips otherwise
+    constexpr int STEP = TD_BLOCKS * TD_THREADS;
+    for (int b0 = block * TD_THREADS + tid; b0 < a.rows; b0 += 4 * STEP) {
+        float v[4][TD_NA];
 #pragma unroll
-        for (int j = 0; j < TD_NA; ++j)
-            if (j < n) { const double v = (double)r[j]; s[j] += v; ss[j] += v * v; }
+        for (int u = 0; u < 4; ++u) {
+            const int b = b0 + u * STEP < a.rows ? b0 + u * STEP : b0;
+            const float* r = b < rr.rows0 ? rr.src0 + (int64_t)b * rr.stride0 : rr.src1 + ((int64_t)b - rr.rows0) * rr.stride1;
+#pragma unroll
+            for (int j = 0; j < TD_NA; ++j) v[u][j] = j < n ? r[j] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (b0 + u * STEP < a.rows) {
+#pragma unroll
+                for (int j = 0; j < TD_NA; ++j)
+                    if (j < n) { const double x = (double)v[u][j]; s[j] += x; ss[j] += x * x; }
+            }
+        }
     }
     // wavefront sums by shuffles (fixed tree), then the block's four wavefronts in index order
     __shared__ double part[TD_THREADS / 64][2 * TD_NA];

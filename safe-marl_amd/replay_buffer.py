@@ -388,6 +388,48 @@ class DeviceReplayBuffer:
             # (the reward's copies fell across two launches, or the plan does not gather the tensor: the pass on its own)
             _lib.check(_lib.load().flexnet_td_stats(C.byref(td[1]), stream), "flexnet_td_stats")
 
+    def window_refresh_args(self, plan, start_cell, td=None):
+        """``plan`` as FlexWindowRefreshArgs with the window's first slot read from the device cell ``start_cell`` (int64, a
+        global slot number as sample_slot returns it) — the refresh a HIP graph can hold (trainer: one graph per update
+        event).  Returns (args, FlexTdLossArgs or None), or None when the plan holds something this form does not cover (a
+        window expanded out of the row ring, rings of different lengths, more jobs than the launch takes)."""
+        from . import _lib
+        a = _lib.FlexWindowRefreshArgs()
+        a.start, a.ring_rows = start_cell.data_ptr(), self.slabs * self.n_envs
+        nj = nc = 0
+        td_args = None
+        for ring_name, col0, width, row_off, rows, dst in plan:
+            if ring_name == "stack_ring":
+                if nc >= _lib.FLEXNET_WINDOW_MAX_CELLS or rows + row_off > self.stack_tail or self.stack_rows != a.ring_rows:
+                    return None
+                a.cell[nc], a.cell_mod[nc] = dst[0].data_ptr(), self.stack_rows
+                nc += 1
+                continue
+            if ring_name == "row_ring" or nj >= _lib.FLEXNET_WINDOW_MAX_JOBS:
+                return None
+            ring = getattr(self, ring_name)
+            if ring.shape[0] * ring.shape[1] != a.ring_rows:
+                return None
+            stride = ring.shape[2]
+            width = stride if width is None else width
+            a.base[nj], a.dst[nj] = ring.data_ptr() + 4 * col0, dst.data_ptr()
+            a.rows[nj], a.row_off[nj], a.width[nj], a.src_stride[nj] = rows, row_off, width, stride
+            if td is not None and dst is td[0]:
+                a.reward_job, td_args = nj, td[1]
+            nj += 1
+        if td is not None and td_args is None:
+            return None
+        a.n_jobs, a.n_cells = nj, nc
+        return a, td_args
+
+    def window_refresh(self, args):
+        """Launch a refresh prepared by window_refresh_args on the current stream (capturable)."""
+        import ctypes as C
+        from . import _lib
+        a, td_args = args
+        _lib.check(_lib.load().flexnet_window_refresh(C.byref(a), C.byref(td_args) if td_args is not None else None,
+                                                      C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_window_refresh")
+
     def scatter(self, ring_name, src, slot, rows):
         """The reverse of one gather job: rows of the contiguous [rows, width] tensor ``src`` into the ring's slots of the
         global slot range [slot, slot + rows) (two pieces at the seam): one launch of flexnet_gather_rows."""

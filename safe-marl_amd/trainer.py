@@ -56,6 +56,10 @@ class PGTrainer(object):
         self._bootstrap_graphs = {}                    # pass size -> graph of MADDPG.bootstrap_values on a static batch
         self._cached_graphs = {}
         self._cached_ready = False
+        # the value sub-updates of an update event as ONE graph (replay_event; FLEX_EVENT_GRAPH=0: one graph launch each)
+        self.event_graphs = os.environ.get("FLEX_EVENT_GRAPH", "1") != "0"
+        self._event_graphs = {}                        # (kind, count) -> graph of `count` sub-updates, or False (not possible)
+        self.event_graph_replays = 0
         self.bootstrap_cached_events = 0
         # more than one rank: the sub-update region is split at the exchange step — graph A (loss, gradients into one flat
         # bucket), eager all-reduce, graph B (clip, RMSprop) — the form that has run on hardware (gloo ranks on one GPU, RCCL
@@ -288,10 +292,71 @@ class PGTrainer(object):
             g["free"].record(main)
             ready = nxt
 
-    def _replay_event_plain(self, stat, kinds, starts):
-        """Gather, then replay, one sub-update at a time; ``starts``: windows already drawn (index in ``kinds`` -> slot)."""
+    def _ensure_event_graph(self, kind, count):
+        """``count`` consecutive sub-updates of ``kind`` ("value" / "value_cached") as ONE HIP graph: each refreshes the static
+        batch of the kind's single-step graph from ITS cell of a device array of window starts (flexnet_window_refresh, the
+        statistics rider included) and runs the very body that graph holds.  A graph launch ends with ~8 us of hand-over before
+        the next thing on the stream starts; an update event of model.py:47-50 paid that ten times.  One rank only (the split
+        form's eager all-reduce sits between two graphs), not with the side-stream refresh.  None: run them one at a time."""
+        if not self.event_graphs or self.world > 1 or self.pipeline_updates or count < 2:
+            return None
+        g = self._ensure_graph(kind)
+        if g is None:
+            return None
+        key = (kind, count)
+        eg = self._event_graphs.get(key)
+        if eg is not None and (eg is False or eg["base"] is g):
+            return eg or None
         buf = self.replay_buffer
+        starts = th.zeros(count, dtype=th.int64, device=self.device)
+        refresh = [buf.window_refresh_args(g["plan"], starts[j:j + 1], g.get("td")) for j in range(count)]
+        eg = False
+        if all(r is not None for r in refresh):
+            graph, out = th.cuda.CUDAGraph(), {}
+            self.behaviour_net.bootstrap_from_batch = kind == "value_cached"
+            try:
+                # (no warm-up of its own: the single-step graph's capture has run these launches on this batch already, and a
+                #  capture executes nothing — weights, optimiser state and statistics are untouched)
+                with graph_capture(graph):
+                    for j in range(count):
+                        buf.window_refresh(refresh[j])
+                        self._sub_update("value", out, g["batch"], fresh_leaves=True)
+                eg = dict(graph=graph, stat=out, starts=starts, base=g, refresh=refresh,
+                          expands=any(p[0] == "stack_ring" for p in g["plan"]))
+            except Exception as exc:
+                import warnings
+                warnings.warn(f"update-event graph capture failed ({exc}); one graph launch per sub-update")
+                th.cuda.synchronize()
+            finally:
+                self.behaviour_net.bootstrap_from_batch = False
+        self._event_graphs[key] = eg
+        return eg or None
+
+    def _replay_event_plain(self, stat, kinds, starts):
+        """Gather, then replay, one sub-update at a time — runs of value sub-updates as one graph where that form exists
+        (_ensure_event_graph); ``starts``: windows already drawn (index in ``kinds`` -> slot)."""
+        buf = self.replay_buffer
+        done_upto = 0
         for j, which in enumerate(kinds):
+            if j < done_upto:
+                continue
+            if which in ("value", "value_cached"):
+                run = 1
+                while j + run < len(kinds) and kinds[j + run] == which:
+                    run += 1
+                eg = self._ensure_event_graph(which, run)
+                if eg is not None:
+                    bs = eg["base"]["bs"]
+                    # drawn in sub-update order, like the one-at-a-time calls (nothing else draws from the NumPy stream in between)
+                    slots = [starts[i] if i in starts else buf.sample_slot(bs) for i in range(j, j + run)]
+                    if eg["expands"]:
+                        buf.expand_stacked()
+                    eg["starts"].copy_(th.tensor(slots, dtype=th.int64))       # (pageable source: staged before the call returns)
+                    eg["graph"].replay()
+                    stat.update(eg["stat"])
+                    self.event_graph_replays += 1
+                    done_upto = j + run
+                    continue
             g = self._ensure_graph(which)
             if g is None:                               # (graphs went away mid-event: the eager step on the same window)
                 need = "value" if which == "value_cached" else which

@@ -50,6 +50,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.FlexRolloutPackArgs) == 8 * 4 + 16 * 8
     assert C.sizeof(_lib.FlexGatherArgs) == 8 + 12 * (8 + 8 + 8 + 4 + 4 + 4)
     assert C.sizeof(_lib.FlexSumArgs) == 8 + 4 + 4 + 3 * 8 + 8
+    assert C.sizeof(_lib.FlexWindowRefreshArgs) == 8 + 8 + 8 + 8 * (8 + 8 + 8 + 8 + 4 + 4) + 4 * (8 + 8) + 8   # round 5
     assert C.sizeof(_lib.FlexWgradArgs) == 4 * 8 + 4 * 4 + 5 * 8 + 3 * 8 + 2 * 4 + 8     # + b_row_cell (round 5)
     assert C.sizeof(_lib.FlexLinear2Args) == 8 + 8 * 4 + 6 * 8
     assert C.sizeof(_lib.FlexLnReluArgs) == 4 * 4 + 13 * 8 + 8

@@ -227,3 +227,58 @@ def test_statistics_ride_in_the_gather_launch(rows, wrap):
     assert lib.flexnet_gather_rows_td(C.byref(a), reward_job, 3, C.byref(t), stream) != 0
     t.rows = rows - 1
     assert lib.flexnet_gather_rows_td(C.byref(a), reward_job, len(segs), C.byref(t), stream) != 0
+
+
+@pytest.mark.parametrize("start", [1234, 40000 * 7 + 39000, 40000 * 3 - 1])
+def test_window_refresh_from_a_device_cell_equals_the_host_side_gather(start):
+    """include/flexnet.h: flexnet_window_refresh — the refresh of a static batch with the window's first slot read from device
+    memory (what lets ONE HIP graph hold every value sub-update of an update event, model.py:47-50): copies, first-row cells
+    and the riding statistics pass equal flexnet_gather_rows_td's on the same window, seam included, bit for bit."""
+    import ctypes as C
+    from safe_marl_amd import _lib
+    lib = _lib.load()
+    rows, n, act_w, stride, cap, row_off = 8192, 5, 20, 27, 40000, 4096
+    g = torch.Generator(device="cuda").manual_seed(start % 1000)
+    small = torch.randn(cap, stride, device="cuda", generator=g)
+    nv = torch.randn(cap, n, device="cuda", generator=g)
+    out = {k: torch.full((rows, w), float("nan"), device="cuda") for k, w in (("action", act_w), ("reward", n), ("done", 1), ("nv", n))}
+    cell = torch.full((2,), -1, dtype=torch.int64, device="cuda")
+    start_cell = torch.tensor([start], dtype=torch.int64, device="cuda")
+    a = _lib.FlexWindowRefreshArgs()
+    a.start, a.ring_rows = start_cell.data_ptr(), cap
+    jobs = [(small, 0, act_w, 0, out["action"]), (small, act_w, n, 0, out["reward"]), (small, act_w + n, 1, 0, out["done"]),
+            (nv, 0, n, row_off, out["nv"])]
+    for j, (ring, col0, w, off, dst) in enumerate(jobs):
+        a.base[j], a.dst[j], a.rows[j], a.row_off[j] = ring.data_ptr() + 4 * col0, dst.data_ptr(), rows, off
+        a.width[j], a.src_stride[j] = w, ring.shape[1]
+    a.n_jobs, a.n_cells, a.reward_job = len(jobs), 2, 1
+    a.cell[0], a.cell_mod[0], a.cell[1], a.cell_mod[1] = cell[0:1].data_ptr(), cap, cell[1:2].data_ptr(), 1000
+    ws = [torch.zeros(_lib.FLEXNET_TD_WS_FLOATS // 2, dtype=torch.float64, device="cuda") for _ in range(2)]
+    t = _lib.FlexTdLossArgs()
+    t.rows, t.n_agents, t.normalise, t.reward = rows, n, 1, out["reward"].data_ptr()
+    t.workspace, t.workspace_floats = ws[0].data_ptr(), 2 * ws[0].numel()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.flexnet_window_refresh(C.byref(a), C.byref(t), stream), "flexnet_window_refresh")
+    torch.cuda.synchronize()
+    idx = (start + torch.arange(rows, device="cuda")) % cap
+    assert torch.equal(out["action"], small[idx, :act_w]) and torch.equal(out["reward"], small[idx, act_w:act_w + n])
+    assert torch.equal(out["done"], small[idx, act_w + n:act_w + n + 1]) and torch.equal(out["nv"], nv[(idx + row_off) % cap])
+    assert cell.tolist() == [start % cap, start % 1000]
+    t.workspace = ws[1].data_ptr()
+    _lib.check(lib.flexnet_td_stats(C.byref(t), stream), "flexnet_td_stats")
+    torch.cuda.synchronize()
+    k = _lib.FLEXNET_TD_STAT_DOUBLES
+    assert torch.equal(ws[0][:k], ws[1][:k])
+    # without the rider; cells alone; refused arguments
+    out["reward"].fill_(float("nan"))
+    _lib.check(lib.flexnet_window_refresh(C.byref(a), None, stream), "flexnet_window_refresh")
+    torch.cuda.synchronize()
+    assert torch.equal(out["reward"], small[idx, act_w:act_w + n])
+    a.n_jobs = 0
+    cell.fill_(-1)
+    _lib.check(lib.flexnet_window_refresh(C.byref(a), None, stream), "flexnet_window_refresh")
+    torch.cuda.synchronize()
+    assert cell.tolist() == [start % cap, start % 1000]
+    assert lib.flexnet_window_refresh(C.byref(a), C.byref(t), stream) != 0           # the rider's job does not exist
+    a.n_jobs, a.reward_job = len(jobs), 0
+    assert lib.flexnet_window_refresh(C.byref(a), C.byref(t), stream) != 0           # job 0 is not the reward's copy
