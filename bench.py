@@ -450,7 +450,9 @@ def critic_backward_roofline(timed):
     t = timed(call)
     flops = 3.0 * 2 * 64 * 64 * samples * n
     return {"kernel": "critic_tail_pgrad16_kernel<TD, SM> + statistics, finish", "rows": samples * n,
-            "what": "value loss + critic backward of a value sub-update (3 launches)", "bound": "mfma", "dtype": "f32",
+            "what": "value loss + critic backward as flexnet_critic_td_backward launches them (3 launches; inside a captured value "
+                    "sub-update the statistics ride in the batch refresh and the finish in the weight gradient's second stage)",
+            "bound": "mfma", "dtype": "f32",
             "achieved": flops / t / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t / 1e12 / 157.3, "launch_us": t * 1e6,
             "note": "16-row tiles on v_mfma_f32_16x16x4_f32, two wavefronts per SIMD; sample-major: d_z_shared / d_z_id formed in the "
                     "backward kernel, no dz1 round trip, no fold launch (3 launches: statistics, backward, finish)"}
@@ -486,7 +488,7 @@ def kernel_shares_child():
     if total <= 0:
         raise SystemExit("no device activity recorded")
     top = sorted(agg.items(), key=lambda kv: -kv[1][0])[:16]
-    subs = sum(v[1] for k, v in agg.items() if k.startswith("gather_rows_kernel"))
+    subs = sum(v[1] for k, v in agg.items() if "clip_rmsprop_kernel" in k)      # one optimiser step per sub-update
     print(json.dumps({"episode": f"MADDPG 5 agents x 4096 envs, one episode of 95 vector steps incl. {subs} sub-updates "
                                  f"(an update event every 60 steps: 10 value + 1 policy)",
                       "gpu_ms_total": total / 1e3,

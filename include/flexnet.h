@@ -516,6 +516,11 @@ typedef struct {
 } FlexWindowRefreshArgs;
 
 int flexnet_window_refresh(const FlexWindowRefreshArgs* args, const FlexTdLossArgs* td /* NULL: none */, void* stream);
+/* flexnet_clip_rmsprop(opt) followed by flexnet_window_refresh(refresh, td) without a launch for the refresh: inside an update
+ * event's graph the optimiser step that ends one value sub-update is followed by the refresh for the next, which depends on
+ * nothing the step computes — its statistics blocks ride in the norm launch, its copy blocks in the step launch.  The caller
+ * guarantees that nothing still reads what the refresh writes (trainer.py:81-108 order: the loss's kernels are done). */
+int flexnet_clip_rmsprop_refresh(const FlexClipRmspropArgs* opt, const FlexWindowRefreshArgs* refresh, const FlexTdLossArgs* td, void* stream);
 
 #ifdef __cplusplus
 }

@@ -74,7 +74,7 @@ SYMBOLS = (
     "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_obs_view", "flexenv_obs_source", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_rollout_burst", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version", "flexenv_abi_version",
-    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_td_loss", "flexnet_td_stats", "flexnet_critic_td_backward", "flexnet_critic_td_backward_phases", "flexnet_wgrad_critic_finish",
+    "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_clip_rmsprop_refresh", "flexnet_td_loss", "flexnet_td_stats", "flexnet_critic_td_backward", "flexnet_critic_td_backward_phases", "flexnet_wgrad_critic_finish",
     "flexnet_scaled_sum", "flexnet_agent_sum_explore", "flexnet_gather_rows", "flexnet_gather_rows_td", "flexnet_window_refresh", "flexnet_gather_window", "flexnet_linear2", "flexnet_gru_backward",
     "flexopf_qp_work_doubles", "flexopf_qp_solve",
 )
@@ -328,6 +328,8 @@ def load():
     lib.flexnet_wgrad.restype = C.c_int
     lib.flexnet_clip_rmsprop.argtypes = [C.POINTER(FlexClipRmspropArgs), vp]
     lib.flexnet_clip_rmsprop.restype = C.c_int
+    lib.flexnet_clip_rmsprop_refresh.argtypes = [C.POINTER(FlexClipRmspropArgs), C.POINTER(FlexWindowRefreshArgs), C.POINTER(FlexTdLossArgs), vp]
+    lib.flexnet_clip_rmsprop_refresh.restype = C.c_int
     lib.flexnet_td_loss.argtypes = [C.POINTER(FlexTdLossArgs), vp]
     lib.flexnet_td_loss.restype = C.c_int
     lib.flexnet_td_stats.argtypes = [C.POINTER(FlexTdLossArgs), vp]

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "flexnet.h"
+#include "window_refresh.h"
 
 #define OPT_THREADS 256
 #define OPT_BLOCKS 64              // partial sums of squares, one per block (= one per lane of the wavefront that folds them)
@@ -37,8 +38,25 @@ __device__ __forceinline__ int opt_find(const OptFlat& f, int n_tensors, int64_t
     return t;
 }
 
+// RIDER (flexnet_clip_rmsprop_refresh): inside an update event's graph the optimiser step that ends value sub-update j is
+// followed by the refresh of the static batch for sub-update j + 1 (csrc/window_refresh.h) — which depends on nothing the step
+// computes, and whose targets (the batch's small columns, the in-place windows' cells, the reward statistics) nobody reads
+// any more once sub-update j's weight gradient and finish are done.  Its statistics blocks ride behind pass 1's blocks, its
+// copy blocks behind pass 2's: no launch of its own (12 us of a 335-us sub-update).
+static_assert(OPT_THREADS == WINDOW_THREADS, "the refresh blocks ride in the optimiser's launches");
+struct WindowRider {
+    FlexWindowRefreshArgs a;
+    WindowPlan p;
+    FlexTdLossArgs td;
+    int32_t has_td, copy_blocks;
+};
+
 // pass 1: this block's share of sum g^2 (fixed order per thread, fixed trees above it: bit-reproducible)
-__global__ __launch_bounds__(OPT_THREADS) void clip_norm_kernel(FlexClipRmspropArgs a, float* partial) {
+template <bool RIDER>
+__global__ __launch_bounds__(OPT_THREADS) void clip_norm_kernel(FlexClipRmspropArgs a, float* partial, WindowRider r) {
+    if constexpr (RIDER) {
+        if (blockIdx.x >= OPT_BLOCKS) { window_refresh_td_block(r.a, r.td, blockIdx.x - OPT_BLOCKS); return; }
+    }
     __shared__ float part[OPT_THREADS / 64];
     __shared__ OptFlat f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,7 +90,11 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_norm_kernel(FlexClipRmspropA
 }
 
 // pass 2: norm from the partials, clip factor, RMSprop step on this block's share
-__global__ __launch_bounds__(OPT_THREADS) void clip_rmsprop_kernel(FlexClipRmspropArgs a, const float* partial) {
+template <bool RIDER>
+__global__ __launch_bounds__(OPT_THREADS) void clip_rmsprop_kernel(FlexClipRmspropArgs a, const float* partial, WindowRider r) {
+    if constexpr (RIDER) {
+        if (blockIdx.x >= OPT_BLOCKS) { window_refresh_copy_block(r.a, r.p, blockIdx.x - OPT_BLOCKS); return; }
+    }
     const int tid = threadIdx.x;
     __shared__ float tot_s;
     __shared__ OptFlat f;
@@ -118,7 +140,7 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_rmsprop_kernel(FlexClipRmspr
     if (gid < a.n_tensors && a.step[gid]) *a.step[gid] += 1.0f;
 }
 
-extern "C" int flexnet_clip_rmsprop(const FlexClipRmspropArgs* a, void* stream) {
+static int clip_rmsprop_run(const FlexClipRmspropArgs* a, const WindowRider* r, void* stream) {
     if (!a || a->n_tensors < 0 || a->n_tensors > FLEXNET_OPT_MAX_TENSORS) return FLEXNET_EINVAL;
     int64_t total = 0;
     for (int t = 0; t < a->n_tensors; ++t) {
@@ -127,8 +149,32 @@ extern "C" int flexnet_clip_rmsprop(const FlexClipRmspropArgs* a, void* stream) 
     }
     if (total > FLEXNET_OPT_MAX_ELEMENTS) return FLEXNET_EUNSUPPORTED;      // a fixed small grid: meant for the MADDPG networks
     if (!a->workspace) return FLEXNET_EINVAL;
-    if (a->n_tensors == 0) return FLEXNET_OK;
-    hipLaunchKernelGGL(clip_norm_kernel, dim3(OPT_BLOCKS), dim3(OPT_THREADS), 0, (hipStream_t)stream, *a, a->workspace);
-    hipLaunchKernelGGL(clip_rmsprop_kernel, dim3(OPT_BLOCKS), dim3(OPT_THREADS), 0, (hipStream_t)stream, *a, a->workspace);
+    if (a->n_tensors == 0) return r ? FLEXNET_EINVAL : FLEXNET_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (r) {
+        hipLaunchKernelGGL(clip_norm_kernel<true>, dim3(OPT_BLOCKS + (r->has_td ? TD_BLOCKS : 0)), dim3(OPT_THREADS), 0, s, *a, a->workspace, *r);
+        hipLaunchKernelGGL(clip_rmsprop_kernel<true>, dim3(OPT_BLOCKS + r->copy_blocks), dim3(OPT_THREADS), 0, s, *a, a->workspace, *r);
+    } else {
+        WindowRider none;
+        none.has_td = none.copy_blocks = 0;                       // (never read without RIDER)
+        hipLaunchKernelGGL(clip_norm_kernel<false>, dim3(OPT_BLOCKS), dim3(OPT_THREADS), 0, s, *a, a->workspace, none);
+        hipLaunchKernelGGL(clip_rmsprop_kernel<false>, dim3(OPT_BLOCKS), dim3(OPT_THREADS), 0, s, *a, a->workspace, none);
+    }
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
+}
+
+extern "C" int flexnet_clip_rmsprop(const FlexClipRmspropArgs* a, void* stream) { return clip_rmsprop_run(a, nullptr, stream); }
+
+// flexnet_clip_rmsprop(a) followed by flexnet_window_refresh(refresh, td) in the optimiser's two launches (include/flexnet.h):
+// the caller guarantees that nothing still reads what the refresh writes (see WindowRider above).
+extern "C" int flexnet_clip_rmsprop_refresh(const FlexClipRmspropArgs* a, const FlexWindowRefreshArgs* refresh, const FlexTdLossArgs* td,
+                                            void* stream) {
+    if (!a || !refresh) return FLEXNET_EINVAL;
+    WindowRider r;
+    const int rc = window_refresh_prepare(refresh, td, &r.p, &r.copy_blocks);
+    if (rc != FLEXNET_OK) return rc;
+    r.a = *refresh;
+    r.has_td = td ? 1 : 0;
+    if (td) r.td = *td;
+    return clip_rmsprop_run(a, &r, stream);
 }

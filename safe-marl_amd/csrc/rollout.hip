@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include "flexnet.h"
 #include "flex_td.h"
+#include "window_refresh.h"
 
 #define PACK_THREADS 256
 #define PACK_ENVS 4                // environments per copy block: all their loads are in flight before the first store
@@ -392,87 +393,24 @@ extern "C" int flexnet_gather_rows_td(const FlexGatherArgs* a, int32_t reward_jo
     return gather_rows_run(a, &t, stream);
 }
 
-// ---- the same refresh with the window's first slot read from device memory (flexnet_window_refresh) ----------------------
-struct WindowPlan { int first_block[FLEXNET_WINDOW_MAX_JOBS + 1]; };
-
+// ---- the same refresh with the window's first slot read from device memory (flexnet_window_refresh, csrc/window_refresh.h) ---
 template <bool TD>
-__global__ __launch_bounds__(GATHER_THREADS) void window_refresh_kernel(FlexWindowRefreshArgs a, WindowPlan p, FlexTdLossArgs td) {
-    const int64_t start = *a.start, cap = a.ring_rows;
+__global__ __launch_bounds__(WINDOW_THREADS) void window_refresh_kernel(FlexWindowRefreshArgs a, WindowPlan p, FlexTdLossArgs td) {
     int bx = blockIdx.x;
     if constexpr (TD) {
-        if (bx < TD_BLOCKS) {                                     // (first in the grid: gather_rows_kernel)
-            const int j = a.reward_job;
-            const int64_t first = (start + a.row_off[j]) % cap;
-            const int64_t rows0 = a.rows[j] < cap - first ? a.rows[j] : cap - first;
-            const TdRewardRows rr = {a.base[j] + first * a.src_stride[j], a.base[j], rows0, a.src_stride[j], a.src_stride[j]};
-            td_stats_block(td, rr, bx);
-            return;
-        }
+        if (bx < TD_BLOCKS) { window_refresh_td_block(a, td, bx); return; }      // (first in the grid: gather_rows_kernel)
         bx -= TD_BLOCKS;
     }
-    if (bx == 0 && threadIdx.x < a.n_cells) *a.cell[threadIdx.x] = start % a.cell_mod[threadIdx.x];
-    if (a.n_jobs == 0) return;
-    int j = 0;
-    while (j + 1 < a.n_jobs && bx >= p.first_block[j + 1]) ++j;
-    const int nb = p.first_block[j + 1] - p.first_block[j], b = bx - p.first_block[j];
-    const float* __restrict__ src = a.base[j];
-    float* __restrict__ dst = a.dst[j];
-    const int w = a.width[j], ss = a.src_stride[j];
-    const int rows = (int)a.rows[j];                          // (< 2^31 / width: checked by the caller)
-    const int64_t first = (start + a.row_off[j]) % cap;
-    const int until_seam = cap - first < rows ? (int)(cap - first) : rows;      // rows before the ring's seam
-    if (w <= 8) {                                             // narrow columns: a thread per ROW (gather_rows_kernel)
-        for (int r = b * GATHER_THREADS + threadIdx.x; r < rows; r += nb * GATHER_THREADS) {
-            const int64_t pr = r < until_seam ? first + r : (int64_t)(r - until_seam);
-            const float* sp = src + pr * ss;
-            float* dp = dst + (int64_t)r * w;
-            float v[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = c < w ? sp[c] : 0.0f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) if (c < w) dp[c] = v[c];
-        }
-    } else {
-        const int total = rows * w;
-        for (int i = b * GATHER_THREADS + threadIdx.x; i < total; i += nb * GATHER_THREADS) {
-            const int r = i / w, c = i - r * w;
-            const int64_t pr = r < until_seam ? first + r : (int64_t)(r - until_seam);
-            dst[i] = src[pr * ss + c];
-        }
-    }
+    window_refresh_copy_block(a, p, bx);
 }
 
 extern "C" int flexnet_window_refresh(const FlexWindowRefreshArgs* a, const FlexTdLossArgs* td, void* stream) {
-    if (!a || !a->start || a->n_jobs < 0 || a->n_jobs > FLEXNET_WINDOW_MAX_JOBS || a->n_cells < 0 ||
-        a->n_cells > FLEXNET_WINDOW_MAX_CELLS || a->ring_rows < 1 || (a->n_jobs == 0 && a->n_cells == 0))
-        return FLEXNET_EINVAL;
-    for (int k = 0; k < a->n_cells; ++k) if (!a->cell[k] || a->cell_mod[k] < 1) return FLEXNET_EINVAL;
     WindowPlan p;
     int blocks = 0;
-    for (int j = 0; j < a->n_jobs; ++j) {
-        if (!a->base[j] || !a->dst[j] || a->rows[j] < 0 || a->rows[j] > a->ring_rows || a->row_off[j] < 0 || a->width[j] < 1 ||
-            a->src_stride[j] < a->width[j] || a->rows[j] * (int64_t)a->width[j] >= 0x7fffffffll)
-            return FLEXNET_EINVAL;
-        p.first_block[j] = blocks;
-        const int64_t bytes = a->rows[j] * (int64_t)a->width[j] * 4;
-        int64_t nb = (bytes + 16383) / 16384;
-        nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
-        blocks += (int)nb;
-    }
-    if (a->n_jobs == 0) { p.first_block[0] = 0; blocks = 1; }            // cells only: one block
-    else p.first_block[a->n_jobs] = blocks;
-    for (int j = a->n_jobs + 1; j <= FLEXNET_WINDOW_MAX_JOBS; ++j) p.first_block[j] = blocks;
-    if (a->n_jobs == 0) p.first_block[0] = 0;
+    const int rc = window_refresh_prepare(a, td, &p, &blocks);
+    if (rc != FLEXNET_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (td) {
-        const int j = a->reward_job;
-        if (j < 0 || j >= a->n_jobs || a->width[j] != td->n_agents || a->rows[j] != td->rows || td->rows < 1 || td->n_agents < 1 ||
-            td->n_agents > TD_NA || !td->workspace || td->workspace_floats < FLEXNET_TD_WS_FLOATS ||
-            (reinterpret_cast<uintptr_t>(td->workspace) & 7) != 0)
-            return FLEXNET_EINVAL;
-        hipLaunchKernelGGL(window_refresh_kernel<true>, dim3(blocks + TD_BLOCKS), dim3(GATHER_THREADS), 0, s, *a, p, *td);
-    } else {
-        hipLaunchKernelGGL(window_refresh_kernel<false>, dim3(blocks), dim3(GATHER_THREADS), 0, s, *a, p, FlexTdLossArgs{});
-    }
+    if (td) hipLaunchKernelGGL(window_refresh_kernel<true>, dim3(blocks + TD_BLOCKS), dim3(WINDOW_THREADS), 0, s, *a, p, *td);
+    else hipLaunchKernelGGL(window_refresh_kernel<false>, dim3(blocks), dim3(WINDOW_THREADS), 0, s, *a, p, FlexTdLossArgs{});
     return hipGetLastError() == hipSuccess ? FLEXNET_OK : FLEXNET_EHIP;
 }

@@ -27,9 +27,12 @@ def _supported(opt, params):
                and p.grad.is_contiguous() and not p.grad.is_sparse for p in live)
 
 
-def clip_and_step(opt, params, max_norm):
+def clip_and_step(opt, params, max_norm, refresh=None):
     """Clip the gradients of ``params`` to ``max_norm`` (2-norm over all of them), take one RMSprop step, return the
-    pre-clip norm (a 0-dim tensor) — ``clip_grad_norm_`` + ``opt.step()``."""
+    pre-clip norm (a 0-dim tensor) — ``clip_grad_norm_`` + ``opt.step()``.
+    ``refresh`` = (FlexWindowRefreshArgs, FlexTdLossArgs or None): the refresh of the NEXT sub-update's static batch rides in
+    the step's two launches (flexnet_clip_rmsprop_refresh; trainer._ensure_event_graph) — launched on its own after the step
+    where the kernel path does not apply."""
     if not (params and params[0].is_cuda and _supported(opt, params)):
         if params and params[0].is_cuda:
             from .util import note_fallback
@@ -37,6 +40,8 @@ def clip_and_step(opt, params, max_norm):
                                           "centering / weight decay, contiguous fp32 tensors)")
         norm = th.nn.utils.clip_grad_norm_(params, max_norm)
         opt.step()
+        if refresh is not None:
+            _launch_refresh(refresh)
         return norm
     from . import _lib
     lib = _lib.load()
@@ -58,6 +63,20 @@ def clip_and_step(opt, params, max_norm):
         a.square_avg[k], a.step[k] = st["square_avg"].data_ptr(), st["step"].data_ptr()
         k += 1
     a.n_tensors = k
-    _lib.check(lib.flexnet_clip_rmsprop(C.byref(a), C.c_void_p(th.cuda.current_stream().cuda_stream)),
-               "flexnet_clip_rmsprop")
+    stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
+    if refresh is not None and k > 0:
+        ra, td = refresh
+        _lib.check(lib.flexnet_clip_rmsprop_refresh(C.byref(a), C.byref(ra), C.byref(td) if td is not None else None, stream),
+                   "flexnet_clip_rmsprop_refresh")
+        return norm
+    _lib.check(lib.flexnet_clip_rmsprop(C.byref(a), stream), "flexnet_clip_rmsprop")
+    if refresh is not None:
+        _launch_refresh(refresh)
     return norm
+
+
+def _launch_refresh(refresh):
+    from . import _lib
+    ra, td = refresh
+    _lib.check(_lib.load().flexnet_window_refresh(C.byref(ra), C.byref(td) if td is not None else None,
+                                                  C.c_void_p(th.cuda.current_stream().cuda_stream)), "flexnet_window_refresh")

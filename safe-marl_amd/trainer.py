@@ -317,10 +317,18 @@ class PGTrainer(object):
             try:
                 # (no warm-up of its own: the single-step graph's capture has run these launches on this batch already, and a
                 #  capture executes nothing — weights, optimiser state and statistics are untouched)
+                # the refresh for sub-update j + 1 rides in the optimiser launches that end sub-update j (optim.clip_and_step:
+                # flexnet_clip_rmsprop_refresh; FLEX_REFRESH_RIDER=0: a launch of its own)
+                ride = os.environ.get("FLEX_REFRESH_RIDER", "1") != "0"
                 with graph_capture(graph):
+                    buf.window_refresh(refresh[0])
                     for j in range(count):
-                        buf.window_refresh(refresh[j])
+                        nxt = refresh[j + 1] if j + 1 < count else None
+                        self._next_refresh = nxt if ride else None
                         self._sub_update("value", out, g["batch"], fresh_leaves=True)
+                        if nxt is not None and (not ride or self._next_refresh is not None):
+                            buf.window_refresh(nxt)              # (not taken along by the step)
+                        self._next_refresh = None
                 eg = dict(graph=graph, stat=out, starts=starts, base=g, refresh=refresh,
                           expands=any(p[0] == "stack_ring" for p in g["plan"]))
             except Exception as exc:
@@ -329,6 +337,7 @@ class PGTrainer(object):
                 th.cuda.synchronize()
             finally:
                 self.behaviour_net.bootstrap_from_batch = False
+                self._next_refresh = None
         self._event_graphs[key] = eg
         return eg or None
 
@@ -785,7 +794,9 @@ class PGTrainer(object):
         params = opt.param_groups[0]["params"]
         if flat is not None and self.world > 1:
             flat.mul_(1.0 / self.world)               # the bucket holds the SUM over ranks
-        grad_norm = clip_and_step(opt, params, self.args.grad_clip_eps)
+        refresh = getattr(self, "_next_refresh", None)
+        self._next_refresh = None                     # (taken: _ensure_event_graph launches it itself otherwise)
+        grad_norm = clip_and_step(opt, params, self.args.grad_clip_eps, refresh=refresh)
         stat[f"mean_train_{which}_grad_norm"] = grad_norm.detach()
 
     # ---- episode loop hooks (train_agent.py:125-146) --------------------------------------------

@@ -8,13 +8,13 @@ def short(n):
     return n.split("(")[0][-64:]
 names = [short(r["Kernel_Name"]) for r in rows]
 # an update event of replay_event: 10 value + 1 policy sub-updates; policy sub-updates contain gru_backward_fused_kernel
-pol = [i for i, n in enumerate(names) if n.startswith("void gru_backward_fused_kernel")]
+pol = [i for i, n in enumerate(names) if "gru_backward_fused_kernel" in n]
 if len(pol) < 3:
     print("fewer than 3 policy sub-updates in the trace"); sys.exit(0)
 a, b = pol[-3] + 1, pol[-2] + 1
 # extend to the end of that policy sub-update: up to and including its clip_rmsprop
 def end_of(i):
-    while i < len(names) and not names[i].startswith("clip_rmsprop_kernel"):
+    while i < len(names) and not "clip_rmsprop_kernel" in names[i]:
         i += 1
     return i + 1
 a, b = end_of(a), end_of(b)
