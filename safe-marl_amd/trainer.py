@@ -219,6 +219,9 @@ class PGTrainer(object):
         bs_all = self.effective_batch_size()
         starts, chunks, boot = {}, [], None
         net = self.behaviour_net
+        # every graph an event may replay exists after the FIRST event (a look-up afterwards): a capture at first use would
+        # land in the middle of somebody's timed region
+        self._ensure_event_graph(kinds[0], n_value)
         # (Passes of ONE size, the sub-update's batch: quarter passes for what an interval leaves over were tried — 12.4 -> 12.0
         # ms per event at the reference's reuse — and given up: at another row count the library picks another first-layer
         # GEMM kernel, the values differ in the seventh digit, and the event is no longer bit-identical to the plain one.)
@@ -236,6 +239,8 @@ class PGTrainer(object):
                 ok = self._ensure_graph("value_cached", 1) is not None
             if not ok:
                 self.cache_bootstrap = eligible = False
+            else:
+                self._ensure_event_graph("value_cached", n_value)       # (the event's one-graph form, captured at the same point)
         if eligible:
             vstarts = [buf.sample_slot(bs_all) for _ in range(n_value)]
             starts = dict(enumerate(vstarts))

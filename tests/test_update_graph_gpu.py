@@ -405,3 +405,36 @@ def test_plain_value_sub_updates_read_both_views_of_their_window_in_place():
     assert torch.isnan(a._update_graphs["value"]["batch"].state).all() and torch.isnan(a._update_graphs["value"]["batch"].next_state).all()
     assert torch.isnan(a._update_graphs["value"]["batch"].hid).all()
     assert "hid_ring" not in pa and "hid_ring" in pb
+
+
+@pytest.mark.parametrize("reuse", [False, True])
+def test_an_events_value_sub_updates_as_one_graph_change_nothing(reuse, monkeypatch):
+    """Round 5: trainer.replay_event runs the ten value sub-updates of an update event (model.py:47-50) as
+    ONE HIP graph — every sub-update refreshing its static batch from its own cell of a device array of window starts
+    (flexnet_window_refresh), the refresh for the next one riding in the optimiser step's launches
+    (flexnet_clip_rmsprop_refresh), the reward statistics riding in the refresh — against one graph launch per sub-update with
+    the refresh issued from the host (trainer.event_graphs off): the same kernels on the same windows in the same order, so the
+    same bits, at the default batch (plain value sub-updates) and at the reference's sample reuse (bootstrap values filed per
+    event, "value_cached")."""
+    n_envs = 1024 if reuse else 4096
+    a, b = _trainer(True, n_envs), _trainer(True, n_envs)
+    b.event_graphs = False
+    if reuse:
+        for tr in (a, b):
+            tr.batch_scale = 1024                                # 32 slabs per window of a ring that holds 95: the windows overlap
+    for ev in range(3):
+        stats = []
+        for tr in (a, b):
+            np.random.seed(500 + ev)
+            st = {}
+            tr.replay_event(st, 10, 1)
+            torch.cuda.synchronize()
+            stats.append({k: float(v) for k, v in st.items()})
+        assert stats[0] == stats[1], (ev, stats)
+        for (ka, va), (kb, vb) in zip(a.behaviour_net.state_dict().items(), b.behaviour_net.state_dict().items()):
+            assert torch.equal(va, vb), (ev, ka)
+    assert a.event_graph_replays == 3 and b.event_graph_replays == 0
+    kind = "value_cached" if reuse else "value"
+    assert a.bootstrap_cached_events == (3 if reuse else 0)
+    eg = a._event_graphs[(kind, 10)]
+    assert eg and eg["base"].get("td") is not None              # the statistics ride in the refresh
