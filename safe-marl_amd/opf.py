@@ -533,7 +533,14 @@ class BatchedOPF:
 
     def _pf(self, pnet, qnet, want_branch=False):
         shape = pnet.shape[:-1]
-        out = pf_solve_batch(self.net, pnet.reshape(-1, self.n_bus), qnet.reshape(-1, self.n_bus), want_branch=True)
+        # Newton on the tree, not the sweeps the env steps with: the central differences of linearise() divide the solver's
+        # error by h = 5e-5, and a sweep solve stops wherever its mismatch estimate passes the tolerance — two neighbouring trial
+        # points may stop a sweep apart, a kink of ~1e-12 / h in one sensitivity that held one of 128 days at a control move
+        # of 4.8e-5 pu for four outer iterations (10 instead of 6: tools/opf_outer_probe.py, profiles/r05bm_opf_outer.txt).
+        # Newton's last step lands orders below the tolerance; the power flow is 5 % of a solve either way.
+        from . import _lib
+        out = pf_solve_batch(self.net, pnet.reshape(-1, self.n_bus), qnet.reshape(-1, self.n_bus), want_branch=True,
+                             solver=_lib.FLEX_SOLVER_TREE)
         if bool(out["failed"].any()):
             raise RuntimeError("power flow failed inside the OPF (voltage collapse at a trial point)")
         v2 = (out["v"] ** 2).reshape(*shape, self.n_bus)
