@@ -148,6 +148,8 @@ def test_pipelined_update_event_equals_one_at_a_time_sub_updates():
             assert torch.equal(va, vb), (ev, ka)
     # the double buffer really was used (of the plain value sub-update, or of its form on filed bootstrap values)
     assert (set(a._update_graphs_alt) == {"value"} or ("value_cached", 1) in a._cached_graphs) and not b._update_graphs_alt
+    # ... by the side-stream pipeline in `a` (no event graph there); `b` ran its events as one graph each (round 5)
+    assert a.event_graph_replays == 0 and b.event_graph_replays == 3
 
 
 @pytest.mark.parametrize("alg", ["matd3", "iddpg"])
