@@ -41,8 +41,9 @@ __device__ __forceinline__ int opt_find(const OptFlat& f, int n_tensors, int64_t
 // RIDER (flexnet_clip_rmsprop_refresh): inside an update event's graph the optimiser step that ends value sub-update j is
 // followed by the refresh of the static batch for sub-update j + 1 (csrc/window_refresh.h) — which depends on nothing the step
 // computes, and whose targets (the batch's small columns, the in-place windows' cells, the reward statistics) nobody reads
-// any more once sub-update j's weight gradient and finish are done.  Its statistics blocks ride behind pass 1's blocks, its
-// copy blocks behind pass 2's: no launch of its own (12 us of a 335-us sub-update).
+// any more once sub-update j's weight gradient and finish are done.  Its copy blocks ride behind pass 1's blocks, its
+// statistics blocks behind pass 2's (on the rewards pass 1's riders have just copied): no launch of its own (12 us of a
+// 335-us sub-update).
 static_assert(OPT_THREADS == WINDOW_THREADS, "the refresh blocks ride in the optimiser's launches");
 struct WindowRider {
     FlexWindowRefreshArgs a;
@@ -55,7 +56,7 @@ struct WindowRider {
 template <bool RIDER>
 __global__ __launch_bounds__(OPT_THREADS) void clip_norm_kernel(FlexClipRmspropArgs a, float* partial, WindowRider r) {
     if constexpr (RIDER) {
-        if (blockIdx.x >= OPT_BLOCKS) { window_refresh_td_block(r.a, r.td, blockIdx.x - OPT_BLOCKS); return; }
+        if (blockIdx.x >= OPT_BLOCKS) { window_refresh_copy_block(r.a, r.p, blockIdx.x - OPT_BLOCKS); return; }
     }
     __shared__ float part[OPT_THREADS / 64];
     __shared__ OptFlat f;
@@ -93,7 +94,13 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_norm_kernel(FlexClipRmspropA
 template <bool RIDER>
 __global__ __launch_bounds__(OPT_THREADS) void clip_rmsprop_kernel(FlexClipRmspropArgs a, const float* partial, WindowRider r) {
     if constexpr (RIDER) {
-        if (blockIdx.x >= OPT_BLOCKS) { window_refresh_copy_block(r.a, r.p, blockIdx.x - OPT_BLOCKS); return; }
+        if (blockIdx.x >= OPT_BLOCKS) {
+            // the statistics of the rewards the norm launch's copy blocks have just written: read from the contiguous copy
+            // (td.reward), not from the ring's 108-byte-apart rows — the same rows in the same partition, 3 us less of chain
+            const TdRewardRows rr = {r.td.reward, r.td.reward, (int64_t)r.td.rows, r.td.n_agents, r.td.n_agents};
+            td_stats_block(r.td, rr, blockIdx.x - OPT_BLOCKS);
+            return;
+        }
     }
     const int tid = threadIdx.x;
     __shared__ float tot_s;
@@ -152,8 +159,8 @@ static int clip_rmsprop_run(const FlexClipRmspropArgs* a, const WindowRider* r, 
     if (a->n_tensors == 0) return r ? FLEXNET_EINVAL : FLEXNET_OK;
     hipStream_t s = (hipStream_t)stream;
     if (r) {
-        hipLaunchKernelGGL(clip_norm_kernel<true>, dim3(OPT_BLOCKS + (r->has_td ? TD_BLOCKS : 0)), dim3(OPT_THREADS), 0, s, *a, a->workspace, *r);
-        hipLaunchKernelGGL(clip_rmsprop_kernel<true>, dim3(OPT_BLOCKS + r->copy_blocks), dim3(OPT_THREADS), 0, s, *a, a->workspace, *r);
+        hipLaunchKernelGGL(clip_norm_kernel<true>, dim3(OPT_BLOCKS + r->copy_blocks), dim3(OPT_THREADS), 0, s, *a, a->workspace, *r);
+        hipLaunchKernelGGL(clip_rmsprop_kernel<true>, dim3(OPT_BLOCKS + (r->has_td ? TD_BLOCKS : 0)), dim3(OPT_THREADS), 0, s, *a, a->workspace, *r);
     } else {
         WindowRider none;
         none.has_td = none.copy_blocks = 0;                       // (never read without RIDER)
@@ -170,6 +177,9 @@ extern "C" int flexnet_clip_rmsprop(const FlexClipRmspropArgs* a, void* stream) 
 extern "C" int flexnet_clip_rmsprop_refresh(const FlexClipRmspropArgs* a, const FlexWindowRefreshArgs* refresh, const FlexTdLossArgs* td,
                                             void* stream) {
     if (!a || !refresh) return FLEXNET_EINVAL;
+    // (the statistics blocks read the copy of the rewards the copy blocks make: td->reward must BE that copy)
+    if (td && (refresh->reward_job < 0 || refresh->reward_job >= refresh->n_jobs || td->reward != refresh->dst[refresh->reward_job]))
+        return FLEXNET_EINVAL;
     WindowRider r;
     const int rc = window_refresh_prepare(refresh, td, &r.p, &r.copy_blocks);
     if (rc != FLEXNET_OK) return rc;
