@@ -19,10 +19,10 @@ CSRC = os.path.join(HERE, "csrc")
 SRC = [os.path.join(CSRC, f) for f in ("flexenv.hip", "actor.hip", "critic.hip", "rollout.hip", "wgrad.hip", "lnrelu.hip",
                                        "optim.hip", "tdloss.hip", "gru.hip", "linear.hip", "opf.hip")]
 SRC = [f for f in SRC if os.path.exists(f)]
-HEADERS = [os.path.join(CSRC, "flex_device.h"), os.path.join(CSRC, "flex_reduce.h"), os.path.join(CSRC, "flex_launch.h"),
-           os.path.join(CSRC, "flex_td.h"), os.path.join(CSRC, "actor_r16.h"),
-           os.path.join(ROOT, "include", "flexenv.h"), os.path.join(ROOT, "include", "flexnet.h"),
-           os.path.join(ROOT, "include", "flexopf.h")]
+# every header under csrc/ and include/ (a list by name missed critic_finish.h and window_refresh.h when they were added:
+# an edit to either neither rebuilt the library nor changed the digest the profiles are stamped with)
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+          sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h"))
 DEPS = SRC + HEADERS
 OUT = os.path.join(HERE, "libflexenv_hip.so")
 STAMP = OUT + ".sha256"

@@ -48,6 +48,22 @@ __device__ __forceinline__ void window_refresh_copy_block(const FlexWindowRefres
 #pragma unroll
             for (int c = 0; c < 8; ++c) if (c < w) dp[c] = v[c];
         }
+    } else if (w <= 32) {
+        // up to 32 columns (the action block: 20): a thread per ROW as well, four columns per round with their loads issued
+        // together — no index division per element (one per element made this path a chain of sixteen dependent round trips
+        // at 32 768 rows); columns past the row's end re-read its last one and are not stored
+        for (int r = b * WINDOW_THREADS + threadIdx.x; r < rows; r += nb * WINDOW_THREADS) {
+            const int64_t pr = r < until_seam ? first + r : (int64_t)(r - until_seam);
+            const float* sp = src + pr * ss;
+            float* dp = dst + (int64_t)r * w;
+            for (int c0 = 0; c0 < w; c0 += 4) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = sp[c0 + u < w ? c0 + u : w - 1];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (c0 + u < w) dp[c0 + u] = v[u];
+            }
+        }
     } else {
         const int total = rows * w;
         for (int i = b * WINDOW_THREADS + threadIdx.x; i < total; i += nb * WINDOW_THREADS) {
