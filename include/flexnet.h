@@ -518,7 +518,8 @@ typedef struct {
 int flexnet_window_refresh(const FlexWindowRefreshArgs* args, const FlexTdLossArgs* td /* NULL: none */, void* stream);
 /* flexnet_clip_rmsprop(opt) followed by flexnet_window_refresh(refresh, td) without a launch for the refresh: inside an update
  * event's graph the optimiser step that ends one value sub-update is followed by the refresh for the next, which depends on
- * nothing the step computes — its statistics blocks ride in the norm launch, its copy blocks in the step launch.  The caller
+ * nothing the step computes — its copy blocks ride in the norm launch, its statistics blocks in the step launch, where they
+ * read the rewards from the copy just made: td->reward must be dst[reward_job] (FLEXNET_EINVAL otherwise).  The caller
  * guarantees that nothing still reads what the refresh writes (trainer.py:81-108 order: the loss's kernels are done). */
 int flexnet_clip_rmsprop_refresh(const FlexClipRmspropArgs* opt, const FlexWindowRefreshArgs* refresh, const FlexTdLossArgs* td, void* stream);
 

@@ -124,3 +124,16 @@ def test_the_next_windows_refresh_rides_in_the_step(supported):
         assert torch.equal(o["action"], small[idx, :act_w]) and torch.equal(o["reward"], small[idx, act_w:act_w + n])
     assert ca.item() == cb.item() == start % cap
     assert torch.equal(wa, wb) and bool(wa.abs().sum() > 0)
+    if supported:
+        # the riding statistics blocks read the copy the riding copy blocks make: statistics arguments that name another
+        # reward tensor are refused before any launch
+        a, _ = _nets()
+        opt = RMSprop(a, lr=1e-3, alpha=0.99, eps=1e-5, capturable=True)
+        for pa in a:
+            pa.grad = torch.ones_like(pa)
+        (ra, rt), out, cell = refresh_args(torch.zeros(_lib.FLEXNET_TD_WS_FLOATS // 2, dtype=torch.float64, device="cuda"))
+        other = torch.zeros(rows, n, device="cuda")
+        rt.reward = other.data_ptr()
+        with pytest.raises(RuntimeError):
+            clip_and_step(opt, a, 1.0, refresh=(ra, rt))
+        torch.cuda.synchronize()
