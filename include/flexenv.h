@@ -183,6 +183,21 @@ int flexenv_step(FlexEnv* env, const void* actions, int32_t act_dtype,
                  double* info /*dev [N, FLEX_INFO_W] or NULL*/, uint8_t* failed /*dev [N] or NULL*/,
                  void* obs /*dev [N, n_agents, 6*history] or NULL*/, int32_t obs_dtype, int32_t flags, void* stream);
 
+/* `steps` consecutive step()s on a GIVEN action sequence in ONE launch: the vectorised form of the reference's open-loop
+ * episode runner (run_env.py:78-92 — sampled actions, step(), per-step records of reward and info).  Step k reads action slab
+ * k mod act_period of `actions` ([act_period][N, n_agents, 4], dtype as in flexenv_step) and writes row k of `reward`, `done`,
+ * `info`, `failed` ([steps][...], per-row layout as in flexenv_step); state, history and every output are bit-identical to
+ * `steps` calls of flexenv_step with the same flags.  get_obs() is the row push: FLEX_STEP_OBS_ROWS is required
+ * (FLEX_STEP_AUTORESET optional), FLEX_EINVAL otherwise and while a row ring is registered (flexenv_set_obs_ring: the
+ * closed-loop forms own its cursor).  Environments are independent, so a wavefront walks its own environments through the
+ * whole sequence without a launch boundary per step.  FLEX_STEP_MANY_NO_CARRY (diagnostic): every step re-loads its integer
+ * record from memory instead of carrying it in registers. */
+#define FLEX_STEP_MANY_NO_CARRY 32
+int flexenv_step_many(FlexEnv* env, const void* actions, int32_t act_dtype, int32_t act_period, int32_t steps,
+                      double* reward /*dev [steps, N]*/, uint8_t* done /*dev [steps, N]*/,
+                      double* info /*dev [steps, N, FLEX_INFO_W] or NULL*/, uint8_t* failed /*dev [steps, N] or NULL*/,
+                      int32_t flags, void* stream);
+
 /* Replaces get_obs() (env:370-403): stateful, appends to the history on every call.  FLEX_EINVAL while a row ring is
  * registered (flexenv_set_obs_ring): a push outside flexenv_step would leave the replay's row records behind the history.
  * The same holds for a MASKED flexenv_reset; a full reset (mask NULL) restarts every history and is allowed. */

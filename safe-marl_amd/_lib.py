@@ -22,6 +22,7 @@ FLEX_STEP_AUTORESET = 1
 FLEX_STEP_OBS_RING = 16
 FLEX_STEP_REPLAY_SINK = 4
 FLEX_STEP_OBS_ROWS = 8
+FLEX_STEP_MANY_NO_CARRY = 32
 FLEX_ROW_FLOATS = 8
 FLEX_SOLVER_TREE, FLEX_SOLVER_DENSE, FLEX_SOLVER_SWEEP = 0, 1, 2
 
@@ -71,7 +72,7 @@ class ResetSpec(C.Structure):
 
 # every symbol include/flexenv.h declares
 SYMBOLS = (
-    "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_obs", "flexenv_obs_view", "flexenv_obs_source", "flexenv_state",
+    "flexenv_create", "flexenv_destroy", "flexenv_reset", "flexenv_step", "flexenv_step_many", "flexenv_obs", "flexenv_obs_view", "flexenv_obs_source", "flexenv_state",
     "flexenv_peek", "flexenv_poke", "flexenv_num_envs", "flexenv_set_step_counter", "flexenv_set_obs_ring", "flexenv_set_replay_sink", "flexenv_rollout_burst", "flexenv_obs_size", "flexenv_state_size",
     "pf_solve_batch", "flexenv_safety_project", "flexenv_safety_project_env", "flexenv_version", "flexenv_abi_version",
     "flexnet_actor_forward", "flexnet_critic_tail_forward", "flexnet_critic_tail_backward", "flexnet_rollout_pack", "flexnet_wgrad", "flexnet_lnrelu_forward", "flexnet_lnrelu_backward", "flexnet_clip_rmsprop", "flexnet_clip_rmsprop_refresh", "flexnet_td_loss", "flexnet_td_stats", "flexnet_critic_td_backward", "flexnet_critic_td_backward_phases", "flexnet_wgrad_critic_finish",
@@ -350,6 +351,8 @@ def load():
     lib.flexenv_reset.restype = C.c_int
     lib.flexenv_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.flexenv_step.restype = C.c_int
+    lib.flexenv_step_many.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp]
+    lib.flexenv_step_many.restype = C.c_int
     lib.flexenv_obs.argtypes = [vp, vp, i32, vp]
     lib.flexenv_obs.restype = C.c_int
     lib.flexenv_obs_view.argtypes = [vp, vp, i32, vp]

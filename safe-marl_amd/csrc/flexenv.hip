@@ -533,11 +533,23 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
 // 160-B record into the replay's slab — instead of a [n_agents, 6 * history] copy of the whole window per step (2 760 B
 // read + 2 880 B written per env-step: 0.65 x the kernel's algorithmic bytes, 15 of its 53 vector loads and 15 of its 58
 // stores).  `obs` is then the row ring's base (or NULL).  !ROWS: the stacked copy into `obs`.
-template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK, bool ROWS>
+// MANY (flex_step_many_kernel: consecutive steps of one launch): `mc` carries, in registers, what the step before has just
+// stored — the lane's network rows (loaded once per launch) and its environment's integer record, the head of the prologue's
+// only two-level load chain (ienv -> series row) — unless an environment of this wavefront restarted in that step.
+#ifndef FLEX_MANY_CARRY_NET
+#define FLEX_MANY_CARRY_NET 1
+#endif
+struct StepCarry {
+    flex_v4i iv;                 // steps, start, row, pushes: the 16 bytes the step wrote to ienv
+    bool have;                   // wavefront-uniform: iv is current
+    LaneNet ln;
+};
+template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK, bool ROWS, bool MANY = false>
 __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, const ActT* __restrict__ actions,
                                                double* __restrict__ reward, uint8_t* __restrict__ done, double* __restrict__ info,
                                                uint8_t* __restrict__ failed, ObsT* __restrict__ obs, int want_obs, int auto_reset,
-                                               const int64_t slab, const bool cells, const unsigned long long kbase) {
+                                               const int64_t slab, const bool cells, const unsigned long long kbase,
+                                               StepCarry* mc = nullptr) {
     constexpr int LW = FLEX_WAVE / EPW;
     const int lane = threadIdx.x & 63;
     const int env0 = wave * EPW;                               // first environment of this wavefront
@@ -563,9 +575,20 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     // the head of the only dependent chain (ienv -> series row) goes out before the 19 table loads
     int32_t* const b_ienv = a.st.ienv + (int64_t)env0 * IF_COUNT;
     const uint32_t o_ienv = g * (IF_COUNT * 4);
-    const int4 iv = ld_at<int4>(b_ienv, o_ienv);                  // steps, start, row, obs_cnt in one load
+    int4 iv;                                                      // steps, start, row, obs_cnt in one load
     LaneNet ln;
-    load_lane_net<EPW>(a.net, lane, ln);
+    if constexpr (MANY) {
+        if (mc->have) iv = int4{mc->iv.x, mc->iv.y, mc->iv.z, mc->iv.w};
+        else iv = ld_at<int4>(b_ienv, o_ienv);
+#if FLEX_MANY_CARRY_NET
+        ln = mc->ln;
+#else
+        load_lane_net<EPW>(a.net, lane, ln);
+#endif
+    } else {
+        iv = ld_at<int4>(b_ienv, o_ienv);
+        load_lane_net<EPW>(a.net, lane, ln);
+    }
     ln.pq = ln.pq && valid;
     const int nb = a.n_bus, na = c.n_agents;
     const bool is_bus = ln.bus >= 0, is_bld = ln.agent >= 0;
@@ -736,13 +759,18 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
         }
         st_at<double>(b_cum, g * 8, cum_before + rwd);                                 // env:343
     }
+    const int cnt_after = obs_cnt + ((want_obs && obs_fast && !restart) ? 1 : 0);
+    if constexpr (MANY) {
+        // (a restart rewrites ienv behind this: the next step of the launch then loads it)
+        mc->iv = flex_v4i{new_steps, start, new_row, cnt_after};
+        mc->have = !(auto_reset && __ballot(restart) != 0ull);
+    }
     if (ln.l == 0 && valid) {
         done[env] = term ? 1 : 0;
         if (failed) failed[env] = ok ? 0 : 1;
         // steps (env:342), start, row (env:340 reads row `steps`: A2) and the push count of the fast observation paths in ONE
         // 16-byte store, the solver statistics in one 8-byte store (five 4-byte stores until round 4); an environment that
         // restarts below overwrites them afterwards — same lane, program order
-        const int cnt_after = obs_cnt + ((want_obs && obs_fast && !restart) ? 1 : 0);
         st_at<flex_v4i>(e_ienv, o_ienv, flex_v4i{new_steps, start, new_row, cnt_after});
         st_at<flex_v2i>(e_ienv, o_ienv + IF_ITERS * 4, flex_v2i{iters, sweeps});
     }
@@ -794,7 +822,8 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     }
     if (auto_reset && __ballot(restart) != 0ull) {       // wavefront-uniform, taken once per episode
         LaneNet ln0;
-        load_lane_net<EPW>(a.net, lane, ln0);
+        if constexpr (MANY && FLEX_MANY_CARRY_NET) ln0 = mc->ln;      // (the carried rows: nothing second is live in the restart's solve)
+        else load_lane_net<EPW>(a.net, lane, ln0);
         const DevResetSpec none = {nullptr, nullptr, nullptr, nullptr, nullptr};
         // the restart reads its configuration through a freshly "discovered" kernarg pointer: otherwise the compiler
         // loads every field the (rare) restart needs at kernel entry and carries them — spilled — across the hot path
@@ -826,6 +855,66 @@ void flex_step_kernel(KArgs a, const ActT* __restrict__ actions, double* __restr
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
     flex_step_body<EPW, ObsT, ActT, NA_CAP, SINK, ROWS>(a, wave, actions, reward, done, info, failed, obs, want_obs, auto_reset, -1, true,
                                                   (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+}
+
+// -------------------------------------------------------------------------------------------------
+// flexenv_step_many: `n_steps` consecutive steps on a GIVEN action sequence in ONE launch — the vectorised form of the
+// reference's open-loop episode runner (run_env.py:78-92: sampled actions, step(), per-step records).  Environments do not
+// interact, so nothing orders one wavefront's steps against another's: each wavefront walks its own environments through the
+// whole sequence — no launch boundary per step (2.6 us of drain + dispatch, and a launch ends with its slowest wavefront:
+// a sequence of launches takes the SUM over steps of the per-step maximum, this kernel the maximum over wavefronts of their
+// own sums).  The body is flex_step_body's: same loads, same stores, same arithmetic per step, state through HBM between
+// steps (bit-identical to n_steps calls of flexenv_step: tests/test_step_many_gpu.py); what a wavefront carries in registers
+// is StepCarry.  Step k reads action slab k mod act_period and writes row k of reward / done / info / failed.
+// KArgs first: the step body re-reads it through relaunder_kernarg.
+// -------------------------------------------------------------------------------------------------
+struct ManyArgs {
+    KArgs k;
+    const void* actions;        // [act_period][N, n_agents, 4]
+    double* reward;             // [n_steps][N]
+    uint8_t* done;              // [n_steps][N]
+    double* info;               // [n_steps][N, FLEX_INFO_W] or NULL
+    uint8_t* failed;            // [n_steps][N] or NULL
+    int32_t n_steps, act_period, auto_reset, carry;
+};
+
+template <int EPW, typename ActT>
+__global__ __launch_bounds__(FLEX_WAVE * FLEX_WAVES_PER_BLOCK, 8 / FLEX_WAVES_PER_BLOCK)
+void flex_step_many_kernel(ManyArgs m) {
+    const unsigned long long kb = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * FLEX_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (wave * EPW >= m.k.n_envs) return;
+    StepCarry mc;
+    mc.have = false;
+    mc.iv = flex_v4i{0, 0, 0, 0};
+    load_lane_net<EPW>(m.k.net, threadIdx.x & 63, mc.ln);
+    const int n_steps = m.n_steps;
+    int slot = 0;
+    for (int k = 0; k < n_steps; ++k) {
+        // (every step reads its arguments through a freshly derived kernarg pointer, as the step body's epilogue does:
+        //  nothing of them is carried — spilled — across the solve)
+        const ManyArgs& b = *relaunder_kernarg<ManyArgs>(kb);
+        const int64_t ne = b.k.n_envs;
+        const ActT* act = reinterpret_cast<const ActT*>(b.actions) + (int64_t)slot * ne * (b.k.cfg.n_agents * 4);
+        if (!b.carry) mc.have = false;
+        flex_step_body<EPW, float, ActT, FLEX_OBS_AGENTS_SMALL, false, true, true>(
+            b.k, wave, act, b.reward + k * ne, b.done + k * ne, b.info ? b.info + k * ne * FLEX_INFO_W : nullptr,
+            b.failed ? b.failed + k * ne : nullptr, nullptr, 1, b.auto_reset, -1, false, kb, &mc);
+        slot = slot + 1 == b.act_period ? 0 : slot + 1;
+        // this wavefront's own stores (state, history; a restart's) are what its next step loads: complete and visible
+        // within the CU before those loads go out (work-group scope: one vector L1, write-through)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                 // the launch counter, as n_steps single launches leave it
+        const ManyArgs& b = *relaunder_kernarg<ManyArgs>(kb);
+        int64_t* const sc = b.k.step_counter;
+        if (sc) {
+            int64_t nx = *sc + n_steps;
+            if (b.k.step_modulo > 0) nx %= b.k.step_modulo;
+            *sc = nx;
+        }
+    }
 }
 
 
@@ -1567,6 +1656,31 @@ int flexenv_step(FlexEnv* e, const void* actions, int32_t act_dtype, double* rew
         default: FLEX_LAUNCH_STEP(2, double, double); break;
     }
 #undef FLEX_LAUNCH_STEP
+    HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+int flexenv_step_many(FlexEnv* e, const void* actions, int32_t act_dtype, int32_t act_period, int32_t steps,
+                      double* reward, uint8_t* done, double* info, uint8_t* failed, int32_t flags, void* stream) {
+    if (!e || !actions || !reward || !done || steps < 1 || act_period < 1) return FLEX_EINVAL;
+    if (act_dtype != FLEX_F32 && act_dtype != FLEX_F64) return FLEX_EINVAL;
+    // get_obs() is the row push (the environment's own history); a registered row ring / replay sink belongs to the
+    // closed-loop forms (flexenv_step, flexenv_rollout_burst), whose cursor cells a launch of many steps does not walk
+    if (flags & ~(FLEX_STEP_AUTORESET | FLEX_STEP_OBS_ROWS | FLEX_STEP_MANY_NO_CARRY)) return FLEX_EINVAL;
+    if (!(flags & FLEX_STEP_OBS_ROWS) || e->obs_slabs > 0) return FLEX_EINVAL;
+    ManyArgs m;
+    m.k = make_args(e);
+    m.k.step_counter = e->step_counter; m.k.step_modulo = e->step_modulo;
+    m.actions = actions; m.reward = reward; m.done = done; m.info = info; m.failed = failed;
+    m.n_steps = steps; m.act_period = act_period; m.auto_reset = (flags & FLEX_STEP_AUTORESET) ? 1 : 0;
+    m.carry = (flags & FLEX_STEP_MANY_NO_CARRY) ? 0 : 1;
+    hipStream_t s = (hipStream_t)stream;
+    const int epw = e->hnet.epw;
+    const dim3 grid = env_grid(e->n_envs, epw);
+    if (epw == 2 && act_dtype == FLEX_F32) hipLaunchKernelGGL((flex_step_many_kernel<2, float>), grid, env_block(), 0, s, m);
+    else if (epw == 2) hipLaunchKernelGGL((flex_step_many_kernel<2, double>), grid, env_block(), 0, s, m);
+    else if (act_dtype == FLEX_F32) hipLaunchKernelGGL((flex_step_many_kernel<1, float>), grid, env_block(), 0, s, m);
+    else hipLaunchKernelGGL((flex_step_many_kernel<1, double>), grid, env_block(), 0, s, m);
     HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }

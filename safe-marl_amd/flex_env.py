@@ -209,6 +209,41 @@ class VecFlexProvisionEnv:
                                          self._dtype_tag(out) if out is not None else 0, flags, _stream()), "flexenv_step")
         return self.reward, self.done, self.info
 
+    def step_many(self, actions, steps=None, auto_reset=False, want_info=True, out=None, carry=True):
+        """``steps`` consecutive vector steps on a GIVEN action sequence in ONE launch (include/flexenv.h:
+        flexenv_step_many) — the reference's open-loop episode runner, run_env.py:78-92 (sampled actions, step(), per-step
+        records), for every environment at once.  ``actions``: [P, N, n_agents, 4]; step k uses slab k mod P (``steps``
+        defaults to P).  get_obs() is the row push of ``step(..., obs_rows=True)``; state, history and outputs equal those of
+        ``steps`` such calls bit for bit.  Returns (reward [steps, N], done [steps, N], info [steps, N, 7] or None,
+        failed [steps, N]) — preallocated tensors may be handed in as ``out`` (same tuple; HIP-graph capture)."""
+        if actions.device != self.device:
+            actions = actions.to(self.device)
+        actions = actions.contiguous()
+        per = self.n_envs * self.n_agents * 4
+        if actions.numel() == 0 or actions.numel() % per:
+            raise ValueError(f"actions must be [P, {self.n_envs}, {self.n_agents}, 4], got {tuple(actions.shape)}")
+        period = actions.numel() // per
+        steps = period if steps is None else int(steps)
+        if steps < 1:
+            raise ValueError("steps must be >= 1")
+        if out is None:
+            reward = torch.empty(steps, self.n_envs, dtype=torch.float64, device=self.device)
+            done = torch.empty(steps, self.n_envs, dtype=torch.uint8, device=self.device)
+            info = torch.empty(steps, self.n_envs, _lib.FLEX_INFO_W, dtype=torch.float64, device=self.device) if want_info else None
+            failed = torch.empty(steps, self.n_envs, dtype=torch.uint8, device=self.device)
+        else:
+            reward, done, info, failed = out
+            for t, w, dt in ((reward, 1, torch.float64), (done, 1, torch.uint8), (info, _lib.FLEX_INFO_W, torch.float64),
+                             (failed, 1, torch.uint8)):
+                if t is not None and not (t.device == self.device and t.is_contiguous() and t.dtype == dt
+                                          and t.numel() == steps * self.n_envs * w):
+                    raise ValueError("step_many: `out` tensors must be contiguous device tensors of [steps, N(, 7)]")
+        self.calls += steps
+        flags = _lib.FLEX_STEP_OBS_ROWS | (_lib.FLEX_STEP_AUTORESET if auto_reset else 0) | (0 if carry else _lib.FLEX_STEP_MANY_NO_CARRY)
+        _lib.check(self.lib.flexenv_step_many(self.handle, _ptr(actions), self._dtype_tag(actions), period, steps, _ptr(reward),
+                                              _ptr(done), _ptr(info), _ptr(failed), flags, _stream()), "flexenv_step_many")
+        return reward, done, info, failed
+
     def rollout_burst(self, actor_args, steps, obs_ring, safety=None):
         """``steps`` vector steps of policy + environment in ONE launch (include/flexenv.h: flexenv_rollout_burst):
         ``actor_args`` is the FlexActorArgs of the ring-mode policy call the burst replaces (nets.fused_actor_forward builds

@@ -1,0 +1,166 @@
+"""GPU parity of flexenv_step_many (include/flexenv.h) — the reference's open-loop episode runner (run_env.py:78-92:
+sampled actions, step(), per-step records) for every environment at once, as ONE launch.
+
+Bar: bit-exact.  The launch runs the step kernel's body per step, so reward, done, info, failed of every step and the state
+and observation history it leaves must EQUAL those of the same number of ``step(obs_rows=True)`` launches on the same
+seeded inputs — which the tests of test_env_gpu.py hold against the CPU oracles; one case here goes to the C oracle
+directly, across episode boundaries, at the bench's batch size."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PEEKS = ("V", "E", "E_INIT", "PRED", "CH", "DIS", "QPV", "PCT", "CUMREW", "STEPS", "ROW", "START", "EPISODE")
+
+
+def _pair(net, series, n, cfg=None, seed=7, **kw):
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    a = VecFlexProvisionEnv(cfg or {}, n, series=series, net=net, seed=seed, **kw)
+    b = VecFlexProvisionEnv(cfg or {}, n, series=series, net=net, seed=seed, **kw)
+    a.reset()
+    b.reset()
+    return a, b
+
+
+def _same_state(a, b, tag):
+    import torch
+    for k in PEEKS:
+        assert torch.equal(a.peek(k), b.peek(k)), (tag, k)
+    assert torch.equal(a.obs_view(), b.obs_view()), (tag, "obs")
+    assert torch.equal(a.get_state(), b.get_state()), (tag, "state")
+
+
+@pytest.mark.parametrize("n,cfg,steps,period,auto,dtype,carry", [
+    (64, {}, 200, 200, True, "f32", True),                       # two episode boundaries inside the launch
+    (33, {}, 120, 16, True, "f32", True),                        # odd batch (spare lane group), actions cycling
+    (47, {"episode_limit": 7}, 40, 40, True, "f64", True),      # a restart every seventh step, fp64 actions
+    (16, {}, 12, 12, False, "f32", True),                        # no restarts
+    (16, {"episode_limit": 5}, 12, 12, False, "f32", True),     # stepping on past the episode's end (done stays 1)
+    (64, {}, 100, 100, True, "f32", False),                      # the diagnostic form: nothing carried in registers
+])
+def test_one_launch_of_many_steps_equals_as_many_launches(net, series_small, n, cfg, steps, period, auto, dtype, carry):
+    import torch
+    a, b = _pair(net, series_small, n, cfg)
+    rng = np.random.default_rng(11)
+    lo = 0.0 if cfg else 0.5                                   # (0, 1) exercises the ESS clipping branches
+    acts = torch.from_numpy(rng.uniform(lo, 1.0, (period, n, 5, 4))).cuda()
+    acts = acts.float() if dtype == "f32" else acts.double()
+    rew, don, inf, fail = [], [], [], []
+    for k in range(steps):
+        r, d, i = a.step(acts[k % period], obs_rows=True, auto_reset=auto)
+        rew.append(r.clone()); don.append(d.clone()); inf.append(i.clone()); fail.append(a.failed.clone())
+    r2, d2, i2, f2 = b.step_many(acts, steps=steps, auto_reset=auto, carry=carry)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.stack(rew), r2)
+    assert torch.equal(torch.stack(don), d2)
+    assert torch.equal(torch.stack(inf), i2)
+    assert torch.equal(torch.stack(fail), f2)
+    if auto and steps >= 95:
+        assert int(d2.sum().item()) >= n                       # (every environment ended an episode inside the launch)
+    _same_state(a, b, "after the launch")
+    # and the two environments go on identically, whichever form stepped them before
+    r, d, i = a.step(acts[0], obs_rows=True, auto_reset=auto)
+    r3, d3, i3, _ = b.step_many(acts[:1], auto_reset=auto, carry=carry)
+    assert torch.equal(r, r3[0]) and torch.equal(d, d3[0]) and torch.equal(i, i3[0])
+    _same_state(a, b, "one step later")
+
+
+def test_without_info_and_into_preallocated_rows(net, series_small):
+    import torch
+    n, steps = 32, 20
+    a, b = _pair(net, series_small, n)
+    acts = (0.5 + 0.5 * torch.rand(steps, n, 5, 4, device="cuda", generator=torch.Generator("cuda").manual_seed(3)))
+    r1, d1, i1, f1 = a.step_many(acts, auto_reset=True)
+    out = (torch.empty(steps, n, dtype=torch.float64, device="cuda"), torch.empty(steps, n, dtype=torch.uint8, device="cuda"),
+           None, torch.empty(steps, n, dtype=torch.uint8, device="cuda"))
+    r2, d2, i2, f2 = b.step_many(acts, auto_reset=True, out=out)
+    assert i2 is None and r2 is out[0]
+    assert torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(f1, f2)
+    _same_state(a, b, "info or not")
+    # cumulative reward before the step (info[6]) is the running sum of the rewards of the launch's own steps
+    assert torch.allclose(i1[1:, :, 6], torch.cumsum(r1, 0)[:-1], rtol=0, atol=1e-12)
+
+
+def test_step_counter_advances_as_single_launches_would(net, series_small):
+    import torch
+    n = 8
+    a, b = _pair(net, series_small, n)
+    ca = torch.zeros(1, dtype=torch.int64, device="cuda")
+    cb = torch.zeros(1, dtype=torch.int64, device="cuda")
+    a.set_step_counter(ca, modulo=7)
+    b.set_step_counter(cb, modulo=7)
+    acts = torch.full((10, n, 5, 4), 0.75, device="cuda")
+    for k in range(10):
+        a.step(acts[k], obs_rows=True)
+    b.step_many(acts)
+    assert ca.item() == cb.item() == 10 % 7
+
+
+def test_arguments_the_launch_cannot_honour_are_refused(net, series_small):
+    import torch
+    from safe_marl_amd import _lib
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv, _ptr, _stream
+    n = 8
+    vec = VecFlexProvisionEnv({}, n, series=series_small, net=net, seed=1)
+    vec.reset()
+    acts = torch.full((4, n, 5, 4), 0.75, device="cuda")
+    rew = torch.empty(4, n, dtype=torch.float64, device="cuda")
+    don = torch.empty(4, n, dtype=torch.uint8, device="cuda")
+
+    def call(flags, steps=4, period=4, actions=acts):
+        return vec.lib.flexenv_step_many(vec.handle, _ptr(actions), _lib.FLEX_F32, period, steps, _ptr(rew), _ptr(don), None, None,
+                                         flags, _stream())
+    assert call(_lib.FLEX_STEP_OBS_ROWS) == _lib.FLEX_OK
+    assert call(0) == _lib.FLEX_EINVAL                                      # a stacked copy per step: flexenv_step's business
+    assert call(_lib.FLEX_STEP_OBS_ROWS | _lib.FLEX_STEP_OBS_RING) == _lib.FLEX_EINVAL
+    assert call(_lib.FLEX_STEP_OBS_ROWS | _lib.FLEX_STEP_REPLAY_SINK) == _lib.FLEX_EINVAL
+    assert call(_lib.FLEX_STEP_OBS_ROWS, steps=0) == _lib.FLEX_EINVAL
+    assert call(_lib.FLEX_STEP_OBS_ROWS, period=0) == _lib.FLEX_EINVAL
+    assert call(_lib.FLEX_STEP_OBS_ROWS, actions=None) == _lib.FLEX_EINVAL
+    cursor = torch.zeros(2, dtype=torch.int64, device="cuda")
+    vec.set_obs_ring(cursor, n * 5 * 8, 4)                                 # the closed-loop forms own the row ring's cursor
+    assert call(_lib.FLEX_STEP_OBS_ROWS) == _lib.FLEX_EINVAL
+    vec.set_obs_ring(None, 0, 0)
+    assert call(_lib.FLEX_STEP_OBS_ROWS) == _lib.FLEX_OK
+    with pytest.raises(ValueError):
+        vec.step_many(torch.zeros(3, n, 5, 3, device="cuda"))
+    torch.cuda.synchronize()
+
+
+def test_bench_batch_against_the_c_oracle_across_two_episode_boundaries(net):
+    """4096 environments x 205 steps in ONE launch (restarts inside it at steps 95 and 190 from the device's Philox stream)
+    against oracle/flexenv_oracle.c stepped 205 times and restarted from the restated stream: reward, info <= 1e-10 at every
+    step, done exact, V, E <= 1e-10 and the observation equal after the fp32 cast at the end."""
+    import torch
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    from oracle import c_oracle
+    from tests.test_env_gpu import _philox_specs
+    s = make_synthetic_series(net, n_days=40)
+    n, seed, steps = 4096, 1234, 205
+    rng = np.random.default_rng(202)
+    vec = VecFlexProvisionEnv({}, n, series=s, net=net, warm_start=True, seed=seed)
+    vec.reset()
+    cenv = c_oracle.COracleEnv(net, s.table, n)
+    spec = _philox_specs(n, 0, seed, s)
+    cenv.reset(spec["interval"] + spec["hour"] * 4 + spec["day"] * 96, spec["e0"], spec["a0"])
+    acts = rng.uniform(0.5, 1.0, (steps, n, 5, 4)).astype(np.float32)
+    reward, done, info, failed = vec.step_many(torch.from_numpy(acts).cuda(), auto_reset=True)
+    reward, done, info = reward.cpu().numpy(), done.cpu().numpy(), info.cpu().numpy()
+    assert failed.sum().item() == 0
+    boundaries = 0
+    worst_r = worst_i = 0.0
+    for t in range(steps):
+        r2, d2, i2 = cenv.step(acts[t].astype(np.float64))
+        worst_r = max(worst_r, np.abs(reward[t] - r2).max())
+        worst_i = max(worst_i, np.abs(info[t] - i2).max())
+        assert np.array_equal(done[t], d2), t
+        if d2.all():
+            boundaries += 1
+            spec = _philox_specs(n, boundaries, seed, s)
+            cenv.reset(spec["interval"] + spec["hour"] * 4 + spec["day"] * 96, spec["e0"], spec["a0"])
+    assert boundaries == 2
+    assert worst_r < 1e-10 and worst_i < 1e-9, (worst_r, worst_i)
+    assert np.abs(vec.peek("V").cpu().numpy() - cenv.V).max() < 1e-10
+    assert np.abs(vec.peek("E").cpu().numpy() - cenv.E).max() < 1e-10
+    assert np.allclose(vec.obs_view().cpu().numpy(), cenv.obs, rtol=2e-7, atol=0)
