@@ -53,8 +53,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--envs", type=int, default=N_ENVS, help="envs per GPU (the metric is quoted at 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training legs (`train`)")
@@ -76,6 +76,11 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--stacked-obs", action="store_true",
                     help="get_obs() as a stacked [n_agents, 6 * history] copy per step (the round-3 kernel) instead of the row push")
+    ap.add_argument("--launch-form", choices=["many", "single"], default="many",
+                    help="many: the K steps as launches of --steps-per-launch steps each (flexenv_step_many: every wavefront walks "
+                         "its own environments through the sequence, run_env.py:78-92 vectorised); single: one flexenv_step launch "
+                         "per step, replayed as HIP graphs (the headline form of rounds 1-4; `single_launch_sibling` either way)")
+    ap.add_argument("--steps-per-launch", type=int, default=256, help="launch length of --launch-form many (a shorter region is ONE launch)")
     ap.add_argument("--solver", choices=["sweep", "newton"], default="sweep",
                     help="sweep: backward/forward sweeps + Newton verification; newton: NR with tree elimination")
     return ap.parse_args()
@@ -552,9 +557,11 @@ def roofline_details(a, env, kern_ms):
     epw = 2 if env.n_bus - 1 <= 32 else 1
     lw = 64 // epw
     small = env.n_agents == 5 and 3 * env.history <= (3 if epw == 2 else 2) * lw
-    want = (f"flex_step_kernel<{epw}, float, float, {5 if small else 8}, false, false>" if a.stacked_obs else
+    many = a.launch_form == "many" and not a.stacked_obs
+    want = (f"flex_step_many_kernel<{epw}, float>" if many else
+            f"flex_step_kernel<{epw}, float, float, {5 if small else 8}, false, false>" if a.stacked_obs else
             f"flex_step_kernel<{epw}, float, float, 5, false, true>")
-    res = [v for v in build.kernel_resources("flex_step_kernel<").values() if v.get("name") == want]
+    res = [v for v in build.kernel_resources("flex_step_many_kernel<" if many else "flex_step_kernel<").values() if v.get("name") == want]
     out["kernel"] = want
     waves = (a.envs + epw - 1) // epw
     out["waves_launched"] = waves
@@ -580,7 +587,13 @@ def roofline_details(a, env, kern_ms):
     if int(t.get("envs_per_launch", -1)) != a.envs or a.solver != "sweep" or want not in (t.get("kernel") or []):
         out["counters_stale"] = "counter passes were taken at another batch size / solver"
         return out
-    out["traffic"] = t.get("flex_step_kernel_bytes_per_launch")
+    # counters are per LAUNCH of the counter passes (`steps_per_launch` steps each); the line quotes them per launch of THIS run
+    spl_t = int(t.get("steps_per_launch", 1))
+    spl = a.steps_per_launch_used if many else 1
+    out["counter_steps_per_launch"] = spl_t
+    scale = spl / float(spl_t)
+    out["traffic"] = int(t.get("flex_step_kernel_bytes_per_launch") * scale) if t.get("flex_step_kernel_bytes_per_launch") else None
+    out["traffic_per_env_step"] = (t.get("flex_step_kernel_bytes_per_launch") / spl_t / a.envs) if t.get("flex_step_kernel_bytes_per_launch") else None
     c = t.get("counters_per_launch", {})
     wave_q, valu_q = c.get("SQ_WAVE_CYCLES"), c.get("SQ_ACTIVE_INST_VALU")
     if wave_q and valu_q:
@@ -677,6 +690,30 @@ def main():
         else:
             env.step(pool[k % ACTION_POOL], obs_rows=True, auto_reset=True)
 
+    # --launch-form many (round 5, the default): the K steps as launches of L = --steps-per-launch steps (flexenv_step_many —
+    # the vectorised form of the reference's open-loop runner, run_env.py:78-92: a given action sequence, step(), per-step
+    # records), a region shorter than L as ONE launch, a remainder as one more.  Every step does what one_step's launch does —
+    # same loads, stores and arithmetic, bit-identical results (tests/test_step_many_gpu.py) — and writes its own row of
+    # reward / done / info / failed; what is gone is the launch boundary per step.  Step k of a launch reads pool[k mod 16].
+    many = a.launch_form == "many" and not a.stacked_obs
+    a.steps_per_launch_used = 1
+    many_out = {}
+
+    def many_launch(n_steps):
+        if n_steps not in many_out:
+            many_out[n_steps] = (torch.empty(n_steps, a.envs, dtype=torch.float64, device=dev),
+                                 torch.empty(n_steps, a.envs, dtype=torch.uint8, device=dev),
+                                 torch.empty(n_steps, a.envs, 7, dtype=torch.float64, device=dev),
+                                 torch.empty(n_steps, a.envs, dtype=torch.uint8, device=dev))
+        env.step_many(pool, steps=n_steps, auto_reset=True, out=many_out[n_steps])
+
+    if many:
+        L_ = max(1, a.steps_per_launch)
+        a.steps_per_launch_used = min(L_, a.steps)
+        for n_ in {L_, a.steps % L_, a.warmup % L_, min(L_, a.steps)} - {0}:     # buffers allocated and every form launched once, untimed
+            many_launch(n_)
+        torch.cuda.synchronize()
+
     # The loop is launch-issue sensitive (9 us of Python + ctypes per launch against a 14 us kernel), so consecutive steps
     # are captured as HIP graphs and replayed: blocks of ACTION_POOL steps plus ONE graph for the remainder (K mod 16); a
     # short run (the driver's --steps 20) is one graph of exactly K step launches.  Work per step is identical either way (one flexenv_step
@@ -692,7 +729,7 @@ def main():
                 one_step(j)
         return g
 
-    if not a.no_graph:
+    if not a.no_graph and not many:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -717,6 +754,13 @@ def main():
 
     def run_steps(count):
         done_steps = 0
+        if many:
+            L = max(1, a.steps_per_launch)
+            for _ in range(count // L):
+                many_launch(L)
+            if count % L:
+                many_launch(count % L)
+            return
         if count in graphs and count != ACTION_POOL:
             graphs[count].replay()
             return
@@ -779,18 +823,24 @@ def main():
     # (rocprofv3 --kernel-trace --stats of the same command agrees: profiles/).  A second pass brackets every
     # launch with its own event pair; that figure carries ~2 us of event overhead per launch and is reported
     # as `bracketed_launch_ms` only.
-    n_ev = min(max(a.steps, 64), 400)
+    n_ev = 12 if many else min(max(a.steps, 64), 400)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     torch.cuda.synchronize()
     for k, (s, e) in enumerate(evs):
         s.record()
-        one_step(k)
+        if many:
+            many_launch(a.steps_per_launch_used)          # (a launch of the timed region's length)
+        else:
+            one_step(k)
         e.record()
     torch.cuda.synchronize()
     durs = sorted(s.elapsed_time(e) for s, e in evs)
     # the kernel's average launch duration: from the longer of the two event-bracketed regions (a 20-step region is
     # 0.3 ms, where the event pair's own ~5 us shows)
     kern_ms = sustained["device_ms_per_step"] if sustained is not None and a.steps < 256 else dev_ms / a.steps
+    if many and a.steps < 256:
+        # (per vector step, from launches of the timed region's own length: the median of the event-bracketed ones above)
+        kern_ms = durs[len(durs) // 2] / a.steps_per_launch_used
     failed_frac = float(env.failed.float().mean().item())
     iters_mean = float(env.peek("PF_ITERS").float().mean().item())
     sweeps_mean = float(env.peek("PF_SWEEPS").float().mean().item())
@@ -839,6 +889,59 @@ def main():
             del env2, g2
         except Exception as exc:
             print(f"[bench] rank {rank}: solver sibling leg failed: {exc!r}", file=sys.stderr)
+
+    # sibling figure with the OTHER launch form (one flexenv_step launch per step, HIP graphs of 16 <-> flexenv_step_many): same
+    # steps, same inputs, same results; 1024 steps, HIP events on the launch stream
+    form_sibling = None
+    if not a.no_sustained and not a.stacked_obs:
+        try:
+            env6 = VecFlexProvisionEnv({}, a.envs, device=f"cuda:{local_rank}", net=net, series=series,
+                                       seed=1234 + 1000 * rank, warm_start=bool(a.warm_start), pf_tol=a.pf_tol,
+                                       solver={"sweep": 2, "newton": 0}[a.solver], sweep_accel=not a.no_sweep_accel)
+            env6.reset()
+            n6 = 1024
+            if many:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    env6.step(pool[0], obs_rows=True, auto_reset=True)
+                torch.cuda.current_stream().wait_stream(side)
+                g6 = torch.cuda.CUDAGraph()
+                with graph_capture(g6):
+                    for j in range(ACTION_POOL):
+                        env6.step(pool[j], obs_rows=True, auto_reset=True)
+
+                def run6():
+                    for _ in range(n6 // ACTION_POOL):
+                        g6.replay()
+                form6, spl6 = "one flexenv_step launch per step (HIP graphs of 16 launches): the headline form of rounds 1-4", 1
+            else:
+                spl6 = max(1, a.steps_per_launch)
+                out6 = (torch.empty(spl6, a.envs, dtype=torch.float64, device=dev), torch.empty(spl6, a.envs, dtype=torch.uint8, device=dev),
+                        torch.empty(spl6, a.envs, 7, dtype=torch.float64, device=dev), torch.empty(spl6, a.envs, dtype=torch.uint8, device=dev))
+                n6 = max(1, n6 // spl6) * spl6
+
+                def run6():
+                    for _ in range(n6 // spl6):
+                        env6.step_many(pool, steps=spl6, auto_reset=True, out=out6)
+                form6 = "flexenv_step_many, %d steps per launch" % spl6
+            run6()
+            barrier()
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t6 = time.perf_counter()
+            q0.record()
+            run6()
+            q1.record()
+            barrier()
+            el6 = max_over_ranks(time.perf_counter() - t6)
+            ms6 = q0.elapsed_time(q1) / n6
+            form_sibling = {"launch_form": form6, "steps_per_launch": spl6, "steps": n6, "value": a.envs * world * n6 / el6,
+                            "unit": "env-steps/s", "device_ms_per_step": ms6, "avg_launch_ms": ms6 * spl6,
+                            "algorithmic_bytes_per_env_step": B_ALG_CORE,
+                            "frac": B_ALG_CORE * a.envs / (ms6 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del env6
+        except Exception as exc:
+            print(f"[bench] rank {rank}: launch-form sibling leg failed: {exc!r}", file=sys.stderr)
 
     # sibling figure with the OTHER observation form (stacked copy per step <-> row push): same step, same inputs
     obs_sibling = None
@@ -988,9 +1091,10 @@ def main():
             "data": "synthetic (stand-in IEEE-33 Baran-Wu network, SURVEY.md App. C; generated series, SURVEY.md §8d)",
             "config": {
                 # (the driver keeps the first 120 characters of this string: envs, solver, tolerance and observation form first)
-                "workload": ("step()+get_obs() %d envs/GPU, 33-bus AC PF, %d agents; %s, pf_tol %g; %s obs; auto-reset" % (
-                    a.envs, n_agents_env, "sweeps+fp64 Newton check" if a.solver == "sweep" else "fp64 Newton (tree)", a.pf_tol,
-                    "stacked-copy" if a.stacked_obs else "row-push")),
+                "workload": ("step()+get_obs() %d envs/GPU, 33-bus PF, %d agents; %s; %s, tol %g; %s obs" % (
+                    a.envs, n_agents_env, ("%d steps/launch" % a.steps_per_launch_used) if many else "1 step/launch",
+                    "sweeps+fp64 Newton check" if a.solver == "sweep" else "fp64 Newton (tree)", a.pf_tol,
+                    "stacked" if a.stacked_obs else "row-push")),
                 "workload_detail": ("flex_provision.step()+get_obs() batched, in-launch auto-reset; get_obs(): %s; solver: %s, "
                                     "inf-norm power mismatch < %g pu") % (
                                  "stacked [5, 144] fp32 copy per step" if a.stacked_obs else
@@ -1007,7 +1111,16 @@ def main():
                 "obs_form": "stacked" if a.stacked_obs else "row_push",
                 "sweep_accel": bool(a.solver == "sweep" and not a.no_sweep_accel),
                 "envs_per_gpu": a.envs, "n_agents": n_agents_env, "n_bus": n_bus_env,
-                "warm_start": bool(a.warm_start), "launches_per_step": 1, "hip_graph": used_graph, "hip_graph_uploaded": used_graph,
+                "launch_form": ("many: flexenv_step_many — the K steps as launches of up to %d steps (the timed region: %s), every wavefront "
+                                "walking its own environments through the sequence (run_env.py:78-92 vectorised); per step the same loads, "
+                                "stores and arithmetic as one flexenv_step launch, results bit-identical (tests/test_step_many_gpu.py); "
+                                "`single_launch_sibling` is the one-launch-per-step form timed in this run" % (
+                                    max(1, a.steps_per_launch),
+                                    " + ".join(["%d x %d" % (a.steps // max(1, a.steps_per_launch), max(1, a.steps_per_launch))] * (a.steps >= max(1, a.steps_per_launch))
+                                               + ["1 x %d" % (a.steps % max(1, a.steps_per_launch))] * (a.steps % max(1, a.steps_per_launch) > 0))))
+                               if many else "single: one flexenv_step launch per step",
+                "steps_per_launch": a.steps_per_launch_used,
+                "warm_start": bool(a.warm_start), "launches_per_step": (1.0 / a.steps_per_launch_used), "hip_graph": used_graph, "hip_graph_uploaded": used_graph,
                 "timed_after": ("the `sustained` leg (%d steps), then W warm-up steps" % sustained["steps"]) if sustained else "W warm-up steps",
                 "device_ms_per_step": dev_ms / a.steps, "solver": ("sweep (mixed fp64/fp32 increments) + fp64 Newton verification" if a.solver == "sweep" else "newton (fp64, tree elimination)"),
                 "pf_newton_iters_mean": iters_mean, "pf_sweeps_mean": sweeps_mean,
@@ -1023,8 +1136,12 @@ def main():
                 # 0.164); `stacked_sibling` below is the kernel that really moves those bytes, timed in this run
                 "frac_at_4220_bytes": B_ALG_WITH_OBS * a.envs / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "frac_at_1340_bytes": B_ALG_CORE * a.envs / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "avg_launch_ms": kern_ms, "bracketed_launch_ms": durs[len(durs) // 2],
+                # one launch = `steps_per_launch` vector steps of `envs_per_gpu` environments: algorithmic bytes per launch =
+                # algorithmic_bytes_per_env_step x envs x steps_per_launch, over avg_launch_ms
+                "steps_per_launch": a.steps_per_launch_used, "device_ms_per_vector_step": kern_ms,
+                "avg_launch_ms": kern_ms * a.steps_per_launch_used, "bracketed_launch_ms": durs[len(durs) // 2],
             }, **roof_extra),
+            "single_launch_sibling" if many else "many_steps_sibling": form_sibling,
             "stacked_sibling" if not a.stacked_obs else "rows_sibling": obs_sibling,
             "sustained": sustained,
             "solver_sibling": sibling,

@@ -541,8 +541,12 @@ void flex_reset_kernel(KArgs a, const uint8_t* __restrict__ mask, DevResetSpec i
 #endif
 struct StepCarry {
     flex_v4i iv;                 // steps, start, row, pushes: the 16 bytes the step wrote to ienv
-    bool have;                   // wavefront-uniform: iv is current
+    bool have;                   // wavefront-uniform: everything below is current
     LaneNet ln;
+    // the lane's inputs of the NEXT step, as that step would load them: its bus's cells of the series row the step advanced to
+    // (read by every lane for get_obs() anyway: env:340 / env:377-382), the ESS state, the warm-start word, the running return
+    double pd, qd, ppv, price, e_cur, e_init, cum;
+    uint32_t vw;
 };
 template <int EPW, typename ObsT, typename ActT, int NA_CAP, bool SINK, bool ROWS, bool MANY = false>
 __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, const ActT* __restrict__ actions,
@@ -612,10 +616,8 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     // issued unconditionally: a conditional load compiles to a branch with a full s_waitcnt behind it, and a
     // handful of those in a row serialise the prologue into as many memory round trips.
     // 1) what the solve needs: current data row (env:340, A2), ESS state, actions, previous voltages
-    const double pd_r = ld_at<double>(a.series, row_off + o_bus), qd_r = ld_at<double>(a.series, row_off + o_qbus);
-    const double ppv_r = ld_at<double>(a.series, row_off + o_pv), price = ld_at<double>(a.series, row_off + o_price);
-    const double e_cur_r = ld_at<double>(b_agent, o_agent + AF_E * AFB);
-    const double e_init_r = ld_at<double>(b_agent, o_agent + AF_EINIT * AFB);
+    // (MANY, wavefront-uniform: the step before left all of the state below in registers — only the actions are loaded)
+    const bool from_regs = MANY && mc->have;
     const uint32_t o_act = (g * na + ag) * (4 * (uint32_t)sizeof(ActT));
     ActT av[4];
     if constexpr (sizeof(ActT) == 4) {
@@ -625,10 +627,22 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
         const double2 t0 = ld_at<double2>(b_act, o_act), t1 = ld_at<double2>(b_act, o_act + 16);
         av[0] = t0.x; av[1] = t0.y; av[2] = t1.x; av[3] = t1.y;
     }
+    double pd_r, qd_r, ppv_r, price, e_cur_r, e_init_r, cum_before;
+    uint32_t vw_word;
+    if (from_regs) {
+        pd_r = mc->pd; qd_r = mc->qd; ppv_r = mc->ppv; price = mc->price;
+        e_cur_r = mc->e_cur; e_init_r = mc->e_init; cum_before = mc->cum; vw_word = mc->vw;
+    } else {
+        pd_r = ld_at<double>(a.series, row_off + o_bus); qd_r = ld_at<double>(a.series, row_off + o_qbus);
+        ppv_r = ld_at<double>(a.series, row_off + o_pv); price = ld_at<double>(a.series, row_off + o_price);
+        e_cur_r = ld_at<double>(b_agent, o_agent + AF_E * AFB);
+        e_init_r = ld_at<double>(b_agent, o_agent + AF_EINIT * AFB);
+        vw_word = ld_at<uint32_t>(b_vw, o_volt);
+        // (the epilogue's only read-modify-write: requested here, not behind the solve — a memory round trip per launch)
+        cum_before = ld_at<double>(a.st.cumrew + env0, g * 8);
+    }
     double we, wf;
-    unpack_warm(ld_at<uint32_t>(b_vw, o_volt), we, wf);
-    // (the epilogue's only read-modify-write: requested here, not behind the solve — a memory round trip per launch)
-    const double cum_before = ld_at<double>(a.st.cumrew + env0, g * 8);
+    unpack_warm(vw_word, we, wf);
     // 2) what only get_obs() needs: the row env:340 will load (start + steps, A2) and the history part of the
     //    stacked observation, which is copied right away and drains underneath the solve; an environment that
     //    turns out to restart below rewrites its whole observation afterwards (same wavefront, program order)
@@ -636,9 +650,10 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     const uint32_t nrow_off = (uint32_t)new_row * (uint32_t)a.row_bytes;
     // (only building lanes use the next row's Pd / Qd / Ppv: every other lane reads the price cell instead — an address this
     //  wavefront fetches anyway — so the observation touches 5 + 5 + 2 sectors of the next row, not all 18)
-    double n_pd = ld_at<double>(a.series, nrow_off + (is_bld ? o_bus : o_price));
-    double n_qd = ld_at<double>(a.series, nrow_off + (is_bld ? o_qbus : o_price));
-    double n_ppv = ld_at<double>(a.series, nrow_off + (is_bld ? o_pv : o_price));
+    // (MANY: every lane reads its OWN bus's cells — they are its inputs of the launch's next step, StepCarry)
+    double n_pd = ld_at<double>(a.series, nrow_off + (is_bld || MANY ? o_bus : o_price));
+    double n_qd = ld_at<double>(a.series, nrow_off + (is_bld || MANY ? o_qbus : o_price));
+    double n_ppv = ld_at<double>(a.series, nrow_off + (is_bld || MANY ? o_pv : o_price));
     const double n_price = ld_at<double>(a.series, nrow_off + o_price);
     const bool obs_fast = want_obs && (ROWS || (na <= NA_CAP && 3 * c.history <= FLEX_OBS_CLASSES(EPW) * LW));
     ObsHist<EPW, ROWS ? 1 : NA_CAP, ObsT> hist;
@@ -761,9 +776,12 @@ __device__ __forceinline__ void flex_step_body(const KArgs& a, const int wave, c
     }
     const int cnt_after = obs_cnt + ((want_obs && obs_fast && !restart) ? 1 : 0);
     if constexpr (MANY) {
-        // (a restart rewrites ienv behind this: the next step of the launch then loads it)
+        // (a restart rewrites all of this in memory behind here: the next step of the launch then loads it)
         mc->iv = flex_v4i{new_steps, start, new_row, cnt_after};
         mc->have = !(auto_reset && __ballot(restart) != 0ull);
+        mc->pd = n_pd; mc->qd = n_qd; mc->ppv = n_ppv; mc->price = n_price;
+        mc->e_cur = e_new; mc->e_init = e_init_r; mc->cum = cum_before + rwd;
+        mc->vw = (ok && ln.bus >= 0) ? pack_warm(e, f) : vw_word;        // (the spare group of an odd batch mirrors environment 0)
     }
     if (ln.l == 0 && valid) {
         done[env] = term ? 1 : 0;

@@ -15,8 +15,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   cd /tmp
-  rocprofv3 --pmc $set --output-format csv -d $O/ctr_${tag}_$i -- python3 $R/bench.py --steps 60 --warmup 20 --envs $envs \
-      --no-cpu-baseline --no-train --no-sustained --no-kernel-shares --no-graph > $O/ctr_${tag}_$i.log 2>&1 || { tail -5 $O/ctr_${tag}_$i.log; exit 1; }
+  # (headline form: flexenv_step_many — every launch of these passes is 20 steps long: 1 set-up + 1 warm-up + 3 timed + 12 bracketed)
+  rocprofv3 --pmc $set --output-format csv -d $O/ctr_${tag}_$i -- python3 $R/bench.py --steps 60 --warmup 20 --steps-per-launch ${SPL:-20} --envs $envs \
+      ${FORM:+--launch-form $FORM} --no-cpu-baseline --no-train --no-sustained --no-kernel-shares --no-graph > $O/ctr_${tag}_$i.log 2>&1 || { tail -5 $O/ctr_${tag}_$i.log; exit 1; }
   cd $R
 done
-python3 tools/env_counters_post.py $tag $envs
+python3 tools/env_counters_post.py $tag $envs ${SPL:-20} ${FORM:-many}
