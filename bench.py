@@ -575,11 +575,12 @@ def roofline_details(a, env, kern_ms):
     fl = flops_per_env_step(sweeps)
     out["flops_per_env_step"] = round(fl)
     out["achieved_gflops"] = fl * a.envs / (kern_ms * 1e-3) / 1e9      # mixed fp64 / fp32 (fp64 vector peak: 78.6 TFLOP/s)
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    # (the headline form's passes; the single-launch kernel's sit beside them: tools/env_counters.sh with FORM=single)
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json" if many else "pmc_traffic_single_launch.json")
     try:
         t = json.load(open(tpath))
     except Exception:
-        out["counters_stale"] = "profiles/pmc_traffic.json missing"
+        out["counters_stale"] = os.path.basename(tpath) + " missing under profiles/"
         return out
     if t.get("source_digest") != build.built_digest():
         out["counters_stale"] = "counter passes were taken on another build (source digest differs)"
