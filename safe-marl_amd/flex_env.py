@@ -244,6 +244,32 @@ class VecFlexProvisionEnv:
                                               _ptr(done), _ptr(info), _ptr(failed), flags, _stream()), "flexenv_step_many")
         return reward, done, info, failed
 
+    def step_many_prepared(self, actions, steps=None, auto_reset=False, want_info=True, out=None, stream=None):
+        """``step_many`` with its arguments checked and marshalled ONCE: returns ``(launch, (reward, done, info, failed))`` where
+        ``launch()`` issues the same flexenv_step_many call again on ``stream`` (default: the stream current now) — for a caller
+        that replays one sequence length on fixed buffers, where the ~10 us of per-call checks would sit in front of a launch of
+        a few dozen steps.  The tensors are kept alive by the closure."""
+        res = self.step_many(actions, steps=steps, auto_reset=auto_reset, want_info=want_info, out=out)   # checked, run once
+        reward, done, info, failed = res
+        actions = actions.to(self.device).contiguous()
+        per = self.n_envs * self.n_agents * 4
+        period = actions.numel() // per
+        n = int(reward.shape[0])
+        flags = _lib.FLEX_STEP_OBS_ROWS | (_lib.FLEX_STEP_AUTORESET if auto_reset else 0)
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        args = (self.handle, _ptr(actions), self._dtype_tag(actions), period, n, _ptr(reward), _ptr(done), _ptr(info), _ptr(failed),
+                flags, st)
+        fn = self.lib.flexenv_step_many
+        keep = (actions, reward, done, info, failed)
+
+        def launch(_fn=fn, _args=args, _keep=keep):
+            rc = _fn(*_args)
+            if rc:
+                _lib.check(rc, "flexenv_step_many")
+            self.calls += n
+
+        return launch, res
+
     def rollout_burst(self, actor_args, steps, obs_ring, safety=None):
         """``steps`` vector steps of policy + environment in ONE launch (include/flexenv.h: flexenv_rollout_burst):
         ``actor_args`` is the FlexActorArgs of the ring-mode policy call the burst replaces (nets.fused_actor_forward builds

@@ -81,6 +81,25 @@ def test_without_info_and_into_preallocated_rows(net, series_small):
     assert torch.allclose(i1[1:, :, 6], torch.cumsum(r1, 0)[:-1], rtol=0, atol=1e-12)
 
 
+def test_a_prepared_launch_replays_the_checked_call(net, series_small):
+    """step_many_prepared: the arguments are checked and marshalled once (that call runs the launch), launch() repeats the bare
+    C call on the same buffers — same results as step_many on the same state."""
+    import torch
+    n, steps = 24, 10
+    a, b = _pair(net, series_small, n)
+    acts = (0.5 + 0.5 * torch.rand(steps, n, 5, 4, device="cuda", generator=torch.Generator("cuda").manual_seed(5)))
+    launch, (r2, d2, i2, f2) = b.step_many_prepared(acts, auto_reset=True)          # first run
+    r1, d1, i1, f1 = a.step_many(acts, auto_reset=True)
+    assert torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(i1, i2) and torch.equal(f1, f2)
+    calls = b.calls
+    launch()                                                                        # second run, into the same rows
+    r1, d1, i1, f1 = a.step_many(acts, auto_reset=True)
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(i1, i2) and torch.equal(f1, f2)
+    assert b.calls == calls + steps
+    _same_state(a, b, "prepared")
+
+
 def test_step_counter_advances_as_single_launches_would(net, series_small):
     import torch
     n = 8
