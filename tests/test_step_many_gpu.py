@@ -81,6 +81,38 @@ def test_without_info_and_into_preallocated_rows(net, series_small):
     assert torch.allclose(i1[1:, :, 6], torch.cumsum(r1, 0)[:-1], rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_one_environment_per_wavefront_on_a_45_bus_feeder(dtype):
+    """The EPW = 1 instantiations (more than 32 PQ buses; four buildings; the deeper feeder takes the pointer-jumping path
+    sums): 30 steps in one launch, restarts inside it (episode_limit 9), against as many single launches — bit for bit."""
+    import torch
+    from tests.test_pf_gpu import _random_feeder
+    from safe_marl_amd.series import make_synthetic_series
+    from safe_marl_amd.flex_env import VecFlexProvisionEnv
+    blds = [7, 19, 33, 41]
+    netx = _random_feeder(45, 11, blds)
+    sx = make_synthetic_series(netx, n_days=6)
+    n, steps = 9, 30
+    cfg = {"buildings": blds, "pv_nodes": blds, "ess_nodes": blds, "episode_limit": 9}
+    a = VecFlexProvisionEnv(cfg, n, series=sx, net=netx, seed=5)
+    b = VecFlexProvisionEnv(cfg, n, series=sx, net=netx, seed=5)
+    a.reset(); b.reset()
+    rng = np.random.default_rng(17)
+    acts = torch.from_numpy(rng.uniform(0, 1, (steps, n, 4, 4))).cuda()
+    acts = acts.float() if dtype == "f32" else acts.double()
+    rew, don, inf, fail = [], [], [], []
+    for k in range(steps):
+        r, d, i = a.step(acts[k], obs_rows=True, auto_reset=True)
+        rew.append(r.clone()); don.append(d.clone()); inf.append(i.clone()); fail.append(a.failed.clone())
+    r2, d2, i2, f2 = b.step_many(acts, auto_reset=True)
+    assert torch.equal(torch.stack(rew), r2) and torch.equal(torch.stack(don), d2) and torch.equal(torch.stack(inf), i2)
+    assert torch.equal(torch.stack(fail), f2)
+    # (on this feeder some (0, 1) actions leave the power flow unsolved or E_next outside its domain: those steps end their
+    #  episode through the failure path of env:314-337 and restart inside the launch as well)
+    assert int(d2.sum().item()) >= n * (steps // 9) and int(d2.sum().item()) == int(torch.stack(don).sum().item())
+    _same_state(a, b, "45-bus")
+
+
 def test_a_prepared_launch_replays_the_checked_call(net, series_small):
     """step_many_prepared: the arguments are checked and marshalled once (that call runs the launch), launch() repeats the bare
     C call on the same buffers — same results as step_many on the same state."""
