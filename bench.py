@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--no-train", action="store_true", help="skip the training legs (`train`)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2048-step env-only leg (`sustained`)")
     ap.add_argument("--no-kernel-shares", action="store_true", help="skip the torch.profiler child (`train_kernel_shares`)")
+    ap.add_argument("--train-deadline", type=int, default=150,
+                    help="N > 1: seconds after which unfinished training legs are given up and the line is printed without them "
+                         "(below the process group's 180 s collective timeout; 0 = off)")
     ap.add_argument("--train-episodes", type=int, default=12,
                     help="timed 95-step episodes per training leg (>= 2).  12 episodes = 1140 vector steps = lcm(95, 60): exactly "
                          "19 update events, the cadence's long-run average (3 episodes hold 4 or 5 events depending on phase)")
@@ -1037,39 +1040,8 @@ def main():
         except Exception as exc:
             print(f"[bench] rank {rank}: tolerance sibling leg failed: {exc!r}", file=sys.stderr)
 
-    # training legs LAST: the headline (which the scaling curve is computed from) is already measured if a leg fails; every
-    # rank takes part — with N > 1 the gradient bucket goes through RCCL — and a failure is recorded, not fatal
-    train = None
-    train_failed = False
-    if not a.no_train:
-        # (alg, agents, envs per GPU, batch divisor): every configuration at the trainer's default batch (envs / 4 x 32:
-        # 1.47 samples per transition) AND at the reference's own sample reuse (envs x 32: 5.87, VERDICT r02 item 2)
-        if distributed:
-            legs = [("maddpg", 5, N_ENVS, 4, False), ("safemaddpg", 5, 2 * N_ENVS, 4, False)]
-        else:
-            # the last leg: config 4 with a policy that CAN act on the safety layer (VERDICT r04 item 9) — labelled, no parity claim
-            legs = [("maddpg", 5, N_ENVS, 4, False), ("maddpg", 5, N_ENVS, 1, False), ("maddpg", 3, N_ENVS, 4, False),
-                    ("maddpg", 3, N_ENVS, 1, False), ("safemaddpg", 5, 2 * N_ENVS, 4, False), ("safemaddpg", 5, 2 * N_ENVS, 1, False),
-                    ("safemaddpg", 5, 2 * N_ENVS, 4, True)]
-        train = []
-        for alg, n_ag, n_env, div, intended in legs:
-            try:
-                train.append(train_leg(alg, n_ag, n_env, max(2, a.train_episodes), rank, local_rank, world, barrier,
-                                       max_over_ranks, batch_div=div, intended=intended))
-            except Exception as exc:                  # a failed leg must not cost the headline line
-                print(f"[bench] rank {rank}: training leg {alg}/{n_ag}/{n_env}/{div} failed: {exc!r}", file=sys.stderr)
-                train.append({"alg": alg, "n_agents": n_ag, "envs_per_gpu": n_env, "n_gpus": world, "batch_div": div,
-                              "error": repr(exc)[:300]})
-                train_failed = True
-                break
-
-    learner = None
-    if rank == 0 and not distributed and not a.no_train:
-        try:
-            learner = learner_rooflines()
-        except Exception as exc:
-            print(f"[bench] learner rooflines failed: {exc!r}", file=sys.stderr)
-
+    # the line's headline part is assembled BEFORE the training legs (what they add is filled in afterwards)
+    out = None
     if rank == 0:
         total_env_steps = a.envs * world * a.steps
         # algorithmic bytes per env-step of the kernel AS IT RUNS: 1 340 B with get_obs() as a row push (the 240 B
@@ -1151,10 +1123,74 @@ def main():
             "sustained": sustained,
             "solver_sibling": sibling,
             "tolerance_sibling": tol_sibling,
-            "train": train,
-            "train_kernel_shares": shares,
-            "learner_rooflines": learner,
+            "train": None,
+            "train_kernel_shares": None,
+            "learner_rooflines": None,
         }
+
+    # training legs LAST: the headline (which the scaling curve is computed from) is already measured if a leg fails; every
+    # rank takes part — with N > 1 the gradient bucket goes through RCCL — and a failure is recorded, not fatal
+    train = None
+    train_failed = False
+    emitted = []
+    deadline = None
+    if distributed and not a.no_train and a.train_deadline > 0:
+        # N > 1 only.  A collective that cannot complete inside a training leg (a rank that died, a transport fault) ends in the
+        # process group's own abort after its 180 s timeout — which would take rank 0 down BEFORE it printed the line whose headline
+        # part (env-steps/s over all ranks, already measured above) the scaling curve is computed from.  So: if the legs have not
+        # finished after --train-deadline seconds, every rank stops waiting; rank 0 prints the ONE line with what the legs recorded
+        # so far plus the reason, and the processes leave without the group's shutdown handshake (it could not complete either).
+        import threading
+
+        def _give_up():
+            if emitted:
+                return
+            emitted.append("deadline")
+            print(f"[bench] rank {rank}: training legs not finished after {a.train_deadline} s: giving up on them", file=sys.stderr, flush=True)
+            if rank == 0:
+                out.update({"train": list(train or []) + [{"error": "training legs not finished after %d s (--train-deadline); "
+                                                           "the headline above was measured before them" % a.train_deadline}]})
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        deadline = threading.Timer(a.train_deadline, _give_up)
+        deadline.daemon = True
+        deadline.start()
+    if not a.no_train:
+        # (alg, agents, envs per GPU, batch divisor): every configuration at the trainer's default batch (envs / 4 x 32:
+        # 1.47 samples per transition) AND at the reference's own sample reuse (envs x 32: 5.87, VERDICT r02 item 2)
+        if distributed:
+            legs = [("maddpg", 5, N_ENVS, 4, False), ("safemaddpg", 5, 2 * N_ENVS, 4, False)]
+        else:
+            # the last leg: config 4 with a policy that CAN act on the safety layer (VERDICT r04 item 9) — labelled, no parity claim
+            legs = [("maddpg", 5, N_ENVS, 4, False), ("maddpg", 5, N_ENVS, 1, False), ("maddpg", 3, N_ENVS, 4, False),
+                    ("maddpg", 3, N_ENVS, 1, False), ("safemaddpg", 5, 2 * N_ENVS, 4, False), ("safemaddpg", 5, 2 * N_ENVS, 1, False),
+                    ("safemaddpg", 5, 2 * N_ENVS, 4, True)]
+        train = []
+        for alg, n_ag, n_env, div, intended in legs:
+            try:
+                train.append(train_leg(alg, n_ag, n_env, max(2, a.train_episodes), rank, local_rank, world, barrier,
+                                       max_over_ranks, batch_div=div, intended=intended))
+            except Exception as exc:                  # a failed leg must not cost the headline line
+                print(f"[bench] rank {rank}: training leg {alg}/{n_ag}/{n_env}/{div} failed: {exc!r}", file=sys.stderr)
+                train.append({"alg": alg, "n_agents": n_ag, "envs_per_gpu": n_env, "n_gpus": world, "batch_div": div,
+                              "error": repr(exc)[:300]})
+                train_failed = True
+                break
+
+    if deadline is not None:
+        deadline.cancel()
+        if emitted:                                       # (the timer fired while the last leg was returning: it owns the exit)
+            time.sleep(3600)
+    learner = None
+    if rank == 0 and not distributed and not a.no_train:
+        try:
+            learner = learner_rooflines()
+        except Exception as exc:
+            print(f"[bench] learner rooflines failed: {exc!r}", file=sys.stderr)
+
+    if rank == 0:
+        out.update({"train": train, "train_kernel_shares": shares, "learner_rooflines": learner})
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(net, series, a.cpu_seconds, envs=a.envs)
             cb = out["cpu_baseline"]
