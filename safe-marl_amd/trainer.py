@@ -241,13 +241,29 @@ class PGTrainer(object):
                 self.cache_bootstrap = eligible = False
             else:
                 self._ensure_event_graph("value_cached", n_value)       # (the event's one-graph form, captured at the same point)
+        elif eligible:
+            # Whether THIS event takes the cached form is decided below from this rank's OWN window draws (how much they overlap);
+            # whether the cached form's graphs are current must not be.  A graph goes stale when the replay's stacked ring is
+            # re-allocated (a later capture asking for a longer tail: ``stack_gen``), and recapturing it runs warm-up steps that
+            # all-reduce and ends in an agreement — left to the first event that CHOSE the cached form, one rank recaptured while
+            # another went on with its plain sub-updates, and their collectives no longer matched (found by the two-rank bench
+            # rehearsal, round 5: `52100 vs 4` in gloo's pair).  So every rank brings them up to date here, at the same event;
+            # afterwards the look-ups below capture nothing.  (One rank: the same recapture, a few lines earlier.)
+            ok = self._ensure_graph("value_cached") is not None and self._ensure_bootstrap(bs_all) is not None
+            if ok and self.pipeline_updates:
+                ok = self._ensure_graph("value_cached", 1) is not None
+            if not ok:
+                self.cache_bootstrap = eligible = False
         if eligible:
             vstarts = [buf.sample_slot(bs_all) for _ in range(n_value)]
             starts = dict(enumerate(vstarts))
             N = buf.n_envs
             chunks = self.bootstrap_chunks(vstarts, bs_all, [(a * N, b * N) for a, b in buf._runs()])
             # a pass costs about what a value sub-update saves: the cached form has to save at least two of them to be chosen
-            if len(chunks) + 2 < n_value:
+            choose = len(chunks) + 2 < n_value
+            if getattr(self, "force_bootstrap_choice", None) is not None:      # (tests: ranks made to choose differently)
+                choose = bool(self.force_bootstrap_choice)
+            if choose:
                 boot = {size: self._ensure_bootstrap(size) for size in {size for _, size in chunks}}
                 if (any(g is None for g in boot.values()) or self._ensure_graph("value_cached") is None or
                         (self.pipeline_updates and self._ensure_graph("value_cached", 1) is None)):
@@ -423,11 +439,17 @@ class PGTrainer(object):
     def _ensure_bootstrap(self, bs):
         g = self._bootstrap_graphs.get(bs)
         if g is None or g["buf"] is not self.replay_buffer or g.get("ring_gen") != getattr(self.replay_buffer, "stack_gen", None):
+            exc = None
             try:
                 g = self._capture_bootstrap(bs)
-            except Exception as exc:
+            except Exception as e:
+                g, exc = None, e
+            # (captures are attempted at the same event on every rank — replay_event — so this is reached by all of them or by
+            #  none; a rank that gave up the cached form alone would skip the NEXT recapture of its graphs, collectives included)
+            if not fdist.all_agree(g is not None, self.device):
                 import warnings
-                warnings.warn(f"bootstrap-value graph capture failed ({exc}); value sub-updates compute their own")
+                why = exc if exc is not None else "another rank's capture failed"
+                warnings.warn(f"bootstrap-value graph capture failed ({why}); value sub-updates compute their own")
                 self.cache_bootstrap = False
                 return None
             g["ring_gen"] = getattr(self.replay_buffer, "stack_gen", None)
@@ -578,10 +600,43 @@ class PGTrainer(object):
         kind, cached = which, which == "value_cached"
         which = "value" if cached else which
         self.behaviour_net.bootstrap_from_batch = cached
+        ar0, ag0 = fdist.STATS["allreduce_calls"], fdist.STATS["agreements"]
         try:
             return self._capture_sub_update_body(kind, which, bs)
+        except Exception as exc:
+            if self.world > 1:
+                self._realign_after_failed_capture(kind, which, exc, ar0, ag0)
+            raise
         finally:
             self.behaviour_net.bootstrap_from_batch = False
+
+    def _realign_after_failed_capture(self, kind, which, exc, ar0, ag0):
+        """More than one rank: a capture that fails on THIS rank must leave it at the same place in the sequence of collectives as
+        the ranks whose capture went through — they ran two warm-up steps (one all-reduce of the gradient bucket each; a third
+        under FLEX_GRAPH_AUDIT) and, in the opt-in one-graph form, one agreement on that form — or the agreement that follows
+        (_ensure_graph: everybody falls back together) meets a peer's gradient bucket instead of a peer's flag.  The missing
+        all-reduces are issued on a zero bucket of the right size (the peers' warm-up results are discarded anyway: every rank
+        restores its weights and optimiser state), the reason is written to stderr at once, not only in the warning behind the
+        agreement.  Not covered: the 8 KB statistics all-reduces of sync_reward_bn inside a warm-up loss."""
+        import sys
+        print(f"[trainer] rank {fdist.rank()}: capture of the {kind} sub-update failed: {exc!r}", file=sys.stderr, flush=True)
+        try:
+            opt = self.policy_optimizer if which == "policy" else self.value_optimizer
+            expected = 2 + (1 if os.environ.get("FLEX_GRAPH_AUDIT") == "1" else 0)
+            missing = expected - (fdist.STATS["allreduce_calls"] - ar0)
+            if missing > 0:
+                if self.device.type == "cuda":
+                    th.cuda.synchronize()
+                n = sum(p.numel() for p in opt.param_groups[0]["params"])
+                flat = th.zeros(n, dtype=th.float32, device=self.device)
+                for _ in range(missing):
+                    fdist.dist.all_reduce(flat, op=fdist.dist.ReduceOp.SUM)
+            if self.allreduce_in_graph and fdist.STATS["agreements"] == ag0:
+                fdist.all_agree(False, self.device)          # the peers' "is the one-graph form in on every rank?"
+                if not self.sync_reward_bn:
+                    self.allreduce_in_graph = False           # (they move to the split form on hearing this)
+        except Exception as exc2:                             # (the group itself is broken: nothing left to align)
+            print(f"[trainer] rank {fdist.rank()}: could not realign after the failed capture: {exc2!r}", file=sys.stderr, flush=True)
 
     def _capture_sub_update_body(self, kind, which, bs):
         from .replay_buffer import Transition

@@ -16,14 +16,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp, graph_updates, nproc=2):
+def _run(tmp, graph_updates, nproc=2, extra=()):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     os.makedirs(tmp, exist_ok=True)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "dist_rehearsal.py"), "--out", tmp,
-           "--graph-updates", str(int(graph_updates))]
+           "--graph-updates", str(int(graph_updates))] + list(extra)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     return [dict(np.load(os.path.join(tmp, f"rank{k}.npz"))) for k in range(nproc)]
@@ -46,6 +46,30 @@ def test_two_ranks_train_with_split_update_graphs(tmp_path):
     # and the exchange mattered: a lone rank from rank 0's start ends elsewhere
     solo = _run(str(tmp_path / "solo"), True, nproc=1)
     assert not np.array_equal(solo[0]["w"], g[0]["w"])
+
+
+def test_ranks_that_choose_different_event_forms_recapture_stale_graphs_together(tmp_path):
+    """Whether an update event reads filed bootstrap values is each rank's own choice (how much ITS windows overlap); recapturing
+    a stale graph is not — its warm-up steps all-reduce.  Second episode after a re-allocation of the stacked ring, rank 0 made to
+    choose the filed form and rank 1 the plain one: both finish, replicas bit-identical.  (Round 5's two-rank bench rehearsal died
+    here once: rank 1 recaptured alone and its agreement met rank 0's gradient bucket.)"""
+    a, b = _run(str(tmp_path / "forced"), True, extra=["--force-cached-rank", "0", "--envs", "2048"])   # (a batch the critic reads in place)
+    assert int(a["steps"]) == int(b["steps"]) == 190
+    assert int(a["ring_gen"]) == int(b["ring_gen"]) >= 2
+    assert int(a["cached_events"]) > int(b["cached_events"])            # they did choose differently
+    assert np.array_equal(a["w"], b["w"]) and np.array_equal(a["sq"], b["sq"])
+
+
+def test_a_capture_that_fails_on_one_rank_moves_every_rank_to_eager_sub_updates(tmp_path):
+    """Rank 1's first capture raises before its warm-up steps; rank 0's goes through (two warm-up all-reduces, then the
+    agreement).  Rank 1 catches up with the all-reduces it missed (trainer._realign_after_failed_capture), the agreement says no,
+    BOTH ranks run eager sub-updates from then on — and end bit-identical, on the weights two eager ranks reach anyway."""
+    a, b = _run(str(tmp_path / "fail"), True, extra=["--fail-capture-rank", "1"])
+    assert int(a["steps"]) == int(b["steps"]) == 95
+    assert len(a["graphs"]) == 0 and len(b["graphs"]) == 0
+    assert np.array_equal(a["w"], b["w"]) and np.array_equal(a["sq"], b["sq"])
+    e = _run(str(tmp_path / "eager"), False)
+    assert np.array_equal(a["w"], e[0]["w"])            # the failed capture left no step of its own behind
 
 
 @pytest.mark.parametrize("in_graph", ["1", "0"])

@@ -24,6 +24,14 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--graph-updates", type=int, default=1)
     ap.add_argument("--envs", type=int, default=256)
+    ap.add_argument("--force-cached-rank", type=int, default=-1,
+                    help="a SECOND episode in which rank R's update events take the filed-bootstrap form and the other ranks' do not "
+                         "(trainer.force_bootstrap_choice), after the replay's stacked ring has been re-allocated — every graph "
+                         "captured against the old ring is stale and is recaptured (warm-up all-reduces, agreement): all ranks "
+                         "must do that at the same event whatever form they go on to choose")
+    ap.add_argument("--fail-capture-rank", type=int, default=-1,
+                    help="rank R's FIRST sub-update capture raises before it has done anything (injected here, not in the product): "
+                         "R has to catch up with its peers' warm-up all-reduces and every rank falls back to eager sub-updates")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -49,8 +57,25 @@ def main():
     np.random.seed(70 + rank)                        # a different replay window per rank
     env = VecFlexProvisionEnv({}, a.envs, device="cuda:0", net=net, series=series, seed=1234 + 1000 * rank, warm_start=True)
     tr = PGTrainer(convert(alg), MADDPG, env, None, replay_capacity=a.envs * 96 * 2, graph_updates=bool(a.graph_updates))
+    if rank == a.fail_capture_rank:
+        body, hit = tr._capture_sub_update_body, []
+
+        def failing_body(*args, **kw):
+            if not hit:
+                hit.append(1)
+                raise RuntimeError("injected capture failure (tools/dist_rehearsal.py --fail-capture-rank)")
+            return body(*args, **kw)
+        tr._capture_sub_update_body = failing_body
     stat = {}
     tr.behaviour_net.train_process(stat, tr)         # 95 vector steps: update events at 30, 60, 90 (33 sub-updates)
+    if a.force_cached_rank >= 0:
+        buf = tr.replay_buffer
+        gen0 = getattr(buf, "stack_gen", None)
+        if getattr(buf, "stack_ring", None) is not None:
+            buf.enable_stacked_ring(buf.stack_tail + buf.n_envs)       # a longer tail: a NEW ring, the captured graphs go stale
+        assert getattr(buf, "stack_gen", None) != gen0 or gen0 is None
+        tr.force_bootstrap_choice = rank == a.force_cached_rank
+        tr.behaviour_net.train_process(stat, tr)
     torch.cuda.synchronize()
     net_ = tr.behaviour_net
     out = {"w": torch.cat([p.detach().reshape(-1) for p in net_.parameters()]).cpu().numpy(),
@@ -58,7 +83,8 @@ def main():
                             for s in o.state.values()]).cpu().numpy(),
            "vloss": np.float64(float(stat["mean_train_value_loss"])), "reward": np.float64(stat["mean_train_reward"]),
            "graphs": np.array(sorted(tr._update_graphs)), "split": np.array([g["apply"] is not None for g in tr._update_graphs.values()]),
-           "steps": np.int64(tr.steps)}
+           "steps": np.int64(tr.steps), "cached_events": np.int64(getattr(tr, "bootstrap_cached_events", 0)),
+           "ring_gen": np.int64(getattr(tr.replay_buffer, "stack_gen", 0) or 0)}
     np.savez(os.path.join(a.out, f"rank{rank}.npz"), **out)
     if world > 1:
         dist.barrier()
