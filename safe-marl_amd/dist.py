@@ -29,6 +29,7 @@ def broadcast_module(module, src=0):
         if not tensors:
             return
         flat = th.cat([t.reshape(-1).float() for t in tensors])
+        _log_collective("broadcast_module", flat.numel() * 4)
         dist.broadcast(flat, src=src)
         off = 0
         for t in tensors:
@@ -41,6 +42,24 @@ def broadcast_module(module, src=0):
 # captured inside an update graph once per REPLAY of that graph (trainer._replay).  bench.py reports them per leg so that
 # the first multi-GPU run can be checked from its own output.
 STATS = {"allreduce_calls": 0, "allreduce_bytes": 0, "agreements": 0}
+
+
+_COLL_LOG = None
+
+
+def _log_collective(what, n_bytes):
+    """FLEX_COLL_LOG=<prefix>: every collective this module issues, one line per call with the caller's frames, appended to
+    <prefix>.rank<r>.log — two ranks' files are compared line by line when their collectives stop matching."""
+    global _COLL_LOG
+    import os
+    prefix = os.environ.get("FLEX_COLL_LOG")
+    if not prefix:
+        return
+    import traceback
+    if _COLL_LOG is None:
+        _COLL_LOG = open(f"{prefix}.rank{rank()}.log", "a", buffering=1)
+    frames = traceback.extract_stack(limit=7)[:-2]
+    _COLL_LOG.write(f"{what} {n_bytes} B <- " + " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}:{f.name}" for f in reversed(frames)) + "\n")
 
 
 def note_allreduce(n_bytes, calls=1):
@@ -57,6 +76,7 @@ def all_agree(ok, device=None):
         return bool(ok)
     dev = device if (device is not None and backend() == "nccl") else th.device("cpu")
     flag = th.tensor([1 if ok else 0], dtype=th.int32, device=dev)
+    _log_collective(f"all_agree({bool(ok)})", 4)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     STATS["agreements"] += 1
     return bool(int(flag.item()))
@@ -77,6 +97,7 @@ def replica_divergence(module, src=0):
                 out.append(0.0)
                 continue
             ref = mine.clone()
+            _log_collective("replica_divergence broadcast + max", ref.numel() * 4)
             dist.broadcast(ref, src=src)
             d = (mine - ref).abs().max().reshape(1)
             dist.all_reduce(d, op=dist.ReduceOp.MAX)
@@ -90,6 +111,7 @@ def allreduce_grads(params):
     if not grads:
         return
     flat = th.cat([g.reshape(-1) for g in grads])
+    _log_collective("allreduce_grads", flat.numel() * flat.element_size())
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     note_allreduce(flat.numel() * flat.element_size())
     flat.div_(dist.get_world_size())
@@ -103,6 +125,7 @@ def allreduce_grads(params):
 def allreduce_flat(flat):
     """SUM over ranks of an already-flat gradient bucket, in place (the caller scales by 1/world — inside its HIP graph
     when the update is graphed).  One ncclAllReduce on RCCL's stream, ordered after the current stream."""
+    _log_collective("allreduce_flat", flat.numel() * flat.element_size())
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if not th.cuda.is_available() or not th.cuda.is_current_stream_capturing():
         note_allreduce(flat.numel() * flat.element_size())          # (a captured one is counted per replay)

@@ -254,6 +254,16 @@ class PGTrainer(object):
                 ok = self._ensure_graph("value_cached", 1) is not None
             if not ok:
                 self.cache_bootstrap = eligible = False
+        # ... and the PLAIN form's graph once more: the cached form's capture above may have re-allocated the stacked ring (SAFEMADDPG:
+        # the plain value sub-update does not read its window in place, the cached one does and creates the ring), which leaves the
+        # graph captured a few lines up stale.  Recaptured lazily, that happened on the ranks whose event went on in the plain form
+        # and not on those that took the cached one — the two-rank bench rehearsal's `52100 vs 4` (collective log: rank 1
+        # in _replay_event_plain -> _ensure_graph -> capture, rank 0 in _replay).  A look-up when nothing moved.
+        if self._ensure_graph(kinds[0]) is None or (self.pipeline_updates and self.world > 1 and self._ensure_graph(kinds[0], 1) is None):
+            for which in kinds:
+                (self.value_replay_process if which == "value" else self.policy_replay_process)(stat)
+            return
+        self._ensure_event_graph(kinds[0], n_value)             # (its base graph may just have been recaptured)
         if eligible:
             vstarts = [buf.sample_slot(bs_all) for _ in range(n_value)]
             starts = dict(enumerate(vstarts))

@@ -60,6 +60,16 @@ def test_ranks_that_choose_different_event_forms_recapture_stale_graphs_together
     assert np.array_equal(a["w"], b["w"]) and np.array_equal(a["sq"], b["sq"])
 
 
+def test_safemaddpg_ranks_that_differ_in_their_first_cached_event(tmp_path):
+    """The sequence the two-rank bench rehearsal died in (round 5): SAFEMADDPG's plain value graph is captured first and reads a
+    gathered batch; the cached form's capture then creates the stacked ring, which makes the plain graph stale inside the same
+    event.  Rank 0 goes on in the cached form, rank 1 in the plain one — which used to recapture alone."""
+    a, b = _run(str(tmp_path / "safe"), True, extra=["--alg", "safemaddpg", "--envs", "2048", "--force-cached-rank", "0", "--force-from-start", "1"])
+    assert int(a["steps"]) == int(b["steps"]) == 95
+    assert int(a["cached_events"]) > 0 and int(b["cached_events"]) == 0
+    assert list(a["graphs"]) == ["policy", "value"] and np.array_equal(a["w"], b["w"]) and np.array_equal(a["sq"], b["sq"])
+
+
 def test_a_capture_that_fails_on_one_rank_moves_every_rank_to_eager_sub_updates(tmp_path):
     """Rank 1's first capture raises before its warm-up steps; rank 0's goes through (two warm-up all-reduces, then the
     agreement).  Rank 1 catches up with the all-reduces it missed (trainer._realign_after_failed_capture), the agreement says no,

@@ -29,6 +29,11 @@ def main():
                          "(trainer.force_bootstrap_choice), after the replay's stacked ring has been re-allocated — every graph "
                          "captured against the old ring is stale and is recaptured (warm-up all-reduces, agreement): all ranks "
                          "must do that at the same event whatever form they go on to choose")
+    ap.add_argument("--alg", default="maddpg", choices=["maddpg", "safemaddpg"])
+    ap.add_argument("--force-from-start", type=int, default=0,
+                    help="with --force-cached-rank: the forced choice holds from the FIRST update event (no second episode, no ring "
+                         "re-allocation by hand) — SAFEMADDPG's plain value graph goes stale when the cached form's capture creates the "
+                         "stacked ring, inside that very event")
     ap.add_argument("--fail-capture-rank", type=int, default=-1,
                     help="rank R's FIRST sub-update capture raises before it has done anything (injected here, not in the product): "
                          "R has to catch up with its peers' warm-up all-reduces and every rank falls back to eager sub-updates")
@@ -38,7 +43,7 @@ def main():
     import safe_marl_amd  # noqa: F401
     from train_maddpg import DEFAULT_ALG_ARGS
     from safe_marl_amd.flex_env import VecFlexProvisionEnv
-    from safe_marl_amd.learner import MADDPG
+    from safe_marl_amd.learner import MADDPG, SAFEMADDPG
     from safe_marl_amd.network import create_network
     from safe_marl_amd.series import make_synthetic_series
     from safe_marl_amd.trainer import PGTrainer
@@ -51,12 +56,12 @@ def main():
     net = create_network()
     series = make_synthetic_series(net, n_days=30)
     alg = dict(DEFAULT_ALG_ARGS)
-    alg.update(alg="maddpg", agent_num=5, obs_size=144, state_size=110, action_dim=4, behaviour_update_freq=30,
+    alg.update(alg=a.alg, v_min=0.9, v_max=1.1, agent_num=5, obs_size=144, state_size=110, action_dim=4, behaviour_update_freq=30,
                target_update_freq=60)
     torch.manual_seed(50 + rank)                     # different initial weights per rank: the broadcast must fix that
     np.random.seed(70 + rank)                        # a different replay window per rank
-    env = VecFlexProvisionEnv({}, a.envs, device="cuda:0", net=net, series=series, seed=1234 + 1000 * rank, warm_start=True)
-    tr = PGTrainer(convert(alg), MADDPG, env, None, replay_capacity=a.envs * 96 * 2, graph_updates=bool(a.graph_updates))
+    env = VecFlexProvisionEnv({"alg": "safemaddpg"} if a.alg == "safemaddpg" else {}, a.envs, device="cuda:0", net=net, series=series, seed=1234 + 1000 * rank, warm_start=True)
+    tr = PGTrainer(convert(alg), {"maddpg": MADDPG, "safemaddpg": SAFEMADDPG}[a.alg], env, None, replay_capacity=a.envs * 96 * 2, graph_updates=bool(a.graph_updates))
     if rank == a.fail_capture_rank:
         body, hit = tr._capture_sub_update_body, []
 
@@ -66,9 +71,11 @@ def main():
                 raise RuntimeError("injected capture failure (tools/dist_rehearsal.py --fail-capture-rank)")
             return body(*args, **kw)
         tr._capture_sub_update_body = failing_body
+    if a.force_cached_rank >= 0 and a.force_from_start:
+        tr.force_bootstrap_choice = rank == a.force_cached_rank
     stat = {}
     tr.behaviour_net.train_process(stat, tr)         # 95 vector steps: update events at 30, 60, 90 (33 sub-updates)
-    if a.force_cached_rank >= 0:
+    if a.force_cached_rank >= 0 and not a.force_from_start:
         buf = tr.replay_buffer
         gen0 = getattr(buf, "stack_gen", None)
         if getattr(buf, "stack_ring", None) is not None:
