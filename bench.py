@@ -1195,6 +1195,7 @@ def main():
         deadline.cancel()
         if emitted:                                       # (the timer fired while the last leg was returning: it owns the exit)
             time.sleep(3600)
+        emitted.append("legs finished")                   # (a timer already past its cancel point finds this and returns)
     learner = None
     if rank == 0 and not distributed and not a.no_train:
         try:
