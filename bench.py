@@ -822,18 +822,15 @@ def main():
     t0 = time.perf_counter()
     run_steps(a.steps)                                    # exactly K steps
     ev1.record()
-    # closing bracket: synchronize, then the barrier; the job's time is the MAX over ranks.  Each rank's clock stops when ITS K steps
-    # are done (after its own synchronize) and the maximum over the ranks is what "all ranks done" costs — the ranks share nothing on
-    # this path.  The barrier collective that follows is the bracket, not the workload: read after it, the clock would add one small
-    # all-reduce's latency (tens of microseconds across eight devices) to a region the driver's K = 20 makes 0.15 ms long.  That
-    # figure is reported too (`ms_per_step_incl_closing_barrier`); at N = 1 the barrier is the synchronize and the two are one.
-    torch.cuda.synchronize()
-    local_elapsed = time.perf_counter() - t0
+    # closing bracket, as the contract words it: barrier + synchronize, THEN the clock; the job's time is the MAX over ranks.  Under
+    # N > 1 that puts the closing barrier's own collective (one small all-reduce queued behind the steps: tens of microseconds
+    # across eight devices) inside a region the driver's K = 20 makes 0.15 ms long — apparatus, not workload: the ranks share
+    # nothing on this path.  The line therefore also carries the maximum over the ranks of each rank's DEVICE time for its K steps
+    # (the HIP events ev0 / ev1 on the launch stream: `value_device_events`), beside the headline, never instead of it.
     barrier()
-    after_barrier = time.perf_counter() - t0
-    elapsed = max_over_ranks(local_elapsed)
-    elapsed_incl_barrier = max_over_ranks(after_barrier) if distributed else elapsed
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     dev_ms = ev0.elapsed_time(ev1)
+    dev_ms_max = max_over_ranks(dev_ms)
 
     # roofline leg.  The timed region above is K back-to-back launches of ONE kernel (flex_step_kernel) on one
     # stream, bracketed by the HIP events ev0/ev1 on that stream: dev_ms / K is its average launch duration
@@ -1070,8 +1067,7 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
-            "ms_per_step_incl_closing_barrier": elapsed_incl_barrier / a.steps * 1e3,
-            "value_incl_closing_barrier": total_env_steps / elapsed_incl_barrier,
+            "value_device_events": total_env_steps / (dev_ms_max * 1e-3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -1109,8 +1105,8 @@ def main():
                                if many else "single: one flexenv_step launch per step",
                 "steps_per_launch": a.steps_per_launch_used,
                 "warm_start": bool(a.warm_start), "launches_per_step": (1.0 / a.steps_per_launch_used), "hip_graph": used_graph, "hip_graph_uploaded": used_graph,
-                "timing": ("barrier + synchronize | K steps | synchronize, clock, barrier; MAX over ranks of the per-rank time"
-                           if distributed else "synchronize | K steps | synchronize"),
+                "timing": ("barrier + synchronize | K steps | barrier + synchronize, clock; MAX over ranks (value_device_events: MAX "
+                           "over ranks of the HIP-event time of each rank's K steps)" if distributed else "synchronize | K steps | synchronize"),
                 "timed_after": ("the `sustained` leg (%d steps), then W warm-up steps" % sustained["steps"]) if sustained else "W warm-up steps",
                 "device_ms_per_step": dev_ms / a.steps, "solver": ("sweep (mixed fp64/fp32 increments) + fp64 Newton verification" if a.solver == "sweep" else "newton (fp64, tree elimination)"),
                 "pf_newton_iters_mean": iters_mean, "pf_sweeps_mean": sweeps_mean,
