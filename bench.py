@@ -633,7 +633,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # (FLEX_BENCH_FORCE_DIST=1: the process-group code paths — RCCL init with a device id, the gathered device report, barriers, the
+    #  maximum over ranks, shutdown — with ONE rank under torch.distributed.run, all a one-GPU box allows of the real backend)
+    distributed = world > 1 or os.environ.get("FLEX_BENCH_FORCE_DIST") == "1"
     if a.gpus != world:
         print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: reporting n_gpus = {world}", file=sys.stderr)
     shares = None
