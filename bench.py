@@ -2,21 +2,27 @@
 """bench.py — env-steps/s of the batched flexibility-provision step on MI355X.
 
 A "step" is ONE vector step of the hot path over one batch of synthetic input: for every one of the
-4096 environments of this GPU, `flexenv_step` (action parse -> 33-bus AC power flow -> ESS update ->
+4096 environments of this GPU, the step body (action parse -> 33-bus AC power flow -> ESS update ->
 reward, with the `get_obs()` that always follows it fused in, and the restart of the environments that just
-terminated) — one kernel launch.  Inputs (series table, action pool) are resident in HBM before the
-timed region starts; nothing crosses PCIe inside it.
+terminated).  The K steps are issued as launches of `flexenv_step_many` (up to --steps-per-launch steps each, the vectorised
+run_env.py:78-92; the driver's K = 20 is ONE launch); `single_launch_sibling` in the same line is the one-launch-per-step form
+(`flexenv_step`).  Inputs (series table, action pool) are resident in HBM before the timed region starts; nothing crosses
+PCIe inside it (tools/pcie_probe.py has the host-buffer rates).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Environments are independent, so ranks share nothing on the data path of the headline metric (weak scaling, no
-collective); the only collectives there are the contract's barrier and the max-over-ranks of the elapsed time.
+collective); the only collectives there are the contract's barrier and the max-over-ranks of the elapsed time.  Under
+N > 1 the line also carries `value_device_events` (max over ranks of the HIP-event time of each rank's K steps: the figure without
+the closing barrier's own collective), what the process group reports about itself (`dist`), and per training leg the all-reduce
+counts against the schedule and `replica_max_abs_diff`; training legs that have not finished after --train-deadline seconds are
+given up and the line is printed without them.
 
 Next to the headline the same JSON line carries:
-  * `sustained`: the same env-only step over >= 2048 steps in this process (the driver's `--steps 20` is one or two graph
-    replays);
+  * `sustained`: the same env-only step over >= 2048 steps in this process, run FIRST (the device enters the timed region at its
+    operating clocks);
   * `train`: the TRAINING loop of model.py:198-267 + model.py:40-71 — rollout (policy inference + env step + replay
     write) and the 11 gradient steps per 60 vector steps — for BASELINE configs 3 (MADDPG, 5 and 3 agents, 4096 envs) and
     4 (SAFEMADDPG, 8192 envs); with N > 1 ranks config 5: MADDPG at 4096 envs per GPU with the flat gradient bucket
