@@ -791,9 +791,17 @@ def main():
         for k in range(done_steps, count):
             one_step(k)
 
+    bar_cell = torch.zeros(1, device=dev) if distributed and a.backend == "nccl" else None
+
     def barrier():
         if distributed:
-            dist.barrier()
+            if bar_cell is not None:
+                # on RCCL a barrier IS an all-reduce of one element followed by a synchronize (ProcessGroupNCCL::barrier); issued on a
+                # cell allocated once it does without the fill launch dist.barrier() queues for a fresh tensor every time — behind
+                # the 20-step launch: +5.0 us instead of +10.7 (tools/barrier_probe.py, profiles/r05dd_barrier_probe.txt)
+                dist.all_reduce(bar_cell)
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
